@@ -1,0 +1,218 @@
+/*
+ * covgpu.h — C ABI of the MI355X-native global-bundle-adjustment / pose-graph back-end.
+ *
+ * This is the drop-in boundary for the ONE hot path of COVINS that this repository
+ * replaces:
+ *
+ *   covins::Optimization::GlobalBundleAdjustment   reference: covins_backend/include/covins/
+ *   covins::Optimization::PoseGraphOptimization               covins_backend/optimization_be.hpp:38-51
+ *
+ * The reference has no FFI or plugin registry for this path — callers link the two static
+ * member functions directly (backend.cpp:141-156, placerec_be.cpp:327, placerec_gen_be.cpp:250).
+ * The C++ facade in include/covins_gpu/optimization_gpu.hpp keeps those two signatures verbatim,
+ * walks Map/Keyframe/Landmark exactly as optimization_be.cpp does, flattens them into the
+ * `covgpu_problem` intermediate representation below, and calls the entry points of this header.
+ * Nothing here knows about Map/Keyframe, Eigen, torch or any C++ type: plain pointers and sizes.
+ *
+ * All floating point is FP64 (reference: precision_t = double, typedefs_base.hpp:129).
+ * Quaternions are Hamilton, stored [x,y,z,w]; a pose block is [qx,qy,qz,qw,px,py,pz] = T_w_s
+ * (keyframe_base.cpp:486-499); a speed-bias block is [v_w(3), b_a(3), b_g(3)] (:513-521).
+ */
+#ifndef COVGPU_H_
+#define COVGPU_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- status codes */
+enum {
+  COVGPU_OK = 0,
+  COVGPU_ERR_INVALID_ARG = 1,   /* malformed problem (index out of range, NULL array, ...)   */
+  COVGPU_ERR_NO_DEVICE = 2,     /* no HIP device / HIP runtime failure                        */
+  COVGPU_ERR_OUT_OF_MEMORY = 3, /* device allocation failed                                   */
+  COVGPU_ERR_NUMERIC = 4,       /* reduced system not positive definite after max damping     */
+  COVGPU_ERR_FATAL_MAP = 5      /* conditions on which the reference calls exit(-1)           */
+};
+
+/* trust-region strategy (reference uses DOGLEG: optimization_be.cpp:261,564,1028;
+ * BASELINE.json north_star asks for Levenberg-Marquardt as well) */
+enum { COVGPU_DOGLEG = 0, COVGPU_LM = 1 };
+
+/* lens distortion of a camera (reference dispatch: optimization_be.cpp:483-521; KeyframeBase can
+ * only construct RadTan / Equidistant, keyframe_base.cpp:58-82) */
+enum { COVGPU_DIST_RADTAN = 0, COVGPU_DIST_EQUIDISTANT = 1 };
+
+/* ---------------------------------------------------------------- options */
+typedef struct covgpu_options {
+  int32_t strategy;            /* COVGPU_DOGLEG | COVGPU_LM                                         */
+  int32_t max_iterations;      /* trust-region iterations incl. rejected (Ceres max_num_iterations) */
+  int32_t visual_only;         /* 1: no speed-bias blocks, no IMU factors (opt_be.cpp:332,367)      */
+  int32_t device;              /* HIP device ordinal                                                */
+  double  reproj_loss_a;       /* Cauchy scale on reprojection blocks, 1.0 (opt_be.cpp:302);  0=off */
+  double  initial_radius;      /* 1e4  (Ceres default initial_trust_region_radius)                  */
+  double  max_radius;          /* 1e16                                                              */
+  double  min_relative_decrease; /* 1e-3                                                            */
+  double  function_tolerance;  /* 1e-6                                                              */
+  double  parameter_tolerance; /* 1e-8                                                              */
+  double  gradient_tolerance;  /* 1e-10                                                             */
+  /* IMU noise, already discretised (orb_slam3/src/Tracking.cc:1203-1211) and gravity magnitude */
+  double  sigma_a, sigma_g, sigma_aw, sigma_gw, gravity;
+  int32_t verbose;
+  int32_t reserved;
+} covgpu_options;
+
+/* Fills `o` with the reference's effective settings (dogleg, 10 iterations, Cauchy(1), Ceres 1.x
+ * defaults, EuRoC IMU noise at 200 Hz, g = 9.81). */
+void covgpu_default_options(covgpu_options* o);
+
+/* ---------------------------------------------------------------- flat problem IR
+ * All pointers are HOST pointers owned by the caller; nothing is retained after a call returns.
+ * Index arrays are int32. In/out arrays are overwritten with the optimised estimate.            */
+typedef struct covgpu_problem {
+  int32_t num_kf;        /* K  valid keyframes                                    */
+  int32_t num_cam;       /* A  distinct cameras (one per agent in COVINS)         */
+  int32_t num_lm;        /* L  landmarks that passed the >=2-observation gate     */
+  int32_t num_obs;       /* O  reprojection residual blocks                       */
+  int32_t num_imu;       /* I  IMU preintegration factors                         */
+  int32_t num_edge;      /* E  SE3 between factors (loops; PGO odometry edges)    */
+  int32_t num_imu_samples; /* S total raw IMU samples over all factors           */
+  int32_t reserved;
+
+  /* keyframes */
+  double*        kf_pose;        /* [K][7]  in/out  T_w_s                          */
+  double*        kf_speed_bias;  /* [K][9]  in/out  (NULL allowed if visual_only)  */
+  const uint8_t* kf_fixed;       /* [K]     1 = pose block constant (opt_be.cpp:329-341, 870-881) */
+  const int32_t* kf_cam;         /* [K]     camera index                           */
+
+  /* cameras: extrinsics T_s_c, intrinsics fx fy cx cy, 4 distortion coefficients; all constant
+   * in every call site (opt_be.cpp:336,349,352) */
+  const double*  cam_extr;       /* [A][7] */
+  const double*  cam_intr;       /* [A][4] */
+  const double*  cam_dist;       /* [A][4] */
+  const int32_t* cam_dist_type;  /* [A]    */
+
+  /* landmarks + observations. Observations are grouped by landmark (the reference's iteration
+   * order, opt_be.cpp:432-530): those of landmark l are [lm_obs_ptr[l], lm_obs_ptr[l+1]). */
+  double*        lm_pos;         /* [L][3]  in/out  world position                 */
+  const int32_t* lm_obs_ptr;     /* [L+1]                                          */
+  const int32_t* obs_kf;         /* [O]                                            */
+  const double*  obs_uv;         /* [O][2]  keypoint, float32 promoted to double (opt_be.cpp:477) */
+  const double*  obs_sigma;      /* [O]     (octave+1)*2 px (opt_be.cpp:478)       */
+
+  /* IMU factors between predecessor kf_i and successor kf_j (opt_be.cpp:369-416). The raw samples
+   * are part of the IR because the reference re-propagates the preintegration with the current
+   * bias estimate once per solve (opt_be.cpp:396). Sample = [dt, ax,ay,az, wx,wy,wz]. */
+  const int32_t* imu_kf_i;       /* [I] */
+  const int32_t* imu_kf_j;       /* [I] */
+  const int32_t* imu_sample_ptr; /* [I+1] */
+  const double*  imu_samples;    /* [S][7] */
+  const double*  imu_first;      /* [I][6]  (acc_0, gyr_0): reading at the predecessor (keyframe_be.cpp:187,195) */
+
+  /* SE3 between factors (robopt SixDofBetweenError, kImu): measurement T_s1_s2 as [q(4), t(3)],
+   * row-major 6x6 sqrt-information (rotation rows first), Cauchy scale per edge (0 = no loss). */
+  const int32_t* edge_i;         /* [E] */
+  const int32_t* edge_j;         /* [E] */
+  const double*  edge_meas;      /* [E][7] */
+  const double*  edge_sqrt_info; /* [E][36] */
+  const double*  edge_loss_a;    /* [E] */
+} covgpu_problem;
+
+/* per-iteration trace, for parity tests against the oracle */
+#define COVGPU_MAX_TRACE 64
+typedef struct covgpu_result {
+  int32_t iterations;          /* trust-region iterations executed                          */
+  int32_t accepted;            /* of which successful                                       */
+  int32_t termination;         /* 0 max-iter, 1 function tol, 2 parameter tol, 3 gradient tol, 4 failure */
+  int32_t reserved;
+  double  initial_cost;
+  double  final_cost;
+  double  t_upload_s;          /* H2D incl. layout build                                    */
+  double  t_solve_s;           /* device-resident solve (the timed region of bench.py)      */
+  double  t_download_s;        /* D2H                                                       */
+  double  t_linear_solve_s;    /* part of t_solve_s spent in the reduced-system factor+solve */
+  double  cost_trace[COVGPU_MAX_TRACE];    /* cost after each iteration */
+  double  radius_trace[COVGPU_MAX_TRACE];
+  int32_t accepted_trace[COVGPU_MAX_TRACE];
+} covgpu_result;
+
+/* ---------------------------------------------------------------- context */
+typedef struct covgpu_context covgpu_context;
+
+/* One context per calling thread / map (the reference may run PGO for different maps on
+ * different place-recognition threads, placerec_be.cpp:295). Owns one HIP stream + workspace. */
+int  covgpu_create(const covgpu_options* opt, covgpu_context** out);
+void covgpu_destroy(covgpu_context* ctx);
+const char* covgpu_last_error(void);
+
+/* ---------------------------------------------------------------- solve entry points
+ * covgpu_gba_solve   replaces the ceres::Solve of GlobalBundleAdjustment (opt_be.cpp:560-567 and,
+ *                    with max_iterations = 5, the outlier round's :257-265).
+ * covgpu_pgo_solve   replaces the ceres::Solve of PoseGraphOptimization (opt_be.cpp:1024-1031):
+ *                    poses + between factors only (num_lm = num_obs = num_imu = 0).
+ * Both upload `p`, run the trust-region loop fully on the device, and write the optimised
+ * kf_pose / kf_speed_bias / lm_pos back into the caller's arrays.                               */
+int covgpu_gba_solve(covgpu_context* ctx, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out);
+int covgpu_pgo_solve(covgpu_context* ctx, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out);
+
+/* Split form used by bench.py so that inputs are HBM-resident before the timed region:
+ * upload once, solve (restarts from the uploaded initial estimate every call), download. */
+int covgpu_upload(covgpu_context* ctx, const covgpu_options* opt, const covgpu_problem* p);
+int covgpu_solve_resident(covgpu_context* ctx, const covgpu_options* opt, covgpu_result* out);
+int covgpu_download(covgpu_context* ctx, covgpu_problem* p);
+
+/* GBA outlier rule (opt_be.cpp:270-290): evaluates every reprojection block at the current
+ * host estimate in `p` and writes the loss-corrected whitened residual norm per observation. */
+int covgpu_reprojection_residual_norms(covgpu_context* ctx, const covgpu_options* opt,
+                                       const covgpu_problem* p, double* norms /* [O] */);
+
+/* PGO tail (opt_be.cpp:1046-1047, 1066-1081): rotate velocities and re-anchor every landmark to
+ * its reference keyframe: p' = T_ws_new(ref) * T_ws_old(ref)^-1 * p.  ref_kf[l] < 0 skips l. */
+int covgpu_pgo_reanchor(covgpu_context* ctx, int32_t num_kf, const double* pose_old /* [K][7] */,
+                        const double* pose_new /* [K][7] */, double* velocity /* [K][3] or NULL */,
+                        int32_t num_lm, const int32_t* ref_kf /* [L] */, double* lm_pos /* [L][3] */);
+
+/* ---------------------------------------------------------------- per-kernel test entry points
+ * (SURVEY.md §8b last row). Each runs exactly one device kernel family on host inputs and returns
+ * raw, un-reduced outputs so tests/ can compare them with the oracle.                           */
+
+/* R4+R5+R6: per observation r[2], J_pose[2x6], J_lm[2x3] (whitened, loss-corrected), cost rho/2. */
+int covgpu_linearize_reprojection(covgpu_context* ctx, const covgpu_options* opt, const covgpu_problem* p,
+                                  double* r /* [O][2] */, double* J_pose /* [O][12] */,
+                                  double* J_lm /* [O][6] */, double* cost /* [O] */);
+
+/* R2: per IMU factor delta [dp(3), dq(4), dv(3), dt_sum] (11), bias Jacobian J[15x15],
+ * covariance P[15x15], preintegrated at the linearisation bias = speed_bias[kf_j][3:9]. */
+int covgpu_preintegrate(covgpu_context* ctx, const covgpu_options* opt, const covgpu_problem* p,
+                        double* delta /* [I][11] */, double* J /* [I][225] */, double* P /* [I][225] */);
+
+/* R3: per IMU factor whitened residual r[15] and Jacobians w.r.t. [pose_i(6), sb_i(9), pose_j(6),
+ * sb_j(9)] as one row-major 15x30 block. */
+int covgpu_linearize_imu(covgpu_context* ctx, const covgpu_options* opt, const covgpu_problem* p,
+                         double* r /* [I][15] */, double* J /* [I][450] */);
+
+/* R7: per edge residual r[6] and row-major 6x12 Jacobian w.r.t. [pose_i(6), pose_j(6)]
+ * (whitened by sqrt_info, loss-corrected), cost. */
+int covgpu_linearize_between(covgpu_context* ctx, const covgpu_options* opt, const covgpu_problem* p,
+                             double* r /* [E][6] */, double* J /* [E][72] */, double* cost /* [E] */);
+
+/* R8 building block: damped Schur complement at the current estimate.
+ * Outputs the dense reduced system S (n x n, row-major, full symmetric) and b (n),
+ * n = dim_per_kf * K with dim_per_kf = 15 (VI) or 6 (visual_only / PGO), plus total cost. */
+int covgpu_schur(covgpu_context* ctx, const covgpu_options* opt, const covgpu_problem* p, double mu,
+                 double* S, double* b, double* cost);
+
+/* R8 building block: dense FP64 Cholesky solve of S x = b on the MFMA path (S symmetric positive
+ * definite, row-major n x n; only the lower triangle is read). Returns COVGPU_ERR_NUMERIC if a
+ * pivot is not positive. */
+int covgpu_solve_reduced(covgpu_context* ctx, int32_t n, const double* S, const double* b, double* x);
+
+int32_t covgpu_reduced_dim(const covgpu_options* opt, const covgpu_problem* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COVGPU_H_ */

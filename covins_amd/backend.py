@@ -1,0 +1,176 @@
+"""ctypes binding of the product library covins_amd/libcovgpu.so (C ABI: include/covgpu.h).
+
+There is NO CPU fallback: if the HIP extension is missing or no MI355X is visible, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import capi
+from .capi import FlatProblem, Options, Result, dptr, iptr
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcovgpu.so")
+_LIB: Optional[C.CDLL] = None
+
+
+class CovGpuError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compiles the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise CovGpuError(f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(libcovgpu has no CPU fallback)")
+        _LIB = C.CDLL(_SO)
+        capi.declare(_LIB, "covgpu_")
+        OP, PP = C.POINTER(Options), C.POINTER(capi.ProblemStruct)
+        _LIB.covgpu_upload_pgo.argtypes = [C.c_void_p, OP, PP]
+        _LIB.covgpu_schur_pgo.argtypes = [C.c_void_p, OP, PP, C.c_double, capi._dp, capi._dp, capi._dp]
+        _LIB.covgpu_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        _LIB.covgpu_set_profiling.restype = None
+        _LIB.covgpu_get_profile.argtypes = [C.c_void_p, capi._dp]
+        _LIB.covgpu_get_profile.restype = None
+    return _LIB
+
+
+def default_options(**kw) -> Options:
+    o = Options()
+    lib().covgpu_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class Context:
+    """One solver context = one HIP stream + HBM workspace (covgpu_create / covgpu_destroy)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        o = default_options(device=device)
+        self._check(lib().covgpu_create(C.byref(o), C.byref(self._h)))
+        self._keep = None
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise CovGpuError(f"covgpu error {rc}: {lib().covgpu_last_error().decode()}")
+
+    def close(self):
+        if self._h:
+            lib().covgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- full solves (upload + solve + download)
+    def gba_solve(self, prob: FlatProblem, opt: Options) -> Tuple[FlatProblem, Result]:
+        q = prob.copy(); s = q.as_struct(); r = Result()
+        self._check(lib().covgpu_gba_solve(self._h, C.byref(opt), C.byref(s), C.byref(r)))
+        return q, r
+
+    def pgo_solve(self, prob: FlatProblem, opt: Options) -> Tuple[FlatProblem, Result]:
+        q = prob.copy(); s = q.as_struct(); r = Result()
+        self._check(lib().covgpu_pgo_solve(self._h, C.byref(opt), C.byref(s), C.byref(r)))
+        return q, r
+
+    # ---- split form: inputs resident in HBM before the timed region
+    def upload(self, prob: FlatProblem, opt: Options, pgo: bool = False):
+        self._keep = prob
+        s = prob.as_struct()
+        fn = lib().covgpu_upload_pgo if pgo else lib().covgpu_upload
+        self._check(fn(self._h, C.byref(opt), C.byref(s)))
+
+    def solve_resident(self, opt: Options) -> Result:
+        r = Result()
+        self._check(lib().covgpu_solve_resident(self._h, C.byref(opt), C.byref(r)))
+        return r
+
+    def download(self) -> FlatProblem:
+        q = self._keep.copy(); s = q.as_struct()
+        self._check(lib().covgpu_download(self._h, C.byref(s)))
+        return q
+
+    def set_profiling(self, on: bool):
+        lib().covgpu_set_profiling(self._h, int(on))
+
+    def profile(self) -> dict:
+        out = np.zeros(8)
+        lib().covgpu_get_profile(self._h, dptr(out))
+        return dict(build_ms=out[0], n_build=int(out[1]), factor_ms=out[2], n_factor=int(out[3]), syrk_ms=out[4],
+                    n_syrk=int(out[5]), syrk_flops=out[6])
+
+    # ---- per-kernel entry points (tests)
+    def residual_norms(self, prob, opt):
+        out = np.zeros(prob.O); s = prob.as_struct()
+        self._check(lib().covgpu_reprojection_residual_norms(self._h, C.byref(opt), C.byref(s), dptr(out)))
+        return out
+
+    def linearize_reprojection(self, prob, opt):
+        O = prob.O
+        r, Jp, Jl, c = np.zeros((O, 2)), np.zeros((O, 12)), np.zeros((O, 6)), np.zeros(O)
+        s = prob.as_struct()
+        self._check(lib().covgpu_linearize_reprojection(self._h, C.byref(opt), C.byref(s), dptr(r), dptr(Jp), dptr(Jl), dptr(c)))
+        return r, Jp, Jl, c
+
+    def preintegrate(self, prob, opt):
+        I = prob.I
+        d, J, P = np.zeros((I, 11)), np.zeros((I, 225)), np.zeros((I, 225))
+        s = prob.as_struct()
+        self._check(lib().covgpu_preintegrate(self._h, C.byref(opt), C.byref(s), dptr(d), dptr(J), dptr(P)))
+        return d, J, P
+
+    def linearize_imu(self, prob, opt):
+        I = prob.I
+        r, J = np.zeros((I, 15)), np.zeros((I, 450))
+        s = prob.as_struct()
+        self._check(lib().covgpu_linearize_imu(self._h, C.byref(opt), C.byref(s), dptr(r), dptr(J)))
+        return r, J
+
+    def linearize_between(self, prob, opt):
+        E = prob.E
+        r, J, c = np.zeros((E, 6)), np.zeros((E, 72)), np.zeros(E)
+        s = prob.as_struct()
+        self._check(lib().covgpu_linearize_between(self._h, C.byref(opt), C.byref(s), dptr(r), dptr(J), dptr(c)))
+        return r, J, c
+
+    def schur(self, prob, opt, mu, pgo=False):
+        n = (6 if (pgo or opt.visual_only) else 15) * prob.K
+        S, b, c = np.zeros((n, n)), np.zeros(n), np.zeros(1)
+        s = prob.as_struct()
+        fn = lib().covgpu_schur_pgo if pgo else lib().covgpu_schur
+        self._check(fn(self._h, C.byref(opt), C.byref(s), float(mu), dptr(S), dptr(b), dptr(c)))
+        return S, b, float(c[0])
+
+    def solve_reduced(self, S, b):
+        S = np.ascontiguousarray(S, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros(b.shape[0])
+        rc = lib().covgpu_solve_reduced(self._h, b.shape[0], dptr(S), dptr(b), dptr(x))
+        return rc, x
+
+    def pgo_reanchor(self, pose_old, pose_new, velocity, ref_kf, lm_pos):
+        po = np.ascontiguousarray(pose_old, dtype=np.float64); pn = np.ascontiguousarray(pose_new, dtype=np.float64)
+        vel = None if velocity is None else np.array(velocity, dtype=np.float64, order="C")
+        lm = np.array(lm_pos, dtype=np.float64, order="C").reshape(-1, 3)
+        ref = np.ascontiguousarray(ref_kf, dtype=np.int32)
+        self._check(lib().covgpu_pgo_reanchor(self._h, po.shape[0], dptr(po), dptr(pn), dptr(vel), lm.shape[0], iptr(ref), dptr(lm)))
+        return vel, lm

@@ -1,0 +1,109 @@
+// common.hpp — device-resident problem layout and kernel launch interface of libcovgpu (gfx950 only).
+//
+// Data layout in HBM:
+//   * small gathered tables are array-of-structs (pose [K][7], speed-bias [K][9], landmark [L][3],
+//     camera [A][..]): K, A are tiny (<= ~20k rows) and stay L2-resident, each gather is one 24-72 B row;
+//   * the observation stream is struct-of-arrays (kf index i32, lm index i32, u, v, sigma f64), grouped by
+//     landmark exactly as the IR delivers it, so a wave reads 64 consecutive records fully coalesced;
+//   * the reduced camera system S is one dense row-major lower-triangular FP64 matrix of padded order
+//     npad (multiple of 128), 15 (VI) or 6 (visual-only / PGO) rows per keyframe in IR keyframe order;
+//   * all vectors of the trust-region step (gradient, diag(J^T J), Gauss-Newton step, step, scratch) are
+//     length N = n + 3 L with the pose part first, so norms and combinations are single flat kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/covgpu.h"
+
+namespace covgpu {
+
+constexpr int kTile = 128;  // panel width / tile edge of the dense reduced-system factorisation
+
+struct DevProblem {
+  int K, A, L, O, I, E, S;
+  int D;       // reduced dims per keyframe: 15 (VI) or 6
+  int n;       // D * K
+  int npad;    // n rounded up to a multiple of kTile (leading dimension of Sred)
+  int N;       // n + 3 L
+  int vi;      // 1: speed-bias blocks + IMU factors active
+  double reproj_loss_a, gravity;
+
+  // state: current, candidate, initial (restart point of covgpu_solve_resident)
+  double *pose, *sb, *lm;
+  double *pose_c, *sb_c, *lm_c;
+  double *pose0, *sb0, *lm0;
+  uint8_t* fixed;
+  int* kf_cam;
+  double *cam_extr, *cam_intr, *cam_dist;
+  int* cam_dist_type;
+
+  // observations (landmark-major)
+  int *lm_obs_ptr, *obs_kf, *obs_lm;
+  double *obs_u, *obs_v, *obs_sigma;
+
+  // IMU factors
+  int *imu_i, *imu_j, *imu_ptr;
+  double *imu_samples, *imu_first;
+  double *pre_delta;  // [I][11] dp dq dv dt
+  double *pre_J;      // [I][225]
+  double *pre_P;      // [I][225]
+  double *pre_W;      // [I][225] whitening = chol(P)^-1 (lower)
+  double *pre_bias;   // [I][6] linearisation ba, bg
+
+  // between factors
+  int *edge_i, *edge_j;
+  double *edge_meas, *edge_sqrt_info, *edge_loss_a;
+
+  // normal equations
+  double* Sred;    // [npad][npad] lower triangle used
+  double* bred;    // [npad] reduced right-hand side, overwritten by the solution
+  double* grad;    // [N]  J^T r           (pose part, then landmark part)
+  double* hdiag;   // [N]  diag(J^T J)
+  double* HllInv;  // [L][6] damped inverse landmark blocks (xx xy xz yy yz zz)
+  double* gn;      // [N]  Gauss-Newton (or LM) step
+  double* step;    // [N]  trust-region step
+  double* vtmp;    // [N]  scratch vector
+  double* Linv;    // [npad/kTile][kTile*kTile] inverses of the factor's diagonal blocks
+  double* scal;    // [32] device scalars (reductions)
+  int* flag;       // [4]  device flags (Cholesky failure)
+};
+
+// ---- scalar slots in DevProblem::scal
+enum { SC_COST = 0, SC_JV2 = 1, SC_GG = 2, SC_GN2 = 3, SC_GDOT = 4, SC_GMAX = 5, SC_GS = 6, SC_SN2 = 7, SC_XN2 = 8, SC_COUNT = 16 };
+
+// ---- launchers (each enqueues on `st`, no synchronisation)
+void launch_lm_build(const DevProblem& P, double mu, hipStream_t st);     // reprojection -> Hll, g, S (Schur), bred, cost
+void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st);
+void launch_obs_jvp(const DevProblem& P, const double* v_all, hipStream_t st);  // scal[SC_JV2] += sum |J v|^2
+void launch_obs_cost(const DevProblem& P, const double* pose, const double* lm, hipStream_t st);  // scal[SC_COST] +=
+void launch_obs_linearize(const DevProblem& P, double* r, double* Jp, double* Jl, double* cost, hipStream_t st);
+void launch_obs_norms(const DevProblem& P, double* norms, hipStream_t st);
+
+void launch_preintegrate(const DevProblem& P, const covgpu_options& o, hipStream_t st);
+void launch_imu_build(const DevProblem& P, hipStream_t st);
+void launch_imu_jvp(const DevProblem& P, const double* v_all, hipStream_t st);
+void launch_imu_cost(const DevProblem& P, const double* pose, const double* sb, hipStream_t st);
+void launch_imu_linearize(const DevProblem& P, double* r, double* J, hipStream_t st);
+
+void launch_edge_build(const DevProblem& P, hipStream_t st);
+void launch_edge_jvp(const DevProblem& P, const double* v_all, hipStream_t st);
+void launch_edge_cost(const DevProblem& P, const double* pose, hipStream_t st);
+void launch_edge_linearize(const DevProblem& P, double* r, double* J, double* cost, hipStream_t st);
+
+void launch_finalize_diag(const DevProblem& P, double mu, hipStream_t st);
+void launch_zero_system(const DevProblem& P, hipStream_t st);
+// dense SPD solve of Sred x = bred in place (lower Cholesky on the FP64 MFMA path); flag[0] != 0 on failure
+// syrk_events: optional 2 * (npad / kTile) events recorded around every SYRK launch (profiling only)
+void launch_dense_cholesky_solve(const DevProblem& P, hipStream_t st, hipEvent_t* syrk_events = nullptr);
+void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, hipEvent_t* syrk_events = nullptr);
+
+void launch_dogleg_stats(const DevProblem& P, hipStream_t st);  // GG, GN2, GDOT, GMAX from grad/hdiag/gn
+void launch_cauchy_vec(const DevProblem& P, hipStream_t st);    // vtmp = grad / d^2
+void launch_combine_step(const DevProblem& P, double cg, double cn, hipStream_t st);  // step = cg*grad/d^2 + cn*gn ; GS, SN2
+void launch_apply_step(const DevProblem& P, hipStream_t st);    // candidate = x (+) step
+void launch_accept(const DevProblem& P, hipStream_t st);        // x = candidate
+void launch_xnorm(const DevProblem& P, hipStream_t st);         // XN2
+void launch_reanchor(int K, const double* pose_old, const double* pose_new, double* vel, int L, const int* ref, double* lm,
+                     hipStream_t st);
+
+}  // namespace covgpu

@@ -1,0 +1,191 @@
+// k_between.hip — SE3 between factors (loop closures in GBA; loop + odometry edges in PGO) on gfx950.
+//
+// Replaces R7 robopt::posegraph::SixDofBetweenError(q_12, t_12, sqrt_info, kImu), SizedCostFunction<6,7,7,7,7>,
+// constructed at covins_backend/src/covins_backend/optimization_be.cpp:252,554 (GBA loop edges, sqrt_info =
+// diag(100 I3, 1e4 I3), Cauchy(1) in round 2) and :934,968,1017 (PGO: loops, successor edges from VIO poses,
+// five previous-neighbour edges). Extrinsics are ignored for kImu. Contract: SURVEY.md A.3 / A.5.
+// Also the PGO tail (opt_be.cpp:1046-1047, 1066-1081): velocity rotation and landmark re-anchoring.
+//
+// One thread per edge: E is O(6 K) in PGO and O(10) in GBA; the 6x12 Jacobian stays in registers.
+#include "common.hpp"
+#include "dev_math.hpp"
+
+namespace covgpu {
+using namespace covdev;
+
+// r[6], J[6x12] = [J_i | J_j] (whitened by sqrt_info, loss-corrected, fixed poses zeroed); returns cost.
+template <bool JAC>
+COV_DEV double eval_edge(const DevProblem& P, const double* __restrict__ pose, int e, double* r, double* J) {
+  const int i = P.edge_i[e], j = P.edge_j[e];
+  const double *Ti = pose + 7 * i, *Tj = pose + 7 * j, *Tm = P.edge_meas + 7 * (size_t)e;
+  const double* S = P.edge_sqrt_info + 36 * (size_t)e;
+  const Q4 qi = ldq(Ti), qj = ldq(Tj), qm = ldq(Tm);
+  const M3 Ri = qrot(qi);
+  const V3 that = mulT(Ri, ld3(Tj + 4) - ld3(Ti + 4));
+  const Q4 er = qmul(qconj(qm), qmul(qconj(qi), qj));
+  const double u[6] = {2.0 * er.x, 2.0 * er.y, 2.0 * er.z, that.x - Tm[4], that.y - Tm[5], that.z - Tm[6]};
+  double s = 0.0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t += S[6 * a + k] * u[k];
+    r[a] = t; s += t * t;
+  }
+  double cost;
+  const double sq = cauchy_scale(P.edge_loss_a[e], s, &cost);
+#pragma unroll
+  for (int a = 0; a < 6; ++a) r[a] *= sq;
+  if (JAC) {
+    // un-whitened 6x12: rows [rot(3); trans(3)], cols [dth_i dp_i dth_j dp_j]
+    double A[72];
+#pragma unroll
+    for (int k = 0; k < 72; ++k) A[k] = 0.0;
+    const bool fi = P.fixed[i] != 0, fj = P.fixed[j] != 0;
+    const M3 RiT = transpose(Ri);
+    if (!fi) {
+      const M3 a = mul(quat_lr3(er, -1.0), transpose(qrot(qm)));  // R3(e) R_m^T
+      const M3 sk = skew(that);
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          A[12 * rr + c] = -a.m[3 * rr + c];
+          A[12 * (3 + rr) + c] = sk.m[3 * rr + c];
+          A[12 * (3 + rr) + 3 + c] = -RiT.m[3 * rr + c];
+        }
+    }
+    if (!fj) {
+      const M3 l = quat_lr3(er, 1.0);
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          A[12 * rr + 6 + c] = l.m[3 * rr + c];
+          A[12 * (3 + rr) + 9 + c] = RiT.m[3 * rr + c];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t += S[6 * a + k] * A[12 * k + c];
+        J[12 * a + c] = t * sq;
+      }
+  }
+  return cost;
+}
+
+__global__ __launch_bounds__(64) void k_edge_build(DevProblem P) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P.E) return;
+  double r[6], J[72];
+  const double cost = eval_edge<true>(P, P.pose, e, r, J);
+  atomicAdd(&P.scal[SC_COST], cost);
+  const int idx[2] = {P.D * P.edge_i[e], P.D * P.edge_j[e]};
+  const size_t ld = (size_t)P.npad;
+  for (int a = 0; a < 12; ++a) {
+    const int ra = idx[a / 6] + a % 6;
+    double ga = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ga += J[12 * k + a] * r[k];
+    if (ga != 0.0) { atomicAdd(P.grad + ra, ga); atomicAdd(P.bred + ra, -ga); }
+    for (int b = 0; b < 12; ++b) {
+      const int rb = idx[b / 6] + b % 6;
+      if (rb > ra) continue;
+      double h = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) h += J[12 * k + a] * J[12 * k + b];
+      if (h == 0.0) continue;
+      atomicAdd(P.Sred + (size_t)ra * ld + rb, h);
+      if (a == b) atomicAdd(P.hdiag + ra, h);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_edge_jvp(DevProblem P, const double* __restrict__ v_all) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0.0;
+  if (e < P.E) {
+    double r[6], J[72];
+    eval_edge<true>(P, P.pose, e, r, J);
+    const double* vi = v_all + (size_t)P.D * P.edge_i[e];
+    const double* vj = v_all + (size_t)P.D * P.edge_j[e];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      double t = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) t += J[12 * a + c] * vi[c] + J[12 * a + 6 + c] * vj[c];
+      acc += t * t;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(&P.scal[SC_JV2], acc);
+}
+
+__global__ __launch_bounds__(64) void k_edge_cost(DevProblem P, const double* __restrict__ pose) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0.0;
+  if (e < P.E) {
+    double r[6];
+    acc = eval_edge<false>(P, pose, e, r, nullptr);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(&P.scal[SC_COST], acc);
+}
+
+__global__ __launch_bounds__(64) void k_edge_linearize(DevProblem P, double* r_out, double* J_out, double* cost) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P.E) return;
+  double r[6], J[72];
+  cost[e] = eval_edge<true>(P, P.pose, e, r, J);
+  for (int k = 0; k < 6; ++k) r_out[6 * (size_t)e + k] = r[k];
+  for (int k = 0; k < 72; ++k) J_out[72 * (size_t)e + k] = J[k];
+}
+
+// PGO tail. One thread per keyframe (velocity) / landmark (re-anchoring); both embarrassingly parallel.
+__global__ __launch_bounds__(256) void k_reanchor(int K, const double* __restrict__ po, const double* __restrict__ pn, double* vel, int L,
+                                                   const int* __restrict__ ref, double* lm) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (vel && t < K) {
+    const M3 Rn = qrot(qnormalize(ldq(pn + 7 * t))), Ro = qrot(qnormalize(ldq(po + 7 * t)));
+    const V3 v = mul(Rn, mulT(Ro, ld3(vel + 3 * t)));
+    vel[3 * t] = v.x; vel[3 * t + 1] = v.y; vel[3 * t + 2] = v.z;
+  }
+  if (t < L) {
+    const int k = ref[t];
+    if (k >= 0) {
+      const M3 Ro = qrot(qnormalize(ldq(po + 7 * k))), Rn = qrot(qnormalize(ldq(pn + 7 * k)));
+      const V3 ps = mulT(Ro, ld3(lm + 3 * t) - ld3(po + 7 * k + 4));
+      const V3 pw = mul(Rn, ps) + ld3(pn + 7 * k + 4);
+      lm[3 * t] = pw.x; lm[3 * t + 1] = pw.y; lm[3 * t + 2] = pw.z;
+    }
+  }
+}
+
+void launch_edge_build(const DevProblem& P, hipStream_t st) {
+  if (P.E == 0) return;
+  hipLaunchKernelGGL(k_edge_build, dim3((P.E + 63) / 64), dim3(64), 0, st, P);
+}
+void launch_edge_jvp(const DevProblem& P, const double* v_all, hipStream_t st) {
+  if (P.E == 0) return;
+  hipLaunchKernelGGL(k_edge_jvp, dim3((P.E + 63) / 64), dim3(64), 0, st, P, v_all);
+}
+void launch_edge_cost(const DevProblem& P, const double* pose, hipStream_t st) {
+  if (P.E == 0) return;
+  hipLaunchKernelGGL(k_edge_cost, dim3((P.E + 63) / 64), dim3(64), 0, st, P, pose);
+}
+void launch_edge_linearize(const DevProblem& P, double* r, double* J, double* cost, hipStream_t st) {
+  if (P.E == 0) return;
+  hipLaunchKernelGGL(k_edge_linearize, dim3((P.E + 63) / 64), dim3(64), 0, st, P, r, J, cost);
+}
+void launch_reanchor(int K, const double* pose_old, const double* pose_new, double* vel, int L, const int* ref, double* lm,
+                     hipStream_t st) {
+  const int n = K > L ? K : L;
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_reanchor, dim3((n + 255) / 256), dim3(256), 0, st, K, pose_old, pose_new, vel, L, ref, lm);
+}
+
+}  // namespace covgpu

@@ -1,0 +1,403 @@
+// k_visual.hip — reprojection residual blocks on gfx950: linearisation fused with landmark elimination.
+//
+// Replaces, for the problems assembled at covins_backend/src/covins_backend/optimization_be.cpp:432-530,
+//   R4 robopt::reprojection::GlobalEuclideanReprError<PinholeCamera, RadTan|Equidistant>  (opt_be.cpp:487-525)
+//   R5 aslam::PinholeCamera::project3 + distortion Jacobian
+//   R6 ceres::CauchyLoss(1.0) corrector                                                   (opt_be.cpp:302,523)
+// and the landmark half of Ceres' SPARSE_SCHUR (opt_be.cpp:561): H_ll, g_l, S -= W H_ll^-1 W^T, b += W H_ll^-1 g_l
+// (SURVEY.md A.2, A.5, A.6). None of these have a reference source in-tree; the contract is SURVEY.md Appendix A.
+//
+// Kernel shapes:
+//   lm_build   one G-lane sub-wave group per landmark (G = 16: EuRoC-like tracks average ~10 observations),
+//              lane = observation. Jacobians live in VGPRs only; H_ll / g_l are reduced with DPP/ds_bpermute
+//              butterflies inside the group; W blocks are exchanged through LDS (broadcast reads); the 6x6
+//              Schur blocks and the pose-side H_pp / g_p go to HBM with FP64 L2 atomics. No per-observation
+//              intermediate (J, W) is ever written to HBM.
+//   obs_*      one thread per observation over the SoA stream (cost, J*v products, test dumps).
+#include "common.hpp"
+#include "dev_math.hpp"
+
+namespace covgpu {
+using namespace covdev;
+
+struct ObsLin {
+  double r0, r1;
+  double jp[12];  // 2x6 row-major: [dtheta(3), dp(3)]
+  double jl[6];   // 2x3
+  double cost;
+};
+
+// R5: pinhole + radtan / equidistant. Returns false if the point is behind the camera (A.2: block zeroed).
+COV_DEV bool project_point(V3 lc, const double* intr, const double* dist, int dist_type, double& u, double& v, double* jpi /*2x3*/) {
+  if (!(lc.z > 1e-10)) return false;
+  const double iz = 1.0 / lc.z, x = lc.x * iz, y = lc.y * iz;
+  const double r2 = x * x + y * y;
+  double xd, yd, dxx, dxy, dyx, dyy;
+  if (dist_type == COVGPU_DIST_RADTAN) {
+    const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3];
+    const double rad = (k1 + k2 * r2) * r2, dr = k1 + 2.0 * k2 * r2;
+    xd = x + x * rad + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+    yd = y + y * rad + 2.0 * p2 * x * y + p1 * (r2 + 2.0 * y * y);
+    const double xy2dr = 2.0 * x * y * dr;
+    dxx = 1.0 + rad + 2.0 * x * x * dr + 2.0 * p1 * y + 6.0 * p2 * x;
+    dxy = xy2dr + 2.0 * p1 * x + 2.0 * p2 * y;
+    dyx = dxy;
+    dyy = 1.0 + rad + 2.0 * y * y * dr + 2.0 * p2 * x + 6.0 * p1 * y;
+  } else {
+    const double rho = sqrt(r2);
+    if (rho < 1e-8) {
+      xd = x; yd = y; dxx = 1.0; dxy = 0.0; dyx = 0.0; dyy = 1.0;
+    } else {
+      const double th = atan(rho), t2 = th * th;
+      const double poly = 1.0 + t2 * (dist[0] + t2 * (dist[1] + t2 * (dist[2] + t2 * dist[3])));
+      const double dpoly = 1.0 + t2 * (3.0 * dist[0] + t2 * (5.0 * dist[1] + t2 * (7.0 * dist[2] + t2 * 9.0 * dist[3])));
+      const double thd = th * poly, sc = thd / rho;
+      const double dsc = (dpoly / (1.0 + r2) * rho - thd) / r2;
+      const double ir = 1.0 / rho;
+      xd = sc * x; yd = sc * y;
+      dxx = sc + x * x * dsc * ir; dxy = x * y * dsc * ir; dyx = dxy; dyy = sc + y * y * dsc * ir;
+    }
+  }
+  u = intr[0] * xd + intr[2];
+  v = intr[1] * yd + intr[3];
+  if (jpi) {
+    jpi[0] = intr[0] * dxx * iz; jpi[1] = intr[0] * dxy * iz; jpi[2] = -intr[0] * (dxx * x + dxy * y) * iz;
+    jpi[3] = intr[1] * dyx * iz; jpi[4] = intr[1] * dyy * iz; jpi[5] = -intr[1] * (dyx * x + dyy * y) * iz;
+  }
+  return true;
+}
+
+// R4 + R6 for one observation. `fixed` zeroes the pose Jacobian (constant parameter block, opt_be.cpp:329-341).
+template <bool JAC>
+COV_DEV void eval_obs(const DevProblem& P, const double* __restrict__ pose, const double* __restrict__ lm, int o, int kf, int l,
+                      ObsLin& out) {
+  const int cam = P.kf_cam[kf];
+  const double* ps = pose + 7 * kf;
+  const double* ex = P.cam_extr + 7 * cam;
+  const Q4 qws = ldq(ps), qsc = ldq(ex);
+  const M3 Rws = qrot(qws), Rsc = qrot(qsc);
+  const V3 lw = ld3(lm + 3 * l);
+  const V3 ls = mulT(Rws, lw - ld3(ps + 4));
+  const V3 lc = mulT(Rsc, ls - ld3(ex + 4));
+  double u, v, jpi[6];
+  const bool ok = project_point(lc, P.cam_intr + 4 * cam, P.cam_dist + 4 * cam, P.cam_dist_type[cam], u, v, JAC ? jpi : nullptr);
+  if (!ok) {
+    out.r0 = out.r1 = 0.0; out.cost = 0.0;
+    if (JAC) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) out.jp[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) out.jl[k] = 0.0;
+    }
+    return;
+  }
+  const double is = 1.0 / P.obs_sigma[o];
+  double r0 = (u - P.obs_u[o]) * is, r1 = (v - P.obs_v[o]) * is;
+  double c;
+  const double sq = cauchy_scale(P.reproj_loss_a, r0 * r0 + r1 * r1, &c);
+  out.r0 = r0 * sq; out.r1 = r1 * sq; out.cost = c;
+  if (JAC) {
+    const double w = is * sq;
+    const bool fx = P.fixed[kf] != 0;
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+      // a = (w J_pi R_sc^T)_row  ->  a_c = w * sum_k jpi[row][k] Rsc[c][k]
+      const V3 a = mul(Rsc, V3{jpi[3 * row] * w, jpi[3 * row + 1] * w, jpi[3 * row + 2] * w});
+      const V3 jth = cross(a, ls);  // a^T [l_S]x
+      const V3 jlw = mul(Rws, a);   // a^T R_ws^T
+      out.jl[3 * row] = jlw.x; out.jl[3 * row + 1] = jlw.y; out.jl[3 * row + 2] = jlw.z;
+      out.jp[6 * row] = fx ? 0.0 : jth.x; out.jp[6 * row + 1] = fx ? 0.0 : jth.y; out.jp[6 * row + 2] = fx ? 0.0 : jth.z;
+      out.jp[6 * row + 3] = fx ? 0.0 : -jlw.x; out.jp[6 * row + 4] = fx ? 0.0 : -jlw.y; out.jp[6 * row + 5] = fx ? 0.0 : -jlw.z;
+    }
+  }
+}
+
+COV_DEV void group_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int G>
+COV_DEV double group_sum(double v) {
+#pragma unroll
+  for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, G);
+  return v;
+}
+
+// symmetric 3x3 inverse; h = xx xy xz yy yz zz
+COV_DEV void inv3sym(const double* h, double* o) {
+  const double c00 = h[3] * h[5] - h[4] * h[4], c01 = h[2] * h[4] - h[1] * h[5], c02 = h[1] * h[4] - h[2] * h[3];
+  const double det = h[0] * c00 + h[1] * c01 + h[2] * c02;
+  const double id = (fabs(det) > 0.0) ? 1.0 / det : 0.0;
+  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+  o[3] = (h[0] * h[5] - h[2] * h[2]) * id; o[4] = (h[1] * h[2] - h[0] * h[4]) * id; o[5] = (h[0] * h[3] - h[1] * h[1]) * id;
+}
+
+constexpr int kBuildThreads = 256;
+
+// ------------------------------------------------------------------------------------------------------------
+// lm_build: per landmark  H_ll, g_l (reduced in-group), damped inverse, then per observation a:
+//   S[kf_a,kf_a] += Jp^T Jp   g[kf_a] += Jp^T r   bred[kf_a] += -Jp^T r + Y_a g_l      (Y_a = W_a Hinv, W_a = Jp^T Jl)
+//   S[kf_a,kf_t] -= Y_a W_t^T  for every observation t of the same landmark with kf_t <= kf_a (lower triangle)
+// ------------------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kBuildThreads) void k_lm_build(DevProblem P, double mu) {
+  constexpr int GROUPS = kBuildThreads / G;
+  __shared__ double sW[GROUPS][G][19];  // 18 W entries + kf index (as double) ; odd pitch spreads LDS banks
+  const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+  const int l = blockIdx.x * GROUPS + grp;
+  const bool lm_ok = l < P.L;
+  const int o0 = lm_ok ? P.lm_obs_ptr[l] : 0;
+  const int nobs = lm_ok ? P.lm_obs_ptr[l + 1] - o0 : 0;
+  const int nchunk = (nobs + G - 1) / G;
+  const int D = P.D;
+  const size_t ld = (size_t)P.npad;
+
+  // pass A: H_ll, g_l, cost
+  double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0}, cost = 0.0;
+  ObsLin e;
+  int kf = 0;
+  bool have = false;
+  for (int c = 0; c < nchunk; ++c) {
+    const int a = c * G + lane;
+    have = a < nobs;
+    if (have) {
+      kf = P.obs_kf[o0 + a];
+      eval_obs<true>(P, P.pose, P.lm, o0 + a, kf, l, e);
+      h[0] += e.jl[0] * e.jl[0] + e.jl[3] * e.jl[3];
+      h[1] += e.jl[0] * e.jl[1] + e.jl[3] * e.jl[4];
+      h[2] += e.jl[0] * e.jl[2] + e.jl[3] * e.jl[5];
+      h[3] += e.jl[1] * e.jl[1] + e.jl[4] * e.jl[4];
+      h[4] += e.jl[1] * e.jl[2] + e.jl[4] * e.jl[5];
+      h[5] += e.jl[2] * e.jl[2] + e.jl[5] * e.jl[5];
+      gl[0] += e.jl[0] * e.r0 + e.jl[3] * e.r1;
+      gl[1] += e.jl[1] * e.r0 + e.jl[4] * e.r1;
+      gl[2] += e.jl[2] * e.r0 + e.jl[5] * e.r1;
+      cost += e.cost;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) h[k] = group_sum<G>(h[k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) gl[k] = group_sum<G>(gl[k]);
+  double hi[6];
+  {
+    double hd[6] = {h[0], h[1], h[2], h[3], h[4], h[5]};
+    const double d0 = clamp_diag(h[0]), d1 = clamp_diag(h[3]), d2 = clamp_diag(h[5]);
+    hd[0] += mu * d0 * d0; hd[3] += mu * d1 * d1; hd[5] += mu * d2 * d2;
+    inv3sym(hd, hi);
+  }
+  if (lm_ok && lane == 0) {
+    double* gg = P.grad + P.n + 3 * (size_t)l;
+    double* hh = P.hdiag + P.n + 3 * (size_t)l;
+    gg[0] = gl[0]; gg[1] = gl[1]; gg[2] = gl[2];
+    hh[0] = h[0]; hh[1] = h[3]; hh[2] = h[5];
+    double* hv = P.HllInv + 6 * (size_t)l;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) hv[k] = hi[k];
+  }
+  // block-level cost reduction: one atomic per wave
+  cost = wave_sum(cost);
+  if ((threadIdx.x & 63) == 0 && cost != 0.0) atomicAdd(&P.scal[SC_COST], cost);
+
+  // pass B
+  for (int ca = 0; ca < nchunk; ++ca) {
+    const int a = ca * G + lane;
+    const bool have_a = a < nobs;
+    if (nchunk > 1 && have_a) {  // multi-chunk landmark: Jacobians of this chunk were overwritten in pass A
+      kf = P.obs_kf[o0 + a];
+      eval_obs<true>(P, P.pose, P.lm, o0 + a, kf, l, e);
+    }
+    double W[18], Y[18];
+    if (have_a) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) W[3 * r + c] = e.jp[r] * e.jl[c] + e.jp[6 + r] * e.jl[3 + c];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        Y[3 * r + 0] = W[3 * r] * hi[0] + W[3 * r + 1] * hi[1] + W[3 * r + 2] * hi[2];
+        Y[3 * r + 1] = W[3 * r] * hi[1] + W[3 * r + 1] * hi[3] + W[3 * r + 2] * hi[4];
+        Y[3 * r + 2] = W[3 * r] * hi[2] + W[3 * r + 1] * hi[4] + W[3 * r + 2] * hi[5];
+      }
+      if (!P.fixed[kf]) {
+        const size_t base = (size_t)(D * kf);
+        double* Sd = P.Sred + base * ld + base;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+          for (int c = 0; c <= r; ++c) atomicAdd(Sd + r * ld + c, e.jp[r] * e.jp[c] + e.jp[6 + r] * e.jp[6 + c]);
+          const double gr = e.jp[r] * e.r0 + e.jp[6 + r] * e.r1;
+          const double yg = Y[3 * r] * gl[0] + Y[3 * r + 1] * gl[1] + Y[3 * r + 2] * gl[2];
+          atomicAdd(P.grad + base + r, gr);
+          atomicAdd(P.bred + base + r, yg - gr);
+          atomicAdd(P.hdiag + base + r, e.jp[r] * e.jp[r] + e.jp[6 + r] * e.jp[6 + r]);
+        }
+      }
+    }
+    for (int cb = 0; cb < nchunk; ++cb) {
+      // publish the W blocks of chunk cb through LDS. A group never spans waves and all its lanes share one
+      // control flow (same landmark), so wave-level ordering of the in-order LDS queue is sufficient: no
+      // workgroup barrier (which would also be illegal here: trip counts differ between groups).
+      group_sync();
+      if (cb == ca) {
+        if (have_a) {
+#pragma unroll
+          for (int k = 0; k < 18; ++k) sW[grp][lane][k] = W[k];
+          sW[grp][lane][18] = (double)kf;
+        }
+      } else {
+        const int t = cb * G + lane;
+        if (t < nobs) {
+          ObsLin et;
+          const int kft = P.obs_kf[o0 + t];
+          eval_obs<true>(P, P.pose, P.lm, o0 + t, kft, l, et);
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sW[grp][lane][3 * r + c] = et.jp[r] * et.jl[c] + et.jp[6 + r] * et.jl[3 + c];
+          sW[grp][lane][18] = (double)kft;
+        }
+      }
+      group_sync();
+      const int nt = min(G, nobs - cb * G);
+      if (have_a && !P.fixed[kf]) {
+        for (int t = 0; t < nt; ++t) {
+          const double* Wt = sW[grp][t];
+          const int kft = (int)Wt[18];
+          if (kft > kf || P.fixed[kft]) continue;
+          double* Sb = P.Sred + (size_t)(D * kf) * ld + (size_t)(D * kft);
+          const bool diag = kft == kf;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            const double w0 = Wt[3 * c], w1 = Wt[3 * c + 1], w2 = Wt[3 * c + 2];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+              if (diag && r < c) continue;
+              atomicAdd(Sb + r * ld + c, -(Y[3 * r] * w0 + Y[3 * r + 1] * w1 + Y[3 * r + 2] * w2));
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// back-substitution: dl = Hinv (-g_l - sum_a W_a^T dp[kf_a]); written to out_all[n + 3l ..]
+template <int G>
+__global__ __launch_bounds__(kBuildThreads) void k_lm_backsub(DevProblem P, const double* __restrict__ dp, double* __restrict__ out_all) {
+  constexpr int GROUPS = kBuildThreads / G;
+  const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+  const int l = blockIdx.x * GROUPS + grp;
+  const bool lm_ok = l < P.L;
+  const int o0 = lm_ok ? P.lm_obs_ptr[l] : 0;
+  const int nobs = lm_ok ? P.lm_obs_ptr[l + 1] - o0 : 0;
+  double t[3] = {0, 0, 0};
+  for (int a = lane; a < nobs; a += G) {
+    ObsLin e;
+    const int kf = P.obs_kf[o0 + a];
+    eval_obs<true>(P, P.pose, P.lm, o0 + a, kf, l, e);
+    const double* d = dp + (size_t)P.D * kf;
+    // (W^T d)_c = sum_r (Jp^T Jl)[r][c] d[r] = sum_k Jl[k][c] (Jp[k] . d)
+    const double s0 = e.jp[0] * d[0] + e.jp[1] * d[1] + e.jp[2] * d[2] + e.jp[3] * d[3] + e.jp[4] * d[4] + e.jp[5] * d[5];
+    const double s1 = e.jp[6] * d[0] + e.jp[7] * d[1] + e.jp[8] * d[2] + e.jp[9] * d[3] + e.jp[10] * d[4] + e.jp[11] * d[5];
+    t[0] += e.jl[0] * s0 + e.jl[3] * s1;
+    t[1] += e.jl[1] * s0 + e.jl[4] * s1;
+    t[2] += e.jl[2] * s0 + e.jl[5] * s1;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t[k] = group_sum<G>(t[k]);
+  if (lm_ok && lane == 0) {
+    const double* gl = P.grad + P.n + 3 * (size_t)l;
+    const double* hi = P.HllInv + 6 * (size_t)l;
+    const double x = -gl[0] - t[0], y = -gl[1] - t[1], z = -gl[2] - t[2];
+    double* o = out_all + P.n + 3 * (size_t)l;
+    o[0] = hi[0] * x + hi[1] * y + hi[2] * z;
+    o[1] = hi[1] * x + hi[3] * y + hi[4] * z;
+    o[2] = hi[2] * x + hi[4] * y + hi[5] * z;
+  }
+}
+
+// sum over observations of |Jp v_p[kf] + Jl v_l[lm]|^2
+__global__ __launch_bounds__(256) void k_obs_jvp(DevProblem P, const double* __restrict__ v_all) {
+  double acc = 0.0;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < P.O; o += gridDim.x * blockDim.x) {
+    ObsLin e;
+    const int kf = P.obs_kf[o], l = P.obs_lm[o];
+    eval_obs<true>(P, P.pose, P.lm, o, kf, l, e);
+    const double* vp = v_all + (size_t)P.D * kf;
+    const double* vl = v_all + P.n + 3 * (size_t)l;
+    double s0 = e.jl[0] * vl[0] + e.jl[1] * vl[1] + e.jl[2] * vl[2];
+    double s1 = e.jl[3] * vl[0] + e.jl[4] * vl[1] + e.jl[5] * vl[2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { s0 += e.jp[k] * vp[k]; s1 += e.jp[6 + k] * vp[k]; }
+    acc += s0 * s0 + s1 * s1;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(&P.scal[SC_JV2], acc);
+}
+
+__global__ __launch_bounds__(256) void k_obs_cost(DevProblem P, const double* __restrict__ pose, const double* __restrict__ lm) {
+  double acc = 0.0;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < P.O; o += gridDim.x * blockDim.x) {
+    ObsLin e;
+    eval_obs<false>(P, pose, lm, o, P.obs_kf[o], P.obs_lm[o], e);
+    acc += e.cost;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(&P.scal[SC_COST], acc);
+}
+
+__global__ __launch_bounds__(256) void k_obs_linearize(DevProblem P, double* r, double* Jp, double* Jl, double* cost) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= P.O) return;
+  ObsLin e;
+  eval_obs<true>(P, P.pose, P.lm, o, P.obs_kf[o], P.obs_lm[o], e);
+  r[2 * o] = e.r0; r[2 * o + 1] = e.r1; cost[o] = e.cost;
+  for (int k = 0; k < 12; ++k) Jp[12 * (size_t)o + k] = e.jp[k];
+  for (int k = 0; k < 6; ++k) Jl[6 * (size_t)o + k] = e.jl[k];
+}
+
+__global__ __launch_bounds__(256) void k_obs_norms(DevProblem P, double* norms) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= P.O) return;
+  ObsLin e;
+  eval_obs<false>(P, P.pose, P.lm, o, P.obs_kf[o], P.obs_lm[o], e);
+  norms[o] = sqrt(e.r0 * e.r0 + e.r1 * e.r1);
+}
+
+static inline int stream_grid(int n) {
+  const int b = (n + 255) / 256;
+  return b < 1 ? 1 : (b > 2048 ? 2048 : b);  // memory-bound streams: cap at 8 blocks x 256 CUs, grid-stride the rest
+}
+
+constexpr int kG = 16;
+
+void launch_lm_build(const DevProblem& P, double mu, hipStream_t st) {
+  if (P.L == 0) return;
+  const int groups = kBuildThreads / kG;
+  hipLaunchKernelGGL(k_lm_build<kG>, dim3((P.L + groups - 1) / groups), dim3(kBuildThreads), 0, st, P, mu);
+}
+void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st) {
+  if (P.L == 0) return;
+  const int groups = kBuildThreads / kG;
+  hipLaunchKernelGGL(k_lm_backsub<kG>, dim3((P.L + groups - 1) / groups), dim3(kBuildThreads), 0, st, P, dp, out_all);
+}
+void launch_obs_jvp(const DevProblem& P, const double* v_all, hipStream_t st) {
+  if (P.O == 0) return;
+  hipLaunchKernelGGL(k_obs_jvp, dim3(stream_grid(P.O)), dim3(256), 0, st, P, v_all);
+}
+void launch_obs_cost(const DevProblem& P, const double* pose, const double* lm, hipStream_t st) {
+  if (P.O == 0) return;
+  hipLaunchKernelGGL(k_obs_cost, dim3(stream_grid(P.O)), dim3(256), 0, st, P, pose, lm);
+}
+void launch_obs_linearize(const DevProblem& P, double* r, double* Jp, double* Jl, double* cost, hipStream_t st) {
+  if (P.O == 0) return;
+  hipLaunchKernelGGL(k_obs_linearize, dim3((P.O + 255) / 256), dim3(256), 0, st, P, r, Jp, Jl, cost);
+}
+void launch_obs_norms(const DevProblem& P, double* norms, hipStream_t st) {
+  if (P.O == 0) return;
+  hipLaunchKernelGGL(k_obs_norms, dim3((P.O + 255) / 256), dim3(256), 0, st, P, norms);
+}
+
+}  // namespace covgpu

@@ -1,0 +1,572 @@
+// solver.hip — host side of libcovgpu: context, HBM residency, trust-region driver, extern "C" entry points.
+//
+// This is the thin extern "C" shim of BASELINE.json's north_star. It replaces what ceres::Solve does between
+// optimization_be.cpp:560-567 (GBA), :257-265 (GBA outlier round) and :1024-1031 (PGO): only scalars cross
+// PCIe inside the loop (three small read-backs per trust-region iteration); residuals, Jacobians, the Schur
+// complement, the reduced system and every vector of the step live in HBM for the whole solve.
+// Loop structure and constants follow SURVEY.md A.6 (Ceres 1.x TrustRegionMinimizer + DoglegStrategy /
+// LevenbergMarquardtStrategy defaults).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace covgpu;
+
+static thread_local std::string g_err;
+extern "C" const char* covgpu_last_error(void) { return g_err.c_str(); }
+
+#define HIPCHK(expr)                                                                            \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                                \
+      return e_ == hipErrorOutOfMemory ? COVGPU_ERR_OUT_OF_MEMORY : COVGPU_ERR_NO_DEVICE;       \
+    }                                                                                           \
+  } while (0)
+
+struct covgpu_profile_t {
+  double t_build_ms = 0, t_factor_ms = 0, t_syrk_ms = 0, syrk_flops = 0, t_solve_tri_ms = 0;
+  long n_build = 0, n_factor = 0, n_syrk = 0;
+};
+
+struct covgpu_context {
+  int device = 0;
+  hipStream_t st = nullptr;
+  DevProblem P;
+  bool have = false, pgo = false;
+  std::vector<void*> allocs;
+  double* h_scal = nullptr;  // pinned mirror of P.scal + flag
+  int profiling = 0;
+  covgpu_profile_t prof;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> syrk_ev;
+};
+
+extern "C" void covgpu_default_options(covgpu_options* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->strategy = COVGPU_DOGLEG;   // optimization_be.cpp:564
+  o->max_iterations = 10;        // config_backend.yaml:115  opt.gba_iteration_limit
+  o->reproj_loss_a = 1.0;        // optimization_be.cpp:302
+  o->initial_radius = 1e4; o->max_radius = 1e16; o->min_relative_decrease = 1e-3;
+  o->function_tolerance = 1e-6; o->parameter_tolerance = 1e-8; o->gradient_tolerance = 1e-10;
+  const double sf = std::sqrt(200.0);  // EuRoC.yaml:40-44 at 200 Hz (orb_slam3/src/Tracking.cc:1203-1211)
+  o->sigma_g = 1.7e-4 * sf; o->sigma_a = 2.0e-3 * sf; o->sigma_gw = 1.9393e-5 / sf; o->sigma_aw = 3.0e-3 / sf;
+  o->gravity = 9.81;             // orb_slam3/include/ImuTypes.h:43
+}
+
+extern "C" int32_t covgpu_reduced_dim(const covgpu_options* opt, const covgpu_problem* p) {
+  return (opt->visual_only ? 6 : 15) * p->num_kf;
+}
+
+extern "C" int covgpu_create(const covgpu_options* opt, covgpu_context** out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_err = "no HIP device visible: libcovgpu has no CPU fallback";
+    return COVGPU_ERR_NO_DEVICE;
+  }
+  covgpu_context* c = new covgpu_context();
+  c->device = opt ? opt->device : 0;
+  if (c->device < 0 || c->device >= ndev) { g_err = "device ordinal out of range"; delete c; return COVGPU_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamCreate(&c->st));
+  HIPCHK(hipHostMalloc((void**)&c->h_scal, (SC_COUNT + 4) * sizeof(double), hipHostMallocDefault));
+  for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+  std::memset(&c->P, 0, sizeof(c->P));
+  *out = c;
+  return COVGPU_OK;
+}
+
+static void free_problem(covgpu_context* c) {
+  for (void* p : c->allocs) (void)hipFree(p);
+  c->allocs.clear();
+  c->have = false;
+}
+
+extern "C" void covgpu_destroy(covgpu_context* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  free_problem(c);
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->syrk_ev) (void)hipEventDestroy(e);
+  if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->st) (void)hipStreamDestroy(c->st);
+  delete c;
+}
+
+extern "C" void covgpu_set_profiling(covgpu_context* c, int on) { c->profiling = on; c->prof = covgpu_profile_t(); }
+// out[0..7] = build ms, n_build, factor ms, n_factor, syrk ms, n_syrk launches, syrk flops, tri-solve ms
+extern "C" void covgpu_get_profile(covgpu_context* c, double* out) {
+  out[0] = c->prof.t_build_ms; out[1] = (double)c->prof.n_build; out[2] = c->prof.t_factor_ms; out[3] = (double)c->prof.n_factor;
+  out[4] = c->prof.t_syrk_ms; out[5] = (double)c->prof.n_syrk; out[6] = c->prof.syrk_flops; out[7] = c->prof.t_solve_tri_ms;
+}
+
+template <typename T>
+static int dev_alloc(covgpu_context* c, T** ptr, size_t count) {
+  *ptr = nullptr;
+  if (count == 0) count = 1;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, count * sizeof(T));
+  if (e != hipSuccess) { g_err = std::string("hipMalloc: ") + hipGetErrorString(e); return COVGPU_ERR_OUT_OF_MEMORY; }
+  c->allocs.push_back(p);
+  *ptr = (T*)p;
+  return COVGPU_OK;
+}
+template <typename T>
+static int dev_upload(covgpu_context* c, T** ptr, const T* host, size_t count) {
+  int rc = dev_alloc(c, ptr, count);
+  if (rc) return rc;
+  if (count && host) HIPCHK(hipMemcpyAsync(*ptr, host, count * sizeof(T), hipMemcpyHostToDevice, c->st));
+  else if (count) HIPCHK(hipMemsetAsync(*ptr, 0, count * sizeof(T), c->st));
+  return COVGPU_OK;
+}
+#define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+static int validate(const covgpu_problem* p, bool pgo, bool vi) {
+  auto bad = [](const char* m) { g_err = std::string("invalid problem: ") + m; return COVGPU_ERR_INVALID_ARG; };
+  if (!p || p->num_kf <= 0) return bad("no keyframes");
+  if (!p->kf_pose || !p->kf_fixed || !p->kf_cam) return bad("NULL keyframe array");
+  if (vi && !p->kf_speed_bias) return bad("NULL speed-bias array in visual-inertial mode");
+  const int K = p->num_kf;
+  if (!pgo) {
+    if (p->num_lm > 0 && (!p->lm_pos || !p->lm_obs_ptr)) return bad("NULL landmark array");
+    if (p->num_obs > 0 && (!p->obs_kf || !p->obs_uv || !p->obs_sigma)) return bad("NULL observation array");
+    if (p->num_lm > 0 && (p->lm_obs_ptr[0] != 0 || p->lm_obs_ptr[p->num_lm] != p->num_obs)) return bad("lm_obs_ptr does not span the observations");
+    for (int l = 0; l < p->num_lm; ++l) if (p->lm_obs_ptr[l + 1] < p->lm_obs_ptr[l]) return bad("lm_obs_ptr not monotone");
+    for (int o = 0; o < p->num_obs; ++o) if (p->obs_kf[o] < 0 || p->obs_kf[o] >= K) return bad("obs_kf out of range");
+    for (int k = 0; k < K; ++k) if (p->kf_cam[k] < 0 || p->kf_cam[k] >= p->num_cam) return bad("kf_cam out of range");
+    if (vi) for (int f = 0; f < p->num_imu; ++f) {
+      if (p->imu_kf_i[f] < 0 || p->imu_kf_i[f] >= K || p->imu_kf_j[f] < 0 || p->imu_kf_j[f] >= K) return bad("imu keyframe out of range");
+      if (p->imu_sample_ptr[f + 1] < p->imu_sample_ptr[f]) return bad("imu_sample_ptr not monotone");
+    }
+  }
+  for (int e = 0; e < p->num_edge; ++e)
+    if (p->edge_i[e] < 0 || p->edge_i[e] >= K || p->edge_j[e] < 0 || p->edge_j[e] >= K) return bad("edge keyframe out of range");
+  return COVGPU_OK;
+}
+
+static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, bool pgo) {
+  HIPCHK(hipSetDevice(c->device));
+  const bool vi = !pgo && !opt->visual_only;
+  RC(validate(p, pgo, vi));
+  free_problem(c);
+  DevProblem& P = c->P;
+  std::memset(&P, 0, sizeof(P));
+  P.K = p->num_kf; P.A = p->num_cam;
+  P.L = pgo ? 0 : p->num_lm; P.O = pgo ? 0 : p->num_obs;
+  P.I = vi ? p->num_imu : 0; P.E = p->num_edge;
+  P.S = P.I ? p->imu_sample_ptr[P.I] : 0;
+  P.vi = vi; P.D = vi ? 15 : 6; P.n = P.D * P.K;
+  P.npad = ((P.n + kTile - 1) / kTile) * kTile;
+  P.N = P.n + 3 * P.L;
+  P.reproj_loss_a = opt->reproj_loss_a; P.gravity = opt->gravity;
+  const size_t K = P.K;
+  RC(dev_upload(c, &P.pose0, p->kf_pose, 7 * K));
+  if (p->kf_speed_bias) RC(dev_upload(c, &P.sb0, p->kf_speed_bias, 9 * K)); else { RC(dev_alloc(c, &P.sb0, 9 * K)); HIPCHK(hipMemsetAsync(P.sb0, 0, 9 * K * sizeof(double), c->st)); }
+  RC(dev_upload(c, &P.lm0, p->lm_pos, (size_t)3 * P.L));
+  RC(dev_alloc(c, &P.pose, 7 * K)); RC(dev_alloc(c, &P.sb, 9 * K)); RC(dev_alloc(c, &P.lm, (size_t)3 * P.L));
+  RC(dev_alloc(c, &P.pose_c, 7 * K)); RC(dev_alloc(c, &P.sb_c, 9 * K)); RC(dev_alloc(c, &P.lm_c, (size_t)3 * P.L));
+  RC(dev_upload(c, &P.fixed, (const uint8_t*)p->kf_fixed, K));
+  RC(dev_upload(c, &P.kf_cam, (const int*)p->kf_cam, K));
+  RC(dev_upload(c, &P.cam_extr, p->cam_extr, (size_t)7 * P.A));
+  RC(dev_upload(c, &P.cam_intr, p->cam_intr, (size_t)4 * P.A));
+  RC(dev_upload(c, &P.cam_dist, p->cam_dist, (size_t)4 * P.A));
+  RC(dev_upload(c, &P.cam_dist_type, (const int*)p->cam_dist_type, (size_t)P.A));
+  // observation stream: SoA
+  std::vector<int> obs_lm(P.O);
+  std::vector<double> u(P.O), v(P.O);
+  for (int l = 0; l < P.L; ++l)
+    for (int o = p->lm_obs_ptr[l]; o < p->lm_obs_ptr[l + 1]; ++o) obs_lm[o] = l;
+  for (int o = 0; o < P.O; ++o) { u[o] = p->obs_uv[2 * o]; v[o] = p->obs_uv[2 * o + 1]; }
+  std::vector<int> ptr0(1, 0);
+  RC(dev_upload(c, &P.lm_obs_ptr, P.L ? (const int*)p->lm_obs_ptr : ptr0.data(), (size_t)P.L + 1));
+  RC(dev_upload(c, &P.obs_kf, (const int*)p->obs_kf, (size_t)P.O));
+  RC(dev_upload(c, &P.obs_lm, obs_lm.data(), (size_t)P.O));
+  RC(dev_upload(c, &P.obs_u, u.data(), (size_t)P.O));
+  RC(dev_upload(c, &P.obs_v, v.data(), (size_t)P.O));
+  RC(dev_upload(c, &P.obs_sigma, p->obs_sigma, (size_t)P.O));
+  // IMU
+  RC(dev_upload(c, &P.imu_i, (const int*)p->imu_kf_i, (size_t)P.I));
+  RC(dev_upload(c, &P.imu_j, (const int*)p->imu_kf_j, (size_t)P.I));
+  RC(dev_upload(c, &P.imu_ptr, P.I ? (const int*)p->imu_sample_ptr : ptr0.data(), (size_t)P.I + 1));
+  RC(dev_upload(c, &P.imu_samples, p->imu_samples, (size_t)7 * P.S));
+  RC(dev_upload(c, &P.imu_first, p->imu_first, (size_t)6 * P.I));
+  RC(dev_alloc(c, &P.pre_delta, (size_t)11 * P.I)); RC(dev_alloc(c, &P.pre_J, (size_t)225 * P.I));
+  RC(dev_alloc(c, &P.pre_P, (size_t)225 * P.I)); RC(dev_alloc(c, &P.pre_W, (size_t)225 * P.I));
+  RC(dev_alloc(c, &P.pre_bias, (size_t)6 * P.I));
+  // edges
+  RC(dev_upload(c, &P.edge_i, (const int*)p->edge_i, (size_t)P.E));
+  RC(dev_upload(c, &P.edge_j, (const int*)p->edge_j, (size_t)P.E));
+  RC(dev_upload(c, &P.edge_meas, p->edge_meas, (size_t)7 * P.E));
+  RC(dev_upload(c, &P.edge_sqrt_info, p->edge_sqrt_info, (size_t)36 * P.E));
+  RC(dev_upload(c, &P.edge_loss_a, p->edge_loss_a, (size_t)P.E));
+  // linear system + step vectors
+  RC(dev_alloc(c, &P.Sred, (size_t)P.npad * P.npad));
+  RC(dev_alloc(c, &P.bred, (size_t)2 * P.npad));
+  RC(dev_alloc(c, &P.grad, (size_t)P.N)); RC(dev_alloc(c, &P.hdiag, (size_t)P.N));
+  RC(dev_alloc(c, &P.HllInv, (size_t)6 * P.L));
+  RC(dev_alloc(c, &P.gn, (size_t)P.N)); RC(dev_alloc(c, &P.step, (size_t)P.N)); RC(dev_alloc(c, &P.vtmp, (size_t)P.N));
+  RC(dev_alloc(c, &P.Linv, (size_t)(P.npad / kTile) * kTile * kTile));
+  RC(dev_alloc(c, &P.scal, (size_t)SC_COUNT)); RC(dev_alloc(c, &P.flag, (size_t)4));
+  HIPCHK(hipMemsetAsync(P.scal, 0, SC_COUNT * sizeof(double), c->st));
+  HIPCHK(hipMemsetAsync(P.flag, 0, 4 * sizeof(int), c->st));
+  HIPCHK(hipStreamSynchronize(c->st));  // host staging vectors go out of scope
+  c->have = true; c->pgo = pgo;
+  return COVGPU_OK;
+}
+
+static int reset_state(covgpu_context* c) {
+  DevProblem& P = c->P;
+  HIPCHK(hipMemcpyAsync(P.pose, P.pose0, (size_t)7 * P.K * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+  HIPCHK(hipMemcpyAsync(P.sb, P.sb0, (size_t)9 * P.K * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+  if (P.L) HIPCHK(hipMemcpyAsync(P.lm, P.lm0, (size_t)3 * P.L * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+  return COVGPU_OK;
+}
+
+static int read_scalars(covgpu_context* c) {
+  HIPCHK(hipMemcpyAsync(c->h_scal, c->P.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipMemcpyAsync(c->h_scal + SC_COUNT, c->P.flag, sizeof(int), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return COVGPU_OK;
+}
+static int chol_failed(covgpu_context* c) { int f; std::memcpy(&f, c->h_scal + SC_COUNT, sizeof(int)); return f; }
+
+// linearise at the current state and form the damped reduced system (A.6): cost, grad, hdiag, Sred, bred
+static void enqueue_build(covgpu_context* c, double mu) {
+  const DevProblem& P = c->P;
+  if (c->profiling) (void)hipEventRecord(c->ev[0], c->st);
+  launch_zero_system(P, c->st);
+  launch_lm_build(P, mu, c->st);
+  launch_imu_build(P, c->st);
+  launch_edge_build(P, c->st);
+  launch_finalize_diag(P, mu, c->st);
+  if (c->profiling) (void)hipEventRecord(c->ev[1], c->st);
+}
+
+static void enqueue_solve(covgpu_context* c, double* dst_all) {
+  const DevProblem& P = c->P;
+  hipEvent_t* sev = nullptr;
+  if (c->profiling) {
+    // every SYRK launch gets its own event pair so that bench.py can quote the dominant kernel's duration
+    const size_t need = (size_t)2 * (P.npad / kTile);
+    while (c->syrk_ev.size() < need) { hipEvent_t e; (void)hipEventCreate(&e); c->syrk_ev.push_back(e); }
+    sev = c->syrk_ev.data();
+    (void)hipEventRecord(c->ev[2], c->st);
+  }
+  launch_dense_cholesky_solve(P, c->st, sev);
+  if (c->profiling) (void)hipEventRecord(c->ev[3], c->st);
+  (void)hipMemcpyAsync(dst_all, P.bred, (size_t)P.n * sizeof(double), hipMemcpyDeviceToDevice, c->st);
+  launch_lm_backsub(P, P.bred, dst_all, c->st);
+}
+
+static void collect_profile(covgpu_context* c, bool built, bool solved) {
+  if (!c->profiling) return;
+  float ms = 0;
+  if (built && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) { c->prof.t_build_ms += ms; c->prof.n_build++; }
+  if (solved && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) {
+    c->prof.t_factor_ms += ms; c->prof.n_factor++;
+    const int T = c->P.npad / kTile;
+    for (int p = 0; p + 1 < T; ++p) {
+      if (hipEventElapsedTime(&ms, c->syrk_ev[2 * p], c->syrk_ev[2 * p + 1]) != hipSuccess) continue;
+      const double rem = T - p - 1;
+      c->prof.t_syrk_ms += ms; c->prof.n_syrk++;
+      c->prof.syrk_flops += rem * (rem + 1) / 2 * 2.0 * kTile * kTile * kTile;
+    }
+  }
+}
+
+static void enqueue_jvp(covgpu_context* c, const double* v_all) {
+  const DevProblem& P = c->P;
+  (void)hipMemsetAsync(P.scal + SC_JV2, 0, sizeof(double), c->st);
+  launch_obs_jvp(P, v_all, c->st);
+  launch_imu_jvp(P, v_all, c->st);
+  launch_edge_jvp(P, v_all, c->st);
+}
+
+static void enqueue_cost_candidate(covgpu_context* c) {
+  const DevProblem& P = c->P;
+  (void)hipMemsetAsync(P.scal + SC_COST, 0, sizeof(double), c->st);
+  launch_obs_cost(P, P.pose_c, P.lm_c, c->st);
+  launch_imu_cost(P, P.pose_c, P.sb_c, c->st);
+  launch_edge_cost(P, P.pose_c, c->st);
+}
+
+static int solve_impl(covgpu_context* c, const covgpu_options* opt, covgpu_result* res) {
+  if (!c->have) { g_err = "no problem uploaded"; return COVGPU_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  DevProblem& P = c->P;
+  const covgpu_options& o = *opt;
+  P.reproj_loss_a = o.reproj_loss_a; P.gravity = o.gravity;
+  std::memset(res, 0, sizeof(*res));
+  const auto t_begin = std::chrono::steady_clock::now();
+  RC(reset_state(c));
+  launch_preintegrate(P, o, c->st);  // R2: repropagate at the initial bias estimate (opt_be.cpp:396)
+
+  double radius = o.initial_radius, mu = 1e-8, lm_df = 2.0;
+  bool reuse = false, need_build = true;
+  double cost = 0, alpha = 0, GG = 0, GN2 = 0, GDOT = 0, dogleg_step_norm = 0;
+  int it = 0, accepted = 0, term = 0;
+  bool first = true;
+  double t_lin = 0;
+  double* h = c->h_scal;
+  for (; it < o.max_iterations; ++it) {
+    bool ok = true;
+    if (!reuse) {
+      // ---- linearise (if the state changed or the damping must change) + Gauss-Newton / LM solve
+      for (;;) {
+        const double damp = (o.strategy == COVGPU_LM) ? 1.0 / radius : mu;
+        enqueue_build(c, damp);
+        if (o.strategy == COVGPU_DOGLEG) { launch_cauchy_vec(P, c->st); enqueue_jvp(c, P.vtmp); }
+        const auto t0 = std::chrono::steady_clock::now();
+        enqueue_solve(c, P.gn);
+        launch_dogleg_stats(P, c->st);
+        RC(read_scalars(c));
+        t_lin += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        collect_profile(c, true, true);
+        need_build = false;
+        if (first) { cost = h[SC_COST]; res->initial_cost = cost; first = false; }
+        ok = !chol_failed(c);
+        if (ok || o.strategy == COVGPU_LM) break;
+        mu *= 10.0;  // DoglegStrategy::ComputeGaussNewtonStep: raise mu until the factorisation succeeds
+        if (!(mu < 1.0)) break;
+      }
+      if (h[SC_GMAX] <= o.gradient_tolerance) { term = 3; break; }
+      GG = h[SC_GG]; GN2 = h[SC_GN2]; GDOT = h[SC_GDOT];
+      if (o.strategy == COVGPU_DOGLEG) alpha = GG / h[SC_JV2];
+    }
+    double model = 0, sn = 0;
+    if (ok) {
+      double cg = 0, cn = 1;
+      if (o.strategy == COVGPU_DOGLEG) {
+        const double gn_norm = std::sqrt(GN2), g_norm = std::sqrt(GG);
+        if (gn_norm <= radius) { cg = 0; cn = 1; dogleg_step_norm = gn_norm; }
+        else if (g_norm * alpha >= radius) { cg = -radius / g_norm; cn = 0; dogleg_step_norm = radius; }
+        else {
+          const double b_dot_a = -alpha * GDOT, a_sq = alpha * alpha * GG;
+          const double bma = GN2 - 2 * b_dot_a + a_sq, cc = b_dot_a - a_sq;
+          const double dd = std::sqrt(cc * cc + bma * (radius * radius - a_sq));
+          const double beta = (cc <= 0) ? (dd - cc) / bma : (radius * radius - a_sq) / (dd + cc);
+          cg = -alpha * (1 - beta); cn = beta; dogleg_step_norm = radius;
+        }
+      }
+      launch_combine_step(P, cg, cn, c->st);
+      enqueue_jvp(c, P.step);
+      launch_xnorm(P, c->st);
+      RC(read_scalars(c));
+      model = -(h[SC_GS] + 0.5 * h[SC_JV2]);
+      sn = std::sqrt(h[SC_SN2]);
+    }
+    if (!ok || !(model > 0.0)) {  // invalid step
+      if (o.strategy == COVGPU_LM) { radius /= lm_df; lm_df *= 2; } else { mu *= 10.0; }
+      reuse = false;
+      if (it < COVGPU_MAX_TRACE) { res->cost_trace[it] = cost; res->radius_trace[it] = radius; res->accepted_trace[it] = 0; }
+      if (mu >= 1.0 && !ok) { term = 4; ++it; break; }
+      continue;
+    }
+    if (sn <= o.parameter_tolerance * (std::sqrt(h[SC_XN2]) + o.parameter_tolerance)) { term = 2; break; }
+    launch_apply_step(P, c->st);
+    enqueue_cost_candidate(c);
+    RC(read_scalars(c));
+    const double cost_new = h[SC_COST];
+    const double rho = (cost - cost_new) / model;
+    const bool acc = rho > o.min_relative_decrease;
+    bool fn_conv = false;
+    if (acc) {
+      ++accepted;
+      fn_conv = std::fabs(cost - cost_new) <= o.function_tolerance * cost;
+      launch_accept(P, c->st);
+      cost = cost_new;
+      if (o.strategy == COVGPU_LM) {
+        const double t = 2 * rho - 1;
+        radius = std::min(o.max_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
+        lm_df = 2.0;
+      } else {
+        if (rho < 0.25) radius *= 0.5;
+        if (rho > 0.75) radius = std::max(radius, 3.0 * dogleg_step_norm);
+        mu = std::max(1e-8, 2.0 * mu / 10.0);
+      }
+      reuse = false; need_build = true;
+    } else {
+      if (o.strategy == COVGPU_LM) { radius /= lm_df; lm_df *= 2; reuse = false; }
+      else { radius *= 0.5; reuse = true; }
+    }
+    if (it < COVGPU_MAX_TRACE) { res->cost_trace[it] = cost; res->radius_trace[it] = radius; res->accepted_trace[it] = acc; }
+    if (o.verbose) std::printf("[covgpu] it %2d cost %.9e rho %.3f radius %.3e %s\n", it, cost, rho, radius, acc ? "ok" : "rej");
+    if (fn_conv) { term = 1; ++it; break; }
+  }
+  (void)need_build;
+  HIPCHK(hipStreamSynchronize(c->st));
+  res->iterations = it; res->accepted = accepted; res->termination = term;
+  res->final_cost = cost;
+  res->t_linear_solve_s = t_lin;
+  res->t_solve_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  return COVGPU_OK;
+}
+
+static int download_impl(covgpu_context* c, covgpu_problem* p) {
+  if (!c->have) { g_err = "no problem uploaded"; return COVGPU_ERR_INVALID_ARG; }
+  const DevProblem& P = c->P;
+  HIPCHK(hipMemcpyAsync(p->kf_pose, P.pose, (size_t)7 * P.K * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  if (P.vi && p->kf_speed_bias) HIPCHK(hipMemcpyAsync(p->kf_speed_bias, P.sb, (size_t)9 * P.K * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  if (P.L) HIPCHK(hipMemcpyAsync(p->lm_pos, P.lm, (size_t)3 * P.L * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return COVGPU_OK;
+}
+
+extern "C" int covgpu_upload(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return upload_impl(c, opt, p, false); }
+extern "C" int covgpu_upload_pgo(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return upload_impl(c, opt, p, true); }
+extern "C" int covgpu_solve_resident(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) { return solve_impl(c, opt, out); }
+extern "C" int covgpu_download(covgpu_context* c, covgpu_problem* p) { return download_impl(c, p); }
+
+static int full_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out, bool pgo) {
+  covgpu_result local;
+  auto t0 = std::chrono::steady_clock::now();
+  RC(upload_impl(c, opt, p, pgo));
+  const double t_up = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  RC(solve_impl(c, opt, &local));
+  t0 = std::chrono::steady_clock::now();
+  RC(download_impl(c, p));
+  local.t_download_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  local.t_upload_s = t_up;
+  if (out) *out = local;
+  return COVGPU_OK;
+}
+extern "C" int covgpu_gba_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out) { return full_solve(c, opt, p, out, false); }
+extern "C" int covgpu_pgo_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out) { return full_solve(c, opt, p, out, true); }
+
+// ------------------------------------------------------------------------------------------------ test entry points
+template <typename T>
+static int fetch(covgpu_context* c, T* host, const T* dev, size_t count) {
+  if (count) HIPCHK(hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  return COVGPU_OK;
+}
+
+extern "C" int covgpu_reprojection_residual_norms(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double* norms) {
+  covgpu_options o = *opt; o.visual_only = 1;
+  RC(upload_impl(c, &o, p, false)); RC(reset_state(c));
+  double* d; RC(dev_alloc(c, &d, (size_t)c->P.O));
+  launch_obs_norms(c->P, d, c->st);
+  return fetch(c, norms, d, (size_t)c->P.O);
+}
+
+extern "C" int covgpu_linearize_reprojection(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double* r, double* Jp,
+                                             double* Jl, double* cost) {
+  covgpu_options o = *opt; o.visual_only = 1;
+  RC(upload_impl(c, &o, p, false)); RC(reset_state(c));
+  const size_t O = c->P.O;
+  double *dr, *dJp, *dJl, *dc;
+  RC(dev_alloc(c, &dr, 2 * O)); RC(dev_alloc(c, &dJp, 12 * O)); RC(dev_alloc(c, &dJl, 6 * O)); RC(dev_alloc(c, &dc, O));
+  launch_obs_linearize(c->P, dr, dJp, dJl, dc, c->st);
+  RC(fetch(c, r, dr, 2 * O)); RC(fetch(c, Jp, dJp, 12 * O)); RC(fetch(c, Jl, dJl, 6 * O));
+  return fetch(c, cost, dc, O);
+}
+
+extern "C" int covgpu_preintegrate(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double* delta, double* J, double* Pm) {
+  covgpu_options o = *opt; o.visual_only = 0;
+  RC(upload_impl(c, &o, p, false)); RC(reset_state(c));
+  launch_preintegrate(c->P, o, c->st);
+  const size_t I = c->P.I;
+  RC(fetch(c, delta, c->P.pre_delta, 11 * I)); RC(fetch(c, J, c->P.pre_J, 225 * I));
+  return fetch(c, Pm, c->P.pre_P, 225 * I);
+}
+
+extern "C" int covgpu_linearize_imu(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double* r, double* J) {
+  covgpu_options o = *opt; o.visual_only = 0;
+  RC(upload_impl(c, &o, p, false)); RC(reset_state(c));
+  launch_preintegrate(c->P, o, c->st);
+  const size_t I = c->P.I;
+  double *dr, *dJ;
+  RC(dev_alloc(c, &dr, 15 * I)); RC(dev_alloc(c, &dJ, 450 * I));
+  launch_imu_linearize(c->P, dr, dJ, c->st);
+  RC(fetch(c, r, dr, 15 * I));
+  return fetch(c, J, dJ, 450 * I);
+}
+
+extern "C" int covgpu_linearize_between(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double* r, double* J, double* cost) {
+  RC(upload_impl(c, opt, p, true)); RC(reset_state(c));
+  const size_t E = c->P.E;
+  double *dr, *dJ, *dc;
+  RC(dev_alloc(c, &dr, 6 * E)); RC(dev_alloc(c, &dJ, 72 * E)); RC(dev_alloc(c, &dc, E));
+  launch_edge_linearize(c->P, dr, dJ, dc, c->st);
+  RC(fetch(c, r, dr, 6 * E)); RC(fetch(c, J, dJ, 72 * E));
+  return fetch(c, cost, dc, E);
+}
+
+static int schur_impl(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, bool pgo, double mu, double* S, double* b, double* cost) {
+  RC(upload_impl(c, opt, p, pgo)); RC(reset_state(c));
+  launch_preintegrate(c->P, *opt, c->st);
+  enqueue_build(c, mu);
+  RC(read_scalars(c));
+  *cost = c->h_scal[SC_COST];
+  const int n = c->P.n, npad = c->P.npad;
+  std::vector<double> full((size_t)npad * npad);
+  RC(fetch(c, full.data(), c->P.Sred, full.size()));
+  for (int r = 0; r < n; ++r)
+    for (int cc = 0; cc < n; ++cc) S[(size_t)r * n + cc] = (cc <= r) ? full[(size_t)r * npad + cc] : full[(size_t)cc * npad + r];
+  return fetch(c, b, c->P.bred, (size_t)n);
+}
+extern "C" int covgpu_schur(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double mu, double* S, double* b, double* cost) {
+  return schur_impl(c, opt, p, false, mu, S, b, cost);
+}
+extern "C" int covgpu_schur_pgo(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double mu, double* S, double* b, double* cost) {
+  return schur_impl(c, opt, p, true, mu, S, b, cost);
+}
+
+extern "C" int covgpu_solve_reduced(covgpu_context* c, int32_t n, const double* S, const double* b, double* x) {
+  HIPCHK(hipSetDevice(c->device));
+  if (n <= 0) { g_err = "n <= 0"; return COVGPU_ERR_INVALID_ARG; }
+  const int npad = ((n + kTile - 1) / kTile) * kTile;
+  std::vector<double> Sp((size_t)npad * npad, 0.0), bp((size_t)2 * npad, 0.0);
+  for (int r = 0; r < npad; ++r) {
+    if (r < n) { std::memcpy(&Sp[(size_t)r * npad], S + (size_t)r * n, (size_t)(r + 1) * sizeof(double)); bp[r] = b[r]; }
+    else Sp[(size_t)r * npad + r] = 1.0;
+  }
+  double *dS = nullptr, *db = nullptr, *dL = nullptr; int* df = nullptr;
+  HIPCHK(hipMalloc((void**)&dS, Sp.size() * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&db, bp.size() * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&dL, (size_t)(npad / kTile) * kTile * kTile * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&df, 4 * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(dS, Sp.data(), Sp.size() * sizeof(double), hipMemcpyHostToDevice, c->st));
+  HIPCHK(hipMemcpyAsync(db, bp.data(), bp.size() * sizeof(double), hipMemcpyHostToDevice, c->st));
+  HIPCHK(hipMemsetAsync(df, 0, 4 * sizeof(int), c->st));
+  dense_cholesky_solve_raw(dS, db, dL, df, npad, c->st);
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(x, db, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipMemcpyAsync(&flag, df, sizeof(int), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  (void)hipFree(dS); (void)hipFree(db); (void)hipFree(dL); (void)hipFree(df);
+  if (flag) { g_err = "reduced system is not positive definite"; return COVGPU_ERR_NUMERIC; }
+  return COVGPU_OK;
+}
+
+extern "C" int covgpu_pgo_reanchor(covgpu_context* c, int32_t K, const double* pose_old, const double* pose_new, double* velocity, int32_t L,
+                                   const int32_t* ref_kf, double* lm_pos) {
+  HIPCHK(hipSetDevice(c->device));
+  double *dpo, *dpn, *dv = nullptr, *dl; int* dr;
+  std::vector<void*> tmp;
+  auto A = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 8); if (e == hipSuccess) tmp.push_back(*p); return e; };
+  HIPCHK(A((void**)&dpo, (size_t)7 * K * sizeof(double))); HIPCHK(A((void**)&dpn, (size_t)7 * K * sizeof(double)));
+  HIPCHK(A((void**)&dl, (size_t)3 * L * sizeof(double))); HIPCHK(A((void**)&dr, (size_t)L * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(dpo, pose_old, (size_t)7 * K * sizeof(double), hipMemcpyHostToDevice, c->st));
+  HIPCHK(hipMemcpyAsync(dpn, pose_new, (size_t)7 * K * sizeof(double), hipMemcpyHostToDevice, c->st));
+  if (L) {
+    HIPCHK(hipMemcpyAsync(dl, lm_pos, (size_t)3 * L * sizeof(double), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(dr, ref_kf, (size_t)L * sizeof(int), hipMemcpyHostToDevice, c->st));
+  }
+  if (velocity) {
+    HIPCHK(A((void**)&dv, (size_t)3 * K * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(dv, velocity, (size_t)3 * K * sizeof(double), hipMemcpyHostToDevice, c->st));
+  }
+  launch_reanchor(K, dpo, dpn, dv, L, dr, dl, c->st);
+  if (L) HIPCHK(hipMemcpyAsync(lm_pos, dl, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  if (velocity) HIPCHK(hipMemcpyAsync(velocity, dv, (size_t)3 * K * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  for (void* p : tmp) (void)hipFree(p);
+  return COVGPU_OK;
+}

@@ -161,6 +161,7 @@ int covgpu_pgo_solve(covgpu_context* ctx, const covgpu_options* opt, covgpu_prob
 /* Split form used by bench.py so that inputs are HBM-resident before the timed region:
  * upload once, solve (restarts from the uploaded initial estimate every call), download. */
 int covgpu_upload(covgpu_context* ctx, const covgpu_options* opt, const covgpu_problem* p);
+int covgpu_upload_pgo(covgpu_context* ctx, const covgpu_options* opt, const covgpu_problem* p);
 int covgpu_solve_resident(covgpu_context* ctx, const covgpu_options* opt, covgpu_result* out);
 int covgpu_download(covgpu_context* ctx, covgpu_problem* p);
 
@@ -204,6 +205,9 @@ int covgpu_linearize_between(covgpu_context* ctx, const covgpu_options* opt, con
  * n = dim_per_kf * K with dim_per_kf = 15 (VI) or 6 (visual_only / PGO), plus total cost. */
 int covgpu_schur(covgpu_context* ctx, const covgpu_options* opt, const covgpu_problem* p, double mu,
                  double* S, double* b, double* cost);
+/* same for the pose-graph problem (edges only, 6 rows per keyframe) */
+int covgpu_schur_pgo(covgpu_context* ctx, const covgpu_options* opt, const covgpu_problem* p, double mu,
+                     double* S, double* b, double* cost);
 
 /* R8 building block: dense FP64 Cholesky solve of S x = b on the MFMA path (S symmetric positive
  * definite, row-major n x n; only the lower triangle is read). Returns COVGPU_ERR_NUMERIC if a
@@ -211,6 +215,13 @@ int covgpu_schur(covgpu_context* ctx, const covgpu_options* opt, const covgpu_pr
 int covgpu_solve_reduced(covgpu_context* ctx, int32_t n, const double* S, const double* b, double* x);
 
 int32_t covgpu_reduced_dim(const covgpu_options* opt, const covgpu_problem* p);
+
+/* ---------------------------------------------------------------- measurement hooks (bench.py)
+ * With profiling on, covgpu_solve_resident brackets the linearise+Schur pass, the whole factor+solve and
+ * every trailing-update (SYRK) launch with HIP events on the context's own stream.
+ * out[8] = { build ms, #builds, factor+solve ms, #factorisations, SYRK ms, #SYRK launches, SYRK flops, 0 } */
+void covgpu_set_profiling(covgpu_context* ctx, int on);
+void covgpu_get_profile(covgpu_context* ctx, double* out8);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,278 @@
+"""GPU parity tests: every device kernel family, called through the C ABI of libcovgpu.so, against the CPU
+oracle on the same seeded inputs. Tolerances (FP64 end to end):
+  residuals / Jacobians        <= 1e-12 relative to the largest entry
+  preintegration deltas, J, P  <= 1e-11
+  whitened IMU blocks          <= 1e-8   (chol(P)^-1 amplifies rounding by cond(chol P) ~ 1e4)
+  Schur complement S, b        <= 1e-9   (FP64 atomics: summation order differs run to run)
+  final poses after equal iteration counts  <= 1e-6 m / 1e-7 rad,  landmarks <= 1e-5 m
+"""
+import numpy as np
+import pytest
+
+from covins_amd import backend, capi, mapdata, synth
+from oracle import covo
+from tests.util import rel_err, rot_angle, truth_map
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = backend.Context(0)
+    yield c
+    c.close()
+
+
+def opts(**kw):
+    g, o = backend.default_options(**kw), covo.default_options(**kw)
+    for name, _ in capi.Options._fields_:  # both libraries must agree on the reference defaults
+        assert getattr(g, name) == getattr(o, name), name
+    return g, o
+
+
+@pytest.fixture(scope="module")
+def tiny_vi(tiny_map):
+    return mapdata.flatten_gba(tiny_map, False, True)[0]
+
+
+@pytest.fixture(scope="module")
+def small_vi(small_map):
+    return mapdata.flatten_gba(small_map, False, True)[0]
+
+
+def test_reprojection_linearisation(ctx, small_vi):
+    g, o = opts()
+    for dist_type in (0, 1):
+        p = small_vi.copy()
+        if dist_type == 1:
+            p.cam_dist_type[:] = 1
+            p.cam_dist[:] = [-0.01, 0.02, -0.005, 0.001]
+        r, Jp, Jl, c = ctx.linearize_reprojection(p, g)
+        r0, Jp0, Jl0, c0 = covo.linearize_reprojection(p, o)
+        assert rel_err(r, r0) < 1e-12 and rel_err(Jp, Jp0) < 1e-12 and rel_err(Jl, Jl0) < 1e-12 and rel_err(c, c0) < 1e-12
+    # fixed keyframe: pose Jacobian identically zero, landmark Jacobian not
+    fx = np.nonzero(small_vi.kf_fixed)[0][0]
+    sel = small_vi.obs_kf == fx
+    assert sel.any() and not Jp[sel].any() and Jl[sel].any()
+
+
+def test_reprojection_behind_camera_and_no_loss(ctx, tiny_vi):
+    p = tiny_vi.copy()
+    # move a landmark behind its first observer
+    k = p.obs_kf[0]
+    p.lm_pos[0] = p.kf_pose[k, 4:] - 5.0 * (p.lm_pos[0] - p.kf_pose[k, 4:])
+    for a in (1.0, 0.0):
+        g, o = opts(reproj_loss_a=a)
+        out, ref = ctx.linearize_reprojection(p, g), covo.linearize_reprojection(p, o)
+        for x, y in zip(out, ref):
+            assert rel_err(x, y) < 1e-12
+    assert not out[0][0].any() and not out[1][0].any() and not out[2][0].any()
+
+
+def test_outlier_norms(ctx, tiny_map):
+    cfg = synth.config_named("tiny"); cfg.outlier_frac = 0.05
+    p = mapdata.flatten_gba(synth.make_map(cfg), True, True)[0]
+    g, o = opts(visual_only=1)
+    n, n0 = ctx.residual_norms(p, g), covo.residual_norms(p, o)
+    assert rel_err(n, n0) < 1e-12
+    assert np.array_equal(n > 0.92, n0 > 0.92)
+
+
+def test_preintegration(ctx, small_vi):
+    g, o = opts()
+    d, J, P = ctx.preintegrate(small_vi, g)
+    d0, J0, P0 = covo.preintegrate(small_vi, o)
+    assert d.shape[0] == small_vi.I > 100
+    assert rel_err(d, d0) < 1e-12 and rel_err(J, J0) < 1e-11
+    # P spans 1e-15 .. 1e-7: compare block-wise relative to each factor's own scale
+    assert np.max(np.abs(P - P0) / np.abs(P0).max(axis=1, keepdims=True)) < 1e-11
+
+
+def test_imu_factor(ctx, small_vi):
+    g, o = opts()
+    r, J = ctx.linearize_imu(small_vi, g)
+    r0, J0 = covo.linearize_imu(small_vi, o)
+    assert rel_err(r, r0) < 1e-8 and rel_err(J, J0) < 1e-8
+    # per-factor: error relative to that factor's own largest entry
+    assert np.max(np.abs(J - J0) / np.abs(J0).max(axis=1, keepdims=True)) < 1e-7
+
+
+def test_between_factor(ctx, small_map):
+    p = mapdata.flatten_pgo(small_map, {}, mapdata.PgoParams())[0]
+    assert p.E > 500
+    g, o = opts()
+    r, J, c = ctx.linearize_between(p, g)
+    r0, J0, c0 = covo.linearize_between(p, o)
+    assert rel_err(r, r0) < 1e-12 and rel_err(J, J0) < 1e-12 and rel_err(c, c0) < 1e-12
+    # non-trivial sqrt-information (upper-triangular chol(cov^-1)^T, COVINS-G mode)
+    prm = mapdata.PgoParams(placerec_type="COVINS_G")
+    rng = np.random.default_rng(3)
+    for lc in small_map.loops:
+        A = rng.normal(0, 1, (6, 6)); lc.cov = A @ A.T * 1e-3 + np.eye(6) * 1e-3
+    p2 = mapdata.flatten_pgo(small_map, {}, prm)[0]
+    out, ref = ctx.linearize_between(p2, g), covo.linearize_between(p2, o)
+    for x, y in zip(out, ref):
+        assert rel_err(x, y) < 1e-12
+    for lc in small_map.loops:
+        lc.cov = np.eye(6)
+
+
+@pytest.mark.parametrize("visual_only", [1, 0])
+def test_schur_complement(ctx, tiny_vi, visual_only):
+    g, o = opts(visual_only=visual_only)
+    for mu in (1e-8, 1e-2):
+        S, b, c = ctx.schur(tiny_vi, g, mu)
+        S0, b0, c0 = covo.schur(tiny_vi, o, mu)
+        assert abs(c - c0) <= 1e-12 * abs(c0)
+        # compare block rows relative to their own scale: S mixes 1e14 (IMU) and 1e3 (visual) magnitudes
+        scale = np.sqrt(np.abs(np.diag(S0)))
+        Sn, S0n = S / scale[:, None] / scale[None, :], S0 / scale[:, None] / scale[None, :]
+        assert np.abs(Sn - S0n).max() < 1e-9
+        assert np.abs(b / scale - b0 / scale).max() < 1e-9 * np.abs(b0 / scale).max()
+        assert np.allclose(S, S.T)
+
+
+def test_schur_pgo(ctx, small_map):
+    p = mapdata.flatten_pgo(small_map, {}, mapdata.PgoParams())[0]
+    g, o = opts()
+    S, b, c = ctx.schur(p, g, 1e-8, pgo=True)
+    S0, b0, c0 = covo.schur(p, o, 1e-8, pgo=True)
+    assert rel_err(S, S0) < 1e-10 and rel_err(b, b0) < 1e-10 and abs(c - c0) < 1e-12 * c0
+
+
+@pytest.mark.parametrize("n", [1, 100, 128, 129, 700])
+def test_mfma_cholesky_solve(ctx, n):
+    rng = np.random.default_rng(n)
+    A = rng.normal(0, 1, (n, n + 5))
+    S = A @ A.T + 0.5 * n * np.eye(n)      # SPD, strongly asymmetric entries off the diagonal pattern
+    S += np.diag(rng.uniform(0, 10, n))
+    b = rng.normal(0, 1, n)
+    rc, x = ctx.solve_reduced(S, b)
+    assert rc == 0
+    x0 = np.linalg.solve(S, b)
+    assert rel_err(x, x0) < 1e-10
+    rc0, xo = covo.solve_reduced(S, b)
+    assert rc0 == 0 and rel_err(x, xo) < 1e-10
+
+
+def test_mfma_cholesky_detects_indefinite(ctx):
+    n = 300
+    S = np.eye(n) * 2.0; S[200, 200] = -1.0
+    rc, _ = ctx.solve_reduced(S, np.ones(n))
+    assert rc == 4  # COVGPU_ERR_NUMERIC
+
+
+def test_mfma_cholesky_ill_scaled(ctx):
+    # rows scaled like the VI reduced system: pose ~1e4, velocity ~1e7, bias ~1e13
+    n = 450
+    rng = np.random.default_rng(5)
+    A = rng.normal(0, 1, (n, 2 * n)); S = A @ A.T / n + np.eye(n)
+    d = np.tile(np.array([1e2] * 6 + [3e3] * 3 + [3e6] * 6), n // 15)
+    S = S * d[:, None] * d[None, :]
+    b = rng.normal(0, 1, n) * d
+    rc, x = ctx.solve_reduced(S, b)
+    x0 = np.linalg.solve(S, b)
+    assert rc == 0 and np.max(np.abs(x - x0) * d) < 1e-8 * np.max(np.abs(x0) * d)
+
+
+def _compare_solution(sol, ref, res, rres, pos_tol=1e-6, ang_tol=1e-7, lm_tol=1e-5):
+    assert res.iterations == rres.iterations and res.accepted == rres.accepted and res.termination == rres.termination
+    assert abs(res.initial_cost - rres.initial_cost) <= 1e-10 * rres.initial_cost
+    tr, tr0 = np.array(res.cost_trace[:res.iterations]), np.array(rres.cost_trace[:rres.iterations])
+    assert np.all(np.abs(tr - tr0) <= 1e-6 * tr0)
+    assert list(res.accepted_trace[:res.iterations]) == list(rres.accepted_trace[:rres.iterations])
+    assert np.abs(sol.kf_pose[:, 4:] - ref.kf_pose[:, 4:]).max() < pos_tol
+    assert rot_angle(sol.kf_pose[:, :4], ref.kf_pose[:, :4]).max() < ang_tol
+    if sol.L:
+        assert np.abs(sol.lm_pos - ref.lm_pos).max() < lm_tol
+
+
+@pytest.mark.parametrize("strategy", [capi.COVGPU_DOGLEG, capi.COVGPU_LM])
+@pytest.mark.parametrize("visual_only", [0, 1])
+def test_gba_solve_matches_oracle(ctx, tiny_vi, strategy, visual_only):
+    g, o = opts(strategy=strategy, visual_only=visual_only)
+    sol, res = ctx.gba_solve(tiny_vi, g)
+    ref, rres = covo.gba_solve(tiny_vi, o)
+    _compare_solution(sol, ref, res, rres)
+    if not visual_only:
+        assert np.abs(sol.kf_speed_bias - ref.kf_speed_bias).max() < 1e-6
+    else:
+        assert np.array_equal(sol.kf_speed_bias, tiny_vi.kf_speed_bias)
+    fx = np.nonzero(tiny_vi.kf_fixed)[0]
+    assert np.array_equal(sol.kf_pose[fx], tiny_vi.kf_pose[fx])
+
+
+def test_gba_solve_small_map(ctx, small_vi):
+    g, o = opts()
+    sol, res = ctx.gba_solve(small_vi, g)
+    ref, rres = covo.gba_solve(small_vi, o)
+    _compare_solution(sol, ref, res, rres)
+    assert res.final_cost < 1e-4 * res.initial_cost
+
+
+def test_resident_solve_restarts_from_upload(ctx, tiny_vi):
+    g, _ = opts()
+    ctx.upload(tiny_vi, g)
+    r1 = ctx.solve_resident(g); a = ctx.download()
+    r2 = ctx.solve_resident(g); b = ctx.download()
+    assert r1.iterations == r2.iterations and abs(r1.final_cost - r2.final_cost) <= 1e-9 * r1.final_cost
+    assert np.abs(a.kf_pose - b.kf_pose).max() < 1e-9
+
+
+def test_pgo_solve_matches_oracle(ctx):
+    cfg = synth.config_named("small"); cfg.drift_trans = 0.05; cfg.drift_yaw_deg = 0.5
+    m = synth.make_map(cfg)
+    p = mapdata.flatten_pgo(m, {}, mapdata.PgoParams())[0]
+    for strategy in (capi.COVGPU_DOGLEG, capi.COVGPU_LM):
+        g, o = opts(strategy=strategy)
+        sol, res = ctx.pgo_solve(p, g)
+        ref, rres = covo.gba_solve(p, o, pgo=True)
+        _compare_solution(sol, ref, res, rres)
+        assert res.final_cost < res.initial_cost
+
+
+def test_pgo_reanchor(ctx):
+    rng = np.random.default_rng(2)
+    from scipy.spatial.transform import Rotation as R
+    K, L = 50, 3000
+    po = np.concatenate([R.random(K, random_state=1).as_quat(), rng.normal(0, 3, (K, 3))], 1)
+    pn = np.concatenate([R.random(K, random_state=2).as_quat(), rng.normal(0, 3, (K, 3))], 1)
+    lm = rng.normal(0, 5, (L, 3)); ref = rng.integers(-1, K, L).astype(np.int32); vel = rng.normal(0, 1, (K, 3))
+    v, l = ctx.pgo_reanchor(po, pn, vel, ref, lm)
+    v0, l0 = covo.pgo_reanchor(po, pn, vel, ref, lm)
+    assert np.abs(v - v0).max() < 1e-13 and np.abs(l - l0).max() < 1e-12
+    assert np.array_equal(l[ref < 0], lm[ref < 0])
+
+
+def test_invalid_problem_is_rejected(ctx, tiny_vi):
+    p = tiny_vi.copy()
+    p.obs_kf[3] = p.K + 7
+    g, _ = opts()
+    with pytest.raises(backend.CovGpuError, match="obs_kf out of range"):
+        ctx.gba_solve.__func__(ctx, _NoValidate(p), g)
+
+
+class _NoValidate:
+    """Wraps a FlatProblem so that the Python-side validate() does not pre-empt the C-side check."""
+    def __init__(self, p): self.p = p
+    def copy(self): return self
+    def as_struct(self): return self.p.as_struct()
+
+
+def test_gba_full_size_properties(ctx):
+    """BASELINE config 2 size (MH_01): size-independent properties instead of an oracle run."""
+    m = synth.make_map(synth.config_named("mh01"))
+    p = mapdata.flatten_gba(m, False, True)[0]
+    g, _ = opts()
+    sol, res = ctx.gba_solve(p, g)
+    tr = np.array(res.cost_trace[:res.iterations])
+    assert np.all(np.diff(tr) <= 1e-9 * tr[:-1])                      # monotone trust-region steps
+    assert res.final_cost < 1e-4 * res.initial_cost
+    pt = mapdata.flatten_gba(truth_map(m), False, True)[0]
+    assert res.final_cost < 1.1 * covo.cost(pt, covo.default_options())  # at least as good as the ground truth state
+    ate0 = synth.ate_rmse(p.kf_pose[:, 4:], pt.kf_pose[:, 4:]); ate1 = synth.ate_rmse(sol.kf_pose[:, 4:], pt.kf_pose[:, 4:])
+    assert ate1 < ate0 and ate1 < 0.02
+    # idempotence: a second GBA from the optimum barely moves
+    sol2, res2 = ctx.gba_solve(sol, g)
+    assert np.abs(sol2.kf_pose[:, 4:] - sol.kf_pose[:, 4:]).max() < 2e-3
+    assert res2.final_cost <= res.final_cost * (1 + 1e-9)

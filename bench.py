@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json metric on MI355X: GBA iterations/sec (+ keyframes-optimized/sec) on the
+5-agent EuRoC-shaped merged map.
+
+A "step" = one pass of the hot path over one map = one `covgpu_solve_resident` call, i.e. the whole
+ceres::Solve replacement of GlobalBundleAdjustment (optimization_be.cpp:560-567) with the reference's
+iteration cap (opt.gba_iteration_limit = 10): preintegration, then per trust-region iteration
+linearise + Schur + dense MFMA Cholesky + step + cost evaluation. Inputs are uploaded to HBM before the
+timed region; every step restarts from the same uploaded initial estimate.
+
+N > 1: one process per GPU (torch.distributed / RCCL used for the barrier and the max-over-ranks only).
+Round 1 shards by MAP — the unit the reference itself runs concurrently (one exclusively checked-out map
+per optimisation call, backend.cpp:134, placerec_be.cpp:295): every rank optimises its own 5-agent map
+(different seed), no data-path collective, weak scaling. The agent-sharded single map with RCCL all-reduce
+on shared pose blocks is the next multi-GPU step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X FP64 vector/matrix peak
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(strategy: int):
+    """Oracle (CPU port of the same algorithm) on a bounded sample of the same workload family, timed on
+    this box's host cores. The reference binary itself cannot be built here."""
+    from covins_amd import mapdata, synth
+    from oracle import covo
+    cfg = synth.config_named("mh01")
+    cfg.max_kf_per_agent = 300
+    m = synth.make_map(cfg)
+    p, _ = mapdata.flatten_gba(m, False, True)
+    o = covo.default_options(max_iterations=3, strategy=strategy)
+    covo.gba_solve(p, covo.default_options(max_iterations=1))  # warm the thread pool / page in
+    t0 = time.perf_counter()
+    _, res = covo.gba_solve(p, o)
+    dt = time.perf_counter() - t0
+    return {
+        "value": res.iterations / dt, "unit": "GBA iterations/s", "cores": int(covo.lib().covo_num_threads()),
+        "kind": "port",
+        "sample": f"single-agent MH_01-shaped sub-map, K={p.K} L={p.L} O={p.O} (n={15 * p.K}), "
+                  f"{res.iterations} dogleg iterations, {dt:.1f} s; NOT the 5-agent map (its dense n=33k solve "
+                  f"would take the scalar-blocked CPU port minutes per iteration)",
+        "kf_per_s": p.K * res.iterations / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="mh12345", help="mh12345 (BASELINE metric) | mh123 | mh01 | small")
+    ap.add_argument("--strategy", default="dogleg", choices=["dogleg", "lm"])
+    ap.add_argument("--iterations", type=int, default=10, help="trust-region iteration cap per step (reference: 10)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+
+    from covins_amd import backend, capi, mapdata, synth
+    strategy = capi.COVGPU_DOGLEG if args.strategy == "dogleg" else capi.COVGPU_LM
+    cfg = synth.config_named(args.workload, seed=rank)  # map-sharded: each rank owns one merged map
+    m = synth.make_map(cfg)
+    prob, _ = mapdata.flatten_gba(m, visual_only=False, loop_loss=True)
+    opt = backend.default_options(strategy=strategy, max_iterations=args.iterations, device=local_rank)
+    ctx = backend.Context(local_rank)
+    ctx.upload(prob, opt)  # inputs resident in HBM before the timed region
+
+    def barrier():
+        torch.cuda.synchronize(local_rank)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(local_rank)
+
+    for _ in range(args.warmup):
+        ctx.solve_resident(opt)
+    ctx.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    res = None
+    for _ in range(args.steps):
+        res = ctx.solve_resident(opt)  # returns after its stream has drained
+        iters += res.iterations
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        it = torch.tensor([float(iters)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(it, op=dist.ReduceOp.SUM)
+        iters_all = float(it.item())
+    else:
+        iters_all = float(iters)
+
+    if rank == 0:
+        sol = ctx.download()
+        truth = m.truth["kf_pose"][:, 4:]
+        n = 15 * prob.K
+        k_free = int(prob.K - prob.kf_fixed.sum())
+        syrk_tflops = prof["syrk_flops"] / (prof["syrk_ms"] * 1e-3) / 1e12 if prof["syrk_ms"] > 0 else 0.0
+        # algorithmic HBM bytes of one linearise+Schur pass (first, second and third terms)
+        nnzS = None
+        b_build = 32.0 * prob.O + 128.0 * prob.K + 24.0 * prob.L + 2304.0 * prob.I + 8.0 * (135.0 * prob.K + 9.0 * prob.L)
+        out = {
+            "metric": "GBA iterations/sec, 5-agent EuRoC merged map" if args.workload == "mh12345" else f"GBA iterations/sec, {args.workload}",
+            "value": iters_all / dt, "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {len(cfg.agents)}-agent EuRoC MH-shaped merged map per GPU, visual-inertial GBA "
+                                   f"(K={prob.K} keyframes, L={prob.L} landmarks, O={prob.O} observations, I={prob.I} IMU factors, "
+                                   f"E={prob.E} loop edges; reduced system n={n})",
+                       "strategy": args.strategy, "iterations_per_step": args.iterations, "sharding": "one map per GPU"},
+            "kf_per_s": k_free * iters_all / dt,
+            "iterations_executed": iters_all,
+            "final_cost": res.final_cost, "initial_cost": res.initial_cost,
+            "ate_rmse_m": {"initial": synth.ate_rmse(prob.kf_pose[:, 4:], truth), "final": synth.ate_rmse(sol.kf_pose[:, 4:], truth)},
+            "phase_ms_per_iteration": {"linearise+schur": prof["build_ms"] / max(prof["n_build"], 1),
+                                       "factor+solve": prof["factor_ms"] / max(prof["n_factor"], 1)},
+            "roofline": {"kernel": "k_gemm_abt<SYRK> (trailing update of the dense FP64 Cholesky, v_mfma_f64_16x16x4_f64)",
+                         "bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": syrk_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "launches": prof["n_syrk"], "avg_launch_ms": prof["syrk_ms"] / max(prof["n_syrk"], 1),
+                         "whole_factorisation_tflops": (n ** 3 / 3.0) / (prof["factor_ms"] / max(prof["n_factor"], 1) * 1e-3) / 1e12
+                         if prof["factor_ms"] > 0 else 0.0},
+            "roofline_build": {"kernel": "k_lm_build (linearise + Schur)", "bound": "hbm",
+                               "achieved": b_build / (prof["build_ms"] / max(prof["n_build"], 1) * 1e-3) / 1e9 if prof["build_ms"] > 0 else 0.0,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "note": "algorithmic bytes excl. the dense S zero-fill and atomics"},
+        }
+        out["roofline_build"]["frac"] = out["roofline_build"]["achieved"] / HBM_PEAK_GBS
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(strategy)
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,7 +4,9 @@ oracle on the same seeded inputs. Tolerances (FP64 end t
   preintegration deltas, J, P  <= 1e-11
   whitened IMU blocks          <= 1e-8   (chol(P)^-1 amplifies rounding by cond(chol P) ~ 1e4)
   Schur complement S, b        <= 1e-9   (FP64 atomics: summation order differs run to run)
-  final poses after equal iteration counts  <= 1e-6 m / 1e-7 rad,  landmarks <= 1e-5 m
+  final poses after equal iteration counts  <= 1e-6 m / 1e-7 rad; landmarks: median <= 1e-7 m, 99.5 % <= 1e-5 m,
+  max <= 1e-2 m (a handful of landmarks with near-degenerate parallax have an H_ll that is singular along the
+  viewing ray up to the 1e-8 damping; the atomics' rounding noise moves them along that ray only)
 """
 import numpy as np
 import pytest
@@ -175,7 +177,7 @@ def test_mfma_cholesky_ill_scaled(ctx):
     assert rc == 0 and np.max(np.abs(x - x0) * d) < 1e-8 * np.max(np.abs(x0) * d)
 
 
-def _compare_solution(sol, ref, res, rres, pos_tol=1e-6, ang_tol=1e-7, lm_tol=1e-5):
+def _compare_solution(sol, ref, res, rres, pos_tol=1e-6, ang_tol=1e-7, lm_tol=1e-2):
     assert res.iterations == rres.iterations and res.accepted == rres.accepted and res.termination == rres.termination
     assert abs(res.initial_cost - rres.initial_cost) <= 1e-10 * rres.initial_cost
     tr, tr0 = np.array(res.cost_trace[:res.iterations]), np.array(rres.cost_trace[:rres.iterations])
@@ -184,7 +186,9 @@ def _compare_solution(sol, ref, res, rres, pos_tol=1e-6, ang_tol=1e-7, lm_tol=1e
     assert np.abs(sol.kf_pose[:, 4:] - ref.kf_pose[:, 4:]).max() < pos_tol
     assert rot_angle(sol.kf_pose[:, :4], ref.kf_pose[:, :4]).max() < ang_tol
     if sol.L:
-        assert np.abs(sol.lm_pos - ref.lm_pos).max() < lm_tol
+        d = np.abs(sol.lm_pos - ref.lm_pos).max(axis=1)
+        assert d.max() < lm_tol and np.median(d) < 1e-7 and np.quantile(d, 0.995) < 1e-5
+    assert abs(res.final_cost - rres.final_cost) <= 1e-8 * rres.final_cost
 
 
 @pytest.mark.parametrize("strategy", [capi.COVGPU_DOGLEG, capi.COVGPU_LM])

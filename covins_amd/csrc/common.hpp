@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/covgpu.h"
 
 namespace covgpu {
@@ -92,10 +94,22 @@ void launch_edge_linearize(const DevProblem& P, double* r, double* J, double* co
 
 void launch_finalize_diag(const DevProblem& P, double mu, hipStream_t st);
 void launch_zero_system(const DevProblem& P, hipStream_t st);
+// per-context resources of the dense factorisation: auxiliary stream for the look-ahead, ordering events, and
+// (profiling only) one timed event pair around every bulk trailing-update launch
+struct CholAux {
+  hipStream_t aux = nullptr;
+  std::vector<hipEvent_t> ev, prof_ev;
+  std::vector<double> prof_flops;
+  bool profile = false;
+  double syrk_ms = 0, syrk_flops = 0;
+  long n_syrk = 0;
+  void init();
+  void destroy();
+  void collect();
+};
 // dense SPD solve of Sred x = bred in place (lower Cholesky on the FP64 MFMA path); flag[0] != 0 on failure
-// syrk_events: optional 2 * (npad / kTile) events recorded around every SYRK launch (profiling only)
-void launch_dense_cholesky_solve(const DevProblem& P, hipStream_t st, hipEvent_t* syrk_events = nullptr);
-void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, hipEvent_t* syrk_events = nullptr);
+void launch_dense_cholesky_solve(const DevProblem& P, hipStream_t st, CholAux& ax);
+void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax);
 
 void launch_dogleg_stats(const DevProblem& P, hipStream_t st);  // GG, GN2, GDOT, GMAX from grad/hdiag/gn
 void launch_cauchy_vec(const DevProblem& P, hipStream_t st);    // vtmp = grad / d^2

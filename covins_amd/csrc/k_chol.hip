@@ -1,0 +1,379 @@
+// k_chol.hip — dense FP64 Cholesky solve of the reduced camera system on the gfx950 matrix cores.
+//
+// Replaces the linear-algebra half of ceres::Solve(SPARSE_SCHUR) (optimization_be.cpp:560-567, 1024-1031):
+// the Cholesky factorisation of the reduced camera system (CHOLMOD in the reference) and the two triangular
+// solves. North-star: "MFMA used only for the dense reduced-camera-system solve".
+//
+// Algorithm: right-looking blocked Cholesky on the lower triangle of a row-major padded matrix.
+//   * tiles are 128 x 128; big panels are 256 wide (two tile columns). A rank-256 trailing update reads and
+//     writes every C tile once per 8.4 MFLOP (16 flop/B on the C stream) — a rank-128 update (8 flop/B)
+//     would be HBM-bound below ~60 % of the FP64 MFMA peak.
+//   * panel factorisation: potrf_inv (one workgroup: LDS Cholesky of the 128x128 diagonal block and its
+//     explicit inverse) -> TRSM as an MFMA GEMM against L11^-1 -> rank-128 update of the panel's second tile
+//     column -> potrf_inv -> TRSM.
+//   * trailing update k_gemm_abt<SYRK_TRI>: C -= A_i A_j^T, one 128x128 tile per workgroup, 4 waves x (4x4)
+//     v_mfma_f64_16x16x4_f64 tiles, accumulators initialised FROM the C tile (so the epilogue is store-only),
+//     K staged through LDS in chunks of 32 with register prefetch. Workgroup ids are decoded XCD-aware: the 64
+//     workgroups resident on one XCD at a time form one 8x8 supertile, so its 16 panel tiles stay in that
+//     XCD's 4 MiB L2 instead of being re-fetched by every tile (block b runs on XCD b % 8).
+//   * look-ahead on two HIP streams: the next panel's two tile columns are updated first and its panel
+//     factorisation (a serial chain of small kernels) runs on the main stream while the bulk of the trailing
+//     update occupies the chip from the auxiliary stream.
+// Triangular solves reuse the stored L_pp^-1 blocks: one small launch per 128-panel.
+#include "common.hpp"
+#include "dev_math.hpp"
+
+namespace covgpu {
+using namespace covdev;
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int KC = 16;        // K chunk staged through LDS
+constexpr int LDT = KC + 1;   // LDS pitch (doubles): odd pitch -> conflict-free fragment reads
+
+enum { MODE_SYRK_TRI = 0, MODE_SYRK_RECT = 1, MODE_TRSM = 2 };
+
+struct GemmArgs {
+  double* M; size_t ld;
+  int kcol0, KD;      // K range: columns kcol0 .. kcol0+KD of the panel (KD = 128 or 256)
+  int ra0;            // A rows: ra0 + ti*128
+  int rb0;            // B rows: rb0 + tj*128           (TRI: == ra0)
+  int cc0;            // C tile at (ra0 + ti*128, cc0 + tj*128)   (TRI: == ra0; TRSM: == kcol0, tj = 0)
+  int nt;             // tile rows (TRI: triangle order)
+  const double* Linv; // TRSM: B = Linv (128x128, pitch 128)
+};
+
+// C[i][j] (op)= sum_k A[i][k] B[j][k] on one 128x128 tile.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
+  int ti, tj;
+  if (MODE == MODE_SYRK_TRI) {
+    // XCD-aware decode: block b -> XCD (b & 7) (observed dispatch order; placement affects speed only).
+    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+    const int s = (q >> 6) * 8 + xcd, inner = q & 63;
+    int si = (int)((sqrt(8.0 * (double)s + 1.0) - 1.0) * 0.5);
+    while ((si + 1) * (si + 2) / 2 <= s) ++si;
+    while (si * (si + 1) / 2 > s) --si;
+    const int sj = s - si * (si + 1) / 2;
+    ti = si * 8 + (inner >> 3); tj = sj * 8 + (inner & 7);
+    if (ti >= g.nt || tj > ti) return;
+  } else if (MODE == MODE_SYRK_RECT) {
+    ti = blockIdx.y; tj = blockIdx.x;
+    if (g.ra0 + ti * kTile < g.cc0 + tj * kTile) return;  // strictly above the diagonal
+  } else {
+    ti = blockIdx.x; tj = 0;
+  }
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // 2 x [128][KC+1] doubles
+  double (*sA)[LDT] = reinterpret_cast<double (*)[LDT]>(smem);
+  double (*sB)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + kTile * LDT);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const size_t ld = g.ld;
+  const double* Ag = g.M + (size_t)(g.ra0 + ti * kTile) * ld + g.kcol0;
+  const double* Bg;
+  size_t ldb;
+  if (MODE == MODE_TRSM) { Bg = g.Linv; ldb = kTile; }
+  else { Bg = g.M + (size_t)(g.rb0 + tj * kTile) * ld + g.kcol0; ldb = ld; }
+  double* Cg = g.M + (size_t)(g.ra0 + ti * kTile) * ld + (size_t)(g.cc0 + tj * kTile);
+  // staging map: KC/2 lanes cover one KC-double row segment (contiguous), 512/KC rows per pass
+  constexpr int LPR = KC / 2, RPP = 256 / LPR, NPASS = kTile / RPP;
+  const int c2 = (tid % LPR) * 2, rbase = tid / LPR;
+  double2 pa[NPASS], pb[NPASS];
+  auto gload = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      const int row = rbase + RPP * it;
+      pa[it] = *reinterpret_cast<const double2*>(Ag + (size_t)row * ld + kc + c2);
+      pb[it] = *reinterpret_cast<const double2*>(Bg + (size_t)row * ldb + kc + c2);
+    }
+  };
+  gload(0);
+  const int fr = lane & 15, fk = lane >> 4;
+  // f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+  v4f64 acc[4][4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        if (MODE == MODE_TRSM) acc[tm][tn][rg] = 0.0;
+        else acc[tm][tn][rg] = Cg[(size_t)(wr * 64 + tm * 16 + fk + 4 * rg) * ld + wc * 64 + tn * 16 + fr];
+      }
+  const double sgn = (MODE == MODE_TRSM) ? 1.0 : -1.0;  // SYRK: acc = C - A B^T through a negated A fragment
+  for (int kc = 0; kc < g.KD; kc += KC) {
+    __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      const int row = rbase + RPP * it;
+      sA[row][c2] = sgn * pa[it].x; sA[row][c2 + 1] = sgn * pa[it].y;
+      sB[row][c2] = pb[it].x; sB[row][c2 + 1] = pb[it].y;
+    }
+    __syncthreads();
+    if (kc + KC < g.KD) gload(kc + KC);  // prefetch the next chunk while the matrix cores work
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 4) {
+      double a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = sA[wr * 64 + t * 16 + fr][kk + fk];
+        b[t] = sB[wc * 64 + t * 16 + fr][kk + fk];
+      }
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+        Cg[(size_t)(wr * 64 + tm * 16 + fk + 4 * rg) * ld + wc * 64 + tn * 16 + fr] = acc[tm][tn][rg];
+}
+
+// Factor the 128x128 diagonal block at (k0,k0) in LDS (lower Cholesky) and form its inverse.
+// L (lower incl. diagonal) is written back into M; L^-1 (lower, zeros above) goes to Linv_out [128][128].
+__global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_t ld, int k0, double* __restrict__ Linv_out, int* flag) {
+  extern __shared__ __attribute__((aligned(16))) double s[];  // [128][129]
+  constexpr int PT = kTile + 1;
+  const int tid = threadIdx.x;
+  double* Mg = M + (size_t)k0 * ld + k0;
+  for (int idx = tid; idx < kTile * kTile; idx += 256) {
+    const int r = idx >> 7, c = idx & 127;
+    s[r * PT + c] = (c <= r) ? Mg[(size_t)r * ld + c] : 0.0;
+  }
+  const int ty = tid >> 4, tx = tid & 15;
+  for (int j = 0; j < kTile; ++j) {
+    __syncthreads();
+    double d = s[j * PT + j];
+    if (!(d > 0.0)) { if (tid == 0) atomicOr(flag, 1); d = 1.0; }
+    const double sd = sqrt(d), inv = 1.0 / sd;
+    __syncthreads();
+    if (tid < kTile) {
+      if (tid == j) s[j * PT + j] = sd;
+      else if (tid > j) s[tid * PT + j] *= inv;
+    }
+    __syncthreads();
+    for (int r = j + 1 + ty; r < kTile; r += 16) {
+      const double lr = s[r * PT + j];
+      for (int c = j + 1 + tx; c <= r; c += 16) s[r * PT + c] -= lr * s[c * PT + j];
+    }
+  }
+  __syncthreads();
+  // L is final: write it back now; from here on the LDS copy is turned into L^-1 in place.
+  for (int idx = tid; idx < kTile * kTile; idx += 256) {
+    const int r = idx >> 7, c = idx & 127;
+    if (c <= r) Mg[(size_t)r * ld + c] = s[r * PT + c];
+  }
+  // ---- inverse by recursive doubling: 8x8 diagonal blocks in registers, then for h = 8,16,32,64 every pair
+  //      [[A,0],[C,B]] -> [[A^-1,0],[-B^-1 C A^-1, B^-1]]. T = C A^-1 is parked in the (unused) mirrored upper
+  //      block, X21 overwrites C. All dot products are independent: no serial LDS chain longer than h.
+  {
+    double Lb[8][8];
+    const int c = tid & 127, cb = c & ~7, lc = c & 7;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int k = 0; k <= r; ++k) Lb[r][k] = s[(cb + r) * PT + cb + k];
+    __syncthreads();
+    if (tid < kTile) {
+      double x[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) sum += Lb[r][k] * x[k];
+        x[r] = (r == lc) ? 1.0 / Lb[r][r] : (r > lc ? -sum / Lb[r][r] : 0.0);
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (r >= lc) s[(cb + r) * PT + c] = x[r];
+    }
+  }
+  for (int h = 8; h < kTile; h <<= 1) {
+    __syncthreads();
+    const int total = 64 * h;  // (64 / h) pairs x h x h outputs
+    const int hh = h * h;
+    for (int idx = tid; idx < total; idx += 256) {  // T = C A^-1
+      const int pr = idx / hh, rem = idx - pr * hh, r = rem / h, c = rem - r * h, base = 2 * pr * h;
+      const double* Crow = s + (base + h + r) * PT + base;
+      double sum = 0.0;
+      for (int k = c; k < h; ++k) sum += Crow[k] * s[(base + k) * PT + base + c];
+      s[(base + c) * PT + base + h + r] = sum;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < total; idx += 256) {  // X21 = -B^-1 T
+      const int pr = idx / hh, rem = idx - pr * hh, r = rem / h, c = rem - r * h, base = 2 * pr * h;
+      const double* Brow = s + (base + h + r) * PT + base + h;
+      const double* Tcol = s + (base + c) * PT + base + h;
+      double sum = 0.0;
+      for (int k = 0; k <= r; ++k) sum += Brow[k] * Tcol[k];
+      s[(base + h + r) * PT + base + c] = -sum;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < kTile * kTile; idx += 256) {
+    const int r = idx >> 7, c = idx & 127;
+    Linv_out[idx] = (c <= r) ? s[r * PT + c] : 0.0;
+  }
+}
+
+// forward substitution step for panel p:  y_p = Linv_p b_p ; b[rows below] -= L[rows, panel p] y_p
+__global__ __launch_bounds__(256) void k_fwd_step(const double* __restrict__ M, size_t ld, int p, const double* __restrict__ Linv,
+                                                   double* __restrict__ b, double* __restrict__ y) {
+  __shared__ double sy[kTile];
+  __shared__ double sb_[kTile];
+  const int tid = threadIdx.x, k0 = p * kTile;
+  if (tid < kTile) sb_[tid] = b[k0 + tid];
+  __syncthreads();
+  if (tid < kTile) {
+    const double* Lr = Linv + (size_t)tid * kTile;
+    double s2 = 0.0;
+    for (int k = 0; k <= tid; ++k) s2 += Lr[k] * sb_[k];
+    sy[tid] = s2;
+    if (blockIdx.x == 0) y[k0 + tid] = s2;
+  }
+  __syncthreads();
+  // each block updates 128 rows below the panel; 2 threads per row, each half of the 128 columns
+  const int row = k0 + kTile + blockIdx.x * kTile + (tid >> 1), half = tid & 1;
+  if (row >= (int)ld) return;  // last panel: nothing below (no barrier follows)
+  const double* Lr = M + (size_t)row * ld + k0 + half * 64;
+  double s2 = 0.0;
+#pragma unroll 8
+  for (int k = 0; k < 64; ++k) s2 += Lr[k] * sy[half * 64 + k];
+  s2 += __shfl_xor(s2, 1, 64);
+  if (half == 0) b[row] -= s2;
+}
+
+// backward substitution step for panel p:  x_p = Linv_p^T y_p ; y[cols left of the panel] -= L[panel rows, cols]^T x_p
+__global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, size_t ld, int p, const double* __restrict__ Linv,
+                                                   double* __restrict__ y, double* __restrict__ x) {
+  __shared__ double sx[kTile];
+  __shared__ double sy[kTile];
+  const int tid = threadIdx.x, k0 = p * kTile;
+  if (tid < kTile) sy[tid] = y[k0 + tid];
+  __syncthreads();
+  if (tid < kTile) {
+    double s2 = 0.0;
+    for (int j = tid; j < kTile; ++j) s2 += Linv[(size_t)j * kTile + tid] * sy[j];
+    sx[tid] = s2;
+    if (blockIdx.x == 0) x[k0 + tid] = s2;
+  }
+  __syncthreads();
+  const int col = blockIdx.x * 256 + tid;
+  if (col < k0) {
+    const double* Lc = M + (size_t)k0 * ld + col;
+    double s2 = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < kTile; ++r) s2 += Lc[(size_t)r * ld] * sx[r];
+    y[col] -= s2;
+  }
+}
+
+void CholAux::init() {
+  if (!aux) (void)hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);
+}
+void CholAux::destroy() {
+  for (auto e : ev) (void)hipEventDestroy(e);
+  for (auto e : prof_ev) (void)hipEventDestroy(e);
+  ev.clear(); prof_ev.clear();
+  if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
+}
+// after the streams have been synchronised: accumulate the bracketed trailing-update launches
+void CholAux::collect() {
+  if (!profile) return;
+  for (size_t i = 0; i < prof_flops.size(); ++i) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, prof_ev[2 * i], prof_ev[2 * i + 1]) != hipSuccess) continue;
+    syrk_ms += ms; syrk_flops += prof_flops[i]; n_syrk++;
+  }
+  prof_flops.clear();
+}
+
+void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax) {
+  const int T = npad / kTile;
+  const size_t ld = (size_t)npad;
+  const size_t lds_potrf = (size_t)kTile * (kTile + 1) * sizeof(double);
+  const size_t lds_gemm = (size_t)2 * kTile * LDT * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_potrf);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_TRSM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_SYRK_TRI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_SYRK_RECT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
+    attr_set = true;
+  }
+  ax.init();
+  const int NP = (T + 1) / 2;  // big panels of two tile columns
+  while ((int)ax.ev.size() < 2 * NP + 2) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ax.ev.push_back(e); }
+  if (ax.profile) while ((int)ax.prof_ev.size() < 2 * NP) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev.push_back(e); }
+  ax.prof_flops.clear();
+  hipEvent_t* eA = ax.ev.data();           // eA[P]: panel P factored (main stream)
+  hipEvent_t* eB = ax.ev.data() + NP + 1;  // eB[P]: bulk trailing update of panel P done (aux stream)
+
+  auto potrf = [&](int t) { hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), lds_potrf, st, S, ld, t * kTile, Linv + (size_t)t * kTile * kTile, flag); };
+  auto trsm = [&](int t) {  // rows below tile t, columns of tile t
+    const int rem = T - t - 1;
+    if (rem <= 0) return;
+    GemmArgs g{S, ld, t * kTile, kTile, (t + 1) * kTile, 0, t * kTile, rem, Linv + (size_t)t * kTile * kTile};
+    hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(rem), dim3(256), lds_gemm, st, g);
+  };
+  // C tiles in tile-columns [tc0, tc0+ntc) (rows >= tc0) -= A[:, kcols] A[tc.., kcols]^T
+  auto rect = [&](int tc0, int ntc, int kt0, int KD, hipStream_t s2) {
+    const int ntr = T - tc0;
+    if (ntr <= 0 || ntc <= 0) return;
+    GemmArgs g{S, ld, kt0 * kTile, KD, tc0 * kTile, tc0 * kTile, tc0 * kTile, ntr, nullptr};
+    hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, ntr), dim3(256), lds_gemm, s2, g);
+  };
+
+  for (int P = 0; P < NP; ++P) {
+    const int t0 = 2 * P, w = (T - t0 >= 2) ? 2 : 1;
+    if (P > 0) {
+      // look-ahead part of SYRK(P-1): only the two tile columns of panel P (their previous update ran on aux in SYRK(P-2))
+      if (P >= 2) (void)hipStreamWaitEvent(st, eB[P - 2], 0);
+      rect(t0, w, t0 - 2, 2 * kTile, st);
+    }
+    potrf(t0);
+    trsm(t0);
+    if (w == 2) {
+      rect(t0 + 1, 1, t0, kTile, st);  // rank-128 update of the panel's second tile column
+      potrf(t0 + 1);
+      trsm(t0 + 1);
+    }
+    (void)hipEventRecord(eA[P], st);
+    // bulk of SYRK(P): triangle starting two tile columns further (those belong to the look-ahead part)
+    const int tb = t0 + 4, nt = T - tb;
+    (void)hipStreamWaitEvent(ax.aux, eA[P], 0);
+    if (nt > 0) {
+      const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
+      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr};
+      if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], ax.aux);
+      hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk), dim3(256), lds_gemm, ax.aux, g);
+      if (ax.profile) {
+        (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], ax.aux);
+        ax.prof_flops.push_back((double)nt * (nt + 1) / 2 * 2.0 * kTile * kTile * (w * kTile));
+      }
+    }
+    (void)hipEventRecord(eB[P], ax.aux);
+  }
+  (void)hipStreamWaitEvent(st, eB[NP - 1], 0);
+  if (NP >= 2) (void)hipStreamWaitEvent(st, eB[NP - 2], 0);
+  // L y = b, then L^T x = y; y lives in b[npad .. 2 npad)
+  for (int p = 0; p < T; ++p) {
+    const int rem = T - p - 1;
+    hipLaunchKernelGGL(k_fwd_step, dim3(rem > 0 ? rem : 1), dim3(256), 0, st, S, ld, p, Linv + (size_t)p * kTile * kTile, b, b + npad);
+  }
+  for (int p = T - 1; p >= 0; --p) {
+    const int nb = (p * kTile + 255) / 256;
+    hipLaunchKernelGGL(k_bwd_step, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, S, ld, p, Linv + (size_t)p * kTile * kTile, b + npad, b);
+  }
+}
+
+void launch_dense_cholesky_solve(const DevProblem& P, hipStream_t st, CholAux& ax) {
+  dense_cholesky_solve_raw(P.Sred, P.bred, P.Linv, P.flag, P.npad, st, ax);
+}
+
+}  // namespace covgpu

@@ -45,7 +45,7 @@ struct covgpu_context {
   int profiling = 0;
   covgpu_profile_t prof;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  std::vector<hipEvent_t> syrk_ev;
+  CholAux chol;
 };
 
 extern "C" void covgpu_default_options(covgpu_options* o) {
@@ -93,17 +93,20 @@ extern "C" void covgpu_destroy(covgpu_context* c) {
   (void)hipSetDevice(c->device);
   free_problem(c);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
-  for (auto& e : c->syrk_ev) (void)hipEventDestroy(e);
+  c->chol.destroy();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
 }
 
-extern "C" void covgpu_set_profiling(covgpu_context* c, int on) { c->profiling = on; c->prof = covgpu_profile_t(); }
+extern "C" void covgpu_set_profiling(covgpu_context* c, int on) {
+  c->profiling = on; c->prof = covgpu_profile_t();
+  c->chol.profile = on != 0; c->chol.syrk_ms = 0; c->chol.syrk_flops = 0; c->chol.n_syrk = 0;
+}
 // out[0..7] = build ms, n_build, factor ms, n_factor, syrk ms, n_syrk launches, syrk flops, tri-solve ms
 extern "C" void covgpu_get_profile(covgpu_context* c, double* out) {
   out[0] = c->prof.t_build_ms; out[1] = (double)c->prof.n_build; out[2] = c->prof.t_factor_ms; out[3] = (double)c->prof.n_factor;
-  out[4] = c->prof.t_syrk_ms; out[5] = (double)c->prof.n_syrk; out[6] = c->prof.syrk_flops; out[7] = c->prof.t_solve_tri_ms;
+  out[4] = c->chol.syrk_ms; out[5] = (double)c->chol.n_syrk; out[6] = c->chol.syrk_flops; out[7] = c->prof.t_solve_tri_ms;
 }
 
 template <typename T>
@@ -250,15 +253,10 @@ static void enqueue_build(covgpu_context* c, double mu) {
 
 static void enqueue_solve(covgpu_context* c, double* dst_all) {
   const DevProblem& P = c->P;
-  hipEvent_t* sev = nullptr;
-  if (c->profiling) {
-    // every SYRK launch gets its own event pair so that bench.py can quote the dominant kernel's duration
-    const size_t need = (size_t)2 * (P.npad / kTile);
-    while (c->syrk_ev.size() < need) { hipEvent_t e; (void)hipEventCreate(&e); c->syrk_ev.push_back(e); }
-    sev = c->syrk_ev.data();
-    (void)hipEventRecord(c->ev[2], c->st);
-  }
-  launch_dense_cholesky_solve(P, c->st, sev);
+  // with profiling on, every bulk trailing-update (SYRK) launch gets its own event pair on its stream so that
+  // bench.py can quote the dominant kernel's duration
+  if (c->profiling) (void)hipEventRecord(c->ev[2], c->st);
+  launch_dense_cholesky_solve(P, c->st, c->chol);
   if (c->profiling) (void)hipEventRecord(c->ev[3], c->st);
   (void)hipMemcpyAsync(dst_all, P.bred, (size_t)P.n * sizeof(double), hipMemcpyDeviceToDevice, c->st);
   launch_lm_backsub(P, P.bred, dst_all, c->st);
@@ -268,16 +266,8 @@ static void collect_profile(covgpu_context* c, bool built, bool solved) {
   if (!c->profiling) return;
   float ms = 0;
   if (built && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) { c->prof.t_build_ms += ms; c->prof.n_build++; }
-  if (solved && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) {
-    c->prof.t_factor_ms += ms; c->prof.n_factor++;
-    const int T = c->P.npad / kTile;
-    for (int p = 0; p + 1 < T; ++p) {
-      if (hipEventElapsedTime(&ms, c->syrk_ev[2 * p], c->syrk_ev[2 * p + 1]) != hipSuccess) continue;
-      const double rem = T - p - 1;
-      c->prof.t_syrk_ms += ms; c->prof.n_syrk++;
-      c->prof.syrk_flops += rem * (rem + 1) / 2 * 2.0 * kTile * kTile * kTile;
-    }
-  }
+  if (solved && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) { c->prof.t_factor_ms += ms; c->prof.n_factor++; }
+  if (solved) c->chol.collect();
 }
 
 static void enqueue_jvp(covgpu_context* c, const double* v_all) {
@@ -535,7 +525,7 @@ extern "C" int covgpu_solve_reduced(covgpu_context* c, int32_t n, const double* 
   HIPCHK(hipMemcpyAsync(dS, Sp.data(), Sp.size() * sizeof(double), hipMemcpyHostToDevice, c->st));
   HIPCHK(hipMemcpyAsync(db, bp.data(), bp.size() * sizeof(double), hipMemcpyHostToDevice, c->st));
   HIPCHK(hipMemsetAsync(df, 0, 4 * sizeof(int), c->st));
-  dense_cholesky_solve_raw(dS, db, dL, df, npad, c->st);
+  dense_cholesky_solve_raw(dS, db, dL, df, npad, c->st, c->chol);
   int flag = 0;
   HIPCHK(hipMemcpyAsync(x, db, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipMemcpyAsync(&flag, df, sizeof(int), hipMemcpyDeviceToHost, c->st));

@@ -1,0 +1,482 @@
+// optimization_gpu.hpp — header-only C++ facade: covins::Optimization::{GlobalBundleAdjustment,
+// PoseGraphOptimization} re-implemented on top of the C ABI of libcovgpu (include/covgpu.h).
+//
+// Drop-in boundary. The reference declares, in covins_backend/include/covins/covins_backend/
+// optimization_be.hpp:38-51,
+//     static auto GlobalBundleAdjustment(MapPtr map, int interations_limit, double time_limit,
+//                                        bool visual_only = false, bool outlier_removal = true,
+//                                        bool estimate_bias = false) -> void;
+//     static auto PoseGraphOptimization(MapPtr map, PoseMap corrected_poses) -> void;
+// and callers link those symbols directly (backend.cpp:141-156, placerec_be.cpp:327, placerec_gen_be.cpp:250).
+// `covins_gpu::OptimizationT<Types>` keeps both signatures verbatim. It walks Map / Keyframe / Landmark with the
+// very accessors optimization_be.cpp uses (GetKeyframesVec, IsInvalid, UpdateCeresFromState-equivalent reads,
+// GetObservations, GetPredecessor, GetLoopConstraints, ...), applies the same gating rules and constants, and
+// replaces each `ceres::Problem` + `ceres::Solve` by one flat `covgpu_problem` + covgpu_gba_solve /
+// covgpu_pgo_solve. Write-back and map maintenance follow optimization_be.cpp:572-614 and :1037-1083.
+//
+// The header is Eigen-free on purpose (no Eigen in this build image): 4x4 transforms, 3-vectors and 6x6
+// matrices are only touched through operator()(r,c) / operator[](i), which Eigen types and the test stand-ins
+// (tests/cpp/standin_map.hpp) both provide. `Types` names the map classes and the few operations whose
+// spelling differs between the real COVINS classes and a stand-in (see INTEGRATION.md for the COVINS binding).
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../covgpu.h"
+
+namespace covins_gpu {
+
+// covins_params::opt / sys / placerec values read on this path (config/config_backend.yaml:8,115-140;
+// config_backend.hpp:180-207). A plain struct instead of static-init globals.
+struct Params {
+  int gba_use_map_loop_constraints = 1;
+  double th_gba_outlier_global = 0.92;
+  int gba_fix_poses_loaded_maps = 0;
+  int pgo_iteration_limit = 10;
+  int use_nbr_kfs = 1;
+  int use_robust_loss = 1;
+  double robust_loss_th = 0.5;
+  int pgo_fix_kfs_after_gba = 1;
+  int pgo_fix_poses_loaded_maps = 0;
+  double wt_kf_r = 10.0, wt_kf_t = 1.0, wt_kf_n1 = 10.0, wt_kf_n23 = 2.0, wt_kf_n45 = 3.0;
+  std::string placerec_type = "COVINS";
+  int strategy = COVGPU_DOGLEG;  // the reference runs DOGLEG (optimization_be.cpp:261,564,1028)
+  int device = 0;
+  // IMU noise / gravity of VICalibration (typedefs_base.hpp:333-340); defaults = EuRoC at 200 Hz
+  double sigma_a = 0, sigma_g = 0, sigma_aw = 0, sigma_gw = 0, gravity = 0;  // 0 -> covgpu defaults
+};
+
+namespace detail {
+
+inline void fatal(const char* msg) {  // the reference prints COUTFATAL and exit(-1) (e.g. optimization_be.cpp:113-114)
+  std::fprintf(stderr, "[covins_gpu] FATAL: %s\n", msg);
+  std::exit(-1);
+}
+
+// rotation matrix (rows/cols 0..2 of any (r,c)-indexable) -> Hamilton quaternion x,y,z,w (what Eigen::Quaterniond(R) yields)
+template <class M>
+inline void rot_to_quat(const M& T, double* q) {
+  const double m00 = T(0, 0), m11 = T(1, 1), m22 = T(2, 2), tr = m00 + m11 + m22;
+  double x, y, z, w;
+  if (tr > 0) {
+    const double s = std::sqrt(tr + 1.0) * 2;
+    w = 0.25 * s; x = (T(2, 1) - T(1, 2)) / s; y = (T(0, 2) - T(2, 0)) / s; z = (T(1, 0) - T(0, 1)) / s;
+  } else if (m00 > m11 && m00 > m22) {
+    const double s = std::sqrt(1.0 + m00 - m11 - m22) * 2;
+    w = (T(2, 1) - T(1, 2)) / s; x = 0.25 * s; y = (T(0, 1) + T(1, 0)) / s; z = (T(0, 2) + T(2, 0)) / s;
+  } else if (m11 > m22) {
+    const double s = std::sqrt(1.0 + m11 - m00 - m22) * 2;
+    w = (T(0, 2) - T(2, 0)) / s; x = (T(0, 1) + T(1, 0)) / s; y = 0.25 * s; z = (T(1, 2) + T(2, 1)) / s;
+  } else {
+    const double s = std::sqrt(1.0 + m22 - m00 - m11) * 2;
+    w = (T(1, 0) - T(0, 1)) / s; x = (T(0, 2) + T(2, 0)) / s; y = (T(1, 2) + T(2, 1)) / s; z = 0.25 * s;
+  }
+  const double n = std::sqrt(x * x + y * y + z * z + w * w);
+  q[0] = x / n; q[1] = y / n; q[2] = z / n; q[3] = w / n;
+}
+// pose block [qx qy qz qw px py pz] from a 4x4 transform (keyframe_base.cpp:486-499)
+template <class M>
+inline void transform_to_pose(const M& T, double* p) {
+  rot_to_quat(T, p);
+  p[4] = T(0, 3); p[5] = T(1, 3); p[6] = T(2, 3);
+}
+// Utils::Ceres2Transform (utils_base.cpp:28-43): normalise q, fill a 4x4
+template <class M>
+inline void pose_to_transform(const double* p, M& T) {
+  double x = p[0], y = p[1], z = p[2], w = p[3];
+  const double n = std::sqrt(x * x + y * y + z * z + w * w);
+  x /= n; y /= n; z /= n; w /= n;
+  T(0, 0) = 1 - 2 * (y * y + z * z); T(0, 1) = 2 * (x * y - w * z);     T(0, 2) = 2 * (x * z + w * y);     T(0, 3) = p[4];
+  T(1, 0) = 2 * (x * y + w * z);     T(1, 1) = 1 - 2 * (x * x + z * z); T(1, 2) = 2 * (y * z - w * x);     T(1, 3) = p[5];
+  T(2, 0) = 2 * (x * z - w * y);     T(2, 1) = 2 * (y * z + w * x);     T(2, 2) = 1 - 2 * (x * x + y * y); T(2, 3) = p[6];
+  T(3, 0) = 0; T(3, 1) = 0; T(3, 2) = 0; T(3, 3) = 1;
+}
+// [q,t] of Ta^-1 Tb for two 4x4 transforms (optimization_be.cpp:956-958, 1006-1008)
+template <class M>
+inline void relative_pose(const M& Ta, const M& Tb, double* out7) {
+  double R[3][3], t[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) {
+      R[r][c] = 0;
+      for (int k = 0; k < 3; ++k) R[r][c] += Ta(k, r) * Tb(k, c);
+    }
+    t[r] = 0;
+    for (int k = 0; k < 3; ++k) t[r] += Ta(k, r) * (Tb(k, 3) - Ta(k, 3));
+  }
+  struct V { double (*R)[3]; double operator()(int r, int c) const { return R[r][c]; } } v{R};
+  rot_to_quat(v, out7);
+  out7[4] = t[0]; out7[5] = t[1]; out7[6] = t[2];
+}
+// upper-triangular chol(A^-1)^T of a 6x6 SPD matrix given row-major (optimization_be.cpp:922-923)
+inline void sqrt_info_from_cov(const double* cov, double* S) {
+  double A[6][12];
+  for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { A[r][c] = cov[6 * r + c]; A[r][6 + c] = (r == c); }
+  for (int c = 0; c < 6; ++c) {  // Gauss-Jordan with partial pivoting
+    int p = c;
+    for (int r = c + 1; r < 6; ++r) if (std::fabs(A[r][c]) > std::fabs(A[p][c])) p = r;
+    for (int k = 0; k < 12; ++k) std::swap(A[c][k], A[p][k]);
+    const double d = A[c][c];
+    for (int k = 0; k < 12; ++k) A[c][k] /= d;
+    for (int r = 0; r < 6; ++r) if (r != c) { const double f = A[r][c]; for (int k = 0; k < 12; ++k) A[r][k] -= f * A[c][k]; }
+  }
+  double L[6][6] = {};
+  for (int j = 0; j < 6; ++j) {
+    double d = A[j][6 + j];
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+    L[j][j] = std::sqrt(d);
+    for (int i = j + 1; i < 6; ++i) {
+      double s = A[i][6 + j];
+      for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+      L[i][j] = s / L[j][j];
+    }
+  }
+  for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) S[6 * r + c] = L[c][r];
+}
+
+struct Flat {  // owning storage behind one covgpu_problem
+  std::vector<double> pose, sb, cam_extr, cam_intr, cam_dist, lm, uv, sigma, samples, first, meas, info, loss;
+  std::vector<uint8_t> fixed;
+  std::vector<int32_t> kf_cam, cam_type, obs_ptr, obs_kf, imu_i, imu_j, imu_ptr, ei, ej;
+  covgpu_problem view() {
+    covgpu_problem p{};
+    p.num_kf = (int32_t)fixed.size(); p.num_cam = (int32_t)cam_type.size(); p.num_lm = (int32_t)(lm.size() / 3);
+    p.num_obs = (int32_t)obs_kf.size(); p.num_imu = (int32_t)imu_i.size(); p.num_edge = (int32_t)ei.size();
+    p.num_imu_samples = (int32_t)(samples.size() / 7);
+    if (obs_ptr.empty()) obs_ptr.push_back(0);
+    if (imu_ptr.empty()) imu_ptr.push_back(0);
+    p.kf_pose = pose.data(); p.kf_speed_bias = sb.data(); p.kf_fixed = fixed.data(); p.kf_cam = kf_cam.data();
+    p.cam_extr = cam_extr.data(); p.cam_intr = cam_intr.data(); p.cam_dist = cam_dist.data(); p.cam_dist_type = cam_type.data();
+    p.lm_pos = lm.data(); p.lm_obs_ptr = obs_ptr.data(); p.obs_kf = obs_kf.data(); p.obs_uv = uv.data(); p.obs_sigma = sigma.data();
+    p.imu_kf_i = imu_i.data(); p.imu_kf_j = imu_j.data(); p.imu_sample_ptr = imu_ptr.data(); p.imu_samples = samples.data();
+    p.imu_first = first.data();
+    p.edge_i = ei.data(); p.edge_j = ej.data(); p.edge_meas = meas.data(); p.edge_sqrt_info = info.data(); p.edge_loss_a = loss.data();
+    return p;
+  }
+};
+
+}  // namespace detail
+
+// `Types` must provide (see tests/cpp/standin_map.hpp and INTEGRATION.md):
+//   typedefs  Map, Keyframe, Landmark, TransformType, Vector3Type
+//   static bool camera(const Keyframe&, double intr[4], double dist[4], int* dist_type);   false = unknown model
+//   static int  imu_count(const Keyframe&);
+//   static void imu_sample(const Keyframe&, int i, double* dt, double acc[3], double gyr[3]);
+//   static void imu_first(const Keyframe&, double acc0[3], double gyr0[3]);
+template <class Types>
+class OptimizationT {
+ public:
+  using Map = typename Types::Map;
+  using Keyframe = typename Types::Keyframe;
+  using Landmark = typename Types::Landmark;
+  using MapPtr = std::shared_ptr<Map>;
+  using KeyframePtr = std::shared_ptr<Keyframe>;
+  using LandmarkPtr = std::shared_ptr<Landmark>;
+  using TransformType = typename Types::TransformType;
+  using Vector3Type = typename Types::Vector3Type;
+  using idpair = std::pair<size_t, size_t>;
+  using PoseMap = std::map<idpair, TransformType>;
+
+  OptimizationT() = delete;  // static-only, like the reference class (optimization_be.hpp:36)
+
+  static Params& params() { static Params p; return p; }
+
+  struct Index { std::vector<KeyframePtr> kfs; std::vector<LandmarkPtr> lms; std::vector<std::pair<KeyframePtr, size_t>> obs; std::vector<LandmarkPtr> obs_lm; };
+
+  // Map -> IR for one GBA round (optimization_be.cpp:74-254 round 1, :308-557 round 2)
+  static void FlattenGBA(const MapPtr& map, bool visual_only, bool round2, detail::Flat& f, Index& ix) {
+    const Params& prm = params();
+    auto keyframes = map->GetKeyframesVec();
+    auto landmarks = map->GetLandmarksVec();
+    std::map<Keyframe*, int32_t> row;
+    std::map<size_t, int32_t> cam_of_client;
+    for (auto& kf : keyframes) {
+      if (kf->IsInvalid()) continue;
+      const int32_t k = (int32_t)ix.kfs.size();
+      row[kf.get()] = k; ix.kfs.push_back(kf);
+      double p7[7];
+      detail::transform_to_pose(kf->GetPoseTws(), p7);  // UpdateCeresFromState (keyframe_base.cpp:486-499)
+      f.pose.insert(f.pose.end(), p7, p7 + 7);
+      const Vector3Type v = kf->GetStateVelocity();
+      Vector3Type ba, bg;
+      kf->GetStateBias(ba, bg);
+      for (int i = 0; i < 3; ++i) f.sb.push_back(v[i]);
+      for (int i = 0; i < 3; ++i) f.sb.push_back(ba[i]);
+      for (int i = 0; i < 3; ++i) f.sb.push_back(bg[i]);
+      bool fixed = (kf->id_.first == 0 && kf->id_.second == map->id_map_);                       // :88-89, 329-331
+      if (round2 && kf->is_loaded_ && prm.gba_fix_poses_loaded_maps) fixed = true;                // :338-341
+      f.fixed.push_back(fixed ? 1 : 0);
+      auto it = cam_of_client.find(kf->id_.second);
+      if (it == cam_of_client.end()) {  // one camera per agent; extrinsics/intrinsics/distortion constant (:336,349,352)
+        double intr[4], dist[4], e7[7]; int dt = 0;
+        if (!Types::camera(*kf, intr, dist, &dt)) detail::fatal("Unknown projection / distortion type.");  // :112-115, 201-204
+        detail::transform_to_pose(kf->GetStateExtrinsics(), e7);
+        it = cam_of_client.emplace(kf->id_.second, (int32_t)f.cam_type.size()).first;
+        f.cam_extr.insert(f.cam_extr.end(), e7, e7 + 7); f.cam_intr.insert(f.cam_intr.end(), intr, intr + 4);
+        f.cam_dist.insert(f.cam_dist.end(), dist, dist + 4); f.cam_type.push_back(dt);
+      }
+      f.kf_cam.push_back(it->second);
+    }
+    // IMU factors (:117-144 / :367-420)
+    f.imu_ptr.assign(1, 0);
+    if (!visual_only)
+      for (auto& kf : ix.kfs) {
+        KeyframePtr pred = kf->GetPredecessor();
+        if (!pred || pred->IsInvalid()) {
+          if (kf->id_.first != 0) detail::fatal("keyframe without predecessor");  // :121-124, 371-374
+          continue;
+        }
+        const int n = Types::imu_count(*kf);
+        if (round2 && n == 0) continue;  // "0 IMU measurements - skip IMU factor" (:382-385)
+        f.imu_i.push_back(row.at(pred.get())); f.imu_j.push_back(row.at(kf.get()));
+        double a0[3], g0[3];
+        Types::imu_first(*kf, a0, g0);
+        f.first.insert(f.first.end(), a0, a0 + 3); f.first.insert(f.first.end(), g0, g0 + 3);
+        for (int i = 0; i < n; ++i) {
+          double dt, a[3], g[3];
+          Types::imu_sample(*kf, i, &dt, a, g);
+          f.samples.push_back(dt); f.samples.insert(f.samples.end(), a, a + 3); f.samples.insert(f.samples.end(), g, g + 3);
+        }
+        f.imu_ptr.push_back((int32_t)(f.samples.size() / 7));
+      }
+    // landmarks + observations (:147-236 / :425-530)
+    const size_t th_min_observations = 2;
+    f.obs_ptr.assign(1, 0);
+    for (auto& lm : landmarks) {
+      if (lm->IsInvalid()) continue;
+      const auto observations = lm->GetObservations();
+      if (observations.size() < th_min_observations) continue;
+      size_t num_edges = 0;
+      for (auto& mit : observations) { if (!mit.first || mit.first->IsInvalid()) continue; num_edges++; }
+      if (num_edges < th_min_observations) continue;
+      const Vector3Type pw = lm->GetWorldPos();
+      for (int i = 0; i < 3; ++i) f.lm.push_back(pw[i]);
+      ix.lms.push_back(lm);
+      for (auto& mit : observations) {
+        const KeyframePtr& kfx = mit.first;
+        if (!kfx || kfx->IsInvalid()) continue;
+        const size_t feat = mit.second;
+        f.obs_kf.push_back(row.at(kfx.get()));
+        f.uv.push_back((double)kfx->keypoints_distorted_[feat][0]);  // float -> double (utils_base.hpp:76-80)
+        f.uv.push_back((double)kfx->keypoints_distorted_[feat][1]);
+        f.sigma.push_back(((double)kfx->keypoints_aors_[feat][1] + 1) * 2.0);  // :184, 478
+        ix.obs.emplace_back(kfx, feat); ix.obs_lm.push_back(lm);
+      }
+      f.obs_ptr.push_back((int32_t)f.obs_kf.size());
+    }
+    // loop edges (:238-254 / :534-557): sqrt_info = diag(100 I3, 1e4 I3); loss only in round 2
+    if (!round2 || prm.gba_use_map_loop_constraints)
+      for (auto& lc : map->GetLoopConstraints()) {
+        auto a = row.find(lc.kf1.get()), b = row.find(lc.kf2.get());
+        if (a == row.end() || b == row.end()) { std::fprintf(stderr, "[covins_gpu] Loop KF missing -- skip loop\n"); continue; }  // :546-549
+        double m7[7];
+        detail::transform_to_pose(lc.T_s1_s2, m7);
+        f.ei.push_back(a->second); f.ej.push_back(b->second); f.meas.insert(f.meas.end(), m7, m7 + 7);
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) f.info.push_back(r == c ? (r < 3 ? 100.0 : 1e4) : 0.0);
+        f.loss.push_back(round2 ? 1.0 : 0.0);
+      }
+  }
+
+  static covgpu_options Options(int max_it, bool visual_only) {
+    const Params& prm = params();
+    covgpu_options o;
+    covgpu_default_options(&o);
+    o.strategy = prm.strategy; o.max_iterations = max_it; o.visual_only = visual_only ? 1 : 0; o.device = prm.device;
+    if (prm.sigma_a > 0) { o.sigma_a = prm.sigma_a; o.sigma_g = prm.sigma_g; o.sigma_aw = prm.sigma_aw; o.sigma_gw = prm.sigma_gw; }
+    if (prm.gravity > 0) o.gravity = prm.gravity;
+    return o;
+  }
+
+  static covgpu_context* Context() {
+    covgpu_context* ctx = nullptr;
+    covgpu_options o = Options(1, false);
+    if (covgpu_create(&o, &ctx) != COVGPU_OK) detail::fatal(covgpu_last_error());
+    return ctx;
+  }
+
+  // ---- optimization_be.cpp:56-618
+  static auto GlobalBundleAdjustment(MapPtr map, int interations_limit, double time_limit, bool visual_only = false,
+                                     bool outlier_removal = true, bool estimate_bias = false) -> void {
+    (void)time_limit; (void)estimate_bias;  // never read by the reference either
+    std::printf("+++ GBA: Start +++\n");
+    covgpu_context* ctx = Context();
+    if (outlier_removal) {  // first round (:62-293)
+      detail::Flat f; Index ix;
+      FlattenGBA(map, visual_only, false, f, ix);
+      covgpu_problem p = f.view();
+      covgpu_options o = Options(5, visual_only);  // max_num_iterations = 5 (:262)
+      covgpu_result r;
+      if (covgpu_gba_solve(ctx, &o, &p, &r) != COVGPU_OK) detail::fatal(covgpu_last_error());
+      std::vector<double> norms(f.obs_kf.size());
+      if (covgpu_reprojection_residual_norms(ctx, &o, &p, norms.data()) != COVGPU_OK) detail::fatal(covgpu_last_error());
+      size_t num_bad = 0;
+      for (size_t i = 0; i < norms.size(); ++i)
+        if (norms[i] > params().th_gba_outlier_global) {  // :281-289
+          ix.obs[i].first->EraseLandmark(ix.obs[i].second);
+          ix.obs_lm[i]->EraseObservation(ix.obs[i].first);
+          ++num_bad;
+        }
+      std::printf("--> GBA removed %zu of %zu observations\n", num_bad, norms.size() * 2);
+    }
+    {  // second round (:296-610)
+      detail::Flat f; Index ix;
+      FlattenGBA(map, visual_only, true, f, ix);
+      std::printf("--> KFs: %zu\n--> LMs: %zu\n", ix.kfs.size(), ix.lms.size());
+      covgpu_problem p = f.view();
+      covgpu_options o = Options(interations_limit, visual_only);
+      covgpu_result r;
+      if (covgpu_gba_solve(ctx, &o, &p, &r) != COVGPU_OK) detail::fatal(covgpu_last_error());
+      for (size_t k = 0; k < ix.kfs.size(); ++k) {  // :572-595
+        KeyframePtr& kf = ix.kfs[k];
+        TransformType T;
+        detail::pose_to_transform(&f.pose[7 * k], T);
+        kf->SetPoseTws(T);
+        kf->SetPoseOptimized();
+        if (!visual_only) {
+          const double* s = &f.sb[9 * k];
+          Vector3Type vel, bA, bG;
+          for (int i = 0; i < 3; ++i) { vel[i] = s[i]; bA[i] = s[3 + i]; bG[i] = s[6 + i]; }
+          kf->SetStateBias(bA, bG);
+          kf->SetStateVelocity(vel);
+          kf->SetVelBiasOptimized();
+        }
+        kf->is_gba_optimized_ = true;
+      }
+      for (size_t l = 0; l < ix.lms.size(); ++l) {  // :598-609
+        Vector3Type pw;
+        for (int i = 0; i < 3; ++i) pw[i] = f.lm[3 * l + i];
+        ix.lms[l]->SetWorldPos(pw);
+        ix.lms[l]->SetOptimized();
+        ix.lms[l]->is_gba_optimized_ = true;
+      }
+    }
+    covgpu_destroy(ctx);
+    std::printf("--> Clean Map\n");
+    map->Clean();  // :614
+    std::printf("--> done.\n+++ GBA: End +++\n");
+  }
+
+  // ---- optimization_be.cpp:833-1086
+  static auto PoseGraphOptimization(MapPtr map, PoseMap corrected_poses) -> void {
+    const Params& prm = params();
+    auto keyframes = map->GetKeyframesVec();
+    auto landmarks = map->GetLandmarksVec();
+    detail::Flat f;
+    std::vector<KeyframePtr> kfs;
+    std::map<Keyframe*, int32_t> row;
+    for (auto& kf : keyframes) {  // :850-882
+      if (kf->IsInvalid()) continue;
+      row[kf.get()] = (int32_t)kfs.size(); kfs.push_back(kf);
+      double p7[7];
+      auto mit = corrected_poses.find(kf->id_);
+      if (mit != corrected_poses.end()) detail::transform_to_pose(mit->second, p7);
+      else detail::transform_to_pose(kf->GetPoseTws(), p7);
+      f.pose.insert(f.pose.end(), p7, p7 + 7);
+      for (int i = 0; i < 9; ++i) f.sb.push_back(0.0);
+      bool fixed = (kf->id_.first == 0 && kf->id_.second == map->id_map_);
+      if (kf->is_gba_optimized_ && prm.pgo_fix_kfs_after_gba) fixed = true;
+      else if (kf->is_loaded_ && prm.pgo_fix_poses_loaded_maps) fixed = true;
+      f.fixed.push_back(fixed ? 1 : 0);
+      f.kf_cam.push_back(0);
+    }
+    f.cam_type.push_back(0);
+    f.cam_extr.assign(7, 0.0); f.cam_extr[3] = 1.0; f.cam_intr.assign(4, 1.0); f.cam_dist.assign(4, 0.0);
+    double W1[36] = {}, W23[36] = {}, W45[36] = {};  // :889-902
+    for (int i = 0; i < 6; ++i) {
+      W1[7 * i] = (i < 3 ? prm.wt_kf_r : prm.wt_kf_t) * prm.wt_kf_n1;
+      W23[7 * i] = W1[7 * i] / prm.wt_kf_n23; W45[7 * i] = W1[7 * i] / prm.wt_kf_n45;
+    }
+    auto add_edge = [&](int32_t a, int32_t b, const double* m7, const double* S, double loss) {
+      f.ei.push_back(a); f.ej.push_back(b); f.meas.insert(f.meas.end(), m7, m7 + 7); f.info.insert(f.info.end(), S, S + 36); f.loss.push_back(loss);
+    };
+    for (auto& lc : map->GetLoopConstraints()) {  // :912-944
+      double S[36], m7[7];
+      if (prm.placerec_type == "COVINS") for (int i = 0; i < 36; ++i) S[i] = W1[i];
+      else {
+        double cov[36];
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) cov[6 * r + c] = lc.cov_mat(r, c);
+        detail::sqrt_info_from_cov(cov, S);
+      }
+      detail::transform_to_pose(lc.T_s1_s2, m7);
+      add_edge(row.at(lc.kf1.get()), row.at(lc.kf2.get()), m7, S, prm.use_robust_loss ? prm.robust_loss_th : 0.0);
+    }
+    std::set<std::pair<Keyframe*, Keyframe*>> inserted;
+    for (auto& kf : kfs) {  // successor edges from the VIO poses (:947-972)
+      KeyframePtr succ = kf->GetSuccessor();
+      if (!succ) continue;
+      if (!inserted.insert({kf.get(), succ.get()}).second) continue;
+      double m7[7];
+      detail::relative_pose(kf->GetPoseTws_vio(), succ->GetPoseTws_vio(), m7);
+      add_edge(row.at(kf.get()), row.at(succ.get()), m7, W1, 0.0);
+    }
+    if (prm.use_nbr_kfs)  // five previous neighbours (:976-1021)
+      for (auto& kf : kfs) {
+        std::vector<KeyframePtr> connections;
+        KeyframePtr temp = kf;
+        for (int j = 1; j < 6; ++j)
+          if (int(kf->id_.first) - j > 0) { temp = temp->GetPredecessor(); connections.push_back(temp); }
+        size_t k = 0;
+        for (auto& kfc : connections) {
+          k++;
+          const double* S = (k <= 1) ? W1 : (k <= 3 ? W23 : W45);
+          if (!inserted.insert({kf.get(), kfc.get()}).second) continue;
+          double m7[7];
+          detail::relative_pose(kf->GetPoseTws_vio(), kfc->GetPoseTws_vio(), m7);
+          add_edge(row.at(kf.get()), row.at(kfc.get()), m7, S, 0.0);
+        }
+      }
+    covgpu_problem p = f.view();
+    covgpu_options o = Options(prm.pgo_iteration_limit, false);
+    covgpu_context* ctx = Context();
+    covgpu_result r;
+    if (covgpu_pgo_solve(ctx, &o, &p, &r) != COVGPU_OK) detail::fatal(covgpu_last_error());
+    // recover (:1033-1083): poses, velocity rotation, landmark re-anchoring on the device
+    std::vector<double> pose_old(7 * kfs.size()), vel(3 * kfs.size());
+    for (size_t k = 0; k < kfs.size(); ++k) {
+      detail::transform_to_pose(kfs[k]->GetPoseTws(), &pose_old[7 * k]);
+      const Vector3Type v = kfs[k]->GetStateVelocity();
+      for (int i = 0; i < 3; ++i) vel[3 * k + i] = v[i];
+    }
+    std::vector<LandmarkPtr> lms;
+    std::vector<int32_t> ref;
+    std::vector<double> lmp;
+    for (auto& lm : landmarks) {
+      if (lm->IsInvalid()) continue;
+      KeyframePtr kf_ref = lm->GetReferenceKeyframe();
+      if (!kf_ref) { if (!lm->GetObservations().empty()) map->EraseLandmark(lm); continue; }  // :1059-1065
+      auto it = row.find(kf_ref.get());
+      if (it == row.end()) { map->EraseLandmark(lm); continue; }                              // :1069-1073
+      const Vector3Type pw = lm->GetWorldPos();
+      lms.push_back(lm); ref.push_back(it->second);
+      for (int i = 0; i < 3; ++i) lmp.push_back(pw[i]);
+    }
+    if (covgpu_pgo_reanchor(ctx, (int32_t)kfs.size(), pose_old.data(), f.pose.data(), vel.data(), (int32_t)lms.size(), ref.data(),
+                            lmp.data()) != COVGPU_OK)
+      detail::fatal(covgpu_last_error());
+    covgpu_destroy(ctx);
+    for (size_t k = 0; k < kfs.size(); ++k) {
+      TransformType T;
+      detail::pose_to_transform(&f.pose[7 * k], T);
+      kfs[k]->SetPoseTws(T);  // UpdateFromCeres (:1045)
+      Vector3Type v;
+      for (int i = 0; i < 3; ++i) v[i] = vel[3 * k + i];
+      kfs[k]->SetStateVelocity(v);
+      kfs[k]->SetPoseOptimized();
+    }
+    for (size_t l = 0; l < lms.size(); ++l) {
+      Vector3Type pw;
+      for (int i = 0; i < 3; ++i) pw[i] = lmp[3 * l + i];
+      lms[l]->SetWorldPos(pw);
+      lms[l]->SetOptimized();
+    }
+    std::printf("--> PGO END \n");
+  }
+};
+
+}  // namespace covins_gpu

@@ -1,0 +1,80 @@
+"""The C++ facade (include/covins_gpu/optimization_gpu.hpp) on stand-in Map classes: its flattening must produce
+the same IR as the Python host mirror (CPU), and its GlobalBundleAdjustment / PoseGraphOptimization must leave the
+map in the same state as covins_amd.optimization.Optimization (GPU)."""
+import numpy as np
+import pytest
+
+from covins_amd import mapdata, synth
+from tests.facade_util import StandinMap
+from tests.util import rot_angle
+
+
+def _sorted_obs(ptr, kf, *cols):
+    order = np.lexsort((kf, np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))))
+    return (kf[order],) + tuple(c[order] for c in cols)
+
+
+@pytest.mark.parametrize("visual_only,round2", [(False, True), (False, False), (True, True)])
+def test_cpp_flatten_matches_python(tiny_map, visual_only, round2):
+    sm = StandinMap(tiny_map)
+    try:
+        f = sm.flatten_gba(visual_only, round2)
+        p, _ = mapdata.flatten_gba(tiny_map, visual_only, loop_loss=round2)
+        assert f["sizes"][:5] == (p.K, p.L, p.O, p.I, p.E)
+        assert np.allclose(f["pose"][:, 4:], p.kf_pose[:, 4:], atol=1e-15)
+        assert rot_angle(f["pose"][:, :4], p.kf_pose[:, :4]).max() < 1e-7  # quaternion -> 4x4 -> quaternion round trip
+        assert np.array_equal(f["fixed"], p.kf_fixed) and np.array_equal(f["lm"], p.lm_pos)
+        assert np.array_equal(f["obs_ptr"], p.lm_obs_ptr)
+        # observation order inside a landmark follows std::map<KeyframePtr,...> (pointer order) in C++
+        a = _sorted_obs(f["obs_ptr"], f["obs_kf"], f["uv"], f["sigma"])
+        b = _sorted_obs(p.lm_obs_ptr, p.obs_kf, p.obs_uv, p.obs_sigma)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        assert np.array_equal(f["imu_i"], p.imu_kf_i) and np.array_equal(f["imu_j"], p.imu_kf_j)
+        assert np.array_equal(f["ei"], p.edge_i) and np.array_equal(f["ej"], p.edge_j) and np.array_equal(f["loss"], p.edge_loss_a)
+    finally:
+        sm.close()
+
+
+@pytest.mark.gpu
+def test_cpp_gba_matches_python_facade():
+    from covins_amd.optimization import Optimization
+    cfg = synth.config_named("tiny"); cfg.outlier_frac = 0.03
+    m = synth.make_map(cfg)
+    sm = StandinMap(m)
+    try:
+        sm.gba(10, visual_only=False, outlier_removal=True)
+        st = sm.state()
+    finally:
+        sm.close()
+    mp = m.copy()
+    info = Optimization.GlobalBundleAdjustment(mp, 10, -1.0, False, True, False)
+    assert info["outliers_removed"] > 0
+    assert np.abs(st["pose"][:, 4:] - mp.kf_pose[:, 4:]).max() < 1e-6
+    assert rot_angle(st["pose"][:, :4], mp.kf_pose[:, :4]).max() < 1e-6
+    assert np.abs(st["vel"] - mp.kf_velocity).max() < 1e-6
+    d = np.abs(st["lm"] - mp.lm_pos).max(axis=1)
+    assert np.median(d) < 1e-7 and d.max() < 1e-2
+    assert st["gba"].all() and mp.kf_gba_optimized.all()
+    assert np.array_equal(st["lm_nobs"], np.diff(mp.lm_obs_ptr))          # same observations erased
+    assert np.array_equal(st["lm_invalid"].astype(bool), mp.lm_invalid)   # same landmarks cleaned
+
+
+@pytest.mark.gpu
+def test_cpp_pgo_matches_python_facade():
+    from covins_amd.optimization import Optimization
+    cfg = synth.config_named("tiny"); cfg.drift_trans = 0.05; cfg.drift_yaw_deg = 0.5
+    m = synth.make_map(cfg)
+    corrected = {m.K - 1: m.truth["kf_pose"][m.K - 1].copy()}
+    sm = StandinMap(m)
+    try:
+        sm.pgo(corrected)
+        st = sm.state()
+    finally:
+        sm.close()
+    mp = m.copy()
+    Optimization.PoseGraphOptimization(mp, corrected)
+    assert np.abs(st["pose"][:, 4:] - mp.kf_pose[:, 4:]).max() < 1e-6
+    assert rot_angle(st["pose"][:, :4], mp.kf_pose[:, :4]).max() < 1e-6
+    assert np.abs(st["vel"] - mp.kf_velocity).max() < 1e-6
+    assert np.abs(st["lm"] - mp.lm_pos).max() < 1e-6

@@ -4,9 +4,10 @@ oracle on the same seeded inputs. Tolerances (FP64 end t
   preintegration deltas, J, P  <= 1e-11
   whitened IMU blocks          <= 1e-8   (chol(P)^-1 amplifies rounding by cond(chol P) ~ 1e4)
   Schur complement S, b        <= 1e-9   (FP64 atomics: summation order differs run to run)
-  final poses after equal iteration counts  <= 1e-6 m / 1e-7 rad; landmarks: median <= 1e-7 m, 99.5 % <= 1e-5 m,
-  max <= 1e-2 m (a handful of landmarks with near-degenerate parallax have an H_ll that is singular along the
-  viewing ray up to the 1e-8 damping; the atomics' rounding noise moves them along that ray only)
+  final poses after equal iteration counts  <= 1e-6 m / 1e-7 rad; landmarks: median <= 1e-7 m, max <= 1e-2 m, and
+  for EVERY landmark sqrt(d^T H_ll d) <= 1e-4 (difference measured in whitened-pixel units: landmarks with
+  near-degenerate parallax have an H_ll that is almost singular along the viewing ray, so the atomics' rounding
+  noise moves them along that ray by up to millimetres without changing any reprojection by 1e-4 sigma)
 """
 import numpy as np
 import pytest
@@ -142,7 +143,7 @@ def test_schur_pgo(ctx, small_map):
     assert rel_err(S, S0) < 1e-10 and rel_err(b, b0) < 1e-10 and abs(c - c0) < 1e-12 * c0
 
 
-@pytest.mark.parametrize("n", [1, 100, 128, 129, 700])
+@pytest.mark.parametrize("n", [1, 100, 128, 129, 300, 700, 1100, 2600])
 def test_mfma_cholesky_solve(ctx, n):
     rng = np.random.default_rng(n)
     A = rng.normal(0, 1, (n, n + 5))
@@ -177,7 +178,19 @@ def test_mfma_cholesky_ill_scaled(ctx):
     assert rc == 0 and np.max(np.abs(x - x0) * d) < 1e-8 * np.max(np.abs(x0) * d)
 
 
-def _compare_solution(sol, ref, res, rres, pos_tol=1e-6, ang_tol=1e-7, lm_tol=1e-2):
+def _lm_whitened_diff(sol, ref, o):
+    """sqrt(d^T H_ll d) per landmark, H_ll from the oracle's linearisation at the oracle's solution."""
+    _, _, Jl, _ = covo.linearize_reprojection(ref, o)
+    Jl = Jl.reshape(-1, 2, 3)
+    obs_lm = np.repeat(np.arange(ref.L), np.diff(ref.lm_obs_ptr))
+    d = (sol.lm_pos - ref.lm_pos)[obs_lm]
+    jd = np.einsum("oij,oj->oi", Jl, d)
+    q = np.zeros(ref.L)
+    np.add.at(q, obs_lm, (jd ** 2).sum(1))
+    return np.sqrt(q)
+
+
+def _compare_solution(sol, ref, res, rres, o, pos_tol=1e-6, ang_tol=1e-7, lm_tol=1e-2):
     assert res.iterations == rres.iterations and res.accepted == rres.accepted and res.termination == rres.termination
     assert abs(res.initial_cost - rres.initial_cost) <= 1e-10 * rres.initial_cost
     tr, tr0 = np.array(res.cost_trace[:res.iterations]), np.array(rres.cost_trace[:rres.iterations])
@@ -187,7 +200,8 @@ def _compare_solution(sol, ref, res, rres, pos_tol=1e-6, ang_tol=1e-7, lm_tol=1e
     assert rot_angle(sol.kf_pose[:, :4], ref.kf_pose[:, :4]).max() < ang_tol
     if sol.L:
         d = np.abs(sol.lm_pos - ref.lm_pos).max(axis=1)
-        assert d.max() < lm_tol and np.median(d) < 1e-7 and np.quantile(d, 0.995) < 1e-5
+        assert d.max() < lm_tol and np.median(d) < 1e-7
+        assert _lm_whitened_diff(sol, ref, o).max() < 1e-4
     assert abs(res.final_cost - rres.final_cost) <= 1e-8 * rres.final_cost
 
 
@@ -197,7 +211,7 @@ def test_gba_solve_matches_oracle(ctx, tiny_vi, strategy, visual_only):
     g, o = opts(strategy=strategy, visual_only=visual_only)
     sol, res = ctx.gba_solve(tiny_vi, g)
     ref, rres = covo.gba_solve(tiny_vi, o)
-    _compare_solution(sol, ref, res, rres)
+    _compare_solution(sol, ref, res, rres, o)
     if not visual_only:
         assert np.abs(sol.kf_speed_bias - ref.kf_speed_bias).max() < 1e-6
     else:
@@ -210,7 +224,7 @@ def test_gba_solve_small_map(ctx, small_vi):
     g, o = opts()
     sol, res = ctx.gba_solve(small_vi, g)
     ref, rres = covo.gba_solve(small_vi, o)
-    _compare_solution(sol, ref, res, rres)
+    _compare_solution(sol, ref, res, rres, o)
     assert res.final_cost < 1e-4 * res.initial_cost
 
 
@@ -231,7 +245,7 @@ def test_pgo_solve_matches_oracle(ctx):
         g, o = opts(strategy=strategy)
         sol, res = ctx.pgo_solve(p, g)
         ref, rres = covo.gba_solve(p, o, pgo=True)
-        _compare_solution(sol, ref, res, rres)
+        _compare_solution(sol, ref, res, rres, o)
         assert res.final_cost < res.initial_cost
 
 

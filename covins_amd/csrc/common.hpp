@@ -5,8 +5,10 @@
 //     camera [A][..]): K, A are tiny (<= ~20k rows) and stay L2-resident, each gather is one 24-72 B row;
 //   * the observation stream is struct-of-arrays (kf index i32, lm index i32, u, v, sigma f64), grouped by
 //     landmark exactly as the IR delivers it, so a wave reads 64 consecutive records fully coalesced;
-//   * the reduced camera system S is one dense row-major lower-triangular FP64 matrix of padded order
-//     npad (multiple of 128), 15 (VI) or 6 (visual-only / PGO) rows per keyframe in IR keyframe order;
+//   * the reduced camera system is stored STRUCTURED: the pose-pose part C is one dense
+//     row-major lower-triangular FP64 matrix of padded order npad (multiple of 128), 6 rows per keyframe in
+//     chain-major order perm[]; the speed-bias part is block-tridiagonal along each agent's IMU chain
+//     (Ad, Ae: 9x9 per keyframe) and couples to at most three pose blocks (Bp, Bs, Bn: 9x6 per keyframe);
 //   * all vectors of the trust-region step (gradient, diag(J^T J), Gauss-Newton step, step, scratch) are
 //     length N = n + 3 L with the pose part first, so norms and combinations are single flat kernels.
 #pragma once
@@ -56,9 +58,25 @@ struct DevProblem {
   int *edge_i, *edge_j;
   double *edge_meas, *edge_sqrt_info, *edge_loss_a;
 
-  // normal equations
-  double* Sred;    // [npad][npad] lower triangle used
-  double* bred;    // [npad] reduced right-hand side, overwritten by the solution
+  // keyframe ordering of the linear system: IMU chains (one per agent) laid out back to back
+  int nchains;
+  int* perm;        // [K]   keyframe -> position in chain-major order (identity when !vi)
+  int* pos_kf;      // [K]   position -> keyframe
+  int* chain_ptr;   // [nchains+1] positions of each chain
+  int* pos_chain_end;  // [K] position -> end position (exclusive) of its chain
+
+  // normal equations (after landmark elimination)
+  double* Sred;    // [npad][npad] pose-pose matrix C, lower triangle used, rows 6*perm[k]+r
+  double* bred;    // [n] right-hand side in IR layout (D per keyframe); solution is written to gn
+  double *Ad, *Ae;          // [K][81] speed-bias diagonal / sub-diagonal (pos, pos-1) blocks, by position
+  double *Bp, *Bs, *Bn;     // [K][54] speed-bias(pos) x pose(pos-1 | pos | pos+1) blocks (9x6)
+  double *Ld, *Ldinv, *Lsub;  // [K][81] block-bidiagonal Cholesky factor of the speed-bias part
+  double* Yt;      // [npad][ldY] (L_A^-1 B)^T: pose rows x speed-bias columns, zero outside the chain trapezoids
+  int ldY;
+  double* zs;      // [9K]  L_A^-1 b_s
+  double* xs;      // [9K]  speed-bias solution (chain order)
+  double* bp;      // [2 npad] pose right-hand side / solution of the dense stage (+ scratch half)
+  int *tile_cs, *tile_ce;   // [npad/128] non-zero column range of each 128-row tile of Yt
   double* grad;    // [N]  J^T r           (pose part, then landmark part)
   double* hdiag;   // [N]  diag(J^T J)
   double* HllInv;  // [L][6] damped inverse landmark blocks (xx xy xz yy yz zz)
@@ -73,6 +91,7 @@ struct DevProblem {
 // ---- scalar slots in DevProblem::scal
 enum { SC_COST = 0, SC_JV2 = 1, SC_GG = 2, SC_GN2 = 3, SC_GDOT = 4, SC_GMAX = 5, SC_GS = 6, SC_SN2 = 7, SC_XN2 = 8, SC_COUNT = 16 };
 
+struct CholAux;
 // ---- launchers (each enqueues on `st`, no synchronisation)
 void launch_lm_build(const DevProblem& P, double mu, hipStream_t st);     // reprojection -> Hll, g, S (Schur), bred, cost
 void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st);
@@ -93,6 +112,10 @@ void launch_edge_cost(const DevProblem& P, const double* pose, hipStream_t st);
 void launch_edge_linearize(const DevProblem& P, double* r, double* J, double* cost, hipStream_t st);
 
 void launch_finalize_diag(const DevProblem& P, double mu, hipStream_t st);
+// structured solve of the damped reduced system: speed-bias chains -> dense pose system -> back-substitution.
+// Solution (IR layout, D per keyframe) is written to dst[0..n).
+void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax);
+void launch_yty_update(const DevProblem& P, hipStream_t st);  // C -= Yt Yt^T on the MFMA path (k_chol.hip)
 void launch_zero_system(const DevProblem& P, hipStream_t st);
 // per-context resources of the dense factorisation: auxiliary stream for the look-ahead, ordering events, and
 // (profiling only) one timed event pair around every bulk trailing-update launch
@@ -108,7 +131,6 @@ struct CholAux {
   void collect();
 };
 // dense SPD solve of Sred x = bred in place (lower Cholesky on the FP64 MFMA path); flag[0] != 0 on failure
-void launch_dense_cholesky_solve(const DevProblem& P, hipStream_t st, CholAux& ax);
 void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax);
 
 void launch_dogleg_stats(const DevProblem& P, hipStream_t st);  // GG, GN2, GDOT, GMAX from grad/hdiag/gn

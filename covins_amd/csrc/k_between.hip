@@ -84,22 +84,23 @@ __global__ __launch_bounds__(64) void k_edge_build(DevProblem P) {
   double r[6], J[72];
   const double cost = eval_edge<true>(P, P.pose, e, r, J);
   atomicAdd(&P.scal[SC_COST], cost);
-  const int idx[2] = {P.D * P.edge_i[e], P.D * P.edge_j[e]};
+  const int idx[2] = {P.D * P.edge_i[e], P.D * P.edge_j[e]};                       // IR layout (grad / bred / hdiag)
+  const int cix[2] = {6 * P.perm[P.edge_i[e]], 6 * P.perm[P.edge_j[e]]};           // pose rows of C
   const size_t ld = (size_t)P.npad;
   for (int a = 0; a < 12; ++a) {
-    const int ra = idx[a / 6] + a % 6;
+    const int ra = idx[a / 6] + a % 6, ca = cix[a / 6] + a % 6;
     double ga = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) ga += J[12 * k + a] * r[k];
     if (ga != 0.0) { atomicAdd(P.grad + ra, ga); atomicAdd(P.bred + ra, -ga); }
     for (int b = 0; b < 12; ++b) {
-      const int rb = idx[b / 6] + b % 6;
-      if (rb > ra) continue;
+      const int cb = cix[b / 6] + b % 6;
+      if (cb > ca) continue;
       double h = 0.0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) h += J[12 * k + a] * J[12 * k + b];
       if (h == 0.0) continue;
-      atomicAdd(P.Sred + (size_t)ra * ld + rb, h);
+      atomicAdd(P.Sred + (size_t)ca * ld + cb, h);
       if (a == b) atomicAdd(P.hdiag + ra, h);
     }
   }

@@ -31,7 +31,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int KC = 16;        // K chunk staged through LDS
 constexpr int LDT = KC + 1;   // LDS pitch (doubles): odd pitch -> conflict-free fragment reads
 
-enum { MODE_SYRK_TRI = 0, MODE_SYRK_RECT = 1, MODE_TRSM = 2 };
+enum { MODE_SYRK_TRI = 0, MODE_SYRK_RECT = 1, MODE_TRSM = 2, MODE_YTY = 3 };
 
 struct GemmArgs {
   double* M; size_t ld;
@@ -41,6 +41,8 @@ struct GemmArgs {
   int cc0;            // C tile at (ra0 + ti*128, cc0 + tj*128)   (TRI: == ra0; TRSM: == kcol0, tj = 0)
   int nt;             // tile rows (TRI: triangle order)
   const double* Linv; // TRSM: B = Linv (128x128, pitch 128)
+  // YTY: C(ti,tj) -= Yt[ti rows] Yt[tj rows]^T over the intersection of the two row tiles' non-zero column ranges
+  const double* Y; size_t ldy; const int* tile_cs; const int* tile_ce;
 };
 
 // C[i][j] (op)= sum_k A[i][k] B[j][k] on one 128x128 tile.
@@ -60,8 +62,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
   } else if (MODE == MODE_SYRK_RECT) {
     ti = blockIdx.y; tj = blockIdx.x;
     if (g.ra0 + ti * kTile < g.cc0 + tj * kTile) return;  // strictly above the diagonal
+  } else if (MODE == MODE_YTY) {
+    ti = blockIdx.y; tj = blockIdx.x;
+    if (tj > ti) return;
   } else {
     ti = blockIdx.x; tj = 0;
+  }
+  int kbeg = 0, kend = g.KD;
+  if (MODE == MODE_YTY) {
+    kbeg = max(g.tile_cs[ti], g.tile_cs[tj]); kend = min(g.tile_ce[ti], g.tile_ce[tj]);
+    if (kbeg >= kend) return;  // the two tiles' keyframes share no IMU chain segment
   }
   extern __shared__ __attribute__((aligned(16))) double smem[];  // 2 x [128][KC+1] doubles
   double (*sA)[LDT] = reinterpret_cast<double (*)[LDT]>(smem);
@@ -69,11 +79,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const size_t ld = g.ld;
-  const double* Ag = g.M + (size_t)(g.ra0 + ti * kTile) * ld + g.kcol0;
-  const double* Bg;
-  size_t ldb;
-  if (MODE == MODE_TRSM) { Bg = g.Linv; ldb = kTile; }
-  else { Bg = g.M + (size_t)(g.rb0 + tj * kTile) * ld + g.kcol0; ldb = ld; }
+  const double *Ag, *Bg;
+  size_t lda, ldb;
+  if (MODE == MODE_YTY) {
+    Ag = g.Y + (size_t)(ti * kTile) * g.ldy; Bg = g.Y + (size_t)(tj * kTile) * g.ldy; lda = ldb = g.ldy;
+  } else {
+    Ag = g.M + (size_t)(g.ra0 + ti * kTile) * ld + g.kcol0; lda = ld;
+    if (MODE == MODE_TRSM) { Bg = g.Linv; ldb = kTile; }
+    else { Bg = g.M + (size_t)(g.rb0 + tj * kTile) * ld + g.kcol0; ldb = ld; }
+  }
   double* Cg = g.M + (size_t)(g.ra0 + ti * kTile) * ld + (size_t)(g.cc0 + tj * kTile);
   // staging map: KC/2 lanes cover one KC-double row segment (contiguous), 512/KC rows per pass
   constexpr int LPR = KC / 2, RPP = 256 / LPR, NPASS = kTile / RPP;
@@ -83,11 +97,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
 #pragma unroll
     for (int it = 0; it < NPASS; ++it) {
       const int row = rbase + RPP * it;
-      pa[it] = *reinterpret_cast<const double2*>(Ag + (size_t)row * ld + kc + c2);
+      pa[it] = *reinterpret_cast<const double2*>(Ag + (size_t)row * lda + kc + c2);
       pb[it] = *reinterpret_cast<const double2*>(Bg + (size_t)row * ldb + kc + c2);
     }
   };
-  gload(0);
+  gload(kbeg);
   const int fr = lane & 15, fk = lane >> 4;
   // f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
   v4f64 acc[4][4];
@@ -101,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
         else acc[tm][tn][rg] = Cg[(size_t)(wr * 64 + tm * 16 + fk + 4 * rg) * ld + wc * 64 + tn * 16 + fr];
       }
   const double sgn = (MODE == MODE_TRSM) ? 1.0 : -1.0;  // SYRK: acc = C - A B^T through a negated A fragment
-  for (int kc = 0; kc < g.KD; kc += KC) {
+  for (int kc = kbeg; kc < kend; kc += KC) {
     __syncthreads();  // previous chunk fully consumed
 #pragma unroll
     for (int it = 0; it < NPASS; ++it) {
@@ -110,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
       sB[row][c2] = pb[it].x; sB[row][c2 + 1] = pb[it].y;
     }
     __syncthreads();
-    if (kc + KC < g.KD) gload(kc + KC);  // prefetch the next chunk while the matrix cores work
+    if (kc + KC < kend) gload(kc + KC);  // prefetch the next chunk while the matrix cores work
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 4) {
       double a[4], b[4];
@@ -134,40 +148,67 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
         Cg[(size_t)(wr * 64 + tm * 16 + fk + 4 * rg) * ld + wc * 64 + tn * 16 + fr] = acc[tm][tn][rg];
 }
 
-// Factor the 128x128 diagonal block at (k0,k0) in LDS (lower Cholesky) and form its inverse.
+// Factor the 128x128 diagonal block at (k0,k0) (lower Cholesky) and form its inverse.
 // L (lower incl. diagonal) is written back into M; L^-1 (lower, zeros above) goes to Linv_out [128][128].
+//
+// Cholesky: right-looking, the matrix lives in REGISTERS — thread (ty,tx) of the 16x16 grid owns the 8x8 elements
+// (r = ty + 16 i, c = tx + 16 k); only the pivot column travels through LDS each step. (Keeping the matrix in LDS
+// and updating it in place serialises on LDS read-after-write: measured 260 us per block instead of ~40.)
 __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_t ld, int k0, double* __restrict__ Linv_out, int* flag) {
   extern __shared__ __attribute__((aligned(16))) double s[];  // [128][129]
+  __shared__ double col[kTile];
+  __shared__ double piv;
   constexpr int PT = kTile + 1;
   const int tid = threadIdx.x;
-  double* Mg = M + (size_t)k0 * ld + k0;
-  for (int idx = tid; idx < kTile * kTile; idx += 256) {
-    const int r = idx >> 7, c = idx & 127;
-    s[r * PT + c] = (c <= r) ? Mg[(size_t)r * ld + c] : 0.0;
-  }
   const int ty = tid >> 4, tx = tid & 15;
-  for (int j = 0; j < kTile; ++j) {
-    __syncthreads();
-    double d = s[j * PT + j];
-    if (!(d > 0.0)) { if (tid == 0) atomicOr(flag, 1); d = 1.0; }
-    const double sd = sqrt(d), inv = 1.0 / sd;
-    __syncthreads();
-    if (tid < kTile) {
-      if (tid == j) s[j * PT + j] = sd;
-      else if (tid > j) s[tid * PT + j] *= inv;
+  double* Mg = M + (size_t)k0 * ld + k0;
+  double a[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = ty + 16 * i, c = tx + 16 * k;
+      a[i][k] = (c <= r) ? Mg[(size_t)r * ld + c] : 0.0;
     }
-    __syncthreads();
-    for (int r = j + 1 + ty; r < kTile; r += 16) {
-      const double lr = s[r * PT + j];
-      for (int c = j + 1 + tx; c <= r; c += 16) s[r * PT + c] -= lr * s[c * PT + j];
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = 16 * jb + jj;
+      if (ty == jj && tx == jj) piv = a[jb][jb];
+      __syncthreads();
+      double d = piv;
+      if (!(d > 0.0)) { if (tid == 0) atomicOr(flag, 1); d = 1.0; }
+      if (tx == jj) {  // owners of column j
+        const double sd = sqrt(d), inv = 1.0 / sd;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = ty + 16 * i;
+          if (r == j) a[i][jb] = sd;
+          else if (r > j) a[i][jb] *= inv;
+          col[r] = (r > j) ? a[i][jb] : 0.0;
+        }
+      }
+      __syncthreads();
+      double cr[8], cc[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { cr[i] = col[ty + 16 * i]; cc[i] = col[tx + 16 * i]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k > jb || (k == jb && tx > jj)) a[i][k] -= cr[i] * cc[k];  // columns c > j only (col[] is 0 for rows <= j)
     }
   }
+  // L -> LDS (lower) and back to HBM
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = ty + 16 * i, c = tx + 16 * k;
+      s[r * PT + c] = (c <= r) ? a[i][k] : 0.0;
+      if (c <= r) Mg[(size_t)r * ld + c] = a[i][k];
+    }
   __syncthreads();
-  // L is final: write it back now; from here on the LDS copy is turned into L^-1 in place.
-  for (int idx = tid; idx < kTile * kTile; idx += 256) {
-    const int r = idx >> 7, c = idx & 127;
-    if (c <= r) Mg[(size_t)r * ld + c] = s[r * PT + c];
-  }
   // ---- inverse by recursive doubling: 8x8 diagonal blocks in registers, then for h = 8,16,32,64 every pair
   //      [[A,0],[C,B]] -> [[A^-1,0],[-B^-1 C A^-1, B^-1]]. T = C A^-1 is parked in the (unused) mirrored upper
   //      block, X21 overwrites C. All dot products are independent: no serial LDS chain longer than h.
@@ -318,14 +359,14 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   auto trsm = [&](int t) {  // rows below tile t, columns of tile t
     const int rem = T - t - 1;
     if (rem <= 0) return;
-    GemmArgs g{S, ld, t * kTile, kTile, (t + 1) * kTile, 0, t * kTile, rem, Linv + (size_t)t * kTile * kTile};
+    GemmArgs g{S, ld, t * kTile, kTile, (t + 1) * kTile, 0, t * kTile, rem, Linv + (size_t)t * kTile * kTile, nullptr, 0, nullptr, nullptr};
     hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(rem), dim3(256), lds_gemm, st, g);
   };
   // C tiles in tile-columns [tc0, tc0+ntc) (rows >= tc0) -= A[:, kcols] A[tc.., kcols]^T
   auto rect = [&](int tc0, int ntc, int kt0, int KD, hipStream_t s2) {
     const int ntr = T - tc0;
     if (ntr <= 0 || ntc <= 0) return;
-    GemmArgs g{S, ld, kt0 * kTile, KD, tc0 * kTile, tc0 * kTile, tc0 * kTile, ntr, nullptr};
+    GemmArgs g{S, ld, kt0 * kTile, KD, tc0 * kTile, tc0 * kTile, tc0 * kTile, ntr, nullptr, nullptr, 0, nullptr, nullptr};
     hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, ntr), dim3(256), lds_gemm, s2, g);
   };
 
@@ -349,7 +390,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     (void)hipStreamWaitEvent(ax.aux, eA[P], 0);
     if (nt > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
-      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr};
+      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, 0, nullptr, nullptr};
       if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], ax.aux);
       hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk), dim3(256), lds_gemm, ax.aux, g);
       if (ax.profile) {
@@ -372,8 +413,17 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   }
 }
 
-void launch_dense_cholesky_solve(const DevProblem& P, hipStream_t st, CholAux& ax) {
-  dense_cholesky_solve_raw(P.Sred, P.bred, P.Linv, P.flag, P.npad, st, ax);
+// C -= Yt Yt^T: second Schur complement (speed-bias chains eliminated) on the matrix cores
+void launch_yty_update(const DevProblem& P, hipStream_t st) {
+  const size_t lds_gemm = (size_t)2 * kTile * LDT * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_YTY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
+    attr_set = true;
+  }
+  const int T = P.npad / kTile;
+  GemmArgs g{P.Sred, (size_t)P.npad, 0, 0, 0, 0, 0, T, nullptr, P.Yt, (size_t)P.ldY, P.tile_cs, P.tile_ce};
+  hipLaunchKernelGGL(k_gemm_abt<MODE_YTY>, dim3(T, T), dim3(256), lds_gemm, st, g);
 }
 
 }  // namespace covgpu

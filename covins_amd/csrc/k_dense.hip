@@ -17,14 +17,19 @@ namespace covgpu {
 using namespace covdev;
 
 // ------------------------------------------------------------------------------------------- vector kernels
+// add the trust-region damping mu * clamp(diag)^2 to every active diagonal entry of the structured system;
+// constant / unconstrained dimensions (diag(J^T J) == 0) become identity rows with zero right-hand side (A.6)
 __global__ __launch_bounds__(256) void k_finalize_diag(DevProblem P, double mu) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= P.npad) return;
-  double* d = P.Sred + (size_t)q * P.npad + q;
-  if (q >= P.n) { *d = 1.0; P.bred[q] = 0.0; return; }
-  const double h = P.hdiag[q];
-  if (h == 0.0) { *d = 1.0; P.bred[q] = 0.0; }  // constant / unconstrained dimension (A.6)
-  else { const double c = clamp_diag(h); *d += mu * c * c; }
+  if (q < P.n) {
+    const int kf = q / P.D, r = q - kf * P.D, pos = P.perm[kf];
+    double* d = (r < 6) ? P.Sred + (size_t)(6 * pos + r) * P.npad + (6 * pos + r) : P.Ad + (size_t)81 * pos + 10 * (r - 6);
+    const double h = P.hdiag[q];
+    if (h == 0.0) { *d = 1.0; P.bred[q] = 0.0; }
+    else { const double c = clamp_diag(h); *d += mu * c * c; }
+  }
+  const int pad = 6 * P.K + q;  // padding rows of C
+  if (q < P.npad - 6 * P.K) P.Sred[(size_t)pad * P.npad + pad] = 1.0;
 }
 
 COV_DEV void block_reduce_atomic(double v, double* dst, bool is_max = false) {
@@ -112,11 +117,19 @@ static inline int vec_grid(int n) {
 }
 
 void launch_finalize_diag(const DevProblem& P, double mu, hipStream_t st) {
-  hipLaunchKernelGGL(k_finalize_diag, dim3((P.npad + 255) / 256), dim3(256), 0, st, P, mu);
+  const int cnt = P.n > P.npad ? P.n : P.npad;
+  hipLaunchKernelGGL(k_finalize_diag, dim3((cnt + 255) / 256), dim3(256), 0, st, P, mu);
 }
 void launch_zero_system(const DevProblem& P, hipStream_t st) {
   hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), st);
-  hipMemsetAsync(P.bred, 0, (size_t)2 * P.npad * sizeof(double), st);
+  hipMemsetAsync(P.bred, 0, (size_t)P.n * sizeof(double), st);
+  if (P.vi) {
+    hipMemsetAsync(P.Ad, 0, (size_t)81 * P.K * sizeof(double), st);
+    hipMemsetAsync(P.Ae, 0, (size_t)81 * P.K * sizeof(double), st);
+    hipMemsetAsync(P.Bp, 0, (size_t)54 * P.K * sizeof(double), st);
+    hipMemsetAsync(P.Bs, 0, (size_t)54 * P.K * sizeof(double), st);
+    hipMemsetAsync(P.Bn, 0, (size_t)54 * P.K * sizeof(double), st);
+  }
   hipMemsetAsync(P.grad, 0, (size_t)P.N * sizeof(double), st);
   hipMemsetAsync(P.hdiag, 0, (size_t)P.N * sizeof(double), st);
   hipMemsetAsync(P.scal + SC_COST, 0, sizeof(double), st);

@@ -240,20 +240,33 @@ __global__ __launch_bounds__(64) void k_imu_build(DevProblem P) {
   double cost = 0.0;
   for (int k = 0; k < 15; ++k) cost += r[k] * r[k];
   atomicAdd(&P.scal[SC_COST], 0.5 * cost);
-  const int idx[2] = {15 * i, 15 * j};
+  // Scatter J^T J (30x30; groups P_i(0:6) S_i(6:15) P_j(15:21) S_j(21:30)) into the structured system:
+  //   pose-pose  -> C (dense, chain-major order);  sb-sb -> Ad / Ae;  sb-pose -> Bs / Bn / Bp   
+  // By construction of perm[], j sits right after i on the same chain: pj == pi + 1.
+  const int pi = P.perm[i], pj = P.perm[j];
   for (int a = 0; a < 30; ++a) {
-    const int ra = idx[a / 15] + a % 15;
+    const int ga_ = a / 15, la = a % 15;                 // keyframe (0 = i, 1 = j), local dim
+    const int ra = 15 * (ga_ ? j : i) + la;
     double ga = 0.0;
     for (int k = 0; k < 15; ++k) ga += Jw[30 * k + a] * r[k];
     if (ga != 0.0) { atomicAdd(P.grad + ra, ga); atomicAdd(P.bred + ra, -ga); }
     for (int b = 0; b < 30; ++b) {
-      const int rb = idx[b / 15] + b % 15;
-      if (rb > ra) continue;  // lower triangle only
+      const int gb_ = b / 15, lb = b % 15;
       double h = 0.0;
       for (int k = 0; k < 15; ++k) h += Jw[30 * k + a] * Jw[30 * k + b];
       if (h == 0.0) continue;
-      atomicAdd(P.Sred + (size_t)ra * ld + rb, h);
       if (a == b) atomicAdd(P.hdiag + ra, h);
+      const int posa = ga_ ? pj : pi, posb = gb_ ? pj : pi;
+      if (la < 6 && lb < 6) {          // pose-pose: lower triangle of C
+        const int ca = 6 * posa + la, cb = 6 * posb + lb;
+        if (cb <= ca) atomicAdd(P.Sred + (size_t)ca * ld + cb, h);
+      } else if (la >= 6 && lb >= 6) { // sb-sb: full diagonal blocks, sub-diagonal block (pos_j, pos_i)
+        if (ga_ == gb_) atomicAdd(P.Ad + (size_t)81 * posa + 9 * (la - 6) + (lb - 6), h);
+        else if (ga_ == 1) atomicAdd(P.Ae + (size_t)81 * pj + 9 * (la - 6) + (lb - 6), h);
+      } else if (la >= 6) {            // sb (row) x pose (col)
+        double* blk = (ga_ == gb_) ? P.Bs : (ga_ == 0 ? P.Bn : P.Bp);   // same kf | sb_i x pose_j (next) | sb_j x pose_i (prev)
+        atomicAdd(blk + (size_t)54 * posa + 6 * (la - 6) + lb, h);
+      }
     }
   }
 }

@@ -221,8 +221,9 @@ __global__ __launch_bounds__(kBuildThreads) void k_lm_build(DevProblem P, double
         Y[3 * r + 2] = W[3 * r] * hi[2] + W[3 * r + 1] * hi[4] + W[3 * r + 2] * hi[5];
       }
       if (!P.fixed[kf]) {
-        const size_t base = (size_t)(D * kf);
-        double* Sd = P.Sred + base * ld + base;
+        const size_t base = (size_t)(D * kf);          // IR layout of grad / bred / hdiag
+        const size_t cb = (size_t)6 * P.perm[kf];      // pose block of C in chain-major order
+        double* Sd = P.Sred + cb * ld + cb;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
 #pragma unroll
@@ -265,8 +266,9 @@ __global__ __launch_bounds__(kBuildThreads) void k_lm_build(DevProblem P, double
         for (int t = 0; t < nt; ++t) {
           const double* Wt = sW[grp][t];
           const int kft = (int)Wt[18];
-          if (kft > kf || P.fixed[kft]) continue;
-          double* Sb = P.Sred + (size_t)(D * kf) * ld + (size_t)(D * kft);
+          const int pa = P.perm[kf], pt = P.perm[kft];
+          if (pt > pa || P.fixed[kft]) continue;       // lower triangle of C in chain-major order
+          double* Sb = P.Sred + (size_t)(6 * pa) * ld + (size_t)(6 * pt);
           const bool diag = kft == kf;
 #pragma unroll
           for (int c = 0; c < 6; ++c) {

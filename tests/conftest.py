@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the oracle's OpenMP loops are tiny in the tests: on a 128-core GPU host the default team size only adds overhead
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -132,7 +132,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {len(cfg.agents)}-agent EuRoC MH-shaped merged map per GPU, visual-inertial GBA "
                                    f"(K={prob.K} keyframes, L={prob.L} landmarks, O={prob.O} observations, I={prob.I} IMU factors, "
-                                   f"E={prob.E} loop edges; reduced system n={n})",
+                                   f"E={prob.E} loop edges; reduced camera system 15K={n}: speed-bias chains eliminated block-tridiagonally, "
+                                   f"dense MFMA Cholesky on the 6K={6 * prob.K} pose system)",
                        "strategy": args.strategy, "iterations_per_step": args.iterations, "sharding": "one map per GPU"},
             "kf_per_s": k_free * iters_all / dt,
             "iterations_executed": iters_all,
@@ -140,11 +141,12 @@ def main():
             "ate_rmse_m": {"initial": synth.ate_rmse(prob.kf_pose[:, 4:], truth), "final": synth.ate_rmse(sol.kf_pose[:, 4:], truth)},
             "phase_ms_per_iteration": {"linearise+schur": prof["build_ms"] / max(prof["n_build"], 1),
                                        "factor+solve": prof["factor_ms"] / max(prof["n_factor"], 1)},
-            "roofline": {"kernel": "k_gemm_abt<SYRK> (trailing update of the dense FP64 Cholesky, v_mfma_f64_16x16x4_f64)",
+            "roofline": {"kernel": "k_gemm_abt<SYRK_TRI> (rank-256 trailing update of the dense FP64 Cholesky, v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
                          "launches": prof["n_syrk"], "avg_launch_ms": prof["syrk_ms"] / max(prof["n_syrk"], 1),
-                         "whole_factorisation_tflops": (n ** 3 / 3.0) / (prof["factor_ms"] / max(prof["n_factor"], 1) * 1e-3) / 1e12
+                         "dense_stage_order": 6 * prob.K,
+                         "dense_factorisation_tflops_incl_panels_and_solves": ((6.0 * prob.K) ** 3 / 3.0) / (prof["factor_ms"] / max(prof["n_factor"], 1) * 1e-3) / 1e12
                          if prof["factor_ms"] > 0 else 0.0},
             "roofline_build": {"kernel": "k_lm_build (linearise + Schur)", "bound": "hbm",
                                "achieved": b_build / (prof["build_ms"] / max(prof["n_build"], 1) * 1e-3) / 1e9 if prof["build_ms"] > 0 else 0.0,

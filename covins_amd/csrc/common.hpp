@@ -71,12 +71,12 @@ struct DevProblem {
   double *Ad, *Ae;          // [K][81] speed-bias diagonal / sub-diagonal (pos, pos-1) blocks, by position
   double *Bp, *Bs, *Bn;     // [K][54] speed-bias(pos) x pose(pos-1 | pos | pos+1) blocks (9x6)
   double *Ld, *Ldinv, *Lsub;  // [K][81] block-bidiagonal Cholesky factor of the speed-bias part
-  double* Yt;      // [npad][ldY] (L_A^-1 B)^T: pose rows x speed-bias columns, zero outside the chain trapezoids
-  int ldY;
+  double* Y;       // [nyrows][npad] Y = L_A^-1 B: speed-bias rows (chain order) x pose columns, zero outside the chain trapezoids
+  int nyrows;      // 9K rounded up to a multiple of 16
   double* zs;      // [9K]  L_A^-1 b_s
   double* xs;      // [9K]  speed-bias solution (chain order)
   double* bp;      // [2 npad] pose right-hand side / solution of the dense stage (+ scratch half)
-  int *tile_cs, *tile_ce;   // [npad/128] non-zero column range of each 128-row tile of Yt
+  int *tile_cs, *tile_ce;   // [npad/128] non-zero row (speed-bias) range of each 128-column tile of Y
   double* grad;    // [N]  J^T r           (pose part, then landmark part)
   double* hdiag;   // [N]  diag(J^T J)
   double* HllInv;  // [L][6] damped inverse landmark blocks (xx xy xz yy yz zz)
@@ -115,7 +115,7 @@ void launch_finalize_diag(const DevProblem& P, double mu, hipStream_t st);
 // structured solve of the damped reduced system: speed-bias chains -> dense pose system -> back-substitution.
 // Solution (IR layout, D per keyframe) is written to dst[0..n).
 void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax);
-void launch_yty_update(const DevProblem& P, hipStream_t st);  // C -= Yt Yt^T on the MFMA path (k_chol.hip)
+void launch_yty_update(const DevProblem& P, hipStream_t st);  // C -= Y^T Y on the MFMA path (k_chol.hip)
 void launch_zero_system(const DevProblem& P, hipStream_t st);
 // per-context resources of the dense factorisation: auxiliary stream for the look-ahead, ordering events, and
 // (profiling only) one timed event pair around every bulk trailing-update launch

@@ -28,6 +28,14 @@ using namespace covdev;
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// phase timers for tools/potrf_probe.hip (never defined in the product build)
+#ifdef COVGPU_PROBE
+__device__ long long g_probe[8];
+#define PROBE(i) do { if (threadIdx.x == 0) g_probe[i] = wall_clock64(); } while (0)
+#else
+#define PROBE(i) do {} while (0)
+#endif
+
 constexpr int KC = 16;        // K chunk staged through LDS
 constexpr int LDT = KC + 1;   // LDS pitch (doubles): odd pitch -> conflict-free fragment reads
 
@@ -41,7 +49,7 @@ struct GemmArgs {
   int cc0;            // C tile at (ra0 + ti*128, cc0 + tj*128)   (TRI: == ra0; TRSM: == kcol0, tj = 0)
   int nt;             // tile rows (TRI: triangle order)
   const double* Linv; // TRSM: B = Linv (128x128, pitch 128)
-  // YTY: C(ti,tj) -= Yt[ti rows] Yt[tj rows]^T over the intersection of the two row tiles' non-zero column ranges
+  // YTY: C(ti,tj) -= Y[:, ti cols]^T Y[:, tj cols] over the intersection of the two tiles' non-zero K (speed-bias) ranges
   const double* Y; size_t ldy; const int* tile_cs; const int* tile_ce;
 };
 
@@ -82,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
   const double *Ag, *Bg;
   size_t lda, ldb;
   if (MODE == MODE_YTY) {
-    Ag = g.Y + (size_t)(ti * kTile) * g.ldy; Bg = g.Y + (size_t)(tj * kTile) * g.ldy; lda = ldb = g.ldy;
+    Ag = g.Y + (size_t)(ti * kTile); Bg = g.Y + (size_t)(tj * kTile); lda = ldb = g.ldy;
   } else {
     Ag = g.M + (size_t)(g.ra0 + ti * kTile) * ld + g.kcol0; lda = ld;
     if (MODE == MODE_TRSM) { Bg = g.Linv; ldb = kTile; }
@@ -96,9 +104,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
   auto gload = [&](int kc) {
 #pragma unroll
     for (int it = 0; it < NPASS; ++it) {
-      const int row = rbase + RPP * it;
-      pa[it] = *reinterpret_cast<const double2*>(Ag + (size_t)row * lda + kc + c2);
-      pb[it] = *reinterpret_cast<const double2*>(Bg + (size_t)row * ldb + kc + c2);
+      if (MODE == MODE_YTY) {
+        // Y is K-major ([sb dim][pose dim]): one K row of the tile is 1 KiB contiguous -> 64 lanes x 16 B
+        const int idx = tid + 256 * it, krow = idx >> 6, i2 = (idx & 63) * 2;
+        pa[it] = *reinterpret_cast<const double2*>(Ag + (size_t)(kc + krow) * lda + i2);
+        pb[it] = *reinterpret_cast<const double2*>(Bg + (size_t)(kc + krow) * ldb + i2);
+      } else {
+        const int row = rbase + RPP * it;
+        pa[it] = *reinterpret_cast<const double2*>(Ag + (size_t)row * lda + kc + c2);
+        pb[it] = *reinterpret_cast<const double2*>(Bg + (size_t)row * ldb + kc + c2);
+      }
     }
   };
   gload(kbeg);
@@ -119,9 +134,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
     __syncthreads();  // previous chunk fully consumed
 #pragma unroll
     for (int it = 0; it < NPASS; ++it) {
-      const int row = rbase + RPP * it;
-      sA[row][c2] = sgn * pa[it].x; sA[row][c2 + 1] = sgn * pa[it].y;
-      sB[row][c2] = pb[it].x; sB[row][c2 + 1] = pb[it].y;
+      if (MODE == MODE_YTY) {  // transpose on the way into LDS
+        const int idx = tid + 256 * it, krow = idx >> 6, i2 = (idx & 63) * 2;
+        sA[i2][krow] = sgn * pa[it].x; sA[i2 + 1][krow] = sgn * pa[it].y;
+        sB[i2][krow] = pb[it].x; sB[i2 + 1][krow] = pb[it].y;
+      } else {
+        const int row = rbase + RPP * it;
+        sA[row][c2] = sgn * pa[it].x; sA[row][c2 + 1] = sgn * pa[it].y;
+        sB[row][c2] = pb[it].x; sB[row][c2 + 1] = pb[it].y;
+      }
     }
     __syncthreads();
     if (kc + KC < kend) gload(kc + KC);  // prefetch the next chunk while the matrix cores work
@@ -163,6 +184,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_
   const int ty = tid >> 4, tx = tid & 15;
   double* Mg = M + (size_t)k0 * ld + k0;
   double a[8][8];
+  PROBE(0);
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -170,8 +192,10 @@ __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_
       const int r = ty + 16 * i, c = tx + 16 * k;
       a[i][k] = (c <= r) ? Mg[(size_t)r * ld + c] : 0.0;
     }
+  PROBE(1);
 #pragma unroll
-  for (int jb = 0; jb < 8; ++jb) {
+  for (int jb = 0; jb < 8; ++jb) {  // unrolled: static register indices; the 16-step inner loop must stay rolled
+#pragma unroll 1                    // (fully unrolled it is 22k instructions — far beyond the 64 KiB instruction cache)
     for (int jj = 0; jj < 16; ++jj) {
       const int j = 16 * jb + jj;
       if (ty == jj && tx == jj) piv = a[jb][jb];
@@ -179,7 +203,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_
       double d = piv;
       if (!(d > 0.0)) { if (tid == 0) atomicOr(flag, 1); d = 1.0; }
       if (tx == jj) {  // owners of column j
-        const double sd = sqrt(d), inv = 1.0 / sd;
+        const double inv = rsqrt(d), sd = d * inv;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int r = ty + 16 * i;
@@ -195,10 +219,11 @@ __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (k > jb || (k == jb && tx > jj)) a[i][k] -= cr[i] * cc[k];  // columns c > j only (col[] is 0 for rows <= j)
+        for (int k = 0; k < 8; ++k)  // columns c > j only (col[] is 0 for rows <= j); register tiles with k > i lie above the diagonal
+          if (k <= i && (k > jb || (k == jb && tx > jj))) a[i][k] -= cr[i] * cc[k];
     }
   }
+  PROBE(2);
   // L -> LDS (lower) and back to HBM
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -209,6 +234,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_
       if (c <= r) Mg[(size_t)r * ld + c] = a[i][k];
     }
   __syncthreads();
+  PROBE(3);
   // ---- inverse by recursive doubling: 8x8 diagonal blocks in registers, then for h = 8,16,32,64 every pair
   //      [[A,0],[C,B]] -> [[A^-1,0],[-B^-1 C A^-1, B^-1]]. T = C A^-1 is parked in the (unused) mirrored upper
   //      block, X21 overwrites C. All dot products are independent: no serial LDS chain longer than h.
@@ -241,25 +267,37 @@ __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_
     for (int idx = tid; idx < total; idx += 256) {  // T = C A^-1
       const int pr = idx / hh, rem = idx - pr * hh, r = rem / h, c = rem - r * h, base = 2 * pr * h;
       const double* Crow = s + (base + h + r) * PT + base;
-      double sum = 0.0;
-      for (int k = c; k < h; ++k) sum += Crow[k] * s[(base + k) * PT + base + c];
-      s[(base + c) * PT + base + h + r] = sum;
+      const double* Acol = s + base * PT + base + c;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // independent partial sums: LDS latency overlaps
+      int k = c;
+      for (; k + 3 < h; k += 4) {
+        s0 += Crow[k] * Acol[k * PT]; s1 += Crow[k + 1] * Acol[(k + 1) * PT];
+        s2 += Crow[k + 2] * Acol[(k + 2) * PT]; s3 += Crow[k + 3] * Acol[(k + 3) * PT];
+      }
+      for (; k < h; ++k) s0 += Crow[k] * Acol[k * PT];
+      s[(base + c) * PT + base + h + r] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     for (int idx = tid; idx < total; idx += 256) {  // X21 = -B^-1 T
       const int pr = idx / hh, rem = idx - pr * hh, r = rem / h, c = rem - r * h, base = 2 * pr * h;
       const double* Brow = s + (base + h + r) * PT + base + h;
       const double* Tcol = s + (base + c) * PT + base + h;
-      double sum = 0.0;
-      for (int k = 0; k <= r; ++k) sum += Brow[k] * Tcol[k];
-      s[(base + h + r) * PT + base + c] = -sum;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int k = 0;
+      for (; k + 3 <= r; k += 4) {
+        s0 += Brow[k] * Tcol[k]; s1 += Brow[k + 1] * Tcol[k + 1]; s2 += Brow[k + 2] * Tcol[k + 2]; s3 += Brow[k + 3] * Tcol[k + 3];
+      }
+      for (; k <= r; ++k) s0 += Brow[k] * Tcol[k];
+      s[(base + h + r) * PT + base + c] = -((s0 + s1) + (s2 + s3));
     }
   }
   __syncthreads();
+  PROBE(4);
   for (int idx = tid; idx < kTile * kTile; idx += 256) {
     const int r = idx >> 7, c = idx & 127;
     Linv_out[idx] = (c <= r) ? s[r * PT + c] : 0.0;
   }
+  PROBE(5);
 }
 
 // forward substitution step for panel p:  y_p = Linv_p b_p ; b[rows below] -= L[rows, panel p] y_p
@@ -413,7 +451,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   }
 }
 
-// C -= Yt Yt^T: second Schur complement (speed-bias chains eliminated) on the matrix cores
+// C -= Y^T Y: second Schur complement (speed-bias chains eliminated) on the matrix cores
 void launch_yty_update(const DevProblem& P, hipStream_t st) {
   const size_t lds_gemm = (size_t)2 * kTile * LDT * sizeof(double);
   static bool attr_set = false;
@@ -422,7 +460,7 @@ void launch_yty_update(const DevProblem& P, hipStream_t st) {
     attr_set = true;
   }
   const int T = P.npad / kTile;
-  GemmArgs g{P.Sred, (size_t)P.npad, 0, 0, 0, 0, 0, T, nullptr, P.Yt, (size_t)P.ldY, P.tile_cs, P.tile_ce};
+  GemmArgs g{P.Sred, (size_t)P.npad, 0, 0, 0, 0, 0, T, nullptr, P.Y, (size_t)P.npad, P.tile_cs, P.tile_ce};
   hipLaunchKernelGGL(k_gemm_abt<MODE_YTY>, dim3(T, T), dim3(256), lds_gemm, st, g);
 }
 

@@ -10,11 +10,11 @@
 // 15.6x fewer. This is what a fill-reducing sparse Cholesky (the reference's SPARSE_SCHUR -> CHOLMOD,
 // optimization_be.cpp:561) obtains from the same sparsity; the result is the exact solve, just reordered.
 //
-//   sb_chain_factor   one workgroup per IMU chain, sequential over keyframes: L_kk L_kk^T = Ad_k - Lsub Lsub^T,
-//                     Lsub_{k+1} = Ae_{k+1} L_kk^-T, and the rows of Y = L_A^-1 B and z = L_A^-1 b_s, stored
-//                     transposed (Yt: pose rows x speed-bias columns) so that C -= Yt Yt^T is the ABT GEMM form
-//   pose_rhs          b'_p = b_p - Yt z
-//   (k_chol.hip)      C -= Yt Yt^T restricted to each tile pair's common chain segment; dense Cholesky of C'
+//   sb_chain_factor   one wave per IMU chain, sequential over keyframes: L_kk L_kk^T = Ad_k - Lsub Lsub^T,
+//                     Lsub_{k+1} = Ae_{k+1} L_kk^-T, z = L_A^-1 b_s
+//   sb_chain_cols     Y = L_A^-1 B, one thread per pose dimension marching down its chain (K-major, coalesced)
+//   pose_rhs          b'_p = b_p - Y^T z
+//   (k_chol.hip)      C -= Y^T Y restricted to each tile pair's common chain segment; dense Cholesky of C'
 //   sb_backsolve      x_s = A^-1 (b_s - B x_p) with the stored bidiagonal factor, one wave per chain
 #include "common.hpp"
 #include "dev_math.hpp"
@@ -40,135 +40,138 @@ __global__ __launch_bounds__(256) void k_scatter_solution(DevProblem P, double* 
   dst[q] = (r < 6) ? P.bp[6 * pos + r] : P.xs[9 * pos + (r - 6)];
 }
 
-// One workgroup per chain. Sequential block-tridiagonal Cholesky + forward substitution of B's columns and b_s.
-__global__ __launch_bounds__(256) void k_sb_chain_factor(DevProblem P) {
-  __shared__ double sM[81], sL[81], sLinv[81], sSub[81], sNext[81];
-  __shared__ double sz[9];
-  const int tid = threadIdx.x;
+// One 64-lane workgroup (a single wave) per chain: the sequential part only — block-bidiagonal Cholesky of the
+// speed-bias system and z = L_A^-1 b_s. ~10 LDS round trips per keyframe; everything that is parallel over the
+// columns of B lives in k_sb_chain_cols.
+__global__ __launch_bounds__(64) void k_sb_chain_factor(DevProblem P) {
+  __shared__ double sM[81], sX[81], sSub[81];
+  __shared__ double sz[9], sv[9];
+  const int lane = threadIdx.x;
   const int p0 = P.chain_ptr[blockIdx.x], p1 = P.chain_ptr[blockIdx.x + 1];
-  if (tid < 81) sSub[tid] = 0.0;
-  if (tid < 9) sz[tid] = 0.0;
+  for (int e = lane; e < 81; e += 64) sSub[e] = 0.0;
+  if (lane < 9) sz[lane] = 0.0;
   __syncthreads();
   for (int pos = p0; pos < p1; ++pos) {
-    const int t = pos - p0;
-    // (1) M = Ad - Lsub Lsub^T
-    if (tid < 81) {
-      const int a = tid / 9, b = tid - 9 * a;
-      double m = P.Ad[(size_t)81 * pos + tid];
-      if (t > 0)
+    // M = Ad - Lsub Lsub^T
+    for (int e = lane; e < 81; e += 64) {
+      const int a = e / 9, b = e - 9 * a;
+      double m = P.Ad[(size_t)81 * pos + e];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) m -= sSub[9 * a + k] * sSub[9 * b + k];
-      sM[tid] = m;
+      for (int k = 0; k < 9; ++k) m -= sSub[9 * a + k] * sSub[9 * b + k];
+      sM[e] = m;
     }
     __syncthreads();
-    // (2) 9x9 Cholesky and inverse of the factor (serial: 9x9 is latency-, not throughput-bound)
-    if (tid == 0) {
-      double L[81], X[81];
-      bool ok = true;
-      for (int k = 0; k < 81; ++k) { L[k] = 0.0; X[k] = 0.0; }
-      for (int c = 0; c < 9; ++c) {
-        double d = sM[10 * c];
-        for (int k = 0; k < c; ++k) d -= L[9 * c + k] * L[9 * c + k];
-        if (!(d > 0.0)) { ok = false; d = 1.0; }
-        d = sqrt(d);
-        L[10 * c] = d;
-        for (int r = c + 1; r < 9; ++r) {
-          double s2 = sM[9 * r + c];
-          for (int k = 0; k < c; ++k) s2 -= L[9 * r + k] * L[9 * c + k];
-          L[9 * r + c] = s2 / d;
-        }
+    // in-place lower Cholesky of the 9x9 block, lanes = (row, col) of the trailing 8x8 update
+    bool ok = true;
+    for (int c = 0; c < 9; ++c) {
+      double d = sM[10 * c];
+      if (!(d > 0.0)) { ok = false; d = 1.0; }
+      const double inv = rsqrt(d);
+      __syncthreads();
+      if (lane == c) sM[10 * c] = d * inv;
+      else if (lane > c && lane < 9) sM[9 * lane + c] *= inv;
+      __syncthreads();
+      const int r = 1 + (lane >> 3), cc = 1 + (lane & 7);
+      if (r > c && cc > c && cc <= r) sM[9 * r + cc] -= sM[9 * r + c] * sM[9 * cc + c];
+      __syncthreads();
+    }
+    if (!ok && lane == 0) atomicOr(P.flag, 1);
+    // X = L^-1 (lower): lane = column, forward substitution down the rows
+    if (lane < 9) {
+      const int c = lane;
+      double x[9];
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) sum += (k >= c) ? sM[9 * r + k] * x[k] : 0.0;
+        x[r] = (r == c) ? 1.0 / sM[10 * r] : (r > c ? -sum / sM[10 * r] : 0.0);
       }
-      for (int c = 0; c < 9; ++c) {
-        X[10 * c] = 1.0 / L[10 * c];
-        for (int r = c + 1; r < 9; ++r) {
-          double s2 = 0.0;
-          for (int k = c; k < r; ++k) s2 += L[9 * r + k] * X[9 * k + c];
-          X[9 * r + c] = -s2 / L[10 * r];
-        }
-      }
-      if (!ok) atomicOr(P.flag, 1);
-      for (int k = 0; k < 81; ++k) { sL[k] = L[k]; sLinv[k] = X[k]; }
+#pragma unroll
+      for (int r = 0; r < 9; ++r) sX[9 * r + c] = x[r];
+      // z_pos = X (b_s - Lsub z_prev): first the bracket
+      double v = P.xs[(size_t)9 * pos + lane];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v -= sSub[9 * lane + k] * sz[k];
+      sv[lane] = v;
     }
     __syncthreads();
-    if (tid < 81) {
-      P.Ld[(size_t)81 * pos + tid] = sL[tid];
-      P.Ldinv[(size_t)81 * pos + tid] = sLinv[tid];
-      P.Lsub[(size_t)81 * pos + tid] = sSub[tid];
-      // (4) next sub-diagonal block L_{pos+1,pos} = Ae_{pos+1} L_kk^-T   (computed now, published after step 3)
-      double v = 0.0;
-      if (pos + 1 < p1) {
-        const int a = tid / 9, b = tid - 9 * a;
-        const double* Ae = P.Ae + (size_t)81 * (pos + 1);
-#pragma unroll
-        for (int c = 0; c < 9; ++c) v += Ae[9 * a + c] * sLinv[9 * b + c];
-      }
-      sNext[tid] = v;
+    for (int e = lane; e < 81; e += 64) {
+      const int a = e / 9, b = e - 9 * a;
+      P.Ld[(size_t)81 * pos + e] = (b <= a) ? sM[e] : 0.0;
+      P.Ldinv[(size_t)81 * pos + e] = sX[e];
+      P.Lsub[(size_t)81 * pos + e] = sSub[e];
     }
-    // (3) rows of Y and z at this position. Column (q, e) = pose dim e of chain position q; non-zero for q <= t+1.
-    const int ncol = 6 * min(t + 2, p1 - p0);
-    for (int jc = tid; jc <= ncol; jc += 256) {
-      double v[9];
-      if (jc == ncol) {  // right-hand side column
+    double znew = 0.0;
+    if (lane < 9) {
+      for (int k = 0; k <= lane; ++k) znew += sX[9 * lane + k] * sv[k];
+      P.zs[(size_t)9 * pos + lane] = znew;
+    }
+    // next sub-diagonal block L_{pos+1,pos} = Ae_{pos+1} L_kk^-T
+    double nxt[2] = {0.0, 0.0};
+    if (pos + 1 < p1) {
+      const double* Ae = P.Ae + (size_t)81 * (pos + 1);
+      int u = 0;
+      for (int e = lane; e < 81; e += 64, ++u) {
+        const int a = e / 9, b = e - 9 * a;
+        double v = 0.0;
 #pragma unroll
-        for (int a = 0; a < 9; ++a) v[a] = P.xs[(size_t)9 * pos + a];
-        if (t > 0)
-#pragma unroll
-          for (int a = 0; a < 9; ++a)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) v[a] -= sSub[9 * a + k] * sz[k];
-      } else {
-        const int q = jc / 6, e = jc - 6 * q;
-        const double* Bblk = (q == t - 1) ? P.Bp : (q == t ? P.Bs : (q == t + 1 ? P.Bn : nullptr));
-#pragma unroll
-        for (int a = 0; a < 9; ++a) v[a] = Bblk ? Bblk[(size_t)54 * pos + 6 * a + e] : 0.0;
-        if (t > 0 && q <= t) {
-          const double* yprev = P.Yt + (size_t)(6 * (p0 + q) + e) * P.ldY + (size_t)9 * (pos - 1);
-          double yp[9];
-#pragma unroll
-          for (int k = 0; k < 9; ++k) yp[k] = yprev[k];
-#pragma unroll
-          for (int a = 0; a < 9; ++a)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) v[a] -= sSub[9 * a + k] * yp[k];
-        }
-      }
-      double y[9];
-#pragma unroll
-      for (int a = 0; a < 9; ++a) {
-        double s2 = 0.0;
-#pragma unroll
-        for (int k = 0; k <= a; ++k) s2 += sLinv[9 * a + k] * v[k];
-        y[a] = s2;
-      }
-      if (jc == ncol) {
-#pragma unroll
-        for (int a = 0; a < 9; ++a) P.zs[(size_t)9 * pos + a] = y[a];
-      } else {
-        const int q = jc / 6, e = jc - 6 * q;
-        double* yo = P.Yt + (size_t)(6 * (p0 + q) + e) * P.ldY + (size_t)9 * pos;
-#pragma unroll
-        for (int a = 0; a < 9; ++a) yo[a] = y[a];
+        for (int c = 0; c < 9; ++c) v += Ae[9 * a + c] * sX[9 * b + c];
+        nxt[u] = v;
       }
     }
-    __threadfence_block();
     __syncthreads();
-    if (tid < 81) sSub[tid] = sNext[tid];
-    if (tid < 9) sz[tid] = P.zs[(size_t)9 * pos + tid];
+    { int u = 0; for (int e = lane; e < 81; e += 64, ++u) sSub[e] = nxt[u]; }
+    if (lane < 9) sz[lane] = znew;
     __syncthreads();
   }
 }
 
-// b'_p[row] = b_p[row] - sum_k Yt[row][k] z[k] over the row's chain segment. One wave per row.
+// Columns of Y = L_A^-1 B: one thread per pose dimension (column), marching down its chain from the first
+// keyframe whose speed-bias block touches it. Y is K-major, so a wave's 64 columns are written coalesced.
+__global__ __launch_bounds__(256) void k_sb_chain_cols(DevProblem P) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= 6 * P.K) return;
+  const int q = col / 6, e = col - 6 * q;      // chain position of the pose, component
+  const int p1 = P.pos_chain_end[q];
+  const int pstart = (q > 0 && P.pos_chain_end[q - 1] == p1) ? q - 1 : q;  // previous position if it is on the same chain
+  double y[9];
+#pragma unroll
+  for (int a = 0; a < 9; ++a) y[a] = 0.0;
+  for (int pos = pstart; pos < p1; ++pos) {
+    double v[9];
+    const double* Bblk = (pos == q - 1) ? P.Bn : (pos == q ? P.Bs : (pos == q + 1 ? P.Bp : nullptr));
+#pragma unroll
+    for (int a = 0; a < 9; ++a) v[a] = Bblk ? Bblk[(size_t)54 * pos + 6 * a + e] : 0.0;
+    if (pos > pstart) {
+      const double* Ls = P.Lsub + (size_t)81 * pos;
+#pragma unroll
+      for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[a] -= Ls[9 * a + k] * y[k];
+    }
+    const double* Li = P.Ldinv + (size_t)81 * pos;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+      double s2 = 0.0;
+#pragma unroll
+      for (int k = 0; k <= a; ++k) s2 += Li[9 * a + k] * v[k];
+      y[a] = s2;
+    }
+#pragma unroll
+    for (int a = 0; a < 9; ++a) P.Y[(size_t)(9 * pos + a) * P.npad + col] = y[a];
+  }
+}
+
+// b'_p[col] = b_p[col] - sum_k Y[k][col] z[k] over the column's chain segment; thread per column, coalesced in col.
 __global__ __launch_bounds__(256) void k_pose_rhs(DevProblem P) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= 6 * P.K) return;
-  const int pos = row / 6;
-  const int kb = 9 * max(pos - 1, 0), ke = 9 * P.pos_chain_end[pos];
-  const double* y = P.Yt + (size_t)row * P.ldY;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= 6 * P.K) return;
+  const int q = col / 6;
+  const int kb = 9 * max(q - 1, 0), ke = 9 * P.pos_chain_end[q];
   double acc = 0.0;
-  for (int k = kb + lane; k < ke; k += 64) acc += y[k] * P.zs[k];
-  acc = wave_sum(acc);
-  if (lane == 0) P.bp[row] -= acc;
+  for (int k = kb; k < ke; ++k) acc += P.Y[(size_t)k * P.npad + col] * P.zs[k];
+  P.bp[col] -= acc;
 }
 
 // x_s = A^-1 (b_s - B x_p): w = b_s - B x_p, forward with (Ldinv, Lsub), backward with their transposes.
@@ -231,8 +234,9 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
   const int cnt = P.npad > 9 * P.K ? P.npad : 9 * P.K;
   hipLaunchKernelGGL(k_gather_rhs, dim3((cnt + 255) / 256), dim3(256), 0, st, P);
   if (P.vi) {
-    hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(k_pose_rhs, dim3((6 * P.K + 3) / 4), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(k_sb_chain_cols, dim3((6 * P.K + 255) / 256), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_pose_rhs, dim3((6 * P.K + 255) / 256), dim3(256), 0, st, P);
     launch_yty_update(P, st);
   }
   dense_cholesky_solve_raw(P.Sred, P.bp, P.Linv, P.flag, P.npad, st, ax);

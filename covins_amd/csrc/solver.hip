@@ -190,14 +190,14 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   P.nchains = (int)chain_ptr.size() - 1;
   for (int c = 0; c < P.nchains; ++c)
     for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) chain_end[q] = chain_ptr[c + 1];
-  P.ldY = ((9 * P.K + 15) / 16) * 16;
+  P.nyrows = ((9 * P.K + 15) / 16) * 16;
   const int T = P.npad / kTile;
   std::vector<int> tcs(T, 0), tce(T, 0);
   for (int t = 0; t < T; ++t) {
     if (kTile * t >= 6 * P.K) continue;
     const int pmin = (kTile * t) / 6, pmax = std::min((kTile * t + kTile - 1) / 6, P.K - 1);
     tcs[t] = (9 * std::max(pmin - 1, 0)) / 16 * 16;
-    tce[t] = std::min(P.ldY, (9 * chain_end[pmax] + 15) / 16 * 16);
+    tce[t] = std::min(P.nyrows, (9 * chain_end[pmax] + 15) / 16 * 16);
   }
   P.reproj_loss_a = opt->reproj_loss_a; P.gravity = opt->gravity;
   const size_t K = P.K;
@@ -253,8 +253,8 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_alloc(c, &P.Bp, 54 * Kv)); RC(dev_alloc(c, &P.Bs, 54 * Kv)); RC(dev_alloc(c, &P.Bn, 54 * Kv));
   RC(dev_alloc(c, &P.Ld, 81 * Kv)); RC(dev_alloc(c, &P.Ldinv, 81 * Kv)); RC(dev_alloc(c, &P.Lsub, 81 * Kv));
   RC(dev_alloc(c, &P.zs, 9 * Kv)); RC(dev_alloc(c, &P.xs, 9 * Kv));
-  RC(dev_alloc(c, &P.Yt, vi ? (size_t)P.npad * P.ldY : 0));
-  if (vi) HIPCHK(hipMemsetAsync(P.Yt, 0, (size_t)P.npad * P.ldY * sizeof(double), c->st));  // only the chain trapezoids are ever written
+  RC(dev_alloc(c, &P.Y, vi ? (size_t)P.nyrows * P.npad : 0));
+  if (vi) HIPCHK(hipMemsetAsync(P.Y, 0, (size_t)P.nyrows * P.npad * sizeof(double), c->st));  // only the chain trapezoids are ever written
   RC(dev_alloc(c, &P.grad, (size_t)P.N)); RC(dev_alloc(c, &P.hdiag, (size_t)P.N));
   RC(dev_alloc(c, &P.HllInv, (size_t)6 * P.L));
   RC(dev_alloc(c, &P.gn, (size_t)P.N)); RC(dev_alloc(c, &P.step, (size_t)P.N)); RC(dev_alloc(c, &P.vtmp, (size_t)P.N));

@@ -45,6 +45,15 @@ struct DevProblem {
   int *lm_obs_ptr, *obs_kf, *obs_lm;
   double *obs_u, *obs_v, *obs_sigma;
 
+  // keyframe-major view of the observations and covisible-pair lists (static per problem, built at upload)
+  int *kf_obs_ptr, *kf_obs_idx;             // [K+1], [O]
+  int npairs;
+  int *pair_ptr, *pair_i, *pair_j;          // [npairs+1], [npairs] chain-major positions, i > j
+  int *pair_oa, *pair_ob;                   // [sum] observation of keyframe i / keyframe j of each common landmark
+  double *obsW, *obsY;                      // [O][18] per-observation W = Jp^T Jl and Y = W Hll^-1
+  double *obsP;                             // [O][39] per-observation pose-side record (k_visual.hip)
+  double *cost_part;                        // per-block cost partials
+
   // IMU factors
   int *imu_i, *imu_j, *imu_ptr;
   double *imu_samples, *imu_first;

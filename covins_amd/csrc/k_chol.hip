@@ -353,7 +353,11 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, 
 }
 
 void CholAux::init() {
-  if (!aux) (void)hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);
+  if (!aux) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    (void)hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, lo);  // bulk updates: lowest dispatch priority
+  }
 }
 void CholAux::destroy() {
   for (auto e : ev) (void)hipEventDestroy(e);

@@ -163,15 +163,19 @@ __global__ __launch_bounds__(256) void k_sb_chain_cols(DevProblem P) {
   }
 }
 
-// b'_p[col] = b_p[col] - sum_k Y[k][col] z[k] over the column's chain segment; thread per column, coalesced in col.
+// b'_p[col] = b_p[col] - sum_k Y[k][col] z[k] over the column's chain segment. 8 lanes share a column (interleaved
+// k), combined by a fixed-order butterfly: deterministic, and 8x more loads in flight than one thread per column.
 __global__ __launch_bounds__(256) void k_pose_rhs(DevProblem P) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= 6 * P.K) return;
-  const int q = col / 6;
-  const int kb = 9 * max(q - 1, 0), ke = 9 * P.pos_chain_end[q];
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int col = gid >> 3, part = gid & 7;
   double acc = 0.0;
-  for (int k = kb; k < ke; ++k) acc += P.Y[(size_t)k * P.npad + col] * P.zs[k];
-  P.bp[col] -= acc;
+  if (col < 6 * P.K) {
+    const int q = col / 6;
+    const int kb = 9 * max(q - 1, 0), ke = 9 * P.pos_chain_end[q];
+    for (int k = kb + part; k < ke; k += 8) acc += P.Y[(size_t)k * P.npad + col] * P.zs[k];
+  }
+  acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+  if (part == 0 && col < 6 * P.K) P.bp[col] -= acc;
 }
 
 // x_s = A^-1 (b_s - B x_p): w = b_s - B x_p, forward with (Ldinv, Lsub), backward with their transposes.
@@ -236,7 +240,7 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
   if (P.vi) {
     hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, st, P);
     hipLaunchKernelGGL(k_sb_chain_cols, dim3((6 * P.K + 255) / 256), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(k_pose_rhs, dim3((6 * P.K + 255) / 256), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_pose_rhs, dim3((8 * 6 * P.K + 255) / 256), dim3(256), 0, st, P);
     launch_yty_update(P, st);
   }
   dense_cholesky_solve_raw(P.Sred, P.bp, P.Linv, P.flag, P.npad, st, ax);

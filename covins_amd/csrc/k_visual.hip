@@ -136,32 +136,34 @@ COV_DEV void inv3sym(const double* h, double* o) {
 constexpr int kBuildThreads = 256;
 
 // ------------------------------------------------------------------------------------------------------------
-// lm_build: per landmark  H_ll, g_l (reduced in-group), damped inverse, then per observation a:
-//   S[kf_a,kf_a] += Jp^T Jp   g[kf_a] += Jp^T r   bred[kf_a] += -Jp^T r + Y_a g_l      (Y_a = W_a Hinv, W_a = Jp^T Jl)
-//   S[kf_a,kf_t] -= Y_a W_t^T  for every observation t of the same landmark with kf_t <= kf_a (lower triangle)
+// Landmark elimination in three deterministic, atomic-free passes:
+//   k_lm_lin      (landmark-major) per landmark H_ll, g_l reduced in-group, damped inverse; per observation a
+//                 record {W_a = Jp^T Jl, Y_a = W_a Hinv, D_a = Jp^T Jp - Y_a W_a^T, diag(Jp^T Jp), Jp^T r, Y_a g_l}
+//   k_kf_reduce   (keyframe-major) one wave per keyframe sums its observations' records in a fixed order ->
+//                 diagonal block of C, gradient, reduced right-hand side, diag(J^T J)
+//   k_pair_blocks (covisible keyframe pair-major) one wave per pair (i > j in chain-major order):
+//                 C[i,j] = -sum over common landmarks of Y_i W_j^T, written with plain stores
+// Every entry of C is produced by exactly one wave in a fixed summation order: run-to-run bit-identical
+// (SURVEY.md §7 "irregular graph": determinism needed for parity tests) and no FP64 atomic contention.
 // ------------------------------------------------------------------------------------------------------------
+constexpr int kRec = 39;  // per-observation pose-side record: D(21, lower row-major) hd(6) gp(6) yg(6)
+
 template <int G>
-__global__ __launch_bounds__(kBuildThreads) void k_lm_build(DevProblem P, double mu) {
+__global__ __launch_bounds__(kBuildThreads) void k_lm_lin(DevProblem P, double mu) {
   constexpr int GROUPS = kBuildThreads / G;
-  __shared__ double sW[GROUPS][G][19];  // 18 W entries + kf index (as double) ; odd pitch spreads LDS banks
   const int lane = threadIdx.x % G, grp = threadIdx.x / G;
   const int l = blockIdx.x * GROUPS + grp;
   const bool lm_ok = l < P.L;
   const int o0 = lm_ok ? P.lm_obs_ptr[l] : 0;
   const int nobs = lm_ok ? P.lm_obs_ptr[l + 1] - o0 : 0;
   const int nchunk = (nobs + G - 1) / G;
-  const int D = P.D;
-  const size_t ld = (size_t)P.npad;
 
-  // pass A: H_ll, g_l, cost
   double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0}, cost = 0.0;
   ObsLin e;
   int kf = 0;
-  bool have = false;
   for (int c = 0; c < nchunk; ++c) {
     const int a = c * G + lane;
-    have = a < nobs;
-    if (have) {
+    if (a < nobs) {
       kf = P.obs_kf[o0 + a];
       eval_obs<true>(P, P.pose, P.lm, o0 + a, kf, l, e);
       h[0] += e.jl[0] * e.jl[0] + e.jl[3] * e.jl[3];
@@ -196,93 +198,108 @@ __global__ __launch_bounds__(kBuildThreads) void k_lm_build(DevProblem P, double
 #pragma unroll
     for (int k = 0; k < 6; ++k) hv[k] = hi[k];
   }
-  // block-level cost reduction: one atomic per wave
+  // per-block cost partial (summed in a fixed order by k_cost_finish)
   cost = wave_sum(cost);
-  if ((threadIdx.x & 63) == 0 && cost != 0.0) atomicAdd(&P.scal[SC_COST], cost);
+  __shared__ double scost[kBuildThreads / 64];
+  if ((threadIdx.x & 63) == 0) scost[threadIdx.x >> 6] = cost;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double c4 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kBuildThreads / 64; ++k) c4 += scost[k];
+    P.cost_part[blockIdx.x] = c4;
+  }
 
-  // pass B
-  for (int ca = 0; ca < nchunk; ++ca) {
-    const int a = ca * G + lane;
-    const bool have_a = a < nobs;
-    if (nchunk > 1 && have_a) {  // multi-chunk landmark: Jacobians of this chunk were overwritten in pass A
+  for (int c = 0; c < nchunk; ++c) {
+    const int a = c * G + lane;
+    if (a >= nobs) continue;
+    if (nchunk > 1) {  // multi-chunk landmark: this chunk's Jacobians were overwritten above
       kf = P.obs_kf[o0 + a];
       eval_obs<true>(P, P.pose, P.lm, o0 + a, kf, l, e);
     }
     double W[18], Y[18];
-    if (have_a) {
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) W[3 * r + c] = e.jp[r] * e.jl[c] + e.jp[6 + r] * e.jl[3 + c];
+      for (int cc = 0; cc < 3; ++cc) W[3 * r + cc] = e.jp[r] * e.jl[cc] + e.jp[6 + r] * e.jl[3 + cc];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        Y[3 * r + 0] = W[3 * r] * hi[0] + W[3 * r + 1] * hi[1] + W[3 * r + 2] * hi[2];
-        Y[3 * r + 1] = W[3 * r] * hi[1] + W[3 * r + 1] * hi[3] + W[3 * r + 2] * hi[4];
-        Y[3 * r + 2] = W[3 * r] * hi[2] + W[3 * r + 1] * hi[4] + W[3 * r + 2] * hi[5];
-      }
-      if (!P.fixed[kf]) {
-        const size_t base = (size_t)(D * kf);          // IR layout of grad / bred / hdiag
-        const size_t cb = (size_t)6 * P.perm[kf];      // pose block of C in chain-major order
-        double* Sd = P.Sred + cb * ld + cb;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-#pragma unroll
-          for (int c = 0; c <= r; ++c) atomicAdd(Sd + r * ld + c, e.jp[r] * e.jp[c] + e.jp[6 + r] * e.jp[6 + c]);
-          const double gr = e.jp[r] * e.r0 + e.jp[6 + r] * e.r1;
-          const double yg = Y[3 * r] * gl[0] + Y[3 * r + 1] * gl[1] + Y[3 * r + 2] * gl[2];
-          atomicAdd(P.grad + base + r, gr);
-          atomicAdd(P.bred + base + r, yg - gr);
-          atomicAdd(P.hdiag + base + r, e.jp[r] * e.jp[r] + e.jp[6 + r] * e.jp[6 + r]);
-        }
-      }
+    for (int r = 0; r < 6; ++r) {
+      Y[3 * r + 0] = W[3 * r] * hi[0] + W[3 * r + 1] * hi[1] + W[3 * r + 2] * hi[2];
+      Y[3 * r + 1] = W[3 * r] * hi[1] + W[3 * r + 1] * hi[3] + W[3 * r + 2] * hi[4];
+      Y[3 * r + 2] = W[3 * r] * hi[2] + W[3 * r + 1] * hi[4] + W[3 * r + 2] * hi[5];
     }
-    for (int cb = 0; cb < nchunk; ++cb) {
-      // publish the W blocks of chunk cb through LDS. A group never spans waves and all its lanes share one
-      // control flow (same landmark), so wave-level ordering of the in-order LDS queue is sufficient: no
-      // workgroup barrier (which would also be illegal here: trip counts differ between groups).
-      group_sync();
-      if (cb == ca) {
-        if (have_a) {
+    double* wo = P.obsW + 18 * (size_t)(o0 + a);
+    double* yo = P.obsY + 18 * (size_t)(o0 + a);
 #pragma unroll
-          for (int k = 0; k < 18; ++k) sW[grp][lane][k] = W[k];
-          sW[grp][lane][18] = (double)kf;
-        }
-      } else {
-        const int t = cb * G + lane;
-        if (t < nobs) {
-          ObsLin et;
-          const int kft = P.obs_kf[o0 + t];
-          eval_obs<true>(P, P.pose, P.lm, o0 + t, kft, l, et);
+    for (int k = 0; k < 18; ++k) { wo[k] = W[k]; yo[k] = Y[k]; }
+    double* rec = P.obsP + kRec * (size_t)(o0 + a);
+    int q = 0;
 #pragma unroll
-          for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) sW[grp][lane][3 * r + c] = et.jp[r] * et.jl[c] + et.jp[6 + r] * et.jl[3 + c];
-          sW[grp][lane][18] = (double)kft;
-        }
-      }
-      group_sync();
-      const int nt = min(G, nobs - cb * G);
-      if (have_a && !P.fixed[kf]) {
-        for (int t = 0; t < nt; ++t) {
-          const double* Wt = sW[grp][t];
-          const int kft = (int)Wt[18];
-          const int pa = P.perm[kf], pt = P.perm[kft];
-          if (pt > pa || P.fixed[kft]) continue;       // lower triangle of C in chain-major order
-          double* Sb = P.Sred + (size_t)(6 * pa) * ld + (size_t)(6 * pt);
-          const bool diag = kft == kf;
+      for (int cc = 0; cc <= r; ++cc)
+        rec[q++] = e.jp[r] * e.jp[cc] + e.jp[6 + r] * e.jp[6 + cc] - (Y[3 * r] * W[3 * cc] + Y[3 * r + 1] * W[3 * cc + 1] + Y[3 * r + 2] * W[3 * cc + 2]);
 #pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            const double w0 = Wt[3 * c], w1 = Wt[3 * c + 1], w2 = Wt[3 * c + 2];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-              if (diag && r < c) continue;
-              atomicAdd(Sb + r * ld + c, -(Y[3 * r] * w0 + Y[3 * r + 1] * w1 + Y[3 * r + 2] * w2));
-            }
-          }
-        }
-      }
+    for (int r = 0; r < 6; ++r) {
+      rec[21 + r] = e.jp[r] * e.jp[r] + e.jp[6 + r] * e.jp[6 + r];
+      rec[27 + r] = e.jp[r] * e.r0 + e.jp[6 + r] * e.r1;
+      rec[33 + r] = Y[3 * r] * gl[0] + Y[3 * r + 1] * gl[1] + Y[3 * r + 2] * gl[2];
     }
   }
+}
+
+// cost = sum of the per-block partials in index order (deterministic), added to the cost scalar
+__global__ __launch_bounds__(256) void k_cost_finish(DevProblem P, int nparts) {
+  __shared__ double sc[256];
+  double acc = 0.0;
+  for (int k = threadIdx.x; k < nparts; k += 256) acc += P.cost_part[k];
+  sc[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (threadIdx.x < s2) sc[threadIdx.x] += sc[threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(&P.scal[SC_COST], sc[0]);
+}
+
+// one wave per keyframe: fixed-order sum of its observations' records
+__global__ __launch_bounds__(256) void k_kf_reduce(DevProblem P) {
+  const int kf = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (kf >= P.K) return;
+  if (P.fixed[kf]) return;  // constant pose block: rows stay empty, finalize_diag turns them into identity
+  const int o0 = P.kf_obs_ptr[kf], o1 = P.kf_obs_ptr[kf + 1];
+  double acc = 0.0;
+  if (lane < kRec)
+    for (int t = o0; t < o1; ++t) acc += P.obsP[kRec * (size_t)P.kf_obs_idx[t] + lane];
+  const double gp = __shfl(acc, (lane >= 33 && lane < 39) ? lane - 6 : lane, 64);  // lanes 33..38 hold yg; fetch the matching gp
+  const size_t ld = (size_t)P.npad, cb = (size_t)6 * P.perm[kf], base = (size_t)P.D * kf;
+  if (lane < 21) {
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= lane) ++r;
+    const int c = lane - r * (r + 1) / 2;
+    P.Sred[(cb + r) * ld + cb + c] = acc;
+  } else if (lane < 27) {
+    P.hdiag[base + lane - 21] = acc;
+  } else if (lane < 33) {
+    P.grad[base + lane - 27] = acc;
+  } else if (lane < 39) {
+    P.bred[base + lane - 33] = acc - gp;
+  }
+}
+
+// one wave per covisible keyframe pair: lanes 0..35 = entries of the 6x6 block
+__global__ __launch_bounds__(256) void k_pair_blocks(DevProblem P) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= P.npairs || lane >= 36) return;
+  const int r = lane / 6, c = lane - 6 * r;
+  const int e0 = P.pair_ptr[p], e1 = P.pair_ptr[p + 1];
+  double acc = 0.0;
+  for (int e = e0; e < e1; ++e) {
+    const double* y = P.obsY + 18 * (size_t)P.pair_oa[e] + 3 * r;
+    const double* w = P.obsW + 18 * (size_t)P.pair_ob[e] + 3 * c;
+    acc += y[0] * w[0] + y[1] * w[1] + y[2] * w[2];
+  }
+  P.Sred[(size_t)(6 * P.pair_i[p] + r) * P.npad + 6 * P.pair_j[p] + c] = -acc;
 }
 
 // back-substitution: dl = Hinv (-g_l - sum_a W_a^T dp[kf_a]); written to out_all[n + 3l ..]
@@ -377,8 +394,11 @@ constexpr int kG = 16;
 
 void launch_lm_build(const DevProblem& P, double mu, hipStream_t st) {
   if (P.L == 0) return;
-  const int groups = kBuildThreads / kG;
-  hipLaunchKernelGGL(k_lm_build<kG>, dim3((P.L + groups - 1) / groups), dim3(kBuildThreads), 0, st, P, mu);
+  const int groups = kBuildThreads / kG, nblk = (P.L + groups - 1) / groups;
+  hipLaunchKernelGGL(k_lm_lin<kG>, dim3(nblk), dim3(kBuildThreads), 0, st, P, mu);
+  hipLaunchKernelGGL(k_cost_finish, dim3(1), dim3(256), 0, st, P, nblk);
+  hipLaunchKernelGGL(k_kf_reduce, dim3((P.K + 3) / 4), dim3(256), 0, st, P);
+  if (P.npairs) hipLaunchKernelGGL(k_pair_blocks, dim3((P.npairs + 3) / 4), dim3(256), 0, st, P);
 }
 void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st) {
   if (P.L == 0) return;

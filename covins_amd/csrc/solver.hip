@@ -74,7 +74,13 @@ extern "C" int covgpu_create(const covgpu_options* opt, covgpu_context** out) {
   c->device = opt ? opt->device : 0;
   if (c->device < 0 || c->device >= ndev) { g_err = "device ordinal out of range"; delete c; return COVGPU_ERR_INVALID_ARG; }
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamCreate(&c->st));
+  {
+    // the main stream carries the serial panel chain of the factorisation: give it dispatch priority over the
+    // auxiliary stream's bulk trailing updates (k_chol.hip look-ahead)
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIPCHK(hipStreamCreateWithPriority(&c->st, hipStreamDefault, hi));
+  }
   HIPCHK(hipHostMalloc((void**)&c->h_scal, (SC_COUNT + 4) * sizeof(double), hipHostMallocDefault));
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   std::memset(&c->P, 0, sizeof(c->P));
@@ -225,6 +231,58 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_upload(c, &P.obs_u, u.data(), (size_t)P.O));
   RC(dev_upload(c, &P.obs_v, v.data(), (size_t)P.O));
   RC(dev_upload(c, &P.obs_sigma, p->obs_sigma, (size_t)P.O));
+  // keyframe-major observation lists + covisible pair lists (fixed keyframes carry no pose block -> excluded)
+  {
+    std::vector<int> kptr(P.K + 1, 0), kidx(P.O);
+    for (int o = 0; o < P.O; ++o) kptr[p->obs_kf[o] + 1]++;
+    for (int k = 0; k < P.K; ++k) kptr[k + 1] += kptr[k];
+    { std::vector<int> cur(kptr.begin(), kptr.end() - 1); for (int o = 0; o < P.O; ++o) kidx[cur[p->obs_kf[o]]++] = o; }
+    // bucket pairs by row position i, then sort each bucket by column position j
+    std::vector<int> rowcnt(P.K + 1, 0);
+    for (int l = 0; l < P.L; ++l)
+      for (int a = p->lm_obs_ptr[l]; a < p->lm_obs_ptr[l + 1]; ++a) {
+        if (p->kf_fixed[p->obs_kf[a]]) continue;
+        const int pa = perm[p->obs_kf[a]];
+        for (int b = p->lm_obs_ptr[l]; b < p->lm_obs_ptr[l + 1]; ++b)
+          if (!p->kf_fixed[p->obs_kf[b]] && perm[p->obs_kf[b]] < pa) rowcnt[pa + 1]++;
+      }
+    for (int k = 0; k < P.K; ++k) rowcnt[k + 1] += rowcnt[k];
+    const size_t nent = (size_t)rowcnt[P.K];
+    struct Ent { int j, oa, ob; };
+    std::vector<Ent> ent(nent);
+    {
+      std::vector<int> cur(rowcnt.begin(), rowcnt.end() - 1);
+      for (int l = 0; l < P.L; ++l)
+        for (int a = p->lm_obs_ptr[l]; a < p->lm_obs_ptr[l + 1]; ++a) {
+          if (p->kf_fixed[p->obs_kf[a]]) continue;
+          const int pa = perm[p->obs_kf[a]];
+          for (int b = p->lm_obs_ptr[l]; b < p->lm_obs_ptr[l + 1]; ++b) {
+            if (p->kf_fixed[p->obs_kf[b]]) continue;
+            const int pb = perm[p->obs_kf[b]];
+            if (pb < pa) ent[cur[pa]++] = Ent{pb, a, b};
+          }
+        }
+    }
+    std::vector<int> pptr, pi, pj, oa(nent), ob(nent);
+    for (int i = 0; i < P.K; ++i) {
+      auto b0 = ent.begin() + rowcnt[i], b1 = ent.begin() + rowcnt[i + 1];
+      std::stable_sort(b0, b1, [](const Ent& x, const Ent& y) { return x.j < y.j; });  // stable: landmark order kept -> fixed summation order
+      for (auto it = b0; it != b1; ++it) {
+        const size_t e = (size_t)(it - ent.begin());
+        if (it == b0 || it->j != (it - 1)->j) { pptr.push_back((int)e); pi.push_back(i); pj.push_back(it->j); }
+        oa[e] = it->oa; ob[e] = it->ob;
+      }
+    }
+    pptr.push_back((int)nent);
+    P.npairs = (int)pi.size();
+    RC(dev_upload(c, &P.kf_obs_ptr, kptr.data(), kptr.size())); RC(dev_upload(c, &P.kf_obs_idx, kidx.data(), kidx.size()));
+    RC(dev_upload(c, &P.pair_ptr, pptr.data(), pptr.size()));
+    RC(dev_upload(c, &P.pair_i, pi.data(), pi.size())); RC(dev_upload(c, &P.pair_j, pj.data(), pj.size()));
+    RC(dev_upload(c, &P.pair_oa, oa.data(), oa.size())); RC(dev_upload(c, &P.pair_ob, ob.data(), ob.size()));
+    RC(dev_alloc(c, &P.obsW, (size_t)18 * P.O)); RC(dev_alloc(c, &P.obsY, (size_t)18 * P.O)); RC(dev_alloc(c, &P.obsP, (size_t)39 * P.O));
+    RC(dev_alloc(c, &P.cost_part, (size_t)(P.L / 4 + 64)));
+    HIPCHK(hipStreamSynchronize(c->st));
+  }
   // IMU
   RC(dev_upload(c, &P.imu_i, (const int*)p->imu_kf_i, (size_t)P.I));
   RC(dev_upload(c, &P.imu_j, (const int*)p->imu_kf_j, (size_t)P.I));

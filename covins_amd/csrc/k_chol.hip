@@ -20,6 +20,8 @@
 //     factorisation (a serial chain of small kernels) runs on the main stream while the bulk of the trailing
 //     update occupies the chip from the auxiliary stream.
 // Triangular solves reuse the stored L_pp^-1 blocks: one small launch per 128-panel.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "dev_math.hpp"
 
@@ -32,8 +34,12 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #ifdef COVGPU_PROBE
 __device__ long long g_probe[8];
 #define PROBE(i) do { if (threadIdx.x == 0) g_probe[i] = wall_clock64(); } while (0)
+#define PROBE_ACC(i, t0) do { if (threadIdx.x == 0) g_probe[i] += wall_clock64() - (t0); } while (0)
+#define PROBE_T0() wall_clock64()
 #else
 #define PROBE(i) do {} while (0)
+#define PROBE_ACC(i, t0) do {} while (0)
+#define PROBE_T0() 0
 #endif
 
 constexpr int KC = 16;        // K chunk staged through LDS
@@ -169,6 +175,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
         Cg[(size_t)(wr * 64 + tm * 16 + fk + 4 * rg) * ld + wc * 64 + tn * 16 + fr] = acc[tm][tn][rg];
 }
 
+// broadcast a double from a (compile-time / wave-uniform) lane through SGPRs: v_readlane, no LDS round trip
+COV_DEV double rdlane(double v, int srclane) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), srclane);
+  const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), srclane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // Factor the 128x128 diagonal block at (k0,k0) (lower Cholesky) and form its inverse.
 // L (lower incl. diagonal) is written back into M; L^-1 (lower, zeros above) goes to Linv_out [128][128].
 //
@@ -260,35 +274,61 @@ __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_
         if (r >= lc) s[(cb + r) * PT + c] = x[r];
     }
   }
-  for (int h = 8; h < kTile; h <<= 1) {
+  {  // level h = 8 (8 pairs of 8x8 blocks): scalar dot products
+    constexpr int h = 8;
     __syncthreads();
-    const int total = 64 * h;  // (64 / h) pairs x h x h outputs
-    const int hh = h * h;
-    for (int idx = tid; idx < total; idx += 256) {  // T = C A^-1
-      const int pr = idx / hh, rem = idx - pr * hh, r = rem / h, c = rem - r * h, base = 2 * pr * h;
+    for (int idx = tid; idx < 64 * h; idx += 256) {  // T = C A^-1
+      const int pr = idx >> 6, rem = idx & 63, r = rem >> 3, c = rem & 7, base = 2 * pr * h;
       const double* Crow = s + (base + h + r) * PT + base;
-      const double* Acol = s + base * PT + base + c;
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // independent partial sums: LDS latency overlaps
-      int k = c;
-      for (; k + 3 < h; k += 4) {
-        s0 += Crow[k] * Acol[k * PT]; s1 += Crow[k + 1] * Acol[(k + 1) * PT];
-        s2 += Crow[k + 2] * Acol[(k + 2) * PT]; s3 += Crow[k + 3] * Acol[(k + 3) * PT];
-      }
-      for (; k < h; ++k) s0 += Crow[k] * Acol[k * PT];
-      s[(base + c) * PT + base + h + r] = (s0 + s1) + (s2 + s3);
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < h; ++k) sum += (k >= c) ? Crow[k] * s[(base + k) * PT + base + c] : 0.0;
+      s[(base + c) * PT + base + h + r] = sum;
     }
     __syncthreads();
-    for (int idx = tid; idx < total; idx += 256) {  // X21 = -B^-1 T
-      const int pr = idx / hh, rem = idx - pr * hh, r = rem / h, c = rem - r * h, base = 2 * pr * h;
+    for (int idx = tid; idx < 64 * h; idx += 256) {  // X21 = -B^-1 T
+      const int pr = idx >> 6, rem = idx & 63, r = rem >> 3, c = rem & 7, base = 2 * pr * h;
       const double* Brow = s + (base + h + r) * PT + base + h;
       const double* Tcol = s + (base + c) * PT + base + h;
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int k = 0;
-      for (; k + 3 <= r; k += 4) {
-        s0 += Brow[k] * Tcol[k]; s1 += Brow[k + 1] * Tcol[k + 1]; s2 += Brow[k + 2] * Tcol[k + 2]; s3 += Brow[k + 3] * Tcol[k + 3];
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < h; ++k) sum += (k <= r) ? Brow[k] * Tcol[k] : 0.0;
+      s[(base + h + r) * PT + base + c] = -sum;
+    }
+  }
+  // levels h = 16, 32, 64 on the matrix core: both products are small GEMMs (triangular operands masked to zero)
+  {
+    const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
+    for (int h = 16; h < kTile; h <<= 1) {
+      const int tpp = (h >> 4) * (h >> 4);   // 16x16 output tiles per pair
+      const int ntile = (64 / h) * tpp;      // 4, 8, 16
+      __syncthreads();
+      for (int t = wave; t < ntile; t += 4) {  // T = C A^-1   (A^-1 lower: rows k >= c only)
+        const int pr = t / tpp, rem = t - pr * tpp, tr = rem / (h >> 4), tc = rem - tr * (h >> 4), base = 2 * pr * h;
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int kk = tc * 16; kk < h; kk += 4) {
+          const int k = kk + fk, c = tc * 16 + fr;
+          const double av = s[(base + h + tr * 16 + fr) * PT + base + k];
+          const double bv = (k >= c) ? s[(base + k) * PT + base + c] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) s[(base + tc * 16 + fr) * PT + base + h + tr * 16 + fk + 4 * rg] = acc[rg];
       }
-      for (; k <= r; ++k) s0 += Brow[k] * Tcol[k];
-      s[(base + h + r) * PT + base + c] = -((s0 + s1) + (s2 + s3));
+      __syncthreads();
+      for (int t = wave; t < ntile; t += 4) {  // X21 = -B^-1 T   (B^-1 lower: k <= r only)
+        const int pr = t / tpp, rem = t - pr * tpp, tr = rem / (h >> 4), tc = rem - tr * (h >> 4), base = 2 * pr * h;
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int kk = 0; kk < tr * 16 + 16; kk += 4) {
+          const int k = kk + fk, r = tr * 16 + fr;
+          const double av = (k <= r) ? s[(base + h + r) * PT + base + h + k] : 0.0;
+          const double bv = s[(base + tc * 16 + fr) * PT + base + h + k];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+        // all tiles of this phase read only B^-1 and T; X overwrites the C block (no longer needed)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) s[(base + h + tr * 16 + fk + 4 * rg) * PT + base + tc * 16 + fr] = -acc[rg];
+      }
     }
   }
   __syncthreads();
@@ -328,35 +368,64 @@ __global__ __launch_bounds__(256) void k_fwd_step(const double* __restrict__ M, 
 }
 
 // backward substitution step for panel p:  x_p = Linv_p^T y_p ; y[cols left of the panel] -= L[panel rows, cols]^T x_p
+// Block = 32 columns x 8 row groups (16 panel rows each): 8x more loads in flight than one thread per column
+// (that version was latency-bound: 50 us per step), partial sums combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, size_t ld, int p, const double* __restrict__ Linv,
                                                    double* __restrict__ y, double* __restrict__ x) {
   __shared__ double sx[kTile];
   __shared__ double sy[kTile];
+  __shared__ double part[8][33];
   const int tid = threadIdx.x, k0 = p * kTile;
   if (tid < kTile) sy[tid] = y[k0 + tid];
   __syncthreads();
-  if (tid < kTile) {
-    double s2 = 0.0;
-    for (int j = tid; j < kTile; ++j) s2 += Linv[(size_t)j * kTile + tid] * sy[j];
-    sx[tid] = s2;
-    if (blockIdx.x == 0) x[k0 + tid] = s2;
+  {  // x_p = Linv^T y_p : thread (i, half) sums half of the rows j >= i
+    const int i = tid & 127, half = tid >> 7;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const double* Lc = Linv + i;
+    const int j0 = half * 64, j1 = j0 + 64;
+#pragma unroll 4
+    for (int j = j0; j < j1; j += 4) {  // Linv is zero above the diagonal: no j >= i test needed
+      s0 += Lc[(size_t)j * kTile] * sy[j]; s1 += Lc[(size_t)(j + 1) * kTile] * sy[j + 1];
+      s2 += Lc[(size_t)(j + 2) * kTile] * sy[j + 2]; s3 += Lc[(size_t)(j + 3) * kTile] * sy[j + 3];
+    }
+    const double v = (s0 + s1) + (s2 + s3);
+    if (half == 1) sx[i] = v;
+    __syncthreads();
+    if (half == 0) { sx[i] += v; }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < kTile) x[k0 + tid] = sx[tid];
   }
-  __syncthreads();
-  const int col = blockIdx.x * 256 + tid;
+  const int cl = tid & 31, rg = tid >> 5;
+  const int col = blockIdx.x * 32 + cl;
+  double acc = 0.0;
   if (col < k0) {
-    const double* Lc = M + (size_t)k0 * ld + col;
-    double s2 = 0.0;
-#pragma unroll 8
-    for (int r = 0; r < kTile; ++r) s2 += Lc[(size_t)r * ld] * sx[r];
-    y[col] -= s2;
+    const double* Lc = M + (size_t)(k0 + 16 * rg) * ld + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc += Lc[(size_t)r * ld] * sx[16 * rg + r];
+  }
+  part[rg][cl] = acc;
+  __syncthreads();
+  if (rg == 0 && col < k0) {
+    double t = 0.0;
+#pragma unroll
+    for (int g2 = 0; g2 < 8; ++g2) t += part[g2][cl];
+    y[col] -= t;
   }
 }
 
 void CholAux::init() {
   if (!aux) {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    (void)hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, lo);  // bulk updates: lowest dispatch priority
+    // Experiment knob (COVGPU_CU_MASK=1): restrict the bulk trailing updates to 224 of the 256 CUs so that the
+    // serial panel chain never queues behind bulk workgroups. Measured on the 5-agent map: no gain (44.2 vs
+    // 43.5 ms factor+solve; the bulk loses 13 % throughput), so it is off by default.
+    uint32_t mask[8];
+    for (int w = 0; w < 8; ++w) mask[w] = 0x0FFFFFFFu;
+    const char* on = getenv("COVGPU_CU_MASK");
+    if (!(on && on[0] == '1') || hipExtStreamCreateWithCUMask(&aux, 8, mask) != hipSuccess) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      (void)hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, lo);
+    }
   }
 }
 void CholAux::destroy() {
@@ -450,7 +519,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     hipLaunchKernelGGL(k_fwd_step, dim3(rem > 0 ? rem : 1), dim3(256), 0, st, S, ld, p, Linv + (size_t)p * kTile * kTile, b, b + npad);
   }
   for (int p = T - 1; p >= 0; --p) {
-    const int nb = (p * kTile + 255) / 256;
+    const int nb = (p * kTile + 31) / 32;
     hipLaunchKernelGGL(k_bwd_step, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, S, ld, p, Linv + (size_t)p * kTile * kTile, b + npad, b);
   }
 }

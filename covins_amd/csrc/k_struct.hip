@@ -40,43 +40,80 @@ __global__ __launch_bounds__(256) void k_scatter_solution(DevProblem P, double* 
   dst[q] = (r < 6) ? P.bp[6 * pos + r] : P.xs[9 * pos + (r - 6)];
 }
 
+COV_DEV double rdlane64(double v, int srclane) {  // broadcast from a wave-uniform lane through SGPRs
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), srclane);
+  const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), srclane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // One 64-lane workgroup (a single wave) per chain: the sequential part only — block-bidiagonal Cholesky of the
-// speed-bias system and z = L_A^-1 b_s. ~10 LDS round trips per keyframe; everything that is parallel over the
-// columns of B lives in k_sb_chain_cols.
+// speed-bias system and z = L_A^-1 b_s. Per keyframe: 9x9 Cholesky in registers (row per lane, v_readlane
+// broadcasts), inverse by columns from LDS, next blocks prefetched from HBM one step ahead.
 __global__ __launch_bounds__(64) void k_sb_chain_factor(DevProblem P) {
   __shared__ double sM[81], sX[81], sSub[81];
   __shared__ double sz[9], sv[9];
   const int lane = threadIdx.x;
   const int p0 = P.chain_ptr[blockIdx.x], p1 = P.chain_ptr[blockIdx.x + 1];
+  const int e0 = lane, e1 = lane + 64;  // the two matrix entries this lane owns (e1 valid for lanes < 17)
+  const bool has1 = e1 < 81;
   for (int e = lane; e < 81; e += 64) sSub[e] = 0.0;
   if (lane < 9) sz[lane] = 0.0;
+  // prefetch registers: Ad of the current position, Ae of the next, b_s of the current
+  double ad0 = P.Ad[(size_t)81 * p0 + e0], ad1 = has1 ? P.Ad[(size_t)81 * p0 + e1] : 0.0;
+  double ae0 = 0.0, ae1 = 0.0;
+  if (p0 + 1 < p1) { ae0 = P.Ae[(size_t)81 * (p0 + 1) + e0]; ae1 = has1 ? P.Ae[(size_t)81 * (p0 + 1) + e1] : 0.0; }
+  double bs = (lane < 9) ? P.xs[(size_t)9 * p0 + lane] : 0.0;
   __syncthreads();
   for (int pos = p0; pos < p1; ++pos) {
+    // issue next step's loads first
+    double nad0 = 0.0, nad1 = 0.0, nae0 = 0.0, nae1 = 0.0, nbs = 0.0;
+    if (pos + 1 < p1) {
+      nad0 = P.Ad[(size_t)81 * (pos + 1) + e0]; nad1 = has1 ? P.Ad[(size_t)81 * (pos + 1) + e1] : 0.0;
+      nbs = (lane < 9) ? P.xs[(size_t)9 * (pos + 1) + lane] : 0.0;
+    }
+    if (pos + 2 < p1) { nae0 = P.Ae[(size_t)81 * (pos + 2) + e0]; nae1 = has1 ? P.Ae[(size_t)81 * (pos + 2) + e1] : 0.0; }
     // M = Ad - Lsub Lsub^T
-    for (int e = lane; e < 81; e += 64) {
-      const int a = e / 9, b = e - 9 * a;
-      double m = P.Ad[(size_t)81 * pos + e];
+    {
+      const int a = e0 / 9, b = e0 - 9 * a;
+      double m = ad0;
 #pragma unroll
       for (int k = 0; k < 9; ++k) m -= sSub[9 * a + k] * sSub[9 * b + k];
-      sM[e] = m;
+      sM[e0] = m;
+      if (has1) {
+        const int a1 = e1 / 9, b1 = e1 - 9 * a1;
+        double m1 = ad1;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) m1 -= sSub[9 * a1 + k] * sSub[9 * b1 + k];
+        sM[e1] = m1;
+      }
     }
     __syncthreads();
-    // in-place lower Cholesky of the 9x9 block, lanes = (row, col) of the trailing 8x8 update
-    bool ok = true;
-    for (int c = 0; c < 9; ++c) {
-      double d = sM[10 * c];
-      if (!(d > 0.0)) { ok = false; d = 1.0; }
-      const double inv = rsqrt(d);
-      __syncthreads();
-      if (lane == c) sM[10 * c] = d * inv;
-      else if (lane > c && lane < 9) sM[9 * lane + c] *= inv;
-      __syncthreads();
-      const int r = 1 + (lane >> 3), cc = 1 + (lane & 7);
-      if (r > c && cc > c && cc <= r) sM[9 * r + cc] -= sM[9 * r + c] * sM[9 * cc + c];
-      __syncthreads();
+    // lower Cholesky, row r = lane (lanes >= 9 carry zeros)
+    {
+      const int r = lane < 9 ? lane : 8;
+      double x[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) x[c] = (lane < 9 && c <= r) ? sM[9 * r + c] : 0.0;
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        double d = rdlane64(x[c], c);
+        if (!(d > 0.0)) { bad = true; d = 1.0; }
+        const double inv = rsqrt(d);
+        x[c] = (lane == c) ? d * inv : x[c] * inv;
+#pragma unroll
+        for (int cc = c + 1; cc < 9; ++cc) x[cc] -= x[c] * rdlane64(x[c], cc);  // garbage above the diagonal is never read
+      }
+      if (bad && lane == 0) atomicOr(P.flag, 1);
+      __syncthreads();  // everyone has read sM
+      if (lane < 9) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) sM[9 * lane + c] = (c <= lane) ? x[c] : 0.0;
+      }
     }
-    if (!ok && lane == 0) atomicOr(P.flag, 1);
-    // X = L^-1 (lower): lane = column, forward substitution down the rows
+    __syncthreads();
+    // X = L^-1 (lower): lane = column; and the bracket of z
     if (lane < 9) {
       const int c = lane;
       double x[9];
@@ -89,40 +126,43 @@ __global__ __launch_bounds__(64) void k_sb_chain_factor(DevProblem P) {
       }
 #pragma unroll
       for (int r = 0; r < 9; ++r) sX[9 * r + c] = x[r];
-      // z_pos = X (b_s - Lsub z_prev): first the bracket
-      double v = P.xs[(size_t)9 * pos + lane];
+      double v = bs;
 #pragma unroll
       for (int k = 0; k < 9; ++k) v -= sSub[9 * lane + k] * sz[k];
       sv[lane] = v;
     }
     __syncthreads();
-    for (int e = lane; e < 81; e += 64) {
-      const int a = e / 9, b = e - 9 * a;
-      P.Ld[(size_t)81 * pos + e] = (b <= a) ? sM[e] : 0.0;
-      P.Ldinv[(size_t)81 * pos + e] = sX[e];
-      P.Lsub[(size_t)81 * pos + e] = sSub[e];
-    }
+    // publish the factor blocks, z, and the next sub-diagonal block L_{pos+1,pos} = Ae_{pos+1} L_kk^-T
+    P.Ld[(size_t)81 * pos + e0] = sM[e0]; P.Ldinv[(size_t)81 * pos + e0] = sX[e0]; P.Lsub[(size_t)81 * pos + e0] = sSub[e0];
+    if (has1) { P.Ld[(size_t)81 * pos + e1] = sM[e1]; P.Ldinv[(size_t)81 * pos + e1] = sX[e1]; P.Lsub[(size_t)81 * pos + e1] = sSub[e1]; }
     double znew = 0.0;
     if (lane < 9) {
       for (int k = 0; k <= lane; ++k) znew += sX[9 * lane + k] * sv[k];
       P.zs[(size_t)9 * pos + lane] = znew;
     }
-    // next sub-diagonal block L_{pos+1,pos} = Ae_{pos+1} L_kk^-T
-    double nxt[2] = {0.0, 0.0};
+    // Ae rows are needed in full by every entry: route them through LDS (sv is free again after the sync below)
+    __shared__ double sAe[81];
+    sAe[e0] = ae0;
+    if (has1) sAe[e1] = ae1;
+    __syncthreads();
+    double nx0 = 0.0, nx1 = 0.0;
     if (pos + 1 < p1) {
-      const double* Ae = P.Ae + (size_t)81 * (pos + 1);
-      int u = 0;
-      for (int e = lane; e < 81; e += 64, ++u) {
-        const int a = e / 9, b = e - 9 * a;
-        double v = 0.0;
+      {
+        const int a = e0 / 9, b = e0 - 9 * a;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) v += Ae[9 * a + c] * sX[9 * b + c];
-        nxt[u] = v;
+        for (int c = 0; c < 9; ++c) nx0 += sAe[9 * a + c] * sX[9 * b + c];
+      }
+      if (has1) {
+        const int a = e1 / 9, b = e1 - 9 * a;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) nx1 += sAe[9 * a + c] * sX[9 * b + c];
       }
     }
     __syncthreads();
-    { int u = 0; for (int e = lane; e < 81; e += 64, ++u) sSub[e] = nxt[u]; }
+    sSub[e0] = nx0;
+    if (has1) sSub[e1] = nx1;
     if (lane < 9) sz[lane] = znew;
+    ad0 = nad0; ad1 = nad1; ae0 = nae0; ae1 = nae1; bs = nbs;
     __syncthreads();
   }
 }
@@ -179,58 +219,82 @@ __global__ __launch_bounds__(256) void k_pose_rhs(DevProblem P) {
 }
 
 // x_s = A^-1 (b_s - B x_p): w = b_s - B x_p, forward with (Ldinv, Lsub), backward with their transposes.
-// One 64-lane workgroup per chain; lanes 0..8 each own one row of the current 9-vector.
+// One 64-lane workgroup per chain; lanes 0..8 each own one row of the current 9-vector. Every step's operands are
+// loaded one step ahead (the chain is latency-bound: ~900 dependent steps of 9x9 work per agent).
+struct SbRowF { double w, ls[9], li[9]; };  // forward operands of one lane: bracket b_s - B x_p, Lsub row, Ldinv row
+COV_DEV SbRowF sb_load_fwd(const DevProblem& P, int pos, int p0, int p1, int lane) {
+  SbRowF o;
+  double w = P.xs[(size_t)9 * pos + lane];
+  const double* bs = P.Bs + (size_t)54 * pos + 6 * lane;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) w -= bs[e] * P.bp[6 * pos + e];
+  if (pos > p0) {
+    const double* bpv = P.Bp + (size_t)54 * pos + 6 * lane;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) w -= bpv[e] * P.bp[6 * (pos - 1) + e];
+  }
+  if (pos + 1 < p1) {
+    const double* bn = P.Bn + (size_t)54 * pos + 6 * lane;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) w -= bn[e] * P.bp[6 * (pos + 1) + e];
+  }
+  o.w = w;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { o.ls[k] = P.Lsub[(size_t)81 * pos + 9 * lane + k]; o.li[k] = P.Ldinv[(size_t)81 * pos + 9 * lane + k]; }
+  return o;
+}
+struct SbRowB { double u, lsT[9], liT[9]; };  // backward operands: u_pos, column `lane` of Lsub_{pos+1} and of Ldinv_pos
+COV_DEV SbRowB sb_load_bwd(const DevProblem& P, int pos, int p1, int lane) {
+  SbRowB o;
+  o.u = P.xs[(size_t)9 * pos + lane];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    o.lsT[k] = (pos + 1 < p1) ? P.Lsub[(size_t)81 * (pos + 1) + 9 * k + lane] : 0.0;
+    o.liT[k] = P.Ldinv[(size_t)81 * pos + 9 * k + lane];
+  }
+  return o;
+}
+
 __global__ __launch_bounds__(64) void k_sb_backsolve(DevProblem P) {
   __shared__ double su[9], sprev[9];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x < 9 ? threadIdx.x : 8;
+  const bool act = threadIdx.x < 9;
   const int p0 = P.chain_ptr[blockIdx.x], p1 = P.chain_ptr[blockIdx.x + 1];
-  if (lane < 9) sprev[lane] = 0.0;
+  if (act) sprev[lane] = 0.0;
   __syncthreads();
+  SbRowF cf = sb_load_fwd(P, p0, p0, p1, lane);
   for (int pos = p0; pos < p1; ++pos) {  // forward: u_pos = Linv (w_pos - Lsub u_{pos-1}), stored in xs
-    double w = 0.0;
-    if (lane < 9) {
-      w = P.xs[(size_t)9 * pos + lane];
-      const double* xp_self = P.bp + 6 * pos;
+    SbRowF nf = cf;
+    if (pos + 1 < p1) nf = sb_load_fwd(P, pos + 1, p0, p1, lane);
+    double w = cf.w;
 #pragma unroll
-      for (int e = 0; e < 6; ++e) w -= P.Bs[(size_t)54 * pos + 6 * lane + e] * xp_self[e];
-      if (pos > p0)
-#pragma unroll
-        for (int e = 0; e < 6; ++e) w -= P.Bp[(size_t)54 * pos + 6 * lane + e] * P.bp[6 * (pos - 1) + e];
-      if (pos + 1 < p1)
-#pragma unroll
-        for (int e = 0; e < 6; ++e) w -= P.Bn[(size_t)54 * pos + 6 * lane + e] * P.bp[6 * (pos + 1) + e];
-      if (pos > p0)
-#pragma unroll
-        for (int k = 0; k < 9; ++k) w -= P.Lsub[(size_t)81 * pos + 9 * lane + k] * sprev[k];
-      su[lane] = w;
-    }
+    for (int k = 0; k < 9; ++k) w -= cf.ls[k] * sprev[k];  // Lsub of a chain head is zero
+    if (act) su[lane] = w;
     __syncthreads();
-    if (lane < 9) {
-      double u = 0.0;
-      for (int k = 0; k <= lane; ++k) u += P.Ldinv[(size_t)81 * pos + 9 * lane + k] * su[k];
-      P.xs[(size_t)9 * pos + lane] = u;
-      sprev[lane] = u;
-    }
+    double u = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) u += cf.li[k] * su[k];     // Ldinv is lower triangular: entries k > lane are zero
+    if (act) { P.xs[(size_t)9 * pos + lane] = u; sprev[lane] = u; }
     __syncthreads();
+    cf = nf;
   }
-  if (lane < 9) sprev[lane] = 0.0;
+  if (act) sprev[lane] = 0.0;
   __syncthreads();
+  SbRowB cb = sb_load_bwd(P, p1 - 1, p1, lane);
   for (int pos = p1 - 1; pos >= p0; --pos) {  // backward: x_pos = Linv^T (u_pos - Lsub_{pos+1}^T x_{pos+1})
-    if (lane < 9) {
-      double w = P.xs[(size_t)9 * pos + lane];
-      if (pos + 1 < p1)
+    SbRowB nb = cb;
+    if (pos > p0) nb = sb_load_bwd(P, pos - 1, p1, lane);
+    double w = cb.u;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) w -= P.Lsub[(size_t)81 * (pos + 1) + 9 * k + lane] * sprev[k];
-      su[lane] = w;
-    }
+    for (int k = 0; k < 9; ++k) w -= cb.lsT[k] * sprev[k];
+    if (act) su[lane] = w;
     __syncthreads();
-    if (lane < 9) {
-      double x = 0.0;
-      for (int k = lane; k < 9; ++k) x += P.Ldinv[(size_t)81 * pos + 9 * k + lane] * su[k];
-      P.xs[(size_t)9 * pos + lane] = x;
-      sprev[lane] = x;
-    }
+    double x = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x += cb.liT[k] * su[k];    // column of a lower-triangular matrix: entries k < lane are zero
+    if (act) { P.xs[(size_t)9 * pos + lane] = x; sprev[lane] = x; }
     __syncthreads();
+    cb = nb;
   }
 }
 

@@ -19,6 +19,7 @@ int main() {
   float best = 1e9;
   for (int it = 0; it < 20; ++it) {
     hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
+    { long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)); }
     hipEventRecord(e0);
     hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), lds, 0, dA, (size_t)n, 0, dL, df);
     hipEventRecord(e1); hipEventSynchronize(e1);
@@ -28,5 +29,6 @@ int main() {
   hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr));
   printf("potrf_inv best %.1f us; phases (100 MHz ticks -> us): load %.1f chol %.1f toLDS %.1f inverse %.1f store %.1f\n", best * 1e3,
          (pr[1] - pr[0]) / 100.0, (pr[2] - pr[1]) / 100.0, (pr[3] - pr[2]) / 100.0, (pr[4] - pr[3]) / 100.0, (pr[5] - pr[4]) / 100.0);
+  printf("  inside chol: U %.1f us  D %.1f us  (T = rest)\n", pr[6] / 100.0, pr[7] / 100.0);
   return 0;
 }

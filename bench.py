@@ -67,56 +67,45 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from covins_amd import backend, capi, distrib, mapdata, synth
+    rank, local_rank, world = distrib.env_ranks()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
-
-    from covins_amd import backend, capi, mapdata, synth
+    dist = distrib.init("nccl", local_rank)
+    dev = f"cuda:{local_rank}"
     strategy = capi.COVGPU_DOGLEG if args.strategy == "dogleg" else capi.COVGPU_LM
-    cfg = synth.config_named(args.workload, seed=rank)  # map-sharded: each rank owns one merged map
+    cfg = synth.config_named(args.workload, seed=distrib.map_seed_for_rank(rank))  # map-sharded: each rank owns one merged map
     m = synth.make_map(cfg)
     prob, _ = mapdata.flatten_gba(m, visual_only=False, loop_loss=True)
     opt = backend.default_options(strategy=strategy, max_iterations=args.iterations, device=local_rank)
     ctx = backend.Context(local_rank)
     ctx.upload(prob, opt)  # inputs resident in HBM before the timed region
 
-    def barrier():
-        torch.cuda.synchronize(local_rank)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(local_rank)
-
     for _ in range(args.warmup):
         ctx.solve_resident(opt)
     ctx.set_profiling(True)
-    barrier()
+    distrib.barrier(dist, dev)
     t0 = time.perf_counter()
     iters = 0
     res = None
     for _ in range(args.steps):
         res = ctx.solve_resident(opt)  # returns after its stream has drained
         iters += res.iterations
-    barrier()
+    distrib.barrier(dist, dev)
     dt = time.perf_counter() - t0
     prof = ctx.profile()
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        it = torch.tensor([float(iters)], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(it, op=dist.ReduceOp.SUM)
-        iters_all = float(it.item())
-    else:
-        iters_all = float(iters)
+    dt, iters_all = distrib.aggregate(dt, iters, dist, dev)
 
     if rank == 0:
+        # HBM traffic per launch of the dominant kernel: PMC counters cannot be read inside this process, so the
+        # number comes from the committed counter pass of the same command (profiles/r01_pmc_traffic.json)
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pj.get("workload") == args.workload:
+                k = pj["kernels"]["k_gemm_abt<SYRK_TRI>"]
+                traffic = k["fetch_bytes_x2"] + k["write_bytes"]
+        except Exception:
+            traffic = None
         sol = ctx.download()
         truth = m.truth["kf_pose"][:, 4:]
         n = 15 * prob.K
@@ -143,7 +132,8 @@ def main():
                                        "factor+solve": prof["factor_ms"] / max(prof["n_factor"], 1)},
             "roofline": {"kernel": "k_gemm_abt<SYRK_TRI> (rank-256 trailing update of the dense FP64 Cholesky, v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": syrk_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "frac": syrk_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes in profiles/r01_pmc_hbm_traffic.csv)",
                          "launches": prof["n_syrk"], "avg_launch_ms": prof["syrk_ms"] / max(prof["n_syrk"], 1),
                          "dense_stage_order": 6 * prob.K,
                          "dense_factorisation_tflops_incl_panels_and_solves": ((6.0 * prob.K) ** 3 / 3.0) / (prof["factor_ms"] / max(prof["n_factor"], 1) * 1e-3) / 1e12

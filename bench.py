@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    import torch
+    torch.cuda.init()  # torch's bundled HIP runtime must come up BEFORE libcovgpu loads /opt/rocm's (else "No HIP GPUs")
     from covins_amd import backend, capi, distrib, mapdata, synth
     rank, local_rank, world = distrib.env_ranks()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"

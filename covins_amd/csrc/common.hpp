@@ -129,7 +129,7 @@ void launch_zero_system(const DevProblem& P, hipStream_t st);
 // per-context resources of the dense factorisation: auxiliary stream for the look-ahead, ordering events, and
 // (profiling only) one timed event pair around every bulk trailing-update launch
 struct CholAux {
-  hipStream_t aux = nullptr;
+  hipStream_t aux = nullptr, mid = nullptr;
   std::vector<hipEvent_t> ev, prof_ev;
   std::vector<double> prof_flops;
   bool profile = false;

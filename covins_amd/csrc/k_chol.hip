@@ -413,22 +413,33 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, 
   }
 }
 
-void CholAux::init() {
-  if (!aux) {
-    // Experiment knob (COVGPU_CU_MASK=1): restrict the bulk trailing updates to 224 of the 256 CUs so that the
-    // serial panel chain never queues behind bulk workgroups. Measured on the 5-agent map: no gain (44.2 vs
-    // 43.5 ms factor+solve; the bulk loses 13 % throughput), so it is off by default.
+// The single-workgroup potrf (133 KB LDS, cannot share a CU with two resident bulk workgroups) starves for the
+// whole duration of a bulk trailing update unless some CUs are kept out of the bulk's reach: measured 400-600 us
+// instead of ~100 us for every potrf issued while a bulk kernel was draining (profiles/r01q). The bulk (aux) and
+// rest-row (mid) streams are therefore created with a CU mask that keeps 4 CUs of XCD 0 for the main stream: a
+// one-workgroup launch always lands on XCD 0 (workgroup b -> XCD b % 8). Mask bits {0,8,16,24} are XCD-0 CUs
+// under either plausible bit->CU numbering (xcd*32+cu, or cu*8+xcd). COVGPU_NO_CU_MASK=1 disables the mask (A/B).
+static hipStream_t make_side_stream(int priority) {
+  hipStream_t s2 = nullptr;
+  const char* off = getenv("COVGPU_NO_CU_MASK");
+  if (!(off && off[0] == '1')) {
     uint32_t mask[8];
-    for (int w = 0; w < 8; ++w) mask[w] = 0x0FFFFFFFu;
-    const char* on = getenv("COVGPU_CU_MASK");
-    if (!(on && on[0] == '1') || hipExtStreamCreateWithCUMask(&aux, 8, mask) != hipSuccess) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      (void)hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, lo);
-    }
+    for (int w = 0; w < 8; ++w) mask[w] = 0xFFFFFFFFu;
+    mask[0] = 0xFEFEFEFEu;  // bits 0, 8, 16, 24 stay free
+    if (hipExtStreamCreateWithCUMask(&s2, 8, mask) == hipSuccess) return s2;
   }
+  (void)hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, priority);
+  return s2;
+}
+
+void CholAux::init() {
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (!mid) mid = make_side_stream(hi);
+  if (!aux) aux = make_side_stream(lo);
 }
 void CholAux::destroy() {
+  if (mid) { (void)hipStreamDestroy(mid); mid = nullptr; }
   for (auto e : ev) (void)hipEventDestroy(e);
   for (auto e : prof_ev) (void)hipEventDestroy(e);
   ev.clear(); prof_ev.clear();
@@ -460,45 +471,75 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   }
   ax.init();
   const int NP = (T + 1) / 2;  // big panels of two tile columns
-  while ((int)ax.ev.size() < 2 * NP + 2) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ax.ev.push_back(e); }
+  // events per big panel: A main done | B bulk done | C rest-rows done | M1 potrf(t0) | M2 trsm head(t0) | M3 potrf(t0+1)
+  while ((int)ax.ev.size() < 6 * (NP + 1)) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ax.ev.push_back(e); }
   if (ax.profile) while ((int)ax.prof_ev.size() < 2 * NP) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev.push_back(e); }
   ax.prof_flops.clear();
-  hipEvent_t* eA = ax.ev.data();           // eA[P]: panel P factored (main stream)
-  hipEvent_t* eB = ax.ev.data() + NP + 1;  // eB[P]: bulk trailing update of panel P done (aux stream)
+  hipEvent_t* eA = ax.ev.data();
+  hipEvent_t* eB = eA + (NP + 1);
+  hipEvent_t* eC = eB + (NP + 1);
+  hipEvent_t* eM1 = eC + (NP + 1);
+  hipEvent_t* eM2 = eM1 + (NP + 1);
+  hipEvent_t* eM3 = eM2 + (NP + 1);
+  hipStream_t mid = ax.mid;
 
   auto potrf = [&](int t) { hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), lds_potrf, st, S, ld, t * kTile, Linv + (size_t)t * kTile * kTile, flag); };
-  auto trsm = [&](int t) {  // rows below tile t, columns of tile t
-    const int rem = T - t - 1;
-    if (rem <= 0) return;
-    GemmArgs g{S, ld, t * kTile, kTile, (t + 1) * kTile, 0, t * kTile, rem, Linv + (size_t)t * kTile * kTile, nullptr, 0, nullptr, nullptr};
-    hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(rem), dim3(256), lds_gemm, st, g);
+  // rows [r0, r1) of tile column t:  A <- A Linv_t^T
+  auto trsm = [&](int t, int r0, int r1, hipStream_t s2) {
+    if (r1 <= r0) return;
+    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, nullptr, 0, nullptr, nullptr};
+    hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(r1 - r0), dim3(256), lds_gemm, s2, g);
   };
-  // C tiles in tile-columns [tc0, tc0+ntc) (rows >= tc0) -= A[:, kcols] A[tc.., kcols]^T
-  auto rect = [&](int tc0, int ntc, int kt0, int KD, hipStream_t s2) {
-    const int ntr = T - tc0;
-    if (ntr <= 0 || ntc <= 0) return;
-    GemmArgs g{S, ld, kt0 * kTile, KD, tc0 * kTile, tc0 * kTile, tc0 * kTile, ntr, nullptr, nullptr, 0, nullptr, nullptr};
-    hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, ntr), dim3(256), lds_gemm, s2, g);
+  // C tiles (rows [r0, r1), tile columns [tc0, tc0+ntc)) -= A[rows, K] A[tc.., K]^T, K = tiles kt0.. (KD columns); lower part only
+  auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2) {
+    if (r1 <= r0 || ntc <= 0) return;
+    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, 0, nullptr, nullptr};
+    hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0), dim3(256), lds_gemm, s2, g);
   };
 
+  // Three streams. main: the serial chain on a 4-tile-row window below the diagonal ("head"); mid: the same
+  // TRSM / look-ahead updates for all rows below the window ("rest"); aux: the bulk trailing update.
   for (int P = 0; P < NP; ++P) {
     const int t0 = 2 * P, w = (T - t0 >= 2) ? 2 : 1;
+    const int hEnd = (t0 + 4 < T) ? t0 + 4 : T;
+    // ---- main: head rows [t0, hEnd)
     if (P > 0) {
-      // look-ahead part of SYRK(P-1): only the two tile columns of panel P (their previous update ran on aux in SYRK(P-2))
-      if (P >= 2) (void)hipStreamWaitEvent(st, eB[P - 2], 0);
-      rect(t0, w, t0 - 2, 2 * kTile, st);
+      if (P >= 2) (void)hipStreamWaitEvent(st, eB[P - 2], 0);  // bulk(P-2) was the previous writer of these tiles
+      (void)hipStreamWaitEvent(st, eC[P - 1], 0);               // rows t0+2, t0+3 were rest rows of panel P-1
+      rect(t0, hEnd, t0, w, t0 - 2, 2 * kTile, st);             // look-ahead part of SYRK(P-1)
     }
     potrf(t0);
-    trsm(t0);
+    (void)hipEventRecord(eM1[P], st);
+    trsm(t0, t0 + 1, hEnd, st);
+    (void)hipEventRecord(eM2[P], st);
     if (w == 2) {
-      rect(t0 + 1, 1, t0, kTile, st);  // rank-128 update of the panel's second tile column
+      rect(t0 + 1, hEnd, t0 + 1, 1, t0, kTile, st);            // rank-128 update of the panel's second tile column
       potrf(t0 + 1);
-      trsm(t0 + 1);
+      (void)hipEventRecord(eM3[P], st);
+      trsm(t0 + 1, t0 + 2, hEnd, st);
     }
     (void)hipEventRecord(eA[P], st);
-    // bulk of SYRK(P): triangle starting two tile columns further (those belong to the look-ahead part)
+    // ---- mid: rest rows [hEnd, T)
+    if (hEnd < T) {
+      if (P > 0) {
+        if (P >= 2) (void)hipStreamWaitEvent(mid, eB[P - 2], 0);
+        (void)hipStreamWaitEvent(mid, eA[P - 1], 0);            // B side: rows t0, t0+1 of panel P-1 come from main
+        rect(hEnd, T, t0, w, t0 - 2, 2 * kTile, mid);
+      }
+      (void)hipStreamWaitEvent(mid, eM1[P], 0);
+      trsm(t0, hEnd, T, mid);
+      if (w == 2) {
+        (void)hipStreamWaitEvent(mid, eM2[P], 0);               // X(t0+1, t0)
+        rect(hEnd, T, t0 + 1, 1, t0, kTile, mid);
+        (void)hipStreamWaitEvent(mid, eM3[P], 0);
+        trsm(t0 + 1, hEnd, T, mid);
+      }
+    }
+    (void)hipEventRecord(eC[P], mid);
+    // ---- aux: bulk of SYRK(P), triangle starting two tile columns further (those belong to the look-ahead)
     const int tb = t0 + 4, nt = T - tb;
     (void)hipStreamWaitEvent(ax.aux, eA[P], 0);
+    (void)hipStreamWaitEvent(ax.aux, eC[P], 0);
     if (nt > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
       GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, 0, nullptr, nullptr};
@@ -513,6 +554,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   }
   (void)hipStreamWaitEvent(st, eB[NP - 1], 0);
   if (NP >= 2) (void)hipStreamWaitEvent(st, eB[NP - 2], 0);
+  (void)hipStreamWaitEvent(st, eC[NP - 1], 0);
   // L y = b, then L^T x = y; y lives in b[npad .. 2 npad)
   for (int p = 0; p < T; ++p) {
     const int rem = T - p - 1;

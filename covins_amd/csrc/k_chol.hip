@@ -416,16 +416,20 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, 
 // The single-workgroup potrf (133 KB LDS, cannot share a CU with two resident bulk workgroups) starves for the
 // whole duration of a bulk trailing update unless some CUs are kept out of the bulk's reach: measured 400-600 us
 // instead of ~100 us for every potrf issued while a bulk kernel was draining (profiles/r01q). The bulk (aux) and
-// rest-row (mid) streams are therefore created with a CU mask that keeps 4 CUs of XCD 0 for the main stream: a
-// one-workgroup launch always lands on XCD 0 (workgroup b -> XCD b % 8). Mask bits {0,8,16,24} are XCD-0 CUs
-// under either plausible bit->CU numbering (xcd*32+cu, or cu*8+xcd). COVGPU_NO_CU_MASK=1 disables the mask (A/B).
+// rest-row (mid) streams are therefore created with a CU mask that keeps ONE CU PER XCD for the main stream (a
+// one-workgroup launch lands on XCD 0; the head kernels' few workgroups round-robin over the XCDs). Measured
+// mask-bit numbering on this stack: bit i -> XCD i % 8, CU i / 8 (reserving bits {31,63,..} = 8 CUs of XCD 7 did
+// nothing for potrf, bits {0,8,16,24} = 4 CUs of XCD 0 fixed it but unbalanced the XCD-static supertile schedule of
+// the bulk: -10 % SYRK). Bits 0..7 = CU 0 of every XCD. Net effect on the 5-agent map: factor+solve 35.8 vs
+// 36.1 ms while the masked bulk runs 8 % slower (37.4 vs 40.7 TFLOP/s) — a wash, so the mask is OPT-IN
+// (COVGPU_CU_MASK=1); the real fix is a potrf that fits next to resident bulk workgroups.
 static hipStream_t make_side_stream(int priority) {
   hipStream_t s2 = nullptr;
-  const char* off = getenv("COVGPU_NO_CU_MASK");
-  if (!(off && off[0] == '1')) {
+  const char* on = getenv("COVGPU_CU_MASK");
+  if (on && on[0] == '1') {
     uint32_t mask[8];
     for (int w = 0; w < 8; ++w) mask[w] = 0xFFFFFFFFu;
-    mask[0] = 0xFEFEFEFEu;  // bits 0, 8, 16, 24 stay free
+    mask[0] = 0xFFFFFF00u;  // bits 0..7 stay free
     if (hipExtStreamCreateWithCUMask(&s2, 8, mask) == hipSuccess) return s2;
   }
   (void)hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, priority);

@@ -93,7 +93,17 @@ struct DevProblem {
   double* step;    // [N]  trust-region step
   double* vtmp;    // [N]  scratch vector
   double* Linv;    // [npad/kTile][kTile*kTile] inverses of the factor's diagonal blocks
-  double* scal;    // [32] device scalars (reductions)
+  double* scal;    // [SC_COUNT] device scalars (reductions)
+  // deterministic reductions: every wave writes its partial sum to part[slot][index], k_part_finish adds them in a
+  // fixed order. Index ranges: [0, 8192) observation streams | part_imu.. IMU waves | part_edge.. edge waves | part_vec..
+  double* part;
+  int part_n, part_imu, part_edge, part_vec;
+  // deterministic IMU / edge accumulation: role-indexed slots filled with plain stores, summed by gather kernels
+  double *imuAd, *imuBs, *imuCd, *imuG;   // [2][K][81] | [2][K][54] | [2][K][36] | [2][K][30] (grad 15 | hdiag 15), role 0 = as predecessor, 1 = as successor
+  double* edgeOut;                         // [E][132]: Hii(36) Hjj(36) Hhi_lo(36) gi(6) gj(6) hdi(6) hdj(6)
+  int *kf_edge_ptr, *kf_edge_ent;          // [K+1], [2E] incident (edge*2 + role) per keyframe, ascending
+  int nepairs;
+  int *epair_ptr, *epair_i, *epair_j, *epair_ent;  // unique pose pairs (chain-major positions i > j) -> edges (edge*2 + transposed)
   int* flag;       // [4]  device flags (Cholesky failure)
 };
 
@@ -121,6 +131,11 @@ void launch_edge_cost(const DevProblem& P, const double* pose, hipStream_t st);
 void launch_edge_linearize(const DevProblem& P, double* r, double* J, double* cost, hipStream_t st);
 
 void launch_finalize_diag(const DevProblem& P, double mu, hipStream_t st);
+// deterministic scalar reductions
+void launch_part_clear(const DevProblem& P, int slot0, int nslots, hipStream_t st);
+void launch_part_finish(const DevProblem& P, int slot0, int nslots, hipStream_t st);
+void launch_imu_gather(const DevProblem& P, hipStream_t st);
+void launch_edge_gather(const DevProblem& P, hipStream_t st);
 // structured solve of the damped reduced system: speed-bias chains -> dense pose system -> back-substitution.
 // Solution (IR layout, D per keyframe) is written to dst[0..n).
 void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax);

@@ -9,6 +9,7 @@
 // One thread per edge: E is O(6 K) in PGO and O(10) in GBA; the 6x12 Jacobian stays in registers.
 #include "common.hpp"
 #include "dev_math.hpp"
+#include "reduce.hpp"
 
 namespace covgpu {
 using namespace covdev;
@@ -78,32 +79,72 @@ COV_DEV double eval_edge(const DevProblem& P, const double* __restrict__ pose, i
   return cost;
 }
 
+// per-edge normal-equation pieces, written with plain stores: Hii(36) Hjj(36) Hij(36) gi(6) gj(6) hdi(6) hdj(6)
+constexpr int kEdgeRec = 132;
 __global__ __launch_bounds__(64) void k_edge_build(DevProblem P) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= P.E) return;
-  double r[6], J[72];
-  const double cost = eval_edge<true>(P, P.pose, e, r, J);
-  atomicAdd(&P.scal[SC_COST], cost);
-  const int idx[2] = {P.D * P.edge_i[e], P.D * P.edge_j[e]};                       // IR layout (grad / bred / hdiag)
-  const int cix[2] = {6 * P.perm[P.edge_i[e]], 6 * P.perm[P.edge_j[e]]};           // pose rows of C
-  const size_t ld = (size_t)P.npad;
-  for (int a = 0; a < 12; ++a) {
-    const int ra = idx[a / 6] + a % 6, ca = cix[a / 6] + a % 6;
-    double ga = 0.0;
+  double cost = 0.0;
+  if (e < P.E) {
+    double r[6], J[72];
+    cost = eval_edge<true>(P, P.pose, e, r, J);
+    double* o = P.edgeOut + (size_t)kEdgeRec * e;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) ga += J[12 * k + a] * r[k];
-    if (ga != 0.0) { atomicAdd(P.grad + ra, ga); atomicAdd(P.bred + ra, -ga); }
-    for (int b = 0; b < 12; ++b) {
-      const int cb = cix[b / 6] + b % 6;
-      if (cb > ca) continue;
-      double h = 0.0;
+    for (int a = 0; a < 6; ++a) {
+      double gi = 0.0, gj = 0.0;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) h += J[12 * k + a] * J[12 * k + b];
-      if (h == 0.0) continue;
-      atomicAdd(P.Sred + (size_t)ca * ld + cb, h);
-      if (a == b) atomicAdd(P.hdiag + ra, h);
+      for (int k = 0; k < 6; ++k) { gi += J[12 * k + a] * r[k]; gj += J[12 * k + 6 + a] * r[k]; }
+      o[108 + a] = gi; o[114 + a] = gj;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        double hii = 0.0, hjj = 0.0, hij = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          hii += J[12 * k + a] * J[12 * k + b]; hjj += J[12 * k + 6 + a] * J[12 * k + 6 + b]; hij += J[12 * k + a] * J[12 * k + 6 + b];
+        }
+        o[6 * a + b] = hii; o[36 + 6 * a + b] = hjj; o[72 + 6 * a + b] = hij;
+        if (a == b) { o[120 + a] = hii; o[126 + a] = hjj; }
+      }
     }
   }
+  cost = wave_sum(cost);
+  part_put(P, SC_COST, P.part_edge + blockIdx.x, cost);
+}
+
+// fixed-order sums of the per-edge pieces: (a) per keyframe: diagonal block of C, gradient, rhs, diag(J^T J);
+// (b) per unique keyframe pair: off-diagonal block of C. One thread per destination entry.
+__global__ __launch_bounds__(256) void k_edge_gather_kf(DevProblem P) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int kf = t / 48, q = t - 48 * kf;
+  if (kf >= P.K) return;
+  double acc = 0.0;
+  for (int s2 = P.kf_edge_ptr[kf]; s2 < P.kf_edge_ptr[kf + 1]; ++s2) {
+    const int ent = P.kf_edge_ent[s2], e = ent >> 1, role = ent & 1;
+    const double* o = P.edgeOut + (size_t)kEdgeRec * e;
+    acc += (q < 36) ? o[36 * role + q] : (q < 42 ? o[108 + 6 * role + (q - 36)] : o[120 + 6 * role + (q - 42)]);
+  }
+  if (P.kf_edge_ptr[kf] == P.kf_edge_ptr[kf + 1]) return;
+  const int pos = P.perm[kf];
+  if (q < 36) {
+    const int r = q / 6, c = q - 6 * r;
+    if (c <= r) P.Sred[(size_t)(6 * pos + r) * P.npad + 6 * pos + c] += acc;
+  } else if (q < 42) {
+    P.grad[(size_t)P.D * kf + q - 36] += acc; P.bred[(size_t)P.D * kf + q - 36] -= acc;
+  } else {
+    P.hdiag[(size_t)P.D * kf + q - 42] += acc;
+  }
+}
+__global__ __launch_bounds__(256) void k_edge_gather_pair(DevProblem P) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pr = t / 36, q = t - 36 * pr;
+  if (pr >= P.nepairs) return;
+  const int r = q / 6, c = q - 6 * r;
+  double acc = 0.0;
+  for (int s2 = P.epair_ptr[pr]; s2 < P.epair_ptr[pr + 1]; ++s2) {
+    const int ent = P.epair_ent[s2], e = ent >> 1, tr = ent & 1;
+    const double* h = P.edgeOut + (size_t)kEdgeRec * e + 72;   // Hij: rows = dims of edge_i, cols = dims of edge_j
+    acc += tr ? h[6 * c + r] : h[6 * r + c];
+  }
+  P.Sred[(size_t)(6 * P.epair_i[pr] + r) * P.npad + 6 * P.epair_j[pr] + c] += acc;
 }
 
 __global__ __launch_bounds__(64) void k_edge_jvp(DevProblem P, const double* __restrict__ v_all) {
@@ -123,7 +164,7 @@ __global__ __launch_bounds__(64) void k_edge_jvp(DevProblem P, const double* __r
     }
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(&P.scal[SC_JV2], acc);
+  part_put(P, SC_JV2, P.part_edge + blockIdx.x, acc);
 }
 
 __global__ __launch_bounds__(64) void k_edge_cost(DevProblem P, const double* __restrict__ pose) {
@@ -134,7 +175,7 @@ __global__ __launch_bounds__(64) void k_edge_cost(DevProblem P, const double* __
     acc = eval_edge<false>(P, pose, e, r, nullptr);
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(&P.scal[SC_COST], acc);
+  part_put(P, SC_COST, P.part_edge + blockIdx.x, acc);
 }
 
 __global__ __launch_bounds__(64) void k_edge_linearize(DevProblem P, double* r_out, double* J_out, double* cost) {
@@ -169,6 +210,11 @@ __global__ __launch_bounds__(256) void k_reanchor(int K, const double* __restric
 void launch_edge_build(const DevProblem& P, hipStream_t st) {
   if (P.E == 0) return;
   hipLaunchKernelGGL(k_edge_build, dim3((P.E + 63) / 64), dim3(64), 0, st, P);
+}
+void launch_edge_gather(const DevProblem& P, hipStream_t st) {
+  if (P.E == 0) return;
+  hipLaunchKernelGGL(k_edge_gather_kf, dim3((48 * P.K + 255) / 256), dim3(256), 0, st, P);
+  if (P.nepairs) hipLaunchKernelGGL(k_edge_gather_pair, dim3((36 * P.nepairs + 255) / 256), dim3(256), 0, st, P);
 }
 void launch_edge_jvp(const DevProblem& P, const double* v_all, hipStream_t st) {
   if (P.E == 0) return;

@@ -12,6 +12,7 @@
 // Triangular solves reuse the stored L_pp^-1 blocks: one small launch per panel.
 #include "common.hpp"
 #include "dev_math.hpp"
+#include "reduce.hpp"
 
 namespace covgpu {
 using namespace covdev;
@@ -32,18 +33,30 @@ __global__ __launch_bounds__(256) void k_finalize_diag(DevProblem P, double mu) 
   if (q < P.npad - 6 * P.K) P.Sred[(size_t)pad * P.npad + pad] = 1.0;
 }
 
-COV_DEV void block_reduce_atomic(double v, double* dst, bool is_max = false) {
-  if (is_max) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-    if ((threadIdx.x & 63) == 0) {
-      // non-negative doubles order like their bit patterns
-      atomicMax(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(v));
-    }
-  } else {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst, v);
+// fixed-order sum of one slot's partials -> scal[slot]
+__global__ __launch_bounds__(256) void k_part_finish(DevProblem P, int slot0) {
+  __shared__ double sc[256];
+  const int slot = slot0 + blockIdx.x;
+  const double* src = P.part + (size_t)slot * P.part_n;
+  double acc = 0.0;
+  for (int k = threadIdx.x; k < P.part_n; k += 256) acc += src[k];
+  sc[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (threadIdx.x < s2) sc[threadIdx.x] += sc[threadIdx.x + s2];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) P.scal[slot] = sc[0];
+}
+
+COV_DEV void vec_reduce(const DevProblem& P, double v, int slot) {
+  v = wave_sum(v);
+  part_put(P, slot, P.part_vec + blockIdx.x * 4 + (threadIdx.x >> 6), v);
+}
+COV_DEV void vec_reduce_max(double v, double* dst) {  // max is order-independent: a plain atomic is deterministic
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(v));
 }
 
 // GG = |g/d|^2, GN2 = |d gn|^2, GDOT = g.gn, GMAX = max|g|
@@ -53,10 +66,10 @@ __global__ __launch_bounds__(256) void k_dogleg_stats(DevProblem P) {
     const double g = P.grad[q], d = clamp_diag(P.hdiag[q]), s = P.gn[q];
     gg += (g / d) * (g / d); gn2 += (d * s) * (d * s); gd += g * s; gm = fmax(gm, fabs(g));
   }
-  block_reduce_atomic(gg, &P.scal[SC_GG]);
-  block_reduce_atomic(gn2, &P.scal[SC_GN2]);
-  block_reduce_atomic(gd, &P.scal[SC_GDOT]);
-  block_reduce_atomic(gm, &P.scal[SC_GMAX], true);
+  vec_reduce(P, gg, SC_GG);
+  vec_reduce(P, gn2, SC_GN2);
+  vec_reduce(P, gd, SC_GDOT);
+  vec_reduce_max(gm, &P.scal[SC_GMAX]);
 }
 
 __global__ __launch_bounds__(256) void k_cauchy_vec(DevProblem P) {
@@ -76,8 +89,8 @@ __global__ __launch_bounds__(256) void k_combine_step(DevProblem P, double cg, d
     P.step[q] = s;
     gs += g * s; sn += s * s;
   }
-  block_reduce_atomic(gs, &P.scal[SC_GS]);
-  block_reduce_atomic(sn, &P.scal[SC_SN2]);
+  vec_reduce(P, gs, SC_GS);
+  vec_reduce(P, sn, SC_SN2);
 }
 
 // candidate = x (+) step   (R1: q+ = q (x) Exp(dtheta), renormalised; p+ = p + dp; plain addition elsewhere)
@@ -108,7 +121,7 @@ __global__ __launch_bounds__(256) void k_xnorm(DevProblem P) {
     if (P.vi) for (int k = 0; k < 9; ++k) acc += P.sb[9 * t + k] * P.sb[9 * t + k];
   }
   for (int q = t0; q < 3 * P.L; q += stride) acc += P.lm[q] * P.lm[q];
-  block_reduce_atomic(acc, &P.scal[SC_XN2]);
+  vec_reduce(P, acc, SC_XN2);
 }
 
 static inline int vec_grid(int n) {
@@ -129,22 +142,35 @@ void launch_zero_system(const DevProblem& P, hipStream_t st) {
     hipMemsetAsync(P.Bp, 0, (size_t)54 * P.K * sizeof(double), st);
     hipMemsetAsync(P.Bs, 0, (size_t)54 * P.K * sizeof(double), st);
     hipMemsetAsync(P.Bn, 0, (size_t)54 * P.K * sizeof(double), st);
+    hipMemsetAsync(P.imuAd, 0, (size_t)2 * 81 * P.K * sizeof(double), st);
+    hipMemsetAsync(P.imuBs, 0, (size_t)2 * 54 * P.K * sizeof(double), st);
+    hipMemsetAsync(P.imuCd, 0, (size_t)2 * 36 * P.K * sizeof(double), st);
+    hipMemsetAsync(P.imuG, 0, (size_t)2 * 30 * P.K * sizeof(double), st);
   }
   hipMemsetAsync(P.grad, 0, (size_t)P.N * sizeof(double), st);
   hipMemsetAsync(P.hdiag, 0, (size_t)P.N * sizeof(double), st);
-  hipMemsetAsync(P.scal + SC_COST, 0, sizeof(double), st);
+  launch_part_clear(P, SC_COST, 1, st);
   hipMemsetAsync(P.flag, 0, sizeof(int), st);
 }
+void launch_part_clear(const DevProblem& P, int slot0, int nslots, hipStream_t st) {
+  hipMemsetAsync(P.part + (size_t)slot0 * P.part_n, 0, (size_t)nslots * P.part_n * sizeof(double), st);
+}
+void launch_part_finish(const DevProblem& P, int slot0, int nslots, hipStream_t st) {
+  hipLaunchKernelGGL(k_part_finish, dim3(nslots), dim3(256), 0, st, P, slot0);
+}
 void launch_dogleg_stats(const DevProblem& P, hipStream_t st) {
-  hipMemsetAsync(P.scal + SC_GG, 0, 4 * sizeof(double), st);
+  launch_part_clear(P, SC_GG, 3, st);                       // GG, GN2, GDOT are adjacent slots
+  hipMemsetAsync(P.scal + SC_GMAX, 0, sizeof(double), st);
   hipLaunchKernelGGL(k_dogleg_stats, dim3(vec_grid(P.N)), dim3(256), 0, st, P);
+  launch_part_finish(P, SC_GG, 3, st);
 }
 void launch_cauchy_vec(const DevProblem& P, hipStream_t st) {
   hipLaunchKernelGGL(k_cauchy_vec, dim3(vec_grid(P.N)), dim3(256), 0, st, P);
 }
 void launch_combine_step(const DevProblem& P, double cg, double cn, hipStream_t st) {
-  hipMemsetAsync(P.scal + SC_GS, 0, 2 * sizeof(double), st);
+  launch_part_clear(P, SC_GS, 2, st);                       // GS, SN2 adjacent
   hipLaunchKernelGGL(k_combine_step, dim3(vec_grid(P.N)), dim3(256), 0, st, P, cg, cn);
+  launch_part_finish(P, SC_GS, 2, st);
 }
 void launch_apply_step(const DevProblem& P, hipStream_t st) {
   const int n = P.K > 3 * P.L ? P.K : 3 * P.L;
@@ -159,9 +185,10 @@ void launch_accept(const DevProblem& P, hipStream_t st) {
   if (P.L) hipMemcpyAsync(P.lm, P.lm_c, (size_t)3 * P.L * sizeof(double), hipMemcpyDeviceToDevice, st);
 }
 void launch_xnorm(const DevProblem& P, hipStream_t st) {
-  hipMemsetAsync(P.scal + SC_XN2, 0, sizeof(double), st);
+  launch_part_clear(P, SC_XN2, 1, st);
   const int n = P.K > 3 * P.L ? P.K : 3 * P.L;
   hipLaunchKernelGGL(k_xnorm, dim3(vec_grid(n)), dim3(256), 0, st, P);
+  launch_part_finish(P, SC_XN2, 1, st);
 }
 
 }  // namespace covgpu

@@ -11,6 +11,7 @@
 // and 1.2 ms per build on the 5-agent map; these take ~0.3 ms and ~0.05 ms.
 #include "common.hpp"
 #include "dev_math.hpp"
+#include "reduce.hpp"
 
 namespace covgpu {
 using namespace covdev;
@@ -296,26 +297,28 @@ __global__ __launch_bounds__(64 * kImuWaves) void k_imu_build(DevProblem P) {
   const bool live = f < P.I;
   double* sl = sm[wave];
   imu_stage<true>(P, P.pose, P.sb, f, live, lane, sl);
+  {
+    double c2 = (live && lane < 15) ? 0.5 * sl[1141 + lane] * sl[1141 + lane] : 0.0;
+    c2 = wave_sum(c2);
+    part_put(P, SC_COST, P.part_imu + blockIdx.x * kImuWaves + wave, c2);
+  }
   if (!live) return;
   const double* Jw = sl + 450;
   const double* r = sl + 1141;
   const int i = P.imu_i[f], j = P.imu_j[f];
   const size_t ld = (size_t)P.npad;
-  if (lane == 0) {
-    double cost = 0.0;
-    for (int k = 0; k < 15; ++k) cost += r[k] * r[k];
-    atomicAdd(&P.scal[SC_COST], 0.5 * cost);
-  }
-  // Scatter J^T J (30x30; groups P_i(0:6) S_i(6:15) P_j(15:21) S_j(21:30)) into the structured system:
-  //   pose-pose  -> C (dense, chain-major order);  sb-sb -> Ad / Ae;  sb-pose -> Bs / Bn / Bp   
-  // By construction of perm[], j sits right after i on the same chain: pj == pi + 1.
+  // Deterministic scatter of J^T J (30x30; groups P_i(0:6) S_i(6:15) P_j(15:21) S_j(21:30)) and J^T r:
+  // every destination has exactly one writer. Blocks that two factors share (a keyframe is the successor of one
+  // factor and the predecessor of the next) go to role-indexed slots [role][position] summed by k_imu_gather in a
+  // fixed order; the cross blocks (pos_j, pos_i) belong to this factor alone. By construction pj == pi + 1.
   const int pi = P.perm[i], pj = P.perm[j];
+  const size_t K = (size_t)P.K;
   if (lane < 30) {
-    const int a = lane, ga_ = a / 15, la = a % 15;
-    const int ra = 15 * (ga_ ? j : i) + la;
-    double ga = 0.0;
-    for (int k = 0; k < 15; ++k) ga += Jw[30 * k + a] * r[k];
-    if (ga != 0.0) { atomicAdd(P.grad + ra, ga); atomicAdd(P.bred + ra, -ga); }
+    const int a = lane, role = a / 15, la = a % 15;
+    double ga = 0.0, haa = 0.0;
+    for (int k = 0; k < 15; ++k) { ga += Jw[30 * k + a] * r[k]; haa += Jw[30 * k + a] * Jw[30 * k + a]; }
+    double* g = P.imuG + (role * K + (role ? pj : pi)) * 30;
+    g[la] = ga; g[15 + la] = haa;
   }
   for (int e = lane; e < 900; e += 64) {
     const int a = e / 30, b = e - 30 * a;
@@ -323,19 +326,40 @@ __global__ __launch_bounds__(64 * kImuWaves) void k_imu_build(DevProblem P) {
     double h = 0.0;
 #pragma unroll
     for (int k = 0; k < 15; ++k) h += Jw[30 * k + a] * Jw[30 * k + b];
-    if (h == 0.0) continue;
-    if (a == b) atomicAdd(P.hdiag + 15 * (ga_ ? j : i) + la, h);
-    const int posa = ga_ ? pj : pi, posb = gb_ ? pj : pi;
-    if (la < 6 && lb < 6) {          // pose-pose: lower triangle of C
-      const int ca = 6 * posa + la, cb = 6 * posb + lb;
-      if (cb <= ca) atomicAdd(P.Sred + (size_t)ca * ld + cb, h);
-    } else if (la >= 6 && lb >= 6) { // sb-sb: full diagonal blocks, sub-diagonal block (pos_j, pos_i)
-      if (ga_ == gb_) atomicAdd(P.Ad + (size_t)81 * posa + 9 * (la - 6) + (lb - 6), h);
-      else if (ga_ == 1) atomicAdd(P.Ae + (size_t)81 * pj + 9 * (la - 6) + (lb - 6), h);
+    const size_t slot = ga_ * K + (ga_ ? pj : pi);
+    if (la < 6 && lb < 6) {          // pose-pose
+      if (ga_ == gb_) P.imuCd[slot * 36 + 6 * la + lb] = h;
+      else if (ga_ == 1) P.Sred[(size_t)(6 * pj + la) * ld + 6 * pi + lb] += h;   // single writer after k_pair_blocks
+    } else if (la >= 6 && lb >= 6) { // sb-sb
+      if (ga_ == gb_) P.imuAd[slot * 81 + 9 * (la - 6) + (lb - 6)] = h;
+      else if (ga_ == 1) P.Ae[(size_t)81 * pj + 9 * (la - 6) + (lb - 6)] = h;
     } else if (la >= 6) {            // sb (row) x pose (col)
-      double* blk = (ga_ == gb_) ? P.Bs : (ga_ == 0 ? P.Bn : P.Bp);   // same kf | sb_i x pose_j (next) | sb_j x pose_i (prev)
-      atomicAdd(blk + (size_t)54 * posa + 6 * (la - 6) + lb, h);
+      if (ga_ == gb_) P.imuBs[slot * 54 + 6 * (la - 6) + lb] = h;
+      else if (ga_ == 0) P.Bn[(size_t)54 * pi + 6 * (la - 6) + lb] = h;   // sb_i x pose_j (next)
+      else P.Bp[(size_t)54 * pj + 6 * (la - 6) + lb] = h;                 // sb_j x pose_i (previous)
     }
+  }
+}
+
+// sums the two role slots of every chain position in a fixed order: Ad, Bs, diagonal block of C, gradient, rhs, diag(J^T J)
+__global__ __launch_bounds__(256) void k_imu_gather(DevProblem P) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pos = t / 201, e = t - 201 * pos;
+  if (pos >= P.K) return;
+  const size_t K = (size_t)P.K, s0 = (size_t)pos, s1 = K + pos;
+  if (e < 81) {
+    P.Ad[81 * s0 + e] = P.imuAd[81 * s0 + e] + P.imuAd[81 * s1 + e];
+  } else if (e < 135) {
+    const int q = e - 81;
+    P.Bs[54 * s0 + q] = P.imuBs[54 * s0 + q] + P.imuBs[54 * s1 + q];
+  } else if (e < 171) {
+    const int q = e - 135, r = q / 6, c = q - 6 * r;
+    if (c <= r) P.Sred[(size_t)(6 * pos + r) * P.npad + 6 * pos + c] += P.imuCd[36 * s0 + q] + P.imuCd[36 * s1 + q];
+  } else {
+    const int q = e - 171, kf = P.pos_kf[pos];
+    const double v = P.imuG[30 * s0 + q] + P.imuG[30 * s1 + q];
+    if (q < 15) { P.grad[(size_t)15 * kf + q] += v; P.bred[(size_t)15 * kf + q] -= v; }
+    else P.hdiag[(size_t)15 * kf + q - 15] += v;
   }
 }
 
@@ -356,7 +380,7 @@ __global__ __launch_bounds__(64 * kImuWaves) void k_imu_jvp(DevProblem P, const 
     acc = s2 * s2;
   }
   acc = wave_sum(acc);
-  if (lane == 0 && acc != 0.0) atomicAdd(&P.scal[SC_JV2], acc);
+  part_put(P, SC_JV2, P.part_imu + blockIdx.x * kImuWaves + wave, acc);
 }
 
 __global__ __launch_bounds__(64 * kImuWaves) void k_imu_cost(DevProblem P, const double* __restrict__ pose, const double* __restrict__ sb) {
@@ -369,7 +393,7 @@ __global__ __launch_bounds__(64 * kImuWaves) void k_imu_cost(DevProblem P, const
   double acc = 0.0;
   if (live && lane < 15) { const double rv = sl[1141 + lane]; acc = 0.5 * rv * rv; }
   acc = wave_sum(acc);
-  if (lane == 0 && acc != 0.0) atomicAdd(&P.scal[SC_COST], acc);
+  part_put(P, SC_COST, P.part_imu + blockIdx.x * kImuWaves + wave, acc);
 }
 
 __global__ __launch_bounds__(64 * kImuWaves) void k_imu_linearize(DevProblem P, double* r_out, double* J_out) {
@@ -393,6 +417,10 @@ void launch_preintegrate(const DevProblem& P, const covgpu_options& o, hipStream
 void launch_imu_build(const DevProblem& P, hipStream_t st) {
   if (P.I == 0) return;
   hipLaunchKernelGGL(k_imu_build, imu_grid(P.I), dim3(64 * kImuWaves), 0, st, P);
+}
+void launch_imu_gather(const DevProblem& P, hipStream_t st) {
+  if (!P.vi) return;
+  hipLaunchKernelGGL(k_imu_gather, dim3((201 * P.K + 255) / 256), dim3(256), 0, st, P);
 }
 void launch_imu_jvp(const DevProblem& P, const double* v_all, hipStream_t st) {
   if (P.I == 0) return;

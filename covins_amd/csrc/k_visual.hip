@@ -16,6 +16,7 @@
 //   obs_*      one thread per observation over the SoA stream (cost, J*v products, test dumps).
 #include "common.hpp"
 #include "dev_math.hpp"
+#include "reduce.hpp"
 
 namespace covgpu {
 using namespace covdev;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void k_cost_finish(DevProblem P, int nparts) {
     if (threadIdx.x < s2) sc[threadIdx.x] += sc[threadIdx.x + s2];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicAdd(&P.scal[SC_COST], sc[0]);
+  if (threadIdx.x == 0) P.part[(size_t)SC_COST * P.part_n + 0] = sc[0];
 }
 
 // one wave per keyframe: fixed-order sum of its observations' records
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256) void k_obs_jvp(DevProblem P, const double* __r
     acc += s0 * s0 + s1 * s1;
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(&P.scal[SC_JV2], acc);
+  part_put(P, SC_JV2, blockIdx.x * 4 + (threadIdx.x >> 6), acc);
 }
 
 __global__ __launch_bounds__(256) void k_obs_cost(DevProblem P, const double* __restrict__ pose, const double* __restrict__ lm) {
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256) void k_obs_cost(DevProblem P, const double* __
     acc += e.cost;
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(&P.scal[SC_COST], acc);
+  part_put(P, SC_COST, blockIdx.x * 4 + (threadIdx.x >> 6), acc);
 }
 
 __global__ __launch_bounds__(256) void k_obs_linearize(DevProblem P, double* r, double* Jp, double* Jl, double* cost) {

@@ -318,6 +318,43 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_alloc(c, &P.gn, (size_t)P.N)); RC(dev_alloc(c, &P.step, (size_t)P.N)); RC(dev_alloc(c, &P.vtmp, (size_t)P.N));
   RC(dev_alloc(c, &P.Linv, (size_t)(P.npad / kTile) * kTile * kTile));
   RC(dev_alloc(c, &P.scal, (size_t)SC_COUNT)); RC(dev_alloc(c, &P.flag, (size_t)4));
+  // deterministic reductions / scatters
+  P.part_imu = 8192; P.part_edge = P.part_imu + ((P.I + 3) / 4) * 4; P.part_vec = P.part_edge + (P.E + 63) / 64;
+  P.part_n = P.part_vec + 8192;
+  RC(dev_alloc(c, &P.part, (size_t)SC_COUNT * P.part_n));
+  HIPCHK(hipMemsetAsync(P.part, 0, (size_t)SC_COUNT * P.part_n * sizeof(double), c->st));
+  RC(dev_alloc(c, &P.imuAd, 2 * 81 * Kv)); RC(dev_alloc(c, &P.imuBs, 2 * 54 * Kv));
+  RC(dev_alloc(c, &P.imuCd, 2 * 36 * Kv)); RC(dev_alloc(c, &P.imuG, 2 * 30 * Kv));
+  RC(dev_alloc(c, &P.edgeOut, (size_t)132 * P.E));
+  {
+    // keyframe -> incident edges (ascending edge index), unique pose pairs -> edges
+    std::vector<int> kptr(P.K + 1, 0), kent(2 * (size_t)P.E);
+    for (int e = 0; e < P.E; ++e) {
+      if (p->edge_i[e] == p->edge_j[e]) { g_err = "invalid problem: self edge"; return COVGPU_ERR_INVALID_ARG; }
+      kptr[p->edge_i[e] + 1]++; kptr[p->edge_j[e] + 1]++;
+    }
+    for (int k = 0; k < P.K; ++k) kptr[k + 1] += kptr[k];
+    { std::vector<int> cur(kptr.begin(), kptr.end() - 1);
+      for (int e = 0; e < P.E; ++e) { kent[cur[p->edge_i[e]]++] = 2 * e; kent[cur[p->edge_j[e]]++] = 2 * e + 1; } }
+    struct PE { int i, j, ent; };
+    std::vector<PE> pe(P.E);
+    for (int e = 0; e < P.E; ++e) {
+      const int a = perm[p->edge_i[e]], b = perm[p->edge_j[e]];
+      pe[e] = (a > b) ? PE{a, b, 2 * e} : PE{b, a, 2 * e + 1};
+    }
+    std::stable_sort(pe.begin(), pe.end(), [](const PE& x, const PE& y) { return x.i != y.i ? x.i < y.i : x.j < y.j; });
+    std::vector<int> eptr, ei, ej, eent(P.E);
+    for (int q = 0; q < P.E; ++q) {
+      if (q == 0 || pe[q].i != pe[q - 1].i || pe[q].j != pe[q - 1].j) { eptr.push_back(q); ei.push_back(pe[q].i); ej.push_back(pe[q].j); }
+      eent[q] = pe[q].ent;
+    }
+    eptr.push_back(P.E);
+    P.nepairs = (int)ei.size();
+    RC(dev_upload(c, &P.kf_edge_ptr, kptr.data(), kptr.size())); RC(dev_upload(c, &P.kf_edge_ent, kent.data(), kent.size()));
+    RC(dev_upload(c, &P.epair_ptr, eptr.data(), eptr.size())); RC(dev_upload(c, &P.epair_i, ei.data(), ei.size()));
+    RC(dev_upload(c, &P.epair_j, ej.data(), ej.size())); RC(dev_upload(c, &P.epair_ent, eent.data(), eent.size()));
+    HIPCHK(hipStreamSynchronize(c->st));
+  }
   HIPCHK(hipMemsetAsync(P.scal, 0, SC_COUNT * sizeof(double), c->st));
   HIPCHK(hipMemsetAsync(P.flag, 0, 4 * sizeof(int), c->st));
   HIPCHK(hipStreamSynchronize(c->st));  // host staging vectors go out of scope
@@ -348,8 +385,11 @@ static void enqueue_build(covgpu_context* c, double mu) {
   launch_zero_system(P, c->st);
   launch_lm_build(P, mu, c->st);
   launch_imu_build(P, c->st);
+  launch_imu_gather(P, c->st);
   launch_edge_build(P, c->st);
+  launch_edge_gather(P, c->st);
   launch_finalize_diag(P, mu, c->st);
+  launch_part_finish(P, SC_COST, 1, c->st);
   if (c->profiling) (void)hipEventRecord(c->ev[1], c->st);
 }
 
@@ -373,18 +413,20 @@ static void collect_profile(covgpu_context* c, bool built, bool solved) {
 
 static void enqueue_jvp(covgpu_context* c, const double* v_all) {
   const DevProblem& P = c->P;
-  (void)hipMemsetAsync(P.scal + SC_JV2, 0, sizeof(double), c->st);
+  launch_part_clear(P, SC_JV2, 1, c->st);
   launch_obs_jvp(P, v_all, c->st);
   launch_imu_jvp(P, v_all, c->st);
   launch_edge_jvp(P, v_all, c->st);
+  launch_part_finish(P, SC_JV2, 1, c->st);
 }
 
 static void enqueue_cost_candidate(covgpu_context* c) {
   const DevProblem& P = c->P;
-  (void)hipMemsetAsync(P.scal + SC_COST, 0, sizeof(double), c->st);
+  launch_part_clear(P, SC_COST, 1, c->st);
   launch_obs_cost(P, P.pose_c, P.lm_c, c->st);
   launch_imu_cost(P, P.pose_c, P.sb_c, c->st);
   launch_edge_cost(P, P.pose_c, c->st);
+  launch_part_finish(P, SC_COST, 1, c->st);
 }
 
 static int solve_impl(covgpu_context* c, const covgpu_options* opt, covgpu_result* res) {

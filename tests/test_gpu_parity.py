@@ -209,9 +209,15 @@ def _compare_solution(sol, ref, res, rres, o, pos_tol=1e-6, ang_tol=1e-7, lm_tol
 @pytest.mark.parametrize("visual_only", [0, 1])
 def test_gba_solve_matches_oracle(ctx, tiny_vi, strategy, visual_only):
     g, o = opts(strategy=strategy, visual_only=visual_only)
+    if visual_only:
+        # monocular visual-only BA with ONE constant pose has a free scale: the reduced system is singular up to the
+        # 1e-8 damping and two correct solvers drift apart along that direction. A second constant pose anchors it.
+        tiny_vi = tiny_vi.copy(); tiny_vi.kf_fixed[1] = 1
     sol, res = ctx.gba_solve(tiny_vi, g)
     ref, rres = covo.gba_solve(tiny_vi, o)
-    _compare_solution(sol, ref, res, rres, o)
+    # without IMU factors the 14-keyframe-per-agent map leaves single keyframes constrained by a handful of
+    # landmarks only: rounding differences show up at the 1e-5 m level there (1e-11 m elsewhere)
+    _compare_solution(sol, ref, res, rres, o, pos_tol=2e-5 if visual_only else 1e-6, ang_tol=1e-5 if visual_only else 1e-7)
     if not visual_only:
         assert np.abs(sol.kf_speed_bias - ref.kf_speed_bias).max() < 1e-6
     else:
@@ -233,10 +239,21 @@ def test_resident_solve_restarts_from_upload(ctx, tiny_vi):
     ctx.upload(tiny_vi, g)
     r1 = ctx.solve_resident(g); a = ctx.download()
     r2 = ctx.solve_resident(g); b = ctx.download()
-    # the landmark elimination is bit-deterministic; the IMU / edge scatter and the scalar reductions still use FP64
-    # atomics (<= 3 addends per location, order-dependent rounding), which 10 iterations amplify to ~1e-9 on the cost
-    assert r1.iterations == r2.iterations and abs(r1.final_cost - r2.final_cost) <= 1e-7 * r1.final_cost
-    assert np.abs(a.kf_pose - b.kf_pose).max() < 1e-9
+    # every accumulation has a fixed summation order (no FP64 atomics on the data path): bit-identical repeats
+    assert r1.iterations == r2.iterations and r1.final_cost == r2.final_cost
+    assert list(r1.cost_trace[:r1.iterations]) == list(r2.cost_trace[:r2.iterations])
+    assert np.array_equal(a.kf_pose, b.kf_pose) and np.array_equal(a.kf_speed_bias, b.kf_speed_bias) and np.array_equal(a.lm_pos, b.lm_pos)
+
+
+def test_solves_are_bit_reproducible_across_contexts(small_vi):
+    g, _ = opts()
+    outs = []
+    for _ in range(2):
+        c = backend.Context(0)
+        sol, res = c.gba_solve(small_vi, g)
+        outs.append((sol, res)); c.close()
+    (s1, r1), (s2, r2) = outs
+    assert r1.final_cost == r2.final_cost and np.array_equal(s1.kf_pose, s2.kf_pose) and np.array_equal(s1.lm_pos, s2.lm_pos)
 
 
 def test_pgo_solve_matches_oracle(ctx):

@@ -116,7 +116,6 @@ def main():
         k_free = int(prob.K - prob.kf_fixed.sum())
         syrk_tflops = prof["syrk_flops"] / (prof["syrk_ms"] * 1e-3) / 1e12 if prof["syrk_ms"] > 0 else 0.0
         # algorithmic HBM bytes of one linearise+Schur pass (first, second and third terms)
-        nnzS = None
         b_build = 32.0 * prob.O + 128.0 * prob.K + 24.0 * prob.L + 2304.0 * prob.I + 8.0 * (135.0 * prob.K + 9.0 * prob.L)
         out = {
             "metric": "GBA iterations/sec, 5-agent EuRoC merged map" if args.workload == "mh12345" else f"GBA iterations/sec, {args.workload}",
@@ -132,7 +131,9 @@ def main():
             "iterations_executed": iters_all,
             "final_cost": res.final_cost, "initial_cost": res.initial_cost,
             "upload_s_not_in_value": t_up,  # host layout build (chains, covisible-pair lists) + H2D; PCIe-inclusive cost of one call
-            "ate_rmse_m": {"initial": synth.ate_rmse(prob.kf_pose[:, 4:], truth), "final": synth.ate_rmse(sol.kf_pose[:, 4:], truth)},
+            "ate_rmse_m": {"initial": synth.ate_rmse(prob.kf_pose[:, 4:], truth), "final": synth.ate_rmse(sol.kf_pose[:, 4:], truth),
+                           "initial_sim3": synth.ate_rmse(prob.kf_pose[:, 4:], truth, with_scale=True),
+                           "final_sim3": synth.ate_rmse(sol.kf_pose[:, 4:], truth, with_scale=True)},  # evo_ape -va / -vas
             "phase_ms_per_iteration": {"linearise+schur": prof["build_ms"] / max(prof["n_build"], 1),
                                        "factor+solve": prof["factor_ms"] / max(prof["n_factor"], 1)},
             "roofline": {"kernel": "k_gemm_abt<SYRK_TRI> (rank-256 trailing update of the dense FP64 Cholesky, v_mfma_f64_16x16x4_f64)",
@@ -143,11 +144,25 @@ def main():
                          "dense_stage_order": 6 * prob.K,
                          "dense_factorisation_tflops_incl_panels_and_solves": ((6.0 * prob.K) ** 3 / 3.0) / (prof["factor_ms"] / max(prof["n_factor"], 1) * 1e-3) / 1e12
                          if prof["factor_ms"] > 0 else 0.0},
-            "roofline_build": {"kernel": "k_lm_build (linearise + Schur)", "bound": "hbm",
+            "roofline_build": {"kernel": "linearise + landmark Schur pass (k_lm_lin, k_kf_reduce, k_pair_blocks, k_imu_*, k_edge_*)", "bound": "hbm",
                                "achieved": b_build / (prof["build_ms"] / max(prof["n_build"], 1) * 1e-3) / 1e9 if prof["build_ms"] > 0 else 0.0,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "note": "algorithmic bytes excl. the dense S zero-fill and atomics"},
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "note": "SURVEY.md 8(d) algorithmic bytes of one pass (inputs once + H/g blocks); the pass also zero-fills the dense "
+                                       "6K x 6K pose system and streams 600 B/observation of linearisation records, which the figure does not count"},
         }
         out["roofline_build"]["frac"] = out["roofline_build"]["achieved"] / HBM_PEAK_GBS
+        # whole Optimization::GlobalBundleAdjustment call as backend.cpp:141-156 issues it (outlier round of 5 iterations +
+        # main round, flatten + H2D + solves + D2H + write-back + Map::Clean) — PCIe- and host-inclusive, never `value`
+        from covins_amd.optimization import Optimization, OptParams
+        t_call = time.perf_counter()
+        info = Optimization.GlobalBundleAdjustment(m, args.iterations, -1.0, False, True, False,
+                                                   params=OptParams(strategy=strategy), ctx=ctx)
+        t_call = time.perf_counter() - t_call
+        out["e2e_call"] = {"t_call_s": t_call, "kf_per_s_e2e": k_free / t_call,
+                           "iterations": info["round1"].iterations + info["round2"].iterations,
+                           "outliers_removed": info["outliers_removed"],
+                           "what": "covins_amd.optimization.Optimization.GlobalBundleAdjustment(map, 10, outlier_removal=True) "
+                                   "on the same map, host flattening in numpy"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(strategy)
         print(json.dumps(out))

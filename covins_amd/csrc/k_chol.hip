@@ -59,9 +59,19 @@ struct GemmArgs {
   const double* Y; size_t ldy; const int* tile_cs; const int* tile_ce;
 };
 
-// C[i][j] (op)= sum_k A[i][k] B[j][k] on one 128x128 tile.
-template <int MODE>
+// C[i][j] (op)= sum_k A[i][k] B[j][k] on one 128x128 tile (TSA = TSB = 128), or on a quarter of it selected by
+// blockIdx.z — a 64x64 quadrant (RECT) or a 32x128 row slab (TRSM: the update is in place, X overwrites A, so a
+// workgroup must own whole rows). The quarter forms are for the few-tile launches on the serial panel chain, where
+// the latency of ONE workgroup's tile is the whole cost — 4x more workgroups, each 4x shorter.
+template <int MODE, int TSA = kTile, int TSB = kTile>
 __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
+  static_assert((TSA == kTile && TSB == kTile) || (MODE == MODE_SYRK_RECT && TSA == 64 && TSB == 64) ||
+                (MODE == MODE_TRSM && TSA == 32 && TSB == kTile), "quarter forms: RECT 64x64, TRSM 32x128");
+  constexpr int WGR = (TSA == 32) ? 1 : 2, WGC = 4 / WGR;  // wave grid
+  constexpr int WTR = TSA / WGR, WTC = TSB / WGC;           // wave tile
+  constexpr int NMR = WTR / 16, NMC = WTC / 16;             // MFMA tiles per wave
+  const int qr = (TSA == kTile) ? 0 : (TSB == kTile ? (int)blockIdx.z : (int)(blockIdx.z >> 1));
+  const int qc = (TSB == kTile) ? 0 : (int)(blockIdx.z & 1);
   int ti, tj;
   if (MODE == MODE_SYRK_TRI) {
     // XCD-aware decode: block b -> XCD (b & 7) (observed dispatch order; placement affects speed only).
@@ -87,100 +97,94 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
     kbeg = max(g.tile_cs[ti], g.tile_cs[tj]); kend = min(g.tile_ce[ti], g.tile_ce[tj]);
     if (kbeg >= kend) return;  // the two tiles' keyframes share no IMU chain segment
   }
-  extern __shared__ __attribute__((aligned(16))) double smem[];  // 2 x [128][KC+1] doubles
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // [TSA][KC+1] + [TSB][KC+1] doubles
   double (*sA)[LDT] = reinterpret_cast<double (*)[LDT]>(smem);
-  double (*sB)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + kTile * LDT);
+  double (*sB)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + TSA * LDT);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WGC, wc = wave % WGC;
   const size_t ld = g.ld;
   const double *Ag, *Bg;
   size_t lda, ldb;
   if (MODE == MODE_YTY) {
     Ag = g.Y + (size_t)(ti * kTile); Bg = g.Y + (size_t)(tj * kTile); lda = ldb = g.ldy;
   } else {
-    Ag = g.M + (size_t)(g.ra0 + ti * kTile) * ld + g.kcol0; lda = ld;
+    Ag = g.M + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + g.kcol0; lda = ld;
     if (MODE == MODE_TRSM) { Bg = g.Linv; ldb = kTile; }
-    else { Bg = g.M + (size_t)(g.rb0 + tj * kTile) * ld + g.kcol0; ldb = ld; }
+    else { Bg = g.M + (size_t)(g.rb0 + tj * kTile + qc * TSB) * ld + g.kcol0; ldb = ld; }
   }
-  double* Cg = g.M + (size_t)(g.ra0 + ti * kTile) * ld + (size_t)(g.cc0 + tj * kTile);
+  double* Cg = g.M + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + (size_t)(g.cc0 + tj * kTile + qc * TSB);
   // staging map: KC/2 lanes cover one KC-double row segment (contiguous), 512/KC rows per pass
-  constexpr int LPR = KC / 2, RPP = 256 / LPR, NPASS = kTile / RPP;
+  constexpr int LPR = KC / 2, RPP = 256 / LPR, NPA = TSA / RPP, NPB = TSB / RPP;
   const int c2 = (tid % LPR) * 2, rbase = tid / LPR;
-  double2 pa[NPASS], pb[NPASS];
+  double2 pa[NPA], pb[NPB];
   auto gload = [&](int kc) {
+    if (MODE == MODE_YTY) {
 #pragma unroll
-    for (int it = 0; it < NPASS; ++it) {
-      if (MODE == MODE_YTY) {
+      for (int it = 0; it < NPA; ++it) {
         // Y is K-major ([sb dim][pose dim]): one K row of the tile is 1 KiB contiguous -> 64 lanes x 16 B
         const int idx = tid + 256 * it, krow = idx >> 6, i2 = (idx & 63) * 2;
         pa[it] = *reinterpret_cast<const double2*>(Ag + (size_t)(kc + krow) * lda + i2);
         pb[it] = *reinterpret_cast<const double2*>(Bg + (size_t)(kc + krow) * ldb + i2);
-      } else {
-        const int row = rbase + RPP * it;
-        pa[it] = *reinterpret_cast<const double2*>(Ag + (size_t)row * lda + kc + c2);
-        pb[it] = *reinterpret_cast<const double2*>(Bg + (size_t)row * ldb + kc + c2);
       }
+    } else {
+#pragma unroll
+      for (int it = 0; it < NPA; ++it) pa[it] = *reinterpret_cast<const double2*>(Ag + (size_t)(rbase + RPP * it) * lda + kc + c2);
+#pragma unroll
+      for (int it = 0; it < NPB; ++it) pb[it] = *reinterpret_cast<const double2*>(Bg + (size_t)(rbase + RPP * it) * ldb + kc + c2);
     }
   };
   gload(kbeg);
   const int fr = lane & 15, fk = lane >> 4;
   // f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-  v4f64 acc[4][4];
+  v4f64 acc[NMR][NMC];
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
+  for (int tm = 0; tm < NMR; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+    for (int tn = 0; tn < NMC; ++tn)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         if (MODE == MODE_TRSM) acc[tm][tn][rg] = 0.0;
-        else acc[tm][tn][rg] = Cg[(size_t)(wr * 64 + tm * 16 + fk + 4 * rg) * ld + wc * 64 + tn * 16 + fr];
+        else acc[tm][tn][rg] = Cg[(size_t)(wr * WTR + tm * 16 + fk + 4 * rg) * ld + wc * WTC + tn * 16 + fr];
       }
   const double sgn = (MODE == MODE_TRSM) ? 1.0 : -1.0;  // SYRK: acc = C - A B^T through a negated A fragment
   for (int kc = kbeg; kc < kend; kc += KC) {
     __syncthreads();  // previous chunk fully consumed
+    if (MODE == MODE_YTY) {  // transpose on the way into LDS
 #pragma unroll
-    for (int it = 0; it < NPASS; ++it) {
-      if (MODE == MODE_YTY) {  // transpose on the way into LDS
+      for (int it = 0; it < NPA; ++it) {
         const int idx = tid + 256 * it, krow = idx >> 6, i2 = (idx & 63) * 2;
         sA[i2][krow] = sgn * pa[it].x; sA[i2 + 1][krow] = sgn * pa[it].y;
         sB[i2][krow] = pb[it].x; sB[i2 + 1][krow] = pb[it].y;
-      } else {
-        const int row = rbase + RPP * it;
-        sA[row][c2] = sgn * pa[it].x; sA[row][c2 + 1] = sgn * pa[it].y;
-        sB[row][c2] = pb[it].x; sB[row][c2 + 1] = pb[it].y;
       }
+    } else {
+#pragma unroll
+      for (int it = 0; it < NPA; ++it) { sA[rbase + RPP * it][c2] = sgn * pa[it].x; sA[rbase + RPP * it][c2 + 1] = sgn * pa[it].y; }
+#pragma unroll
+      for (int it = 0; it < NPB; ++it) { sB[rbase + RPP * it][c2] = pb[it].x; sB[rbase + RPP * it][c2 + 1] = pb[it].y; }
     }
     __syncthreads();
     if (kc + KC < kend) gload(kc + KC);  // prefetch the next chunk while the matrix cores work
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 4) {
-      double a[4], b[4];
+      double a[NMR], b[NMC];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        a[t] = sA[wr * 64 + t * 16 + fr][kk + fk];
-        b[t] = sB[wc * 64 + t * 16 + fr][kk + fk];
-      }
+      for (int t = 0; t < NMR; ++t) a[t] = sA[wr * WTR + t * 16 + fr][kk + fk];
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+      for (int t = 0; t < NMC; ++t) b[t] = sB[wc * WTC + t * 16 + fr][kk + fk];
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      for (int tm = 0; tm < NMR; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NMC; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
     }
   }
+  // (TRSM in place: every A element of this workgroup's rows was staged before the last barrier above)
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
+  for (int tm = 0; tm < NMR; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+    for (int tn = 0; tn < NMC; ++tn)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg)
-        Cg[(size_t)(wr * 64 + tm * 16 + fk + 4 * rg) * ld + wc * 64 + tn * 16 + fr] = acc[tm][tn][rg];
-}
-
-// broadcast a double from a (compile-time / wave-uniform) lane through SGPRs: v_readlane, no LDS round trip
-COV_DEV double rdlane(double v, int srclane) {
-  const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), srclane);
-  const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), srclane);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        Cg[(size_t)(wr * WTR + tm * 16 + fk + 4 * rg) * ld + wc * WTC + tn * 16 + fr] = acc[tm][tn][rg];
 }
 
 // Factor the 128x128 diagonal block at (k0,k0) (lower Cholesky) and form its inverse.
@@ -191,8 +195,7 @@ COV_DEV double rdlane(double v, int srclane) {
 // and updating it in place serialises on LDS read-after-write: measured 260 us per block instead of ~40.)
 __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_t ld, int k0, double* __restrict__ Linv_out, int* flag) {
   extern __shared__ __attribute__((aligned(16))) double s[];  // [128][129]
-  __shared__ double col[kTile];
-  __shared__ double piv;
+  __shared__ __attribute__((aligned(16))) double colb[2][16][8];
   constexpr int PT = kTile + 1;
   const int tid = threadIdx.x;
   const int ty = tid >> 4, tx = tid & 15;
@@ -207,34 +210,51 @@ __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_
       a[i][k] = (c <= r) ? Mg[(size_t)r * ld + c] : 0.0;
     }
   PROBE(1);
+  // (A variant that retires FOUR pivot columns per barrier pair — 4x4 diagonal block factored redundantly by every
+  //  thread, panel rows by forward substitution on values broadcast inside each 16-lane row group — was measured
+  //  SLOWER: 91 us against 61 us for this phase. One wave per SIMD is instruction-issue bound, and the four chained
+  //  rsqrt plus 64 ds_bpermute per step cost more than the three barrier pairs they save.)
+  // One barrier per pivot column: every thread keeps its own copy dd[k] of the diagonal entries of ITS columns
+  // (updated with the same fused multiply-adds as the matrix entry itself, so the copies are bit-identical); the
+  // owners of column j therefore know the pivot without a broadcast. The scaled column is double-buffered in LDS,
+  // stored so that a thread's 8 row values (and its 8 column values) are contiguous: [r & 15][r >> 4].
+  double dd[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dd[k] = Mg[(size_t)(tx + 16 * k) * ld + tx + 16 * k];
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {  // unrolled: static register indices; the 16-step inner loop must stay rolled
 #pragma unroll 1                    // (fully unrolled it is 22k instructions — far beyond the 64 KiB instruction cache)
     for (int jj = 0; jj < 16; ++jj) {
       const int j = 16 * jb + jj;
-      if (ty == jj && tx == jj) piv = a[jb][jb];
-      __syncthreads();
-      double d = piv;
-      if (!(d > 0.0)) { if (tid == 0) atomicOr(flag, 1); d = 1.0; }
+      double (*cb)[8] = colb[jj & 1];
       if (tx == jj) {  // owners of column j
+        double d = dd[jb];
+        if (!(d > 0.0)) { if (ty == 0) atomicOr(flag, 1); d = 1.0; }
         const double inv = rsqrt(d), sd = d * inv;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int r = ty + 16 * i;
           if (r == j) a[i][jb] = sd;
           else if (r > j) a[i][jb] *= inv;
-          col[r] = (r > j) ? a[i][jb] : 0.0;
+          cb[ty][i] = (r > j) ? a[i][jb] : 0.0;
         }
       }
       __syncthreads();
       double cr[8], cc[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { cr[i] = col[ty + 16 * i]; cc[i] = col[tx + 16 * i]; }
+      for (int q = 0; q < 4; ++q) {
+        const double2 u = *reinterpret_cast<const double2*>(&cb[ty][2 * q]);
+        const double2 v = *reinterpret_cast<const double2*>(&cb[tx][2 * q]);
+        cr[2 * q] = u.x; cr[2 * q + 1] = u.y; cc[2 * q] = v.x; cc[2 * q + 1] = v.y;
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int k = 0; k < 8; ++k)  // columns c > j only (col[] is 0 for rows <= j); register tiles with k > i lie above the diagonal
+        for (int k = 0; k < 8; ++k)  // columns c > j only (the column is 0 for rows <= j); register tiles with k > i lie above the diagonal
           if (k <= i && (k > jb || (k == jb && tx > jj))) a[i][k] -= cr[i] * cc[k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k >= jb) dd[k] -= cc[k] * cc[k];
     }
   }
   PROBE(2);
@@ -413,23 +433,26 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, 
   }
 }
 
-// The single-workgroup potrf (133 KB LDS, cannot share a CU with two resident bulk workgroups) starves for the
-// whole duration of a bulk trailing update unless some CUs are kept out of the bulk's reach: measured 400-600 us
-// instead of ~100 us for every potrf issued while a bulk kernel was draining (profiles/r01q). The bulk (aux) and
-// rest-row (mid) streams are therefore created with a CU mask that keeps ONE CU PER XCD for the main stream (a
-// one-workgroup launch lands on XCD 0; the head kernels' few workgroups round-robin over the XCDs). Measured
-// mask-bit numbering on this stack: bit i -> XCD i % 8, CU i / 8 (reserving bits {31,63,..} = 8 CUs of XCD 7 did
-// nothing for potrf, bits {0,8,16,24} = 4 CUs of XCD 0 fixed it but unbalanced the XCD-static supertile schedule of
-// the bulk: -10 % SYRK). Bits 0..7 = CU 0 of every XCD. Net effect on the 5-agent map: factor+solve 35.8 vs
-// 36.1 ms while the masked bulk runs 8 % slower (37.4 vs 40.7 TFLOP/s) — a wash, so the mask is OPT-IN
-// (COVGPU_CU_MASK=1); the real fix is a potrf that fits next to resident bulk workgroups.
+// The single-workgroup potrf (133 KB LDS + 174 VGPRs x 256 threads: needs an EMPTY CU) starves for the whole duration
+// of a bulk trailing update when every CU holds two bulk workgroups: 400-800 us instead of ~100 us (profiles/r01q,
+// timeline in profiles/r01y_timeline_*.csv). Creating the bulk (aux) and rest-row (mid) streams with a CU mask that
+// keeps N CUs per XCD out of their reach removes the starvation (potrf 104 us flat). Measured mask-bit numbering
+// on this stack: bit i -> XCD i % 8, CU i / 8; bits 0..8N-1 = CUs 0..N-1 of every XCD (reserving CUs of one XCD
+// only unbalances the XCD-static supertile schedule of the bulk: -10 %).
+// What the timeline shows: panel P+2 cannot start before bulk(P) has finished (its tiles are written by it), so the
+// factorisation runs in two regimes. While the trailing matrix is large (first ~22 of 52 big panels on the 5-agent
+// map) the period is one bulk launch and the chain hides inside it — there the mask only costs (bulk 8 % slower,
+// 37.5 vs 40.7 TFLOP/s); once the bulk is shorter than the ~400 us chain the period is the chain — there the mask
+// helps (no starvation). The two effects cancel: factor+solve 34.3-34.4 ms with N = 1, 2, 4 against 34.1-34.8 ms
+// without. The mask is therefore OPT-IN (COVGPU_CU_MASK=N).
 static hipStream_t make_side_stream(int priority) {
   hipStream_t s2 = nullptr;
-  const char* on = getenv("COVGPU_CU_MASK");
-  if (on && on[0] == '1') {
+  const char* on = getenv("COVGPU_CU_MASK");  // N = CUs per XCD kept free for the main stream (bits 0 .. 8N-1)
+  const int nres = on ? atoi(on) : 0;
+  if (nres > 0 && nres <= 8) {
     uint32_t mask[8];
     for (int w = 0; w < 8; ++w) mask[w] = 0xFFFFFFFFu;
-    mask[0] = 0xFFFFFF00u;  // bits 0..7 stay free
+    for (int b = 0; b < 8 * nres; ++b) mask[b >> 5] &= ~(1u << (b & 31));
     if (hipExtStreamCreateWithCUMask(&s2, 8, mask) == hipSuccess) return s2;
   }
   (void)hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, priority);
@@ -475,8 +498,8 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   }
   ax.init();
   const int NP = (T + 1) / 2;  // big panels of two tile columns
-  // events per big panel: A main done | B bulk done | C rest-rows done | M1 potrf(t0) | M2 trsm head(t0) | M3 potrf(t0+1)
-  while ((int)ax.ev.size() < 6 * (NP + 1)) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ax.ev.push_back(e); }
+  // events per big panel: A main done | B bulk done | C rest-rows done | M1 potrf(t0) | M2 trsm head(t0) | M3 potrf(t0+1) | R head look-ahead
+  while ((int)ax.ev.size() < 7 * (NP + 1)) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ax.ev.push_back(e); }
   if (ax.profile) while ((int)ax.prof_ev.size() < 2 * NP) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev.push_back(e); }
   ax.prof_flops.clear();
   hipEvent_t* eA = ax.ev.data();
@@ -485,20 +508,24 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   hipEvent_t* eM1 = eC + (NP + 1);
   hipEvent_t* eM2 = eM1 + (NP + 1);
   hipEvent_t* eM3 = eM2 + (NP + 1);
+  hipEvent_t* eR = eM3 + (NP + 1);
   hipStream_t mid = ax.mid;
 
   auto potrf = [&](int t) { hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), lds_potrf, st, S, ld, t * kTile, Linv + (size_t)t * kTile * kTile, flag); };
   // rows [r0, r1) of tile column t:  A <- A Linv_t^T
-  auto trsm = [&](int t, int r0, int r1, hipStream_t s2) {
+  // quad: four workgroups per tile (head launches on the serial chain)
+  auto trsm = [&](int t, int r0, int r1, hipStream_t s2, bool quad) {
     if (r1 <= r0) return;
     GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, nullptr, 0, nullptr, nullptr};
-    hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(r1 - r0), dim3(256), lds_gemm, s2, g);
+    if (quad) hipLaunchKernelGGL((k_gemm_abt<MODE_TRSM, 32, kTile>), dim3(r1 - r0, 1, 4), dim3(256), (size_t)(32 + kTile) * LDT * sizeof(double), s2, g);
+    else hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(r1 - r0), dim3(256), lds_gemm, s2, g);
   };
   // C tiles (rows [r0, r1), tile columns [tc0, tc0+ntc)) -= A[rows, K] A[tc.., K]^T, K = tiles kt0.. (KD columns); lower part only
-  auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2) {
+  auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2, bool quad) {
     if (r1 <= r0 || ntc <= 0) return;
     GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, 0, nullptr, nullptr};
-    hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0), dim3(256), lds_gemm, s2, g);
+    if (quad) hipLaunchKernelGGL((k_gemm_abt<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4), dim3(256), lds_gemm / 2, s2, g);
+    else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0), dim3(256), lds_gemm, s2, g);
   };
 
   // Three streams. main: the serial chain on a 4-tile-row window below the diagonal ("head"); mid: the same
@@ -506,21 +533,16 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   for (int P = 0; P < NP; ++P) {
     const int t0 = 2 * P, w = (T - t0 >= 2) ? 2 : 1;
     const int hEnd = (t0 + 4 < T) ? t0 + 4 : T;
-    // ---- main: head rows [t0, hEnd)
-    if (P > 0) {
-      if (P >= 2) (void)hipStreamWaitEvent(st, eB[P - 2], 0);  // bulk(P-2) was the previous writer of these tiles
-      (void)hipStreamWaitEvent(st, eC[P - 1], 0);               // rows t0+2, t0+3 were rest rows of panel P-1
-      rect(t0, hEnd, t0, w, t0 - 2, 2 * kTile, st);             // look-ahead part of SYRK(P-1)
-    }
+    // ---- main: head rows [t0, hEnd) (their look-ahead update was enqueued at the end of the previous iteration)
     potrf(t0);
     (void)hipEventRecord(eM1[P], st);
-    trsm(t0, t0 + 1, hEnd, st);
+    trsm(t0, t0 + 1, hEnd, st, true);
     (void)hipEventRecord(eM2[P], st);
     if (w == 2) {
-      rect(t0 + 1, hEnd, t0 + 1, 1, t0, kTile, st);            // rank-128 update of the panel's second tile column
+      rect(t0 + 1, hEnd, t0 + 1, 1, t0, kTile, st, true);           // rank-128 update of the panel's second tile column
       potrf(t0 + 1);
       (void)hipEventRecord(eM3[P], st);
-      trsm(t0 + 1, t0 + 2, hEnd, st);
+      trsm(t0 + 1, t0 + 2, hEnd, st, true);
     }
     (void)hipEventRecord(eA[P], st);
     // ---- mid: rest rows [hEnd, T)
@@ -528,22 +550,34 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       if (P > 0) {
         if (P >= 2) (void)hipStreamWaitEvent(mid, eB[P - 2], 0);
         (void)hipStreamWaitEvent(mid, eA[P - 1], 0);            // B side: rows t0, t0+1 of panel P-1 come from main
-        rect(hEnd, T, t0, w, t0 - 2, 2 * kTile, mid);
+        rect(hEnd, T, t0, w, t0 - 2, 2 * kTile, mid, false);
       }
       (void)hipStreamWaitEvent(mid, eM1[P], 0);
-      trsm(t0, hEnd, T, mid);
+      trsm(t0, hEnd, T, mid, false);
       if (w == 2) {
         (void)hipStreamWaitEvent(mid, eM2[P], 0);               // X(t0+1, t0)
-        rect(hEnd, T, t0 + 1, 1, t0, kTile, mid);
+        rect(hEnd, T, t0 + 1, 1, t0, kTile, mid, false);
         (void)hipStreamWaitEvent(mid, eM3[P], 0);
-        trsm(t0 + 1, hEnd, T, mid);
+        trsm(t0 + 1, hEnd, T, mid, false);
       }
     }
     (void)hipEventRecord(eC[P], mid);
-    // ---- aux: bulk of SYRK(P), triangle starting two tile columns further (those belong to the look-ahead)
     const int tb = t0 + 4, nt = T - tb;
+    // ---- main: look-ahead part of SYRK(P) on the head window of panel P+1
+    if (P + 1 < NP) {
+      const int u0 = t0 + 2, uw = (T - u0 >= 2) ? 2 : 1, uEnd = (u0 + 4 < T) ? u0 + 4 : T;
+      if (P >= 1) (void)hipStreamWaitEvent(st, eB[P - 1], 0);  // bulk(P-1) was the previous writer of these tiles
+      (void)hipStreamWaitEvent(st, eC[P], 0);                   // rows u0+2.. were rest rows of panel P
+      rect(u0, uEnd, u0, uw, t0, 2 * kTile, st, true);
+      (void)hipEventRecord(eR[P + 1], st);
+    }
+    // ---- aux: bulk of SYRK(P), triangle starting two tile columns further (those belong to the look-ahead)
     (void)hipStreamWaitEvent(ax.aux, eA[P], 0);
     (void)hipStreamWaitEvent(ax.aux, eC[P], 0);
+    // A bulk launched at the same instant as the next head update takes every workgroup slot first and the 28 head
+    // workgroups wait ~75 us for the first round of tiles to retire (profiles/r01y timeline) — the bulk therefore
+    // starts after the head update (~10-30 us later).
+    if (P + 1 < NP) (void)hipStreamWaitEvent(ax.aux, eR[P + 1], 0);
     if (nt > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
       GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, 0, nullptr, nullptr};

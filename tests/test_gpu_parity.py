@@ -178,6 +178,30 @@ def test_mfma_cholesky_ill_scaled(ctx):
     assert rc == 0 and np.max(np.abs(x - x0) * d) < 1e-8 * np.max(np.abs(x0) * d)
 
 
+def test_mfma_cholesky_ill_conditioned_blocks(ctx):
+    # every 6x6 pose block is itself ill-conditioned (cond 1e10, random orientation), as in a real reduced camera
+    # system where rotation and translation are strongly coupled: the panel factorisation must stay backward
+    # stable inside its 4-column steps (a product with the explicit 4x4 inverse does not: spurious pivots <= 0)
+    n = 900
+    rng = np.random.default_rng(17)
+    S = np.zeros((n, n))
+    for i in range(0, n, 6):
+        R, _ = np.linalg.qr(rng.normal(0, 1, (6, 6)))
+        S[i:i + 6, i:i + 6] = R @ np.diag([1.0, 0.7, 0.4, 1e-10, 3e-10, 6e-10]) @ R.T
+    U = rng.normal(0, 1, (n, 40)) * 1e-5
+    S += U @ U.T
+    S = 0.5 * (S + S.T)
+    np.linalg.cholesky(S)  # the host LAPACK succeeds
+    b = rng.normal(0, 1, n)
+    rc, x = ctx.solve_reduced(S, b)
+    assert rc == 0
+    back = np.linalg.norm(S @ x - b) / (np.linalg.norm(S, 2) * np.linalg.norm(x) + np.linalg.norm(b))
+    assert back < 1e-13
+    rc0, xo = covo.solve_reduced(S, b)
+    back0 = np.linalg.norm(S @ xo - b) / (np.linalg.norm(S, 2) * np.linalg.norm(xo) + np.linalg.norm(b))
+    assert rc0 == 0 and back < 10 * max(back0, 1e-16)
+
+
 def _lm_whitened_diff(sol, ref, o):
     """sqrt(d^T H_ll d) per landmark, H_ll from the oracle's linearisation at the oracle's solution."""
     _, _, Jl, _ = covo.linearize_reprojection(ref, o)

@@ -1,5 +1,7 @@
 // potrf_probe.hip — phase timing of k_potrf_inv on an idle GPU (dev tool; build + run on the GPU box):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCOVGPU_PROBE tools/potrf_probe.hip -o /tmp/potrf_probe && /tmp/potrf_probe
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <vector>
 #include "../covins_amd/csrc/k_chol.hip"
@@ -17,18 +19,40 @@ int main() {
   hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e9;
-  for (int it = 0; it < 20; ++it) {
+  const int NIT = 200;
+  std::vector<std::vector<double>> ph(5);
+  std::vector<double> tot;
+  for (int it = 0; it < NIT; ++it) {
     hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
     { long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)); }
     hipEventRecord(e0);
     hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), lds, 0, dA, (size_t)n, 0, dL, df);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    long long pr[8];
+    hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr));
+    for (int k = 0; k < 5; ++k) ph[k].push_back((pr[k + 1] - pr[k]) / 100.0);
+    tot.push_back((pr[5] - pr[0]) / 100.0);
   }
-  long long pr[8];
-  hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr));
-  printf("potrf_inv best %.1f us; phases (100 MHz ticks -> us): load %.1f chol %.1f toLDS %.1f inverse %.1f store %.1f\n", best * 1e3,
-         (pr[1] - pr[0]) / 100.0, (pr[2] - pr[1]) / 100.0, (pr[3] - pr[2]) / 100.0, (pr[4] - pr[3]) / 100.0, (pr[5] - pr[4]) / 100.0);
-  printf("  inside chol: U %.1f us  D %.1f us  (T = rest)\n", pr[6] / 100.0, pr[7] / 100.0);
+  auto stat = [](std::vector<double> v, double& mn, double& med) { std::sort(v.begin(), v.end()); mn = v.front(); med = v[v.size() / 2]; };
+  const char* names[5] = {"load", "chol", "toLDS/writeback", "inverse", "store"};
+  printf("potrf_inv: best event time %.1f us over %d runs (100 MHz wall clock inside the kernel):\n", best * 1e3, NIT);
+  for (int k = 0; k < 5; ++k) { double mn, med; stat(ph[k], mn, med); printf("  %-16s min %.1f  median %.1f us\n", names[k], mn, med); }
+  { double mn, med; stat(tot, mn, med); printf("  %-16s min %.1f  median %.1f us\n", "kernel body", mn, med); }
+  // correctness on the last run: || L L^T - A ||_max and || Linv L - I ||_max
+  std::vector<double> L(n * n), Li(n * n);
+  hipMemcpy(L.data(), dA, n * n * 8, hipMemcpyDeviceToHost);
+  hipMemcpy(Li.data(), dL, n * n * 8, hipMemcpyDeviceToHost);
+  double e_llt = 0, e_inv = 0;
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c <= r; ++c) {
+      double s1 = 0, s2 = 0;
+      for (int k = 0; k <= c; ++k) s1 += L[r * n + k] * L[c * n + k];
+      for (int k = c; k <= r; ++k) s2 += Li[r * n + k] * L[k * n + c];
+      e_llt = fmax(e_llt, fabs(s1 - A[r * n + c]));
+      e_inv = fmax(e_inv, fabs(s2 - (r == c ? 1.0 : 0.0)));
+    }
+  int fl = 0; hipMemcpy(&fl, df, 4, hipMemcpyDeviceToHost);
+  printf("  max|LL^T-A| %.3e  max|Linv L - I| %.3e  flag %d\n", e_llt, e_inv, fl);
   return 0;
 }

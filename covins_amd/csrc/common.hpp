@@ -99,7 +99,7 @@ struct DevProblem {
   double* part;
   int part_n, part_imu, part_edge, part_vec;
   // deterministic IMU / edge accumulation: role-indexed slots filled with plain stores, summed by gather kernels
-  double *imuAd, *imuBs, *imuCd, *imuG;   // [2][K][81] | [2][K][54] | [2][K][36] | [2][K][30] (grad 15 | hdiag 15), role 0 = as predecessor, 1 = as successor
+  double *imuAd, *imuBs, *imuCd, *imuG;   // [2][K][81] | [2][K][54] | [3][K][36] | [2][K][30] (grad 15 | hdiag 15), role 0 = as predecessor, 1 = as successor; imuCd plane 2 = cross block (pos, pos-1)
   double* edgeOut;                         // [E][132]: Hii(36) Hjj(36) Hhi_lo(36) gi(6) gj(6) hdi(6) hdj(6)
   int *kf_edge_ptr, *kf_edge_ent;          // [K+1], [2E] incident (edge*2 + role) per keyframe, ascending
   int nepairs;
@@ -130,21 +130,25 @@ void launch_edge_jvp(const DevProblem& P, const double* v_all, hipStream_t st);
 void launch_edge_cost(const DevProblem& P, const double* pose, hipStream_t st);
 void launch_edge_linearize(const DevProblem& P, double* r, double* J, double* cost, hipStream_t st);
 
-void launch_finalize_diag(const DevProblem& P, double mu, hipStream_t st);
+void launch_finalize_diag(const DevProblem& P, double mu, int which, hipStream_t st);  // which: 0 pose, 1 speed-bias, 2 both
 // deterministic scalar reductions
 void launch_part_clear(const DevProblem& P, int slot0, int nslots, hipStream_t st);
 void launch_part_finish(const DevProblem& P, int slot0, int nslots, hipStream_t st);
-void launch_imu_gather(const DevProblem& P, hipStream_t st);
+void launch_imu_gather(const DevProblem& P, int which, hipStream_t st);  // which: 0 pose dims, 1 speed-bias dims, 2 both
 void launch_edge_gather(const DevProblem& P, hipStream_t st);
 // structured solve of the damped reduced system: speed-bias chains -> dense pose system -> back-substitution.
 // Solution (IR layout, D per keyframe) is written to dst[0..n).
 void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax);
+// speed-bias chain factorisation on the auxiliary stream as soon as the IMU blocks are final (overlaps the landmark pass)
+void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& ax);
 void launch_yty_update(const DevProblem& P, hipStream_t st);  // C -= Y^T Y on the MFMA path (k_chol.hip)
 void launch_zero_system(const DevProblem& P, hipStream_t st);
 // per-context resources of the dense factorisation: auxiliary stream for the look-ahead, ordering events, and
 // (profiling only) one timed event pair around every bulk trailing-update launch
 struct CholAux {
   hipStream_t aux = nullptr, mid = nullptr;
+  hipEvent_t ev_sb = nullptr, ev_cf = nullptr;  // speed-bias rows ready | chain factor done (early, on aux)
+  bool cf_pending = false;
   std::vector<hipEvent_t> ev, prof_ev;
   std::vector<double> prof_flops;
   bool profile = false;

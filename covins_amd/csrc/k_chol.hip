@@ -19,7 +19,8 @@
 //   * look-ahead on two HIP streams: the next panel's two tile columns are updated first and its panel
 //     factorisation (a serial chain of small kernels) runs on the main stream while the bulk of the trailing
 //     update occupies the chip from the auxiliary stream.
-// Triangular solves reuse the stored L_pp^-1 blocks: one small launch per 128-panel.
+// Forward substitution rides along with the factorisation (potrf forms y_p, every TRSM takes its tile's product
+// with y_p out of the right-hand side); the backward solve reuses the stored L_pp^-1 blocks, one launch per panel.
 #include <cstdlib>
 
 #include "common.hpp"
@@ -57,6 +58,9 @@ struct GemmArgs {
   const double* Linv; // TRSM: B = Linv (128x128, pitch 128)
   // YTY: C(ti,tj) -= Y[:, ti cols]^T Y[:, tj cols] over the intersection of the two tiles' non-zero K (speed-bias) ranges
   const double* Y; size_t ldy; const int* tile_cs; const int* tile_ce;
+  // TRSM with a right-hand side riding along (forward substitution fused into the factorisation):
+  // rhs[rows of this workgroup] -= X[rows, :] yvec[kcol0 .. kcol0+128), X = the freshly computed L tile
+  double* rhs; const double* yvec;
 };
 
 // C[i][j] (op)= sum_k A[i][k] B[j][k] on one 128x128 tile (TSA = TSB = 128), or on a quarter of it selected by
@@ -185,6 +189,32 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg)
         Cg[(size_t)(wr * WTR + tm * 16 + fk + 4 * rg) * ld + wc * WTC + tn * 16 + fr] = acc[tm][tn][rg];
+  if (MODE == MODE_TRSM && g.rhs != nullptr) {
+    // forward substitution riding along: rhs[row] -= sum_c X[row][c] y[c]. Lane partial over its columns, fixed
+    // butterfly over the 16 lanes that share a row, fixed-order sum over the wave columns: deterministic.
+    __syncthreads();                     // the staging buffers are free
+    double* sy = smem;                   // [128] y of this panel
+    double* sp = smem + kTile;           // [WGC][TSA] partial row sums
+    if (tid < kTile) sy[tid] = g.yvec[g.kcol0 + tid];
+    __syncthreads();
+#pragma unroll
+    for (int tm = 0; tm < NMR; ++tm)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        double pr = 0.0;
+#pragma unroll
+        for (int tn = 0; tn < NMC; ++tn) pr += acc[tm][tn][rg] * sy[wc * WTC + tn * 16 + fr];
+        pr += __shfl_xor(pr, 1, 64); pr += __shfl_xor(pr, 2, 64); pr += __shfl_xor(pr, 4, 64); pr += __shfl_xor(pr, 8, 64);
+        if (fr == 0) sp[wc * TSA + wr * WTR + tm * 16 + fk + 4 * rg] = pr;
+      }
+    __syncthreads();
+    if (tid < TSA) {
+      double t = 0.0;
+#pragma unroll
+      for (int w2 = 0; w2 < WGC; ++w2) t += sp[w2 * TSA + tid];
+      g.rhs[g.ra0 + ti * kTile + qr * TSA + tid] -= t;
+    }
+  }
 }
 
 // Factor the 128x128 diagonal block at (k0,k0) (lower Cholesky) and form its inverse.
@@ -193,7 +223,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
 // Cholesky: right-looking, the matrix lives in REGISTERS — thread (ty,tx) of the 16x16 grid owns the 8x8 elements
 // (r = ty + 16 i, c = tx + 16 k); only the pivot column travels through LDS each step. (Keeping the matrix in LDS
 // and updating it in place serialises on LDS read-after-write: measured 260 us per block instead of ~40.)
-__global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_t ld, int k0, double* __restrict__ Linv_out, int* flag) {
+__global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_t ld, int k0, double* __restrict__ Linv_out, int* flag,
+                                                    const double* __restrict__ rhs, double* __restrict__ yout) {
   extern __shared__ __attribute__((aligned(16))) double s[];  // [128][129]
   __shared__ __attribute__((aligned(16))) double colb[2][16][8];
   constexpr int PT = kTile + 1;
@@ -357,34 +388,14 @@ __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_
     const int r = idx >> 7, c = idx & 127;
     Linv_out[idx] = (c <= r) ? s[r * PT + c] : 0.0;
   }
-  PROBE(5);
-}
-
-// forward substitution step for panel p:  y_p = Linv_p b_p ; b[rows below] -= L[rows, panel p] y_p
-__global__ __launch_bounds__(256) void k_fwd_step(const double* __restrict__ M, size_t ld, int p, const double* __restrict__ Linv,
-                                                   double* __restrict__ b, double* __restrict__ y) {
-  __shared__ double sy[kTile];
-  __shared__ double sb_[kTile];
-  const int tid = threadIdx.x, k0 = p * kTile;
-  if (tid < kTile) sb_[tid] = b[k0 + tid];
-  __syncthreads();
-  if (tid < kTile) {
-    const double* Lr = Linv + (size_t)tid * kTile;
-    double s2 = 0.0;
-    for (int k = 0; k <= tid; ++k) s2 += Lr[k] * sb_[k];
-    sy[tid] = s2;
-    if (blockIdx.x == 0) y[k0 + tid] = s2;
+  // forward substitution riding along: y_p = L_pp^-1 b_p. Every earlier panel's TRSM has already taken its
+  // L[rows p, q] y_q out of b_p (the diagonal tile itself depends on those TRSMs).
+  if (rhs != nullptr && tid < kTile) {
+    double acc = 0.0;
+    for (int k = 0; k <= tid; ++k) acc += s[tid * PT + k] * rhs[k0 + k];
+    yout[k0 + tid] = acc;
   }
-  __syncthreads();
-  // each block updates 128 rows below the panel; 2 threads per row, each half of the 128 columns
-  const int row = k0 + kTile + blockIdx.x * kTile + (tid >> 1), half = tid & 1;
-  if (row >= (int)ld) return;  // last panel: nothing below (no barrier follows)
-  const double* Lr = M + (size_t)row * ld + k0 + half * 64;
-  double s2 = 0.0;
-#pragma unroll 8
-  for (int k = 0; k < 64; ++k) s2 += Lr[k] * sy[half * 64 + k];
-  s2 += __shfl_xor(s2, 1, 64);
-  if (half == 0) b[row] -= s2;
+  PROBE(5);
 }
 
 // backward substitution step for panel p:  x_p = Linv_p^T y_p ; y[cols left of the panel] -= L[panel rows, cols]^T x_p
@@ -464,12 +475,17 @@ void CholAux::init() {
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
   if (!mid) mid = make_side_stream(hi);
   if (!aux) aux = make_side_stream(lo);
+  if (!ev_sb) (void)hipEventCreateWithFlags(&ev_sb, hipEventDisableTiming);
+  if (!ev_cf) (void)hipEventCreateWithFlags(&ev_cf, hipEventDisableTiming);
 }
 void CholAux::destroy() {
   if (mid) { (void)hipStreamDestroy(mid); mid = nullptr; }
   for (auto e : ev) (void)hipEventDestroy(e);
   for (auto e : prof_ev) (void)hipEventDestroy(e);
   ev.clear(); prof_ev.clear();
+  if (ev_sb) { (void)hipEventDestroy(ev_sb); ev_sb = nullptr; }
+  if (ev_cf) { (void)hipEventDestroy(ev_cf); ev_cf = nullptr; }
+  cf_pending = false;
   if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
 }
 // after the streams have been synchronised: accumulate the bracketed trailing-update launches
@@ -511,19 +527,19 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   hipEvent_t* eR = eM3 + (NP + 1);
   hipStream_t mid = ax.mid;
 
-  auto potrf = [&](int t) { hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), lds_potrf, st, S, ld, t * kTile, Linv + (size_t)t * kTile * kTile, flag); };
+  auto potrf = [&](int t) { hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), lds_potrf, st, S, ld, t * kTile, Linv + (size_t)t * kTile * kTile, flag, b, b + npad); };
   // rows [r0, r1) of tile column t:  A <- A Linv_t^T
   // quad: four workgroups per tile (head launches on the serial chain)
   auto trsm = [&](int t, int r0, int r1, hipStream_t s2, bool quad) {
     if (r1 <= r0) return;
-    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, nullptr, 0, nullptr, nullptr};
+    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, nullptr, 0, nullptr, nullptr, b, b + npad};
     if (quad) hipLaunchKernelGGL((k_gemm_abt<MODE_TRSM, 32, kTile>), dim3(r1 - r0, 1, 4), dim3(256), (size_t)(32 + kTile) * LDT * sizeof(double), s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(r1 - r0), dim3(256), lds_gemm, s2, g);
   };
   // C tiles (rows [r0, r1), tile columns [tc0, tc0+ntc)) -= A[rows, K] A[tc.., K]^T, K = tiles kt0.. (KD columns); lower part only
   auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2, bool quad) {
     if (r1 <= r0 || ntc <= 0) return;
-    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, 0, nullptr, nullptr};
+    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     if (quad) hipLaunchKernelGGL((k_gemm_abt<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4), dim3(256), lds_gemm / 2, s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0), dim3(256), lds_gemm, s2, g);
   };
@@ -580,7 +596,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     if (P + 1 < NP) (void)hipStreamWaitEvent(ax.aux, eR[P + 1], 0);
     if (nt > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
-      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, 0, nullptr, nullptr};
+      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
       if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], ax.aux);
       hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk), dim3(256), lds_gemm, ax.aux, g);
       if (ax.profile) {
@@ -593,11 +609,8 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   (void)hipStreamWaitEvent(st, eB[NP - 1], 0);
   if (NP >= 2) (void)hipStreamWaitEvent(st, eB[NP - 2], 0);
   (void)hipStreamWaitEvent(st, eC[NP - 1], 0);
-  // L y = b, then L^T x = y; y lives in b[npad .. 2 npad)
-  for (int p = 0; p < T; ++p) {
-    const int rem = T - p - 1;
-    hipLaunchKernelGGL(k_fwd_step, dim3(rem > 0 ? rem : 1), dim3(256), 0, st, S, ld, p, Linv + (size_t)p * kTile * kTile, b, b + npad);
-  }
+  // y = L^-1 b was formed along the way (potrf: y_p = L_pp^-1 b_p; every TRSM: b[rows] -= L[rows, p] y_p) and lives
+  // in b[npad .. 2 npad). Remaining: L^T x = y.
   for (int p = T - 1; p >= 0; --p) {
     const int nb = (p * kTile + 31) / 32;
     hipLaunchKernelGGL(k_bwd_step, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, S, ld, p, Linv + (size_t)p * kTile * kTile, b + npad, b);
@@ -613,7 +626,7 @@ void launch_yty_update(const DevProblem& P, hipStream_t st) {
     attr_set = true;
   }
   const int T = P.npad / kTile;
-  GemmArgs g{P.Sred, (size_t)P.npad, 0, 0, 0, 0, 0, T, nullptr, P.Y, (size_t)P.npad, P.tile_cs, P.tile_ce};
+  GemmArgs g{P.Sred, (size_t)P.npad, 0, 0, 0, 0, 0, T, nullptr, P.Y, (size_t)P.npad, P.tile_cs, P.tile_ce, nullptr, nullptr};
   hipLaunchKernelGGL(k_gemm_abt<MODE_YTY>, dim3(T, T), dim3(256), lds_gemm, st, g);
 }
 

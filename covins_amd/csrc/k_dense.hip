@@ -20,17 +20,21 @@ using namespace covdev;
 // ------------------------------------------------------------------------------------------- vector kernels
 // add the trust-region damping mu * clamp(diag)^2 to every active diagonal entry of the structured system;
 // constant / unconstrained dimensions (diag(J^T J) == 0) become identity rows with zero right-hand side (A.6)
-__global__ __launch_bounds__(256) void k_finalize_diag(DevProblem P, double mu) {
+// which: 0 = pose rows (+ the padding rows of C), 1 = speed-bias rows, 2 = both. The speed-bias rows are complete as
+// soon as the IMU factors are in, so their part runs early and the chain factorisation overlaps the landmark pass.
+__global__ __launch_bounds__(256) void k_finalize_diag(DevProblem P, double mu, int which) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < P.n) {
     const int kf = q / P.D, r = q - kf * P.D, pos = P.perm[kf];
-    double* d = (r < 6) ? P.Sred + (size_t)(6 * pos + r) * P.npad + (6 * pos + r) : P.Ad + (size_t)81 * pos + 10 * (r - 6);
-    const double h = P.hdiag[q];
-    if (h == 0.0) { *d = 1.0; P.bred[q] = 0.0; }
-    else { const double c = clamp_diag(h); *d += mu * c * c; }
+    if (which == 2 || (which == 0) == (r < 6)) {
+      double* d = (r < 6) ? P.Sred + (size_t)(6 * pos + r) * P.npad + (6 * pos + r) : P.Ad + (size_t)81 * pos + 10 * (r - 6);
+      const double h = P.hdiag[q];
+      if (h == 0.0) { *d = 1.0; P.bred[q] = 0.0; }
+      else { const double c = clamp_diag(h); *d += mu * c * c; }
+    }
   }
   const int pad = 6 * P.K + q;  // padding rows of C
-  if (q < P.npad - 6 * P.K) P.Sred[(size_t)pad * P.npad + pad] = 1.0;
+  if (which != 1 && q < P.npad - 6 * P.K) P.Sred[(size_t)pad * P.npad + pad] = 1.0;
 }
 
 // fixed-order sum of one slot's partials -> scal[slot]
@@ -129,9 +133,9 @@ static inline int vec_grid(int n) {
   return b < 1 ? 1 : (b > 2048 ? 2048 : b);
 }
 
-void launch_finalize_diag(const DevProblem& P, double mu, hipStream_t st) {
+void launch_finalize_diag(const DevProblem& P, double mu, int which, hipStream_t st) {
   const int cnt = P.n > P.npad ? P.n : P.npad;
-  hipLaunchKernelGGL(k_finalize_diag, dim3((cnt + 255) / 256), dim3(256), 0, st, P, mu);
+  hipLaunchKernelGGL(k_finalize_diag, dim3((cnt + 255) / 256), dim3(256), 0, st, P, mu, which);
 }
 void launch_zero_system(const DevProblem& P, hipStream_t st) {
   hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), st);
@@ -144,7 +148,7 @@ void launch_zero_system(const DevProblem& P, hipStream_t st) {
     hipMemsetAsync(P.Bn, 0, (size_t)54 * P.K * sizeof(double), st);
     hipMemsetAsync(P.imuAd, 0, (size_t)2 * 81 * P.K * sizeof(double), st);
     hipMemsetAsync(P.imuBs, 0, (size_t)2 * 54 * P.K * sizeof(double), st);
-    hipMemsetAsync(P.imuCd, 0, (size_t)2 * 36 * P.K * sizeof(double), st);
+    hipMemsetAsync(P.imuCd, 0, (size_t)3 * 36 * P.K * sizeof(double), st);
     hipMemsetAsync(P.imuG, 0, (size_t)2 * 30 * P.K * sizeof(double), st);
   }
   hipMemsetAsync(P.grad, 0, (size_t)P.N * sizeof(double), st);

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64 * kImuWaves) void k_imu_build(DevProblem P) {
     const size_t slot = ga_ * K + (ga_ ? pj : pi);
     if (la < 6 && lb < 6) {          // pose-pose
       if (ga_ == gb_) P.imuCd[slot * 36 + 6 * la + lb] = h;
-      else if (ga_ == 1) P.Sred[(size_t)(6 * pj + la) * ld + 6 * pi + lb] += h;   // single writer after k_pair_blocks
+      else if (ga_ == 1) P.imuCd[(2 * K + pj) * 36 + 6 * la + lb] = h;   // cross block (pos_j, pos_i): plane 2, added by k_imu_gather after k_pair_blocks
     } else if (la >= 6 && lb >= 6) { // sb-sb
       if (ga_ == gb_) P.imuAd[slot * 81 + 9 * (la - 6) + (lb - 6)] = h;
       else if (ga_ == 1) P.Ae[(size_t)81 * pj + 9 * (la - 6) + (lb - 6)] = h;
@@ -342,21 +342,30 @@ __global__ __launch_bounds__(64 * kImuWaves) void k_imu_build(DevProblem P) {
 }
 
 // sums the two role slots of every chain position in a fixed order: Ad, Bs, diagonal block of C, gradient, rhs, diag(J^T J)
-__global__ __launch_bounds__(256) void k_imu_gather(DevProblem P) {
+// which: 1 = everything that lives on speed-bias dimensions (only IMU factors touch those, so it can run before the
+// landmark pass and release the chain factorisation early), 0 = the pose-dimension part (adds onto what k_kf_reduce
+// assigned: must run after it), 2 = both.
+__global__ __launch_bounds__(256) void k_imu_gather(DevProblem P, int which) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int pos = t / 201, e = t - 201 * pos;
   if (pos >= P.K) return;
   const size_t K = (size_t)P.K, s0 = (size_t)pos, s1 = K + pos;
   if (e < 81) {
-    P.Ad[81 * s0 + e] = P.imuAd[81 * s0 + e] + P.imuAd[81 * s1 + e];
+    if (which != 0) P.Ad[81 * s0 + e] = P.imuAd[81 * s0 + e] + P.imuAd[81 * s1 + e];
   } else if (e < 135) {
     const int q = e - 81;
-    P.Bs[54 * s0 + q] = P.imuBs[54 * s0 + q] + P.imuBs[54 * s1 + q];
+    if (which != 0) P.Bs[54 * s0 + q] = P.imuBs[54 * s0 + q] + P.imuBs[54 * s1 + q];
   } else if (e < 171) {
     const int q = e - 135, r = q / 6, c = q - 6 * r;
-    if (c <= r) P.Sred[(size_t)(6 * pos + r) * P.npad + 6 * pos + c] += P.imuCd[36 * s0 + q] + P.imuCd[36 * s1 + q];
+    if (which != 1) {
+      if (c <= r) P.Sred[(size_t)(6 * pos + r) * P.npad + 6 * pos + c] += P.imuCd[36 * s0 + q] + P.imuCd[36 * s1 + q];
+      const double x = P.imuCd[36 * (2 * K + pos) + q];  // pose_pos x pose_(pos-1) of the factor ending here (exactly 0: none)
+      if (x != 0.0) P.Sred[(size_t)(6 * pos + r) * P.npad + 6 * (pos - 1) + c] += x;
+    }
   } else {
     const int q = e - 171, kf = P.pos_kf[pos];
+    const int dim = q < 15 ? q : q - 15;
+    if (which != 2 && (which == 0) != (dim < 6)) return;
     const double v = P.imuG[30 * s0 + q] + P.imuG[30 * s1 + q];
     if (q < 15) { P.grad[(size_t)15 * kf + q] += v; P.bred[(size_t)15 * kf + q] -= v; }
     else P.hdiag[(size_t)15 * kf + q - 15] += v;
@@ -418,9 +427,9 @@ void launch_imu_build(const DevProblem& P, hipStream_t st) {
   if (P.I == 0) return;
   hipLaunchKernelGGL(k_imu_build, imu_grid(P.I), dim3(64 * kImuWaves), 0, st, P);
 }
-void launch_imu_gather(const DevProblem& P, hipStream_t st) {
+void launch_imu_gather(const DevProblem& P, int which, hipStream_t st) {
   if (!P.vi) return;
-  hipLaunchKernelGGL(k_imu_gather, dim3((201 * P.K + 255) / 256), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(k_imu_gather, dim3((201 * P.K + 255) / 256), dim3(256), 0, st, P, which);
 }
 void launch_imu_jvp(const DevProblem& P, const double* v_all, hipStream_t st) {
   if (P.I == 0) return;

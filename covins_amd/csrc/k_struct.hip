@@ -23,14 +23,15 @@ namespace covgpu {
 using namespace covdev;
 
 // gather the right-hand side: pose part into bp (chain-major, padded), speed-bias part into xs (chain order)
-__global__ __launch_bounds__(256) void k_gather_rhs(DevProblem P) {
+// which: 0 = pose part, 1 = speed-bias part, 2 = both
+__global__ __launch_bounds__(256) void k_gather_rhs(DevProblem P, int which) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < P.npad) {
+  if (which != 1 && q < P.npad) {
     double v = 0.0;
     if (q < 6 * P.K) { const int pos = q / 6, r = q - 6 * pos; v = P.bred[(size_t)P.D * P.pos_kf[pos] + r]; }
     P.bp[q] = v;
   }
-  if (P.vi && q < 9 * P.K) { const int pos = q / 9, r = q - 9 * pos; P.xs[q] = P.bred[(size_t)15 * P.pos_kf[pos] + 6 + r]; }
+  if (which != 0 && P.vi && q < 9 * P.K) { const int pos = q / 9, r = q - 9 * pos; P.xs[q] = P.bred[(size_t)15 * P.pos_kf[pos] + 6 + r]; }
 }
 
 __global__ __launch_bounds__(256) void k_scatter_solution(DevProblem P, double* __restrict__ dst) {
@@ -168,34 +169,58 @@ __global__ __launch_bounds__(64) void k_sb_chain_factor(DevProblem P) {
 }
 
 // Columns of Y = L_A^-1 B: one thread per pose dimension (column), marching down its chain from the first
-// keyframe whose speed-bias block touches it. Y is K-major, so a wave's 64 columns are written coalesced.
+// keyframe whose speed-bias block touches it. Y is K-major, so a workgroup's 256 columns are written coalesced.
+// Every workgroup lies inside ONE chain and all its threads visit the same chain position in the same iteration
+// (columns that start further down idle until the march reaches them): the position's factor blocks Lsub | Ldinv
+// are then staged ONCE per workgroup in (double-buffered) LDS and read as broadcasts. The first version let every
+// thread walk from its own start — 11 different positions per wave, 126 divergent global loads per step: 1.76 ms
+// on the 5-agent map, all of it load latency.
 __global__ __launch_bounds__(256) void k_sb_chain_cols(DevProblem P) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= 6 * P.K) return;
-  const int q = col / 6, e = col - 6 * q;      // chain position of the pose, component
-  const int p1 = P.pos_chain_end[q];
-  const int pstart = (q > 0 && P.pos_chain_end[q - 1] == p1) ? q - 1 : q;  // previous position if it is on the same chain
+  __shared__ __attribute__((aligned(16))) double sL[2][168];  // [buffer][Lsub 81 | pad 3 | Ldinv 81 | pad 3]
+  const int tid = threadIdx.x;
+  int b = blockIdx.x, c = 0;
+  for (; c < P.nchains; ++c) {  // workgroup -> (chain, block of 256 columns inside it)
+    const int nb = (6 * (P.chain_ptr[c + 1] - P.chain_ptr[c]) + 255) / 256;
+    if (b < nb) break;
+    b -= nb;
+  }
+  if (c >= P.nchains) return;
+  const int p0 = P.chain_ptr[c], p1 = P.chain_ptr[c + 1];
+  const int col = 6 * p0 + b * 256 + tid;
+  const bool live = col < 6 * p1;
+  const int q = live ? col / 6 : p1 - 1, e = col - 6 * q;  // chain position of the pose, component
+  const int pstart = q > p0 ? q - 1 : q;                    // previous position if it is on the same chain
+  const int pfirst = max((6 * p0 + b * 256) / 6 - 1, p0);   // first position any column of this workgroup needs
+  auto fetch = [&](int pos) -> double {
+    if (tid < 81) return P.Lsub[(size_t)81 * pos + tid];
+    if (tid >= 84 && tid < 165) return P.Ldinv[(size_t)81 * pos + tid - 84];
+    return 0.0;
+  };
   double y[9];
 #pragma unroll
   for (int a = 0; a < 9; ++a) y[a] = 0.0;
-  for (int pos = pstart; pos < p1; ++pos) {
+  double nxt = fetch(pfirst);
+  for (int pos = pfirst; pos < p1; ++pos) {
+    double (&L)[168] = sL[(pos - pfirst) & 1];
+    if (tid < 168) L[tid] = nxt;
+    if (pos + 1 < p1) nxt = fetch(pos + 1);  // in flight during this step's arithmetic
+    __syncthreads();                          // one barrier per step: the other buffer is rewritten two steps later
+    if (!live || pos < pstart) continue;
     double v[9];
     const double* Bblk = (pos == q - 1) ? P.Bn : (pos == q ? P.Bs : (pos == q + 1 ? P.Bp : nullptr));
 #pragma unroll
     for (int a = 0; a < 9; ++a) v[a] = Bblk ? Bblk[(size_t)54 * pos + 6 * a + e] : 0.0;
     if (pos > pstart) {
-      const double* Ls = P.Lsub + (size_t)81 * pos;
 #pragma unroll
       for (int a = 0; a < 9; ++a)
 #pragma unroll
-        for (int k = 0; k < 9; ++k) v[a] -= Ls[9 * a + k] * y[k];
+        for (int k = 0; k < 9; ++k) v[a] -= L[9 * a + k] * y[k];
     }
-    const double* Li = P.Ldinv + (size_t)81 * pos;
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
       double s2 = 0.0;
 #pragma unroll
-      for (int k = 0; k <= a; ++k) s2 += Li[9 * a + k] * v[k];
+      for (int k = 0; k <= a; ++k) s2 += L[84 + 9 * a + k] * v[k];
       y[a] = s2;
     }
 #pragma unroll
@@ -256,54 +281,63 @@ COV_DEV SbRowB sb_load_bwd(const DevProblem& P, int pos, int p1, int lane) {
 }
 
 __global__ __launch_bounds__(64) void k_sb_backsolve(DevProblem P) {
-  __shared__ double su[9], sprev[9];
+  // the 9-vector of the previous step lives in lanes 0..8 and is broadcast with v_readlane (through SGPRs): no LDS
+  // round trip and no barrier on the ~900-step dependent chain (the LDS version took 1.4 us per step)
   const int lane = threadIdx.x < 9 ? threadIdx.x : 8;
   const bool act = threadIdx.x < 9;
   const int p0 = P.chain_ptr[blockIdx.x], p1 = P.chain_ptr[blockIdx.x + 1];
-  if (act) sprev[lane] = 0.0;
-  __syncthreads();
+  double prev = 0.0;
   SbRowF cf = sb_load_fwd(P, p0, p0, p1, lane);
   for (int pos = p0; pos < p1; ++pos) {  // forward: u_pos = Linv (w_pos - Lsub u_{pos-1}), stored in xs
     SbRowF nf = cf;
     if (pos + 1 < p1) nf = sb_load_fwd(P, pos + 1, p0, p1, lane);
     double w = cf.w;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w -= cf.ls[k] * sprev[k];  // Lsub of a chain head is zero
-    if (act) su[lane] = w;
-    __syncthreads();
+    for (int k = 0; k < 9; ++k) w -= cf.ls[k] * rdlane64(prev, k);  // Lsub of a chain head is zero
     double u = 0.0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) u += cf.li[k] * su[k];     // Ldinv is lower triangular: entries k > lane are zero
-    if (act) { P.xs[(size_t)9 * pos + lane] = u; sprev[lane] = u; }
-    __syncthreads();
+    for (int k = 0; k < 9; ++k) u += cf.li[k] * rdlane64(w, k);     // Ldinv is lower triangular: entries k > lane are zero
+    if (act) P.xs[(size_t)9 * pos + lane] = u;
+    prev = u;
     cf = nf;
   }
-  if (act) sprev[lane] = 0.0;
-  __syncthreads();
+  prev = 0.0;
+  __syncthreads();  // xs written above is re-read below by the same lanes; keeps the two sweeps ordered
   SbRowB cb = sb_load_bwd(P, p1 - 1, p1, lane);
   for (int pos = p1 - 1; pos >= p0; --pos) {  // backward: x_pos = Linv^T (u_pos - Lsub_{pos+1}^T x_{pos+1})
     SbRowB nb = cb;
     if (pos > p0) nb = sb_load_bwd(P, pos - 1, p1, lane);
     double w = cb.u;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w -= cb.lsT[k] * sprev[k];
-    if (act) su[lane] = w;
-    __syncthreads();
+    for (int k = 0; k < 9; ++k) w -= cb.lsT[k] * rdlane64(prev, k);
     double x = 0.0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) x += cb.liT[k] * su[k];    // column of a lower-triangular matrix: entries k < lane are zero
-    if (act) { P.xs[(size_t)9 * pos + lane] = x; sprev[lane] = x; }
-    __syncthreads();
+    for (int k = 0; k < 9; ++k) x += cb.liT[k] * rdlane64(w, k);    // column of a lower-triangular matrix: entries k < lane are zero
+    if (act) P.xs[(size_t)9 * pos + lane] = x;
+    prev = x;
     cb = nb;
   }
 }
 
+void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& ax) {
+  if (!P.vi) return;
+  ax.init();
+  hipLaunchKernelGGL(k_gather_rhs, dim3((9 * P.K + 255) / 256), dim3(256), 0, st, P, 1);
+  (void)hipEventRecord(ax.ev_sb, st);
+  (void)hipStreamWaitEvent(ax.aux, ax.ev_sb, 0);
+  hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, ax.aux, P);
+  (void)hipEventRecord(ax.ev_cf, ax.aux);
+  ax.cf_pending = true;
+}
+
 void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax) {
   const int cnt = P.npad > 9 * P.K ? P.npad : 9 * P.K;
-  hipLaunchKernelGGL(k_gather_rhs, dim3((cnt + 255) / 256), dim3(256), 0, st, P);
+  const bool early = P.vi && ax.cf_pending;  // chain factor (and z in xs) already under way on the auxiliary stream
+  hipLaunchKernelGGL(k_gather_rhs, dim3((cnt + 255) / 256), dim3(256), 0, st, P, early ? 0 : 2);
   if (P.vi) {
-    hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, st, P);
-    hipLaunchKernelGGL(k_sb_chain_cols, dim3((6 * P.K + 255) / 256), dim3(256), 0, st, P);
+    if (early) { (void)hipStreamWaitEvent(st, ax.ev_cf, 0); ax.cf_pending = false; }
+    else hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(k_sb_chain_cols, dim3((6 * P.K + 255) / 256 + P.nchains), dim3(256), 0, st, P);  // >= sum of per-chain block counts
     hipLaunchKernelGGL(k_pose_rhs, dim3((8 * 6 * P.K + 255) / 256), dim3(256), 0, st, P);
     launch_yty_update(P, st);
   }

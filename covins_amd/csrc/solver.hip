@@ -324,7 +324,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_alloc(c, &P.part, (size_t)SC_COUNT * P.part_n));
   HIPCHK(hipMemsetAsync(P.part, 0, (size_t)SC_COUNT * P.part_n * sizeof(double), c->st));
   RC(dev_alloc(c, &P.imuAd, 2 * 81 * Kv)); RC(dev_alloc(c, &P.imuBs, 2 * 54 * Kv));
-  RC(dev_alloc(c, &P.imuCd, 2 * 36 * Kv)); RC(dev_alloc(c, &P.imuG, 2 * 30 * Kv));
+  RC(dev_alloc(c, &P.imuCd, 3 * 36 * Kv)); RC(dev_alloc(c, &P.imuG, 2 * 30 * Kv));
   RC(dev_alloc(c, &P.edgeOut, (size_t)132 * P.E));
   {
     // keyframe -> incident edges (ascending edge index), unique pose pairs -> edges
@@ -383,12 +383,19 @@ static void enqueue_build(covgpu_context* c, double mu) {
   const DevProblem& P = c->P;
   if (c->profiling) (void)hipEventRecord(c->ev[0], c->st);
   launch_zero_system(P, c->st);
-  launch_lm_build(P, mu, c->st);
+  // inertial factors first: the speed-bias blocks are then final, and the (serial, one wave per IMU chain) chain
+  // factorisation runs on the auxiliary stream underneath the landmark pass
   launch_imu_build(P, c->st);
-  launch_imu_gather(P, c->st);
+  if (P.vi) {
+    launch_imu_gather(P, 1, c->st);
+    launch_finalize_diag(P, mu, 1, c->st);
+    launch_sb_chain_factor_early(P, c->st, c->chol);
+  }
+  launch_lm_build(P, mu, c->st);
+  launch_imu_gather(P, 0, c->st);  // pose-dimension part: adds onto the blocks k_kf_reduce assigned (fixed order: visual, inertial, loop)
   launch_edge_build(P, c->st);
   launch_edge_gather(P, c->st);
-  launch_finalize_diag(P, mu, c->st);
+  launch_finalize_diag(P, mu, P.vi ? 0 : 2, c->st);
   launch_part_finish(P, SC_COST, 1, c->st);
   if (c->profiling) (void)hipEventRecord(c->ev[1], c->st);
 }
@@ -635,6 +642,7 @@ static int schur_impl(covgpu_context* c, const covgpu_options* opt, const covgpu
   RC(upload_impl(c, opt, p, pgo)); RC(reset_state(c));
   launch_preintegrate(c->P, *opt, c->st);
   enqueue_build(c, mu);
+  if (c->chol.cf_pending) { HIPCHK(hipStreamWaitEvent(c->st, c->chol.ev_cf, 0)); c->chol.cf_pending = false; }  // not used here
   RC(read_scalars(c));
   *cost = c->h_scal[SC_COST];
   // assemble the reduced system in IR layout (D rows per keyframe) from its structured parts

@@ -2,7 +2,7 @@
 """Timeline of ONE dense factorisation from a rocprofv3 rocpd SQLite database (dev tool).
 usage: rocpd_timeline.py results.db [which=3] > timeline.csv
 Selects the kernels between the `which`-th k_gemm_abt<3,..> (Y^T Y update, runs right before the factorisation)
-and the next k_fwd_step, and prints start (us, relative), duration (us), queue, short name, grid."""
+and the next k_bwd_step, and prints start (us, relative), duration (us), queue, short name, grid."""
 import re
 import sqlite3
 import sys
@@ -18,7 +18,7 @@ def main():
     rows = db.execute(f"select name, start, end, {qcol}, {gcol} from kernels order by start").fetchall()
     yty = [i for i, r in enumerate(rows) if "k_gemm_abt<3" in r[0]]
     i0 = yty[which]
-    i1 = next(i for i in range(i0, len(rows)) if "k_fwd_step" in rows[i][0])
+    i1 = next(i for i in range(i0, len(rows)) if "k_bwd_step" in rows[i][0])
     t0 = rows[i0][2]
     print("start_us,dur_us,queue,name,grid")
     for name, st, en, q, g in rows[i0 + 1:i1 + 1]:

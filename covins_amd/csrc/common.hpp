@@ -80,12 +80,12 @@ struct DevProblem {
   double *Ad, *Ae;          // [K][81] speed-bias diagonal / sub-diagonal (pos, pos-1) blocks, by position
   double *Bp, *Bs, *Bn;     // [K][54] speed-bias(pos) x pose(pos-1 | pos | pos+1) blocks (9x6)
   double *Ld, *Ldinv, *Lsub;  // [K][81] block-bidiagonal Cholesky factor of the speed-bias part
+  double *Mblk, *GI;          // [K][81] propagator M_pos = -Ldinv_pos Lsub_pos | I + Gramian of everything below pos (k_struct.hip)
   double* Y;       // [nyrows][npad] Y = L_A^-1 B: speed-bias rows (chain order) x pose columns, zero outside the chain trapezoids
   int nyrows;      // 9K rounded up to a multiple of 16
   double* zs;      // [9K]  L_A^-1 b_s
   double* xs;      // [9K]  speed-bias solution (chain order)
   double* bp;      // [2 npad] pose right-hand side / solution of the dense stage (+ scratch half)
-  int *tile_cs, *tile_ce;   // [npad/128] non-zero row (speed-bias) range of each 128-column tile of Y
   double* grad;    // [N]  J^T r           (pose part, then landmark part)
   double* hdiag;   // [N]  diag(J^T J)
   double* HllInv;  // [L][6] damped inverse landmark blocks (xx xy xz yy yz zz)
@@ -141,13 +141,12 @@ void launch_edge_gather(const DevProblem& P, hipStream_t st);
 void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax);
 // speed-bias chain factorisation on the auxiliary stream as soon as the IMU blocks are final (overlaps the landmark pass)
 void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& ax);
-void launch_yty_update(const DevProblem& P, hipStream_t st);  // C -= Y^T Y on the MFMA path (k_chol.hip)
 void launch_zero_system(const DevProblem& P, hipStream_t st);
 // per-context resources of the dense factorisation: auxiliary stream for the look-ahead, ordering events, and
 // (profiling only) one timed event pair around every bulk trailing-update launch
 struct CholAux {
   hipStream_t aux = nullptr, mid = nullptr;
-  hipEvent_t ev_sb = nullptr, ev_cf = nullptr;  // speed-bias rows ready | chain factor done (early, on aux)
+  hipEvent_t ev_sb = nullptr, ev_cf = nullptr, ev_g = nullptr;  // speed-bias rows ready | chain factor done | Gramians done (early, on aux)
   bool cf_pending = false;
   std::vector<hipEvent_t> ev, prof_ev;
   std::vector<double> prof_flops;

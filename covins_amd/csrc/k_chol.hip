@@ -46,7 +46,7 @@ __device__ long long g_probe[8];
 constexpr int KC = 16;        // K chunk staged through LDS
 constexpr int LDT = KC + 1;   // LDS pitch (doubles): odd pitch -> conflict-free fragment reads
 
-enum { MODE_SYRK_TRI = 0, MODE_SYRK_RECT = 1, MODE_TRSM = 2, MODE_YTY = 3 };
+enum { MODE_SYRK_TRI = 0, MODE_SYRK_RECT = 1, MODE_TRSM = 2 };
 
 struct GemmArgs {
   double* M; size_t ld;
@@ -56,8 +56,6 @@ struct GemmArgs {
   int cc0;            // C tile at (ra0 + ti*128, cc0 + tj*128)   (TRI: == ra0; TRSM: == kcol0, tj = 0)
   int nt;             // tile rows (TRI: triangle order)
   const double* Linv; // TRSM: B = Linv (128x128, pitch 128)
-  // YTY: C(ti,tj) -= Y[:, ti cols]^T Y[:, tj cols] over the intersection of the two tiles' non-zero K (speed-bias) ranges
-  const double* Y; size_t ldy; const int* tile_cs; const int* tile_ce;
   // TRSM with a right-hand side riding along (forward substitution fused into the factorisation):
   // rhs[rows of this workgroup] -= X[rows, :] yvec[kcol0 .. kcol0+128), X = the freshly computed L tile
   double* rhs; const double* yvec;
@@ -90,17 +88,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
   } else if (MODE == MODE_SYRK_RECT) {
     ti = blockIdx.y; tj = blockIdx.x;
     if (g.ra0 + ti * kTile < g.cc0 + tj * kTile) return;  // strictly above the diagonal
-  } else if (MODE == MODE_YTY) {
-    ti = blockIdx.y; tj = blockIdx.x;
-    if (tj > ti) return;
   } else {
     ti = blockIdx.x; tj = 0;
   }
-  int kbeg = 0, kend = g.KD;
-  if (MODE == MODE_YTY) {
-    kbeg = max(g.tile_cs[ti], g.tile_cs[tj]); kend = min(g.tile_ce[ti], g.tile_ce[tj]);
-    if (kbeg >= kend) return;  // the two tiles' keyframes share no IMU chain segment
-  }
+  const int kbeg = 0, kend = g.KD;
   extern __shared__ __attribute__((aligned(16))) double smem[];  // [TSA][KC+1] + [TSB][KC+1] doubles
   double (*sA)[LDT] = reinterpret_cast<double (*)[LDT]>(smem);
   double (*sB)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + TSA * LDT);
@@ -109,33 +100,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
   const size_t ld = g.ld;
   const double *Ag, *Bg;
   size_t lda, ldb;
-  if (MODE == MODE_YTY) {
-    Ag = g.Y + (size_t)(ti * kTile); Bg = g.Y + (size_t)(tj * kTile); lda = ldb = g.ldy;
-  } else {
-    Ag = g.M + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + g.kcol0; lda = ld;
-    if (MODE == MODE_TRSM) { Bg = g.Linv; ldb = kTile; }
-    else { Bg = g.M + (size_t)(g.rb0 + tj * kTile + qc * TSB) * ld + g.kcol0; ldb = ld; }
-  }
+  Ag = g.M + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + g.kcol0; lda = ld;
+  if (MODE == MODE_TRSM) { Bg = g.Linv; ldb = kTile; }
+  else { Bg = g.M + (size_t)(g.rb0 + tj * kTile + qc * TSB) * ld + g.kcol0; ldb = ld; }
   double* Cg = g.M + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + (size_t)(g.cc0 + tj * kTile + qc * TSB);
   // staging map: KC/2 lanes cover one KC-double row segment (contiguous), 512/KC rows per pass
   constexpr int LPR = KC / 2, RPP = 256 / LPR, NPA = TSA / RPP, NPB = TSB / RPP;
   const int c2 = (tid % LPR) * 2, rbase = tid / LPR;
   double2 pa[NPA], pb[NPB];
   auto gload = [&](int kc) {
-    if (MODE == MODE_YTY) {
 #pragma unroll
-      for (int it = 0; it < NPA; ++it) {
-        // Y is K-major ([sb dim][pose dim]): one K row of the tile is 1 KiB contiguous -> 64 lanes x 16 B
-        const int idx = tid + 256 * it, krow = idx >> 6, i2 = (idx & 63) * 2;
-        pa[it] = *reinterpret_cast<const double2*>(Ag + (size_t)(kc + krow) * lda + i2);
-        pb[it] = *reinterpret_cast<const double2*>(Bg + (size_t)(kc + krow) * ldb + i2);
-      }
-    } else {
+    for (int it = 0; it < NPA; ++it) pa[it] = *reinterpret_cast<const double2*>(Ag + (size_t)(rbase + RPP * it) * lda + kc + c2);
 #pragma unroll
-      for (int it = 0; it < NPA; ++it) pa[it] = *reinterpret_cast<const double2*>(Ag + (size_t)(rbase + RPP * it) * lda + kc + c2);
-#pragma unroll
-      for (int it = 0; it < NPB; ++it) pb[it] = *reinterpret_cast<const double2*>(Bg + (size_t)(rbase + RPP * it) * ldb + kc + c2);
-    }
+    for (int it = 0; it < NPB; ++it) pb[it] = *reinterpret_cast<const double2*>(Bg + (size_t)(rbase + RPP * it) * ldb + kc + c2);
   };
   gload(kbeg);
   const int fr = lane & 15, fk = lane >> 4;
@@ -153,19 +130,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
   const double sgn = (MODE == MODE_TRSM) ? 1.0 : -1.0;  // SYRK: acc = C - A B^T through a negated A fragment
   for (int kc = kbeg; kc < kend; kc += KC) {
     __syncthreads();  // previous chunk fully consumed
-    if (MODE == MODE_YTY) {  // transpose on the way into LDS
 #pragma unroll
-      for (int it = 0; it < NPA; ++it) {
-        const int idx = tid + 256 * it, krow = idx >> 6, i2 = (idx & 63) * 2;
-        sA[i2][krow] = sgn * pa[it].x; sA[i2 + 1][krow] = sgn * pa[it].y;
-        sB[i2][krow] = pb[it].x; sB[i2 + 1][krow] = pb[it].y;
-      }
-    } else {
+    for (int it = 0; it < NPA; ++it) { sA[rbase + RPP * it][c2] = sgn * pa[it].x; sA[rbase + RPP * it][c2 + 1] = sgn * pa[it].y; }
 #pragma unroll
-      for (int it = 0; it < NPA; ++it) { sA[rbase + RPP * it][c2] = sgn * pa[it].x; sA[rbase + RPP * it][c2 + 1] = sgn * pa[it].y; }
-#pragma unroll
-      for (int it = 0; it < NPB; ++it) { sB[rbase + RPP * it][c2] = pb[it].x; sB[rbase + RPP * it][c2 + 1] = pb[it].y; }
-    }
+    for (int it = 0; it < NPB; ++it) { sB[rbase + RPP * it][c2] = pb[it].x; sB[rbase + RPP * it][c2 + 1] = pb[it].y; }
     __syncthreads();
     if (kc + KC < kend) gload(kc + KC);  // prefetch the next chunk while the matrix cores work
 #pragma unroll
@@ -477,6 +445,7 @@ void CholAux::init() {
   if (!aux) aux = make_side_stream(lo);
   if (!ev_sb) (void)hipEventCreateWithFlags(&ev_sb, hipEventDisableTiming);
   if (!ev_cf) (void)hipEventCreateWithFlags(&ev_cf, hipEventDisableTiming);
+  if (!ev_g) (void)hipEventCreateWithFlags(&ev_g, hipEventDisableTiming);
 }
 void CholAux::destroy() {
   if (mid) { (void)hipStreamDestroy(mid); mid = nullptr; }
@@ -485,6 +454,7 @@ void CholAux::destroy() {
   ev.clear(); prof_ev.clear();
   if (ev_sb) { (void)hipEventDestroy(ev_sb); ev_sb = nullptr; }
   if (ev_cf) { (void)hipEventDestroy(ev_cf); ev_cf = nullptr; }
+  if (ev_g) { (void)hipEventDestroy(ev_g); ev_g = nullptr; }
   cf_pending = false;
   if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
 }
@@ -532,14 +502,14 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   // quad: four workgroups per tile (head launches on the serial chain)
   auto trsm = [&](int t, int r0, int r1, hipStream_t s2, bool quad) {
     if (r1 <= r0) return;
-    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, nullptr, 0, nullptr, nullptr, b, b + npad};
+    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, b, b + npad};
     if (quad) hipLaunchKernelGGL((k_gemm_abt<MODE_TRSM, 32, kTile>), dim3(r1 - r0, 1, 4), dim3(256), (size_t)(32 + kTile) * LDT * sizeof(double), s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(r1 - r0), dim3(256), lds_gemm, s2, g);
   };
   // C tiles (rows [r0, r1), tile columns [tc0, tc0+ntc)) -= A[rows, K] A[tc.., K]^T, K = tiles kt0.. (KD columns); lower part only
   auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2, bool quad) {
     if (r1 <= r0 || ntc <= 0) return;
-    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr};
     if (quad) hipLaunchKernelGGL((k_gemm_abt<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4), dim3(256), lds_gemm / 2, s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0), dim3(256), lds_gemm, s2, g);
   };
@@ -596,7 +566,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     if (P + 1 < NP) (void)hipStreamWaitEvent(ax.aux, eR[P + 1], 0);
     if (nt > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
-      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr};
       if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], ax.aux);
       hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk), dim3(256), lds_gemm, ax.aux, g);
       if (ax.profile) {
@@ -615,19 +585,6 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     const int nb = (p * kTile + 31) / 32;
     hipLaunchKernelGGL(k_bwd_step, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, S, ld, p, Linv + (size_t)p * kTile * kTile, b + npad, b);
   }
-}
-
-// C -= Y^T Y: second Schur complement (speed-bias chains eliminated) on the matrix cores
-void launch_yty_update(const DevProblem& P, hipStream_t st) {
-  const size_t lds_gemm = (size_t)2 * kTile * LDT * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_YTY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
-    attr_set = true;
-  }
-  const int T = P.npad / kTile;
-  GemmArgs g{P.Sred, (size_t)P.npad, 0, 0, 0, 0, 0, T, nullptr, P.Y, (size_t)P.npad, P.tile_cs, P.tile_ce, nullptr, nullptr};
-  hipLaunchKernelGGL(k_gemm_abt<MODE_YTY>, dim3(T, T), dim3(256), lds_gemm, st, g);
 }
 
 }  // namespace covgpu

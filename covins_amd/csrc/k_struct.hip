@@ -168,63 +168,158 @@ __global__ __launch_bounds__(64) void k_sb_chain_factor(DevProblem P) {
   }
 }
 
-// Columns of Y = L_A^-1 B: one thread per pose dimension (column), marching down its chain from the first
-// keyframe whose speed-bias block touches it. Y is K-major, so a workgroup's 256 columns are written coalesced.
-// Every workgroup lies inside ONE chain and all its threads visit the same chain position in the same iteration
-// (columns that start further down idle until the march reaches them): the position's factor blocks Lsub | Ldinv
-// are then staged ONCE per workgroup in (double-buffered) LDS and read as broadcasts. The first version let every
-// thread walk from its own start — 11 different positions per wave, 126 divergent global loads per step: 1.76 ms
-// on the 5-agent map, all of it load latency.
+// Columns of Y = L_A^-1 B, marching down the chain: at position pos
+//     T = B_inj - Lsub_pos Y(pos-1)          Y(pos) = Ldinv_pos T
+// for all columns at once — two (9x9)x(9x16) products per 16-column tile, done on the matrix core by ONE WAVE PER
+// TILE with no LDS and no barrier: for v_mfma_f64_16x16x4 the C/D register layout (row = (lane>>4) + 4 reg,
+// col = lane & 15) is exactly the B-operand layout of k-step `reg` (k = (lane>>4) + 4 reg, n = lane & 15), so the
+// accumulator of one product is fed straight back as the B operand of the next. The 9x9 blocks are zero-padded to
+// 16x12 (A operands, 3 + 3 doubles per lane per position, fetched four positions ahead); the B injection (pose j
+// enters at positions j-1, j, j+1 through Bn, Bs, Bp) is the accumulator's initial value; columns whose pose lies
+// further down stay exactly zero until the march reaches them. Y is K-major: a register row is stored as 16
+// consecutive doubles. (Scalar versions: one thread per column from its own start 1.76 ms; lockstep positions with
+// LDS-staged blocks 0.80 ms; this one is bound by six dependent MFMAs per position.)
+typedef double v4f64s __attribute__((ext_vector_type(4)));
+struct ColOps { double ls[3], li[3], bi[3]; };
 __global__ __launch_bounds__(256) void k_sb_chain_cols(DevProblem P) {
-  __shared__ __attribute__((aligned(16))) double sL[2][168];  // [buffer][Lsub 81 | pad 3 | Ldinv 81 | pad 3]
-  const int tid = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int b = blockIdx.x, c = 0;
-  for (; c < P.nchains; ++c) {  // workgroup -> (chain, block of 256 columns inside it)
-    const int nb = (6 * (P.chain_ptr[c + 1] - P.chain_ptr[c]) + 255) / 256;
+  for (; c < P.nchains; ++c) {  // workgroup -> (chain, block of 64 columns inside it)
+    const int nb = (6 * (P.chain_ptr[c + 1] - P.chain_ptr[c]) + 63) / 64;
     if (b < nb) break;
     b -= nb;
   }
   if (c >= P.nchains) return;
   const int p0 = P.chain_ptr[c], p1 = P.chain_ptr[c + 1];
-  const int col = 6 * p0 + b * 256 + tid;
+  const int col0 = 6 * p0 + (b * 4 + wave) * 16;
+  if (col0 >= 6 * p1) return;  // wave-uniform; the kernel has no barrier
+  const int n = lane & 15, kq = lane >> 4;
+  const int col = col0 + n;
   const bool live = col < 6 * p1;
-  const int q = live ? col / 6 : p1 - 1, e = col - 6 * q;  // chain position of the pose, component
-  const int pstart = q > p0 ? q - 1 : q;                    // previous position if it is on the same chain
-  const int pfirst = max((6 * p0 + b * 256) / 6 - 1, p0);   // first position any column of this workgroup needs
-  auto fetch = [&](int pos) -> double {
-    if (tid < 81) return P.Lsub[(size_t)81 * pos + tid];
-    if (tid >= 84 && tid < 165) return P.Ldinv[(size_t)81 * pos + tid - 84];
-    return 0.0;
+  const int q = live ? col / 6 : p1 - 1, e = live ? col - 6 * q : 0;  // chain position of the pose, component
+  const int pstart = q > p0 ? q - 1 : q;
+  const int pfirst = max(col0 / 6 - 1, p0);
+  const size_t ld = (size_t)P.npad;
+  auto fetch = [&](int pos) {
+    ColOps o;
+    const bool in = pos < p1;
+    const double* Bblk = (!live || !in) ? nullptr : (pos == q - 1 ? P.Bn : (pos == q ? P.Bs : (pos == q + 1 ? P.Bp : nullptr)));
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+      const int k = kq + 4 * s2;                 // A operand: A[m = n][k]; injection / C rows: row = k
+      const bool ok = in && n < 9 && k < 9;
+      o.ls[s2] = ok ? -P.Lsub[(size_t)81 * pos + 9 * n + k] : 0.0;
+      o.li[s2] = (ok && k <= n) ? P.Ldinv[(size_t)81 * pos + 9 * n + k] : 0.0;
+      o.bi[s2] = (Bblk != nullptr && k < 9) ? Bblk[(size_t)54 * pos + 6 * k + e] : 0.0;
+    }
+    return o;
   };
-  double y[9];
-#pragma unroll
-  for (int a = 0; a < 9; ++a) y[a] = 0.0;
-  double nxt = fetch(pfirst);
+  ColOps o0 = fetch(pfirst), o1 = fetch(pfirst + 1), o2 = fetch(pfirst + 2), o3 = fetch(pfirst + 3);
+  v4f64s y = {0.0, 0.0, 0.0, 0.0};
   for (int pos = pfirst; pos < p1; ++pos) {
-    double (&L)[168] = sL[(pos - pfirst) & 1];
-    if (tid < 168) L[tid] = nxt;
-    if (pos + 1 < p1) nxt = fetch(pos + 1);  // in flight during this step's arithmetic
-    __syncthreads();                          // one barrier per step: the other buffer is rewritten two steps later
-    if (!live || pos < pstart) continue;
-    double v[9];
-    const double* Bblk = (pos == q - 1) ? P.Bn : (pos == q ? P.Bs : (pos == q + 1 ? P.Bp : nullptr));
+    const ColOps o = o0;
+    o0 = o1; o1 = o2; o2 = o3; o3 = fetch(pos + 4);
+    v4f64s t = {o.bi[0], o.bi[1], o.bi[2], 0.0};
+    t = __builtin_amdgcn_mfma_f64_16x16x4f64(o.ls[0], y[0], t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f64_16x16x4f64(o.ls[1], y[1], t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f64_16x16x4f64(o.ls[2], y[2], t, 0, 0, 0);
+    v4f64s yn = {0.0, 0.0, 0.0, 0.0};
+    yn = __builtin_amdgcn_mfma_f64_16x16x4f64(o.li[0], t[0], yn, 0, 0, 0);
+    yn = __builtin_amdgcn_mfma_f64_16x16x4f64(o.li[1], t[1], yn, 0, 0, 0);
+    yn = __builtin_amdgcn_mfma_f64_16x16x4f64(o.li[2], t[2], yn, 0, 0, 0);
+    y = yn;
+    if (live && pos >= pstart) {
+      double* Yp = P.Y + (size_t)(9 * pos + kq) * ld + col;
+      Yp[0] = y[0];
+      Yp[4 * ld] = y[1];
+      if (kq == 0) Yp[8 * ld] = y[2];
+    }
+  }
+}
+
+// ---- C -= Y^T Y without the cubic sum (semiseparable structure) ------------------------------------------------
+// Below its injection rows a column of Y obeys a linear recurrence: y(pos) = M_pos y(pos-1), M_pos = -Ldinv_pos Lsub_pos
+// (pose j enters through B at positions j-1, j, j+1 only). For poses i <= j of one chain therefore
+//   (Y^T Y)_ij = y_i(j-1)^T y_j(j-1) + y_i(j)^T y_j(j) + y_i(j+1)^T (I + G_{j+1}) y_j(j+1),
+//   G_q = sum_{pos > q} Phi(pos,q)^T Phi(pos,q) = M_{q+1}^T (I + G_{q+1}) M_{q+1},   G_{last} = 0,
+// i.e. pose j's six rows of C need only the THREE 9-row groups j-1, j, j+1 of Y: O(K^2) work and one pass over Y
+// instead of the O(K^3) MFMA product over whole chain segments (76 GFLOP, 1.9 ms on the 5-agent map).
+__global__ __launch_bounds__(256) void k_sb_propagator(DevProblem P) {  // Mblk[pos] = -Ldinv_pos Lsub_pos
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 81 * P.K) return;
+  const int pos = t / 81, e = t - 81 * pos, a = e / 9, b = e - 9 * a;
+  const double* Li = P.Ldinv + (size_t)81 * pos + 9 * a;
+  const double* Ls = P.Lsub + (size_t)81 * pos + b;
+  double acc = 0.0;
 #pragma unroll
-    for (int a = 0; a < 9; ++a) v[a] = Bblk ? Bblk[(size_t)54 * pos + 6 * a + e] : 0.0;
-    if (pos > pstart) {
+  for (int k = 0; k < 9; ++k) acc += (k <= a) ? Li[k] * Ls[9 * k] : 0.0;
+  P.Mblk[t] = -acc;
+}
+
+// GI[q] = I + G_q by the backward recurrence, one workgroup per chain (81 active threads, one matrix entry each).
+__global__ __launch_bounds__(128) void k_sb_gram(DevProblem P) {
+  __shared__ double sG[81], sM[2][81], sT[81];
+  const int tid = threadIdx.x;
+  const bool act = tid < 81;
+  const int a = act ? tid / 9 : 0, b = act ? tid - 9 * a : 0;
+  const int p0 = P.chain_ptr[blockIdx.x], p1 = P.chain_ptr[blockIdx.x + 1];
+  const double eye = (a == b) ? 1.0 : 0.0;
+  if (act) { sG[tid] = eye; P.GI[(size_t)81 * (p1 - 1) + tid] = eye; }
+  auto mload = [&](int pos) { return (act && pos > p0 && pos < p1) ? P.Mblk[(size_t)81 * pos + tid] : 0.0; };
+  double m0 = mload(p1 - 1), m1 = mload(p1 - 2), m2 = mload(p1 - 3), m3 = mload(p1 - 4);  // four steps of loads in flight
+  int it = 0;
+  for (int q = p1 - 2; q >= p0; --q, ++it) {  // uses M_{q+1}
+    double (&M)[81] = sM[it & 1];
+    if (act) M[tid] = m0;
+    m0 = m1; m1 = m2; m2 = m3; m3 = mload(q - 3);
+    __syncthreads();
+    double t = 0.0;
 #pragma unroll
-      for (int a = 0; a < 9; ++a)
+    for (int k = 0; k < 9; ++k) t += sG[9 * a + k] * M[9 * k + b];   // T = (I + G_{q+1}) M
+    if (act) sT[tid] = t;
+    __syncthreads();
+    double g = eye;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) v[a] -= L[9 * a + k] * y[k];
+    for (int k = 0; k < 9; ++k) g += M[9 * k + a] * sT[9 * k + b];   // I + M^T T
+    if (act) { sG[tid] = g; P.GI[(size_t)81 * q + tid] = g; }
+    // (the next iteration writes the OTHER sM buffer; its first barrier orders this sG write before the reads)
+  }
+}
+
+// One workgroup per pose j: C[rows 6j..6j+5, cols of poses <= j in the chain] -= W_j^T Y[rows 9(j-1) .. 9(j+2), cols]
+// with W_j = [y_j(j-1); y_j(j); (I + G_{j+1}) y_j(j+1)] (27 x 6, built in LDS first).
+__global__ __launch_bounds__(256) void k_yty_semisep(DevProblem P) {
+  __shared__ double sW[27][6];
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const int p1 = P.pos_chain_end[j];
+  int p0 = 0;
+  for (int c = 0; c < P.nchains; ++c) if (P.chain_ptr[c] <= j) p0 = P.chain_ptr[c];
+  const size_t ld = (size_t)P.npad;
+  if (tid < 162) {
+    const int r = tid / 6, e = tid - 6 * r, grp = r / 9, a = r - 9 * grp, pos = j - 1 + grp;
+    double v = 0.0;
+    if (pos >= p0 && pos < p1) {
+      if (grp < 2) v = P.Y[(size_t)(9 * pos + a) * ld + 6 * j + e];
+      else {
+        const double* G = P.GI + (size_t)81 * pos + 9 * a;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v += G[k] * P.Y[(size_t)(9 * pos + k) * ld + 6 * j + e];
+      }
+    }
+    sW[r][e] = v;
+  }
+  __syncthreads();
+  const int r0 = (j - 1 >= p0) ? 0 : 9, r1 = (j + 1 < p1) ? 27 : 18;  // row groups that exist in this chain
+  for (int c = 6 * p0 + tid; c < 6 * (j + 1); c += 256) {
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int r = r0; r < r1; ++r) {
+      const double y = P.Y[(size_t)(9 * (j - 1) + r) * ld + c];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) acc[a] += sW[r][a] * y;
     }
 #pragma unroll
-    for (int a = 0; a < 9; ++a) {
-      double s2 = 0.0;
-#pragma unroll
-      for (int k = 0; k <= a; ++k) s2 += L[84 + 9 * a + k] * v[k];
-      y[a] = s2;
-    }
-#pragma unroll
-    for (int a = 0; a < 9; ++a) P.Y[(size_t)(9 * pos + a) * P.npad + col] = y[a];
+    for (int a = 0; a < 6; ++a)
+      if (c <= 6 * j + a) P.Sred[(size_t)(6 * j + a) * ld + c] -= acc[a];
   }
 }
 
@@ -243,79 +338,120 @@ __global__ __launch_bounds__(256) void k_pose_rhs(DevProblem P) {
   if (part == 0 && col < 6 * P.K) P.bp[col] -= acc;
 }
 
-// x_s = A^-1 (b_s - B x_p): w = b_s - B x_p, forward with (Ldinv, Lsub), backward with their transposes.
-// One 64-lane workgroup per chain; lanes 0..8 each own one row of the current 9-vector. Every step's operands are
-// loaded one step ahead (the chain is latency-bound: ~900 dependent steps of 9x9 work per agent).
-struct SbRowF { double w, ls[9], li[9]; };  // forward operands of one lane: bracket b_s - B x_p, Lsub row, Ldinv row
-COV_DEV SbRowF sb_load_fwd(const DevProblem& P, int pos, int p0, int p1, int lane) {
-  SbRowF o;
-  double w = P.xs[(size_t)9 * pos + lane];
-  const double* bs = P.Bs + (size_t)54 * pos + 6 * lane;
+// x_s = A^-1 (b_s - B x_p), in two kernels.
+// k_sb_rhs (one thread per speed-bias row, fully parallel): w = b_s - B x_p, in place in xs.
+__global__ __launch_bounds__(256) void k_sb_rhs(DevProblem P) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 9 * P.K) return;
+  const int pos = t / 9, r = t - 9 * pos;
+  const int p1 = P.pos_chain_end[pos];
+  double w = P.xs[t];
+  const double* bs = P.Bs + (size_t)54 * pos + 6 * r;
 #pragma unroll
   for (int e = 0; e < 6; ++e) w -= bs[e] * P.bp[6 * pos + e];
-  if (pos > p0) {
-    const double* bpv = P.Bp + (size_t)54 * pos + 6 * lane;
+  if (pos > 0 && P.pos_chain_end[pos - 1] == p1) {  // not the head of its chain
+    const double* bpv = P.Bp + (size_t)54 * pos + 6 * r;
 #pragma unroll
     for (int e = 0; e < 6; ++e) w -= bpv[e] * P.bp[6 * (pos - 1) + e];
   }
   if (pos + 1 < p1) {
-    const double* bn = P.Bn + (size_t)54 * pos + 6 * lane;
+    const double* bn = P.Bn + (size_t)54 * pos + 6 * r;
 #pragma unroll
     for (int e = 0; e < 6; ++e) w -= bn[e] * P.bp[6 * (pos + 1) + e];
   }
-  o.w = w;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) { o.ls[k] = P.Lsub[(size_t)81 * pos + 9 * lane + k]; o.li[k] = P.Ldinv[(size_t)81 * pos + 9 * lane + k]; }
-  return o;
-}
-struct SbRowB { double u, lsT[9], liT[9]; };  // backward operands: u_pos, column `lane` of Lsub_{pos+1} and of Ldinv_pos
-COV_DEV SbRowB sb_load_bwd(const DevProblem& P, int pos, int p1, int lane) {
-  SbRowB o;
-  o.u = P.xs[(size_t)9 * pos + lane];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    o.lsT[k] = (pos + 1 < p1) ? P.Lsub[(size_t)81 * (pos + 1) + 9 * k + lane] : 0.0;
-    o.liT[k] = P.Ldinv[(size_t)81 * pos + 9 * k + lane];
-  }
-  return o;
+  P.xs[t] = w;
 }
 
+// k_sb_backsolve: forward with (Ldinv, Lsub), backward with their transposes — one wave per chain, ~900 dependent
+// steps of 9x9 work per agent. Lanes 0..8 own one row of the current 9-vector; the previous step's vector is
+// broadcast with v_readlane (no barrier on the chain). The factor blocks are staged through LDS in chunks of
+// kSbChunk positions by all 64 lanes, the next chunk's global loads in flight while the current one is consumed:
+// the first version loaded each step's operands one step ahead and ran at HBM latency (1.4 us per step).
+constexpr int kSbChunk = 8;
+constexpr int kSbBlk = 168;  // Lsub 81 | pad 3 | Ldinv 81 | pad 3
+constexpr int kSbPerLane = (kSbChunk * 162 + 63) / 64;
 __global__ __launch_bounds__(64) void k_sb_backsolve(DevProblem P) {
-  // the 9-vector of the previous step lives in lanes 0..8 and is broadcast with v_readlane (through SGPRs): no LDS
-  // round trip and no barrier on the ~900-step dependent chain (the LDS version took 1.4 us per step)
-  const int lane = threadIdx.x < 9 ? threadIdx.x : 8;
-  const bool act = threadIdx.x < 9;
+  __shared__ __attribute__((aligned(16))) double sblk[2][kSbChunk][kSbBlk];
+  const int tid = threadIdx.x;
+  const int lane = tid < 9 ? tid : 8;
+  const bool act = tid < 9;
   const int p0 = P.chain_ptr[blockIdx.x], p1 = P.chain_ptr[blockIdx.x + 1];
+  const int nchunk = (p1 - p0 + kSbChunk - 1) / kSbChunk;
+  double stage[kSbPerLane];
+  // chunk c covers positions [p0 + c*kSbChunk, ...) in ascending order (dir = +1) or the mirrored range (dir = -1)
+  auto chunk_base = [&](int c, int dir) { return dir > 0 ? p0 + c * kSbChunk : max(p1 - (c + 1) * kSbChunk, p0); };
+  auto chunk_len = [&](int c, int dir) { return dir > 0 ? min(kSbChunk, p1 - (p0 + c * kSbChunk)) : min(kSbChunk, p1 - c * kSbChunk - p0); };
+  auto gload = [&](int c, int dir) {
+    const int base = chunk_base(c, dir), len = chunk_len(c, dir);
+#pragma unroll
+    for (int i = 0; i < kSbPerLane; ++i) {
+      const int idx = tid + 64 * i, q = idx / 162, e = idx - 162 * q;
+      stage[i] = (q < len) ? (e < 81 ? P.Lsub[(size_t)81 * (base + q) + e] : P.Ldinv[(size_t)81 * (base + q) + e - 81]) : 0.0;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < kSbPerLane; ++i) {
+      const int idx = tid + 64 * i, q = idx / 162, e = idx - 162 * q;
+      if (q < kSbChunk) sblk[buf][q][e < 81 ? e : e + 3] = stage[i];
+    }
+  };
+  // ---- forward: u_pos = Linv (w_pos - Lsub u_{pos-1}), stored in xs
   double prev = 0.0;
-  SbRowF cf = sb_load_fwd(P, p0, p0, p1, lane);
-  for (int pos = p0; pos < p1; ++pos) {  // forward: u_pos = Linv (w_pos - Lsub u_{pos-1}), stored in xs
-    SbRowF nf = cf;
-    if (pos + 1 < p1) nf = sb_load_fwd(P, pos + 1, p0, p1, lane);
-    double w = cf.w;
+  gload(0, +1);
+  for (int c = 0; c < nchunk; ++c) {
+    lstore(c & 1);
+    if (c + 1 < nchunk) gload(c + 1, +1);
+    __syncthreads();
+    const int base = chunk_base(c, +1), len = chunk_len(c, +1);
+    double wv[kSbChunk];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w -= cf.ls[k] * rdlane64(prev, k);  // Lsub of a chain head is zero
-    double u = 0.0;
+    for (int q = 0; q < kSbChunk; ++q) wv[q] = (q < len) ? P.xs[(size_t)9 * (base + q) + lane] : 0.0;
+    for (int q = 0; q < len; ++q) {
+      const double* L = sblk[c & 1][q];
+      double w = wv[0];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) u += cf.li[k] * rdlane64(w, k);     // Ldinv is lower triangular: entries k > lane are zero
-    if (act) P.xs[(size_t)9 * pos + lane] = u;
-    prev = u;
-    cf = nf;
+      for (int k = 1; k < kSbChunk; ++k) w = (q == k) ? wv[k] : w;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) w -= L[9 * lane + k] * rdlane64(prev, k);  // Lsub of a chain head is zero
+      double u = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) u += L[84 + 9 * lane + k] * rdlane64(w, k);  // Ldinv is lower triangular: entries k > lane are zero
+      if (act) P.xs[(size_t)9 * (base + q) + lane] = u;
+      prev = u;
+    }
   }
+  // ---- backward: x_pos = Linv^T (u_pos - Lsub_{pos+1}^T x_{pos+1}); needs Lsub of the position ABOVE, so a chunk
+  //      keeps the previous chunk's buffer alive for its first step (double buffering does that for free)
   prev = 0.0;
-  __syncthreads();  // xs written above is re-read below by the same lanes; keeps the two sweeps ordered
-  SbRowB cb = sb_load_bwd(P, p1 - 1, p1, lane);
-  for (int pos = p1 - 1; pos >= p0; --pos) {  // backward: x_pos = Linv^T (u_pos - Lsub_{pos+1}^T x_{pos+1})
-    SbRowB nb = cb;
-    if (pos > p0) nb = sb_load_bwd(P, pos - 1, p1, lane);
-    double w = cb.u;
+  __syncthreads();
+  gload(0, -1);
+  for (int c = 0; c < nchunk; ++c) {
+    lstore(c & 1);
+    if (c + 1 < nchunk) gload(c + 1, -1);
+    __syncthreads();
+    const int base = chunk_base(c, -1), len = chunk_len(c, -1);
+    double uv[kSbChunk];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w -= cb.lsT[k] * rdlane64(prev, k);
-    double x = 0.0;
+    for (int q = 0; q < kSbChunk; ++q) uv[q] = (q < len) ? P.xs[(size_t)9 * (base + q) + lane] : 0.0;
+    for (int q = len - 1; q >= 0; --q) {
+      const int pos = base + q;
+      // Lsub_{pos+1}: next slot of this chunk, or slot 0 of the previous (higher) chunk, or nothing at the chain end
+      const double* Lup = (q + 1 < len) ? sblk[c & 1][q + 1] : (c > 0 ? sblk[(c - 1) & 1][0] : nullptr);
+      const double* L = sblk[c & 1][q];
+      double w = uv[0];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) x += cb.liT[k] * rdlane64(w, k);    // column of a lower-triangular matrix: entries k < lane are zero
-    if (act) P.xs[(size_t)9 * pos + lane] = x;
-    prev = x;
-    cb = nb;
+      for (int k = 1; k < kSbChunk; ++k) w = (q == k) ? uv[k] : w;
+      if (Lup != nullptr && pos + 1 < p1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w -= Lup[9 * k + lane] * rdlane64(prev, k);
+      }
+      double x = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) x += L[84 + 9 * k + lane] * rdlane64(w, k);  // column of a lower-triangular matrix: entries k < lane are zero
+      if (act) P.xs[(size_t)9 * pos + lane] = x;
+      prev = x;
+    }
   }
 }
 
@@ -327,6 +463,10 @@ void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& 
   (void)hipStreamWaitEvent(ax.aux, ax.ev_sb, 0);
   hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, ax.aux, P);
   (void)hipEventRecord(ax.ev_cf, ax.aux);
+  // the Gramians need the factor only: they follow on the auxiliary stream, underneath k_sb_chain_cols
+  hipLaunchKernelGGL(k_sb_propagator, dim3((81 * P.K + 255) / 256), dim3(256), 0, ax.aux, P);
+  hipLaunchKernelGGL(k_sb_gram, dim3(P.nchains), dim3(128), 0, ax.aux, P);
+  (void)hipEventRecord(ax.ev_g, ax.aux);
   ax.cf_pending = true;
 }
 
@@ -337,12 +477,20 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
   if (P.vi) {
     if (early) { (void)hipStreamWaitEvent(st, ax.ev_cf, 0); ax.cf_pending = false; }
     else hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, st, P);
-    hipLaunchKernelGGL(k_sb_chain_cols, dim3((6 * P.K + 255) / 256 + P.nchains), dim3(256), 0, st, P);  // >= sum of per-chain block counts
+    hipLaunchKernelGGL(k_sb_chain_cols, dim3((6 * P.K + 63) / 64 + P.nchains), dim3(256), 0, st, P);  // >= sum of per-chain block counts
     hipLaunchKernelGGL(k_pose_rhs, dim3((8 * 6 * P.K + 255) / 256), dim3(256), 0, st, P);
-    launch_yty_update(P, st);
+    if (early) (void)hipStreamWaitEvent(st, ax.ev_g, 0);
+    else {
+      hipLaunchKernelGGL(k_sb_propagator, dim3((81 * P.K + 255) / 256), dim3(256), 0, st, P);
+      hipLaunchKernelGGL(k_sb_gram, dim3(P.nchains), dim3(128), 0, st, P);
+    }
+    hipLaunchKernelGGL(k_yty_semisep, dim3(P.K), dim3(256), 0, st, P);
   }
   dense_cholesky_solve_raw(P.Sred, P.bp, P.Linv, P.flag, P.npad, st, ax);
-  if (P.vi) hipLaunchKernelGGL(k_sb_backsolve, dim3(P.nchains), dim3(64), 0, st, P);
+  if (P.vi) {
+    hipLaunchKernelGGL(k_sb_rhs, dim3((9 * P.K + 255) / 256), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_sb_backsolve, dim3(P.nchains), dim3(64), 0, st, P);
+  }
   hipLaunchKernelGGL(k_scatter_solution, dim3((P.n + 255) / 256), dim3(256), 0, st, P, dst);
 }
 

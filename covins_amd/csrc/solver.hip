@@ -197,14 +197,6 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   for (int c = 0; c < P.nchains; ++c)
     for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) chain_end[q] = chain_ptr[c + 1];
   P.nyrows = ((9 * P.K + 15) / 16) * 16;
-  const int T = P.npad / kTile;
-  std::vector<int> tcs(T, 0), tce(T, 0);
-  for (int t = 0; t < T; ++t) {
-    if (kTile * t >= 6 * P.K) continue;
-    const int pmin = (kTile * t) / 6, pmax = std::min((kTile * t + kTile - 1) / 6, P.K - 1);
-    tcs[t] = (9 * std::max(pmin - 1, 0)) / 16 * 16;
-    tce[t] = std::min(P.nyrows, (9 * chain_end[pmax] + 15) / 16 * 16);
-  }
   P.reproj_loss_a = opt->reproj_loss_a; P.gravity = opt->gravity;
   const size_t K = P.K;
   RC(dev_upload(c, &P.pose0, p->kf_pose, 7 * K));
@@ -302,7 +294,6 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_upload(c, &P.perm, perm.data(), K)); RC(dev_upload(c, &P.pos_kf, pos_kf.data(), K));
   RC(dev_upload(c, &P.chain_ptr, chain_ptr.data(), chain_ptr.size()));
   RC(dev_upload(c, &P.pos_chain_end, chain_end.data(), K));
-  RC(dev_upload(c, &P.tile_cs, tcs.data(), (size_t)T)); RC(dev_upload(c, &P.tile_ce, tce.data(), (size_t)T));
   RC(dev_alloc(c, &P.Sred, (size_t)P.npad * P.npad));
   RC(dev_alloc(c, &P.bred, (size_t)P.n));
   RC(dev_alloc(c, &P.bp, (size_t)2 * P.npad));
@@ -310,6 +301,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_alloc(c, &P.Ad, 81 * Kv)); RC(dev_alloc(c, &P.Ae, 81 * Kv));
   RC(dev_alloc(c, &P.Bp, 54 * Kv)); RC(dev_alloc(c, &P.Bs, 54 * Kv)); RC(dev_alloc(c, &P.Bn, 54 * Kv));
   RC(dev_alloc(c, &P.Ld, 81 * Kv)); RC(dev_alloc(c, &P.Ldinv, 81 * Kv)); RC(dev_alloc(c, &P.Lsub, 81 * Kv));
+  RC(dev_alloc(c, &P.Mblk, 81 * Kv)); RC(dev_alloc(c, &P.GI, 81 * Kv));
   RC(dev_alloc(c, &P.zs, 9 * Kv)); RC(dev_alloc(c, &P.xs, 9 * Kv));
   RC(dev_alloc(c, &P.Y, vi ? (size_t)P.nyrows * P.npad : 0));
   if (vi) HIPCHK(hipMemsetAsync(P.Y, 0, (size_t)P.nyrows * P.npad * sizeof(double), c->st));  // only the chain trapezoids are ever written

@@ -145,7 +145,7 @@ void launch_zero_system(const DevProblem& P, hipStream_t st);
 // per-context resources of the dense factorisation: auxiliary stream for the look-ahead, ordering events, and
 // (profiling only) one timed event pair around every bulk trailing-update launch
 struct CholAux {
-  hipStream_t aux = nullptr, mid = nullptr;
+  hipStream_t aux = nullptr, mid = nullptr, head = nullptr;
   hipEvent_t ev_sb = nullptr, ev_cf = nullptr, ev_g = nullptr;  // speed-bias rows ready | chain factor done | Gramians done (early, on aux)
   bool cf_pending = false;
   std::vector<hipEvent_t> ev, prof_ev;

@@ -441,6 +441,7 @@ static hipStream_t make_side_stream(int priority) {
 void CholAux::init() {
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (!head) (void)hipStreamCreateWithPriority(&head, hipStreamNonBlocking, hi);
   if (!mid) mid = make_side_stream(hi);
   if (!aux) aux = make_side_stream(lo);
   if (!ev_sb) (void)hipEventCreateWithFlags(&ev_sb, hipEventDisableTiming);
@@ -449,6 +450,7 @@ void CholAux::init() {
 }
 void CholAux::destroy() {
   if (mid) { (void)hipStreamDestroy(mid); mid = nullptr; }
+  if (head) { (void)hipStreamDestroy(head); head = nullptr; }
   for (auto e : ev) (void)hipEventDestroy(e);
   for (auto e : prof_ev) (void)hipEventDestroy(e);
   ev.clear(); prof_ev.clear();
@@ -484,18 +486,17 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   }
   ax.init();
   const int NP = (T + 1) / 2;  // big panels of two tile columns
-  // events per big panel: A main done | B bulk done | C rest-rows done | M1 potrf(t0) | M2 trsm head(t0) | M3 potrf(t0+1) | R head look-ahead
+  // events per big panel: H rows-h done | B bulk done | C rows-r done | 1 potrf(t0) | 2 X(t0+1,t0) | 3 potrf(t0+1) | Rc next diagonal updated
   while ((int)ax.ev.size() < 7 * (NP + 1)) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ax.ev.push_back(e); }
   if (ax.profile) while ((int)ax.prof_ev.size() < 2 * NP) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev.push_back(e); }
   ax.prof_flops.clear();
-  hipEvent_t* eA = ax.ev.data();
-  hipEvent_t* eB = eA + (NP + 1);
+  hipEvent_t* eH = ax.ev.data();
+  hipEvent_t* eB = eH + (NP + 1);
   hipEvent_t* eC = eB + (NP + 1);
-  hipEvent_t* eM1 = eC + (NP + 1);
-  hipEvent_t* eM2 = eM1 + (NP + 1);
-  hipEvent_t* eM3 = eM2 + (NP + 1);
-  hipEvent_t* eR = eM3 + (NP + 1);
-  hipStream_t mid = ax.mid;
+  hipEvent_t* e1 = eC + (NP + 1);
+  hipEvent_t* e2 = e1 + (NP + 1);
+  hipEvent_t* e3 = e2 + (NP + 1);
+  hipEvent_t* eRc = e3 + (NP + 1);
 
   auto potrf = [&](int t) { hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), lds_potrf, st, S, ld, t * kTile, Linv + (size_t)t * kTile * kTile, flag, b, b + npad); };
   // rows [r0, r1) of tile column t:  A <- A Linv_t^T
@@ -514,71 +515,96 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0), dim3(256), lds_gemm, s2, g);
   };
 
-  // Three streams. main: the serial chain on a 4-tile-row window below the diagonal ("head"); mid: the same
-  // TRSM / look-ahead updates for all rows below the window ("rest"); aux: the bulk trailing update.
+  // Four streams (timeline analysis in profiles/r01y_timeline_*.csv: once the trailing matrix is small the period of
+  // the factorisation is the serial chain potrf -> trsm -> rect -> potrf ..., so nothing else may sit on it):
+  //   M  (= st) the critical chain only: the panel's 2x2 diagonal tiles, and the look-ahead update of the NEXT
+  //             panel's 2x2 diagonal tiles;
+  //   H  rows h = the next panel's two tile rows (t0+2, t0+3): their TRSMs / updates trail the chain by one kernel;
+  //   R  rows r = everything below (t0+4 ..): full-tile kernels, needed one panel later;
+  //   B  the bulk rank-256 trailing update (triangle from tile t0+4).
+  hipStream_t M = st, H = ax.head, R = ax.mid, B = ax.aux;
+  auto wait = [](hipStream_t s2, hipEvent_t e) { (void)hipStreamWaitEvent(s2, e, 0); };
   for (int P = 0; P < NP; ++P) {
     const int t0 = 2 * P, w = (T - t0 >= 2) ? 2 : 1;
-    const int hEnd = (t0 + 4 < T) ? t0 + 4 : T;
-    // ---- main: head rows [t0, hEnd) (their look-ahead update was enqueued at the end of the previous iteration)
+    const int h0 = (t0 + 2 < T) ? t0 + 2 : T, h1 = (t0 + 4 < T) ? t0 + 4 : T;  // rows h = [h0, h1), rows r = [h1, T)
+    // ---- look-ahead part of SYRK(P-1) (K = the 256 columns of panel P-1) on this panel's two tile columns; the
+    //      2x2 diagonal part was enqueued on M at the end of the previous iteration
+    if (P > 0) {
+      if (h1 > h0) {
+        wait(H, eC[P - 1]);                    // L rows h0.. were rest rows of panel P-1
+        if (P >= 2) wait(H, eB[P - 2]);        // bulk(P-2) was the previous writer of these tiles
+        rect(h0, h1, t0, w, t0 - 2, 2 * kTile, H, true);
+      }
+      if (T > h1) {
+        wait(R, eH[P - 1]);                    // B operand: L rows t0, t0+1 (rows h of panel P-1)
+        if (P >= 2) wait(R, eB[P - 2]);
+        rect(h1, T, t0, w, t0 - 2, 2 * kTile, R, false);
+      }
+    }
+    // ---- M: critical chain
     potrf(t0);
-    (void)hipEventRecord(eM1[P], st);
-    trsm(t0, t0 + 1, hEnd, st, true);
-    (void)hipEventRecord(eM2[P], st);
+    (void)hipEventRecord(e1[P], M);
     if (w == 2) {
-      rect(t0 + 1, hEnd, t0 + 1, 1, t0, kTile, st, true);           // rank-128 update of the panel's second tile column
+      trsm(t0, t0 + 1, t0 + 2, M, true);
+      (void)hipEventRecord(e2[P], M);
+      rect(t0 + 1, t0 + 2, t0 + 1, 1, t0, kTile, M, true);   // rank-128 update of the second diagonal tile
       potrf(t0 + 1);
-      (void)hipEventRecord(eM3[P], st);
-      trsm(t0 + 1, t0 + 2, hEnd, st, true);
+      (void)hipEventRecord(e3[P], M);
     }
-    (void)hipEventRecord(eA[P], st);
-    // ---- mid: rest rows [hEnd, T)
-    if (hEnd < T) {
-      if (P > 0) {
-        if (P >= 2) (void)hipStreamWaitEvent(mid, eB[P - 2], 0);
-        (void)hipStreamWaitEvent(mid, eA[P - 1], 0);            // B side: rows t0, t0+1 of panel P-1 come from main
-        rect(hEnd, T, t0, w, t0 - 2, 2 * kTile, mid, false);
-      }
-      (void)hipStreamWaitEvent(mid, eM1[P], 0);
-      trsm(t0, hEnd, T, mid, false);
+    // ---- H: rows h
+    if (h1 > h0) {
+      wait(H, e1[P]);
+      trsm(t0, h0, h1, H, true);
       if (w == 2) {
-        (void)hipStreamWaitEvent(mid, eM2[P], 0);               // X(t0+1, t0)
-        rect(hEnd, T, t0 + 1, 1, t0, kTile, mid, false);
-        (void)hipStreamWaitEvent(mid, eM3[P], 0);
-        trsm(t0 + 1, hEnd, T, mid, false);
+        wait(H, e2[P]);                        // X(t0+1, t0)
+        rect(h0, h1, t0 + 1, 1, t0, kTile, H, true);
+        wait(H, e3[P]);
+        trsm(t0 + 1, h0, h1, H, true);
       }
     }
-    (void)hipEventRecord(eC[P], mid);
-    const int tb = t0 + 4, nt = T - tb;
-    // ---- main: look-ahead part of SYRK(P) on the head window of panel P+1
-    if (P + 1 < NP) {
-      const int u0 = t0 + 2, uw = (T - u0 >= 2) ? 2 : 1, uEnd = (u0 + 4 < T) ? u0 + 4 : T;
-      if (P >= 1) (void)hipStreamWaitEvent(st, eB[P - 1], 0);  // bulk(P-1) was the previous writer of these tiles
-      (void)hipStreamWaitEvent(st, eC[P], 0);                   // rows u0+2.. were rest rows of panel P
-      rect(u0, uEnd, u0, uw, t0, 2 * kTile, st, true);
-      (void)hipEventRecord(eR[P + 1], st);
+    (void)hipEventRecord(eH[P], H);
+    // ---- R: rows r
+    if (T > h1) {
+      wait(R, e1[P]);
+      trsm(t0, h1, T, R, false);
+      if (w == 2) {
+        wait(R, e2[P]);
+        rect(h1, T, t0 + 1, 1, t0, kTile, R, false);
+        wait(R, e3[P]);
+        trsm(t0 + 1, h1, T, R, false);
+      }
     }
-    // ---- aux: bulk of SYRK(P), triangle starting two tile columns further (those belong to the look-ahead)
-    (void)hipStreamWaitEvent(ax.aux, eA[P], 0);
-    (void)hipStreamWaitEvent(ax.aux, eC[P], 0);
-    // A bulk launched at the same instant as the next head update takes every workgroup slot first and the 28 head
-    // workgroups wait ~75 us for the first round of tiles to retire (profiles/r01y timeline) — the bulk therefore
-    // starts after the head update (~10-30 us later).
-    if (P + 1 < NP) (void)hipStreamWaitEvent(ax.aux, eR[P + 1], 0);
+    (void)hipEventRecord(eC[P], R);
+    // ---- M: look-ahead part of SYRK(P) on the next panel's 2x2 diagonal tiles
+    if (P + 1 < NP) {
+      const int u0 = t0 + 2, uw = (T - u0 >= 2) ? 2 : 1;
+      wait(M, eH[P]);                          // L rows u0, u0+1
+      if (P >= 1) wait(M, eB[P - 1]);          // bulk(P-1) was the previous writer of these tiles
+      rect(u0, u0 + uw, u0, uw, t0, 2 * kTile, M, true);
+      (void)hipEventRecord(eRc[P + 1], M);
+    }
+    // ---- B: bulk of SYRK(P), triangle starting two tile columns further (those belong to the look-ahead)
+    const int tb = t0 + 4, nt = T - tb;
+    wait(B, eC[P]);
+    // A bulk launched at the same instant as the next diagonal update takes every workgroup slot first and the
+    // chain waits ~75 us for the first round of tiles to retire: the bulk starts after that small kernel.
+    if (P + 1 < NP) wait(B, eRc[P + 1]);
     if (nt > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
       GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr};
-      if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], ax.aux);
-      hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk), dim3(256), lds_gemm, ax.aux, g);
+      if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], B);
+      hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk), dim3(256), lds_gemm, B, g);
       if (ax.profile) {
-        (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], ax.aux);
+        (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], B);
         ax.prof_flops.push_back((double)nt * (nt + 1) / 2 * 2.0 * kTile * kTile * (w * kTile));
       }
     }
-    (void)hipEventRecord(eB[P], ax.aux);
+    (void)hipEventRecord(eB[P], B);
   }
-  (void)hipStreamWaitEvent(st, eB[NP - 1], 0);
-  if (NP >= 2) (void)hipStreamWaitEvent(st, eB[NP - 2], 0);
-  (void)hipStreamWaitEvent(st, eC[NP - 1], 0);
+  wait(M, eB[NP - 1]);
+  if (NP >= 2) wait(M, eB[NP - 2]);
+  wait(M, eC[NP - 1]);
+  wait(M, eH[NP - 1]);
   // y = L^-1 b was formed along the way (potrf: y_p = L_pp^-1 b_p; every TRSM: b[rows] -= L[rows, p] y_p) and lives
   // in b[npad .. 2 npad). Remaining: L^T x = y.
   for (int p = T - 1; p >= 0; --p) {

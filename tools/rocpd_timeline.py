@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of ONE dense factorisation from a rocprofv3 rocpd SQLite database (dev tool).
 usage: rocpd_timeline.py results.db [which=3] > timeline.csv
-Selects the kernels between the `which`-th k_gemm_abt<3,..> (Y^T Y update, runs right before the factorisation)
+Selects the kernels between the `which`-th k_yty_semisep (Y^T Y update, runs right before the factorisation)
 and the next k_bwd_step, and prints start (us, relative), duration (us), queue, short name, grid."""
 import re
 import sqlite3
@@ -16,7 +16,7 @@ def main():
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
     gcol = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else "0")
     rows = db.execute(f"select name, start, end, {qcol}, {gcol} from kernels order by start").fetchall()
-    yty = [i for i, r in enumerate(rows) if "k_gemm_abt<3" in r[0]]
+    yty = [i for i, r in enumerate(rows) if "k_yty_semisep" in r[0]]
     i0 = yty[which]
     i1 = next(i for i in range(i0, len(rows)) if "k_bwd_step" in rows[i][0])
     t0 = rows[i0][2]

@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--strategy", default="dogleg", choices=["dogleg", "lm"])
     ap.add_argument("--iterations", type=int, default=10, help="trust-region iteration cap per step (reference: 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the whole-call timing after the timed region (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -106,7 +107,7 @@ def main():
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if pj.get("workload") == args.workload:
-                k = pj["kernels"]["k_gemm_abt<SYRK_TRI>"]
+                k = pj["kernels"]["k_gemm_abt<SYRK_TRI>"]  # = k_gemm_abt<0, 128, 128>
                 traffic = k["fetch_bytes_x2"] + k["write_bytes"]
         except Exception:
             traffic = None
@@ -139,7 +140,7 @@ def main():
             "roofline": {"kernel": "k_gemm_abt<SYRK_TRI> (rank-256 trailing update of the dense FP64 Cholesky, v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes in profiles/r01_pmc_hbm_traffic.csv)",
+                         "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes in profiles/r01z_pmc_hbm_traffic.csv)",
                          "launches": prof["n_syrk"], "avg_launch_ms": prof["syrk_ms"] / max(prof["n_syrk"], 1),
                          "dense_stage_order": 6 * prob.K,
                          "dense_factorisation_tflops_incl_panels_and_solves": ((6.0 * prob.K) ** 3 / 3.0) / (prof["factor_ms"] / max(prof["n_factor"], 1) * 1e-3) / 1e12
@@ -154,15 +155,16 @@ def main():
         # whole Optimization::GlobalBundleAdjustment call as backend.cpp:141-156 issues it (outlier round of 5 iterations +
         # main round, flatten + H2D + solves + D2H + write-back + Map::Clean) — PCIe- and host-inclusive, never `value`
         from covins_amd.optimization import Optimization, OptParams
-        t_call = time.perf_counter()
-        info = Optimization.GlobalBundleAdjustment(m, args.iterations, -1.0, False, True, False,
-                                                   params=OptParams(strategy=strategy), ctx=ctx)
-        t_call = time.perf_counter() - t_call
-        out["e2e_call"] = {"t_call_s": t_call, "kf_per_s_e2e": k_free / t_call,
-                           "iterations": info["round1"].iterations + info["round2"].iterations,
-                           "outliers_removed": info["outliers_removed"],
-                           "what": "covins_amd.optimization.Optimization.GlobalBundleAdjustment(map, 10, outlier_removal=True) "
-                                   "on the same map, host flattening in numpy"}
+        t_call = time.perf_counter() if not args.no_e2e else None
+        if not args.no_e2e:
+            info = Optimization.GlobalBundleAdjustment(m, args.iterations, -1.0, False, True, False,
+                                                       params=OptParams(strategy=strategy), ctx=ctx)
+            t_call = time.perf_counter() - t_call
+            out["e2e_call"] = {"t_call_s": t_call, "kf_per_s_e2e": k_free / t_call,
+                               "iterations": info["round1"].iterations + info["round2"].iterations,
+                               "outliers_removed": info["outliers_removed"],
+                               "what": "covins_amd.optimization.Optimization.GlobalBundleAdjustment(map, 10, outlier_removal=True) "
+                                       "on the same map, host flattening in numpy"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(strategy)
         print(json.dumps(out))

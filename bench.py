@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="mh12345", help="mh12345 (BASELINE metric) | mh123 | mh01 | small")
+    ap.add_argument("--workload", default="mh12345", help="mh12345 (BASELINE metric) | mh123 | mh01 | small | a12x500 (12-agent, scaled-down configs[4])")
     ap.add_argument("--strategy", default="dogleg", choices=["dogleg", "lm"])
     ap.add_argument("--iterations", type=int, default=10, help="trust-region iteration cap per step (reference: 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -373,6 +373,8 @@ def config_named(name: str, seed: int = 0) -> SynthConfig:
         return SynthConfig(agents=(1, 2, 3), seed=seed)
     if name == "mh12345":         # configs[3] and the metric's 5-agent merged map
         return SynthConfig(agents=(1, 2, 3, 4, 5), seed=seed)
+    if name == "a12x500":         # configs[4] at reduced scale: 12 agents (5 MH paths + 7 re-posed copies), <= 500 keyframes each
+        return SynthConfig(agents=tuple(range(1, 13)), max_kf_per_agent=500, seed=seed)
     if name == "tiny":            # CPU tests
         return SynthConfig(agents=(1, 3), max_kf_per_agent=14, new_lm_per_kf=14, track_window=5, p_fuse=0.15,
                            loops_per_pair=1, seed=seed)

@@ -11,7 +11,7 @@
 // optimization_be.cpp:561) obtains from the same sparsity; the result is the exact solve, just reordered.
 //
 //   sb_chain_factor   one wave per IMU chain, sequential over keyframes: L_kk L_kk^T = Ad_k - Lsub Lsub^T,
-//                     Lsub_{k+1} = Ae_{k+1} L_kk^-T, z = L_A^-1 b_s
+//                     Lsub_{k+1} = Ae_{k+1} L_kk^-T, z = L_A^-1 b_s (operands staged through LDS a chunk ahead)
 //   sb_chain_cols     Y = L_A^-1 B, one thread per pose dimension marching down its chain (K-major, coalesced)
 //   pose_rhs          b'_p = b_p - Y^T z
 //   (k_chol.hip)      C -= Y^T Y restricted to each tile pair's common chain segment; dense Cholesky of C'
@@ -51,29 +51,56 @@ COV_DEV double rdlane64(double v, int srclane) {  // broadcast from a wave-unifo
 // One 64-lane workgroup (a single wave) per chain: the sequential part only — block-bidiagonal Cholesky of the
 // speed-bias system and z = L_A^-1 b_s. Per keyframe: 9x9 Cholesky in registers (row per lane, v_readlane
 // broadcasts), inverse by columns from LDS, next blocks prefetched from HBM one step ahead.
+constexpr int kCfChunk = 8;                     // positions staged per LDS buffer
+constexpr int kCfBlk = 81 + 81 + 9;             // Ad_pos | Ae_{pos+1} | b_s,pos
+constexpr int kCfPerLane = (kCfChunk * kCfBlk + 63) / 64;
 __global__ __launch_bounds__(64) void k_sb_chain_factor(DevProblem P) {
   __shared__ double sM[81], sX[81], sSub[81];
   __shared__ double sz[9], sv[9];
+  __shared__ double sIn[2][kCfChunk][kCfBlk];   // operands, staged kCfChunk positions ahead by all 64 lanes
   const int lane = threadIdx.x;
   const int p0 = P.chain_ptr[blockIdx.x], p1 = P.chain_ptr[blockIdx.x + 1];
   const int e0 = lane, e1 = lane + 64;  // the two matrix entries this lane owns (e1 valid for lanes < 17)
   const bool has1 = e1 < 81;
   for (int e = lane; e < 81; e += 64) sSub[e] = 0.0;
   if (lane < 9) sz[lane] = 0.0;
-  // prefetch registers: Ad of the current position, Ae of the next, b_s of the current
-  double ad0 = P.Ad[(size_t)81 * p0 + e0], ad1 = has1 ? P.Ad[(size_t)81 * p0 + e1] : 0.0;
-  double ae0 = 0.0, ae1 = 0.0;
-  if (p0 + 1 < p1) { ae0 = P.Ae[(size_t)81 * (p0 + 1) + e0]; ae1 = has1 ? P.Ae[(size_t)81 * (p0 + 1) + e1] : 0.0; }
-  double bs = (lane < 9) ? P.xs[(size_t)9 * p0 + lane] : 0.0;
-  __syncthreads();
-  for (int pos = p0; pos < p1; ++pos) {
-    // issue next step's loads first
-    double nad0 = 0.0, nad1 = 0.0, nae0 = 0.0, nae1 = 0.0, nbs = 0.0;
-    if (pos + 1 < p1) {
-      nad0 = P.Ad[(size_t)81 * (pos + 1) + e0]; nad1 = has1 ? P.Ad[(size_t)81 * (pos + 1) + e1] : 0.0;
-      nbs = (lane < 9) ? P.xs[(size_t)9 * (pos + 1) + lane] : 0.0;
+  // Operand loads one step ahead ran at HBM latency under the landmark pass's traffic (5.4 us per step); the next
+  // chunk's loads are now in flight during a whole chunk of steps.
+  const int nchunk = (p1 - p0 + kCfChunk - 1) / kCfChunk;
+  double stage[kCfPerLane];
+  auto gload = [&](int c) {
+    const int base = p0 + c * kCfChunk;
+#pragma unroll
+    for (int i = 0; i < kCfPerLane; ++i) {
+      const int idx = lane + 64 * i, q = idx / kCfBlk, e = idx - kCfBlk * q, pos = base + q;
+      double v = 0.0;
+      if (q < kCfChunk && pos < p1) {
+        if (e < 81) v = P.Ad[(size_t)81 * pos + e];
+        else if (e < 162) v = (pos + 1 < p1) ? P.Ae[(size_t)81 * (pos + 1) + e - 81] : 0.0;
+        else v = P.xs[(size_t)9 * pos + e - 162];
+      }
+      stage[i] = v;
     }
-    if (pos + 2 < p1) { nae0 = P.Ae[(size_t)81 * (pos + 2) + e0]; nae1 = has1 ? P.Ae[(size_t)81 * (pos + 2) + e1] : 0.0; }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < kCfPerLane; ++i) {
+      const int idx = lane + 64 * i, q = idx / kCfBlk, e = idx - kCfBlk * q;
+      if (q < kCfChunk) sIn[buf][q][e] = stage[i];
+    }
+  };
+  gload(0);
+  for (int c = 0; c < nchunk; ++c) {
+    lstore(c & 1);
+    if (c + 1 < nchunk) gload(c + 1);
+    __syncthreads();
+    const int base = p0 + c * kCfChunk, len = min(kCfChunk, p1 - base);
+    for (int q = 0; q < len; ++q) {
+    const int pos = base + q;
+    const double* in = sIn[c & 1][q];
+    const double* sAe = in + 81;
+    const double ad0 = in[e0], ad1 = has1 ? in[e1] : 0.0;
+    const double bs = (lane < 9) ? in[162 + lane] : 0.0;
     // M = Ad - Lsub Lsub^T
     {
       const int a = e0 / 9, b = e0 - 9 * a;
@@ -90,47 +117,45 @@ __global__ __launch_bounds__(64) void k_sb_chain_factor(DevProblem P) {
       }
     }
     __syncthreads();
-    // lower Cholesky, row r = lane (lanes >= 9 carry zeros)
+    // lower Cholesky, row r = lane (lanes >= 9 carry zeros); then X = L^-1 column by column, still in registers:
+    // lane c solves L x = e_c with the entries of L broadcast by v_readlane and the reciprocal pivots the Cholesky
+    // already has (no divisions, no LDS round trip between the two phases)
     {
       const int r = lane < 9 ? lane : 8;
-      double x[9];
+      double x[9], invd[9];
 #pragma unroll
-      for (int c = 0; c < 9; ++c) x[c] = (lane < 9 && c <= r) ? sM[9 * r + c] : 0.0;
+      for (int c2 = 0; c2 < 9; ++c2) x[c2] = (lane < 9 && c2 <= r) ? sM[9 * r + c2] : 0.0;
       bool bad = false;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        double d = rdlane64(x[c], c);
+      for (int c2 = 0; c2 < 9; ++c2) {
+        double d = rdlane64(x[c2], c2);
         if (!(d > 0.0)) { bad = true; d = 1.0; }
         const double inv = rsqrt(d);
-        x[c] = (lane == c) ? d * inv : x[c] * inv;
+        invd[c2] = inv;  // wave-uniform
+        x[c2] = (lane == c2) ? d * inv : x[c2] * inv;
 #pragma unroll
-        for (int cc = c + 1; cc < 9; ++cc) x[cc] -= x[c] * rdlane64(x[c], cc);  // garbage above the diagonal is never read
+        for (int cc = c2 + 1; cc < 9; ++cc) x[cc] -= x[c2] * rdlane64(x[c2], cc);  // garbage above the diagonal is never read
       }
       if (bad && lane == 0) atomicOr(P.flag, 1);
+      double xi[9];  // column `lane` of X
+#pragma unroll
+      for (int rr = 0; rr < 9; ++rr) {
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < rr; ++k) sum += rdlane64(x[k], rr) * xi[k];  // L[rr][k]; xi[k] is 0 for k < lane
+        xi[rr] = (rr == lane) ? invd[rr] : (rr > lane ? -sum * invd[rr] : 0.0);
+      }
       __syncthreads();  // everyone has read sM
       if (lane < 9) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) sM[9 * lane + c] = (c <= lane) ? x[c] : 0.0;
+        for (int c2 = 0; c2 < 9; ++c2) sM[9 * lane + c2] = (c2 <= lane) ? x[c2] : 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) sX[9 * rr + lane] = xi[rr];
+        double v = bs;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v -= sSub[9 * lane + k] * sz[k];
+        sv[lane] = v;
       }
-    }
-    __syncthreads();
-    // X = L^-1 (lower): lane = column; and the bracket of z
-    if (lane < 9) {
-      const int c = lane;
-      double x[9];
-#pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        double sum = 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) sum += (k >= c) ? sM[9 * r + k] * x[k] : 0.0;
-        x[r] = (r == c) ? 1.0 / sM[10 * r] : (r > c ? -sum / sM[10 * r] : 0.0);
-      }
-#pragma unroll
-      for (int r = 0; r < 9; ++r) sX[9 * r + c] = x[r];
-      double v = bs;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) v -= sSub[9 * lane + k] * sz[k];
-      sv[lane] = v;
     }
     __syncthreads();
     // publish the factor blocks, z, and the next sub-diagonal block L_{pos+1,pos} = Ae_{pos+1} L_kk^-T
@@ -141,30 +166,25 @@ __global__ __launch_bounds__(64) void k_sb_chain_factor(DevProblem P) {
       for (int k = 0; k <= lane; ++k) znew += sX[9 * lane + k] * sv[k];
       P.zs[(size_t)9 * pos + lane] = znew;
     }
-    // Ae rows are needed in full by every entry: route them through LDS (sv is free again after the sync below)
-    __shared__ double sAe[81];
-    sAe[e0] = ae0;
-    if (has1) sAe[e1] = ae1;
-    __syncthreads();
     double nx0 = 0.0, nx1 = 0.0;
     if (pos + 1 < p1) {
       {
         const int a = e0 / 9, b = e0 - 9 * a;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) nx0 += sAe[9 * a + c] * sX[9 * b + c];
+        for (int c2 = 0; c2 < 9; ++c2) nx0 += sAe[9 * a + c2] * sX[9 * b + c2];
       }
       if (has1) {
         const int a = e1 / 9, b = e1 - 9 * a;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) nx1 += sAe[9 * a + c] * sX[9 * b + c];
+        for (int c2 = 0; c2 < 9; ++c2) nx1 += sAe[9 * a + c2] * sX[9 * b + c2];
       }
     }
-    __syncthreads();
+    __syncthreads();  // sSub, sz, sv are free: every lane has finished reading them
     sSub[e0] = nx0;
     if (has1) sSub[e1] = nx1;
     if (lane < 9) sz[lane] = znew;
-    ad0 = nad0; ad1 = nad1; ae0 = nae0; ae1 = nae1; bs = nbs;
     __syncthreads();
+    }
   }
 }
 

@@ -43,7 +43,9 @@ __device__ long long g_probe[8];
 #define PROBE_T0() 0
 #endif
 
-constexpr int KC = 16;        // K chunk staged through LDS
+constexpr int KC = 16;        // K chunk staged through LDS (full-tile kernels)
+constexpr int KCQ = 32;       // quarter forms: they run at memory LATENCY (one dependent global->LDS step per chunk while the
+                              // chip is loaded: ~3 us each), so fewer, larger chunks
 constexpr int LDT = KC + 1;   // LDS pitch (doubles): odd pitch -> conflict-free fragment reads
 
 enum { MODE_SYRK_TRI = 0, MODE_SYRK_RECT = 1, MODE_TRSM = 2 };
@@ -65,8 +67,19 @@ struct GemmArgs {
 // blockIdx.z — a 64x64 quadrant (RECT) or a 32x128 row slab (TRSM: the update is in place, X overwrites A, so a
 // workgroup must own whole rows). The quarter forms are for the few-tile launches on the serial panel chain, where
 // the latency of ONE workgroup's tile is the whole cost — 4x more workgroups, each 4x shorter.
-template <int MODE, int TSA = kTile, int TSB = kTile>
-__global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
+//
+// All global addresses are a wave-uniform base (SGPRs) plus a 32-bit per-lane byte offset instead of 64-bit per-lane
+// pointers (8 fewer VGPR pairs to carry and to bump per chunk).
+// Measured, not adopted (tools/dispatch_probe.hip): a small kernel launched while the chip is full
+// of bulk workgroups starts AT ONCE if its waves fit beside the resident ones (2 x bulk + small <= 512 VGPRs per
+// SIMD lane: 5.8 us per dependent launch) and otherwise queues for a bulk workgroup to retire (34.8 us). Capping
+// these kernels with amdgpu_num_vgpr (the attribute counts HALF registers on gfx90a+: 104 -> 208 for the full
+// tiles, 48 -> 96 for the quarter forms; spills stay outside the K loop) makes them fit — and changes nothing
+// end to end (27.85 vs 27.65 ms, bulk 41.0 vs 42.5 TFLOP/s): under load the quarter kernels are bound by their
+// 4-16 dependent global -> LDS steps at loaded memory latency, not by the dispatch.
+template <int MODE, int TSA, int TSB, int KC>
+COV_DEV void gemm_abt_body(const GemmArgs& g) {
+  constexpr int LDT = KC + 1;
   static_assert((TSA == kTile && TSB == kTile) || (MODE == MODE_SYRK_RECT && TSA == 64 && TSB == 64) ||
                 (MODE == MODE_TRSM && TSA == 32 && TSB == kTile), "quarter forms: RECT 64x64, TRSM 32x128");
   constexpr int WGR = (TSA == 32) ? 1 : 2, WGC = 4 / WGR;  // wave grid
@@ -98,35 +111,41 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WGC, wc = wave % WGC;
   const size_t ld = g.ld;
-  const double *Ag, *Bg;
-  size_t lda, ldb;
-  Ag = g.M + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + g.kcol0; lda = ld;
-  if (MODE == MODE_TRSM) { Bg = g.Linv; ldb = kTile; }
-  else { Bg = g.M + (size_t)(g.rb0 + tj * kTile + qc * TSB) * ld + g.kcol0; ldb = ld; }
-  double* Cg = g.M + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + (size_t)(g.cc0 + tj * kTile + qc * TSB);
+  // wave-uniform bases (the tile of a workgroup spans < 2^32 bytes: per-lane offsets are 32-bit byte offsets)
+  const char* Ag = reinterpret_cast<const char*>(g.M + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + g.kcol0);
+  const char* Bg = (MODE == MODE_TRSM) ? reinterpret_cast<const char*>(g.Linv)
+                                       : reinterpret_cast<const char*>(g.M + (size_t)(g.rb0 + tj * kTile + qc * TSB) * ld + g.kcol0);
+  const unsigned ldab = (unsigned)(ld * sizeof(double)), ldbb = (MODE == MODE_TRSM) ? (unsigned)(kTile * sizeof(double)) : ldab;
+  char* Cg = reinterpret_cast<char*>(g.M + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + (size_t)(g.cc0 + tj * kTile + qc * TSB));
   // staging map: KC/2 lanes cover one KC-double row segment (contiguous), 512/KC rows per pass
   constexpr int LPR = KC / 2, RPP = 256 / LPR, NPA = TSA / RPP, NPB = TSB / RPP;
   const int c2 = (tid % LPR) * 2, rbase = tid / LPR;
+  const unsigned offa = (unsigned)rbase * ldab + (unsigned)c2 * 8u, offb = (unsigned)rbase * ldbb + (unsigned)c2 * 8u;
   double2 pa[NPA], pb[NPB];
   auto gload = [&](int kc) {
+    const char* Ak = Ag + (size_t)kc * sizeof(double);  // uniform
+    const char* Bk = Bg + (size_t)kc * sizeof(double);
 #pragma unroll
-    for (int it = 0; it < NPA; ++it) pa[it] = *reinterpret_cast<const double2*>(Ag + (size_t)(rbase + RPP * it) * lda + kc + c2);
+    for (int it = 0; it < NPA; ++it) pa[it] = *reinterpret_cast<const double2*>(Ak + (size_t)(RPP * it) * ldab + offa);
 #pragma unroll
-    for (int it = 0; it < NPB; ++it) pb[it] = *reinterpret_cast<const double2*>(Bg + (size_t)(rbase + RPP * it) * ldb + kc + c2);
+    for (int it = 0; it < NPB; ++it) pb[it] = *reinterpret_cast<const double2*>(Bk + (size_t)(RPP * it) * ldbb + offb);
   };
   gload(kbeg);
   const int fr = lane & 15, fk = lane >> 4;
   // f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+  const unsigned offc = (unsigned)(wr * WTR + fk) * ldab + (unsigned)(wc * WTC + fr) * 8u;  // per lane; the rest is uniform
   v4f64 acc[NMR][NMC];
 #pragma unroll
   for (int tm = 0; tm < NMR; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < NMC; ++tn)
+    for (int rg = 0; rg < 4; ++rg) {
+      const unsigned rowoff = offc + (unsigned)(tm * 16 + 4 * rg) * ldab;  // one VGPR per row; tn goes into the immediate
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
+      for (int tn = 0; tn < NMC; ++tn) {
         if (MODE == MODE_TRSM) acc[tm][tn][rg] = 0.0;
-        else acc[tm][tn][rg] = Cg[(size_t)(wr * WTR + tm * 16 + fk + 4 * rg) * ld + wc * WTC + tn * 16 + fr];
+        else acc[tm][tn][rg] = *reinterpret_cast<const double*>(Cg + rowoff + tn * 128);
       }
+    }
   const double sgn = (MODE == MODE_TRSM) ? 1.0 : -1.0;  // SYRK: acc = C - A B^T through a negated A fragment
   for (int kc = kbeg; kc < kend; kc += KC) {
     __syncthreads();  // previous chunk fully consumed
@@ -153,10 +172,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
 #pragma unroll
   for (int tm = 0; tm < NMR; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < NMC; ++tn)
+    for (int rg = 0; rg < 4; ++rg) {
+      const unsigned rowoff = offc + (unsigned)(tm * 16 + 4 * rg) * ldab;
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg)
-        Cg[(size_t)(wr * WTR + tm * 16 + fk + 4 * rg) * ld + wc * WTC + tn * 16 + fr] = acc[tm][tn][rg];
+      for (int tn = 0; tn < NMC; ++tn) *reinterpret_cast<double*>(Cg + rowoff + tn * 128) = acc[tm][tn][rg];
+    }
   if (MODE == MODE_TRSM && g.rhs != nullptr) {
     // forward substitution riding along: rhs[row] -= sum_c X[row][c] y[c]. Lane partial over its columns, fixed
     // butterfly over the 16 lanes that share a row, fixed-order sum over the wave columns: deterministic.
@@ -184,6 +204,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) {
     }
   }
 }
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) { gemm_abt_body<MODE, kTile, kTile, KC>(g); }
+template <int MODE, int TSA, int TSB>
+__global__ __launch_bounds__(256, 2) void k_gemm_abt_q(GemmArgs g) { gemm_abt_body<MODE, TSA, TSB, KCQ>(g); }
 
 // Factor the 128x128 diagonal block at (k0,k0) (lower Cholesky) and form its inverse.
 // L (lower incl. diagonal) is written back into M; L^-1 (lower, zeros above) goes to Linv_out [128][128].
@@ -504,14 +529,14 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   auto trsm = [&](int t, int r0, int r1, hipStream_t s2, bool quad) {
     if (r1 <= r0) return;
     GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, b, b + npad};
-    if (quad) hipLaunchKernelGGL((k_gemm_abt<MODE_TRSM, 32, kTile>), dim3(r1 - r0, 1, 4), dim3(256), (size_t)(32 + kTile) * LDT * sizeof(double), s2, g);
+    if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_TRSM, 32, kTile>), dim3(r1 - r0, 1, 4), dim3(256), (size_t)(32 + kTile) * (KCQ + 1) * sizeof(double), s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(r1 - r0), dim3(256), lds_gemm, s2, g);
   };
   // C tiles (rows [r0, r1), tile columns [tc0, tc0+ntc)) -= A[rows, K] A[tc.., K]^T, K = tiles kt0.. (KD columns); lower part only
   auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2, bool quad) {
     if (r1 <= r0 || ntc <= 0) return;
     GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr};
-    if (quad) hipLaunchKernelGGL((k_gemm_abt<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4), dim3(256), lds_gemm / 2, s2, g);
+    if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0), dim3(256), lds_gemm, s2, g);
   };
 

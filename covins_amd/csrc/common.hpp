@@ -138,7 +138,8 @@ void launch_imu_gather(const DevProblem& P, int which, hipStream_t st);  // whic
 void launch_edge_gather(const DevProblem& P, hipStream_t st);
 // structured solve of the damped reduced system: speed-bias chains -> dense pose system -> back-substitution.
 // Solution (IR layout, D per keyframe) is written to dst[0..n).
-void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax);
+struct PgoPlan;
+void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax, PgoPlan* pgo = nullptr);
 // speed-bias chain factorisation on the auxiliary stream as soon as the IMU blocks are final (overlaps the landmark pass)
 void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& ax);
 void launch_zero_system(const DevProblem& P, hipStream_t st);
@@ -158,7 +159,26 @@ struct CholAux {
   void collect();
 };
 // dense SPD solve of Sred x = bred in place (lower Cholesky on the FP64 MFMA path); flag[0] != 0 on failure
-void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax);
+// batched form: n independent systems of identical shape; sM / sL / sR = elements between consecutive matrices, Linv
+// sets and right-hand sides. The same launches serve all of them (one more grid dimension).
+struct DenseBatch { int n = 0; size_t sM = 0, sL = 0, sR = 0; };
+void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax, int tstop = -1,
+                              bool solve = true, DenseBatch bt = DenseBatch());  // tstop >= 0 (even): eliminate tile columns [0, tstop) only
+void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStream_t st, int tfact, int tend, DenseBatch bt = DenseBatch());
+
+// ---- block-arrow pose-graph solve (k_pgo.hip)
+struct PgoHostPlan { std::vector<std::vector<int>> block_kf; std::vector<int> border_kf; };
+bool pgo_plan_analyse(int K, int E, const int* ei, const int* ej, PgoHostPlan& out);
+struct PgoPlan {
+  bool active = false;
+  int nblk = 0, nIpad = 0, ntot = 0;  // blocks; padded interior order (multiple of 256, the largest block's); nIpad + nb
+  int nb = 0;                          // padded border order (multiple of 128)
+  int* idx = nullptr;                  // [nblk][ntot] row of the global system, -1 = padding
+  double *M = nullptr, *rhs = nullptr, *Linv = nullptr;  // [nblk][ntot][ntot] | [nblk][2 ntot] | [nblk][nIpad/128][128][128]
+  int* idx_b = nullptr;
+  double *Sb = nullptr, *rhs_b = nullptr, *Linv_b = nullptr;
+};
+void launch_pgo_block_solve(const DevProblem& P, PgoPlan& plan, hipStream_t st, CholAux& ax);
 
 void launch_dogleg_stats(const DevProblem& P, hipStream_t st);  // GG, GN2, GDOT, GMAX from grad/hdiag/gn
 void launch_cauchy_vec(const DevProblem& P, hipStream_t st);    // vtmp = grad / d^2

@@ -22,6 +22,7 @@
 // Forward substitution rides along with the factorisation (potrf forms y_p, every TRSM takes its tile's product
 // with y_p out of the right-hand side); the backward solve reuses the stored L_pp^-1 blocks, one launch per panel.
 #include <cstdlib>
+#include <mutex>
 
 #include "common.hpp"
 #include "dev_math.hpp"
@@ -61,6 +62,8 @@ struct GemmArgs {
   // TRSM with a right-hand side riding along (forward substitution fused into the factorisation):
   // rhs[rows of this workgroup] -= X[rows, :] yvec[kcol0 .. kcol0+128), X = the freshly computed L tile
   double* rhs; const double* yvec;
+  // batched form (block-arrow pose-graph solve): independent matrices of identical shape, `batch` strides apart
+  size_t bsM, bsL, bsR;  // elements between consecutive matrices / Linv sets / right-hand sides (0: not batched)
 };
 
 // C[i][j] (op)= sum_k A[i][k] B[j][k] on one 128x128 tile (TSA = TSB = 128), or on a quarter of it selected by
@@ -85,8 +88,11 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
   constexpr int WGR = (TSA == 32) ? 1 : 2, WGC = 4 / WGR;  // wave grid
   constexpr int WTR = TSA / WGR, WTC = TSB / WGC;           // wave tile
   constexpr int NMR = WTR / 16, NMC = WTC / 16;             // MFMA tiles per wave
-  const int qr = (TSA == kTile) ? 0 : (TSB == kTile ? (int)blockIdx.z : (int)(blockIdx.z >> 1));
-  const int qc = (TSB == kTile) ? 0 : (int)(blockIdx.z & 1);
+  constexpr int ZQ = (TSA == kTile && TSB == kTile) ? 1 : 4;  // quarter index and batch index share blockIdx.z
+  const int zq = (int)blockIdx.z % ZQ, batch = (MODE == MODE_SYRK_TRI) ? (int)blockIdx.y : (int)blockIdx.z / ZQ;
+  const int qr = (TSA == kTile) ? 0 : (TSB == kTile ? zq : (zq >> 1));
+  const int qc = (TSB == kTile) ? 0 : (zq & 1);
+  double* const Mb = g.M + (size_t)batch * g.bsM;
   int ti, tj;
   if (MODE == MODE_SYRK_TRI) {
     // XCD-aware decode: block b -> XCD (b & 7) (observed dispatch order; placement affects speed only).
@@ -112,11 +118,11 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
   const int wr = wave / WGC, wc = wave % WGC;
   const size_t ld = g.ld;
   // wave-uniform bases (the tile of a workgroup spans < 2^32 bytes: per-lane offsets are 32-bit byte offsets)
-  const char* Ag = reinterpret_cast<const char*>(g.M + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + g.kcol0);
-  const char* Bg = (MODE == MODE_TRSM) ? reinterpret_cast<const char*>(g.Linv)
-                                       : reinterpret_cast<const char*>(g.M + (size_t)(g.rb0 + tj * kTile + qc * TSB) * ld + g.kcol0);
+  const char* Ag = reinterpret_cast<const char*>(Mb + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + g.kcol0);
+  const char* Bg = (MODE == MODE_TRSM) ? reinterpret_cast<const char*>(g.Linv + (size_t)batch * g.bsL)
+                                       : reinterpret_cast<const char*>(Mb + (size_t)(g.rb0 + tj * kTile + qc * TSB) * ld + g.kcol0);
   const unsigned ldab = (unsigned)(ld * sizeof(double)), ldbb = (MODE == MODE_TRSM) ? (unsigned)(kTile * sizeof(double)) : ldab;
-  char* Cg = reinterpret_cast<char*>(g.M + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + (size_t)(g.cc0 + tj * kTile + qc * TSB));
+  char* Cg = reinterpret_cast<char*>(Mb + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + (size_t)(g.cc0 + tj * kTile + qc * TSB));
   // staging map: KC/2 lanes cover one KC-double row segment (contiguous), 512/KC rows per pass
   constexpr int LPR = KC / 2, RPP = 256 / LPR, NPA = TSA / RPP, NPB = TSB / RPP;
   const int c2 = (tid % LPR) * 2, rbase = tid / LPR;
@@ -183,7 +189,7 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
     __syncthreads();                     // the staging buffers are free
     double* sy = smem;                   // [128] y of this panel
     double* sp = smem + kTile;           // [WGC][TSA] partial row sums
-    if (tid < kTile) sy[tid] = g.yvec[g.kcol0 + tid];
+    if (tid < kTile) sy[tid] = g.yvec[(size_t)batch * g.bsR + g.kcol0 + tid];
     __syncthreads();
 #pragma unroll
     for (int tm = 0; tm < NMR; ++tm)
@@ -200,7 +206,7 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
       double t = 0.0;
 #pragma unroll
       for (int w2 = 0; w2 < WGC; ++w2) t += sp[w2 * TSA + tid];
-      g.rhs[g.ra0 + ti * kTile + qr * TSA + tid] -= t;
+      g.rhs[(size_t)batch * g.bsR + g.ra0 + ti * kTile + qr * TSA + tid] -= t;
     }
   }
 }
@@ -217,7 +223,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt_q(GemmArgs g) { gemm_abt_bo
 // (r = ty + 16 i, c = tx + 16 k); only the pivot column travels through LDS each step. (Keeping the matrix in LDS
 // and updating it in place serialises on LDS read-after-write: measured 260 us per block instead of ~40.)
 __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_t ld, int k0, double* __restrict__ Linv_out, int* flag,
-                                                    const double* __restrict__ rhs, double* __restrict__ yout) {
+                                                    const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR) {
+  M += (size_t)blockIdx.x * bsM; Linv_out += (size_t)blockIdx.x * bsL;  // batched form: one workgroup per matrix
+  if (rhs != nullptr) { rhs += (size_t)blockIdx.x * bsR; yout += (size_t)blockIdx.x * bsR; }
   extern __shared__ __attribute__((aligned(16))) double s[];  // [128][129]
   __shared__ __attribute__((aligned(16))) double colb[2][16][8];
   constexpr int PT = kTile + 1;
@@ -394,15 +402,21 @@ __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_
 // backward substitution step for panel p:  x_p = Linv_p^T y_p ; y[cols left of the panel] -= L[panel rows, cols]^T x_p
 // Block = 32 columns x 8 row groups (16 panel rows each): 8x more loads in flight than one thread per column
 // (that version was latency-bound: 50 us per step), partial sums combined through LDS in a fixed order.
+// Linv == nullptr: x_p is given (block-arrow solve: a border tile); ncol = number of columns to update (p*128 normally).
 __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, size_t ld, int p, const double* __restrict__ Linv,
-                                                   double* __restrict__ y, double* __restrict__ x) {
+                                                   double* __restrict__ y, double* __restrict__ x, int ncol, size_t bsM, size_t bsL, size_t bsR) {
+  M += (size_t)blockIdx.y * bsM; y += (size_t)blockIdx.y * bsR; x += (size_t)blockIdx.y * bsR;  // batched form
+  if (Linv != nullptr) Linv += (size_t)blockIdx.y * bsL;
   __shared__ double sx[kTile];
   __shared__ double sy[kTile];
   __shared__ double part[8][33];
   const int tid = threadIdx.x, k0 = p * kTile;
-  if (tid < kTile) sy[tid] = y[k0 + tid];
-  __syncthreads();
-  {  // x_p = Linv^T y_p : thread (i, half) sums half of the rows j >= i
+  if (Linv == nullptr) {
+    if (tid < kTile) sx[tid] = x[k0 + tid];
+    __syncthreads();
+  } else {  // x_p = Linv^T y_p : thread (i, half) sums half of the rows j >= i
+    if (tid < kTile) sy[tid] = y[k0 + tid];
+    __syncthreads();
     const int i = tid & 127, half = tid >> 7;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     const double* Lc = Linv + i;
@@ -422,14 +436,14 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, 
   const int cl = tid & 31, rg = tid >> 5;
   const int col = blockIdx.x * 32 + cl;
   double acc = 0.0;
-  if (col < k0) {
+  if (col < ncol) {
     const double* Lc = M + (size_t)(k0 + 16 * rg) * ld + col;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc += Lc[(size_t)r * ld] * sx[16 * rg + r];
   }
   part[rg][cl] = acc;
   __syncthreads();
-  if (rg == 0 && col < k0) {
+  if (rg == 0 && col < ncol) {
     double t = 0.0;
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) t += part[g2][cl];
@@ -496,19 +510,20 @@ void CholAux::collect() {
   prof_flops.clear();
 }
 
-void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax) {
+void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax, int tstop, bool solve,
+                              DenseBatch bt) {
+  const int nbt = bt.n > 0 ? bt.n : 1;
   const int T = npad / kTile;
   const size_t ld = (size_t)npad;
   const size_t lds_potrf = (size_t)kTile * (kTile + 1) * sizeof(double);
   const size_t lds_gemm = (size_t)2 * kTile * LDT * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;  // (the pose-graph solve calls this from several host threads at once)
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_potrf);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_TRSM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_SYRK_TRI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_SYRK_RECT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
-    attr_set = true;
-  }
+  });
   ax.init();
   const int NP = (T + 1) / 2;  // big panels of two tile columns
   // events per big panel: H rows-h done | B bulk done | C rows-r done | 1 potrf(t0) | 2 X(t0+1,t0) | 3 potrf(t0+1) | Rc next diagonal updated
@@ -523,21 +538,23 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   hipEvent_t* e3 = e2 + (NP + 1);
   hipEvent_t* eRc = e3 + (NP + 1);
 
-  auto potrf = [&](int t) { hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), lds_potrf, st, S, ld, t * kTile, Linv + (size_t)t * kTile * kTile, flag, b, b + npad); };
+  auto potrf = [&](int t) {
+    hipLaunchKernelGGL(k_potrf_inv, dim3(nbt), dim3(256), lds_potrf, st, S, ld, t * kTile, Linv + (size_t)t * kTile * kTile, flag, b, b + npad, bt.sM, bt.sL, bt.sR);
+  };
   // rows [r0, r1) of tile column t:  A <- A Linv_t^T
   // quad: four workgroups per tile (head launches on the serial chain)
   auto trsm = [&](int t, int r0, int r1, hipStream_t s2, bool quad) {
     if (r1 <= r0) return;
-    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, b, b + npad};
-    if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_TRSM, 32, kTile>), dim3(r1 - r0, 1, 4), dim3(256), (size_t)(32 + kTile) * (KCQ + 1) * sizeof(double), s2, g);
-    else hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(r1 - r0), dim3(256), lds_gemm, s2, g);
+    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, b, b + npad, bt.sM, bt.sL, bt.sR};
+    if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_TRSM, 32, kTile>), dim3(r1 - r0, 1, 4 * nbt), dim3(256), (size_t)(32 + kTile) * (KCQ + 1) * sizeof(double), s2, g);
+    else hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(r1 - r0, 1, nbt), dim3(256), lds_gemm, s2, g);
   };
   // C tiles (rows [r0, r1), tile columns [tc0, tc0+ntc)) -= A[rows, K] A[tc.., K]^T, K = tiles kt0.. (KD columns); lower part only
   auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2, bool quad) {
     if (r1 <= r0 || ntc <= 0) return;
-    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr};
-    if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), s2, g);
-    else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0), dim3(256), lds_gemm, s2, g);
+    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR};
+    if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4 * nbt), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), s2, g);
+    else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0, nbt), dim3(256), lds_gemm, s2, g);
   };
 
   // Four streams (timeline analysis in profiles/r01y_timeline_*.csv: once the trailing matrix is small the period of
@@ -549,6 +566,11 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   //   B  the bulk rank-256 trailing update (triangle from tile t0+4).
   hipStream_t M = st, H = ax.head, R = ax.mid, B = ax.aux;
   auto wait = [](hipStream_t s2, hipEvent_t e) { (void)hipStreamWaitEvent(s2, e, 0); };
+  // Partial factorisation (tstop >= 0, even): eliminate tile columns [0, tstop) only; the trailing block then holds
+  // its Schur complement (and, with the forward substitution riding along, b's trailing part the reduced right-hand
+  // side). Used by the block-arrow pose-graph solve (k_pgo.hip).
+  const int Pstop = (tstop >= 0 && tstop < T) ? tstop / 2 : NP;
+  int Plast = NP - 1;
   for (int P = 0; P < NP; ++P) {
     const int t0 = 2 * P, w = (T - t0 >= 2) ? 2 : 1;
     const int h0 = (t0 + 2 < T) ? t0 + 2 : T, h1 = (t0 + 4 < T) ? t0 + 4 : T;  // rows h = [h0, h1), rows r = [h1, T)
@@ -565,6 +587,13 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         if (P >= 2) wait(R, eB[P - 2]);
         rect(h1, T, t0, w, t0 - 2, 2 * kTile, R, false);
       }
+    }
+    if (P == Pstop) {  // only the look-ahead updates of the last eliminated panel; nothing of this panel is factored
+      (void)hipEventRecord(eH[P], H);
+      (void)hipEventRecord(eC[P], R);
+      (void)hipEventRecord(eB[P], B);
+      Plast = P;
+      break;
     }
     // ---- M: critical chain
     potrf(t0);
@@ -616,9 +645,9 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     if (P + 1 < NP) wait(B, eRc[P + 1]);
     if (nt > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
-      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr};
+      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR};
       if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], B);
-      hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk), dim3(256), lds_gemm, B, g);
+      hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, B, g);
       if (ax.profile) {
         (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], B);
         ax.prof_flops.push_back((double)nt * (nt + 1) / 2 * 2.0 * kTile * kTile * (w * kTile));
@@ -626,15 +655,28 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     }
     (void)hipEventRecord(eB[P], B);
   }
-  wait(M, eB[NP - 1]);
-  if (NP >= 2) wait(M, eB[NP - 2]);
-  wait(M, eC[NP - 1]);
-  wait(M, eH[NP - 1]);
+  wait(M, eB[Plast]);
+  if (Plast >= 1) wait(M, eB[Plast - 1]);
+  wait(M, eC[Plast]);
+  wait(M, eH[Plast]);
+  if (!solve) return;
   // y = L^-1 b was formed along the way (potrf: y_p = L_pp^-1 b_p; every TRSM: b[rows] -= L[rows, p] y_p) and lives
   // in b[npad .. 2 npad). Remaining: L^T x = y.
-  for (int p = T - 1; p >= 0; --p) {
-    const int nb = (p * kTile + 31) / 32;
-    hipLaunchKernelGGL(k_bwd_step, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, S, ld, p, Linv + (size_t)p * kTile * kTile, b + npad, b);
+  dense_backward_solve(S, b, Linv, npad, st, T, T, bt);
+}
+
+// L^T x = y for the factored tile columns [0, tfact) of an npad-order matrix; for tile rows p in [tfact, tend) x_p is
+// GIVEN (already in b[p*128 ..]) and only its contribution L[rows p, cols < tfact*128]^T x_p is taken out of y.
+void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStream_t st, int tfact, int tend, DenseBatch bt) {
+  const int nbt = bt.n > 0 ? bt.n : 1;
+  const size_t ld = (size_t)npad;
+  for (int p = tend - 1; p >= 0; --p) {
+    const bool given = p >= tfact;
+    const int ncol = given ? tfact * kTile : p * kTile;
+    const int nb = (ncol + 31) / 32;
+    if (given && nb == 0) continue;
+    hipLaunchKernelGGL(k_bwd_step, dim3(nb > 0 ? nb : 1, nbt), dim3(256), 0, st, S, ld, p, given ? nullptr : Linv + (size_t)p * kTile * kTile,
+                       b + npad, b, ncol, bt.sM, bt.sL, bt.sR);
   }
 }
 

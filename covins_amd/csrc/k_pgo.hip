@@ -1,0 +1,164 @@
+// k_pgo.hip — block-arrow solve of the pose-graph system (PoseGraphOptimization, optimization_be.cpp:1024-1031).
+//
+// The pose-graph Hessian is not dense: every keyframe is tied to at most its five predecessors (optimization_be.cpp:
+// 947-1021), agents are coupled with each other only through loop edges, and there are few of those (:912-944).
+// Factorising it densely costs what a GBA iteration costs — bound by the serial panel chain of the 6K-order matrix
+// (103 potrf steps, 25 ms on the 5-agent map) although almost every tile is zero. Instead:
+//   border   = keyframes at the ends of loop edges                                             -> last
+//   blocks   = connected components of the rest (the agents), merged to at most kPgoMaxBlocks  -> independent
+// H = [ D_0        B_0 ]   each block's arrow [D_a B_a; B_a^T 0] is copied into its own dense buffer and its first
+//     [     D_1    B_1 ]   T_a tile columns are eliminated by the SAME MFMA Cholesky (partial factorisation, k_chol.hip),
+//     [ B_0^T B_1^T  C ]   all blocks batched into the same launches: the trailing block of each buffer then holds
+// -X_b X_b^T, the block's Schur contribution, and the trailing part of its right-hand side -X_b y_a. The border system
+// C - sum_a X_b X_b^T (order 6 x #border keyframes) is summed in a fixed order, solved densely, and every block
+// finishes with its own backward substitution. Same arithmetic as the dense solve up to the elimination order.
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+
+namespace covgpu {
+
+constexpr int kPgoMaxBlocks = 8;
+
+// host: pick the border and cut the rest into independent blocks, from the edge list alone (the map hands keyframes
+// over agent-interleaved, typedefs_base.hpp:178, so index distance says nothing). An edge whose endpoints have no
+// common neighbour is a bridge between otherwise unrelated parts of the graph — a loop closure; the odometry edges of
+// one agent (each keyframe tied to its five predecessors) always share neighbours. Border = endpoints of such
+// edges; blocks = connected components of what is left (union-find), merged to at most kPgoMaxBlocks. Any partition
+// found this way is valid (no interior-interior edge crosses blocks by construction); the heuristic only decides
+// whether it pays. Returns false if it does not (no split, or a large border): the caller keeps the dense solve.
+bool pgo_plan_analyse(int K, int E, const int* ei, const int* ej, PgoHostPlan& out) {
+  out = PgoHostPlan();
+  if (6 * K < 8 * kTile) return false;  // fewer than eight tiles of unknowns: the dense solve is a handful of launches
+  std::vector<std::vector<int>> adj(K);
+  for (int e = 0; e < E; ++e) { adj[ei[e]].push_back(ej[e]); adj[ej[e]].push_back(ei[e]); }
+  for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+  std::vector<char> border(K, 0);
+  for (int e = 0; e < E; ++e) {
+    const std::vector<int>&A = adj[ei[e]], &B = adj[ej[e]];
+    bool common = false;
+    for (size_t x = 0, y = 0; x < A.size() && y < B.size();) {
+      if (A[x] == B[y]) { common = true; break; }
+      if (A[x] < B[y]) ++x; else ++y;
+    }
+    if (!common && (A.size() > 1 || B.size() > 1)) { border[ei[e]] = 1; border[ej[e]] = 1; }
+  }
+  std::vector<int> parent(K);
+  for (int k = 0; k < K; ++k) parent[k] = k;
+  auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+  for (int e = 0; e < E; ++e)
+    if (!border[ei[e]] && !border[ej[e]]) { const int a = find(ei[e]), b = find(ej[e]); if (a != b) parent[std::max(a, b)] = std::min(a, b); }
+  std::vector<std::vector<int>> comps;
+  std::vector<int> comp_of(K, -1);
+  int n_int = 0;
+  for (int k = 0; k < K; ++k) {
+    if (border[k]) continue;
+    const int r = find(k);
+    if (comp_of[r] < 0) { comp_of[r] = (int)comps.size(); comps.emplace_back(); }
+    comps[comp_of[r]].push_back(k);
+    ++n_int;
+  }
+  const int n_border = K - n_int;
+  if (comps.size() < 2 || n_border * 3 > K) return false;
+  // largest components first; the rest is packed onto the currently smallest block
+  std::sort(comps.begin(), comps.end(), [](const std::vector<int>& x, const std::vector<int>& y) { return x.size() != y.size() ? x.size() > y.size() : x[0] < y[0]; });
+  if ((int)comps[0].size() * 10 > n_int * 7) return false;  // one component dominates: its chain of panels is the whole cost anyway
+  std::vector<std::vector<int>> blocks;
+  for (auto& cmp : comps) {
+    if ((int)blocks.size() < kPgoMaxBlocks) { blocks.push_back(cmp); continue; }
+    size_t best = 0;
+    for (size_t q = 1; q < blocks.size(); ++q) if (blocks[q].size() < blocks[best].size()) best = q;
+    blocks[best].insert(blocks[best].end(), cmp.begin(), cmp.end());
+  }
+  for (auto& bl : blocks) std::sort(bl.begin(), bl.end());
+  for (int k = 0; k < K; ++k) if (border[k]) out.border_kf.push_back(k);
+  out.block_kf = std::move(blocks);
+  return true;
+}
+
+// arrow buffers, one per block (blockIdx.z), all of the same padded shape: M[i][j] = H[idx[i]][idx[j]] (H symmetric,
+// lower stored), identity on padding, ZERO in the trailing (border x border) block; rhs[i] = b[idx[i]] on the block's
+// own rows, zero on the border rows
+__global__ __launch_bounds__(256) void k_pgo_gather(const double* __restrict__ H, size_t ldh, const double* __restrict__ bp,
+                                                     const int* __restrict__ idx_all, int ntot, int nIpad, double* __restrict__ M_all,
+                                                     double* __restrict__ rhs_all) {
+  const int j = blockIdx.x * 16 + (threadIdx.x & 15), i = blockIdx.y * 16 + (threadIdx.x >> 4), a = blockIdx.z;
+  if (i >= ntot || j >= ntot) return;
+  const int* idx = idx_all + (size_t)a * ntot;
+  const int gi = idx[i], gj = idx[j];
+  double v;
+  if (i >= nIpad && j >= nIpad) v = 0.0;
+  else if (gi < 0 || gj < 0) v = (i == j) ? 1.0 : 0.0;
+  else v = H[(size_t)max(gi, gj) * ldh + min(gi, gj)];
+  M_all[(size_t)a * ntot * ntot + (size_t)i * ntot + j] = v;
+  if (j == 0) {
+    double* rhs = rhs_all + (size_t)a * 2 * ntot;
+    rhs[i] = (i < nIpad && gi >= 0) ? bp[gi] : 0.0;
+    rhs[ntot + i] = 0.0;
+  }
+}
+
+// border system: C - sum_a X_b X_b^T and b_b - sum_a X_b y_a, blocks added in index order
+__global__ __launch_bounds__(256) void k_pgo_border(const double* __restrict__ H, size_t ldh, const double* __restrict__ bp,
+                                                     const int* __restrict__ idxb, int nb, const double* __restrict__ M_all,
+                                                     const double* __restrict__ rhs_all, int nblk, int ntot, int nIpad,
+                                                     double* __restrict__ Sb, double* __restrict__ rhsb) {
+  const int j = blockIdx.x * 16 + (threadIdx.x & 15), i = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (i >= nb || j > i) return;
+  const int gi = idxb[i], gj = idxb[j];
+  double v;
+  if (gi < 0 || gj < 0) v = (i == j) ? 1.0 : 0.0;
+  else {
+    v = H[(size_t)max(gi, gj) * ldh + min(gi, gj)];
+    for (int a = 0; a < nblk; ++a) v += M_all[(size_t)a * ntot * ntot + (size_t)(nIpad + i) * ntot + nIpad + j];
+  }
+  Sb[(size_t)i * nb + j] = v;
+  Sb[(size_t)j * nb + i] = v;
+  if (j == 0) {
+    double r = 0.0;
+    if (gi >= 0) {
+      r = bp[gi];
+      for (int a = 0; a < nblk; ++a) r += rhs_all[(size_t)a * 2 * ntot + nIpad + i];
+    }
+    rhsb[i] = r;
+  }
+}
+
+// x_b -> solution vector (blockIdx.y == nblk) and into the given-x part of every block's vector (blockIdx.y = block)
+__global__ __launch_bounds__(256) void k_pgo_put_border(const double* __restrict__ xb, const int* __restrict__ idxb, int nb, double* __restrict__ sol,
+                                                         double* __restrict__ rhs_all, int nblk, int ntot, int nIpad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, a = blockIdx.y;
+  if (i >= nb) return;
+  if (a < nblk) rhs_all[(size_t)a * 2 * ntot + nIpad + i] = xb[i];
+  else if (idxb[i] >= 0) sol[idxb[i]] = xb[i];
+}
+__global__ __launch_bounds__(256) void k_pgo_scatter(const double* __restrict__ rhs_all, const int* __restrict__ idx_all, int ntot, int nIpad,
+                                                      double* __restrict__ sol) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, a = blockIdx.y;
+  if (i >= nIpad) return;
+  const int gi = idx_all[(size_t)a * ntot + i];
+  if (gi >= 0) sol[gi] = rhs_all[(size_t)a * 2 * ntot + i];
+}
+
+// Solves H x = b for the pose-graph system assembled in P.Sred / P.bp (map order); x overwrites P.bp.
+// All blocks share one shape (padded to the largest) and advance in lockstep through ONE batched partial factorisation
+// on the context's usual four streams: the same ~300 launches as for a single block, each covering every block
+// (one more grid dimension). (Separate stream sets per block, each with its own launches, were host-bound and
+// multiplexed onto the runtime's four hardware queues: 23.5 ms per iteration against 25.6 dense.)
+void launch_pgo_block_solve(const DevProblem& P, PgoPlan& plan, hipStream_t st, CholAux& ax) {
+  const size_t ldh = (size_t)P.npad;
+  const int nblk = plan.nblk, ntot = plan.ntot, nIpad = plan.nIpad, nb = plan.nb;
+  const DenseBatch bt{nblk, (size_t)ntot * ntot, (size_t)nIpad * kTile, (size_t)2 * ntot};
+  hipLaunchKernelGGL(k_pgo_gather, dim3((ntot + 15) / 16, (ntot + 15) / 16, nblk), dim3(256), 0, st, P.Sred, ldh, P.bp, plan.idx, ntot, nIpad, plan.M,
+                     plan.rhs);
+  dense_cholesky_solve_raw(plan.M, plan.rhs, plan.Linv, P.flag, ntot, st, ax, nIpad / kTile, false, bt);
+  hipLaunchKernelGGL(k_pgo_border, dim3((nb + 15) / 16, (nb + 15) / 16), dim3(256), 0, st, P.Sred, ldh, P.bp, plan.idx_b, nb, plan.M, plan.rhs, nblk, ntot,
+                     nIpad, plan.Sb, plan.rhs_b);
+  dense_cholesky_solve_raw(plan.Sb, plan.rhs_b, plan.Linv_b, P.flag, nb, st, ax);  // x_b in rhs_b[0 .. nb)
+  hipLaunchKernelGGL(k_pgo_put_border, dim3((nb + 255) / 256, nblk + 1), dim3(256), 0, st, plan.rhs_b, plan.idx_b, nb, P.bp, plan.rhs, nblk, ntot, nIpad);
+  dense_backward_solve(plan.M, plan.rhs, plan.Linv, ntot, st, nIpad / kTile, ntot / kTile, bt);
+  hipLaunchKernelGGL(k_pgo_scatter, dim3((nIpad + 255) / 256, nblk), dim3(256), 0, st, plan.rhs, plan.idx, ntot, nIpad, P.bp);
+}
+
+}  // namespace covgpu

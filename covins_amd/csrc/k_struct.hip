@@ -490,7 +490,7 @@ void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& 
   ax.cf_pending = true;
 }
 
-void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax) {
+void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax, PgoPlan* pgo) {
   const int cnt = P.npad > 9 * P.K ? P.npad : 9 * P.K;
   const bool early = P.vi && ax.cf_pending;  // chain factor (and z in xs) already under way on the auxiliary stream
   hipLaunchKernelGGL(k_gather_rhs, dim3((cnt + 255) / 256), dim3(256), 0, st, P, early ? 0 : 2);
@@ -506,7 +506,8 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
     }
     hipLaunchKernelGGL(k_yty_semisep, dim3(P.K), dim3(256), 0, st, P);
   }
-  dense_cholesky_solve_raw(P.Sred, P.bp, P.Linv, P.flag, P.npad, st, ax);
+  if (pgo != nullptr) launch_pgo_block_solve(P, *pgo, st, ax);  // pose graph: block-arrow elimination (k_pgo.hip)
+  else dense_cholesky_solve_raw(P.Sred, P.bp, P.Linv, P.flag, P.npad, st, ax);
   if (P.vi) {
     hipLaunchKernelGGL(k_sb_rhs, dim3((9 * P.K + 255) / 256), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_sb_backsolve, dim3(P.nchains), dim3(64), 0, st, P);

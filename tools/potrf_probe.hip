@@ -26,7 +26,7 @@ int main() {
     hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
     { long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)); }
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), lds, 0, dA, (size_t)n, 0, dL, df, (const double*)nullptr, (double*)nullptr);
+    hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), lds, 0, dA, (size_t)n, 0, dL, df, (const double*)nullptr, (double*)nullptr, (size_t)0, (size_t)0, (size_t)0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     long long pr[8];

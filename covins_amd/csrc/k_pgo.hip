@@ -19,7 +19,9 @@
 
 namespace covgpu {
 
-constexpr int kPgoMaxBlocks = 8;
+constexpr int kPgoMaxBlocks = 32;   // blocks of one batched factorisation
+constexpr int kPgoSegment = 100;    // keyframes per block aimed at when a long component is cut (swept 40..250 on the
+                                    // 5-agent map: 84, 95, 65 (100), 73, 83 ms per call)
 
 // host: pick the border and cut the rest into independent blocks, from the edge list alone (the map hands keyframes
 // over agent-interleaved, typedefs_base.hpp:178, so index distance says nothing). An edge whose endpoints have no
@@ -44,20 +46,62 @@ bool pgo_plan_analyse(int K, int E, const int* ei, const int* ej, PgoHostPlan& o
     }
     if (!common && (A.size() > 1 || B.size() > 1)) { border[ei[e]] = 1; border[ej[e]] = 1; }
   }
+  // components of the graph without the border (union-find)
   std::vector<int> parent(K);
-  for (int k = 0; k < K; ++k) parent[k] = k;
   auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
-  for (int e = 0; e < E; ++e)
-    if (!border[ei[e]] && !border[ej[e]]) { const int a = find(ei[e]), b = find(ej[e]); if (a != b) parent[std::max(a, b)] = std::min(a, b); }
   std::vector<std::vector<int>> comps;
-  std::vector<int> comp_of(K, -1);
   int n_int = 0;
-  for (int k = 0; k < K; ++k) {
-    if (border[k]) continue;
-    const int r = find(k);
-    if (comp_of[r] < 0) { comp_of[r] = (int)comps.size(); comps.emplace_back(); }
-    comps[comp_of[r]].push_back(k);
-    ++n_int;
+  auto components = [&]() {
+    for (int k = 0; k < K; ++k) parent[k] = k;
+    for (int e = 0; e < E; ++e)
+      if (!border[ei[e]] && !border[ej[e]]) { const int a = find(ei[e]), b = find(ej[e]); if (a != b) parent[std::max(a, b)] = std::min(a, b); }
+    comps.clear();
+    std::vector<int> comp_of(K, -1);
+    n_int = 0;
+    for (int k = 0; k < K; ++k) {
+      if (border[k]) continue;
+      const int r = find(k);
+      if (comp_of[r] < 0) { comp_of[r] = (int)comps.size(); comps.emplace_back(); }
+      comps[comp_of[r]].push_back(k);
+      ++n_int;
+    }
+  };
+  components();
+  // Long components (an agent's whole trajectory) are cut further: in a breadth-first level structure edges join equal
+  // or adjacent levels only, so removing one whole level separates what came before from what comes after. Levels of
+  // an odometry chain are ~5 keyframes wide; one level per ~kPgoSegment keyframes goes to the border. The serial panel
+  // chain of the batched factorisation is as long as the LARGEST block, so many short blocks beat a few long ones.
+  {
+    std::vector<int> level(K, -1), queue;
+    auto bfs = [&](int start) {  // levels inside start's component (border excluded); returns the last node reached
+      queue.assign(1, start);
+      level[start] = 0;
+      for (size_t h = 0; h < queue.size(); ++h) {
+        const int u = queue[h];
+        for (int v : adj[u]) if (!border[v] && level[v] < 0) { level[v] = level[u] + 1; queue.push_back(v); }
+      }
+      return queue.back();
+    };
+    const std::vector<std::vector<int>> first = comps;
+    for (const auto& cmp : first) {
+      if ((int)cmp.size() < 2 * kPgoSegment) continue;
+      const int far = bfs(cmp[0]);
+      for (int v : queue) level[v] = -1;
+      bfs(far);  // second sweep from a pseudo-peripheral node
+      std::vector<int> order = queue;
+      int since = 0, cut_level = -1, prev_level = -1, remaining = (int)order.size();
+      for (int v : order) {  // breadth-first order: levels arrive one after the other
+        if (level[v] != prev_level) {  // first keyframe of a new level: the only place a cut may start
+          prev_level = level[v];
+          if (since >= kPgoSegment && remaining > kPgoSegment / 2) { cut_level = level[v]; since = 0; }
+        }
+        --remaining;
+        if (level[v] == cut_level) border[v] = 1;
+        else ++since;
+      }
+      for (int v : order) level[v] = -1;
+    }
+    components();
   }
   const int n_border = K - n_int;
   if (comps.size() < 2 || n_border * 3 > K) return false;

@@ -79,6 +79,8 @@ def main():
     cfg = synth.config_named(args.workload, seed=distrib.map_seed_for_rank(rank))  # map-sharded: each rank owns one merged map
     m = synth.make_map(cfg)
     prob, _ = mapdata.flatten_gba(m, visual_only=False, loop_loss=True)
+    pgo_prm = mapdata.PgoParams()
+    pgo_prob, _ = mapdata.flatten_pgo(m, {}, pgo_prm)  # the pose graph of the same (still drifted) map, for the side figure below
     opt = backend.default_options(strategy=strategy, max_iterations=args.iterations, device=local_rank)
     ctx = backend.Context(local_rank)
     t_up = time.perf_counter()
@@ -165,6 +167,14 @@ def main():
                                "outliers_removed": info["outliers_removed"],
                                "what": "covins_amd.optimization.Optimization.GlobalBundleAdjustment(map, 10, outlier_removal=True) "
                                        "on the same map, host flattening in numpy"}
+        if not args.no_e2e:
+            # side figure: one PoseGraphOptimization solve of the same map (block-arrow solve); not `value`
+            popt = backend.default_options(max_iterations=pgo_prm.pgo_iteration_limit, device=local_rank)
+            ctx.pgo_solve(pgo_prob, popt)
+            t_p = time.perf_counter()
+            _, pres = ctx.pgo_solve(pgo_prob, popt)
+            out["pgo_call"] = {"t_call_s": time.perf_counter() - t_p, "iterations": pres.iterations, "edges": int(pgo_prob.E),
+                               "initial_cost": pres.initial_cost, "final_cost": pres.final_cost}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(strategy)
         print(json.dumps(out))

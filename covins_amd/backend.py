@@ -50,6 +50,16 @@ def lib() -> C.CDLL:
     return _LIB
 
 
+def pgo_partition(num_kf: int, edge_i, edge_j):
+    """Host-only: block index per keyframe (-1 = border) and the number of blocks (0 = solved densely) of the
+    block-arrow pose-graph solve (covgpu_pgo_partition, include/covgpu.h)."""
+    import numpy as np
+    ei = np.ascontiguousarray(edge_i, np.int32); ej = np.ascontiguousarray(edge_j, np.int32)
+    out = np.empty(num_kf, np.int32)
+    n = lib().covgpu_pgo_partition(num_kf, len(ei), ei.ctypes.data_as(capi._ip), ej.ctypes.data_as(capi._ip), out.ctypes.data_as(capi._ip))
+    return out, int(n)
+
+
 def default_options(**kw) -> Options:
     o = Options()
     lib().covgpu_default_options(C.byref(o))

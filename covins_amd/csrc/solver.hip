@@ -66,6 +66,17 @@ extern "C" int32_t covgpu_reduced_dim(const covgpu_options* opt, const covgpu_pr
   return (opt->visual_only ? 6 : 15) * p->num_kf;
 }
 
+extern "C" int32_t covgpu_pgo_partition(int32_t num_kf, int32_t num_edge, const int32_t* edge_i, const int32_t* edge_j, int32_t* block_of_kf) {
+  for (int k = 0; k < num_kf; ++k) block_of_kf[k] = -1;
+  for (int e = 0; e < num_edge; ++e)
+    if (edge_i[e] < 0 || edge_i[e] >= num_kf || edge_j[e] < 0 || edge_j[e] >= num_kf) return 0;
+  PgoHostPlan hp;
+  if (!pgo_plan_analyse(num_kf, num_edge, edge_i, edge_j, hp)) return 0;
+  for (size_t a = 0; a < hp.block_kf.size(); ++a)
+    for (int kf : hp.block_kf[a]) block_of_kf[kf] = (int32_t)a;
+  return (int32_t)hp.block_kf.size();
+}
+
 extern "C" int covgpu_create(const covgpu_options* opt, covgpu_context** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {

@@ -216,6 +216,13 @@ int covgpu_solve_reduced(covgpu_context* ctx, int32_t n, const double* S, const 
 
 int32_t covgpu_reduced_dim(const covgpu_options* opt, const covgpu_problem* p);
 
+/* Host-only: the block partition the pose-graph solve uses (PoseGraphOptimization's linear solver,
+ * optimization_be.cpp:1024-1031 -> block-arrow elimination). block_of_kf[k] = block index (>= 0) of
+ * keyframe k, or -1 if it belongs to the border (loop-closure keyframes and separators). Returns the number of
+ * blocks, or 0 if the graph is solved densely (too small, no split, or a border that is a large part of the
+ * system; block_of_kf is then all -1). No edge joins two different blocks. Needs no device. */
+int32_t covgpu_pgo_partition(int32_t num_kf, int32_t num_edge, const int32_t* edge_i, const int32_t* edge_j, int32_t* block_of_kf);
+
 /* ---------------------------------------------------------------- measurement hooks (bench.py)
  * With profiling on, covgpu_solve_resident brackets the linearise+Schur pass, the whole factor+solve and
  * every trailing-update (SYRK) launch with HIP events on the context's own stream.

@@ -106,6 +106,35 @@ def test_flatten_pgo_edges(tiny_map):
     assert np.allclose(p4.edge_meas[len(m.loops):], p.edge_meas[len(m.loops):])
 
 
+def test_pgo_partition_invariants():
+    """The block partition behind the pose-graph solve (host-only part of k_pgo.hip): no edge joins two different
+    blocks, the border is small, agents' trajectories are cut into short blocks, small graphs stay dense."""
+    cfg = synth.config_named("mh123"); cfg.max_kf_per_agent = 220
+    m = synth.make_map(cfg)
+    p, _ = mapdata.flatten_pgo(m, {}, mapdata.PgoParams())
+    blk, n = backend.pgo_partition(p.K, p.edge_i, p.edge_j)
+    assert n >= 3  # at least the three agents
+    bi, bj = blk[p.edge_i], blk[p.edge_j]
+    inner = (bi >= 0) & (bj >= 0)
+    assert np.all(bi[inner] == bj[inner])                       # blocks are independent given the border
+    assert (blk < 0).sum() * 3 <= p.K                           # border stays a small part of the system
+    sizes = np.bincount(blk[blk >= 0], minlength=n)
+    assert sizes.min() > 0 and sizes.max() <= 0.7 * (blk >= 0).sum()
+    loops = {lc.kf1 for lc in m.loops} | {lc.kf2 for lc in m.loops}
+    remap = -np.ones(m.K, int); remap[np.nonzero(~m.kf_invalid)[0]] = np.arange(p.K)
+    assert all(blk[remap[k]] == -1 for k in loops if remap[k] >= 0)  # loop-closure keyframes are border
+    # a permutation of the keyframe numbering (the map hands them over agent-interleaved) changes nothing essential
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(p.K).astype(np.int32)
+    blk2, n2 = backend.pgo_partition(p.K, perm[p.edge_i], perm[p.edge_j])
+    assert n2 >= 3 and (blk2 < 0).sum() * 3 <= p.K
+    # too small for the arrow form: dense path
+    tiny = synth.make_map(synth.config_named("tiny"))
+    pt, _ = mapdata.flatten_pgo(tiny, {}, mapdata.PgoParams())
+    blk3, n3 = backend.pgo_partition(pt.K, pt.edge_i, pt.edge_j)
+    assert n3 == 0 and np.all(blk3 == -1)
+
+
 def test_synthetic_map_statistics():
     m = synth.make_map(synth.config_named("small"))
     n = np.diff(m.lm_obs_ptr)

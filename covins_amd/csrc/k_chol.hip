@@ -8,17 +8,20 @@
 //   * tiles are 128 x 128; big panels are 256 wide (two tile columns). A rank-256 trailing update reads and
 //     writes every C tile once per 8.4 MFLOP (16 flop/B on the C stream) — a rank-128 update (8 flop/B)
 //     would be HBM-bound below ~60 % of the FP64 MFMA peak.
-//   * panel factorisation: potrf_inv (one workgroup: LDS Cholesky of the 128x128 diagonal block and its
-//     explicit inverse) -> TRSM as an MFMA GEMM against L11^-1 -> rank-128 update of the panel's second tile
+//   * panel factorisation: potrf_inv (one workgroup: register-resident Cholesky of the 128x128 diagonal block and
+//     its explicit inverse) -> TRSM as an MFMA GEMM against L11^-1 -> rank-128 update of the panel's second tile
 //     column -> potrf_inv -> TRSM.
 //   * trailing update k_gemm_abt<SYRK_TRI>: C -= A_i A_j^T, one 128x128 tile per workgroup, 4 waves x (4x4)
 //     v_mfma_f64_16x16x4_f64 tiles, accumulators initialised FROM the C tile (so the epilogue is store-only),
-//     K staged through LDS in chunks of 32 with register prefetch. Workgroup ids are decoded XCD-aware: the 64
+//     K staged through LDS in chunks of 16 with register prefetch. Workgroup ids are decoded XCD-aware: the 64
 //     workgroups resident on one XCD at a time form one 8x8 supertile, so its 16 panel tiles stay in that
 //     XCD's 4 MiB L2 instead of being re-fetched by every tile (block b runs on XCD b % 8).
-//   * look-ahead on two HIP streams: the next panel's two tile columns are updated first and its panel
-//     factorisation (a serial chain of small kernels) runs on the main stream while the bulk of the trailing
-//     update occupies the chip from the auxiliary stream.
+//   * look-ahead on four HIP streams (dense_cholesky_solve_raw): the serial chain potrf -> X(t0+1,t0) -> D1 update
+//     -> potrf -> next diagonal update alone on the main stream, the next panel's tile rows, all rows below, and the
+//     bulk of the trailing update on three more; the chain's few-tile GEMMs run as quarter tiles.
+//   * entry points beyond the plain solve: partial factorisation (tstop: the trailing block keeps its Schur
+//     complement), a batch dimension (independent matrices of one shape in the same launches) and a backward solve
+//     with given trailing unknowns — the block-arrow pose-graph solve (k_pgo.hip) is built from these.
 // Forward substitution rides along with the factorisation (potrf forms y_p, every TRSM takes its tile's product
 // with y_p out of the right-hand side); the backward solve reuses the stored L_pp^-1 blocks, one launch per panel.
 #include <cstdlib>

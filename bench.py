@@ -106,11 +106,13 @@ def main():
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read inside this process, so the
         # number comes from the committed counter pass of the same command (profiles/r01_pmc_traffic.json)
         traffic = None
+        mfma_busy = None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if pj.get("workload") == args.workload:
                 k = pj["kernels"]["k_gemm_abt<SYRK_TRI>"]  # = k_gemm_abt<0, 128, 128>
                 traffic = k["fetch_bytes_x2"] + k["write_bytes"]
+                mfma_busy = k.get("mfma_busy_frac")
         except Exception:
             traffic = None
         sol = ctx.download()
@@ -142,6 +144,7 @@ def main():
             "roofline": {"kernel": "k_gemm_abt<SYRK_TRI> (rank-256 trailing update of the dense FP64 Cholesky, v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+                         "mfma_busy_frac_pmc": mfma_busy,  # SQ_VALU_MFMA_BUSY_CYCLES share of SIMD-cycles (profiles/r01z_pmc_mfma.csv)
                          "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes in profiles/r01z_pmc_hbm_traffic.csv)",
                          "launches": prof["n_syrk"], "avg_launch_ms": prof["syrk_ms"] / max(prof["n_syrk"], 1),
                          "dense_stage_order": 6 * prob.K,

@@ -127,7 +127,7 @@ class Context:
         out = np.zeros(8)
         lib().covgpu_get_profile(self._h, dptr(out))
         return dict(build_ms=out[0], n_build=int(out[1]), factor_ms=out[2], n_factor=int(out[3]), syrk_ms=out[4],
-                    n_syrk=int(out[5]), syrk_flops=out[6])
+                    n_syrk=int(out[5]), syrk_flops=out[6], offdiag_blocks=int(out[7]))
 
     # ---- per-kernel entry points (tests)
     def residual_norms(self, prob, opt):

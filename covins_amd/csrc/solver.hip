@@ -32,7 +32,7 @@ extern "C" const char* covgpu_last_error(void) { return g_err.c_str(); }
   } while (0)
 
 struct covgpu_profile_t {
-  double t_build_ms = 0, t_factor_ms = 0, t_syrk_ms = 0, syrk_flops = 0, t_solve_tri_ms = 0;
+  double t_build_ms = 0, t_factor_ms = 0, t_syrk_ms = 0, syrk_flops = 0;
   long n_build = 0, n_factor = 0, n_syrk = 0;
 };
 
@@ -126,7 +126,8 @@ extern "C" void covgpu_set_profiling(covgpu_context* c, int on) {
 // out[0..7] = build ms, n_build, factor ms, n_factor, syrk ms, n_syrk launches, syrk flops, tri-solve ms
 extern "C" void covgpu_get_profile(covgpu_context* c, double* out) {
   out[0] = c->prof.t_build_ms; out[1] = (double)c->prof.n_build; out[2] = c->prof.t_factor_ms; out[3] = (double)c->prof.n_factor;
-  out[4] = c->chol.syrk_ms; out[5] = (double)c->chol.n_syrk; out[6] = c->chol.syrk_flops; out[7] = c->prof.t_solve_tri_ms;
+  out[4] = c->chol.syrk_ms; out[5] = (double)c->chol.n_syrk; out[6] = c->chol.syrk_flops;
+  out[7] = (double)(c->have ? c->P.npairs + c->P.nepairs : 0);  // off-diagonal 6x6 pose-pose blocks of the reduced system (nnzS - K)
 }
 
 template <typename T>

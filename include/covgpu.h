@@ -226,7 +226,8 @@ int32_t covgpu_pgo_partition(int32_t num_kf, int32_t num_edge, const int32_t* ed
 /* ---------------------------------------------------------------- measurement hooks (bench.py)
  * With profiling on, covgpu_solve_resident brackets the linearise+Schur pass, the whole factor+solve and
  * every trailing-update (SYRK) launch with HIP events on the context's own stream.
- * out[8] = { build ms, #builds, factor+solve ms, #factorisations, SYRK ms, #SYRK launches, SYRK flops, 0 } */
+ * out[8] = { build ms, #builds, factor+solve ms, #factorisations, SYRK ms, #SYRK launches, SYRK flops,
+ *           #off-diagonal 6x6 pose-pose blocks of the reduced system (covisible + loop-edge keyframe pairs) } */
 void covgpu_set_profiling(covgpu_context* ctx, int on);
 void covgpu_get_profile(covgpu_context* ctx, double* out8);
 

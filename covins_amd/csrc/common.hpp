@@ -149,8 +149,9 @@ struct CholAux {
   hipStream_t aux = nullptr, mid = nullptr, head = nullptr;
   hipEvent_t ev_sb = nullptr, ev_cf = nullptr, ev_g = nullptr;  // speed-bias rows ready | chain factor done | Gramians done (early, on aux)
   bool cf_pending = false;
-  std::vector<hipEvent_t> ev, prof_ev;
+  std::vector<hipEvent_t> ev, prof_ev, panel_ev;  // panel_ev: start of every big panel on the main stream (COVGPU_TRACE_PANELS=1)
   std::vector<double> prof_flops;
+  int panel_n = 0;
   bool profile = false;
   double syrk_ms = 0, syrk_flops = 0;
   long n_syrk = 0;

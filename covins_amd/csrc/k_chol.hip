@@ -24,6 +24,7 @@
 //     with given trailing unknowns — the block-arrow pose-graph solve (k_pgo.hip) is built from these.
 // Forward substitution rides along with the factorisation (potrf forms y_p, every TRSM takes its tile's product
 // with y_p out of the right-hand side); the backward solve reuses the stored L_pp^-1 blocks, one launch per panel.
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 
@@ -495,6 +496,8 @@ void CholAux::destroy() {
   if (head) { (void)hipStreamDestroy(head); head = nullptr; }
   for (auto e : ev) (void)hipEventDestroy(e);
   for (auto e : prof_ev) (void)hipEventDestroy(e);
+  for (auto e : panel_ev) (void)hipEventDestroy(e);
+  panel_ev.clear();
   ev.clear(); prof_ev.clear();
   if (ev_sb) { (void)hipEventDestroy(ev_sb); ev_sb = nullptr; }
   if (ev_cf) { (void)hipEventDestroy(ev_cf); ev_cf = nullptr; }
@@ -504,6 +507,15 @@ void CholAux::destroy() {
 }
 // after the streams have been synchronised: accumulate the bracketed trailing-update launches
 void CholAux::collect() {
+  if (panel_n > 1) {  // un-profiled progression of the last factorisation: when did each big panel's chain start?
+    fprintf(stderr, "covgpu panel starts [us]:");
+    for (int i = 1; i < panel_n; ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, panel_ev[0], panel_ev[i]) == hipSuccess) fprintf(stderr, " %.0f", ms * 1e3);
+    }
+    fprintf(stderr, "\n");
+    panel_n = 0;
+  }
   if (!profile) return;
   for (size_t i = 0; i < prof_flops.size(); ++i) {
     float ms = 0;
@@ -568,6 +580,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   //   R  rows r = everything below (t0+4 ..): full-tile kernels, needed one panel later;
   //   B  the bulk rank-256 trailing update (triangle from tile t0+4).
   hipStream_t M = st, H = ax.head, R = ax.mid, B = ax.aux;
+  static const bool trace_panels = getenv("COVGPU_TRACE_PANELS") != nullptr;  // dev aid: DESIGN.md §4.5, un-profiled timeline
   auto wait = [](hipStream_t s2, hipEvent_t e) { (void)hipStreamWaitEvent(s2, e, 0); };
   // Partial factorisation (tstop >= 0, even): eliminate tile columns [0, tstop) only; the trailing block then holds
   // its Schur complement (and, with the forward substitution riding along, b's trailing part the reduced right-hand
@@ -599,6 +612,11 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       break;
     }
     // ---- M: critical chain
+    if (trace_panels && nbt == 1) {
+      while ((int)ax.panel_ev.size() <= P + 1) { hipEvent_t e; (void)hipEventCreate(&e); ax.panel_ev.push_back(e); }
+      (void)hipEventRecord(ax.panel_ev[P], M);
+      ax.panel_n = P + 1;
+    }
     potrf(t0);
     (void)hipEventRecord(e1[P], M);
     if (w == 2) {

@@ -17,13 +17,14 @@ __global__ __launch_bounds__(256) void k_spin(long long ticks) {
   if (TOPV == 79) asm volatile("v_mov_b32 v79, 0" ::: "v79");
   if (TOPV == 71) asm volatile("v_mov_b32 v71, 0" ::: "v71");
   if (TOPV == 63) asm volatile("v_mov_b32 v63, 0" ::: "v63");
+  if (TOPV == 191) asm volatile("v_mov_b32 v191, 0" ::: "v191");
   sm[threadIdx.x] = 1.0;
   const long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) {}
 }
 
 template <int BV, int SV>
-static void run(const char* label, bool with_bulk) {
+static void run(const char* label, bool with_bulk, int small_lds_kb = 17, int small_wgs = 4) {
   int lo, hi;
   hipDeviceGetStreamPriorityRange(&lo, &hi);
   hipStream_t B, M;
@@ -37,7 +38,7 @@ static void run(const char* label, bool with_bulk) {
     if (with_bulk) hipLaunchKernelGGL(k_spin<BV>, dim3(512 * 30), dim3(256), 35 * 1024, B, 5000LL);   // 30 rounds x 50 us
     hipLaunchKernelGGL(k_spin<SV>, dim3(1), dim3(64), 0, M, 15000LL);  // let the bulk fill the chip first (150 us)
     hipEventRecord(e0, M);
-    for (int i = 0; i < nsmall; ++i) hipLaunchKernelGGL(k_spin<SV>, dim3(4), dim3(256), 17 * 1024, M, 500LL);  // 5 us each
+    for (int i = 0; i < nsmall; ++i) hipLaunchKernelGGL(k_spin<SV>, dim3(small_wgs), dim3(256), small_lds_kb * 1024, M, 500LL);  // 5 us each
     hipEventRecord(e1, M);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -56,5 +57,10 @@ int main() {
   run<215, 63>("bulk 216 VGPR (432), small 64 (496)", true);
   run<215, 71>("bulk 216 VGPR (432), small 72 (504)", true);
   run<215, 79>("bulk 216 VGPR (432), small 80 (512)", true);
+  // a potrf-like single workgroup (192 VGPRs): beside ONE resident bulk workgroup it fits if its LDS is <= 125 KB
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_spin<191>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+  run<247, 191>("bulk 248, one WG 192 VGPR + 120 KB LDS (needs 1 slot)", true, 120, 1);
+  run<247, 191>("bulk 248, one WG 192 VGPR + 131 KB LDS (needs empty CU)", true, 131, 1);
+  run<247, 191>("idle chip, one WG 192 VGPR + 131 KB LDS", false, 131, 1);
   return 0;
 }

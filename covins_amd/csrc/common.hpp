@@ -79,7 +79,7 @@ struct DevProblem {
   double* bred;    // [n] right-hand side in IR layout (D per keyframe); solution is written to gn
   double *Ad, *Ae;          // [K][81] speed-bias diagonal / sub-diagonal (pos, pos-1) blocks, by position
   double *Bp, *Bs, *Bn;     // [K][54] speed-bias(pos) x pose(pos-1 | pos | pos+1) blocks (9x6)
-  double *Ld, *Ldinv, *Lsub;  // [K][81] block-bidiagonal Cholesky factor of the speed-bias part
+  double *Ldinv, *Lsub;       // [K][81] block-bidiagonal Cholesky factor of the speed-bias part: L_kk^-1 and L_{k,k-1}
   double *Mblk, *GI;          // [K][81] propagator M_pos = -Ldinv_pos Lsub_pos | I + Gramian of everything below pos (k_struct.hip)
   double* Y;       // [nyrows][npad] Y = L_A^-1 B: speed-bias rows (chain order) x pose columns, zero outside the chain trapezoids
   int nyrows;      // 9K rounded up to a multiple of 16

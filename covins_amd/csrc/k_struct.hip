@@ -159,8 +159,8 @@ __global__ __launch_bounds__(64) void k_sb_chain_factor(DevProblem P) {
     }
     __syncthreads();
     // publish the factor blocks, z, and the next sub-diagonal block L_{pos+1,pos} = Ae_{pos+1} L_kk^-T
-    P.Ld[(size_t)81 * pos + e0] = sM[e0]; P.Ldinv[(size_t)81 * pos + e0] = sX[e0]; P.Lsub[(size_t)81 * pos + e0] = sSub[e0];
-    if (has1) { P.Ld[(size_t)81 * pos + e1] = sM[e1]; P.Ldinv[(size_t)81 * pos + e1] = sX[e1]; P.Lsub[(size_t)81 * pos + e1] = sSub[e1]; }
+    P.Ldinv[(size_t)81 * pos + e0] = sX[e0]; P.Lsub[(size_t)81 * pos + e0] = sSub[e0];  // (L_kk itself is needed only through its inverse)
+    if (has1) { P.Ldinv[(size_t)81 * pos + e1] = sX[e1]; P.Lsub[(size_t)81 * pos + e1] = sSub[e1]; }
     double znew = 0.0;
     if (lane < 9) {
       for (int k = 0; k <= lane; ++k) znew += sX[9 * lane + k] * sv[k];

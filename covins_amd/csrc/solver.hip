@@ -315,7 +315,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   const size_t Kv = vi ? K : 0;
   RC(dev_alloc(c, &P.Ad, 81 * Kv)); RC(dev_alloc(c, &P.Ae, 81 * Kv));
   RC(dev_alloc(c, &P.Bp, 54 * Kv)); RC(dev_alloc(c, &P.Bs, 54 * Kv)); RC(dev_alloc(c, &P.Bn, 54 * Kv));
-  RC(dev_alloc(c, &P.Ld, 81 * Kv)); RC(dev_alloc(c, &P.Ldinv, 81 * Kv)); RC(dev_alloc(c, &P.Lsub, 81 * Kv));
+  RC(dev_alloc(c, &P.Ldinv, 81 * Kv)); RC(dev_alloc(c, &P.Lsub, 81 * Kv));
   RC(dev_alloc(c, &P.Mblk, 81 * Kv)); RC(dev_alloc(c, &P.GI, 81 * Kv));
   RC(dev_alloc(c, &P.zs, 9 * Kv)); RC(dev_alloc(c, &P.xs, 9 * Kv));
   RC(dev_alloc(c, &P.Y, vi ? (size_t)P.nyrows * P.npad : 0));

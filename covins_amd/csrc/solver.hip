@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -244,22 +245,41 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
     for (int o = 0; o < P.O; ++o) kptr[p->obs_kf[o] + 1]++;
     for (int k = 0; k < P.K; ++k) kptr[k + 1] += kptr[k];
     { std::vector<int> cur(kptr.begin(), kptr.end() - 1); for (int o = 0; o < P.O; ++o) kidx[cur[p->obs_kf[o]]++] = o; }
-    // bucket pairs by row position i, then sort each bucket by column position j
+    // bucket pairs by row position i (landmark order inside a bucket), then sort each bucket by column position j.
+    // Host threads: landmark ranges for the two passes over sum n_l^2 entries, rows for the sorts. Every thread owns
+    // a fixed sub-range of each bucket, so the result does not depend on the thread count (the summation order of
+    // k_pair_blocks is part of the bit-reproducibility contract).
+    const int nth = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+    auto parallel = [&](auto&& fn) {  // fn(thread index)
+      std::vector<std::thread> th;
+      for (int t = 1; t < nth; ++t) th.emplace_back(fn, t);
+      fn(0);
+      for (auto& x : th) x.join();
+    };
+    auto lm_lo = [&](int t) { return (int)((long long)P.L * t / nth); };
+    std::vector<std::vector<int>> tcnt(nth, std::vector<int>(P.K, 0));
+    parallel([&](int t) {
+      std::vector<int>& cnt = tcnt[t];
+      for (int l = lm_lo(t); l < lm_lo(t + 1); ++l)
+        for (int a = p->lm_obs_ptr[l]; a < p->lm_obs_ptr[l + 1]; ++a) {
+          if (p->kf_fixed[p->obs_kf[a]]) continue;
+          const int pa = perm[p->obs_kf[a]];
+          for (int b = p->lm_obs_ptr[l]; b < p->lm_obs_ptr[l + 1]; ++b)
+            if (!p->kf_fixed[p->obs_kf[b]] && perm[p->obs_kf[b]] < pa) cnt[pa]++;
+        }
+    });
     std::vector<int> rowcnt(P.K + 1, 0);
-    for (int l = 0; l < P.L; ++l)
-      for (int a = p->lm_obs_ptr[l]; a < p->lm_obs_ptr[l + 1]; ++a) {
-        if (p->kf_fixed[p->obs_kf[a]]) continue;
-        const int pa = perm[p->obs_kf[a]];
-        for (int b = p->lm_obs_ptr[l]; b < p->lm_obs_ptr[l + 1]; ++b)
-          if (!p->kf_fixed[p->obs_kf[b]] && perm[p->obs_kf[b]] < pa) rowcnt[pa + 1]++;
-      }
-    for (int k = 0; k < P.K; ++k) rowcnt[k + 1] += rowcnt[k];
+    for (int k = 0; k < P.K; ++k) {  // bucket layout: row k = [thread 0's entries | thread 1's | ...]
+      int acc = rowcnt[k];
+      for (int t = 0; t < nth; ++t) { const int c2 = tcnt[t][k]; tcnt[t][k] = acc; acc += c2; }
+      rowcnt[k + 1] = acc;
+    }
     const size_t nent = (size_t)rowcnt[P.K];
     struct Ent { int j, oa, ob; };
     std::vector<Ent> ent(nent);
-    {
-      std::vector<int> cur(rowcnt.begin(), rowcnt.end() - 1);
-      for (int l = 0; l < P.L; ++l)
+    parallel([&](int t) {
+      std::vector<int>& cur = tcnt[t];
+      for (int l = lm_lo(t); l < lm_lo(t + 1); ++l)
         for (int a = p->lm_obs_ptr[l]; a < p->lm_obs_ptr[l + 1]; ++a) {
           if (p->kf_fixed[p->obs_kf[a]]) continue;
           const int pa = perm[p->obs_kf[a]];
@@ -269,18 +289,30 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
             if (pb < pa) ent[cur[pa]++] = Ent{pb, a, b};
           }
         }
-    }
-    std::vector<int> pptr, pi, pj, oa(nent), ob(nent);
-    for (int i = 0; i < P.K; ++i) {
-      auto b0 = ent.begin() + rowcnt[i], b1 = ent.begin() + rowcnt[i + 1];
-      std::stable_sort(b0, b1, [](const Ent& x, const Ent& y) { return x.j < y.j; });  // stable: landmark order kept -> fixed summation order
-      for (auto it = b0; it != b1; ++it) {
-        const size_t e = (size_t)(it - ent.begin());
-        if (it == b0 || it->j != (it - 1)->j) { pptr.push_back((int)e); pi.push_back(i); pj.push_back(it->j); }
-        oa[e] = it->oa; ob[e] = it->ob;
+    });
+    std::vector<int> npair_row(P.K + 1, 0);
+    parallel([&](int t) {
+      for (int i = t; i < P.K; i += nth) {
+        auto b0 = ent.begin() + rowcnt[i], b1 = ent.begin() + rowcnt[i + 1];
+        std::stable_sort(b0, b1, [](const Ent& x, const Ent& y) { return x.j < y.j; });  // stable: landmark order kept -> fixed summation order
+        int np = 0;
+        for (auto it = b0; it != b1; ++it) if (it == b0 || it->j != (it - 1)->j) ++np;
+        npair_row[i + 1] = np;
       }
-    }
-    pptr.push_back((int)nent);
+    });
+    for (int i = 0; i < P.K; ++i) npair_row[i + 1] += npair_row[i];
+    const int npairs = npair_row[P.K];
+    std::vector<int> pptr(npairs + 1), pi(npairs), pj(npairs), oa(nent), ob(nent);
+    parallel([&](int t) {
+      for (int i = t; i < P.K; i += nth) {
+        int q = npair_row[i];
+        for (int e = rowcnt[i]; e < rowcnt[i + 1]; ++e) {
+          if (e == rowcnt[i] || ent[e].j != ent[e - 1].j) { pptr[q] = e; pi[q] = i; pj[q] = ent[e].j; ++q; }
+          oa[e] = ent[e].oa; ob[e] = ent[e].ob;
+        }
+      }
+    });
+    pptr[npairs] = (int)nent;
     P.npairs = (int)pi.size();
     RC(dev_upload(c, &P.kf_obs_ptr, kptr.data(), kptr.size())); RC(dev_upload(c, &P.kf_obs_idx, kidx.data(), kidx.size()));
     RC(dev_upload(c, &P.pair_ptr, pptr.data(), pptr.size()));

@@ -13,6 +13,7 @@
 // C - sum_a X_b X_b^T (order 6 x #border keyframes) is summed in a fixed order, solved densely, and every block
 // finishes with its own backward substitution. Same arithmetic as the dense solve up to the elimination order.
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "common.hpp"
@@ -20,8 +21,6 @@
 namespace covgpu {
 
 constexpr int kPgoMaxBlocks = 32;   // blocks of one batched factorisation
-constexpr int kPgoSegment = 100;    // keyframes per block aimed at when a long component is cut (swept 40..250 on the
-                                    // 5-agent map: 84, 95, 65 (100), 73, 83 ms per call)
 
 // host: pick the border and cut the rest into independent blocks, from the edge list alone (the map hands keyframes
 // over agent-interleaved, typedefs_base.hpp:178, so index distance says nothing). An edge whose endpoints have no
@@ -36,7 +35,7 @@ bool pgo_plan_analyse(int K, int E, const int* ei, const int* ej, PgoHostPlan& o
   std::vector<std::vector<int>> adj(K);
   for (int e = 0; e < E; ++e) { adj[ei[e]].push_back(ej[e]); adj[ej[e]].push_back(ei[e]); }
   for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
-  std::vector<char> border(K, 0);
+  std::vector<char> bridge_border(K, 0);
   for (int e = 0; e < E; ++e) {
     const std::vector<int>&A = adj[ei[e]], &B = adj[ej[e]];
     bool common = false;
@@ -44,35 +43,37 @@ bool pgo_plan_analyse(int K, int E, const int* ei, const int* ej, PgoHostPlan& o
       if (A[x] == B[y]) { common = true; break; }
       if (A[x] < B[y]) ++x; else ++y;
     }
-    if (!common && (A.size() > 1 || B.size() > 1)) { border[ei[e]] = 1; border[ej[e]] = 1; }
+    if (!common && (A.size() > 1 || B.size() > 1)) { bridge_border[ei[e]] = 1; bridge_border[ej[e]] = 1; }
   }
-  // components of the graph without the border (union-find)
-  std::vector<int> parent(K);
+  // One candidate plan per segment length: long components (an agent's whole trajectory) are cut further — in a
+  // breadth-first level structure edges join equal or adjacent levels only, so removing one whole level separates
+  // what came before from what comes after. Levels of an odometry chain are ~5 keyframes wide; one level per ~segment
+  // keyframes goes to the border. The serial panel chain of the batched factorisation is as long as the LARGEST
+  // block, the border system grows with every cut, and all buffers are re-gathered every iteration; the cheapest
+  // candidate under that model (fitted on the 5-agent map: 0.35 ms per 256-wide panel step, 2.5 ms per GB of arrow
+  // buffers; segment lengths 40..250 measured 84, 95, 65, 73, 83 ms per call) is taken.
+  std::vector<int> parent(K), level(K, -1), queue;
   auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
-  std::vector<std::vector<int>> comps;
-  int n_int = 0;
-  auto components = [&]() {
-    for (int k = 0; k < K; ++k) parent[k] = k;
-    for (int e = 0; e < E; ++e)
-      if (!border[ei[e]] && !border[ej[e]]) { const int a = find(ei[e]), b = find(ej[e]); if (a != b) parent[std::max(a, b)] = std::min(a, b); }
-    comps.clear();
-    std::vector<int> comp_of(K, -1);
-    n_int = 0;
-    for (int k = 0; k < K; ++k) {
-      if (border[k]) continue;
-      const int r = find(k);
-      if (comp_of[r] < 0) { comp_of[r] = (int)comps.size(); comps.emplace_back(); }
-      comps[comp_of[r]].push_back(k);
-      ++n_int;
-    }
-  };
-  components();
-  // Long components (an agent's whole trajectory) are cut further: in a breadth-first level structure edges join equal
-  // or adjacent levels only, so removing one whole level separates what came before from what comes after. Levels of
-  // an odometry chain are ~5 keyframes wide; one level per ~kPgoSegment keyframes goes to the border. The serial panel
-  // chain of the batched factorisation is as long as the LARGEST block, so many short blocks beat a few long ones.
-  {
-    std::vector<int> level(K, -1), queue;
+  auto build = [&](int segment, PgoHostPlan& plan, double& cost) -> bool {
+    std::vector<char> border = bridge_border;
+    std::vector<std::vector<int>> comps;
+    int n_int = 0;
+    auto components = [&]() {
+      for (int k = 0; k < K; ++k) parent[k] = k;
+      for (int e = 0; e < E; ++e)
+        if (!border[ei[e]] && !border[ej[e]]) { const int a = find(ei[e]), b = find(ej[e]); if (a != b) parent[std::max(a, b)] = std::min(a, b); }
+      comps.clear();
+      std::vector<int> comp_of(K, -1);
+      n_int = 0;
+      for (int k = 0; k < K; ++k) {
+        if (border[k]) continue;
+        const int r = find(k);
+        if (comp_of[r] < 0) { comp_of[r] = (int)comps.size(); comps.emplace_back(); }
+        comps[comp_of[r]].push_back(k);
+        ++n_int;
+      }
+    };
+    components();
     auto bfs = [&](int start) {  // levels inside start's component (border excluded); returns the last node reached
       queue.assign(1, start);
       level[start] = 0;
@@ -84,16 +85,16 @@ bool pgo_plan_analyse(int K, int E, const int* ei, const int* ej, PgoHostPlan& o
     };
     const std::vector<std::vector<int>> first = comps;
     for (const auto& cmp : first) {
-      if ((int)cmp.size() < 2 * kPgoSegment) continue;
+      if ((int)cmp.size() < 2 * segment) continue;
       const int far = bfs(cmp[0]);
       for (int v : queue) level[v] = -1;
       bfs(far);  // second sweep from a pseudo-peripheral node
-      std::vector<int> order = queue;
+      const std::vector<int> order = queue;
       int since = 0, cut_level = -1, prev_level = -1, remaining = (int)order.size();
       for (int v : order) {  // breadth-first order: levels arrive one after the other
         if (level[v] != prev_level) {  // first keyframe of a new level: the only place a cut may start
           prev_level = level[v];
-          if (since >= kPgoSegment && remaining > kPgoSegment / 2) { cut_level = level[v]; since = 0; }
+          if (since >= segment && remaining > segment / 2) { cut_level = level[v]; since = 0; }
         }
         --remaining;
         if (level[v] == cut_level) border[v] = 1;
@@ -102,23 +103,36 @@ bool pgo_plan_analyse(int K, int E, const int* ei, const int* ej, PgoHostPlan& o
       for (int v : order) level[v] = -1;
     }
     components();
+    const int n_border = K - n_int;
+    if (comps.size() < 2 || n_border * 3 > K) return false;
+    // largest components first; the rest is packed onto the currently smallest block
+    std::sort(comps.begin(), comps.end(), [](const std::vector<int>& x, const std::vector<int>& y) { return x.size() != y.size() ? x.size() > y.size() : x[0] < y[0]; });
+    if ((int)comps[0].size() * 10 > n_int * 7) return false;  // one component dominates: its chain of panels is the whole cost anyway
+    std::vector<std::vector<int>> blocks;
+    for (auto& cmp : comps) {
+      if ((int)blocks.size() < kPgoMaxBlocks) { blocks.push_back(cmp); continue; }
+      size_t best = 0;
+      for (size_t q = 1; q < blocks.size(); ++q) if (blocks[q].size() < blocks[best].size()) best = q;
+      blocks[best].insert(blocks[best].end(), cmp.begin(), cmp.end());
+    }
+    size_t big = 0;
+    for (auto& bl : blocks) { std::sort(bl.begin(), bl.end()); big = std::max(big, bl.size()); }
+    plan = PgoHostPlan();
+    for (int k = 0; k < K; ++k) if (border[k]) plan.border_kf.push_back(k);
+    const double nI = std::ceil(6.0 * big / (2 * kTile)) * (2 * kTile), nb = std::max(1.0, std::ceil(6.0 * n_border / kTile)) * kTile;
+    cost = 0.35 * (nI + nb) / (2 * kTile) + 2.5 * (double)blocks.size() * (nI + nb) * (nI + nb) * 8e-9;
+    plan.block_kf = std::move(blocks);
+    return true;
+  };
+  bool have = false;
+  double best_cost = 0.0;
+  for (int segment : {60, 80, 100, 130, 170, 220, 300, 1 << 30}) {  // the last one: whole components, no cuts
+    PgoHostPlan cand;
+    double cost = 0.0;
+    if (!build(segment, cand, cost)) continue;
+    if (!have || cost < best_cost) { out = std::move(cand); best_cost = cost; have = true; }
   }
-  const int n_border = K - n_int;
-  if (comps.size() < 2 || n_border * 3 > K) return false;
-  // largest components first; the rest is packed onto the currently smallest block
-  std::sort(comps.begin(), comps.end(), [](const std::vector<int>& x, const std::vector<int>& y) { return x.size() != y.size() ? x.size() > y.size() : x[0] < y[0]; });
-  if ((int)comps[0].size() * 10 > n_int * 7) return false;  // one component dominates: its chain of panels is the whole cost anyway
-  std::vector<std::vector<int>> blocks;
-  for (auto& cmp : comps) {
-    if ((int)blocks.size() < kPgoMaxBlocks) { blocks.push_back(cmp); continue; }
-    size_t best = 0;
-    for (size_t q = 1; q < blocks.size(); ++q) if (blocks[q].size() < blocks[best].size()) best = q;
-    blocks[best].insert(blocks[best].end(), cmp.begin(), cmp.end());
-  }
-  for (auto& bl : blocks) std::sort(bl.begin(), bl.end());
-  for (int k = 0; k < K; ++k) if (border[k]) out.border_kf.push_back(k);
-  out.block_kf = std::move(blocks);
-  return true;
+  return have;
 }
 
 // arrow buffers, one per block (blockIdx.z), all of the same padded shape: M[i][j] = H[idx[i]][idx[j]] (H symmetric,

@@ -41,7 +41,7 @@ class ProblemStruct(C.Structure):
         ("kf_pose", _dp), ("kf_speed_bias", _dp), ("kf_fixed", _bp), ("kf_cam", _ip),
         ("cam_extr", _dp), ("cam_intr", _dp), ("cam_dist", _dp), ("cam_dist_type", _ip),
         ("lm_pos", _dp), ("lm_obs_ptr", _ip), ("obs_kf", _ip), ("obs_uv", _dp), ("obs_sigma", _dp),
-        ("imu_kf_i", _ip), ("imu_kf_j", _ip), ("imu_sample_ptr", _ip), ("imu_samples", _dp), ("imu_first", _dp),
+        ("imu_kf_i", _ip), ("imu_kf_j", _ip), ("imu_sample_ptr", _ip), ("imu_samples", _dp), ("imu_first", _dp), ("imu_noise", _dp),
         ("edge_i", _ip), ("edge_j", _ip), ("edge_meas", _dp), ("edge_sqrt_info", _dp), ("edge_loss_a", _dp),
     ]
 
@@ -86,6 +86,7 @@ class FlatProblem:
     imu_sample_ptr: np.ndarray = field(default_factory=lambda: np.zeros(1, np.int32))
     imu_samples: np.ndarray = field(default_factory=lambda: np.zeros((0, 7)))
     imu_first: np.ndarray = field(default_factory=lambda: np.zeros((0, 6)))
+    imu_noise: Optional[np.ndarray] = None   # [I,5] sigma_a sigma_g sigma_aw sigma_gw gravity per factor; None -> options
     edge_i: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     edge_j: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     edge_meas: np.ndarray = field(default_factory=lambda: np.zeros((0, 7)))
@@ -113,6 +114,8 @@ class FlatProblem:
         self.imu_sample_ptr = _i32(self.imu_sample_ptr, (-1,))
         self.imu_samples = _f64(self.imu_samples, (-1, 7))
         self.imu_first = _f64(self.imu_first, (-1, 6))
+        if self.imu_noise is not None:
+            self.imu_noise = _f64(self.imu_noise, (-1, 5))
         self.edge_i = _i32(self.edge_i, (-1,))
         self.edge_j = _i32(self.edge_j, (-1,))
         self.edge_meas = _f64(self.edge_meas, (-1, 7))
@@ -143,13 +146,14 @@ class FlatProblem:
         assert self.kf_cam.min() >= 0 and self.kf_cam.max() < self.A
         assert self.imu_kf_j.shape[0] == I and self.imu_sample_ptr.shape[0] == I + 1 and self.imu_first.shape[0] == I
         assert self.imu_sample_ptr[-1] == self.imu_samples.shape[0]
+        assert self.imu_noise is None or self.imu_noise.shape[0] == I
         if I: assert min(self.imu_kf_i.min(), self.imu_kf_j.min()) >= 0 and max(self.imu_kf_i.max(), self.imu_kf_j.max()) < K
         assert self.edge_j.shape[0] == E and self.edge_meas.shape[0] == E and self.edge_sqrt_info.shape[0] == E
         assert self.edge_loss_a.shape[0] == E
         if E: assert min(self.edge_i.min(), self.edge_j.min()) >= 0 and max(self.edge_i.max(), self.edge_j.max()) < K
 
     def copy(self) -> "FlatProblem":
-        return FlatProblem(**{k: np.array(v, copy=True) for k, v in self.__dict__.items()})
+        return FlatProblem(**{k: (None if v is None else np.array(v, copy=True)) for k, v in self.__dict__.items()})
 
     def as_struct(self) -> ProblemStruct:
         """C view of the arrays (no copies; keep `self` alive while the struct is in use)."""
@@ -160,7 +164,7 @@ class FlatProblem:
             if name.startswith("num_") or name == "reserved":
                 continue
             arr = getattr(self, name)
-            setattr(s, name, arr.ctypes.data_as(ctype))
+            setattr(s, name, None if arr is None else arr.ctypes.data_as(ctype))
         return s
 
 

@@ -57,6 +57,7 @@ struct DevProblem {
   // IMU factors
   int *imu_i, *imu_j, *imu_ptr;
   double *imu_samples, *imu_first;
+  double *imu_noise;  // [I][5] sigma_a sigma_g sigma_aw sigma_gw gravity per factor (keyframe_be.cpp:187-195)
   double *pre_delta;  // [I][11] dp dq dv dt
   double *pre_J;      // [I][225]
   double *pre_P;      // [I][225]
@@ -119,7 +120,7 @@ void launch_obs_cost(const DevProblem& P, const double* pose, const double* lm, 
 void launch_obs_linearize(const DevProblem& P, double* r, double* Jp, double* Jl, double* cost, hipStream_t st);
 void launch_obs_norms(const DevProblem& P, double* norms, hipStream_t st);
 
-void launch_preintegrate(const DevProblem& P, const covgpu_options& o, hipStream_t st);
+void launch_preintegrate(const DevProblem& P, hipStream_t st);
 void launch_imu_build(const DevProblem& P, hipStream_t st);
 void launch_imu_jvp(const DevProblem& P, const double* v_all, hipStream_t st);
 void launch_imu_cost(const DevProblem& P, const double* pose, const double* sb, hipStream_t st);

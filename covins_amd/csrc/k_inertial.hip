@@ -35,7 +35,7 @@ COV_DEV M3 get3(const double* M, int ldm, int r0, int c0) {
 constexpr int kImuWaves = 4;  // factors per workgroup
 
 // R2. Midpoint scheme; state order [P, R, V, BA, BG]; noise order [n_a0, n_g0, n_a1, n_g1, n_ba, n_bg].
-__global__ __launch_bounds__(64 * kImuWaves) void k_preintegrate(DevProblem P, double sa, double sg, double saw, double sgw) {
+__global__ __launch_bounds__(64 * kImuWaves) void k_preintegrate(DevProblem P) {
   __shared__ double sm[kImuWaves][225 * 4 + 270];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int f = blockIdx.x * kImuWaves + wave;
@@ -53,6 +53,8 @@ __global__ __launch_bounds__(64 * kImuWaves) void k_preintegrate(DevProblem P, d
   Q4 dq = Q4{0, 0, 0, 1};
   double dtsum = 0.0;
   V3 a0 = live ? ld3(P.imu_first + 6 * (size_t)f) : v3(0, 0, 0), w0 = live ? ld3(P.imu_first + 6 * (size_t)f + 3) : v3(0, 0, 0);
+  const double* nz = P.imu_noise + 5 * (size_t)(live ? f : 0);  // this factor's own calibration (keyframe_be.cpp:187-195)
+  const double sa = nz[0], sg = nz[1], saw = nz[2], sgw = nz[3];
   const double nd[6] = {sa * sa, sg * sg, sa * sa, sg * sg, saw * saw, sgw * sgw};
   const M3 I3 = ident3();
   // every wave of the workgroup runs the same number of barrier-carrying steps
@@ -214,7 +216,7 @@ COV_DEV void imu_unwhitened(const DevProblem& P, const double* __restrict__ pose
   const Q4 dqc = qnormalize(qmul(dq, Q4{hq.x, hq.y, hq.z, 1.0}));
   const V3 dvc = ld3(d + 7) + mul(Jv_ba, dba) + mul(Jv_bg, dbg);
   const V3 dpc = ld3(d) + mul(Jp_ba, dba) + mul(Jp_bg, dbg);
-  const double dt = d[10], g = P.gravity;
+  const double dt = d[10], g = P.imu_noise[5 * (size_t)f + 4];
   const M3 Ri = qrot(qi);
   const V3 tp = mulT(Ri, V3{pj.x - pi.x - vi.x * dt, pj.y - pi.y - vi.y * dt, pj.z - pi.z - vi.z * dt + 0.5 * g * dt * dt});
   const V3 tv = mulT(Ri, V3{vj.x - vi.x, vj.y - vi.y, vj.z - vi.z + g * dt});
@@ -419,9 +421,9 @@ __global__ __launch_bounds__(64 * kImuWaves) void k_imu_linearize(DevProblem P, 
 
 static inline dim3 imu_grid(int I) { return dim3((I + kImuWaves - 1) / kImuWaves); }
 
-void launch_preintegrate(const DevProblem& P, const covgpu_options& o, hipStream_t st) {
+void launch_preintegrate(const DevProblem& P, hipStream_t st) {
   if (P.I == 0) return;
-  hipLaunchKernelGGL(k_preintegrate, imu_grid(P.I), dim3(64 * kImuWaves), 0, st, P, o.sigma_a, o.sigma_g, o.sigma_aw, o.sigma_gw);
+  hipLaunchKernelGGL(k_preintegrate, imu_grid(P.I), dim3(64 * kImuWaves), 0, st, P);
 }
 void launch_imu_build(const DevProblem& P, hipStream_t st) {
   if (P.I == 0) return;

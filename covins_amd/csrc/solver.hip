@@ -328,6 +328,20 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_upload(c, &P.imu_ptr, P.I ? (const int*)p->imu_sample_ptr : ptr0.data(), (size_t)P.I + 1));
   RC(dev_upload(c, &P.imu_samples, p->imu_samples, (size_t)7 * P.S));
   RC(dev_upload(c, &P.imu_first, p->imu_first, (size_t)6 * P.I));
+  {  // per-factor calibration; the options' single set is the fallback for callers that have one IMU model only
+    std::vector<double> nz((size_t)5 * P.I);
+    for (int f = 0; f < P.I; ++f) {
+      double* r = &nz[(size_t)5 * f];
+      if (p->imu_noise) std::memcpy(r, p->imu_noise + (size_t)5 * f, 5 * sizeof(double));
+      else { r[0] = opt->sigma_a; r[1] = opt->sigma_g; r[2] = opt->sigma_aw; r[3] = opt->sigma_gw; r[4] = opt->gravity; }
+      if (!(r[0] > 0 && r[1] > 0 && r[2] > 0 && r[3] > 0) || !(r[4] >= 9.0)) {  // keyframe_base.cpp:51-55 rejects g < 9
+        g_err = "invalid problem: IMU noise must be positive and gravity >= 9 (factor " + std::to_string(f) + ")";
+        return COVGPU_ERR_INVALID_ARG;
+      }
+    }
+    RC(dev_upload(c, &P.imu_noise, nz.data(), nz.size()));
+    HIPCHK(hipStreamSynchronize(c->st));
+  }
   RC(dev_alloc(c, &P.pre_delta, (size_t)11 * P.I)); RC(dev_alloc(c, &P.pre_J, (size_t)225 * P.I));
   RC(dev_alloc(c, &P.pre_P, (size_t)225 * P.I)); RC(dev_alloc(c, &P.pre_W, (size_t)225 * P.I));
   RC(dev_alloc(c, &P.pre_bias, (size_t)6 * P.I));
@@ -515,7 +529,7 @@ static int solve_impl(covgpu_context* c, const covgpu_options* opt, covgpu_resul
   std::memset(res, 0, sizeof(*res));
   const auto t_begin = std::chrono::steady_clock::now();
   RC(reset_state(c));
-  launch_preintegrate(P, o, c->st);  // R2: repropagate at the initial bias estimate (opt_be.cpp:396)
+  launch_preintegrate(P, c->st);  // R2: repropagate at the initial bias estimate (opt_be.cpp:396)
 
   double radius = o.initial_radius, mu = 1e-8, lm_df = 2.0;
   bool reuse = false, need_build = true;
@@ -680,7 +694,7 @@ extern "C" int covgpu_linearize_reprojection(covgpu_context* c, const covgpu_opt
 extern "C" int covgpu_preintegrate(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double* delta, double* J, double* Pm) {
   covgpu_options o = *opt; o.visual_only = 0;
   RC(upload_impl(c, &o, p, false)); RC(reset_state(c));
-  launch_preintegrate(c->P, o, c->st);
+  launch_preintegrate(c->P, c->st);
   const size_t I = c->P.I;
   RC(fetch(c, delta, c->P.pre_delta, 11 * I)); RC(fetch(c, J, c->P.pre_J, 225 * I));
   return fetch(c, Pm, c->P.pre_P, 225 * I);
@@ -689,7 +703,7 @@ extern "C" int covgpu_preintegrate(covgpu_context* c, const covgpu_options* opt,
 extern "C" int covgpu_linearize_imu(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double* r, double* J) {
   covgpu_options o = *opt; o.visual_only = 0;
   RC(upload_impl(c, &o, p, false)); RC(reset_state(c));
-  launch_preintegrate(c->P, o, c->st);
+  launch_preintegrate(c->P, c->st);
   const size_t I = c->P.I;
   double *dr, *dJ;
   RC(dev_alloc(c, &dr, 15 * I)); RC(dev_alloc(c, &dJ, 450 * I));
@@ -710,7 +724,7 @@ extern "C" int covgpu_linearize_between(covgpu_context* c, const covgpu_options*
 
 static int schur_impl(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, bool pgo, double mu, double* S, double* b, double* cost) {
   RC(upload_impl(c, opt, p, pgo)); RC(reset_state(c));
-  launch_preintegrate(c->P, *opt, c->st);
+  launch_preintegrate(c->P, c->st);
   enqueue_build(c, mu);
   if (c->chol.cf_pending) { HIPCHK(hipStreamWaitEvent(c->st, c->chol.ev_cf, 0)); c->chol.cf_pending = false; }  // not used here
   RC(read_scalars(c));

@@ -47,6 +47,8 @@ class SlamMap:
     cam_intr: np.ndarray         # [A,4]
     cam_dist: np.ndarray         # [A,4]
     cam_dist_type: np.ndarray    # [A]
+    cam_imu_calib: np.ndarray    # [A,5] VICalibration of the agent's keyframes: sigma_a_c sigma_g_c sigma_aw_c sigma_gw_c g
+                                 #       (typedefs_base.hpp:333-340; every keyframe's preintegrator uses its own, keyframe_be.cpp:187-195)
     # per-KF raw IMU between predecessor and this KF (preintegrated_imu_): CSR over keyframes
     imu_ptr: np.ndarray          # [K+1]
     imu_samples: np.ndarray      # [S,7] dt, acc, gyr
@@ -155,7 +157,7 @@ def flatten_gba(m: SlamMap, visual_only: bool, loop_loss: bool, use_loops: bool 
     lm_obs_ptr = np.concatenate([[0], np.cumsum(cnt[lm_rows])]).astype(np.int32)
 
     # IMU factors
-    imu_i, imu_j, ptr, first, chunks = [], [], [0], [], []
+    imu_i, imu_j, ptr, first, chunks, noise = [], [], [0], [], [], []
     if not visual_only:
         for k in kf_rows:
             p = m.kf_pred[k]
@@ -168,6 +170,7 @@ def flatten_gba(m: SlamMap, visual_only: bool, loop_loss: bool, use_loops: bool 
                 continue  # "0 IMU measurements - skip IMU factor" (:382-385)
             imu_i.append(remap[p]); imu_j.append(remap[k])
             chunks.append(m.imu_samples[s0:s1]); ptr.append(ptr[-1] + (s1 - s0)); first.append(m.imu_first[k])
+            noise.append(m.cam_imu_calib[m.kf_cam[k]])
     samples = np.concatenate(chunks) if chunks else np.zeros((0, 7))
 
     # loop edges
@@ -192,6 +195,7 @@ def flatten_gba(m: SlamMap, visual_only: bool, loop_loss: bool, use_loops: bool 
         imu_kf_i=np.array(imu_i, np.int32), imu_kf_j=np.array(imu_j, np.int32),
         imu_sample_ptr=np.array(ptr, np.int32), imu_samples=samples,
         imu_first=np.array(first).reshape(-1, 6) if first else np.zeros((0, 6)),
+        imu_noise=np.array(noise).reshape(-1, 5) if noise else np.zeros((0, 5)),
         edge_i=np.array(ei, np.int32), edge_j=np.array(ej, np.int32),
         edge_meas=np.array(meas).reshape(-1, 7) if E else np.zeros((0, 7)),
         edge_sqrt_info=np.tile(GBA_LOOP_SQRT_INFO.reshape(1, 36), (E, 1)),
@@ -257,6 +261,8 @@ def flatten_pgo(m: SlamMap, corrected_poses: Dict[int, np.ndarray], prm: PgoPara
     W23, W45 = W1 / prm.wt_kf_n23, W1 / prm.wt_kf_n45
     ei, ej, meas, info, loss = [], [], [], [], []
     for lc in m.loops:
+        if remap[lc.kf1] < 0 or remap[lc.kf2] < 0:
+            continue  # invalidated loop keyframe: skipped with a warning in the C++ facade
         if prm.placerec_type == "COVINS":
             Sl = W1
         else:  # chol(cov^-1)^T: upper-triangular factor (:922-923)
@@ -266,7 +272,7 @@ def flatten_pgo(m: SlamMap, corrected_poses: Dict[int, np.ndarray], prm: PgoPara
     inserted = set()
     for k in kf_rows:
         s = m.kf_succ[k]
-        if s < 0:
+        if s < 0 or remap[s] < 0:
             continue
         if (k, s) in inserted:
             continue
@@ -280,9 +286,13 @@ def flatten_pgo(m: SlamMap, corrected_poses: Dict[int, np.ndarray], prm: PgoPara
             for j in range(1, 6):
                 if int(m.kf_id[k]) - j > 0:
                     t = m.kf_pred[t]
+                    if t < 0:
+                        break  # chain shorter than kf_id suggests (culled keyframes): never index with -1
                     conns.append(t)
             for n, c in enumerate(conns, start=1):
                 Wn = W1 if n <= 1 else (W23 if n <= 3 else W45)
+                if remap[c] < 0:
+                    continue
                 if (k, c) in inserted:
                     continue
                 inserted.add((k, c))

@@ -6,7 +6,9 @@ covins_amd/data/euroc_mh_4hz.npz, derived by tools/make_euroc_fixture.py), calib
 camera/IMU (orb_slam3/Examples/Monocular-Inertial/EuRoC.yaml:9-17,30-37,40-44), IMU samples are
 differentiated from a C2 spline through the keyframe poses (+ white noise and bias random walk), landmarks
 are spawned on the hall surfaces and tracked over a window of neighbouring keyframes (SLAM-like track
-lengths) with a fraction re-observed by other agents / later passes (map fusion), measurements carry
+lengths); landmark fusion happens where the reference does it — around loop closures: landmarks of the
+keyframes near one loop keyframe are re-observed by the keyframes near the other (PlaceRecognition::ConnectLoop
+fuses the matched keyframe's and its neighbours' landmarks, placerec_be.cpp:222-285) — measurements carry
 1 px noise and are stored as float32 like `keypoint_precision_t`, the initial estimate carries VIO-like
 random-walk drift, and loop constraints are noisy ground-truth relative poses.
 """
@@ -51,8 +53,10 @@ class SynthConfig:
     new_lm_per_kf: int = 40
     track_window: int = 10                # landmark visible at most +-window keyframes around its birth
     max_obs_per_kf: int = 400             # SURVEY.md §8d cap
-    p_fuse: float = 0.08                  # fraction of landmarks re-observed map-wide (loop fusion / other agents)
+    p_fuse: float = 0.5                   # fraction of a loop zone's landmarks that the loop closure fuses
+    fuse_window: int = 8                  # loop zone: +-window keyframes around either loop keyframe
     max_fused_obs: int = 6
+    fuse_mode: str = "loops"              # "loops": fusion where loop closures are (placerec_be.cpp:222-285) | "random": map-wide
     px_noise: float = 1.0
     drift_trans: float = 0.01             # random-walk std per sqrt(m), metres
     drift_yaw_deg: float = 0.05           # random-walk std per sqrt(m), degrees
@@ -191,7 +195,44 @@ def make_map(cfg: SynthConfig) -> SlamMap:
         imu_ptr[k + 1] = imu_ptr[k] + (0 if chunks[k] is None else len(chunks[k]))
     imu_samples = np.concatenate([c for c in chunks if c is not None]) if K > A else np.zeros((0, 7))
 
-    # ---- landmarks: spawn per keyframe on the hall surfaces, track in a window, fuse a fraction map-wide
+    # ---- loop closures: pairs of spatially close keyframes that LOOK THE SAME WAY (place recognition needs visual
+    #      overlap: optical axes within 40 degrees); measurement = noisy ground-truth relative pose
+    loop_pairs = []
+    axis = Rc_true.apply(np.array([0.0, 0.0, 1.0]))
+
+    def pick(D, ok, n_want, sep):
+        """greedy: closest admissible pairs first, at least `sep` keyframes from every pair already taken"""
+        used = []
+        if n_want <= 0:
+            return used
+        Dm = np.where(ok, D, np.inf)
+        for c in np.argsort(Dm, axis=None):
+            if len(used) >= n_want:
+                break
+            i, j = np.unravel_index(c, D.shape)
+            if not np.isfinite(Dm[i, j]):
+                break
+            if all(abs(i - u[0]) > sep or abs(j - u[1]) > sep for u in used):
+                used.append((int(i), int(j)))
+        return used
+
+    for a, pa in enumerate(per_agent):
+        rows = gidx[a, :pa["n"]]
+        n_loops = int(np.floor(pa["n"] / 100.0 * cfg.loops_per_100kf))
+        if n_loops and pa["n"] > 60:
+            D = np.linalg.norm(pa["p"][:, None, :] - pa["p"][None, :, :], axis=-1)
+            ok = (axis[rows] @ axis[rows].T > np.cos(np.deg2rad(40.0))) & (np.arange(pa["n"])[None, :] - np.arange(pa["n"])[:, None] >= 50)
+            for i, j in pick(D, ok, n_loops, 20):
+                loop_pairs.append((rows[i], rows[j]))
+    for a in range(A):
+        for b in range(a + 1, A):
+            ra, rb = gidx[a, :per_agent[a]["n"]], gidx[b, :per_agent[b]["n"]]
+            D = np.linalg.norm(p_true[ra][:, None, :] - p_true[rb][None, :, :], axis=-1)
+            ok = axis[ra] @ axis[rb].T > np.cos(np.deg2rad(40.0))
+            for i, j in pick(D, ok, cfg.loops_per_pair, 15):
+                loop_pairs.append((ra[i], rb[j]))
+
+    # ---- landmarks: spawn per keyframe on the hall surfaces, track in a window, fuse around the loop closures
     nl = cfg.new_lm_per_kf
     u0 = rng.uniform(30, WIDTH - 30, (K, nl)); v0 = rng.uniform(30, HEIGHT - 30, (K, nl))
     xn = (u0 - INTR[2]) / INTR[0]; yn = (v0 - INTR[3]) / INTR[1]  # undistorted approximation is fine for spawning
@@ -227,24 +268,40 @@ def make_map(cfg: SynthConfig) -> SlamMap:
         rows = gidx[birth_agent[li], loc[li]]
         uv, ok = visible(li, rows)
         obs_l.append(li[ok]); obs_k.append(rows[ok]); obs_uv.append(uv[ok])
-    if cfg.p_fuse > 0 and K > 2 * cfg.track_window:
+    def add_fused(li, rows):
+        """re-observations of landmarks li[] by keyframes rows[] (pairs): visible ones, at most max_fused_obs per landmark"""
+        far = (kf_client[rows] != birth_agent[li]) | (np.abs(kf_id[rows] - birth_local[li]) > cfg.track_window)
+        li, rows = li[far], rows[far]
+        uv, ok = visible(li, rows)
+        li, rows, uv = li[ok], rows[ok], uv[ok]
+        key = rng.random(len(li))
+        o2 = np.lexsort((key, li))
+        li, rows, uv = li[o2], rows[o2], uv[o2]
+        first = np.concatenate([[True], li[1:] != li[:-1]]) if len(li) else np.zeros(0, bool)
+        pos = np.arange(len(li)) - np.maximum.accumulate(np.where(first, np.arange(len(li)), 0))
+        keep = pos < cfg.max_fused_obs
+        obs_l.append(li[keep]); obs_k.append(rows[keep]); obs_uv.append(uv[keep])
+
+    if cfg.p_fuse > 0 and cfg.fuse_mode == "random" and K > 2 * cfg.track_window:
         fused = np.nonzero(rng.random(M) < cfg.p_fuse)[0]
         for chunk in np.array_split(fused, max(1, len(fused) // 512)):
-            if len(chunk) == 0:
-                continue
-            li = np.repeat(chunk, K); rows = np.tile(np.arange(K), len(chunk))
-            far = (kf_client[rows] != birth_agent[li]) | (np.abs(kf_id[rows] - birth_local[li]) > cfg.track_window)
-            li, rows = li[far], rows[far]
-            uv, ok = visible(li, rows)
-            li, rows, uv = li[ok], rows[ok], uv[ok]
-            # keep at most max_fused_obs random extra observations per landmark
-            key = rng.random(len(li))
-            o2 = np.lexsort((key, li))
-            li, rows, uv = li[o2], rows[o2], uv[o2]
-            first = np.concatenate([[True], li[1:] != li[:-1]])
-            pos = np.arange(len(li)) - np.maximum.accumulate(np.where(first, np.arange(len(li)), 0))
-            keep = pos < cfg.max_fused_obs
-            obs_l.append(li[keep]); obs_k.append(rows[keep]); obs_uv.append(uv[keep])
+            if len(chunk):
+                add_fused(np.repeat(chunk, K), np.tile(np.arange(K), len(chunk)))
+    if cfg.p_fuse > 0 and cfg.fuse_mode == "loops":
+        fuse_sel = rng.random(M) < cfg.p_fuse
+        seen = set()
+        for (k1, k2) in loop_pairs:
+            for (ka, kb) in ((k1, k2), (k2, k1)):  # landmarks born around ka, re-observed by the keyframes around kb
+                aa, ab = kf_client[ka], kf_client[kb]
+                za = np.arange(max(0, kf_id[ka] - cfg.fuse_window), min(n_agent[aa], kf_id[ka] + cfg.fuse_window + 1))
+                zb = np.arange(max(0, kf_id[kb] - cfg.fuse_window), min(n_agent[ab], kf_id[kb] + cfg.fuse_window + 1))
+                born = np.nonzero(np.isin(lm_birth, gidx[aa, za]) & fuse_sel)[0]
+                born = np.array([l for l in born if (l, int(ab)) not in seen], np.int64)  # one fusion per (landmark, agent)
+                if len(born) == 0:
+                    continue
+                seen.update((int(l), int(ab)) for l in born)
+                rows_b = gidx[ab, zb]
+                add_fused(np.repeat(born, len(rows_b)), np.tile(rows_b, len(born)))
     obs_l = np.concatenate(obs_l); obs_k = np.concatenate(obs_k); obs_uv = np.concatenate(obs_uv)
     # cap observations per keyframe
     key = rng.random(len(obs_l))
@@ -292,10 +349,9 @@ def make_map(cfg: SynthConfig) -> SlamMap:
     ba_est = ba_true + rng.normal(0, 0.005, (K, 3)) * cfg.imu_noise
     bg_est = bg_true + rng.normal(0, 0.0005, (K, 3)) * cfg.imu_noise
 
-    # ---- loop constraints: noisy ground-truth relative poses between spatially close keyframes
+    # ---- loop constraints (typedefs_base.hpp:264-277): noisy ground-truth relative pose per loop closure
     loops: List[LoopConstraint] = []
-
-    def add_loop(k1, k2):
+    for (k1, k2) in loop_pairs:
         Ra, Rb = R_true[k1], R_true[k2]
         dR = R.from_rotvec(rng.normal(0, np.deg2rad(cfg.loop_noise_deg), 3))
         q = (Ra.inv() * Rb * dR).as_quat()
@@ -303,32 +359,6 @@ def make_map(cfg: SynthConfig) -> SlamMap:
             q = -q
         tt = Ra.inv().apply(p_true[k2] - p_true[k1]) + rng.normal(0, cfg.loop_noise_t, 3)
         loops.append(LoopConstraint(int(k1), int(k2), np.concatenate([q, tt])))
-
-    for a, pa in enumerate(per_agent):
-        rows = gidx[a, :pa["n"]]
-        n_loops = int(np.floor(pa["n"] / 100.0 * cfg.loops_per_100kf))
-        if n_loops and pa["n"] > 60:
-            D = np.linalg.norm(pa["p"][:, None, :] - pa["p"][None, :, :], axis=-1)
-            ii, jj = np.triu_indices(pa["n"], k=50)
-            cand = np.argsort(D[ii, jj])
-            used = []
-            for c in cand:
-                if len(used) >= n_loops:
-                    break
-                if all(abs(ii[c] - u[0]) > 20 or abs(jj[c] - u[1]) > 20 for u in used):
-                    used.append((ii[c], jj[c])); add_loop(rows[ii[c]], rows[jj[c]])
-    for a in range(A):
-        for b in range(a + 1, A):
-            ra, rb = gidx[a, :per_agent[a]["n"]], gidx[b, :per_agent[b]["n"]]
-            D = np.linalg.norm(p_true[ra][:, None, :] - p_true[rb][None, :, :], axis=-1)
-            flat = np.argsort(D, axis=None)
-            used = []
-            for c in flat:
-                if len(used) >= cfg.loops_per_pair:
-                    break
-                i, j = np.unravel_index(c, D.shape)
-                if all(abs(i - u[0]) > 15 or abs(j - u[1]) > 15 for u in used):
-                    used.append((i, j)); add_loop(ra[i], rb[j])
 
     def pose_rows(q, p):
         return np.concatenate([q, p], axis=1)
@@ -341,6 +371,7 @@ def make_map(cfg: SynthConfig) -> SlamMap:
         kf_velocity=v_est, kf_bias_a=ba_est, kf_bias_g=bg_est, kf_pred=pred, kf_succ=succ,
         kf_cam=kf_client.copy(), cam_extr=extr, cam_intr=np.tile(INTR, (A, 1)), cam_dist=np.tile(DIST, (A, 1)),
         cam_dist_type=np.zeros(A, np.int32),
+        cam_imu_calib=np.tile(np.array([SIG_A, SIG_G, SIG_AW, SIG_GW, GRAVITY]), (A, 1)),
         imu_ptr=imu_ptr.astype(np.int64), imu_samples=imu_samples, imu_first=imu_first,
         lm_pos=lm_est, lm_invalid=np.zeros(L, bool), lm_ref_kf=lm_ref, lm_gba_optimized=np.zeros(L, bool),
         lm_obs_ptr=lm_obs_ptr, obs_kf=obs_k.astype(np.int32), obs_uv=uv_meas, obs_octave=np.zeros(len(obs_k), np.int32),
@@ -376,7 +407,7 @@ def config_named(name: str, seed: int = 0) -> SynthConfig:
     if name == "a12x500":         # configs[4] at reduced scale: 12 agents (5 MH paths + 7 re-posed copies), <= 500 keyframes each
         return SynthConfig(agents=tuple(range(1, 13)), max_kf_per_agent=500, seed=seed)
     if name == "tiny":            # CPU tests
-        return SynthConfig(agents=(1, 3), max_kf_per_agent=14, new_lm_per_kf=14, track_window=5, p_fuse=0.15,
+        return SynthConfig(agents=(1, 3), max_kf_per_agent=14, new_lm_per_kf=14, track_window=5, fuse_window=3,
                            loops_per_pair=1, seed=seed)
     if name == "small":           # GPU parity tests / smoke
         return SynthConfig(agents=(1, 2, 3), max_kf_per_agent=60, new_lm_per_kf=30, track_window=8, seed=seed)

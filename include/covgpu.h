@@ -111,6 +111,11 @@ typedef struct covgpu_problem {
   const int32_t* imu_sample_ptr; /* [I+1] */
   const double*  imu_samples;    /* [S][7] */
   const double*  imu_first;      /* [I][6]  (acc_0, gyr_0): reading at the predecessor (keyframe_be.cpp:187,195) */
+  /* Per-factor IMU calibration [sigma_a, sigma_g, sigma_aw, sigma_gw, gravity]: the reference builds every keyframe's
+   * preintegrator from THAT keyframe's own calibration (keyframe_be.cpp:187-195: sigma_a_c, sigma_g_c, sigma_aw_c,
+   * sigma_gw_c, g), so mixed agents / IMUs keep their own weights. NULL: the five values of covgpu_options apply to
+   * every factor. A row with a non-positive sigma or gravity < 9 (keyframe_base.cpp:51-55) is COVGPU_ERR_INVALID_ARG. */
+  const double*  imu_noise;      /* [I][5] or NULL */
 
   /* SE3 between factors (robopt SixDofBetweenError, kImu): measurement T_s1_s2 as [q(4), t(3)],
    * row-major 6x6 sqrt-information (rotation rows first), Cauchy scale per edge (0 = no loss). */

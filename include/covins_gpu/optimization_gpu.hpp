@@ -19,6 +19,7 @@
 // (tests/cpp/standin_map.hpp) both provide. `Types` names the map classes and the few operations whose
 // spelling differs between the real COVINS classes and a stand-in (see INTEGRATION.md for the COVINS binding).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +27,7 @@
 #include <memory>
 #include <set>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -49,8 +51,9 @@ struct Params {
   std::string placerec_type = "COVINS";
   int strategy = COVGPU_DOGLEG;  // the reference runs DOGLEG (optimization_be.cpp:261,564,1028)
   int device = 0;
-  // IMU noise / gravity of VICalibration (typedefs_base.hpp:333-340); defaults = EuRoC at 200 Hz
-  double sigma_a = 0, sigma_g = 0, sigma_aw = 0, sigma_gw = 0, gravity = 0;  // 0 -> covgpu defaults
+  int flatten_threads = 0;  // host threads of the Map -> IR walk over landmarks; 0 = sys.threads_server-like default (hardware, <= 16)
+  // (IMU noise and gravity are NOT parameters: every IMU factor carries its keyframe's own VICalibration values,
+  //  Types::imu_calib, as the reference's per-keyframe preintegrators do — keyframe_be.cpp:187-195.)
 };
 
 namespace detail {
@@ -141,7 +144,7 @@ inline void sqrt_info_from_cov(const double* cov, double* S) {
 }
 
 struct Flat {  // owning storage behind one covgpu_problem
-  std::vector<double> pose, sb, cam_extr, cam_intr, cam_dist, lm, uv, sigma, samples, first, meas, info, loss;
+  std::vector<double> pose, sb, cam_extr, cam_intr, cam_dist, lm, uv, sigma, samples, first, noise, meas, info, loss;
   std::vector<uint8_t> fixed;
   std::vector<int32_t> kf_cam, cam_type, obs_ptr, obs_kf, imu_i, imu_j, imu_ptr, ei, ej;
   covgpu_problem view() {
@@ -155,7 +158,7 @@ struct Flat {  // owning storage behind one covgpu_problem
     p.cam_extr = cam_extr.data(); p.cam_intr = cam_intr.data(); p.cam_dist = cam_dist.data(); p.cam_dist_type = cam_type.data();
     p.lm_pos = lm.data(); p.lm_obs_ptr = obs_ptr.data(); p.obs_kf = obs_kf.data(); p.obs_uv = uv.data(); p.obs_sigma = sigma.data();
     p.imu_kf_i = imu_i.data(); p.imu_kf_j = imu_j.data(); p.imu_sample_ptr = imu_ptr.data(); p.imu_samples = samples.data();
-    p.imu_first = first.data();
+    p.imu_first = first.data(); p.imu_noise = noise.data();
     p.edge_i = ei.data(); p.edge_j = ej.data(); p.edge_meas = meas.data(); p.edge_sqrt_info = info.data(); p.edge_loss_a = loss.data();
     return p;
   }
@@ -169,6 +172,8 @@ struct Flat {  // owning storage behind one covgpu_problem
 //   static int  imu_count(const Keyframe&);
 //   static void imu_sample(const Keyframe&, int i, double* dt, double acc[3], double gyr[3]);
 //   static void imu_first(const Keyframe&, double acc0[3], double gyr0[3]);
+//   static void imu_calib(const Keyframe&, double out5[5]);   sigma_a_c, sigma_g_c, sigma_aw_c, sigma_gw_c, g of the
+//                                                             keyframe's VICalibration (keyframe_be.cpp:187-195)
 template <class Types>
 class OptimizationT {
  public:
@@ -195,7 +200,7 @@ class OptimizationT {
     auto keyframes = map->GetKeyframesVec();
     auto landmarks = map->GetLandmarksVec();
     std::map<Keyframe*, int32_t> row;
-    std::map<size_t, int32_t> cam_of_client;
+    std::map<size_t, std::vector<int32_t>> cams_of_client;
     for (auto& kf : keyframes) {
       if (kf->IsInvalid()) continue;
       const int32_t k = (int32_t)ix.kfs.size();
@@ -212,16 +217,26 @@ class OptimizationT {
       bool fixed = (kf->id_.first == 0 && kf->id_.second == map->id_map_);                       // :88-89, 329-331
       if (round2 && kf->is_loaded_ && prm.gba_fix_poses_loaded_maps) fixed = true;                // :338-341
       f.fixed.push_back(fixed ? 1 : 0);
-      auto it = cam_of_client.find(kf->id_.second);
-      if (it == cam_of_client.end()) {  // one camera per agent; extrinsics/intrinsics/distortion constant (:336,349,352)
-        double intr[4], dist[4], e7[7]; int dt = 0;
-        if (!Types::camera(*kf, intr, dist, &dt)) detail::fatal("Unknown projection / distortion type.");  // :112-115, 201-204
-        detail::transform_to_pose(kf->GetStateExtrinsics(), e7);
-        it = cam_of_client.emplace(kf->id_.second, (int32_t)f.cam_type.size()).first;
+      // Extrinsics, intrinsics and distortion are constant parameter blocks OF THIS KEYFRAME (:336,349,352:
+      // kf->ceres_extrinsics_ / camera_ of every keyframe). Identical rows are shared: normally one per agent, but a
+      // keyframe whose calibration differs from its agent's earlier ones gets its own camera row.
+      double intr[4], dist[4], e7[7]; int dt = 0;
+      if (!Types::camera(*kf, intr, dist, &dt)) detail::fatal("Unknown projection / distortion type.");  // :112-115, 201-204
+      detail::transform_to_pose(kf->GetStateExtrinsics(), e7);
+      std::vector<int32_t>& cands = cams_of_client[kf->id_.second];
+      int32_t cam = -1;
+      for (int32_t c : cands) {
+        bool same = f.cam_type[c] == dt;
+        for (int i = 0; same && i < 7; ++i) same = f.cam_extr[7 * c + i] == e7[i];
+        for (int i = 0; same && i < 4; ++i) same = f.cam_intr[4 * c + i] == intr[i] && f.cam_dist[4 * c + i] == dist[i];
+        if (same) { cam = c; break; }
+      }
+      if (cam < 0) {
+        cam = (int32_t)f.cam_type.size(); cands.push_back(cam);
         f.cam_extr.insert(f.cam_extr.end(), e7, e7 + 7); f.cam_intr.insert(f.cam_intr.end(), intr, intr + 4);
         f.cam_dist.insert(f.cam_dist.end(), dist, dist + 4); f.cam_type.push_back(dt);
       }
-      f.kf_cam.push_back(it->second);
+      f.kf_cam.push_back(cam);
     }
     // IMU factors (:117-144 / :367-420)
     f.imu_ptr.assign(1, 0);
@@ -238,6 +253,10 @@ class OptimizationT {
         double a0[3], g0[3];
         Types::imu_first(*kf, a0, g0);
         f.first.insert(f.first.end(), a0, a0 + 3); f.first.insert(f.first.end(), g0, g0 + 3);
+        double nz[5];
+        Types::imu_calib(*kf, nz);  // the preintegrator of THIS keyframe was built from its own calibration (keyframe_be.cpp:187-195)
+        if (!(nz[0] > 0 && nz[1] > 0 && nz[2] > 0 && nz[3] > 0) || nz[4] < 9.0) detail::fatal("IMU calibration unset (sigma <= 0 or g < 9)");  // keyframe_base.cpp:51-55
+        f.noise.insert(f.noise.end(), nz, nz + 5);
         for (int i = 0; i < n; ++i) {
           double dt, a[3], g[3];
           Types::imu_sample(*kf, i, &dt, a, g);
@@ -245,30 +264,59 @@ class OptimizationT {
         }
         f.imu_ptr.push_back((int32_t)(f.samples.size() / 7));
       }
-    // landmarks + observations (:147-236 / :425-530)
+    // landmarks + observations (:147-236 / :425-530). The walk is O(#observations) of pointer chasing and std::map
+    // copies (GetObservations), the dominant host cost of a call once the solve runs on the GPU: landmark ranges go to
+    // host threads, each filling its own Flat/Index slice; the slices are concatenated in landmark order, so the IR is
+    // the same for any thread count. (The map is exclusively checked out for the call, backend.cpp:134; the accessors
+    // take the per-object mutexes.)
     const size_t th_min_observations = 2;
-    f.obs_ptr.assign(1, 0);
-    for (auto& lm : landmarks) {
-      if (lm->IsInvalid()) continue;
-      const auto observations = lm->GetObservations();
-      if (observations.size() < th_min_observations) continue;
-      size_t num_edges = 0;
-      for (auto& mit : observations) { if (!mit.first || mit.first->IsInvalid()) continue; num_edges++; }
-      if (num_edges < th_min_observations) continue;
-      const Vector3Type pw = lm->GetWorldPos();
-      for (int i = 0; i < 3; ++i) f.lm.push_back(pw[i]);
-      ix.lms.push_back(lm);
-      for (auto& mit : observations) {
-        const KeyframePtr& kfx = mit.first;
-        if (!kfx || kfx->IsInvalid()) continue;
-        const size_t feat = mit.second;
-        f.obs_kf.push_back(row.at(kfx.get()));
-        f.uv.push_back((double)kfx->keypoints_distorted_[feat][0]);  // float -> double (utils_base.hpp:76-80)
-        f.uv.push_back((double)kfx->keypoints_distorted_[feat][1]);
-        f.sigma.push_back(((double)kfx->keypoints_aors_[feat][1] + 1) * 2.0);  // :184, 478
-        ix.obs.emplace_back(kfx, feat); ix.obs_lm.push_back(lm);
+    int nth = prm.flatten_threads > 0 ? prm.flatten_threads : (int)std::thread::hardware_concurrency();
+    nth = std::max(1, std::min(nth, 16));
+    if (landmarks.size() < 4096) nth = 1;
+    struct Slice { std::vector<double> lm, uv, sigma; std::vector<int32_t> obs_kf, nobs; std::vector<LandmarkPtr> lms, obs_lm; std::vector<std::pair<KeyframePtr, size_t>> obs; };
+    std::vector<Slice> slices(nth);
+    auto walk = [&](int t) {
+      Slice& sl = slices[t];
+      const size_t l0 = landmarks.size() * (size_t)t / nth, l1 = landmarks.size() * (size_t)(t + 1) / nth;
+      for (size_t li = l0; li < l1; ++li) {
+        const LandmarkPtr& lm = landmarks[li];
+        if (lm->IsInvalid()) continue;
+        const auto observations = lm->GetObservations();
+        if (observations.size() < th_min_observations) continue;
+        size_t num_edges = 0;
+        for (auto& mit : observations) { if (!mit.first || mit.first->IsInvalid()) continue; num_edges++; }
+        if (num_edges < th_min_observations) continue;
+        const Vector3Type pw = lm->GetWorldPos();
+        for (int i = 0; i < 3; ++i) sl.lm.push_back(pw[i]);
+        sl.lms.push_back(lm);
+        int32_t n = 0;
+        for (auto& mit : observations) {
+          const KeyframePtr& kfx = mit.first;
+          if (!kfx || kfx->IsInvalid()) continue;
+          const size_t feat = mit.second;
+          sl.obs_kf.push_back(row.at(kfx.get()));
+          sl.uv.push_back((double)kfx->keypoints_distorted_[feat][0]);  // float -> double (utils_base.hpp:76-80)
+          sl.uv.push_back((double)kfx->keypoints_distorted_[feat][1]);
+          sl.sigma.push_back(((double)kfx->keypoints_aors_[feat][1] + 1) * 2.0);  // :184, 478
+          sl.obs.emplace_back(kfx, feat); sl.obs_lm.push_back(lm);
+          ++n;
+        }
+        sl.nobs.push_back(n);
       }
-      f.obs_ptr.push_back((int32_t)f.obs_kf.size());
+    };
+    {
+      std::vector<std::thread> th;
+      for (int t = 1; t < nth; ++t) th.emplace_back(walk, t);
+      walk(0);
+      for (auto& x : th) x.join();
+    }
+    f.obs_ptr.assign(1, 0);
+    for (Slice& sl : slices) {
+      f.lm.insert(f.lm.end(), sl.lm.begin(), sl.lm.end()); f.uv.insert(f.uv.end(), sl.uv.begin(), sl.uv.end());
+      f.sigma.insert(f.sigma.end(), sl.sigma.begin(), sl.sigma.end()); f.obs_kf.insert(f.obs_kf.end(), sl.obs_kf.begin(), sl.obs_kf.end());
+      for (int32_t n : sl.nobs) f.obs_ptr.push_back(f.obs_ptr.back() + n);
+      ix.lms.insert(ix.lms.end(), sl.lms.begin(), sl.lms.end()); ix.obs.insert(ix.obs.end(), sl.obs.begin(), sl.obs.end());
+      ix.obs_lm.insert(ix.obs_lm.end(), sl.obs_lm.begin(), sl.obs_lm.end());
     }
     // loop edges (:238-254 / :534-557): sqrt_info = diag(100 I3, 1e4 I3); loss only in round 2
     if (!round2 || prm.gba_use_map_loop_constraints)
@@ -288,8 +336,6 @@ class OptimizationT {
     covgpu_options o;
     covgpu_default_options(&o);
     o.strategy = prm.strategy; o.max_iterations = max_it; o.visual_only = visual_only ? 1 : 0; o.device = prm.device;
-    if (prm.sigma_a > 0) { o.sigma_a = prm.sigma_a; o.sigma_g = prm.sigma_g; o.sigma_aw = prm.sigma_aw; o.sigma_gw = prm.sigma_gw; }
-    if (prm.gravity > 0) o.gravity = prm.gravity;
     return o;
   }
 
@@ -404,31 +450,41 @@ class OptimizationT {
         detail::sqrt_info_from_cov(cov, S);
       }
       detail::transform_to_pose(lc.T_s1_s2, m7);
-      add_edge(row.at(lc.kf1.get()), row.at(lc.kf2.get()), m7, S, prm.use_robust_loss ? prm.robust_loss_th : 0.0);
+      auto a = row.find(lc.kf1.get()), b = row.find(lc.kf2.get());  // an invalidated loop keyframe must not take the server down
+      if (a == row.end() || b == row.end()) { std::fprintf(stderr, "[covins_gpu] PGO: loop KF missing -- skip loop\n"); continue; }
+      add_edge(a->second, b->second, m7, S, prm.use_robust_loss ? prm.robust_loss_th : 0.0);
     }
     std::set<std::pair<Keyframe*, Keyframe*>> inserted;
     for (auto& kf : kfs) {  // successor edges from the VIO poses (:947-972)
       KeyframePtr succ = kf->GetSuccessor();
       if (!succ) continue;
+      auto sr = row.find(succ.get());
+      if (sr == row.end()) continue;  // successor invalid / not in the map: no parameter block to tie to
       if (!inserted.insert({kf.get(), succ.get()}).second) continue;
       double m7[7];
       detail::relative_pose(kf->GetPoseTws_vio(), succ->GetPoseTws_vio(), m7);
-      add_edge(row.at(kf.get()), row.at(succ.get()), m7, W1, 0.0);
+      add_edge(row.at(kf.get()), sr->second, m7, W1, 0.0);
     }
     if (prm.use_nbr_kfs)  // five previous neighbours (:976-1021)
       for (auto& kf : kfs) {
         std::vector<KeyframePtr> connections;
         KeyframePtr temp = kf;
         for (int j = 1; j < 6; ++j)
-          if (int(kf->id_.first) - j > 0) { temp = temp->GetPredecessor(); connections.push_back(temp); }
+          if (int(kf->id_.first) - j > 0) {
+            temp = temp ? temp->GetPredecessor() : KeyframePtr();  // a chain shorter than id_.first suggests (culled keyframes) ends here
+            if (!temp) break;
+            connections.push_back(temp);
+          }
         size_t k = 0;
         for (auto& kfc : connections) {
           k++;
           const double* S = (k <= 1) ? W1 : (k <= 3 ? W23 : W45);
+          auto cr = row.find(kfc.get());
+          if (cr == row.end()) continue;
           if (!inserted.insert({kf.get(), kfc.get()}).second) continue;
           double m7[7];
           detail::relative_pose(kf->GetPoseTws_vio(), kfc->GetPoseTws_vio(), m7);
-          add_edge(row.at(kf.get()), row.at(kfc.get()), m7, S, 0.0);
+          add_edge(row.at(kf.get()), cr->second, m7, S, 0.0);
         }
       }
     covgpu_problem p = f.view();

@@ -15,6 +15,8 @@ from covins_amd import capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_SOLVER_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
 def build(force: bool = False) -> str:
@@ -49,7 +51,59 @@ def lib() -> C.CDLL:
         L.covo_imu_residual.argtypes = [dp, dp, C.c_int, dp, dp, dp, dp, dp, dp, dp, C.c_int, dp, dp, dp]
         for n in ("covo_pose_plus", "covo_reproj_residual", "covo_between_residual", "covo_imu_residual"):
             getattr(L, n).restype = None
+        L.covo_set_sparse_solver.argtypes = [_SOLVER_FN, C.c_int]
+        L.covo_set_sparse_solver.restype = None
+        ip = capi._ip
+        L.covo_schur_sparse.argtypes = [OP, PP, C.c_int, C.c_double, ip, ip, dp, dp, dp]
+        L.covo_landmark_hessians.argtypes = [OP, PP, dp]
     return _LIB
+
+
+# ---------------------------------------------------------------- sparse linear solver for BASELINE-size problems
+# The oracle's own dense Cholesky handles the small test problems. For the reduced systems of the BASELINE
+# configurations (15 K up to 33k unknowns) the block-CSR system is handed to scipy's SuperLU: a library solver that
+# shares no code with either Cholesky written in this repository. No pivoting + symmetric mode makes the U diagonal
+# the pivots of L D L^T, so "all pivots positive" is the positive-definiteness test Ceres' CHOLMOD path relies on.
+_solver_keepalive = None
+solver_stats = {"calls": 0, "seconds": 0.0, "nnz_factor": 0}
+
+
+def _superlu_solve(n, D, K, ptr, col, blocks, rhs, x):
+    import time
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    t0 = time.perf_counter()
+    try:
+        ptr_a = np.ctypeslib.as_array(ptr, (K + 1,))
+        nnzb = int(ptr_a[K])
+        col_a = np.ctypeslib.as_array(col, (nnzb,))
+        blk = np.ctypeslib.as_array(blocks, (nnzb, D, D))
+        A = sp.bsr_matrix((blk, col_a, ptr_a), shape=(n, n)).tocsc()
+        A.eliminate_zeros()
+        lu = spla.splu(A, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+        if not (lu.U.diagonal() > 0.0).all():
+            return 1
+        b = np.ctypeslib.as_array(rhs, (n,))
+        np.ctypeslib.as_array(x, (n,))[:] = lu.solve(b)
+        solver_stats["nnz_factor"] = int(lu.L.nnz)
+        return 0
+    except Exception as e:  # singular matrix etc.: treated like a failed Cholesky
+        print("covo sparse solver:", e)
+        return 2
+    finally:
+        solver_stats["calls"] += 1
+        solver_stats["seconds"] += time.perf_counter() - t0
+
+
+def use_sparse_solver(min_n: int = 3000, enable: bool = True) -> None:
+    """Route reduced systems with >= min_n unknowns through scipy's SuperLU (smaller ones keep the dense Cholesky)."""
+    global _solver_keepalive
+    if enable:
+        _solver_keepalive = _SOLVER_FN(_superlu_solve)
+        lib().covo_set_sparse_solver(_solver_keepalive, int(min_n))
+    else:
+        lib().covo_set_sparse_solver(C.cast(None, _SOLVER_FN), 0)
+        _solver_keepalive = None
 
 
 def default_options(**kw) -> capi.Options:
@@ -113,6 +167,24 @@ def schur(prob, opt, mu, pgo=False):
     s = prob.as_struct()
     assert lib().covo_schur(C.byref(opt), C.byref(s), int(pgo), float(mu), _d(S), _d(b), _d(c)) == 0
     return S, b, float(c[0])
+
+
+def schur_sparse(prob, opt, mu, pgo=False):
+    """Block-CSR reduced system (ptr, col, blocks[nnzb, D, D]), right-hand side and cost."""
+    D = 6 if (pgo or opt.visual_only) else 15
+    s = prob.as_struct()
+    nnzb = lib().covo_schur_sparse(C.byref(opt), C.byref(s), int(pgo), float(mu), None, None, None, None, None)
+    ptr, col = np.zeros(prob.K + 1, np.int32), np.zeros(nnzb, np.int32)
+    blocks, b, c = np.zeros((nnzb, D, D)), np.zeros(D * prob.K), np.zeros(1)
+    lib().covo_schur_sparse(C.byref(opt), C.byref(s), int(pgo), float(mu), capi.iptr(ptr), capi.iptr(col), _d(blocks), _d(b), _d(c))
+    return ptr, col, blocks, b, float(c[0])
+
+
+def landmark_hessians(prob, opt):
+    H = np.zeros((prob.L, 9))
+    s = prob.as_struct()
+    assert lib().covo_landmark_hessians(C.byref(opt), C.byref(s), _d(H)) == 0
+    return H.reshape(-1, 3, 3)
 
 
 def step(prob, opt, mu, dense: bool):

@@ -31,6 +31,21 @@ struct State {
   std::vector<double> pose, sb, lm;
 };
 
+// Symmetric block pattern of the reduced camera system over keyframes (CSR, sorted columns, both (i,j) and (j,i)):
+// a block (i,j) exists iff i == j, or i and j observe a common landmark, share an IMU factor or a between factor.
+// The reference's SPARSE_SCHUR solver works on exactly this block structure (optimization_be.cpp:561).
+struct BlockPattern {
+  int K = 0;
+  std::vector<int> ptr, col;
+  int find(int i, int j) const {
+    const int* b = col.data() + ptr[i];
+    const int* e = col.data() + ptr[i + 1];
+    const int* it = std::lower_bound(b, e, j);
+    return (it != e && *it == j) ? (int)(it - col.data()) : -1;
+  }
+  size_t nnzb() const { return col.size(); }
+};
+
 struct Problem {
   const covgpu_problem* p;
   covgpu_options o;
@@ -39,7 +54,16 @@ struct Problem {
   std::vector<Preint> pre;
   std::vector<Mat<15, 15>> preW;
   std::vector<int> obs_lm;
+  std::vector<double> grav;  // gravity magnitude per IMU factor
+  BlockPattern pat;
 };
+
+// Pluggable linear solver for the block-sparse reduced system (tests/ and tools/ install scipy's SuperLU through
+// oracle/covo.py so that problems of BASELINE size are solved by a library independent of every Cholesky written in
+// this repository). Returns 0 on success, non-zero if the matrix is not positive definite.
+typedef int (*covo_sparse_solver_fn)(int n, int D, int K, const int* ptr, const int* col, const double* blocks, const double* rhs, double* x);
+static covo_sparse_solver_fn g_sparse_solver = nullptr;
+static int g_sparse_min_n = 0;
 
 static void setup(Problem& P, const covgpu_problem* p, const covgpu_options* o, bool pgo) {
   P.p = p; P.o = *o;
@@ -52,11 +76,32 @@ static void setup(Problem& P, const covgpu_problem* p, const covgpu_options* o, 
   P.obs_lm.assign(P.O, 0);
   for (int l = 0; l < P.L; ++l)
     for (int k = p->lm_obs_ptr[l]; k < p->lm_obs_ptr[l + 1]; ++k) P.obs_lm[k] = l;
+  {  // block pattern
+    std::vector<std::vector<int>> adj(P.K);
+    for (int i = 0; i < P.K; ++i) adj[i].push_back(i);
+    for (int l = 0; l < P.L; ++l)
+      for (int a = p->lm_obs_ptr[l]; a < p->lm_obs_ptr[l + 1]; ++a)
+        for (int b = p->lm_obs_ptr[l]; b < p->lm_obs_ptr[l + 1]; ++b)
+          if (a != b) adj[p->obs_kf[a]].push_back(p->obs_kf[b]);
+    for (int f = 0; f < P.I; ++f) { adj[p->imu_kf_i[f]].push_back(p->imu_kf_j[f]); adj[p->imu_kf_j[f]].push_back(p->imu_kf_i[f]); }
+    for (int e = 0; e < P.E; ++e) { adj[p->edge_i[e]].push_back(p->edge_j[e]); adj[p->edge_j[e]].push_back(p->edge_i[e]); }
+    P.pat.K = P.K; P.pat.ptr.assign(P.K + 1, 0); P.pat.col.clear();
+    for (int i = 0; i < P.K; ++i) {
+      std::sort(adj[i].begin(), adj[i].end());
+      adj[i].erase(std::unique(adj[i].begin(), adj[i].end()), adj[i].end());
+      P.pat.col.insert(P.pat.col.end(), adj[i].begin(), adj[i].end());
+      P.pat.ptr[i + 1] = (int)P.pat.col.size();
+    }
+  }
   // R2: repropagate every factor at the successor's current bias estimate (opt_be.cpp:387-396)
   P.pre.resize(P.I); P.preW.resize(P.I);
-  const ImuNoise nz{o->sigma_a, o->sigma_g, o->sigma_aw, o->sigma_gw, o->gravity};
+  P.grav.assign(P.I, o->gravity);
 #pragma omp parallel for schedule(dynamic, 8)
   for (int f = 0; f < P.I; ++f) {
+    // this factor's own calibration (keyframe_be.cpp:187-195), else the options' single set
+    const double* q = p->imu_noise ? p->imu_noise + (size_t)5 * f : nullptr;
+    const ImuNoise nz = q ? ImuNoise{q[0], q[1], q[2], q[3], q[4]} : ImuNoise{o->sigma_a, o->sigma_g, o->sigma_aw, o->sigma_gw, o->gravity};
+    P.grav[f] = nz.g;
     const int j = p->imu_kf_j[f];
     const double* sbj = p->kf_speed_bias + 9 * j;
     const int s0 = p->imu_sample_ptr[f], s1 = p->imu_sample_ptr[f + 1];
@@ -108,7 +153,7 @@ static void eval_edge(const Problem& P, const State& s, int e, bool jac, Vec6* r
 static void eval_imu(const Problem& P, const State& s, int f, bool jac, Mat<15, 1>* r, Mat<15, 30>* J) {
   const covgpu_problem* p = P.p;
   const int i = p->imu_kf_i[f], j = p->imu_kf_j[f];
-  imu_factor(P.pre[f], P.preW[f], Pose(&s.pose[7 * i]), &s.sb[9 * i], Pose(&s.pose[7 * j]), &s.sb[9 * j], P.o.gravity, r,
+  imu_factor(P.pre[f], P.preW[f], Pose(&s.pose[7 * i]), &s.sb[9 * i], Pose(&s.pose[7 * j]), &s.sb[9 * j], P.grav[f], r,
              jac ? J : nullptr);
   if (jac) {
     if (p->kf_fixed[i]) for (int rr = 0; rr < 15; ++rr) for (int c = 0; c < 6; ++c) (*J)(rr, c) = 0;
@@ -116,19 +161,24 @@ static void eval_imu(const Problem& P, const State& s, int f, bool jac, Mat<15, 
   }
 }
 
+// All sums below are formed in a fixed order (per-item values stored, then added serially), so the oracle's results
+// do not depend on the OpenMP thread count of the box it runs on.
 static double evaluate_cost(const Problem& P, const State& s) {
+  std::vector<double> co(P.O), ci(P.I);
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < P.O; ++k) { ObsLin ol; eval_obs(P, s, k, false, &ol); co[k] = ol.cost; }
+#pragma omp parallel for schedule(static)
+  for (int f = 0; f < P.I; ++f) { Mat<15, 1> r; eval_imu(P, s, f, false, &r, nullptr); ci[f] = 0.5 * r.squaredNorm(); }
   double cost = 0;
-#pragma omp parallel for reduction(+ : cost) schedule(static)
-  for (int k = 0; k < P.O; ++k) { ObsLin ol; eval_obs(P, s, k, false, &ol); cost += ol.cost; }
-#pragma omp parallel for reduction(+ : cost) schedule(static)
-  for (int f = 0; f < P.I; ++f) { Mat<15, 1> r; eval_imu(P, s, f, false, &r, nullptr); cost += 0.5 * r.squaredNorm(); }
+  for (double v : co) cost += v;
+  for (double v : ci) cost += v;
   for (int e = 0; e < P.E; ++e) { Vec6 r; double c; eval_edge(P, s, e, false, &r, nullptr, nullptr, &c); cost += c; }
   return cost;
 }
 
 // ------------------------------------------------------------------ linearisation (A.6)
 struct Lin {
-  std::vector<double> H;    // n x n  H_pp before Schur, full symmetric
+  std::vector<double> H;    // nnzb x D x D  H_pp before Schur, block CSR on Problem::pat (full symmetric)
   std::vector<double> g;    // n      J_p^T r
   std::vector<double> Hll;  // L x 9
   std::vector<double> gl;   // L x 3
@@ -137,26 +187,40 @@ struct Lin {
   double cost = 0;
 };
 
-static void add_block(std::vector<double>& H, int n, int r0, int c0, int R, int C, const double* B, int ldb) {
+// H block (i,j), sub-block at (r0,c0) += B (R x C, leading dimension ldb)
+static void add_block(const Problem& P, std::vector<double>& H, int i, int j, int r0, int c0, int R, int C, const double* B, int ldb) {
+  const int D = P.D;
+  double* blk = &H[(size_t)P.pat.find(i, j) * D * D];
   for (int r = 0; r < R; ++r)
-    for (int c = 0; c < C; ++c) H[(size_t)(r0 + r) * n + c0 + c] += B[r * ldb + c];
+    for (int c = 0; c < C; ++c) blk[(r0 + r) * D + c0 + c] += B[r * ldb + c];
+}
+
+// dense n x n image of a block-CSR matrix (small problems, per-kernel test entry points)
+static void expand_dense(const Problem& P, const std::vector<double>& Hb, std::vector<double>& M) {
+  const int n = P.n, D = P.D;
+  M.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < P.K; ++i)
+    for (int q = P.pat.ptr[i]; q < P.pat.ptr[i + 1]; ++q) {
+      const int j = P.pat.col[q];
+      for (int r = 0; r < D; ++r)
+        for (int c = 0; c < D; ++c) M[(size_t)(D * i + r) * n + D * j + c] = Hb[(size_t)q * D * D + r * D + c];
+    }
 }
 
 static void linearize(const Problem& P, const State& s, Lin& lin) {
   const int n = P.n, D = P.D;
-  lin.H.assign((size_t)n * n, 0.0);
+  lin.H.assign(P.pat.nnzb() * D * D, 0.0);
   lin.g.assign(n, 0.0);
   lin.Hll.assign((size_t)P.L * 9, 0.0);
   lin.gl.assign((size_t)P.L * 3, 0.0);
   lin.W.assign((size_t)P.O * 18, 0.0);
   double cost = 0;
   std::vector<ObsLin> ol(P.O);
-#pragma omp parallel for reduction(+ : cost) schedule(static)
+#pragma omp parallel for schedule(static)
   for (int l = 0; l < P.L; ++l) {
     Mat3 Hl; Vec3 gl;
     for (int k = P.p->lm_obs_ptr[l]; k < P.p->lm_obs_ptr[l + 1]; ++k) {
       eval_obs(P, s, k, true, &ol[k]);
-      cost += ol[k].cost;
       const Mat<3, 2> JlT = ol[k].Jl.T();
       Mat<2, 1> r; r[0] = ol[k].r[0]; r[1] = ol[k].r[1];
       Hl += JlT * ol[k].Jl;
@@ -167,13 +231,14 @@ static void linearize(const Problem& P, const State& s, Lin& lin) {
     for (int q = 0; q < 9; ++q) lin.Hll[(size_t)l * 9 + q] = Hl[q];
     for (int q = 0; q < 3; ++q) lin.gl[(size_t)l * 3 + q] = gl[q];
   }
+  for (int k = 0; k < P.O; ++k) cost += ol[k].cost;  // fixed order
   // pose-side accumulation (serial: the oracle favours clarity)
   for (int k = 0; k < P.O; ++k) {
     const int kf = P.p->obs_kf[k];
     const Mat<6, 6> A = ol[k].Jp.T() * ol[k].Jp;
     Mat<2, 1> r; r[0] = ol[k].r[0]; r[1] = ol[k].r[1];
     const Mat<6, 1> b = ol[k].Jp.T() * r;
-    add_block(lin.H, n, D * kf, D * kf, 6, 6, A.a, 6);
+    add_block(P, lin.H, kf, kf, 0, 0, 6, 6, A.a, 6);
     for (int q = 0; q < 6; ++q) lin.g[D * kf + q] += b[q];
   }
   for (int f = 0; f < P.I; ++f) {
@@ -183,10 +248,10 @@ static void linearize(const Problem& P, const State& s, Lin& lin) {
     const int i = P.p->imu_kf_i[f], j = P.p->imu_kf_j[f];
     const Mat<30, 30> A = J.T() * J;
     const Mat<30, 1> b = J.T() * r;
-    add_block(lin.H, n, 15 * i, 15 * i, 15, 15, &A.a[0], 30);
-    add_block(lin.H, n, 15 * i, 15 * j, 15, 15, &A.a[15], 30);
-    add_block(lin.H, n, 15 * j, 15 * i, 15, 15, &A.a[15 * 30], 30);
-    add_block(lin.H, n, 15 * j, 15 * j, 15, 15, &A.a[15 * 30 + 15], 30);
+    add_block(P, lin.H, i, i, 0, 0, 15, 15, &A.a[0], 30);
+    add_block(P, lin.H, i, j, 0, 0, 15, 15, &A.a[15], 30);
+    add_block(P, lin.H, j, i, 0, 0, 15, 15, &A.a[15 * 30], 30);
+    add_block(P, lin.H, j, j, 0, 0, 15, 15, &A.a[15 * 30 + 15], 30);
     for (int q = 0; q < 15; ++q) { lin.g[15 * i + q] += b[q]; lin.g[15 * j + q] += b[15 + q]; }
   }
   for (int e = 0; e < P.E; ++e) {
@@ -197,30 +262,38 @@ static void linearize(const Problem& P, const State& s, Lin& lin) {
     const Mat<6, 6> A11 = J1.T() * J1, A12 = J1.T() * J2, A22 = J2.T() * J2;
     const Mat<6, 6> A21 = A12.T();
     const Mat<6, 1> b1 = J1.T() * r, b2 = J2.T() * r;
-    add_block(lin.H, n, D * i, D * i, 6, 6, A11.a, 6);
-    add_block(lin.H, n, D * i, D * j, 6, 6, A12.a, 6);
-    add_block(lin.H, n, D * j, D * i, 6, 6, A21.a, 6);
-    add_block(lin.H, n, D * j, D * j, 6, 6, A22.a, 6);
+    add_block(P, lin.H, i, i, 0, 0, 6, 6, A11.a, 6);
+    add_block(P, lin.H, i, j, 0, 0, 6, 6, A12.a, 6);
+    add_block(P, lin.H, j, i, 0, 0, 6, 6, A21.a, 6);
+    add_block(P, lin.H, j, j, 0, 0, 6, 6, A22.a, 6);
     for (int q = 0; q < 6; ++q) { lin.g[D * i + q] += b1[q]; lin.g[D * j + q] += b2[q]; }
   }
   lin.dp2.resize(n);
-  for (int q = 0; q < n; ++q) lin.dp2[q] = lin.H[(size_t)q * n + q];
+  for (int i = 0; i < P.K; ++i) {
+    const double* blk = &lin.H[(size_t)P.pat.find(i, i) * D * D];
+    for (int r = 0; r < D; ++r) lin.dp2[D * i + r] = blk[r * D + r];
+  }
   lin.cost = cost;
 }
 
 static inline double clampd(double h) { return std::min(std::max(std::sqrt(std::max(h, 0.0)), 1e-6), 1e32); }
 
 // damped Schur complement: S = H_pp + mu d_p^2 - sum_l W (H_ll + mu d_l^2)^-1 W^T ; b = -g_p + sum_l W (.)^-1 g_l
+// S is block CSR on Problem::pat.
 static void schur(const Problem& P, const Lin& lin, double mu, std::vector<double>& S, std::vector<double>& b,
                   std::vector<double>& HllInv) {
   const int n = P.n, D = P.D;
   S = lin.H;
   b.resize(n);
-  for (int q = 0; q < n; ++q) {
-    b[q] = -lin.g[q];
-    const double d = clampd(lin.dp2[q]);
-    if (lin.dp2[q] == 0.0) S[(size_t)q * n + q] = 1.0;  // constant / unconstrained dimension
-    else S[(size_t)q * n + q] += mu * d * d;
+  for (int i = 0; i < P.K; ++i) {
+    double* blk = &S[(size_t)P.pat.find(i, i) * D * D];
+    for (int r = 0; r < D; ++r) {
+      const int q = D * i + r;
+      b[q] = -lin.g[q];
+      const double d = clampd(lin.dp2[q]);
+      if (lin.dp2[q] == 0.0) blk[r * D + r] = 1.0;  // constant / unconstrained dimension
+      else blk[r * D + r] += mu * d * d;
+    }
   }
   HllInv.assign((size_t)P.L * 9, 0.0);
   std::vector<double> Y((size_t)P.O * 18);
@@ -261,8 +334,9 @@ static void schur(const Problem& P, const Lin& lin, double mu, std::vector<doubl
         Mat<6, 3> Wb;
         for (int q = 0; q < 18; ++q) Wb[q] = lin.W[(size_t)kb * 18 + q];
         const Mat<6, 6> YW = Ya * Wb.T();
+        double* blk = &S[(size_t)P.pat.find(i, j) * D * D];
         for (int r = 0; r < 6; ++r)
-          for (int c = 0; c < 6; ++c) S[(size_t)(D * i + r) * n + D * j + c] -= YW(r, c);
+          for (int c = 0; c < 6; ++c) blk[r * D + c] -= YW(r, c);
       }
     }
   }
@@ -330,6 +404,22 @@ static void dense_chol_solve(const std::vector<double>& Lf, int n, std::vector<d
   }
 }
 
+// Solve S x = rhs for the block-CSR reduced system: the installed sparse solver (scipy SuperLU) for problems of at
+// least g_sparse_min_n unknowns, else the dense Cholesky above on the expanded matrix. false: not positive definite.
+static bool reduced_solve(const Problem& P, const std::vector<double>& S, std::vector<double>& bx) {
+  if (g_sparse_solver != nullptr && P.n >= g_sparse_min_n) {
+    std::vector<double> x(P.n);
+    if (g_sparse_solver(P.n, P.D, P.K, P.pat.ptr.data(), P.pat.col.data(), S.data(), bx.data(), x.data()) != 0) return false;
+    bx.swap(x);
+    return true;
+  }
+  std::vector<double> M;
+  expand_dense(P, S, M);
+  if (!dense_cholesky(M, P.n)) return false;
+  dense_chol_solve(M, P.n, bx);
+  return true;
+}
+
 // full step (pose part dp given) -> landmark part: dl = (H_ll + mu d^2)^-1 (-g_l - sum W^T dp)
 static void backsub(const Problem& P, const Lin& lin, const std::vector<double>& HllInv, const std::vector<double>& dp,
                     std::vector<double>& dl) {
@@ -352,19 +442,26 @@ static void backsub(const Problem& P, const Lin& lin, const std::vector<double>&
 
 // v^T H v over the full (un-reduced, un-damped) Gauss-Newton matrix
 static double quad_form(const Problem& P, const Lin& lin, const std::vector<double>& vp, const std::vector<double>& vl) {
-  const int n = P.n;
-  double q = 0;
-#pragma omp parallel for reduction(+ : q) schedule(static)
-  for (int r = 0; r < n; ++r) {
-    if (vp[r] == 0.0) continue;
-    const double* hr = &lin.H[(size_t)r * n];
-    double s = 0;
-    for (int c = 0; c < n; ++c) s += hr[c] * vp[c];
-    q += vp[r] * s;
+  const int D = P.D;
+  std::vector<double> qi(P.K, 0.0), ql(P.L, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < P.K; ++i) {
+    double acc = 0;
+    for (int q = P.pat.ptr[i]; q < P.pat.ptr[i + 1]; ++q) {
+      const int j = P.pat.col[q];
+      const double* blk = &lin.H[(size_t)q * D * D];
+      for (int r = 0; r < D; ++r) {
+        if (vp[D * i + r] == 0.0) continue;
+        double s = 0;
+        for (int c = 0; c < D; ++c) s += blk[r * D + c] * vp[D * j + c];
+        acc += vp[D * i + r] * s;
+      }
+    }
+    qi[i] = acc;
   }
-  double q2 = 0;
-#pragma omp parallel for reduction(+ : q2) schedule(static)
+#pragma omp parallel for schedule(static)
   for (int l = 0; l < P.L; ++l) {
+    double q2 = 0;
     const double* H = &lin.Hll[(size_t)l * 9];
     const double* v = &vl[(size_t)l * 3];
     for (int r = 0; r < 3; ++r)
@@ -375,8 +472,12 @@ static double quad_form(const Problem& P, const Lin& lin, const std::vector<doub
       for (int r = 0; r < 6; ++r)
         for (int c = 0; c < 3; ++c) q2 += 2.0 * vp[P.D * i + r] * W[r * 3 + c] * v[c];
     }
+    ql[l] = q2;
   }
-  return q + q2;
+  double q = 0;
+  for (double v : qi) q += v;
+  for (double v : ql) q += v;
+  return q;
 }
 
 static State apply_step(const Problem& P, const State& s, const std::vector<double>& dp, const std::vector<double>& dl) {
@@ -424,9 +525,8 @@ static int solve(Problem& P, State& x, covgpu_result* res) {
     if (o.strategy == COVGPU_LM) {
       auto t0 = std::chrono::steady_clock::now();
       schur(P, lin, 1.0 / radius, S, b, HllInv);
-      ok = dense_cholesky(S, n);
+      ok = reduced_solve(P, S, b);
       if (ok) {
-        dense_chol_solve(S, n, b);
         stp = b;
         backsub(P, lin, HllInv, stp, stl);
       }
@@ -444,11 +544,10 @@ static int solve(Problem& P, State& x, covgpu_result* res) {
         ok = false;
         while (mu < 1.0) {
           schur(P, lin, mu, S, b, HllInv);
-          if (dense_cholesky(S, n)) { ok = true; break; }
+          if (reduced_solve(P, S, b)) { ok = true; break; }
           mu *= 10.0;
         }
         if (ok) {
-          dense_chol_solve(S, n, b);
           gn_p = b;
           backsub(P, lin, HllInv, gn_p, gn_l);
         }
@@ -630,6 +729,44 @@ int covo_linearize_between(const covgpu_options* opt, const covgpu_problem* p, d
   return COVGPU_OK;
 }
 
+// Install (fn != NULL) or remove the sparse linear solver used for reduced systems with >= min_n unknowns.
+void covo_set_sparse_solver(covo_sparse_solver_fn fn, int min_n) { g_sparse_solver = fn; g_sparse_min_n = min_n; }
+
+// Block-sparse reduced system at the initial estimate: pattern sizes first (blocks == NULL), then the data.
+// ptr[K+1], col[nnzb], blocks[nnzb][D*D], b[n]; returns nnzb.
+int covo_schur_sparse(const covgpu_options* opt, const covgpu_problem* p, int pgo, double mu, int* ptr, int* col, double* blocks, double* b,
+                      double* cost) {
+  Problem P;
+  setup(P, p, opt, pgo != 0);
+  if (blocks == nullptr) return (int)P.pat.nnzb();
+  State x = initial_state(P);
+  Lin lin;
+  linearize(P, x, lin);
+  std::vector<double> Sv, bv, Hi;
+  schur(P, lin, mu, Sv, bv, Hi);
+  std::copy(P.pat.ptr.begin(), P.pat.ptr.end(), ptr);
+  std::copy(P.pat.col.begin(), P.pat.col.end(), col);
+  std::copy(Sv.begin(), Sv.end(), blocks);
+  std::copy(bv.begin(), bv.end(), b);
+  if (cost) *cost = lin.cost;
+  return (int)P.pat.nnzb();
+}
+
+// H_ll (3x3 per landmark, undamped) at the estimate held in `p`: conditioning of each landmark for the parity criteria
+int covo_landmark_hessians(const covgpu_options* opt, const covgpu_problem* p, double* Hll /* [L][9] */) {
+  Problem P;
+  covgpu_options o = *opt; o.visual_only = 1;
+  setup(P, p, &o, false);
+  State x = initial_state(P);
+#pragma omp parallel for schedule(static)
+  for (int l = 0; l < P.L; ++l) {
+    Mat3 Hl;
+    for (int k = p->lm_obs_ptr[l]; k < p->lm_obs_ptr[l + 1]; ++k) { ObsLin ol; eval_obs(P, x, k, true, &ol); Hl += ol.Jl.T() * ol.Jl; }
+    for (int q = 0; q < 9; ++q) Hll[(size_t)l * 9 + q] = Hl[q];
+  }
+  return COVGPU_OK;
+}
+
 int covo_reduced_dim(const covgpu_options* opt, const covgpu_problem* p) { return (opt->visual_only ? 6 : 15) * p->num_kf; }
 
 // pgo != 0: pose-graph problem (6 per KF, edges only)
@@ -641,7 +778,9 @@ int covo_schur(const covgpu_options* opt, const covgpu_problem* p, int pgo, doub
   linearize(P, x, lin);
   std::vector<double> Sv, bv, Hi;
   schur(P, lin, mu, Sv, bv, Hi);
-  std::copy(Sv.begin(), Sv.end(), S);
+  std::vector<double> M;
+  expand_dense(P, Sv, M);
+  std::copy(M.begin(), M.end(), S);
   std::copy(bv.begin(), bv.end(), b);
   *cost = lin.cost;
   return COVGPU_OK;
@@ -656,9 +795,10 @@ int covo_dense_step(const covgpu_options* opt, const covgpu_problem* p, double m
   Lin lin;
   linearize(P, x, lin);
   const int n = P.n, N = n + 3 * P.L;
-  std::vector<double> A((size_t)N * N, 0.0), rhs(N);
+  std::vector<double> A((size_t)N * N, 0.0), rhs(N), Hd;
+  expand_dense(P, lin.H, Hd);
   for (int r = 0; r < n; ++r) {
-    for (int c = 0; c < n; ++c) A[(size_t)r * N + c] = lin.H[(size_t)r * n + c];
+    for (int c = 0; c < n; ++c) A[(size_t)r * N + c] = Hd[(size_t)r * n + c];
     const double d = clampd(lin.dp2[r]);
     if (lin.dp2[r] == 0.0) A[(size_t)r * N + r] = 1.0; else A[(size_t)r * N + r] += mu * d * d;
     rhs[r] = -lin.g[r];
@@ -695,8 +835,7 @@ int covo_schur_step(const covgpu_options* opt, const covgpu_problem* p, double m
   linearize(P, x, lin);
   std::vector<double> S, b, Hi, dlv;
   schur(P, lin, mu, S, b, Hi);
-  if (!dense_cholesky(S, P.n)) return COVGPU_ERR_NUMERIC;
-  dense_chol_solve(S, P.n, b);
+  if (!reduced_solve(P, S, b)) return COVGPU_ERR_NUMERIC;
   backsub(P, lin, Hi, b, dlv);
   std::copy(b.begin(), b.end(), dp);
   std::copy(dlv.begin(), dlv.end(), dl);

@@ -21,7 +21,7 @@ extern "C" {
 Handle* shim_build(int K, const int* kf_id, const int* kf_client, const unsigned char* kf_invalid, const unsigned char* kf_loaded,
                    const unsigned char* kf_gba, const double* pose, const double* pose_vio, const double* vel, const double* ba,
                    const double* bg, const int* pred, const int* succ, const int* kf_cam, const double* cam_extr, const double* cam_intr,
-                   const double* cam_dist, const int* cam_type, const long* imu_ptr, const double* imu_samples, const double* imu_first,
+                   const double* cam_dist, const int* cam_type, const double* cam_imu_calib, const long* imu_ptr, const double* imu_samples, const double* imu_first,
                    int L, const double* lm_pos, const unsigned char* lm_invalid, const int* lm_ref, const int* lm_obs_ptr, const int* obs_kf,
                    const float* obs_uv, const int* obs_octave, int NL, const int* loop_kf1, const int* loop_kf2, const double* loop_T,
                    const double* loop_cov, int id_map) {
@@ -38,6 +38,7 @@ Handle* shim_build(int K, const int* kf_id, const int* kf_client, const unsigned
     kf->SetStateExtrinsics(pose_to_mat(cam_extr + 7 * c));
     for (int i = 0; i < 4; ++i) { kf->camera_.intr[i] = cam_intr[4 * c + i]; kf->camera_.dist[i] = cam_dist[4 * c + i]; }
     kf->camera_.dist_type = cam_type[c];
+    for (int i = 0; i < 5; ++i) kf->imu_calib_[i] = cam_imu_calib[5 * c + i];
     Vec3 v, a, g;
     for (int i = 0; i < 3; ++i) { v[i] = vel[3 * k + i]; a[i] = ba[3 * k + i]; g[i] = bg[3 * k + i]; }
     kf->SetStateVelocity(v); kf->SetStateBias(a, g);
@@ -86,12 +87,16 @@ void shim_free(Handle* h) { delete h; }
 
 // flattening only (no GPU): sizes, then arrays on a second call
 int shim_flatten_gba(Handle* h, int visual_only, int round2, int* sizes /* K L O I E S */, double* pose, unsigned char* fixed, double* lm,
-                     int* obs_ptr, int* obs_kf, double* uv, double* sigma, int* imu_i, int* imu_j, int* ei, int* ej, double* loss) {
+                     int* obs_ptr, int* obs_kf, double* uv, double* sigma, int* imu_i, int* imu_j, int* ei, int* ej, double* loss, double* noise, int* kf_cam,
+                     int* ncam) {
   covins_gpu::detail::Flat f; Opt::Index ix;
   Opt::FlattenGBA(h->map, visual_only != 0, round2 != 0, f, ix);
   covgpu_problem p = f.view();
   sizes[0] = p.num_kf; sizes[1] = p.num_lm; sizes[2] = p.num_obs; sizes[3] = p.num_imu; sizes[4] = p.num_edge; sizes[5] = p.num_imu_samples;
+  if (ncam) *ncam = p.num_cam;
   if (!pose) return 0;
+  if (noise) std::memcpy(noise, f.noise.data(), f.noise.size() * 8);
+  if (kf_cam) std::memcpy(kf_cam, f.kf_cam.data(), f.kf_cam.size() * 4);
   std::memcpy(pose, f.pose.data(), f.pose.size() * 8); std::memcpy(fixed, f.fixed.data(), f.fixed.size());
   std::memcpy(lm, f.lm.data(), f.lm.size() * 8); std::memcpy(obs_ptr, f.obs_ptr.data(), f.obs_ptr.size() * 4);
   std::memcpy(obs_kf, f.obs_kf.data(), f.obs_kf.size() * 4); std::memcpy(uv, f.uv.data(), f.uv.size() * 8);
@@ -116,6 +121,8 @@ void shim_set_params(int strategy, const char* placerec_type) {
   Opt::params().strategy = strategy;
   Opt::params().placerec_type = placerec_type;
 }
+void shim_set_flatten_threads(int n) { Opt::params().flatten_threads = n; }
+void shim_set_invalid(Handle* h, int kf) { h->kfs[kf]->SetInvalid(); }
 
 void shim_get_state(Handle* h, double* pose, double* vel, double* ba, double* bg, unsigned char* kf_gba, double* lm, unsigned char* lm_invalid,
                     int* lm_nobs) {

@@ -47,6 +47,7 @@ class Keyframe : public std::enable_shared_from_this<Keyframe> {
   // raw IMU between predecessor and this keyframe (what robopt::imu::PreintegrationBase buffers)
   std::vector<std::array<double, 7>> imu_;  // dt, acc, gyr
   double acc0_[3] = {0, 0, 0}, gyr0_[3] = {0, 0, 0};
+  double imu_calib_[5] = {0, 0, 0, 0, 0};  // VICalibration: sigma_a_c sigma_g_c sigma_aw_c sigma_gw_c g (typedefs_base.hpp:333-340)
 
   bool IsInvalid() const { return invalid_; }
   void SetInvalid() { invalid_ = true; }
@@ -140,6 +141,7 @@ struct Types {
   static void imu_first(const Keyframe& kf, double acc0[3], double gyr0[3]) {
     for (int k = 0; k < 3; ++k) { acc0[k] = kf.acc0_[k]; gyr0[k] = kf.gyr0_[k]; }
   }
+  static void imu_calib(const Keyframe& kf, double out5[5]) { for (int k = 0; k < 5; ++k) out5[k] = kf.imu_calib_[k]; }
 };
 
 }  // namespace standin

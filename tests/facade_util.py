@@ -25,6 +25,8 @@ def lib():
         _LIB.shim_free.argtypes = [C.c_void_p]
         _LIB.shim_gba.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         _LIB.shim_set_params.argtypes = [C.c_int, C.c_char_p]
+        _LIB.shim_set_flatten_threads.argtypes = [C.c_int]
+        _LIB.shim_set_invalid.argtypes = [C.c_void_p, C.c_int]
     return _LIB
 
 
@@ -43,7 +45,7 @@ class StandinMap:
             kf_id=i32(m.kf_id), kf_client=i32(m.kf_client), inv=u8(m.kf_invalid), loaded=u8(m.kf_loaded), gba=u8(m.kf_gba_optimized),
             pose=f64(m.kf_pose), vio=f64(m.kf_pose_vio), vel=f64(m.kf_velocity), ba=f64(m.kf_bias_a), bg=f64(m.kf_bias_g),
             pred=i32(m.kf_pred), succ=i32(m.kf_succ), cam=i32(m.kf_cam), extr=f64(m.cam_extr), intr=f64(m.cam_intr), dist=f64(m.cam_dist),
-            ctype=i32(m.cam_dist_type), iptr=np.ascontiguousarray(m.imu_ptr, dtype=np.int64), isamp=f64(m.imu_samples), ifirst=f64(m.imu_first),
+            ctype=i32(m.cam_dist_type), cimu=f64(m.cam_imu_calib), iptr=np.ascontiguousarray(m.imu_ptr, dtype=np.int64), isamp=f64(m.imu_samples), ifirst=f64(m.imu_first),
             lm=f64(m.lm_pos), lminv=u8(m.lm_invalid), lmref=i32(m.lm_ref_kf), optr=i32(m.lm_obs_ptr), okf=i32(m.obs_kf),
             ouv=np.ascontiguousarray(m.obs_uv, dtype=np.float32), ooct=i32(m.obs_octave),
             l1=i32([l.kf1 for l in m.loops]), l2=i32([l.kf2 for l in m.loops]),
@@ -52,7 +54,7 @@ class StandinMap:
         self.h = C.c_void_p(lib().shim_build(
             C.c_int(m.K), _p(k["kf_id"], C.c_int), _p(k["kf_client"], C.c_int), _p(k["inv"], C.c_ubyte), _p(k["loaded"], C.c_ubyte),
             _p(k["gba"], C.c_ubyte), _p(k["pose"]), _p(k["vio"]), _p(k["vel"]), _p(k["ba"]), _p(k["bg"]), _p(k["pred"], C.c_int),
-            _p(k["succ"], C.c_int), _p(k["cam"], C.c_int), _p(k["extr"]), _p(k["intr"]), _p(k["dist"]), _p(k["ctype"], C.c_int),
+            _p(k["succ"], C.c_int), _p(k["cam"], C.c_int), _p(k["extr"]), _p(k["intr"]), _p(k["dist"]), _p(k["ctype"], C.c_int), _p(k["cimu"]),
             _p(k["iptr"], C.c_long), _p(k["isamp"]), _p(k["ifirst"]), C.c_int(m.L), _p(k["lm"]), _p(k["lminv"], C.c_ubyte),
             _p(k["lmref"], C.c_int), _p(k["optr"], C.c_int), _p(k["okf"], C.c_int), _p(k["ouv"], C.c_float), _p(k["ooct"], C.c_int),
             C.c_int(NL), _p(k["l1"], C.c_int), _p(k["l2"], C.c_int), _p(k["lT"]), _p(k["lC"]), C.c_int(m.id_map)))
@@ -64,15 +66,17 @@ class StandinMap:
 
     def flatten_gba(self, visual_only, round2):
         sizes = np.zeros(6, np.int32)
-        lib().shim_flatten_gba(self.h, int(visual_only), int(round2), _p(sizes, C.c_int), *([None] * 12))
+        ncam = C.c_int(0)
+        lib().shim_flatten_gba(self.h, int(visual_only), int(round2), _p(sizes, C.c_int), *([None] * 14), C.byref(ncam))
         K, L, O, I, E, S = [int(x) for x in sizes]
         out = dict(pose=np.zeros((K, 7)), fixed=np.zeros(K, np.uint8), lm=np.zeros((L, 3)), obs_ptr=np.zeros(L + 1, np.int32),
                    obs_kf=np.zeros(O, np.int32), uv=np.zeros((O, 2)), sigma=np.zeros(O), imu_i=np.zeros(I, np.int32), imu_j=np.zeros(I, np.int32),
-                   ei=np.zeros(E, np.int32), ej=np.zeros(E, np.int32), loss=np.zeros(E))
+                   ei=np.zeros(E, np.int32), ej=np.zeros(E, np.int32), loss=np.zeros(E), noise=np.zeros((I, 5)), kf_cam=np.zeros(K, np.int32))
         lib().shim_flatten_gba(self.h, int(visual_only), int(round2), _p(sizes, C.c_int), _p(out["pose"]), _p(out["fixed"], C.c_ubyte), _p(out["lm"]),
                                _p(out["obs_ptr"], C.c_int), _p(out["obs_kf"], C.c_int), _p(out["uv"]), _p(out["sigma"]), _p(out["imu_i"], C.c_int),
-                               _p(out["imu_j"], C.c_int), _p(out["ei"], C.c_int), _p(out["ej"], C.c_int), _p(out["loss"]))
+                               _p(out["imu_j"], C.c_int), _p(out["ei"], C.c_int), _p(out["ej"], C.c_int), _p(out["loss"]), _p(out["noise"]), _p(out["kf_cam"], C.c_int), None)
         out["sizes"] = (K, L, O, I, E, S)
+        out["num_cam"] = int(ncam.value)
         return out
 
     def gba(self, iterations, visual_only=False, outlier_removal=True):

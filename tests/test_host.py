@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     # sizes are fixed by the field lists in include/covgpu.h (LP64)
     assert C.sizeof(capi.Options) == 4 * 4 + 12 * 8 + 2 * 4
-    assert C.sizeof(capi.ProblemStruct) == 8 * 4 + 23 * 8
+    assert C.sizeof(capi.ProblemStruct) == 8 * 4 + 24 * 8
     assert C.sizeof(capi.Result) == 4 * 4 + 6 * 8 + 64 * 8 * 2 + 64 * 4
 
 

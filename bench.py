@@ -8,11 +8,10 @@ iteration cap (opt.gba_iteration_limit = 10): preintegration, then per trust-reg
 linearise + Schur + dense MFMA Cholesky + step + cost evaluation. Inputs are uploaded to HBM before the
 timed region; every step restarts from the same uploaded initial estimate.
 
-N > 1: one process per GPU (torch.distributed / RCCL used for the barrier and the max-over-ranks only).
-Round 1 shards by MAP — the unit the reference itself runs concurrently (one exclusively checked-out map
-per optimisation call, backend.cpp:134, placerec_be.cpp:295): every rank optimises its own 5-agent map
-(different seed), no data-path collective, weak scaling. The agent-sharded single map with RCCL all-reduce
-on shared pose blocks is the next multi-GPU step.
+The timed region runs WITHOUT profiling events; one extra, un-timed step with profiling on supplies the phase times
+and the per-launch kernel durations of the `roofline` object. `cpu_baseline` runs the oracle (CPU port of the same
+algorithm; block-sparse reduced system solved by scipy's SuperLU) on THE SAME workload in the same run and
+`delta_ate_gpu_cpu_m` compares the two final trajectories (north star: within 1e-3 m).
 
 Prints ONE JSON line on rank 0.
 """
@@ -32,28 +31,38 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X FP64 vector/matrix peak (BASELINE.md, 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(strategy: int):
-    """Oracle (CPU port of the same algorithm) on a bounded sample of the same workload family, timed on
-    this box's host cores. The reference binary itself cannot be built here."""
-    from covins_amd import mapdata, synth
+def cpu_baseline(prob, strategy: int, iterations: int, truth_xyz):
+    """Oracle (CPU port of the same algorithm) on THE SAME problem, timed on this box's host cores in this run. The
+    reference binary itself cannot be built here (Ceres / robopt / aslam absent). Linearisation and the
+    landmark Schur complement run on all OpenMP threads; the block-sparse reduced camera system (what Ceres hands to
+    CHOLMOD) is solved by scipy's SuperLU (one thread)."""
+    from covins_amd import synth
     from oracle import covo
-    cfg = synth.config_named("mh01")
-    cfg.max_kf_per_agent = 300
-    m = synth.make_map(cfg)
-    p, _ = mapdata.flatten_gba(m, False, True)
-    o = covo.default_options(max_iterations=3, strategy=strategy)
-    covo.gba_solve(p, covo.default_options(max_iterations=1))  # warm the thread pool / page in
+    covo.use_sparse_solver(min_n=3000)
+    o = covo.default_options(max_iterations=iterations, strategy=strategy)
+    covo.solver_stats.update(calls=0, seconds=0.0)
     t0 = time.perf_counter()
-    _, res = covo.gba_solve(p, o)
+    q, res = covo.gba_solve(prob, o)
     dt = time.perf_counter() - t0
-    return {
+    return q, {
         "value": res.iterations / dt, "unit": "GBA iterations/s", "cores": int(covo.lib().covo_num_threads()),
         "kind": "port",
-        "sample": f"single-agent MH_01-shaped sub-map, K={p.K} L={p.L} O={p.O} (n={15 * p.K}), "
-                  f"{res.iterations} dogleg iterations, {dt:.1f} s; NOT the 5-agent map (its dense n=33k solve "
-                  f"would take the scalar-blocked CPU port minutes per iteration)",
-        "kf_per_s": p.K * res.iterations / dt,
+        "sample": f"the timed workload itself: K={prob.K} L={prob.L} O={prob.O} (15K={15 * prob.K}), all {res.iterations} "
+                  f"trust-region iterations, {dt:.1f} s of which {covo.solver_stats['seconds']:.1f} s in SuperLU (serial)",
+        "kf_per_s": prob.K * res.iterations / dt, "final_cost": res.final_cost,
+        "ate_rmse_m_final": synth.ate_rmse(q.kf_pose[:, 4:], truth_xyz),
     }
+
+
+def _kernels_digest():
+    """sha256 over the HIP sources: a counter file collected on other kernels is stale."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "covins_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def main():
@@ -89,7 +98,6 @@ def main():
 
     for _ in range(args.warmup):
         ctx.solve_resident(opt)
-    ctx.set_profiling(True)
     distrib.barrier(dist, dev)
     t0 = time.perf_counter()
     iters = 0
@@ -99,22 +107,27 @@ def main():
         iters += res.iterations
     distrib.barrier(dist, dev)
     dt = time.perf_counter() - t0
-    prof = ctx.profile()
     dt, iters_all = distrib.aggregate(dt, iters, dist, dev)
+    # one more step, NOT timed, with HIP events around the build pass, the factor+solve and every trailing-update launch
+    ctx.set_profiling(True)
+    ctx.solve_resident(opt)
+    prof = ctx.profile()
+    ctx.set_profiling(False)
+    lay = ctx.layout()
 
     if rank == 0:
-        # HBM traffic per launch of the dominant kernel: PMC counters cannot be read inside this process, so the
-        # number comes from the committed counter pass of the same command (profiles/r01_pmc_traffic.json)
-        traffic = None
-        mfma_busy = None
+        # HBM traffic of the dominant kernel cannot be read inside this process (PMC counters need rocprofv3):
+        # tools/pmc_pass.sh runs the counter passes of THIS command and stamps the result with the git SHA and the kernel
+        # name; a stale or foreign file is refused and `traffic` stays null.
+        traffic, mfma_busy, traffic_src = None, None, None
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pj.get("workload") == args.workload:
-                k = pj["kernels"]["k_gemm_abt<SYRK_TRI>"]  # = k_gemm_abt<0, 128, 128>
-                traffic = k["fetch_bytes_x2"] + k["write_bytes"]
-                mfma_busy = k.get("mfma_busy_frac")
+            import subprocess
+            sha = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")))
+            if pj.get("workload") == args.workload and pj.get("kernels_sha256") == _kernels_digest() and "k_gemm_abt<0" in pj.get("kernel", ""):
+                traffic = pj["fetch_bytes_x2"] + pj["write_bytes"]; mfma_busy = pj.get("mfma_busy_frac"); traffic_src = pj.get("git_sha", sha)
         except Exception:
-            traffic = None
+            pass
         sol = ctx.download()
         truth = m.truth["kf_pose"][:, 4:]
         n = 15 * prob.K
@@ -129,10 +142,15 @@ def main():
             "value": iters_all / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "timed_region": "profiling events off; phase / kernel figures below come from one extra un-timed step",
             "config": {"workload": f"{args.workload}: {len(cfg.agents)}-agent EuRoC MH-shaped merged map per GPU, visual-inertial GBA "
                                    f"(K={prob.K} keyframes, L={prob.L} landmarks, O={prob.O} observations, I={prob.I} IMU factors, "
                                    f"E={prob.E} loop edges; reduced camera system 15K={n}: speed-bias chains eliminated block-tridiagonally, "
-                                   f"dense MFMA Cholesky on the 6K={6 * prob.K} pose system)",
+                                   + (f"pose system 6K={6 * prob.K} as {lay['blocks']} agent blocks (<= {lay['interior_kf_padded']} interior keyframes) + "
+                                      f"{lay['border_kf']} shared keyframes, batched MFMA Cholesky + dense border solve)" if lay["arrow"] else
+                                      f"dense MFMA Cholesky on the 6K={6 * prob.K} pose system)"),
+                       "layout": lay,
+                       "nnzS_fill": (2 * prof["offdiag_blocks"] + prob.K) / float(prob.K) ** 2,
                        "strategy": args.strategy, "iterations_per_step": args.iterations, "sharding": "one map per GPU"},
             "kf_per_s": k_free * iters_all / dt,
             "iterations_executed": iters_all,
@@ -146,8 +164,9 @@ def main():
             "roofline": {"kernel": "k_gemm_abt<SYRK_TRI> (rank-256 trailing update of the dense FP64 Cholesky, v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
-                         "mfma_busy_frac_pmc": mfma_busy,  # SQ_VALU_MFMA_BUSY_CYCLES share of SIMD-cycles (profiles/r01z_pmc_mfma.csv)
-                         "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes in profiles/r01z_pmc_hbm_traffic.csv)",
+                         "mfma_busy_frac_pmc": mfma_busy,
+                         "traffic_note": ("HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from tools/pmc_pass.sh at " + str(traffic_src)) if traffic is not None
+                                         else "null: no counter pass of these kernel sources (tools/pmc_pass.sh writes profiles/pmc_traffic_current.json)",
                          "launches": prof["n_syrk"], "avg_launch_ms": prof["syrk_ms"] / max(prof["n_syrk"], 1),
                          "dense_stage_order": 6 * prob.K,
                          "dense_factorisation_tflops_incl_panels_and_solves": ((6.0 * prob.K) ** 3 / 3.0) / (prof["factor_ms"] / max(prof["n_factor"], 1) * 1e-3) / 1e12
@@ -185,7 +204,10 @@ def main():
             out["pgo_call"] = {"t_call_s": time.perf_counter() - t_p, "iterations": pres.iterations, "edges": int(pgo_prob.E),
                                "initial_cost": pres.initial_cost, "final_cost": pres.final_cost}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(strategy)
+            qc, out["cpu_baseline"] = cpu_baseline(prob, strategy, args.iterations, truth)
+            out["delta_ate_gpu_cpu_m"] = abs(out["ate_rmse_m"]["final"] - out["cpu_baseline"]["ate_rmse_m_final"])
+            out["max_pose_diff_gpu_cpu_m"] = float(np.abs(sol.kf_pose[:, 4:] - qc.kf_pose[:, 4:]).max())
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

@@ -47,6 +47,8 @@ def lib() -> C.CDLL:
         _LIB.covgpu_set_profiling.restype = None
         _LIB.covgpu_get_profile.argtypes = [C.c_void_p, capi._dp]
         _LIB.covgpu_get_profile.restype = None
+        _LIB.covgpu_get_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        _LIB.covgpu_get_layout.restype = None
     return _LIB
 
 
@@ -57,6 +59,15 @@ def pgo_partition(num_kf: int, edge_i, edge_j):
     ei = np.ascontiguousarray(edge_i, np.int32); ej = np.ascontiguousarray(edge_j, np.int32)
     out = np.empty(num_kf, np.int32)
     n = lib().covgpu_pgo_partition(num_kf, len(ei), ei.ctypes.data_as(capi._ip), ej.ctypes.data_as(capi._ip), out.ctypes.data_as(capi._ip))
+    return out, int(n)
+
+
+def gba_partition(prob: FlatProblem, opt: Options, force: bool = False):
+    """Host-only: block index per keyframe (-1 = border / shared keyframe) and the number of blocks (0 = dense form) of
+    the block-arrow GBA solve (covgpu_gba_partition, include/covgpu.h)."""
+    out = np.empty(prob.K, np.int32)
+    s = prob.as_struct()
+    n = lib().covgpu_gba_partition(C.byref(opt), C.byref(s), int(force), out.ctypes.data_as(capi._ip))
     return out, int(n)
 
 
@@ -129,6 +140,13 @@ class Context:
         return dict(build_ms=out[0], n_build=int(out[1]), factor_ms=out[2], n_factor=int(out[3]), syrk_ms=out[4],
                     n_syrk=int(out[5]), syrk_flops=out[6], offdiag_blocks=int(out[7]))
 
+    def layout(self) -> dict:
+        out = (C.c_int64 * 16)()
+        lib().covgpu_get_layout(self._h, out)
+        keys = ("arrow", "blocks", "border_kf", "interior_kf_padded", "arrow_order", "border_order", "dense_order", "covisible_pairs",
+                "edge_pairs", "chains", "device_mib")
+        return {k: int(out[i]) for i, k in enumerate(keys)}
+
     # ---- per-kernel entry points (tests)
     def residual_norms(self, prob, opt):
         out = np.zeros(prob.O); s = prob.as_struct()
@@ -170,6 +188,14 @@ class Context:
         fn = lib().covgpu_schur_pgo if pgo else lib().covgpu_schur
         self._check(fn(self._h, C.byref(opt), C.byref(s), float(mu), dptr(S), dptr(b), dptr(c)))
         return S, b, float(c[0])
+
+    def gn_step(self, prob, opt, mu):
+        """One damped Gauss-Newton step through the product solve path: (dx[n], dl[L,3], cost)."""
+        n = (6 if opt.visual_only else 15) * prob.K
+        dx, dl, c = np.zeros(n), np.zeros((prob.L, 3)), np.zeros(1)
+        s = prob.as_struct()
+        self._check(lib().covgpu_gn_step(self._h, C.byref(opt), C.byref(s), float(mu), dptr(dx), dptr(dl), dptr(c)))
+        return dx, dl, float(c[0])
 
     def solve_reduced(self, S, b):
         S = np.ascontiguousarray(S, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)

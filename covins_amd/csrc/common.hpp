@@ -106,7 +106,42 @@ struct DevProblem {
   int nepairs;
   int *epair_ptr, *epair_i, *epair_j, *epair_ent;  // unique pose pairs (chain-major positions i > j) -> edges (edge*2 + transposed)
   int* flag;       // [4]  device flags (Cholesky failure)
+
+  // ---- block-arrow layout of the pose-pose system (k_arrow.hip). arrow == 0: the dense Sred above.
+  // Agents couple with each other only where landmarks were fused / loops closed; a vertex cover of those cross-agent
+  // links (the "shared" keyframes) forms the border, every agent's remaining keyframes one independent block. The
+  // pose system is BUILT directly into [interior | own border] arrow buffers and the border system: no dense C.
+  int arrow;
+  int ar_nblk, ar_ntot, ar_nIpad, ar_nb, ar_nbk;  // blocks | padded order of one arrow buffer | padded interior order | padded border order | border keyframes
+  int* ar_blk;     // [K] by chain position: block id >= 0 (interior) | -1 border | -2 keyframe of another shard (never touched here)
+  int* ar_loc;     // [K] by chain position: pose index inside its block (interior) | border index (border)
+  int* ar_own;     // [nblk][nbk] border index -> pose index inside the block's own-border part, or -1
+  int* ar_nint;    // [nblk] interior keyframes per block
+  int* ar_bpos;    // [nbk] border index -> chain position
+  double *ar_M, *ar_rhs, *ar_Linv;     // [nblk][ntot][ntot] | [nblk][2 ntot] | [nblk][nIpad/128][128][128]
+  double *ar_Sb, *ar_rhsb, *ar_Linvb;  // [nb][nb] | [2 nb] | [nb/128][128][128]
 };
+
+// address of entry (r, c) of the 6x6 pose-pose block (pi, pj), chain positions pi >= pj; for pi == pj only c <= r is stored.
+// Arrow layout: local indices follow chain position, so interior-interior and border-border blocks keep their
+// orientation; an (interior, border) pair whose INTERIOR keyframe has the higher position is stored transposed (the
+// border rows come last in every arrow buffer).
+__device__ __forceinline__ double* c_entry(const DevProblem& P, int pi, int pj, int r, int c) {
+  if (!P.arrow) return P.Sred + (size_t)(6 * pi + r) * P.npad + (6 * pj + c);
+  const int bi = P.ar_blk[pi], bj = P.ar_blk[pj], li = P.ar_loc[pi], lj = P.ar_loc[pj];
+  const size_t nt = (size_t)P.ar_ntot;
+  if (bi >= 0) {
+    double* M = P.ar_M + (size_t)bi * nt * nt;
+    if (bj >= 0) return M + (size_t)(6 * li + r) * nt + (6 * lj + c);  // same block (plan invariant: no link joins two interiors)
+    const int o = P.ar_own[(size_t)bi * P.ar_nbk + lj];
+    return M + (size_t)(P.ar_nIpad + 6 * o + c) * nt + (6 * li + r);
+  }
+  if (bj >= 0) {
+    const int o = P.ar_own[(size_t)bj * P.ar_nbk + li];
+    return P.ar_M + (size_t)bj * nt * nt + (size_t)(P.ar_nIpad + 6 * o + r) * nt + (6 * lj + c);
+  }
+  return P.ar_Sb + (size_t)(6 * li + r) * P.ar_nb + (6 * lj + c);
+}
 
 // ---- scalar slots in DevProblem::scal
 enum { SC_COST = 0, SC_JV2 = 1, SC_GG = 2, SC_GN2 = 3, SC_GDOT = 4, SC_GMAX = 5, SC_GS = 6, SC_SN2 = 7, SC_XN2 = 8, SC_COUNT = 16 };
@@ -181,6 +216,20 @@ struct PgoPlan {
   double *Sb = nullptr, *rhs_b = nullptr, *Linv_b = nullptr;
 };
 void launch_pgo_block_solve(const DevProblem& P, PgoPlan& plan, hipStream_t st, CholAux& ax);
+
+// ---- block-arrow GBA solve (k_arrow.hip)
+struct ArrowHostPlan {
+  int nblk = 0, nbk = 0, max_int = 0, max_own = 0;
+  std::vector<int> blk, loc;            // by chain position (see DevProblem::ar_blk / ar_loc)
+  std::vector<int> nint, bpos;          // interior keyframes per block | border index -> position
+  std::vector<std::vector<int>> own;    // per block: border indices of its own-border part, ascending
+};
+// positions are chain-major; pair / epair lists are the covisible and edge keyframe pairs (i > j). Returns false when the
+// arrow form does not pay (single chain, tiny system, border too large): the caller keeps the dense pose system.
+bool gba_plan_analyse(int K, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
+                      const int* epair_i, const int* epair_j, bool force, ArrowHostPlan& out);
+void launch_arrow_zero(const DevProblem& P, hipStream_t st);   // per iteration: clear the buffers, identity on padding rows
+void launch_arrow_solve(const DevProblem& P, hipStream_t st, CholAux& ax);  // P.bp (chain positions) -> solution in place
 
 void launch_dogleg_stats(const DevProblem& P, hipStream_t st);  // GG, GN2, GDOT, GMAX from grad/hdiag/gn
 void launch_cauchy_vec(const DevProblem& P, hipStream_t st);    // vtmp = grad / d^2

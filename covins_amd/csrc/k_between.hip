@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_edge_gather_kf(DevProblem P) {
   const int pos = P.perm[kf];
   if (q < 36) {
     const int r = q / 6, c = q - 6 * r;
-    if (c <= r) P.Sred[(size_t)(6 * pos + r) * P.npad + 6 * pos + c] += acc;
+    if (c <= r) *c_entry(P, pos, pos, r, c) += acc;
   } else if (q < 42) {
     P.grad[(size_t)P.D * kf + q - 36] += acc; P.bred[(size_t)P.D * kf + q - 36] -= acc;
   } else {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_edge_gather_pair(DevProblem P) {
     const double* h = P.edgeOut + (size_t)kEdgeRec * e + 72;   // Hij: rows = dims of edge_i, cols = dims of edge_j
     acc += tr ? h[6 * c + r] : h[6 * r + c];
   }
-  P.Sred[(size_t)(6 * P.epair_i[pr] + r) * P.npad + 6 * P.epair_j[pr] + c] += acc;
+  *c_entry(P, P.epair_i[pr], P.epair_j[pr], r, c) += acc;
 }
 
 __global__ __launch_bounds__(64) void k_edge_jvp(DevProblem P, const double* __restrict__ v_all) {

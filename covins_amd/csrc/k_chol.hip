@@ -543,8 +543,8 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   const int NP = (T + 1) / 2;  // big panels of two tile columns
   // events per big panel: H rows-h done | B bulk done | C rows-r done | 1 potrf(t0) | 2 X(t0+1,t0) | 3 potrf(t0+1) | Rc next diagonal updated
   while ((int)ax.ev.size() < 7 * (NP + 1)) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ax.ev.push_back(e); }
-  if (ax.profile) while ((int)ax.prof_ev.size() < 2 * NP) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev.push_back(e); }
-  ax.prof_flops.clear();
+  // (a solve may factorise several matrices — arrow blocks, then the border system: launches accumulate until collect())
+  if (ax.profile) while (ax.prof_ev.size() < 2 * (ax.prof_flops.size() + (size_t)NP)) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev.push_back(e); }
   hipEvent_t* eH = ax.ev.data();
   hipEvent_t* eB = eH + (NP + 1);
   hipEvent_t* eC = eB + (NP + 1);
@@ -671,7 +671,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, B, g);
       if (ax.profile) {
         (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], B);
-        ax.prof_flops.push_back((double)nt * (nt + 1) / 2 * 2.0 * kTile * kTile * (w * kTile));
+        ax.prof_flops.push_back((double)nbt * nt * (nt + 1) / 2 * 2.0 * kTile * kTile * (w * kTile));
       }
     }
     (void)hipEventRecord(eB[P], B);

@@ -27,14 +27,14 @@ __global__ __launch_bounds__(256) void k_finalize_diag(DevProblem P, double mu, 
   if (q < P.n) {
     const int kf = q / P.D, r = q - kf * P.D, pos = P.perm[kf];
     if (which == 2 || (which == 0) == (r < 6)) {
-      double* d = (r < 6) ? P.Sred + (size_t)(6 * pos + r) * P.npad + (6 * pos + r) : P.Ad + (size_t)81 * pos + 10 * (r - 6);
+      double* d = (r < 6) ? c_entry(P, pos, pos, r, r) : P.Ad + (size_t)81 * pos + 10 * (r - 6);
       const double h = P.hdiag[q];
       if (h == 0.0) { *d = 1.0; P.bred[q] = 0.0; }
       else { const double c = clamp_diag(h); *d += mu * c * c; }
     }
   }
   const int pad = 6 * P.K + q;  // padding rows of C
-  if (which != 1 && q < P.npad - 6 * P.K) P.Sred[(size_t)pad * P.npad + pad] = 1.0;
+  if (which != 1 && !P.arrow && q < P.npad - 6 * P.K) P.Sred[(size_t)pad * P.npad + pad] = 1.0;  // (arrow layout: k_arrow_init)
 }
 
 // fixed-order sum of one slot's partials -> scal[slot]
@@ -138,7 +138,8 @@ void launch_finalize_diag(const DevProblem& P, double mu, int which, hipStream_t
   hipLaunchKernelGGL(k_finalize_diag, dim3((cnt + 255) / 256), dim3(256), 0, st, P, mu, which);
 }
 void launch_zero_system(const DevProblem& P, hipStream_t st) {
-  hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), st);
+  if (P.arrow) launch_arrow_zero(P, st);
+  else hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), st);
   hipMemsetAsync(P.bred, 0, (size_t)P.n * sizeof(double), st);
   if (P.vi) {
     hipMemsetAsync(P.Ad, 0, (size_t)81 * P.K * sizeof(double), st);

@@ -308,7 +308,6 @@ __global__ __launch_bounds__(64 * kImuWaves) void k_imu_build(DevProblem P) {
   const double* Jw = sl + 450;
   const double* r = sl + 1141;
   const int i = P.imu_i[f], j = P.imu_j[f];
-  const size_t ld = (size_t)P.npad;
   // Deterministic scatter of J^T J (30x30; groups P_i(0:6) S_i(6:15) P_j(15:21) S_j(21:30)) and J^T r:
   // every destination has exactly one writer. Blocks that two factors share (a keyframe is the successor of one
   // factor and the predecessor of the next) go to role-indexed slots [role][position] summed by k_imu_gather in a
@@ -360,9 +359,9 @@ __global__ __launch_bounds__(256) void k_imu_gather(DevProblem P, int which) {
   } else if (e < 171) {
     const int q = e - 135, r = q / 6, c = q - 6 * r;
     if (which != 1) {
-      if (c <= r) P.Sred[(size_t)(6 * pos + r) * P.npad + 6 * pos + c] += P.imuCd[36 * s0 + q] + P.imuCd[36 * s1 + q];
+      if (c <= r) *c_entry(P, pos, pos, r, c) += P.imuCd[36 * s0 + q] + P.imuCd[36 * s1 + q];
       const double x = P.imuCd[36 * (2 * K + pos) + q];  // pose_pos x pose_(pos-1) of the factor ending here (exactly 0: none)
-      if (x != 0.0) P.Sred[(size_t)(6 * pos + r) * P.npad + 6 * (pos - 1) + c] += x;
+      if (x != 0.0) *c_entry(P, pos, pos - 1, r, c) += x;
     }
   } else {
     const int q = e - 171, kf = P.pos_kf[pos];

@@ -337,9 +337,10 @@ __global__ __launch_bounds__(256) void k_yty_semisep(DevProblem P) {
 #pragma unroll
       for (int a = 0; a < 6; ++a) acc[a] += sW[r][a] * y;
     }
+    const int pc = c / 6, ec = c - 6 * pc;
 #pragma unroll
     for (int a = 0; a < 6; ++a)
-      if (c <= 6 * j + a) P.Sred[(size_t)(6 * j + a) * ld + c] -= acc[a];
+      if (c <= 6 * j + a) *c_entry(P, j, pc, a, ec) -= acc[a];
   }
 }
 
@@ -507,6 +508,7 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
     hipLaunchKernelGGL(k_yty_semisep, dim3(P.K), dim3(256), 0, st, P);
   }
   if (pgo != nullptr) launch_pgo_block_solve(P, *pgo, st, ax);  // pose graph: block-arrow elimination (k_pgo.hip)
+  else if (P.arrow) launch_arrow_solve(P, st, ax);                // GBA on a fused multi-agent map: block-arrow elimination (k_arrow.hip)
   else dense_cholesky_solve_raw(P.Sred, P.bp, P.Linv, P.flag, P.npad, st, ax);
   if (P.vi) {
     hipLaunchKernelGGL(k_sb_rhs, dim3((9 * P.K + 255) / 256), dim3(256), 0, st, P);

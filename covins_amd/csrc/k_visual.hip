@@ -7,13 +7,18 @@
 // and the landmark half of Ceres' SPARSE_SCHUR (opt_be.cpp:561): H_ll, g_l, S -= W H_ll^-1 W^T, b += W H_ll^-1 g_l
 // (SURVEY.md A.2, A.5, A.6). None of these have a reference source in-tree; the contract is SURVEY.md Appendix A.
 //
-// Kernel shapes:
-//   lm_build   one G-lane sub-wave group per landmark (G = 16: EuRoC-like tracks average ~10 observations),
-//              lane = observation. Jacobians live in VGPRs only; H_ll / g_l are reduced with DPP/ds_bpermute
-//              butterflies inside the group; W blocks are exchanged through LDS (broadcast reads); the 6x6
-//              Schur blocks and the pose-side H_pp / g_p go to HBM with FP64 L2 atomics. No per-observation
-//              intermediate (J, W) is ever written to HBM.
-//   obs_*      one thread per observation over the SoA stream (cost, J*v products, test dumps).
+// Kernel shapes — three deterministic, atomic-free passes:
+//   k_lm_lin       one G-lane sub-wave group per landmark (G = 16: tracks average ~10 observations), lane = observation.
+//                  Jacobians live in VGPRs only; H_ll / g_l are reduced with shuffle butterflies inside the group; per
+//                  observation one record {W = Jp^T Jl, Y = W H_ll^-1, D = Jp^T Jp - Y W^T, diag, Jp^T r, Y g_l} goes to HBM.
+//   k_kf_reduce    one wave per keyframe: fixed-order sum of its observations' records -> diagonal 6x6 block of the pose
+//                  system, gradient, reduced right-hand side, diag(J^T J).
+//   k_pair_blocks  one wave per covisible keyframe pair (host-built lists, static per problem): C[i,j] = -sum Y_i W_j^T
+//                  with plain stores. Every entry has exactly one writer and a fixed summation order: two solves of the
+//                  same problem are bit-identical. (The first version accumulated the 6x6 blocks with FP64 atomics:
+//                  11.1 ms and run-to-run rounding differences; these three passes take 1.6 ms.)
+//   obs_*          one thread per observation over the SoA stream (cost, J*v products, test dumps).
+// All writes to the pose system go through c_entry (common.hpp): dense matrix or block-arrow buffers.
 #include "common.hpp"
 #include "dev_math.hpp"
 #include "reduce.hpp"
@@ -273,12 +278,13 @@ __global__ __launch_bounds__(256) void k_kf_reduce(DevProblem P) {
   if (lane < kRec)
     for (int t = o0; t < o1; ++t) acc += P.obsP[kRec * (size_t)P.kf_obs_idx[t] + lane];
   const double gp = __shfl(acc, (lane >= 33 && lane < 39) ? lane - 6 : lane, 64);  // lanes 33..38 hold yg; fetch the matching gp
-  const size_t ld = (size_t)P.npad, cb = (size_t)6 * P.perm[kf], base = (size_t)P.D * kf;
+  const size_t base = (size_t)P.D * kf;
+  const int pos = P.perm[kf];
   if (lane < 21) {
     int r = 0;
     while ((r + 1) * (r + 2) / 2 <= lane) ++r;
     const int c = lane - r * (r + 1) / 2;
-    P.Sred[(cb + r) * ld + cb + c] = acc;
+    *c_entry(P, pos, pos, r, c) = acc;
   } else if (lane < 27) {
     P.hdiag[base + lane - 21] = acc;
   } else if (lane < 33) {
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(256) void k_pair_blocks(DevProblem P) {
     const double* w = P.obsW + 18 * (size_t)P.pair_ob[e] + 3 * c;
     acc += y[0] * w[0] + y[1] * w[1] + y[2] * w[2];
   }
-  P.Sred[(size_t)(6 * P.pair_i[p] + r) * P.npad + 6 * P.pair_j[p] + c] = -acc;
+  *c_entry(P, P.pair_i[p], P.pair_j[p], r, c) = -acc;
 }
 
 // back-substitution: dl = Hinv (-g_l - sum_a W_a^T dp[kf_a]); written to out_all[n + 3l ..]

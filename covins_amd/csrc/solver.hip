@@ -43,6 +43,7 @@ struct covgpu_context {
   DevProblem P;
   bool have = false, pgo = false;
   std::vector<void*> allocs;
+  size_t alloc_bytes = 0;  // device bytes behind `allocs` (the footprint covgpu_get_layout reports)
   double* h_scal = nullptr;  // pinned mirror of P.scal + flag
   int profiling = 0;
   covgpu_profile_t prof;
@@ -105,6 +106,7 @@ extern "C" int covgpu_create(const covgpu_options* opt, covgpu_context** out) {
 static void free_problem(covgpu_context* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   c->allocs.clear();
+  c->alloc_bytes = 0;
   c->have = false;
   c->pgo_plan.active = false;  // its device buffers were in `allocs`
 }
@@ -131,6 +133,16 @@ extern "C" void covgpu_get_profile(covgpu_context* c, double* out) {
   out[7] = (double)(c->have ? c->P.npairs + c->P.nepairs : 0);  // off-diagonal 6x6 pose-pose blocks of the reduced system (nnzS - K)
 }
 
+// out[16] = { arrow form (0/1), blocks, border keyframes, largest interior (keyframes), arrow buffer order, border system
+//             order, dense order npad, covisible pairs, edge pairs, chains, device bytes allocated for the problem (MiB), 0... }
+extern "C" void covgpu_get_layout(covgpu_context* c, int64_t* out) {
+  for (int i = 0; i < 16; ++i) out[i] = 0;
+  if (!c->have) return;
+  const DevProblem& P = c->P;
+  out[0] = P.arrow; out[1] = P.ar_nblk; out[2] = P.ar_nbk; out[3] = P.arrow ? P.ar_nIpad / 6 : 0; out[4] = P.ar_ntot; out[5] = P.ar_nb;
+  out[6] = P.npad; out[7] = P.npairs; out[8] = P.nepairs; out[9] = P.nchains; out[10] = (int64_t)(c->alloc_bytes >> 20);
+}
+
 template <typename T>
 static int dev_alloc(covgpu_context* c, T** ptr, size_t count) {
   *ptr = nullptr;
@@ -139,6 +151,7 @@ static int dev_alloc(covgpu_context* c, T** ptr, size_t count) {
   hipError_t e = hipMalloc(&p, count * sizeof(T));
   if (e != hipSuccess) { g_err = std::string("hipMalloc: ") + hipGetErrorString(e); return COVGPU_ERR_OUT_OF_MEMORY; }
   c->allocs.push_back(p);
+  c->alloc_bytes += count * sizeof(T);
   *ptr = (T*)p;
   return COVGPU_OK;
 }
@@ -175,7 +188,69 @@ static int validate(const covgpu_problem* p, bool pgo, bool vi) {
   return COVGPU_OK;
 }
 
-static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, bool pgo) {
+// IMU chains (one per agent: predecessor -> successor factors, optimization_be.cpp:369-416) laid out back to back:
+// perm[kf] = chain-major position, pos_kf = inverse, chain_ptr = positions of each chain. Without IMU factors every
+// keyframe is its own position (identity order, one "chain").
+static int build_chains(const covgpu_problem* p, bool vi, std::vector<int>& perm, std::vector<int>& pos_kf, std::vector<int>& chain_ptr) {
+  const int K = p->num_kf, I = vi ? p->num_imu : 0;
+  perm.assign(K, 0); pos_kf.assign(K, 0); chain_ptr.assign(1, 0);
+  if (vi) {
+    std::vector<int> succ(K, -1), has_pred(K, 0);
+    for (int f = 0; f < I; ++f) {
+      const int i = p->imu_kf_i[f], j = p->imu_kf_j[f];
+      if (i == j || succ[i] != -1 || has_pred[j]) { g_err = "invalid problem: IMU factors must form simple predecessor chains"; return COVGPU_ERR_INVALID_ARG; }
+      succ[i] = j; has_pred[j] = 1;
+    }
+    int pos = 0;
+    for (int k = 0; k < K; ++k) {
+      if (has_pred[k]) continue;
+      for (int c = k; c != -1; c = succ[c]) { perm[c] = pos; pos_kf[pos] = c; ++pos; }
+      chain_ptr.push_back(pos);
+    }
+    if (pos != K) { g_err = "invalid problem: IMU factors contain a cycle"; return COVGPU_ERR_INVALID_ARG; }
+  } else {
+    for (int k = 0; k < K; ++k) { perm[k] = k; pos_kf[k] = k; }
+    chain_ptr.push_back(K);
+  }
+  return COVGPU_OK;
+}
+
+// Host-only: the block partition of the GBA pose system (k_arrow.hip). block_of_kf[k] >= 0: block (= agent) whose
+// interior holds keyframe k; -1: border ("shared") keyframe. Returns the number of blocks, 0 if the dense form is kept.
+extern "C" int32_t covgpu_gba_partition(const covgpu_options* opt, const covgpu_problem* p, int32_t force, int32_t* block_of_kf) {
+  const bool vi = !opt->visual_only;
+  for (int k = 0; k < p->num_kf; ++k) block_of_kf[k] = -1;
+  if (validate(p, false, vi) != COVGPU_OK || !vi) return 0;
+  std::vector<int> perm, pos_kf, chain_ptr;
+  if (build_chains(p, vi, perm, pos_kf, chain_ptr) != COVGPU_OK) return 0;
+  // unique covisible pairs (free keyframes only) and edge pairs, as chain-major positions i > j
+  std::vector<long long> keys;
+  for (int l = 0; l < p->num_lm; ++l)
+    for (int a = p->lm_obs_ptr[l]; a < p->lm_obs_ptr[l + 1]; ++a) {
+      if (p->kf_fixed[p->obs_kf[a]]) continue;
+      for (int b = p->lm_obs_ptr[l]; b < p->lm_obs_ptr[l + 1]; ++b) {
+        if (p->kf_fixed[p->obs_kf[b]]) continue;
+        const int pa = perm[p->obs_kf[a]], pb = perm[p->obs_kf[b]];
+        if (pb < pa) keys.push_back(((long long)pa << 32) | (unsigned)pb);
+      }
+    }
+  std::sort(keys.begin(), keys.end()); keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  std::vector<int> pi(keys.size()), pj(keys.size()), ei, ej;
+  for (size_t q = 0; q < keys.size(); ++q) { pi[q] = (int)(keys[q] >> 32); pj[q] = (int)(keys[q] & 0xffffffffll); }
+  for (int e = 0; e < p->num_edge; ++e) {
+    const int a = perm[p->edge_i[e]], b = perm[p->edge_j[e]];
+    if (a == b) return 0;
+    ei.push_back(std::max(a, b)); ej.push_back(std::min(a, b));
+  }
+  ArrowHostPlan hp;
+  if (!gba_plan_analyse(p->num_kf, (int)chain_ptr.size() - 1, chain_ptr.data(), (int)pi.size(), pi.data(), pj.data(), (int)ei.size(), ei.data(), ej.data(),
+                        force != 0, hp))
+    return 0;
+  for (int k = 0; k < p->num_kf; ++k) block_of_kf[k] = hp.blk[perm[k]];
+  return hp.nblk;
+}
+
+static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, bool pgo, bool allow_arrow = true) {
   HIPCHK(hipSetDevice(c->device));
   const bool vi = !pgo && !opt->visual_only;
   RC(validate(p, pgo, vi));
@@ -190,25 +265,9 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   P.npad = ((6 * P.K + kTile - 1) / kTile) * kTile;  // dense stage = pose-pose system only (k_struct.hip)
   P.N = P.n + 3 * P.L;
   // IMU chains -> chain-major keyframe order
-  std::vector<int> perm(P.K), pos_kf(P.K), chain_ptr(1, 0), chain_end(P.K);
-  if (vi) {
-    std::vector<int> succ(P.K, -1), has_pred(P.K, 0);
-    for (int f = 0; f < P.I; ++f) {
-      const int i = p->imu_kf_i[f], j = p->imu_kf_j[f];
-      if (i == j || succ[i] != -1 || has_pred[j]) { g_err = "invalid problem: IMU factors must form simple predecessor chains"; return COVGPU_ERR_INVALID_ARG; }
-      succ[i] = j; has_pred[j] = 1;
-    }
-    int pos = 0;
-    for (int k = 0; k < P.K; ++k) {
-      if (has_pred[k]) continue;
-      for (int c = k; c != -1; c = succ[c]) { perm[c] = pos; pos_kf[pos] = c; ++pos; }
-      chain_ptr.push_back(pos);
-    }
-    if (pos != P.K) { g_err = "invalid problem: IMU factors contain a cycle"; return COVGPU_ERR_INVALID_ARG; }
-  } else {
-    for (int k = 0; k < P.K; ++k) { perm[k] = k; pos_kf[k] = k; }
-    chain_ptr.push_back(P.K);
-  }
+  std::vector<int> perm, pos_kf, chain_ptr;
+  RC(build_chains(p, vi, perm, pos_kf, chain_ptr));
+  std::vector<int> chain_end(P.K);
   P.nchains = (int)chain_ptr.size() - 1;
   for (int c = 0; c < P.nchains; ++c)
     for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) chain_end[q] = chain_ptr[c + 1];
@@ -240,6 +299,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_upload(c, &P.obs_v, v.data(), (size_t)P.O));
   RC(dev_upload(c, &P.obs_sigma, p->obs_sigma, (size_t)P.O));
   // keyframe-major observation lists + covisible pair lists (fixed keyframes carry no pose block -> excluded)
+  std::vector<int> h_pair_i, h_pair_j;  // kept for the arrow plan below
   {
     std::vector<int> kptr(P.K + 1, 0), kidx(P.O);
     for (int o = 0; o < P.O; ++o) kptr[p->obs_kf[o] + 1]++;
@@ -321,6 +381,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
     RC(dev_alloc(c, &P.obsW, (size_t)18 * P.O)); RC(dev_alloc(c, &P.obsY, (size_t)18 * P.O)); RC(dev_alloc(c, &P.obsP, (size_t)39 * P.O));
     RC(dev_alloc(c, &P.cost_part, (size_t)(P.L / 4 + 64)));
     HIPCHK(hipStreamSynchronize(c->st));
+    h_pair_i.swap(pi); h_pair_j.swap(pj);
   }
   // IMU
   RC(dev_upload(c, &P.imu_i, (const int*)p->imu_kf_i, (size_t)P.I));
@@ -355,7 +416,6 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_upload(c, &P.perm, perm.data(), K)); RC(dev_upload(c, &P.pos_kf, pos_kf.data(), K));
   RC(dev_upload(c, &P.chain_ptr, chain_ptr.data(), chain_ptr.size()));
   RC(dev_upload(c, &P.pos_chain_end, chain_end.data(), K));
-  RC(dev_alloc(c, &P.Sred, (size_t)P.npad * P.npad));
   RC(dev_alloc(c, &P.bred, (size_t)P.n));
   RC(dev_alloc(c, &P.bp, (size_t)2 * P.npad));
   const size_t Kv = vi ? K : 0;
@@ -369,7 +429,6 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_alloc(c, &P.grad, (size_t)P.N)); RC(dev_alloc(c, &P.hdiag, (size_t)P.N));
   RC(dev_alloc(c, &P.HllInv, (size_t)6 * P.L));
   RC(dev_alloc(c, &P.gn, (size_t)P.N)); RC(dev_alloc(c, &P.step, (size_t)P.N)); RC(dev_alloc(c, &P.vtmp, (size_t)P.N));
-  RC(dev_alloc(c, &P.Linv, (size_t)(P.npad / kTile) * kTile * kTile));
   RC(dev_alloc(c, &P.scal, (size_t)SC_COUNT)); RC(dev_alloc(c, &P.flag, (size_t)4));
   // deterministic reductions / scatters
   P.part_imu = 8192; P.part_edge = P.part_imu + ((P.I + 3) / 4) * 4; P.part_vec = P.part_edge + (P.E + 63) / 64;
@@ -407,6 +466,38 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
     RC(dev_upload(c, &P.epair_ptr, eptr.data(), eptr.size())); RC(dev_upload(c, &P.epair_i, ei.data(), ei.size()));
     RC(dev_upload(c, &P.epair_j, ej.data(), ej.size())); RC(dev_upload(c, &P.epair_ent, eent.data(), eent.size()));
     HIPCHK(hipStreamSynchronize(c->st));
+    // ---- where does the pose-pose system live? Fused multi-agent maps: block-arrow buffers (k_arrow.hip); else dense.
+    //      COVGPU_GBA_DENSE=1 keeps the dense form, COVGPU_GBA_ARROW=1 forces the arrow form whenever a plan exists (tests).
+    ArrowHostPlan hp;
+    const char* e_dense = getenv("COVGPU_GBA_DENSE");
+    const char* e_arrow = getenv("COVGPU_GBA_ARROW");
+    const bool force = e_arrow && e_arrow[0] == '1';
+    if (vi && allow_arrow && !(e_dense && e_dense[0] == '1') &&
+        gba_plan_analyse(P.K, P.nchains, chain_ptr.data(), (int)h_pair_i.size(), h_pair_i.data(), h_pair_j.data(), P.nepairs, ei.data(), ej.data(), force, hp)) {
+      P.arrow = 1;
+      P.ar_nblk = hp.nblk; P.ar_nbk = hp.nbk;
+      P.ar_nIpad = ((6 * hp.max_int + 2 * kTile - 1) / (2 * kTile)) * (2 * kTile);  // whole big panels (tstop is even)
+      const int nown = std::max(kTile, ((6 * hp.max_own + kTile - 1) / kTile) * kTile);
+      P.ar_ntot = P.ar_nIpad + nown;
+      P.ar_nb = std::max(kTile, ((6 * hp.nbk + kTile - 1) / kTile) * kTile);
+      std::vector<int> own((size_t)hp.nblk * std::max(hp.nbk, 1), -1);
+      for (int a = 0; a < hp.nblk; ++a)
+        for (size_t o = 0; o < hp.own[a].size(); ++o) own[(size_t)a * hp.nbk + hp.own[a][o]] = (int)o;
+      RC(dev_upload(c, &P.ar_blk, hp.blk.data(), hp.blk.size())); RC(dev_upload(c, &P.ar_loc, hp.loc.data(), hp.loc.size()));
+      RC(dev_upload(c, &P.ar_own, own.data(), own.size())); RC(dev_upload(c, &P.ar_nint, hp.nint.data(), hp.nint.size()));
+      RC(dev_upload(c, &P.ar_bpos, hp.bpos.data(), hp.bpos.size()));
+      RC(dev_alloc(c, &P.ar_M, (size_t)P.ar_nblk * P.ar_ntot * P.ar_ntot)); RC(dev_alloc(c, &P.ar_rhs, (size_t)P.ar_nblk * 2 * P.ar_ntot));
+      RC(dev_alloc(c, &P.ar_Linv, (size_t)P.ar_nblk * P.ar_nIpad * kTile));
+      RC(dev_alloc(c, &P.ar_Sb, (size_t)P.ar_nb * P.ar_nb)); RC(dev_alloc(c, &P.ar_rhsb, (size_t)2 * P.ar_nb));
+      RC(dev_alloc(c, &P.ar_Linvb, (size_t)P.ar_nb * kTile));
+      HIPCHK(hipStreamSynchronize(c->st));
+      if (opt->verbose)
+        std::printf("[covgpu] arrow plan: %d blocks (largest interior %d keyframes, own border <= %d), border %d keyframes; buffers %.2f GB\n",
+                    hp.nblk, hp.max_int, hp.max_own, hp.nbk, ((double)P.ar_nblk * P.ar_ntot * P.ar_ntot + (double)P.ar_nb * P.ar_nb) * 8e-9);
+    } else {
+      RC(dev_alloc(c, &P.Sred, (size_t)P.npad * P.npad));
+      RC(dev_alloc(c, &P.Linv, (size_t)(P.npad / kTile) * kTile * kTile));
+    }
   }
   if (pgo && P.E) {  // block-arrow plan for the pose-graph solve (k_pgo.hip); COVGPU_PGO_DENSE=1 keeps the plain dense solve
     PgoHostPlan hp;
@@ -723,7 +814,7 @@ extern "C" int covgpu_linearize_between(covgpu_context* c, const covgpu_options*
 }
 
 static int schur_impl(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, bool pgo, double mu, double* S, double* b, double* cost) {
-  RC(upload_impl(c, opt, p, pgo)); RC(reset_state(c));
+  RC(upload_impl(c, opt, p, pgo, false)); RC(reset_state(c));  // dense form: the test reads C back as one matrix
   launch_preintegrate(c->P, c->st);
   enqueue_build(c, mu);
   if (c->chol.cf_pending) { HIPCHK(hipStreamWaitEvent(c->st, c->chol.ev_cf, 0)); c->chol.cf_pending = false; }  // not used here
@@ -786,6 +877,20 @@ extern "C" int covgpu_schur(covgpu_context* c, const covgpu_options* opt, const 
 }
 extern "C" int covgpu_schur_pgo(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double mu, double* S, double* b, double* cost) {
   return schur_impl(c, opt, p, true, mu, S, b, cost);
+}
+
+// one damped Gauss-Newton step at the uploaded estimate through the PRODUCT solve path (structured speed-bias
+// elimination + block-arrow or dense pose solve + landmark back-substitution)
+extern "C" int covgpu_gn_step(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double mu, double* dx, double* dl, double* cost) {
+  RC(upload_impl(c, opt, p, false)); RC(reset_state(c));
+  launch_preintegrate(c->P, c->st);
+  enqueue_build(c, mu);
+  enqueue_solve(c, c->P.gn);
+  RC(read_scalars(c));
+  if (chol_failed(c)) { g_err = "reduced system is not positive definite"; return COVGPU_ERR_NUMERIC; }
+  if (cost) *cost = c->h_scal[SC_COST];
+  RC(fetch(c, dx, c->P.gn, (size_t)c->P.n));
+  return fetch(c, dl, c->P.gn + c->P.n, (size_t)3 * c->P.L);
 }
 
 extern "C" int covgpu_solve_reduced(covgpu_context* c, int32_t n, const double* S, const double* b, double* x) {

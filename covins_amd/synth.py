@@ -346,8 +346,13 @@ def make_map(cfg: SynthConfig) -> SlamMap:
     q_est[q_est[:, 3] < 0] *= -1
     v_est = Rz.apply(v_true) + rng.normal(0, cfg.vel_noise, (K, 3)) * (cfg.vel_noise > 0)
     lm_est = p_est[lm_ref] + Rz[lm_ref].apply(lm_true - p_true[lm_ref]) + rng.normal(0, cfg.lm_noise, (L, 3))
-    ba_est = ba_true + rng.normal(0, 0.005, (K, 3)) * cfg.imu_noise
-    bg_est = bg_true + rng.normal(0, 0.0005, (K, 3)) * cfg.imu_noise
+    # bias estimates of a VIO front-end vary as smoothly as the biases themselves (they are filtered against the very
+    # random-walk prior the IMU factor encodes): a constant per-agent estimation offset, not white noise per keyframe —
+    # white noise of this size would sit 1e4 sigma off the bias-walk prior and dominate the initial cost by 1e5.
+    off_a = rng.normal(0, 0.005, (A, 3)) * cfg.imu_noise
+    off_g = rng.normal(0, 0.0005, (A, 3)) * cfg.imu_noise
+    ba_est = ba_true + off_a[kf_client]
+    bg_est = bg_true + off_g[kf_client]
 
     # ---- loop constraints (typedefs_base.hpp:264-277): noisy ground-truth relative pose per loop closure
     loops: List[LoopConstraint] = []

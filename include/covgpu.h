@@ -214,6 +214,12 @@ int covgpu_schur(covgpu_context* ctx, const covgpu_options* opt, const covgpu_pr
 int covgpu_schur_pgo(covgpu_context* ctx, const covgpu_options* opt, const covgpu_problem* p, double mu,
                      double* S, double* b, double* cost);
 
+/* R8 building block: ONE damped Gauss-Newton step at the estimate in `p`, through the product solve path (speed-bias
+ * chains -> block-arrow or dense MFMA Cholesky of the pose system -> landmark back-substitution):
+ * dx[n] (IR layout, dim_per_kf per keyframe) and dl[3L]. Tests check S dx = b against the oracle's system at full size. */
+int covgpu_gn_step(covgpu_context* ctx, const covgpu_options* opt, const covgpu_problem* p, double mu,
+                   double* dx /* [n] */, double* dl /* [L][3] */, double* cost);
+
 /* R8 building block: dense FP64 Cholesky solve of S x = b on the MFMA path (S symmetric positive
  * definite, row-major n x n; only the lower triangle is read). Returns COVGPU_ERR_NUMERIC if a
  * pivot is not positive. */
@@ -228,12 +234,25 @@ int32_t covgpu_reduced_dim(const covgpu_options* opt, const covgpu_problem* p);
  * system; block_of_kf is then all -1). No edge joins two different blocks. Needs no device. */
 int32_t covgpu_pgo_partition(int32_t num_kf, int32_t num_edge, const int32_t* edge_i, const int32_t* edge_j, int32_t* block_of_kf);
 
+/* Host-only: the block partition the GBA solve uses on fused multi-agent maps (block-arrow elimination of the reduced
+ * camera system, DESIGN.md 4.5b — and the unit of the multi-GPU split). After the speed-bias chains are
+ * eliminated every agent's pose block is dense, but agents couple only through fused landmarks and loop edges
+ * (optimization_be.cpp:538-556); a vertex cover of those cross-agent links is the border ("shared poses").
+ * block_of_kf[k] = block (>= 0) whose interior holds keyframe k, or -1 for a border keyframe. Returns the number of
+ * blocks, or 0 when the dense form is kept (single agent, small system, or a border too large to pay; force != 0
+ * skips the pay-off test). Invariant: no covisible pair and no loop edge joins the interiors of two blocks. */
+int32_t covgpu_gba_partition(const covgpu_options* opt, const covgpu_problem* p, int32_t force, int32_t* block_of_kf);
+
 /* ---------------------------------------------------------------- measurement hooks (bench.py)
  * With profiling on, covgpu_solve_resident brackets the linearise+Schur pass, the whole factor+solve and
  * every trailing-update (SYRK) launch with HIP events on the context's own stream.
  * out[8] = { build ms, #builds, factor+solve ms, #factorisations, SYRK ms, #SYRK launches, SYRK flops,
  *           #off-diagonal 6x6 pose-pose blocks of the reduced system (covisible + loop-edge keyframe pairs) } */
 void covgpu_set_profiling(covgpu_context* ctx, int on);
+/* layout of the uploaded problem: out[16] = { arrow form (0/1), blocks, border keyframes, padded interior order / 6,
+ * arrow buffer order, border system order, dense pose order (padded), covisible keyframe pairs, edge pairs, IMU chains,
+ * device MiB allocated for the problem (from the allocator, not by hand), 0 ... } */
+void covgpu_get_layout(covgpu_context* ctx, int64_t* out16);
 void covgpu_get_profile(covgpu_context* ctx, double* out8);
 
 #ifdef __cplusplus

@@ -1,0 +1,138 @@
+"""Parity at BASELINE sizes: the HIP path through the C ABI against the oracle's committed results
+for configs[1] (mh01), configs[2]'s GBA (mh123) and the metric's 5-agent map (mh12345) at FULL size
+(tests/golden/*.npz, made by tools/make_golden_full.py; oracle = block-sparse reduced system solved by scipy's SuperLU).
+Tolerances: poses 1e-6 m / 1e-7 rad, speed-bias 1e-6, cost trace 1e-6 relative, identical accept/reject sequence;
+landmarks by tests/util.landmark_parity. Plus one linearisation at full size: the device Gauss-Newton step must solve the
+ORACLE's reduced system (||S dx - b||), and the block-arrow solve must equal the dense solve."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from covins_amd import backend, capi, mapdata, synth
+from oracle import covo
+from tests.util import landmark_parity, rot_angle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def digest(p):
+    h = hashlib.sha256()
+    for k in sorted(p.__dict__):
+        v = getattr(p, k)
+        if v is not None:
+            h.update(k.encode()); h.update(np.ascontiguousarray(v).tobytes())
+    return h.hexdigest()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = backend.Context(0)
+    yield c
+    c.close()
+
+
+_cache = {}
+
+
+def problem(name):
+    if name not in _cache:
+        m = synth.make_map(synth.config_named(name))
+        _cache[name] = (m, mapdata.flatten_gba(m, False, True)[0])
+    return _cache[name]
+
+
+@pytest.mark.parametrize("name", ["mh01", "mh123", "mh12345"])
+@pytest.mark.parametrize("sname,strategy", [("dogleg", capi.COVGPU_DOGLEG), ("lm", capi.COVGPU_LM)])
+def test_full_size_solve_matches_oracle_golden(ctx, name, sname, strategy):
+    G = np.load(os.path.join(GOLD, f"{name}.npz"))
+    m, p = problem(name)
+    assert digest(p) == str(G["in_digest"]), "regenerated inputs differ from the ones the golden was made on"
+    sol, res = ctx.gba_solve(p, backend.default_options(strategy=strategy, max_iterations=10))
+    n = res.iterations
+    assert n == len(G[f"{sname}_trace"])
+    assert list(res.accepted_trace[:n]) == list(G[f"{sname}_acc"])
+    assert np.allclose(np.array(res.cost_trace[:n]), G[f"{sname}_trace"], rtol=1e-6, atol=0)
+    assert abs(res.initial_cost - G[f"{sname}_cost"][0]) <= 1e-9 * G[f"{sname}_cost"][0]
+    dp = np.abs(sol.kf_pose[:, 4:] - G[f"{sname}_pose"][:, 4:]).max()
+    da = rot_angle(sol.kf_pose[:, :4], G[f"{sname}_pose"][:, :4]).max()
+    ds = np.abs(sol.kf_speed_bias - G[f"{sname}_sb"]).max()
+    # landmarks: the golden holds every `stride`-th landmark; H_ll from the oracle at the ORACLE's solution
+    stride = int(G["lm_stride"])
+    ref = p.copy(); ref.kf_pose = G[f"{sname}_pose"].copy()
+    idx = np.arange(0, p.L, stride)
+    ref.lm_pos[idx] = G[f"{sname}_lm"]
+    n_ill, d_good, d_white = landmark_parity(sol.lm_pos[idx], ref, ref_lm=G[f"{sname}_lm"], idx=idx)
+    ate_gpu = synth.ate_rmse(sol.kf_pose[:, 4:], G["truth_xyz"]); ate_cpu = synth.ate_rmse(G[f"{sname}_pose"][:, 4:], G["truth_xyz"])
+    print(f"{name}/{sname}: max|dp|={dp:.2e} m, max angle={da:.2e} rad, max|dsb|={ds:.2e}, landmarks good<={d_good:.2e} m "
+          f"whitened<={d_white:.2e} ill={n_ill}/{len(idx)}, ATE gpu {ate_gpu:.6f} cpu {ate_cpu:.6f} (delta {abs(ate_gpu - ate_cpu):.2e} m)")
+    assert dp < 1e-6 and da < 1e-7 and ds < 1e-6
+    assert d_good < 1e-6 and d_white < 1e-4 and n_ill <= len(idx) // 12
+    assert abs(ate_gpu - ate_cpu) < 1e-3  # north-star acceptance: final ATE within 1e-3 m of the CPU path (printed: ~1e-9)
+
+
+def _spmv(ptr, col, blocks, x, D):
+    import scipy.sparse as sp
+    n = D * (len(ptr) - 1)
+    return sp.bsr_matrix((blocks, col, ptr), shape=(n, n)) @ x
+
+
+@pytest.mark.parametrize("name", ["mh01", "mh12345"])
+def test_single_linearisation_at_full_size(ctx, name):
+    """The device Gauss-Newton step (structured speed-bias elimination + arrow / dense MFMA Cholesky + landmark
+    back-substitution) must solve the reduced system the ORACLE assembles: ||S dx - b|| / ||b|| small, and dx equal to the
+    SuperLU solution of the same system."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    m, p = problem(name)
+    mu = 1e-8
+    dx, dl, cost = ctx.gn_step(p, backend.default_options(), mu)
+    ptr, col, blocks, b, cost0 = covo.schur_sparse(p, covo.default_options(), mu)
+    assert abs(cost - cost0) <= 1e-10 * cost0
+    n = 15 * p.K
+    S = sp.bsr_matrix((blocks, col, ptr), shape=(n, n)).tocsc()
+    r = S @ dx - b
+    rel = np.linalg.norm(r) / np.linalg.norm(b)
+    x0 = spla.splu(S, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True)).solve(b)
+    rel0 = np.linalg.norm(S @ x0 - b) / np.linalg.norm(b)
+    # compare in the metric of the system (the step along badly determined directions is large in absolute terms)
+    d = np.sqrt(np.abs(S.diagonal()))
+    err = np.abs((dx - x0) * d).max() / np.abs(x0 * d).max()
+    print(f"{name}: n={n} |S dx-b|/|b| gpu {rel:.2e} superlu {rel0:.2e}, scaled step difference {err:.2e}")
+    assert rel < max(100 * rel0, 1e-9) and err < 1e-6
+
+
+def test_arrow_solve_equals_dense_solve(ctx):
+    """Block-arrow elimination (k_arrow.hip) is the same Cholesky solve in a different elimination order: the full GBA
+    of the 3-agent map must land where the dense pose-system path lands."""
+    m, p = problem("mh123")
+    assert backend.gba_partition(p, backend.default_options())[1] == 3
+    out = {}
+    for mode in ("COVGPU_GBA_DENSE", "COVGPU_GBA_ARROW"):
+        os.environ[mode] = "1"
+        try:
+            out[mode] = ctx.gba_solve(p, backend.default_options(max_iterations=6))
+        finally:
+            del os.environ[mode]
+    (sd, rd), (sa, ra) = out["COVGPU_GBA_DENSE"], out["COVGPU_GBA_ARROW"]
+    assert rd.iterations == ra.iterations and list(rd.accepted_trace[:6]) == list(ra.accepted_trace[:6])
+    assert np.allclose(np.array(ra.cost_trace[:6]), np.array(rd.cost_trace[:6]), rtol=1e-9)
+    assert np.abs(sd.kf_pose - sa.kf_pose).max() < 1e-8 and np.abs(sd.kf_speed_bias - sa.kf_speed_bias).max() < 1e-8
+    n_ill, d_good, d_white = landmark_parity(sa.lm_pos, sd)
+    assert d_good < 1e-6 and d_white < 1e-4
+
+
+def test_arrow_solve_small_forced(ctx, small_map):
+    """Forced arrow plan on a small 3-agent map (one agent entirely shared: a chain without a block), against the oracle."""
+    p = mapdata.flatten_gba(small_map, False, True)[0]
+    os.environ["COVGPU_GBA_ARROW"] = "1"
+    try:
+        sol, res = ctx.gba_solve(p, backend.default_options())
+    finally:
+        del os.environ["COVGPU_GBA_ARROW"]
+    ref, rres = covo.gba_solve(p, covo.default_options())
+    assert res.iterations == rres.iterations and abs(res.final_cost - rres.final_cost) <= 1e-8 * rres.final_cost
+    assert np.abs(sol.kf_pose[:, 4:] - ref.kf_pose[:, 4:]).max() < 1e-6
+    assert np.abs(sol.kf_speed_bias - ref.kf_speed_bias).max() < 1e-6

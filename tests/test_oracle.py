@@ -315,7 +315,7 @@ def test_vi_gba_reduces_cost_and_stays_near_truth(tiny_map):
         o = covo.default_options(strategy=strategy)
         q, res = covo.gba_solve(p, o)
         assert res.iterations == 10 or res.termination in (1, 2, 3)
-        assert res.final_cost < 1e-5 * res.initial_cost
+        assert res.final_cost < 1e-2 * res.initial_cost  # (initial bias estimates follow the random-walk prior now: no 1e10 start)
         assert res.final_cost < 1.2 * covo.cost(pt, o)
         assert np.linalg.norm(q.kf_pose[:, 4:] - pt.kf_pose[:, 4:], axis=1).mean() < 0.02
         tr = np.array(res.cost_trace[:res.iterations])
@@ -363,3 +363,33 @@ def test_pgo_reanchor_is_rigid():
         ps = R.from_quat(po[k, :4]).inv().apply(lm[l] - po[k, 4:])
         assert np.allclose(lm2[l], R.from_quat(pn[k, :4]).apply(ps) + pn[k, 4:], atol=1e-12)
     assert np.allclose(np.linalg.norm(v2, axis=1), np.linalg.norm(vel, axis=1))
+
+
+def test_landmark_sensitivity_is_a_property_of_the_problem(small_map):
+    """Two CORRECT linear solvers inside the same oracle (own dense Cholesky vs scipy's SuperLU on the block-sparse
+    system) agree on poses to 1e-8 m and on cost to 1e-10, yet a few landmarks with near-degenerate parallax land far
+    apart (cond(H_ll) >= 1e6, along the viewing ray). This is why the parity criterion for landmarks is conditioned on
+    cond(H_ll) (tests/util.landmark_parity) — and it also checks the sparse-solver path against the dense one."""
+    from tests.util import landmark_parity
+    p, _ = mapdata.flatten_gba(small_map, False, True)
+    o = covo.default_options()
+    covo.use_sparse_solver(enable=False)
+    qd, rd = covo.gba_solve(p, o)
+    covo.use_sparse_solver(min_n=0)
+    try:
+        qs, rs = covo.gba_solve(p, o)
+    finally:
+        covo.use_sparse_solver(enable=False)
+    assert rd.iterations == rs.iterations and abs(rd.final_cost - rs.final_cost) < 1e-9 * rd.final_cost
+    assert np.abs(qd.kf_pose - qs.kf_pose).max() < 1e-8
+    n_ill, d_good, d_white = landmark_parity(qs.lm_pos, qd)
+    assert d_good < 1e-6 and d_white < 1e-4 and n_ill <= max(5, p.L // 12), (n_ill, d_good, d_white)
+    # thread-count independence of the oracle (fixed-order sums): 1 thread vs the default team gives identical bits
+    nt = covo.lib().covo_num_threads()
+    covo.lib().covo_set_num_threads(1)
+    try:
+        q1, _ = covo.gba_solve(p, covo.default_options(max_iterations=3))
+    finally:
+        covo.lib().covo_set_num_threads(nt)
+    qn, _ = covo.gba_solve(p, covo.default_options(max_iterations=3))
+    assert np.array_equal(q1.kf_pose, qn.kf_pose) and np.array_equal(q1.lm_pos, qn.lm_pos)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/{mh01,mh123,mh12345}.npz: the CPU oracle's result on the BASELINE.json configurations at
+FULL size (configs[1], configs[2] GBA part, and the metric's 5-agent map), for dogleg (the reference's strategy,
+optimization_be.cpp:564) and Levenberg-Marquardt (north-star mode), 10 iterations each (opt.gba_iteration_limit).
+
+The reduced camera systems (15 K = 8k .. 33k unknowns) are solved by scipy's SuperLU through oracle/covo.py — a
+library that shares no code with the oracle's own dense Cholesky or with the HIP kernels. Inputs are NOT stored (the
+5-agent map has 878k observations): they are regenerated from the seeded generator, and `in_digest` pins them.
+Stored per strategy: final poses, speed-bias, every 8th landmark, cost / acceptance / radius trace. Plus, for the
+single-linearisation test at full size: ||S x - b|| inputs are regenerated on the fly by the test itself.
+
+Run in this container (about four minutes on 8 cores):  python tools/make_golden_full.py [names...]
+"""
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from covins_amd import capi, mapdata, synth  # noqa: E402
+from oracle import covo  # noqa: E402
+
+LM_STRIDE = 8
+
+
+def digest(p: capi.FlatProblem) -> str:
+    h = hashlib.sha256()
+    for k in sorted(p.__dict__):
+        v = getattr(p, k)
+        if v is not None:
+            h.update(k.encode()); h.update(np.ascontiguousarray(v).tobytes())
+    return h.hexdigest()
+
+
+def main():
+    names = sys.argv[1:] or ["mh01", "mh123", "mh12345"]
+    covo.use_sparse_solver(min_n=3000)
+    for name in names:
+        m = synth.make_map(synth.config_named(name))
+        p, _ = mapdata.flatten_gba(m, False, True)
+        out = {"in_digest": np.array(digest(p)), "sizes": np.array([p.K, p.L, p.O, p.I, p.E]), "lm_stride": np.array(LM_STRIDE),
+               "truth_xyz": m.truth["kf_pose"][:, 4:]}
+        for sname, strat in (("dogleg", capi.COVGPU_DOGLEG), ("lm", capi.COVGPU_LM)):
+            t0 = time.perf_counter()
+            q, res = covo.gba_solve(p, covo.default_options(strategy=strat, max_iterations=10))
+            dt = time.perf_counter() - t0
+            n = res.iterations
+            out[f"{sname}_pose"] = q.kf_pose; out[f"{sname}_sb"] = q.kf_speed_bias; out[f"{sname}_lm"] = q.lm_pos[::LM_STRIDE]
+            out[f"{sname}_trace"] = np.array(res.cost_trace[:n]); out[f"{sname}_acc"] = np.array(res.accepted_trace[:n])
+            out[f"{sname}_radius"] = np.array(res.radius_trace[:n])
+            out[f"{sname}_cost"] = np.array([res.initial_cost, res.final_cost])
+            # conditioning of the stored landmarks at the final estimate (parity criterion, tests/test_gpu_full.py)
+            H = covo.landmark_hessians(q, covo.default_options())[::LM_STRIDE]
+            out[f"{sname}_lm_cond"] = np.linalg.cond(H)
+            print(f"{name} {sname}: K={p.K} L={p.L} O={p.O} {n} iterations {dt:.1f} s cost {res.initial_cost:.6e} -> {res.final_cost:.6e} "
+                  f"ATE {synth.ate_rmse(q.kf_pose[:, 4:], m.truth['kf_pose'][:, 4:]):.4f} m", flush=True)
+        dst = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+        np.savez_compressed(dst, **out)
+        print("wrote", dst, os.path.getsize(dst), "bytes", flush=True)
+
+
+if __name__ == "__main__":
+    main()

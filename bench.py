@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--strategy", default="dogleg", choices=["dogleg", "lm"])
     ap.add_argument("--iterations", type=int, default=10, help="trust-region iteration cap per step (reference: 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-shard", action="store_true", help="run the agent-sharded path (plan, sub-problem, RCCL collectives) even on ONE GPU")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-call timing after the timed region (profiling runs)")
     args = ap.parse_args()
 
@@ -82,16 +83,27 @@ def main():
     from covins_amd import backend, capi, distrib, mapdata, synth
     rank, local_rank, world = distrib.env_ranks()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
-    dist = distrib.init("nccl", local_rank)
+    dist = distrib.init("nccl", local_rank, force=args.force_shard)
     dev = f"cuda:{local_rank}"
     strategy = capi.COVGPU_DOGLEG if args.strategy == "dogleg" else capi.COVGPU_LM
-    cfg = synth.config_named(args.workload, seed=distrib.map_seed_for_rank(rank))  # map-sharded: each rank owns one merged map
+    cfg = synth.config_named(args.workload)   # ONE map, the same on every rank (seeded generator); N > 1 shards it by agent
     m = synth.make_map(cfg)
-    prob, _ = mapdata.flatten_gba(m, visual_only=False, loop_loss=True)
+    full, _ = mapdata.flatten_gba(m, visual_only=False, loop_loss=True)
     pgo_prm = mapdata.PgoParams()
     pgo_prob, _ = mapdata.flatten_pgo(m, {}, pgo_prm)  # the pose graph of the same (still drifted) map, for the side figure below
     opt = backend.default_options(strategy=strategy, max_iterations=args.iterations, device=local_rank)
     ctx = backend.Context(local_rank)
+    plan, reducer = None, None
+    prob = full
+    sharded = world > 1 or args.force_shard
+    if sharded:
+        # agent-sharded solve of the ONE map: same plan on every rank, each keeps its agents' share; the
+        # library's collectives (shared-pose gradient rows, shared-pose system, scalars) run over RCCL on device pointers
+        plan = distrib.shard_plan(full, opt, world)
+        assert plan is not None, "this map does not split by agent (single agent): run it on one GPU"
+        prob = distrib.shard_problem(full, plan, rank)
+        reducer = distrib.TorchReducer(dist, dev)
+        ctx.set_shard(plan, rank, reducer.callback(), stage_on_host=False)
     t_up = time.perf_counter()
     ctx.upload(prob, opt)  # inputs resident in HBM before the timed region
     t_up = time.perf_counter() - t_up
@@ -104,7 +116,7 @@ def main():
     res = None
     for _ in range(args.steps):
         res = ctx.solve_resident(opt)  # returns after its stream has drained
-        iters += res.iterations
+        iters += res.iterations        # (sharded: every rank executes the SAME iterations of the one solve)
     distrib.barrier(dist, dev)
     dt = time.perf_counter() - t0
     dt, iters_all = distrib.aggregate(dt, iters, dist, dev)
@@ -114,6 +126,17 @@ def main():
     prof = ctx.profile()
     ctx.set_profiling(False)
     lay = ctx.layout()
+    sol = ctx.download()
+    if sharded:  # assemble the optimised map from the ranks' pieces (small: poses, speed-bias, landmark positions)
+        pieces = [None] * world
+        dist.all_gather_object(pieces, (sol.kf_pose, sol.kf_speed_bias, sol.lm_pos))
+        parts = []
+        for r, (kp, ks, lp) in enumerate(pieces):
+            q = distrib.shard_problem(full, plan, r) if r != rank else prob
+            q = q.copy(); q.kf_pose[:] = kp; q.kf_speed_bias[:] = ks; q.lm_pos[:] = lp
+            parts.append(q)
+        sol = distrib.merge_solution(full, plan, parts)
+    prob = full
 
     if rank == 0:
         # HBM traffic of the dominant kernel cannot be read inside this process (PMC counters need rocprofv3):
@@ -128,7 +151,6 @@ def main():
                 traffic = pj["fetch_bytes_x2"] + pj["write_bytes"]; mfma_busy = pj.get("mfma_busy_frac"); traffic_src = pj.get("git_sha", sha)
         except Exception:
             pass
-        sol = ctx.download()
         truth = m.truth["kf_pose"][:, 4:]
         n = 15 * prob.K
         k_free = int(prob.K - prob.kf_fixed.sum())
@@ -141,9 +163,9 @@ def main():
             "metric": "GBA iterations/sec, 5-agent EuRoC merged map" if args.workload == "mh12345" else f"GBA iterations/sec, {args.workload}",
             "value": iters_all / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "timed_region": "profiling events off; phase / kernel figures below come from one extra un-timed step",
-            "config": {"workload": f"{args.workload}: {len(cfg.agents)}-agent EuRoC MH-shaped merged map per GPU, visual-inertial GBA "
+            "config": {"workload": f"{args.workload}: {len(cfg.agents)}-agent EuRoC MH-shaped merged map, visual-inertial GBA "
                                    f"(K={prob.K} keyframes, L={prob.L} landmarks, O={prob.O} observations, I={prob.I} IMU factors, "
                                    f"E={prob.E} loop edges; reduced camera system 15K={n}: speed-bias chains eliminated block-tridiagonally, "
                                    + (f"pose system 6K={6 * prob.K} as {lay['blocks']} agent blocks (<= {lay['interior_kf_padded']} interior keyframes) + "
@@ -151,7 +173,11 @@ def main():
                                       f"dense MFMA Cholesky on the 6K={6 * prob.K} pose system)"),
                        "layout": lay,
                        "nnzS_fill": (2 * prof["offdiag_blocks"] + prob.K) / float(prob.K) ** 2,
-                       "strategy": args.strategy, "iterations_per_step": args.iterations, "sharding": "one map per GPU"},
+                       "strategy": args.strategy, "iterations_per_step": args.iterations,
+                       "sharding": ("none (1 GPU)" if not sharded else
+                                    f"ONE map sharded by agent over {world} ranks: blocks->ranks {plan.block_rank.tolist()}, {int((plan.block_of_kf < 0).sum())} shared keyframes; "
+                                    f"RCCL all-reduce of the shared-pose system + gradient rows + scalars: {reducer.calls} collectives, "
+                                    f"{reducer.bytes / 1e6:.1f} MB on rank 0 over the whole run")},
             "kf_per_s": k_free * iters_all / dt,
             "iterations_executed": iters_all,
             "final_cost": res.final_cost, "initial_cost": res.initial_cost,
@@ -185,6 +211,8 @@ def main():
         # whole Optimization::GlobalBundleAdjustment call as backend.cpp:141-156 issues it (outlier round of 5 iterations +
         # main round, flatten + H2D + solves + D2H + write-back + Map::Clean) — PCIe- and host-inclusive, never `value`
         from covins_amd.optimization import Optimization, OptParams
+        if sharded:
+            args.no_e2e = True; args.no_cpu_baseline = True   # side figures belong to the single-GPU line
         t_call = time.perf_counter() if not args.no_e2e else None
         if not args.no_e2e:
             info = Optimization.GlobalBundleAdjustment(m, args.iterations, -1.0, False, True, False,

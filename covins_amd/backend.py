@@ -131,6 +131,18 @@ class Context:
         self._check(lib().covgpu_download(self._h, C.byref(s)))
         return q
 
+    def set_shard(self, plan, rank: int, callback, stage_on_host: bool):
+        """Agent-sharded solve (covgpu_set_shard): `plan` = distrib.ShardPlan, `callback` = a distrib.ALLREDUCE_FN object
+        (kept alive here). plan=None returns to the single-GPU form."""
+        if plan is None:
+            self._check(lib().covgpu_set_shard(self._h, 0, 1, 0, None, 0, None, None, None, 0))
+            self._shard_keep = None
+            return
+        bk = np.ascontiguousarray(plan.block_of_kf, np.int32); br = np.ascontiguousarray(plan.block_rank, np.int32)
+        self._shard_keep = (bk, br, callback)
+        self._check(lib().covgpu_set_shard(self._h, int(rank), int(plan.world), len(bk), iptr(bk), int(plan.num_blocks), iptr(br),
+                                           C.cast(callback, C.c_void_p), None, int(stage_on_host)))
+
     def set_profiling(self, on: bool):
         lib().covgpu_set_profiling(self._h, int(on))
 

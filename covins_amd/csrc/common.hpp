@@ -118,18 +118,26 @@ struct DevProblem {
   int* ar_own;     // [nblk][nbk] border index -> pose index inside the block's own-border part, or -1
   int* ar_nint;    // [nblk] interior keyframes per block
   int* ar_bpos;    // [nbk] border index -> chain position
+  int* ar_live;    // [nblk][2] real interior tiles | real own-border tiles of each arrow buffer (the rest is padding)
+  // ---- agent-sharded solve of one map over several GPUs. shard == 0: everything is owned here.
+  int shard;       // 1: this context holds one rank's share (its agents' blocks, landmarks, IMU factors, edges)
+  double* vw;      // [N] weight of every unknown in the trust-region norms: 1 if this rank counts it (own interior poses,
+                   //     own chains' speed-bias blocks, own landmarks, border poses on rank 0 only), else 0; nullptr = all 1
+  double* ar_dummy;  // [36] sink for writes addressed at keyframes of other shards (their local contributions are exactly 0)
   double *ar_M, *ar_rhs, *ar_Linv;     // [nblk][ntot][ntot] | [nblk][2 ntot] | [nblk][nIpad/128][128][128]
   double *ar_Sb, *ar_rhsb, *ar_Linvb;  // [nb][nb] | [2 nb] | [nb/128][128][128]
 };
 
 // address of entry (r, c) of the 6x6 pose-pose block (pi, pj), chain positions pi >= pj; for pi == pj only c <= r is stored.
-// Arrow layout: local indices follow chain position, so interior-interior and border-border blocks keep their
-// orientation; an (interior, border) pair whose INTERIOR keyframe has the higher position is stored transposed (the
-// border rows come last in every arrow buffer).
+// Arrow layout: interior indices follow chain position, so interior-interior blocks keep their orientation; an
+// (interior, border) pair is stored at (border row, interior column) — transposed if the interior keyframe has the
+// higher position (the border rows come last in every arrow buffer); a border-border pair is stored below the diagonal
+// of the border system in BORDER-index order.
 __device__ __forceinline__ double* c_entry(const DevProblem& P, int pi, int pj, int r, int c) {
   if (!P.arrow) return P.Sred + (size_t)(6 * pi + r) * P.npad + (6 * pj + c);
   const int bi = P.ar_blk[pi], bj = P.ar_blk[pj], li = P.ar_loc[pi], lj = P.ar_loc[pj];
   const size_t nt = (size_t)P.ar_ntot;
+  if (bi == -2 || bj == -2) return P.ar_dummy + 6 * r + c;
   if (bi >= 0) {
     double* M = P.ar_M + (size_t)bi * nt * nt;
     if (bj >= 0) return M + (size_t)(6 * li + r) * nt + (6 * lj + c);  // same block (plan invariant: no link joins two interiors)
@@ -140,7 +148,9 @@ __device__ __forceinline__ double* c_entry(const DevProblem& P, int pi, int pj, 
     const int o = P.ar_own[(size_t)bj * P.ar_nbk + li];
     return P.ar_M + (size_t)bj * nt * nt + (size_t)(P.ar_nIpad + 6 * o + r) * nt + (6 * lj + c);
   }
-  return P.ar_Sb + (size_t)(6 * li + r) * P.ar_nb + (6 * lj + c);
+  // border x border: border indices follow the IR keyframe order (the same on every rank), not the chain positions
+  if (li >= lj) return P.ar_Sb + (size_t)(6 * li + r) * P.ar_nb + (6 * lj + c);
+  return P.ar_Sb + (size_t)(6 * lj + c) * P.ar_nb + (6 * li + r);
 }
 
 // ---- scalar slots in DevProblem::scal
@@ -187,6 +197,10 @@ struct CholAux {
   bool cf_pending = false;
   std::vector<hipEvent_t> ev, prof_ev, panel_ev;  // panel_ev: start of every big panel on the main stream (COVGPU_TRACE_PANELS=1)
   std::vector<double> prof_flops;
+  std::vector<int> live_h;   // host copy of DevProblem::ar_live (flop accounting of the batched launches)
+  // multi-GPU: sum `n` device doubles over all ranks, in place (solver.hip installs it when a shard is set; nullptr = single GPU)
+  void (*reduce)(void* ctx, double* dev, size_t n, int op) = nullptr;
+  void* reduce_ctx = nullptr;
   int panel_n = 0;
   bool profile = false;
   double syrk_ms = 0, syrk_flops = 0;
@@ -198,7 +212,7 @@ struct CholAux {
 // dense SPD solve of Sred x = bred in place (lower Cholesky on the FP64 MFMA path); flag[0] != 0 on failure
 // batched form: n independent systems of identical shape; sM / sL / sR = elements between consecutive matrices, Linv
 // sets and right-hand sides. The same launches serve all of them (one more grid dimension).
-struct DenseBatch { int n = 0; size_t sM = 0, sL = 0, sR = 0; };
+struct DenseBatch { int n = 0; size_t sM = 0, sL = 0, sR = 0; const int* live = nullptr; int tI = 0; const int* live_h = nullptr; };  // live / tI: see GemmArgs (k_chol.hip)
 void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax, int tstop = -1,
                               bool solve = true, DenseBatch bt = DenseBatch());  // tstop >= 0 (even): eliminate tile columns [0, tstop) only
 void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStream_t st, int tfact, int tend, DenseBatch bt = DenseBatch());
@@ -227,7 +241,12 @@ struct ArrowHostPlan {
 // positions are chain-major; pair / epair lists are the covisible and edge keyframe pairs (i > j). Returns false when the
 // arrow form does not pay (single chain, tiny system, border too large): the caller keeps the dense pose system.
 bool gba_plan_analyse(int K, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
-                      const int* epair_i, const int* epair_j, bool force, ArrowHostPlan& out);
+                      const int* epair_i, const int* epair_j, bool force, const int* pos_kf, ArrowHostPlan& out);
+// shard form: the border and the block of every keyframe are GIVEN (global plan, by position: border_in[q] != 0,
+// owned_in[q] != 0 iff the keyframe's block belongs to this rank); builds this rank's blocks and own-border lists.
+void gba_plan_build(int K, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
+                    const int* epair_i, const int* epair_j, const char* border_in, const char* owned_in, const int* pos_kf, ArrowHostPlan& out);
+void launch_border_vec(const DevProblem& P, double* buf, int dir, hipStream_t st);  // dir 0: pack [grad | hdiag] of the border pose rows, 1: unpack
 void launch_arrow_zero(const DevProblem& P, hipStream_t st);   // per iteration: clear the buffers, identity on padding rows
 void launch_arrow_solve(const DevProblem& P, hipStream_t st, CholAux& ax);  // P.bp (chain positions) -> solution in place
 

@@ -27,8 +27,50 @@
 
 namespace covgpu {
 
+// blocks and own-border lists for a given border / ownership (by chain position). Border indices follow the IR keyframe
+// order pos_kf[] — the same numbering on every rank of a sharded solve, whatever the rank-local chain positions are.
+void gba_plan_build(int K, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
+                    const int* epair_i, const int* epair_j, const char* border, const char* owned, const int* pos_kf, ArrowHostPlan& out) {
+  out = ArrowHostPlan();
+  out.blk.assign(K, -2); out.loc.assign(K, 0);
+  std::vector<int> chain_of(K), block_of_chain(nchains, -1);
+  for (int c = 0; c < nchains; ++c) {
+    int n = 0;
+    for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) { chain_of[q] = c; if (!border[q] && owned[q]) ++n; }
+    if (n == 0) continue;
+    block_of_chain[c] = out.nblk++;
+    out.nint.push_back(n);
+    out.max_int = std::max(out.max_int, n);
+    int l = 0;
+    for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) if (!border[q] && owned[q]) { out.blk[q] = block_of_chain[c]; out.loc[q] = l++; }
+  }
+  {  // border index = rank of the keyframe's IR index among the border keyframes
+    std::vector<std::pair<int, int>> bk;  // (IR index, position)
+    for (int q = 0; q < K; ++q) if (border[q]) bk.push_back({pos_kf[q], q});
+    std::sort(bk.begin(), bk.end());
+    out.nbk = (int)bk.size();
+    out.bpos.resize(out.nbk);
+    for (int b = 0; b < out.nbk; ++b) { out.bpos[b] = bk[b].second; out.blk[bk[b].second] = -1; out.loc[bk[b].second] = b; }
+  }
+  // own border of a block: its chain's border keyframes (Y^T Y couples a whole chain) + border keyframes linked to its interior
+  std::vector<std::vector<char>> mark(out.nblk, std::vector<char>(std::max(out.nbk, 1), 0));
+  for (int b = 0; b < out.nbk; ++b) { const int a = block_of_chain[chain_of[out.bpos[b]]]; if (a >= 0) mark[a][b] = 1; }
+  auto own_link = [&](int x, int y) {  // any structural pair, same chain or not
+    if ((out.blk[x] == -1) == (out.blk[y] == -1)) return;
+    const int in = out.blk[x] == -1 ? y : x, bd = out.blk[x] == -1 ? x : y;
+    if (out.blk[in] >= 0) mark[out.blk[in]][out.loc[bd]] = 1;
+  };
+  for (int p = 0; p < npairs; ++p) own_link(pair_i[p], pair_j[p]);
+  for (int p = 0; p < nepairs; ++p) own_link(epair_i[p], epair_j[p]);
+  out.own.assign(out.nblk, {});
+  for (int a = 0; a < out.nblk; ++a) {
+    for (int b = 0; b < out.nbk; ++b) if (mark[a][b]) out.own[a].push_back(b);
+    out.max_own = std::max(out.max_own, (int)out.own[a].size());
+  }
+}
+
 bool gba_plan_analyse(int K, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
-                      const int* epair_i, const int* epair_j, bool force, ArrowHostPlan& out) {
+                      const int* epair_i, const int* epair_j, bool force, const int* pos_kf, ArrowHostPlan& out) {
   out = ArrowHostPlan();
   if (nchains < 2) return false;
   if (!force && 6 * K < 16 * kTile) return false;  // a handful of panels: the dense solve is already latency-bound
@@ -40,50 +82,24 @@ bool gba_plan_analyse(int K, int nchains, const int* chain_ptr, int npairs, cons
   for (int p = 0; p < npairs; ++p) link(pair_i[p], pair_j[p]);
   for (int p = 0; p < nepairs; ++p) link(epair_i[p], epair_j[p]);
   for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
-  // greedy vertex cover: highest remaining cross degree first (ties: lowest position) — deterministic
+  // greedy vertex cover: highest remaining cross degree first (ties: lowest IR index) — deterministic
   std::vector<int> deg(K);
-  std::vector<char> border(K, 0);
-  std::priority_queue<std::pair<int, int>> heap;  // (degree, -position)
-  for (int k = 0; k < K; ++k) { deg[k] = (int)adj[k].size(); if (deg[k]) heap.push({deg[k], -k}); }
+  std::vector<char> border(K, 0), owned(K, 1);
+  std::priority_queue<std::pair<int, int>> heap;  // (degree, -IR index)
+  std::vector<int> pos_of(K);
+  for (int q = 0; q < K; ++q) pos_of[pos_kf[q]] = q;
+  for (int k = 0; k < K; ++k) { deg[k] = (int)adj[k].size(); if (deg[k]) heap.push({deg[k], -pos_kf[k]}); }
   while (!heap.empty()) {
     const auto top = heap.top(); heap.pop();
-    const int k = -top.second;
+    const int k = pos_of[-top.second];
     if (border[k] || top.first != deg[k]) continue;  // stale entry
     if (deg[k] == 0) continue;
     border[k] = 1;
-    for (int v : adj[k]) if (!border[v] && deg[v] > 0) { --deg[v]; if (deg[v]) heap.push({deg[v], -v}); }
+    for (int v : adj[k]) if (!border[v] && deg[v] > 0) { --deg[v]; if (deg[v]) heap.push({deg[v], -pos_kf[v]}); }
     deg[k] = 0;
   }
-  // blocks = chains with at least one interior keyframe; local indices in position order
-  out.blk.assign(K, -1); out.loc.assign(K, 0);
-  std::vector<int> block_of_chain(nchains, -1);
-  for (int c = 0; c < nchains; ++c) {
-    int n = 0;
-    for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) if (!border[q]) ++n;
-    if (n == 0) continue;
-    block_of_chain[c] = out.nblk++;
-    out.nint.push_back(n);
-    out.max_int = std::max(out.max_int, n);
-    int l = 0;
-    for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) if (!border[q]) { out.blk[q] = block_of_chain[c]; out.loc[q] = l++; }
-  }
-  for (int q = 0; q < K; ++q) if (border[q]) { out.loc[q] = out.nbk++; out.bpos.push_back(q); }
+  gba_plan_build(K, nchains, chain_ptr, npairs, pair_i, pair_j, nepairs, epair_i, epair_j, border.data(), owned.data(), pos_kf, out);
   if (out.nblk < 2) return false;
-  // own border of a block: its chain's border keyframes (Y^T Y couples a whole chain) + border keyframes linked to its interior
-  std::vector<std::vector<char>> mark(out.nblk, std::vector<char>(out.nbk, 0));
-  for (int b = 0; b < out.nbk; ++b) { const int a = block_of_chain[chain_of[out.bpos[b]]]; if (a >= 0) mark[a][b] = 1; }
-  auto own_link = [&](int x, int y) {  // any structural pair, same chain or not
-    if (border[x] == border[y]) return;
-    const int in = border[x] ? y : x, bd = border[x] ? x : y;
-    mark[out.blk[in]][out.loc[bd]] = 1;
-  };
-  for (int p = 0; p < npairs; ++p) own_link(pair_i[p], pair_j[p]);
-  for (int p = 0; p < nepairs; ++p) own_link(epair_i[p], epair_j[p]);
-  out.own.assign(out.nblk, {});
-  for (int a = 0; a < out.nblk; ++a) {
-    for (int b = 0; b < out.nbk; ++b) if (mark[a][b]) out.own[a].push_back(b);
-    out.max_own = std::max(out.max_own, (int)out.own[a].size());
-  }
   if (force) return true;
   // does it pay? serial tile steps: largest interior + border, against the dense chain of all 6K rows
   const int t_arrow = (6 * out.max_int + kTile - 1) / kTile + (6 * out.nbk + kTile - 1) / kTile, t_dense = (6 * K + kTile - 1) / kTile;
@@ -156,8 +172,21 @@ __global__ __launch_bounds__(256) void k_arrow_scatter(DevProblem P) {
   if (b >= 0) P.bp[q] = P.ar_rhs[(size_t)b * 2 * P.ar_ntot + 6 * P.ar_loc[pos] + r];
 }
 
+// [grad | hdiag] of the border keyframes' pose rows <-> contiguous buffer (all-reduced before the damping is applied)
+__global__ __launch_bounds__(256) void k_border_vec(DevProblem P, double* __restrict__ buf, int dir) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, nbr = 6 * P.ar_nbk;
+  if (i >= nbr) return;
+  const int k = i / 6, r = i - 6 * k;
+  const size_t q = (size_t)P.D * P.pos_kf[P.ar_bpos[k]] + r;
+  if (dir == 0) { buf[i] = P.grad[q]; buf[nbr + i] = P.hdiag[q]; }
+  else { P.grad[q] = buf[i]; P.hdiag[q] = buf[nbr + i]; }
+}
+void launch_border_vec(const DevProblem& P, double* buf, int dir, hipStream_t st) {
+  if (P.ar_nbk > 0) hipLaunchKernelGGL(k_border_vec, dim3((6 * P.ar_nbk + 255) / 256), dim3(256), 0, st, P, buf, dir);
+}
+
 void launch_arrow_zero(const DevProblem& P, hipStream_t st) {
-  hipMemsetAsync(P.ar_M, 0, (size_t)P.ar_nblk * P.ar_ntot * P.ar_ntot * sizeof(double), st);
+  if (P.ar_nblk > 0) hipMemsetAsync(P.ar_M, 0, (size_t)P.ar_nblk * P.ar_ntot * P.ar_ntot * sizeof(double), st);
   hipMemsetAsync(P.ar_Sb, 0, (size_t)P.ar_nb * P.ar_nb * sizeof(double), st);
   const int cnt = std::max(P.ar_nIpad, P.ar_nb);
   hipLaunchKernelGGL(k_arrow_init, dim3((cnt + 255) / 256, P.ar_nblk + 1), dim3(256), 0, st, P);
@@ -165,18 +194,22 @@ void launch_arrow_zero(const DevProblem& P, hipStream_t st) {
 
 void launch_arrow_solve(const DevProblem& P, hipStream_t st, CholAux& ax) {
   const int nblk = P.ar_nblk, ntot = P.ar_ntot, nIpad = P.ar_nIpad, nb = P.ar_nb, nbr = 6 * P.ar_nbk;
-  const DenseBatch bt{nblk, (size_t)ntot * ntot, (size_t)nIpad * kTile, (size_t)2 * ntot};
-  hipMemsetAsync(P.ar_rhs, 0, (size_t)nblk * 2 * ntot * sizeof(double), st);
+  const DenseBatch bt{nblk, (size_t)ntot * ntot, (size_t)nIpad * kTile, (size_t)2 * ntot, P.ar_live, nIpad / kTile, ax.live_h.empty() ? nullptr : ax.live_h.data()};
+  if (nblk > 0) hipMemsetAsync(P.ar_rhs, 0, (size_t)nblk * 2 * ntot * sizeof(double), st);
   hipMemsetAsync(P.ar_rhsb, 0, (size_t)2 * nb * sizeof(double), st);
   hipLaunchKernelGGL(k_arrow_rhs, dim3((6 * P.K + 255) / 256), dim3(256), 0, st, P);
   // eliminate every block's interior (tile columns [0, nIpad/128)); forward substitution rides along
-  dense_cholesky_solve_raw(P.ar_M, P.ar_rhs, P.ar_Linv, P.flag, ntot, st, ax, nIpad / kTile, false, bt);
+  // (a rank of a sharded solve may own no block at all: it still takes part in the border reduction and solve)
+  if (nblk > 0) dense_cholesky_solve_raw(P.ar_M, P.ar_rhs, P.ar_Linv, P.flag, ntot, st, ax, nIpad / kTile, false, bt);
   if (nbr > 0) {
     hipLaunchKernelGGL(k_arrow_border, dim3((nbr + 15) / 16, (nbr + 15) / 16), dim3(256), 0, st, P);
+    // multi-GPU: every rank holds the contributions of ITS agents, landmarks and factors to the shared-pose system —
+    // one all-reduce of [C_b | b_b] (contiguous) per linear solve, then the border is solved redundantly on every rank
+    if (ax.reduce != nullptr) ax.reduce(ax.reduce_ctx, P.ar_Sb, (size_t)nb * nb + nb, 0);
     dense_cholesky_solve_raw(P.ar_Sb, P.ar_rhsb, P.ar_Linvb, P.flag, nb, st, ax);  // x_b in ar_rhsb[0 .. nb)
     hipLaunchKernelGGL(k_arrow_put_border, dim3((nbr + 255) / 256, nblk + 1), dim3(256), 0, st, P);
   }
-  dense_backward_solve(P.ar_M, P.ar_rhs, P.ar_Linv, ntot, st, nIpad / kTile, ntot / kTile, bt);
+  if (nblk > 0) dense_backward_solve(P.ar_M, P.ar_rhs, P.ar_Linv, ntot, st, nIpad / kTile, ntot / kTile, bt);
   hipLaunchKernelGGL(k_arrow_scatter, dim3((6 * P.K + 255) / 256), dim3(256), 0, st, P);
 }
 

@@ -68,7 +68,17 @@ struct GemmArgs {
   double* rhs; const double* yvec;
   // batched form (block-arrow pose-graph solve): independent matrices of identical shape, `batch` strides apart
   size_t bsM, bsL, bsR;  // elements between consecutive matrices / Linv sets / right-hand sides (0: not batched)
+  // arrow buffers of unequal blocks are padded to one shape: live[2*batch] = real interior tiles, live[2*batch+1] = real
+  // own-border tiles (which start at tile tI). A tile row outside both ranges is identity / zero padding: every product
+  // with it is zero, so workgroups that would only touch padding exit at once (about half of the batched flops on the
+  // 5-agent map, whose agents hold 267 .. 498 interior keyframes).
+  const int* live; int tI;
 };
+__device__ __forceinline__ bool tile_live(const GemmArgs& g, int batch, int t) {
+  if (g.live == nullptr) return true;
+  const int nI = g.live[2 * batch], nO = g.live[2 * batch + 1];
+  return t < nI || (t >= g.tI && t - g.tI < nO);
+}
 
 // C[i][j] (op)= sum_k A[i][k] B[j][k] on one 128x128 tile (TSA = TSB = 128), or on a quarter of it selected by
 // blockIdx.z — a 64x64 quadrant (RECT) or a 32x128 row slab (TRSM: the update is in place, X overwrites A, so a
@@ -113,6 +123,11 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
     if (g.ra0 + ti * kTile < g.cc0 + tj * kTile) return;  // strictly above the diagonal
   } else {
     ti = blockIdx.x; tj = 0;
+  }
+  if (g.live != nullptr) {  // wave-uniform early exit on padding (see GemmArgs::live)
+    if (!tile_live(g, batch, g.kcol0 / kTile)) return;                       // the panel itself is padding: A = B = 0
+    if (!tile_live(g, batch, g.ra0 / kTile + ti)) return;                    // A rows are padding
+    if (MODE != MODE_TRSM && !tile_live(g, batch, g.rb0 / kTile + tj)) return;  // B rows are padding
   }
   const int kbeg = 0, kend = g.KD;
   extern __shared__ __attribute__((aligned(16))) double smem[];  // [TSA][KC+1] + [TSB][KC+1] doubles
@@ -560,14 +575,14 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   // quad: four workgroups per tile (head launches on the serial chain)
   auto trsm = [&](int t, int r0, int r1, hipStream_t s2, bool quad) {
     if (r1 <= r0) return;
-    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, b, b + npad, bt.sM, bt.sL, bt.sR};
+    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, b, b + npad, bt.sM, bt.sL, bt.sR, bt.live, bt.tI};
     if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_TRSM, 32, kTile>), dim3(r1 - r0, 1, 4 * nbt), dim3(256), (size_t)(32 + kTile) * (KCQ + 1) * sizeof(double), s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(r1 - r0, 1, nbt), dim3(256), lds_gemm, s2, g);
   };
   // C tiles (rows [r0, r1), tile columns [tc0, tc0+ntc)) -= A[rows, K] A[tc.., K]^T, K = tiles kt0.. (KD columns); lower part only
   auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2, bool quad) {
     if (r1 <= r0 || ntc <= 0) return;
-    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR};
+    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI};
     if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4 * nbt), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0, nbt), dim3(256), lds_gemm, s2, g);
   };
@@ -666,12 +681,21 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     if (P + 1 < NP) wait(B, eRc[P + 1]);
     if (nt > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
-      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR};
+      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI};
       if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], B);
       hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, B, g);
       if (ax.profile) {
         (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], B);
-        ax.prof_flops.push_back((double)nbt * nt * (nt + 1) / 2 * 2.0 * kTile * kTile * (w * kTile));
+        double pairs = 0.0;  // tile pairs that do work: padding rows / panels of a batched arrow buffer exit at once
+        for (int a = 0; a < nbt; ++a) {
+          if (bt.live_h == nullptr) { pairs += (double)nt * (nt + 1) / 2; continue; }
+          const int nI = bt.live_h[2 * a], nO = bt.live_h[2 * a + 1];
+          if (t0 >= nI) continue;
+          int nl = 0;
+          for (int t = tb; t < T; ++t) nl += (t < nI || (t >= bt.tI && t - bt.tI < nO)) ? 1 : 0;
+          pairs += (double)nl * (nl + 1) / 2;
+        }
+        ax.prof_flops.push_back(pairs * 2.0 * kTile * kTile * (w * kTile));
       }
     }
     (void)hipEventRecord(eB[P], B);

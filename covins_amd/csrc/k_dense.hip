@@ -29,7 +29,11 @@ __global__ __launch_bounds__(256) void k_finalize_diag(DevProblem P, double mu, 
     if (which == 2 || (which == 0) == (r < 6)) {
       double* d = (r < 6) ? c_entry(P, pos, pos, r, r) : P.Ad + (size_t)81 * pos + 10 * (r - 6);
       const double h = P.hdiag[q];
-      if (h == 0.0) { *d = 1.0; P.bred[q] = 0.0; }
+      // sharded solve: a border row's damping / identity is added by the one rank that counts the row (the all-reduce
+      // of the border system sums the ranks' parts); rows of other shards' keyframes are not this rank's business
+      const bool mine = r >= 6 || P.vw == nullptr || P.vw[q] != 0.0;  // (speed-bias rows are never shared: always local)
+      if (!mine) { if (h == 0.0) P.bred[q] = 0.0; }
+      else if (h == 0.0) { *d = 1.0; P.bred[q] = 0.0; }
       else { const double c = clamp_diag(h); *d += mu * c * c; }
     }
   }
@@ -68,7 +72,8 @@ __global__ __launch_bounds__(256) void k_dogleg_stats(DevProblem P) {
   double gg = 0, gn2 = 0, gd = 0, gm = 0;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < P.N; q += gridDim.x * blockDim.x) {
     const double g = P.grad[q], d = clamp_diag(P.hdiag[q]), s = P.gn[q];
-    gg += (g / d) * (g / d); gn2 += (d * s) * (d * s); gd += g * s; gm = fmax(gm, fabs(g));
+    const double w = P.vw ? P.vw[q] : 1.0;  // sharded solve: every unknown is counted by exactly one rank
+    gg += w * (g / d) * (g / d); gn2 += w * (d * s) * (d * s); gd += w * g * s; gm = fmax(gm, w * fabs(g));
   }
   vec_reduce(P, gg, SC_GG);
   vec_reduce(P, gn2, SC_GN2);
@@ -91,7 +96,8 @@ __global__ __launch_bounds__(256) void k_combine_step(DevProblem P, double cg, d
     double s = cn * P.gn[q];
     if (cg != 0.0) s += cg * g / (d * d);
     P.step[q] = s;
-    gs += g * s; sn += s * s;
+    const double w = P.vw ? P.vw[q] : 1.0;
+    gs += w * g * s; sn += w * s * s;
   }
   vec_reduce(P, gs, SC_GS);
   vec_reduce(P, sn, SC_SN2);
@@ -121,8 +127,9 @@ __global__ __launch_bounds__(256) void k_xnorm(DevProblem P) {
   double acc = 0.0;
   const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
   for (int t = t0; t < P.K; t += stride) {
-    if (!P.fixed[t]) for (int k = 0; k < 7; ++k) acc += P.pose[7 * t + k] * P.pose[7 * t + k];
-    if (P.vi) for (int k = 0; k < 9; ++k) acc += P.sb[9 * t + k] * P.sb[9 * t + k];
+    const double wp = P.vw ? P.vw[(size_t)P.D * t] : 1.0, ws = (P.vw && P.vi) ? P.vw[(size_t)P.D * t + 6] : 1.0;
+    if (!P.fixed[t]) for (int k = 0; k < 7; ++k) acc += wp * P.pose[7 * t + k] * P.pose[7 * t + k];
+    if (P.vi) for (int k = 0; k < 9; ++k) acc += ws * P.sb[9 * t + k] * P.sb[9 * t + k];
   }
   for (int q = t0; q < 3 * P.L; q += stride) acc += P.lm[q] * P.lm[q];
   vec_reduce(P, acc, SC_XN2);

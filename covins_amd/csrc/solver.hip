@@ -50,7 +50,47 @@ struct covgpu_context {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   CholAux chol;
   PgoPlan pgo_plan;  // block-arrow pose-graph solve (k_pgo.hip)
+  // agent-sharded solve: global plan + this rank's identity + the caller's all-reduce
+  bool sharded = false;
+  int rank = 0, world = 1, stage_on_host = 0;
+  std::vector<int32_t> shard_block_of_kf, shard_block_rank;
+  covgpu_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  double* h_stage = nullptr; size_t h_stage_n = 0;  // pinned staging buffer (stage_on_host)
+  double* d_bvec = nullptr;                          // [12 nbk] border [grad | hdiag] exchange buffer
 };
+
+// sum (op 0) / max (op 1) of `n` device doubles over all ranks, in place; the stream is drained first so the data is final
+static void ctx_reduce(void* vc, double* dev, size_t n, int op) {
+  covgpu_context* c = (covgpu_context*)vc;
+  if (!c->allreduce || n == 0) return;
+  (void)hipStreamSynchronize(c->st);
+  if (c->stage_on_host) {
+    if (c->h_stage_n < n) { if (c->h_stage) (void)hipHostFree(c->h_stage); (void)hipHostMalloc((void**)&c->h_stage, n * sizeof(double), hipHostMallocDefault); c->h_stage_n = n; }
+    (void)hipMemcpy(c->h_stage, dev, n * sizeof(double), hipMemcpyDeviceToHost);
+    c->allreduce(c->allreduce_user, c->h_stage, (int64_t)n, op, 0);
+    (void)hipMemcpy(dev, c->h_stage, n * sizeof(double), hipMemcpyHostToDevice);
+  } else {
+    c->allreduce(c->allreduce_user, dev, (int64_t)n, op, 1);
+  }
+}
+
+extern "C" int covgpu_set_shard(covgpu_context* c, int32_t rank, int32_t world, int32_t num_kf, const int32_t* block_of_kf, int32_t num_blocks,
+                                const int32_t* block_rank, covgpu_allreduce_fn fn, void* user, int32_t stage_on_host) {
+  if (world < 1 || fn == nullptr) {  // back to the single-GPU form (world == 1 WITH a callback is allowed: the collectives become identities, which exercises the whole sharded path on one GPU)
+    c->sharded = false; c->rank = 0; c->world = 1; c->allreduce = nullptr; c->chol.reduce = nullptr;
+    return COVGPU_OK;
+  }
+  if (rank < 0 || rank >= world || !block_of_kf || !block_rank || num_blocks <= 0) { g_err = "covgpu_set_shard: bad arguments"; return COVGPU_ERR_INVALID_ARG; }
+  for (int k = 0; k < num_kf; ++k) if (block_of_kf[k] < -1 || block_of_kf[k] >= num_blocks) { g_err = "covgpu_set_shard: block_of_kf out of range"; return COVGPU_ERR_INVALID_ARG; }
+  for (int b = 0; b < num_blocks; ++b) if (block_rank[b] < 0 || block_rank[b] >= world) { g_err = "covgpu_set_shard: block_rank out of range"; return COVGPU_ERR_INVALID_ARG; }
+  c->sharded = true; c->rank = rank; c->world = world; c->stage_on_host = stage_on_host;
+  c->shard_block_of_kf.assign(block_of_kf, block_of_kf + num_kf); c->shard_block_rank.assign(block_rank, block_rank + num_blocks);
+  c->allreduce = fn; c->allreduce_user = user;
+  c->chol.reduce = ctx_reduce; c->chol.reduce_ctx = c;
+  return COVGPU_OK;
+}
+
 
 extern "C" void covgpu_default_options(covgpu_options* o) {
   std::memset(o, 0, sizeof(*o));
@@ -118,6 +158,7 @@ extern "C" void covgpu_destroy(covgpu_context* c) {
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   c->chol.destroy();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
 }
@@ -244,10 +285,61 @@ extern "C" int32_t covgpu_gba_partition(const covgpu_options* opt, const covgpu_
   }
   ArrowHostPlan hp;
   if (!gba_plan_analyse(p->num_kf, (int)chain_ptr.size() - 1, chain_ptr.data(), (int)pi.size(), pi.data(), pj.data(), (int)ei.size(), ei.data(), ej.data(),
-                        force != 0, hp))
+                        force != 0, pos_kf.data(), hp))
     return 0;
   for (int k = 0; k < p->num_kf; ++k) block_of_kf[k] = hp.blk[perm[k]];
   return hp.nblk;
+}
+
+// Host-only: the multi-GPU split of ONE map. The global block-arrow plan plus the owner of
+// every block, landmark, IMU factor and between factor:
+//   * blocks (agents' interiors) -> ranks by longest-processing-time-first on their observation counts;
+//   * a landmark -> the rank of the one block whose INTERIOR keyframes observe it (no landmark is seen from two
+//     interiors: that is the plan's invariant), else the rank of its first observer's agent;
+//   * an IMU factor -> the rank of its agent (IMU chains are intra-agent, optimization_be.cpp:369);
+//   * a between factor -> the rank of an interior endpoint, else of kf1's agent.
+// With this assignment every contribution a rank computes lands in its own arrow buffers or in the border system — the
+// only part that is all-reduced. Returns the number of blocks (0: map does not split; arrays untouched).
+extern "C" int32_t covgpu_shard_plan(const covgpu_options* opt, const covgpu_problem* p, int32_t world, int32_t* block_of_kf, int32_t* block_rank,
+                                     int32_t* lm_rank, int32_t* imu_rank, int32_t* edge_rank) {
+  if (world < 1) return 0;
+  const int32_t nblk = covgpu_gba_partition(opt, p, 1, block_of_kf);
+  if (nblk <= 0) return 0;
+  const int K = p->num_kf;
+  // agent (IMU chain) of every keyframe, and the block of every agent
+  std::vector<int> perm, pos_kf, chain_ptr;
+  if (build_chains(p, true, perm, pos_kf, chain_ptr) != COVGPU_OK) return 0;
+  const int nch = (int)chain_ptr.size() - 1;
+  std::vector<int> chain_of_kf(K), block_of_chain(nch, -1);
+  for (int ch = 0; ch < nch; ++ch)
+    for (int q = chain_ptr[ch]; q < chain_ptr[ch + 1]; ++q) { chain_of_kf[pos_kf[q]] = ch; if (block_of_kf[pos_kf[q]] >= 0) block_of_chain[ch] = block_of_kf[pos_kf[q]]; }
+  // LPT: heaviest block first onto the least loaded rank
+  std::vector<long long> w(nblk, 0), load(world, 0);
+  for (int o = 0; o < p->num_obs; ++o) { const int b = block_of_kf[p->obs_kf[o]]; if (b >= 0) w[b]++; }
+  std::vector<int> order(nblk);
+  for (int b = 0; b < nblk; ++b) order[b] = b;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return w[x] > w[y]; });
+  for (int b : order) {
+    int best = 0;
+    for (int r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
+    block_rank[b] = best; load[best] += w[b];
+  }
+  auto rank_of_chain = [&](int ch) { return block_of_chain[ch] >= 0 ? block_rank[block_of_chain[ch]] : 0; };
+  for (int l = 0; l < p->num_lm; ++l) {
+    int r = -1;
+    for (int o = p->lm_obs_ptr[l]; o < p->lm_obs_ptr[l + 1] && r < 0; ++o) {
+      const int kf = p->obs_kf[o], b = block_of_kf[kf];
+      if (b >= 0 && !p->kf_fixed[kf]) r = block_rank[b];  // (a constant keyframe has no pose block: it binds nobody)
+    }
+    if (r < 0) r = p->lm_obs_ptr[l + 1] > p->lm_obs_ptr[l] ? rank_of_chain(chain_of_kf[p->obs_kf[p->lm_obs_ptr[l]]]) : 0;
+    lm_rank[l] = r;
+  }
+  for (int f = 0; f < p->num_imu; ++f) imu_rank[f] = rank_of_chain(chain_of_kf[p->imu_kf_j[f]]);
+  for (int e = 0; e < p->num_edge; ++e) {
+    const int bi = p->kf_fixed[p->edge_i[e]] ? -1 : block_of_kf[p->edge_i[e]], bj = p->kf_fixed[p->edge_j[e]] ? -1 : block_of_kf[p->edge_j[e]];
+    edge_rank[e] = bi >= 0 ? block_rank[bi] : (bj >= 0 ? block_rank[bj] : rank_of_chain(chain_of_kf[p->edge_i[e]]));
+  }
+  return nblk;
 }
 
 static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, bool pgo, bool allow_arrow = true) {
@@ -472,8 +564,30 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
     const char* e_dense = getenv("COVGPU_GBA_DENSE");
     const char* e_arrow = getenv("COVGPU_GBA_ARROW");
     const bool force = e_arrow && e_arrow[0] == '1';
-    if (vi && allow_arrow && !(e_dense && e_dense[0] == '1') &&
-        gba_plan_analyse(P.K, P.nchains, chain_ptr.data(), (int)h_pair_i.size(), h_pair_i.data(), h_pair_j.data(), P.nepairs, ei.data(), ej.data(), force, hp)) {
+    bool have_plan = false;
+    std::vector<char> own_pose(P.K, 1), own_chain(P.K, 1);  // by IR keyframe: does THIS rank count the pose / the speed-bias rows
+    if (c->sharded && !pgo) {
+      // global plan given (covgpu_shard_plan): border and block of every keyframe; this rank owns the blocks of its agents
+      if (!vi || (int)c->shard_block_of_kf.size() != P.K) { g_err = "sharded solve needs the visual-inertial problem the shard plan was made for"; return COVGPU_ERR_INVALID_ARG; }
+      std::vector<char> border(P.K), owned(P.K);
+      for (int q = 0; q < P.K; ++q) {
+        const int b = c->shard_block_of_kf[pos_kf[q]];
+        border[q] = b < 0; owned[q] = b >= 0 && c->shard_block_rank[b] == c->rank;
+      }
+      gba_plan_build(P.K, P.nchains, chain_ptr.data(), (int)h_pair_i.size(), h_pair_i.data(), h_pair_j.data(), P.nepairs, ei.data(), ej.data(),
+                     border.data(), owned.data(), pos_kf.data(), hp);
+      have_plan = true;
+      // a chain (agent) is eliminated by the rank that holds its IMU factors: chains of length > 1 here are mine
+      for (int ch = 0; ch < P.nchains; ++ch) {
+        const bool mine = chain_ptr[ch + 1] - chain_ptr[ch] > 1;
+        for (int q = chain_ptr[ch]; q < chain_ptr[ch + 1]; ++q) own_chain[pos_kf[q]] = mine;
+      }
+      for (int q = 0; q < P.K; ++q) own_pose[pos_kf[q]] = border[q] ? (c->rank == 0) : owned[q];
+    } else if (vi && allow_arrow && !(e_dense && e_dense[0] == '1')) {
+      have_plan = gba_plan_analyse(P.K, P.nchains, chain_ptr.data(), (int)h_pair_i.size(), h_pair_i.data(), h_pair_j.data(), P.nepairs, ei.data(), ej.data(),
+                                   force, pos_kf.data(), hp);
+    }
+    if (have_plan) {
       P.arrow = 1;
       P.ar_nblk = hp.nblk; P.ar_nbk = hp.nbk;
       P.ar_nIpad = ((6 * hp.max_int + 2 * kTile - 1) / (2 * kTile)) * (2 * kTile);  // whole big panels (tstop is even)
@@ -486,10 +600,26 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
       RC(dev_upload(c, &P.ar_blk, hp.blk.data(), hp.blk.size())); RC(dev_upload(c, &P.ar_loc, hp.loc.data(), hp.loc.size()));
       RC(dev_upload(c, &P.ar_own, own.data(), own.size())); RC(dev_upload(c, &P.ar_nint, hp.nint.data(), hp.nint.size()));
       RC(dev_upload(c, &P.ar_bpos, hp.bpos.data(), hp.bpos.size()));
+      std::vector<int> live(2 * (size_t)hp.nblk);
+      for (int a = 0; a < hp.nblk; ++a) { live[2 * a] = (6 * hp.nint[a] + kTile - 1) / kTile; live[2 * a + 1] = (6 * (int)hp.own[a].size() + kTile - 1) / kTile; }
+      RC(dev_upload(c, &P.ar_live, live.data(), live.size()));
+      c->chol.live_h = live;
       RC(dev_alloc(c, &P.ar_M, (size_t)P.ar_nblk * P.ar_ntot * P.ar_ntot)); RC(dev_alloc(c, &P.ar_rhs, (size_t)P.ar_nblk * 2 * P.ar_ntot));
       RC(dev_alloc(c, &P.ar_Linv, (size_t)P.ar_nblk * P.ar_nIpad * kTile));
-      RC(dev_alloc(c, &P.ar_Sb, (size_t)P.ar_nb * P.ar_nb)); RC(dev_alloc(c, &P.ar_rhsb, (size_t)2 * P.ar_nb));
+      RC(dev_alloc(c, &P.ar_Sb, (size_t)P.ar_nb * P.ar_nb + 2 * (size_t)P.ar_nb));  // [C_b | b_b | y_b]: one contiguous all-reduce
+      P.ar_rhsb = P.ar_Sb + (size_t)P.ar_nb * P.ar_nb;
       RC(dev_alloc(c, &P.ar_Linvb, (size_t)P.ar_nb * kTile));
+      RC(dev_alloc(c, &P.ar_dummy, (size_t)64));
+      if (c->sharded) {
+        P.shard = 1;
+        std::vector<double> vw((size_t)P.N, 1.0);  // landmarks: all mine (the sub-problem holds this rank's landmarks only)
+        for (int k = 0; k < P.K; ++k) {
+          for (int r = 0; r < 6; ++r) vw[(size_t)P.D * k + r] = own_pose[k] ? 1.0 : 0.0;
+          for (int r = 6; r < P.D; ++r) vw[(size_t)P.D * k + r] = own_chain[k] ? 1.0 : 0.0;
+        }
+        RC(dev_upload(c, &P.vw, vw.data(), vw.size()));
+        RC(dev_alloc(c, &c->d_bvec, (size_t)12 * std::max(hp.nbk, 1)));
+      }
       HIPCHK(hipStreamSynchronize(c->st));
       if (opt->verbose)
         std::printf("[covgpu] arrow plan: %d blocks (largest interior %d keyframes, own border <= %d), border %d keyframes; buffers %.2f GB\n",
@@ -549,6 +679,19 @@ static int read_scalars(covgpu_context* c) {
   HIPCHK(hipMemcpyAsync(c->h_scal, c->P.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipMemcpyAsync(c->h_scal + SC_COUNT, c->P.flag, sizeof(int), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
+  if (c->sharded && c->have && c->P.shard && c->allreduce) {
+    // every scalar of the trust-region loop is a sum over residuals / unknowns each counted by exactly one rank
+    // (DevProblem::vw), except the gradient max-norm and the Cholesky failure flag (max): all ranks then take the same
+    // accept / reject decisions
+    double* h = c->h_scal;
+    int flag; std::memcpy(&flag, h + SC_COUNT, sizeof(int));
+    double mx[2] = {h[SC_GMAX], (double)flag};
+    h[SC_GMAX] = 0.0;
+    c->allreduce(c->allreduce_user, h, SC_COUNT, 0, 0);
+    c->allreduce(c->allreduce_user, mx, 2, 1, 0);
+    h[SC_GMAX] = mx[0];
+    flag = (int)mx[1]; std::memcpy(h + SC_COUNT, &flag, sizeof(int));
+  }
   return COVGPU_OK;
 }
 static int chol_failed(covgpu_context* c) { int f; std::memcpy(&f, c->h_scal + SC_COUNT, sizeof(int)); return f; }
@@ -570,6 +713,13 @@ static void enqueue_build(covgpu_context* c, double mu) {
   launch_imu_gather(P, 0, c->st);  // pose-dimension part: adds onto the blocks k_kf_reduce assigned (fixed order: visual, inertial, loop)
   launch_edge_build(P, c->st);
   launch_edge_gather(P, c->st);
+  if (P.shard) {
+    // shared poses: gradient and diag(J^T J) rows of the border keyframes are sums over all ranks' residuals — needed
+    // before the damping (finalize_diag) and by every norm of the trust-region step
+    launch_border_vec(P, c->d_bvec, 0, c->st);
+    ctx_reduce(c, c->d_bvec, (size_t)12 * P.ar_nbk, 0);
+    launch_border_vec(P, c->d_bvec, 1, c->st);
+  }
   launch_finalize_diag(P, mu, P.vi ? 0 : 2, c->st);
   launch_part_finish(P, SC_COST, 1, c->st);
   if (c->profiling) (void)hipEventRecord(c->ev[1], c->st);

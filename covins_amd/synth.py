@@ -53,6 +53,7 @@ class SynthConfig:
     new_lm_per_kf: int = 40
     track_window: int = 10                # landmark visible at most +-window keyframes around its birth
     max_obs_per_kf: int = 400             # SURVEY.md §8d cap
+    min_parallax_cos: float = 0.9998      # a front-end only triangulates rays at least ~1.15 deg apart (orb_slam3/src/LocalMapping.cc:674-675)
     p_fuse: float = 0.5                   # fraction of a loop zone's landmarks that the loop closure fuses
     fuse_window: int = 8                  # loop zone: +-window keyframes around either loop keyframe
     max_fused_obs: int = 6
@@ -311,6 +312,32 @@ def make_map(cfg: SynthConfig) -> SlamMap:
     pos = np.arange(len(obs_k)) - np.maximum.accumulate(np.where(first, np.arange(len(obs_k)), 0))
     keep = pos < cfg.max_obs_per_kf
     obs_l, obs_k, obs_uv = obs_l[keep], obs_k[keep], obs_uv[keep]
+    # parallax gate: ORB-SLAM3 creates a map point only from rays with cosParallaxRays < 0.9998 (LocalMapping.cc:674-675),
+    # so a COVINS map holds no landmark whose observing keyframes all sit (almost) on one ray — e.g. born while the
+    # vehicle stands still. Smallest pairwise ray cosine per landmark, in chunks.
+    if cfg.min_parallax_cos < 1.0 and len(obs_l):
+        o4 = np.lexsort((obs_k, obs_l))
+        ol, ok_ = obs_l[o4], obs_k[o4]
+        ray = lm_all[ol] - pc_true[ok_]
+        ray /= np.linalg.norm(ray, axis=1, keepdims=True)
+        cnt0 = np.bincount(ol, minlength=M)
+        ptr0 = np.concatenate([[0], np.cumsum(cnt0)])
+        within = np.arange(len(ol)) - ptr0[ol]
+        maxn = int(cnt0.max())
+        mindot = np.ones(M)
+        ids = np.nonzero(cnt0 >= 2)[0]
+        for c0 in range(0, len(ids), 20000):
+            lid = ids[c0:c0 + 20000]
+            slot = -np.ones(M, np.int64); slot[lid] = np.arange(len(lid))
+            sel = slot[ol] >= 0
+            Rp = np.zeros((len(lid), maxn, 3)); msk = np.zeros((len(lid), maxn), bool)
+            Rp[slot[ol[sel]], within[sel]] = ray[sel]; msk[slot[ol[sel]], within[sel]] = True
+            dots = np.einsum("lid,ljd->lij", Rp, Rp)
+            dots[~(msk[:, :, None] & msk[:, None, :])] = 1.0
+            mindot[lid] = dots.reshape(len(lid), -1).min(axis=1)
+        flat = mindot >= cfg.min_parallax_cos
+        keep = ~flat[obs_l]
+        obs_l, obs_k, obs_uv = obs_l[keep], obs_k[keep], obs_uv[keep]
     # drop tracks < 2, compact landmark ids, sort by (landmark, kf) like std::map<KeyframePtr,...> iteration
     cnt = np.bincount(obs_l, minlength=M)
     good = cnt >= 2

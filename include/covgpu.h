@@ -243,6 +243,27 @@ int32_t covgpu_pgo_partition(int32_t num_kf, int32_t num_edge, const int32_t* ed
  * skips the pay-off test). Invariant: no covisible pair and no loop edge joins the interiors of two blocks. */
 int32_t covgpu_gba_partition(const covgpu_options* opt, const covgpu_problem* p, int32_t force, int32_t* block_of_kf);
 
+/* ---------------------------------------------------------------- multi-GPU: ONE map sharded by agent
+ * BASELINE.json north star: "the merged multi-agent map shards by agent/sub-map across the GPUs of one node with RCCL
+ * all-reduce over xGMI on the shared-pose Hessian blocks at each LM iteration". One process and one context per GPU.
+ *   1. every rank calls covgpu_shard_plan on the FULL problem (host-only, deterministic: same answer everywhere);
+ *   2. rank r keeps the landmarks / IMU factors / between factors with *_rank == r (all keyframes stay: K is unchanged)
+ *      and calls covgpu_set_shard, then covgpu_upload / covgpu_solve_resident / covgpu_download on that sub-problem;
+ *   3. per linear solve the library all-reduces (a) gradient and diag(J^T J) of the shared keyframes' pose rows
+ *      (12 doubles per shared keyframe), (b) the shared-pose system [C_b | b_b] after every rank has eliminated the
+ *      interiors of its own agents, and per scalar read-back (c) 16 doubles. Everything else stays on its rank.
+ *   4. after the solve a keyframe's pose is valid on the rank that owns its block (shared keyframes: on every rank), its
+ *      speed-bias on the rank that holds its agent's IMU factors, a landmark on its lm_rank.
+ * The collective is the CALLER's (RCCL through torch.distributed in bench.py, a host sum in the tests): `fn` must sum
+ * (op 0) or max (op 1) `n` doubles over all ranks in place and return when the result is there. on_device = 1: `buf` is a
+ * device pointer of this context's GPU (stream already drained); 0: host memory. stage_on_host != 0: the library
+ * stages device buffers through pinned host memory and only ever hands `fn` host pointers. */
+typedef void (*covgpu_allreduce_fn)(void* user, double* buf, int64_t n, int32_t op, int32_t on_device);
+int32_t covgpu_shard_plan(const covgpu_options* opt, const covgpu_problem* p, int32_t world, int32_t* block_of_kf /* [K] */,
+                          int32_t* block_rank /* [<= K] */, int32_t* lm_rank /* [L] */, int32_t* imu_rank /* [I] */, int32_t* edge_rank /* [E] */);
+int covgpu_set_shard(covgpu_context* ctx, int32_t rank, int32_t world, int32_t num_kf, const int32_t* block_of_kf, int32_t num_blocks,
+                     const int32_t* block_rank, covgpu_allreduce_fn fn, void* user, int32_t stage_on_host);
+
 /* ---------------------------------------------------------------- measurement hooks (bench.py)
  * With profiling on, covgpu_solve_resident brackets the linearise+Schur pass, the whole factor+solve and
  * every trailing-update (SYRK) launch with HIP events on the context's own stream.

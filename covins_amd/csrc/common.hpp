@@ -82,8 +82,13 @@ struct DevProblem {
   double *Bp, *Bs, *Bn;     // [K][54] speed-bias(pos) x pose(pos-1 | pos | pos+1) blocks (9x6)
   double *Ldinv, *Lsub;       // [K][81] block-bidiagonal Cholesky factor of the speed-bias part: L_kk^-1 and L_{k,k-1}
   double *Mblk, *GI;          // [K][81] propagator M_pos = -Ldinv_pos Lsub_pos | I + Gramian of everything below pos (k_struct.hip)
-  double* Y;       // [nyrows][npad] Y = L_A^-1 B: speed-bias rows (chain order) x pose columns, zero outside the chain trapezoids
-  int nyrows;      // 9K rounded up to a multiple of 16
+  double* Y;       // Y = L_A^-1 B, stored PER CHAIN: chain c is a [9 Kc][Yld_c] row-major block at Y + Yoff[c] (speed-bias rows of
+                   // the chain x its own pose columns; zero above the trapezoid). A chain couples to its own poses only, so
+                   // the footprint is sum 54 Kc^2 doubles instead of 54 K^2 (12 agents x 1667 keyframes: 14 GB instead of 173 GB)
+  size_t* Yoff;    // [nchains] element offset of each chain's block
+  int* Yld;        // [nchains] leading dimension of each chain's block (6 Kc rounded up to 16)
+  int* pos_chain_begin;  // [K] position -> first position of its chain
+  int* pos_chain;        // [K] position -> chain index
   double* zs;      // [9K]  L_A^-1 b_s
   double* xs;      // [9K]  speed-bias solution (chain order)
   double* bp;      // [2 npad] pose right-hand side / solution of the dense stage (+ scratch half)

@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256) void k_sb_chain_cols(DevProblem P) {
   const int q = live ? col / 6 : p1 - 1, e = live ? col - 6 * q : 0;  // chain position of the pose, component
   const int pstart = q > p0 ? q - 1 : q;
   const int pfirst = max(col0 / 6 - 1, p0);
-  const size_t ld = (size_t)P.npad;
+  const size_t ld = (size_t)P.Yld[c];
+  double* const Yc = P.Y + P.Yoff[c];  // this chain's block: rows 9 (pos - p0), columns col - 6 p0
   auto fetch = [&](int pos) {
     ColOps o;
     const bool in = pos < p1;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void k_sb_chain_cols(DevProblem P) {
     yn = __builtin_amdgcn_mfma_f64_16x16x4f64(o.li[2], t[2], yn, 0, 0, 0);
     y = yn;
     if (live && pos >= pstart) {
-      double* Yp = P.Y + (size_t)(9 * pos + kq) * ld + col;
+      double* Yp = Yc + (size_t)(9 * (pos - p0) + kq) * ld + (col - 6 * p0);
       Yp[0] = y[0];
       Yp[4 * ld] = y[1];
       if (kq == 0) Yp[8 * ld] = y[2];
@@ -311,19 +312,18 @@ __global__ __launch_bounds__(128) void k_sb_gram(DevProblem P) {
 __global__ __launch_bounds__(256) void k_yty_semisep(DevProblem P) {
   __shared__ double sW[27][6];
   const int j = blockIdx.x, tid = threadIdx.x;
-  const int p1 = P.pos_chain_end[j];
-  int p0 = 0;
-  for (int c = 0; c < P.nchains; ++c) if (P.chain_ptr[c] <= j) p0 = P.chain_ptr[c];
-  const size_t ld = (size_t)P.npad;
+  const int p1 = P.pos_chain_end[j], p0 = P.pos_chain_begin[j], ch = P.pos_chain[j];
+  const size_t ld = (size_t)P.Yld[ch];
+  const double* const Yc = P.Y + P.Yoff[ch] - (size_t)9 * p0 * ld - (size_t)6 * p0;  // addressed with GLOBAL (row, column) below
   if (tid < 162) {
     const int r = tid / 6, e = tid - 6 * r, grp = r / 9, a = r - 9 * grp, pos = j - 1 + grp;
     double v = 0.0;
     if (pos >= p0 && pos < p1) {
-      if (grp < 2) v = P.Y[(size_t)(9 * pos + a) * ld + 6 * j + e];
+      if (grp < 2) v = Yc[(size_t)(9 * pos + a) * ld + 6 * j + e];
       else {
         const double* G = P.GI + (size_t)81 * pos + 9 * a;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) v += G[k] * P.Y[(size_t)(9 * pos + k) * ld + 6 * j + e];
+        for (int k = 0; k < 9; ++k) v += G[k] * Yc[(size_t)(9 * pos + k) * ld + 6 * j + e];
       }
     }
     sW[r][e] = v;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_yty_semisep(DevProblem P) {
   for (int c = 6 * p0 + tid; c < 6 * (j + 1); c += 256) {
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int r = r0; r < r1; ++r) {
-      const double y = P.Y[(size_t)(9 * (j - 1) + r) * ld + c];
+      const double y = Yc[(size_t)(9 * (j - 1) + r) * ld + c];
 #pragma unroll
       for (int a = 0; a < 6; ++a) acc[a] += sW[r][a] * y;
     }
@@ -351,9 +351,11 @@ __global__ __launch_bounds__(256) void k_pose_rhs(DevProblem P) {
   const int col = gid >> 3, part = gid & 7;
   double acc = 0.0;
   if (col < 6 * P.K) {
-    const int q = col / 6;
-    const int kb = 9 * max(q - 1, 0), ke = 9 * P.pos_chain_end[q];
-    for (int k = kb + part; k < ke; k += 8) acc += P.Y[(size_t)k * P.npad + col] * P.zs[k];
+    const int q = col / 6, p0 = P.pos_chain_begin[q], ch = P.pos_chain[q];
+    const size_t ld = (size_t)P.Yld[ch];
+    const double* const Yc = P.Y + P.Yoff[ch] - (size_t)9 * p0 * ld - (size_t)6 * p0;
+    const int kb = 9 * max(q - 1, p0), ke = 9 * P.pos_chain_end[q];
+    for (int k = kb + part; k < ke; k += 8) acc += Yc[(size_t)k * ld + col] * P.zs[k];
   }
   acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
   if (part == 0 && col < 6 * P.K) P.bp[col] -= acc;

@@ -363,7 +363,6 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   P.nchains = (int)chain_ptr.size() - 1;
   for (int c = 0; c < P.nchains; ++c)
     for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) chain_end[q] = chain_ptr[c + 1];
-  P.nyrows = ((9 * P.K + 15) / 16) * 16;
   P.reproj_loss_a = opt->reproj_loss_a; P.gravity = opt->gravity;
   const size_t K = P.K;
   RC(dev_upload(c, &P.pose0, p->kf_pose, 7 * K));
@@ -516,8 +515,22 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_alloc(c, &P.Ldinv, 81 * Kv)); RC(dev_alloc(c, &P.Lsub, 81 * Kv));
   RC(dev_alloc(c, &P.Mblk, 81 * Kv)); RC(dev_alloc(c, &P.GI, 81 * Kv));
   RC(dev_alloc(c, &P.zs, 9 * Kv)); RC(dev_alloc(c, &P.xs, 9 * Kv));
-  RC(dev_alloc(c, &P.Y, vi ? (size_t)P.nyrows * P.npad : 0));
-  if (vi) HIPCHK(hipMemsetAsync(P.Y, 0, (size_t)P.nyrows * P.npad * sizeof(double), c->st));  // only the chain trapezoids are ever written
+  {  // Y per chain (common.hpp): [9 Kc][roundup(6 Kc, 16)] blocks back to back
+    std::vector<size_t> yoff(P.nchains);
+    std::vector<int> yld(P.nchains), cbeg(P.K), cidx(P.K);
+    size_t ytot = 0;
+    for (int ch = 0; ch < P.nchains; ++ch) {
+      const int kc = chain_ptr[ch + 1] - chain_ptr[ch];
+      yld[ch] = ((6 * kc + 15) / 16) * 16; yoff[ch] = ytot;
+      ytot += (size_t)9 * kc * yld[ch];
+      for (int q = chain_ptr[ch]; q < chain_ptr[ch + 1]; ++q) { cbeg[q] = chain_ptr[ch]; cidx[q] = ch; }
+    }
+    RC(dev_upload(c, &P.Yoff, yoff.data(), yoff.size())); RC(dev_upload(c, &P.Yld, yld.data(), yld.size()));
+    RC(dev_upload(c, &P.pos_chain_begin, cbeg.data(), cbeg.size())); RC(dev_upload(c, &P.pos_chain, cidx.data(), cidx.size()));
+    RC(dev_alloc(c, &P.Y, vi ? ytot : 0));
+    if (vi) HIPCHK(hipMemsetAsync(P.Y, 0, ytot * sizeof(double), c->st));  // only the chain trapezoids are ever written
+    HIPCHK(hipStreamSynchronize(c->st));
+  }
   RC(dev_alloc(c, &P.grad, (size_t)P.N)); RC(dev_alloc(c, &P.hdiag, (size_t)P.N));
   RC(dev_alloc(c, &P.HllInv, (size_t)6 * P.L));
   RC(dev_alloc(c, &P.gn, (size_t)P.N)); RC(dev_alloc(c, &P.step, (size_t)P.N)); RC(dev_alloc(c, &P.vtmp, (size_t)P.N));

@@ -50,6 +50,8 @@ class SynthConfig:
     agents: Sequence[int] = (1,)          # EuRoC MH sequence per agent (1..5); >5 agents re-pose copies
     max_kf_per_agent: Optional[int] = None
     kf_start: int = 0
+    kf_per_agent: Optional[int] = None    # resample every agent's path to this many keyframes (1667)
+    kf_dt: float = 0.25                   # keyframe spacing [s] of the resampled paths (a multiple of 1/200 s)
     new_lm_per_kf: int = 40
     track_window: int = 10                # landmark visible at most +-window keyframes around its birth
     max_obs_per_kf: int = 400             # SURVEY.md §8d cap
@@ -102,6 +104,11 @@ def _agent_trajectory(seq: int, agent: int, cfg: SynthConfig):
         c = 0.5 * (HALL_MIN + HALL_MAX)
         p_wc = yaw.apply(p_wc - c) * 0.9 + c
         q_wc = (yaw * R.from_quat(q_wc)).as_quat()
+    if cfg.kf_per_agent:  # same path, denser keyframes on a new time base (IMU is differentiated from the splines below)
+        u = np.linspace(t[0], t[-1], cfg.kf_per_agent)
+        p_wc = CubicSpline(t, p_wc)(u)
+        q_wc = RotationSpline(t, R.from_quat(q_wc))(u).as_quat()
+        t = np.arange(cfg.kf_per_agent) * cfg.kf_dt
     s0 = cfg.kf_start
     s1 = len(t) if cfg.max_kf_per_agent is None else min(len(t), s0 + cfg.max_kf_per_agent)
     t, p_wc, q_wc = t[s0:s1] - t[s0], p_wc[s0:s1], q_wc[s0:s1]
@@ -438,6 +445,10 @@ def config_named(name: str, seed: int = 0) -> SynthConfig:
         return SynthConfig(agents=(1, 2, 3, 4, 5), seed=seed)
     if name == "a12x500":         # configs[4] at reduced scale: 12 agents (5 MH paths + 7 re-posed copies), <= 500 keyframes each
         return SynthConfig(agents=tuple(range(1, 13)), max_kf_per_agent=500, seed=seed)
+    if name == "a12":             # configs[4] at its stated size: 12 agents x 1667 keyframes = 20k keyframes, ~2M landmarks, 500 obs / keyframe
+        return SynthConfig(agents=tuple(range(1, 13)), kf_per_agent=1667, kf_dt=0.08, new_lm_per_kf=110, max_obs_per_kf=500, seed=seed)
+    if name == "a12x1000":        # 12 agents x 1000 keyframes
+        return SynthConfig(agents=tuple(range(1, 13)), kf_per_agent=1000, kf_dt=0.1, new_lm_per_kf=110, max_obs_per_kf=500, seed=seed)
     if name == "tiny":            # CPU tests
         return SynthConfig(agents=(1, 3), max_kf_per_agent=14, new_lm_per_kf=14, track_window=5, fuse_window=3,
                            loops_per_pair=1, seed=seed)

@@ -91,3 +91,32 @@ def test_visual_only_gba_and_equidistant_camera():
     me.obs_uv[idx.obs_rows] = (r * pt.obs_sigma[:, None] + rng.normal(0, 1.0, r.shape)).astype(np.float32)
     Optimization.GlobalBundleAdjustment(me, 10, -1.0, False, True, False)
     assert ate(me) < 0.01
+
+
+def test_twelve_agent_map_runs_on_one_gpu():
+    """BASELINE configs[4] shape at 12 x 1000 keyframes (1.1M landmarks, 5.4M observations) on ONE GPU (VERDICT r01 item 6 /
+    row J1): no K^2 allocation is left (pose system in block-arrow buffers, Y per chain), so the footprint reported by the
+    allocator stays far below the 115 + 173 GB the dense layout would need at the stated 20k-keyframe size. Size-independent
+    properties instead of an oracle run (the CPU oracle does not finish at this size): monotone accepted steps, ATE drops."""
+    import os
+    name = "a12" if os.environ.get("COVGPU_TEST_A12") == "1" else "a12x1000"   # a12 = the stated 20k keyframes / 2M landmarks
+    m = synth.make_map(synth.config_named(name))
+    p = mapdata.flatten_gba(m, False, True)[0]
+    assert p.K >= 12000 and p.L > 1_000_000
+    ctx = backend.Context(0)
+    o = backend.default_options(max_iterations=6)
+    ctx.upload(p, o)
+    lay = ctx.layout()
+    assert lay["arrow"] == 1 and lay["blocks"] == 12
+    dense_gb = (6.0 * p.K) ** 2 * 8e-9 * (1 + 1.5)   # dense C + K-major Y of the round-1 layout
+    print(f"{name}: K={p.K} L={p.L} O={p.O} layout {lay} (round-1 layout would need {dense_gb:.0f} GB for C and Y alone)")
+    assert lay["device_mib"] / 1024.0 < 0.5 * dense_gb
+    res = ctx.solve_resident(o)
+    sol = ctx.download()
+    ctx.close()
+    tr = np.array(res.cost_trace[:res.iterations]); acc = np.array(res.accepted_trace[:res.iterations])
+    assert acc.sum() >= 4 and np.all(np.diff(tr) <= 1e-9 * tr[:-1]) and res.final_cost < 0.2 * res.initial_cost
+    truth = m.truth["kf_pose"][:, 4:]
+    a0, a1 = synth.ate_rmse(p.kf_pose[:, 4:], truth), synth.ate_rmse(sol.kf_pose[:, 4:], truth)
+    print(f"{name}: {res.iterations} iterations in {res.t_solve_s:.2f} s, cost {res.initial_cost:.4e} -> {res.final_cost:.4e}, ATE {a0:.4f} -> {a1:.4f} m")
+    assert a1 < 0.5 * a0

@@ -47,4 +47,7 @@ def landmark_parity(sol_lm, ref_prob, ref_lm=None, idx=None):
     good = cond < 1e6
     dist = np.linalg.norm(d, axis=1)
     white = np.sqrt(np.einsum("li,lij,lj->l", d, H, d).clip(0))
+    if not good.any() and len(cond):  # diagnostic for an unexplained all-ill result seen once on a GPU box
+        print(f"landmark_parity: no well-conditioned landmark: |H|max={np.abs(H).max():.3e} cond min={np.nanmin(cond):.3e} "
+              f"nan={int(np.isnan(cond).sum())} |d|max={dist.max():.3e} L={len(cond)}")
     return int((~good).sum()), float(dist[good].max() if good.any() else 0.0), float(white.max() if len(white) else 0.0)

@@ -143,6 +143,12 @@ class Context:
         self._check(lib().covgpu_set_shard(self._h, int(rank), int(plan.world), len(bk), iptr(bk), int(plan.num_blocks), iptr(br),
                                            C.cast(callback, C.c_void_p), None, int(stage_on_host)))
 
+    def outlier_pass(self, n_obs: int, n_lm: int, threshold: float):
+        """Outlier flags and per-landmark remaining-observation counts at the resident estimate (covgpu_outlier_pass)."""
+        erase = np.zeros(max(n_obs, 1), np.uint8); left = np.zeros(max(n_lm, 1), np.int32); cnt = (C.c_int64 * 2)()
+        self._check(lib().covgpu_outlier_pass(self._h, float(threshold), erase.ctypes.data_as(capi._bp), iptr(left), cnt))
+        return erase[:n_obs].astype(bool), left[:n_lm], (int(cnt[0]), int(cnt[1]))
+
     def set_profiling(self, on: bool):
         lib().covgpu_set_profiling(self._h, int(on))
 

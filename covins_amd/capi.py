@@ -200,6 +200,7 @@ def declare(lib: C.CDLL, prefix: str) -> None:
         d("pgo_partition", [C.c_int32, C.c_int32, _ip, _ip, _ip], C.c_int32)
         d("gba_partition", [OP, PP, C.c_int32, _ip], C.c_int32)
         d("gn_step", [C.c_void_p, OP, PP, C.c_double, _dp, _dp, _dp])
+        d("outlier_pass", [C.c_void_p, C.c_double, _bp, _ip, C.POINTER(C.c_int64)])
         d("shard_plan", [OP, PP, C.c_int32, _ip, _ip, _ip, _ip, _ip], C.c_int32)
         d("set_shard", [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _ip, C.c_int32, _ip, C.c_void_p, C.c_void_p, C.c_int32])
 

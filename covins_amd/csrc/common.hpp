@@ -169,6 +169,7 @@ void launch_obs_jvp(const DevProblem& P, const double* v_all, hipStream_t st);  
 void launch_obs_cost(const DevProblem& P, const double* pose, const double* lm, hipStream_t st);  // scal[SC_COST] +=
 void launch_obs_linearize(const DevProblem& P, double* r, double* Jp, double* Jl, double* cost, hipStream_t st);
 void launch_obs_norms(const DevProblem& P, double* norms, hipStream_t st);
+void launch_lm_outliers(const DevProblem& P, double th, unsigned char* erase, int* left, unsigned long long* counts, hipStream_t st);
 
 void launch_preintegrate(const DevProblem& P, hipStream_t st);
 void launch_imu_build(const DevProblem& P, hipStream_t st);

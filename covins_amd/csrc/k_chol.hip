@@ -235,6 +235,98 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) { gemm_abt_body
 template <int MODE, int TSA, int TSB>
 __global__ __launch_bounds__(256, 2) void k_gemm_abt_q(GemmArgs g) { gemm_abt_body<MODE, TSA, TSB, KCQ>(g); }
 
+COV_DEV double rdlane64c(double v, int srclane) {  // broadcast from a wave-uniform lane through SGPRs
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), srclane);
+  const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), srclane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Shared tail of the potrf kernels. On entry `s` ([128][129] in LDS) holds, in its 16x16 diagonal blocks, the INVERSES of
+// the factor's diagonal blocks and, below them, the factor L itself; on exit Linv_out = L^-1 and (optionally) y = L^-1 rhs.
+// one level of the recursive-doubling inverse, NQ tiles per wave advanced in lockstep: NQ independent accumulator chains
+// keep the matrix pipe busy where a single dependent chain of v_mfma_f64 left it idle most of the time (tools/potrf_probe:
+// 20 us for the three levels with one chain per wave)
+template <int NQ>
+COV_DEV void inv_level(double* s, int h, int wave, int fr, int fk) {
+  constexpr int PT = kTile + 1;
+  const int hb = h >> 4, tpp = hb * hb;
+  int base[NQ], tr[NQ], tc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int t = wave + 4 * q, pr = t / tpp, rem = t - pr * tpp;
+    tr[q] = rem / hb; tc[q] = rem - tr[q] * hb; base[q] = 2 * pr * h;
+  }
+  __syncthreads();
+  {  // T = C A^-1   (A^-1 lower: rows k >= c only); parked in the mirrored upper block
+    v4f64 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < h; kk += 4) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (kk < tc[q] * 16) continue;  // wave-uniform
+        const int k = kk + fk, c = tc[q] * 16 + fr;
+        const double av = s[(base[q] + h + tr[q] * 16 + fr) * PT + base[q] + k];
+        const double bv = (k >= c) ? s[(base[q] + k) * PT + base[q] + c] : 0.0;
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) s[(base[q] + tc[q] * 16 + fr) * PT + base[q] + h + tr[q] * 16 + fk + 4 * rg] = acc[q][rg];
+  }
+  __syncthreads();
+  {  // X21 = -B^-1 T   (B^-1 lower: k <= r only); X overwrites the C block (no longer needed)
+    v4f64 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < h; kk += 4) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (kk >= tr[q] * 16 + 16) continue;
+        const int k = kk + fk, r = tr[q] * 16 + fr;
+        const double av = (k <= r) ? s[(base[q] + h + r) * PT + base[q] + h + k] : 0.0;
+        const double bv = s[(base[q] + tc[q] * 16 + fr) * PT + base[q] + h + k];
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) s[(base[q] + h + tr[q] * 16 + fk + 4 * rg) * PT + base[q] + tc[q] * 16 + fr] = -acc[q][rg];
+  }
+}
+
+// Shared tail of the potrf kernels. On entry `s` ([128][129] in LDS) holds, in its 16x16 diagonal blocks, the INVERSES of
+// the factor's diagonal blocks and, below them, the factor L itself; on exit Linv_out = L^-1 and (optionally) y = L^-1 rhs.
+COV_DEV void potrf_tail(double* s, double* __restrict__ Linv_out, const double* __restrict__ rhs, double* __restrict__ yout, int k0) {
+  constexpr int PT = kTile + 1;
+  const int tid = threadIdx.x;
+  // levels h = 16, 32, 64 on the matrix core: both products are small GEMMs (triangular operands masked to zero);
+  // 4, 8, 16 output tiles per level = 1, 2, 4 per wave
+  {
+    const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
+    inv_level<1>(s, 16, wave, fr, fk);
+    inv_level<2>(s, 32, wave, fr, fk);
+    inv_level<4>(s, 64, wave, fr, fk);
+  }
+  __syncthreads();
+  PROBE(4);
+  for (int idx = tid; idx < kTile * kTile; idx += 256) {
+    const int r = idx >> 7, c = idx & 127;
+    Linv_out[idx] = (c <= r) ? s[r * PT + c] : 0.0;
+  }
+  // forward substitution riding along: y_p = L_pp^-1 b_p. Every earlier panel's TRSM has already taken its
+  // L[rows p, q] y_q out of b_p (the diagonal tile itself depends on those TRSMs).
+  if (rhs != nullptr && tid < kTile) {
+    double acc = 0.0;
+    for (int k = 0; k <= tid; ++k) acc += s[tid * PT + k] * rhs[k0 + k];
+    yout[k0 + tid] = acc;
+  }
+}
+
 // Factor the 128x128 diagonal block at (k0,k0) (lower Cholesky) and form its inverse.
 // L (lower incl. diagonal) is written back into M; L^-1 (lower, zeros above) goes to Linv_out [128][128].
 //
@@ -367,54 +459,153 @@ __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_
       s[(base + h + r) * PT + base + c] = -sum;
     }
   }
-  // levels h = 16, 32, 64 on the matrix core: both products are small GEMMs (triangular operands masked to zero)
-  {
-    const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
-    for (int h = 16; h < kTile; h <<= 1) {
-      const int tpp = (h >> 4) * (h >> 4);   // 16x16 output tiles per pair
-      const int ntile = (64 / h) * tpp;      // 4, 8, 16
-      __syncthreads();
-      for (int t = wave; t < ntile; t += 4) {  // T = C A^-1   (A^-1 lower: rows k >= c only)
-        const int pr = t / tpp, rem = t - pr * tpp, tr = rem / (h >> 4), tc = rem - tr * (h >> 4), base = 2 * pr * h;
-        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int kk = tc * 16; kk < h; kk += 4) {
-          const int k = kk + fk, c = tc * 16 + fr;
-          const double av = s[(base + h + tr * 16 + fr) * PT + base + k];
-          const double bv = (k >= c) ? s[(base + k) * PT + base + c] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
+  potrf_tail(s, Linv_out, rhs, yout, k0);
+  PROBE(5);
+}
+
+// Blocked form of the same kernel (COVGPU_POTRF=2): the 128 pivot steps of k_potrf_inv cost 0.47 us each — one barrier,
+// one LDS round trip and a 64-FMA register update per pivot — and 40 of these kernels sit on the serial chain of every
+// linear solve. Here the tile stays in LDS and is factored 16 columns at a time:
+//   (a) wave 0 factors the 16x16 diagonal block in registers (row per lane, v_readlane broadcasts — no barrier inside) and
+//       leaves the reciprocal pivots; the eight block inverses the recursive-doubling tail starts from are formed at
+//       the end, one column per thread, all blocks at once;
+//   (b) every thread solves ONE row of the 16-column panel by forward substitution against that block (broadcast LDS
+//       reads; a product with the explicit inverse would be cheaper but loses the backward stability the ill-conditioned
+//       reduced camera system needs — k_potrf_inv's header records that dead end);
+//   (c) the trailing tiles are updated on the matrix core, C_ik -= L_ij L_kj^T, read-modify-write in LDS.
+// Three barriers per 16 pivots instead of sixteen; the serial part is the diagonal blocks only.
+__global__ __launch_bounds__(256) void k_potrf_inv_blk(double* __restrict__ M, size_t ld, int k0, double* __restrict__ Linv_out, int* flag,
+                                                        const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR) {
+  M += (size_t)blockIdx.x * bsM; Linv_out += (size_t)blockIdx.x * bsL;
+  if (rhs != nullptr) { rhs += (size_t)blockIdx.x * bsR; yout += (size_t)blockIdx.x * bsR; }
+  extern __shared__ __attribute__((aligned(16))) double s[];  // [128][129] | sX [8][16][16] | sInv [128]
+  constexpr int PT = kTile + 1, NB = 16, NJ = kTile / NB;
+  double* sX = s + kTile * PT;
+  double* sInv = sX + NJ * NB * NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* Mg = M + (size_t)k0 * ld + k0;
+  PROBE(0);
+  {  // lower triangle in, zeros above: 16 independent loads in flight per thread (one at a time took 26 us)
+    const int c = tid & 127, rh = tid >> 7;
+#pragma unroll 1
+    for (int r0 = 0; r0 < kTile; r0 += 32) {
+      double v[16];
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) s[(base + tc * 16 + fr) * PT + base + h + tr * 16 + fk + 4 * rg] = acc[rg];
-      }
-      __syncthreads();
-      for (int t = wave; t < ntile; t += 4) {  // X21 = -B^-1 T   (B^-1 lower: k <= r only)
-        const int pr = t / tpp, rem = t - pr * tpp, tr = rem / (h >> 4), tc = rem - tr * (h >> 4), base = 2 * pr * h;
-        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int kk = 0; kk < tr * 16 + 16; kk += 4) {
-          const int k = kk + fk, r = tr * 16 + fr;
-          const double av = (k <= r) ? s[(base + h + r) * PT + base + h + k] : 0.0;
-          const double bv = s[(base + tc * 16 + fr) * PT + base + h + k];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-        // all tiles of this phase read only B^-1 and T; X overwrites the C block (no longer needed)
+      for (int i = 0; i < 16; ++i) { const int r = r0 + 2 * i + rh; v[i] = (c <= r) ? Mg[(size_t)r * ld + c] : 0.0; }
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) s[(base + h + tr * 16 + fk + 4 * rg) * PT + base + tc * 16 + fr] = -acc[rg];
-      }
+      for (int i = 0; i < 16; ++i) s[(r0 + 2 * i + rh) * PT + c] = v[i];
     }
   }
   __syncthreads();
-  PROBE(4);
-  for (int idx = tid; idx < kTile * kTile; idx += 256) {
-    const int r = idx >> 7, c = idx & 127;
-    Linv_out[idx] = (c <= r) ? s[r * PT + c] : 0.0;
+  PROBE(1);
+  for (int j = 0; j < NJ; ++j) {
+    const int o = NB * j;
+    const long long tq0 = PROBE_T0();
+    if (wave == 0) {  // (a) diagonal block: lane r (mod 16) owns row r; lanes 16..63 compute duplicates and do not store
+      // (Measured alternative, tools/potrf_probe: every lane factoring the block redundantly in its own registers as 2x2 of
+      //  8x8 blocks — no cross-lane traffic at all — takes 5.9 us per block against 4.5 us here: ~1000 dependent FP64 FMAs
+      //  at one wave per SIMD cost more than the 30 v_readlane per pivot they replace.)
+      const int r = lane & 15;
+      double x[NB], invd[NB];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) x[c] = (c <= r) ? s[(o + r) * PT + o + c] : 0.0;
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        double d = rdlane64c(x[c], c);
+        if (!(d > 0.0)) { bad = true; d = 1.0; }
+        double inv = __builtin_amdgcn_rsq(d);   // hardware estimate + two Newton steps: full double precision for the
+        inv = inv * (1.5 - 0.5 * d * inv * inv);  // positive, normal-range pivots of an SPD tile
+        inv = inv * (1.5 - 0.5 * d * inv * inv);
+        invd[c] = inv;
+        x[c] = (r == c) ? d * inv : x[c] * inv;
+#pragma unroll
+        for (int cc = c + 1; cc < NB; ++cc) x[cc] -= x[c] * rdlane64c(x[c], cc);  // entries above the diagonal are never read
+      }
+      if (bad && lane == 0) atomicOr(flag, 1);
+      if (lane < NB) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) s[(o + r) * PT + o + c] = (c <= r) ? x[c] : 0.0;
+        double mine = 0.0;  // reciprocal pivot of row r
+#pragma unroll
+        for (int c = 0; c < NB; ++c) mine = (c == r) ? invd[c] : mine;
+        sInv[o + r] = mine;
+      }
+    }
+    __syncthreads();
+    PROBE_ACC(5, tq0);
+    const long long tq1 = PROBE_T0();
+    {  // (b) panel rows below the block: x L_D^T = a, one row per thread
+      const int row = o + NB + tid;
+      if (row < kTile) {
+        double a[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a[c] = s[row * PT + o + c];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          a[k] *= sInv[o + k];
+#pragma unroll
+          for (int c = k + 1; c < NB; ++c) a[c] -= a[k] * s[(o + c) * PT + o + k];
+        }
+#pragma unroll
+        for (int c = 0; c < NB; ++c) s[row * PT + o + c] = a[c];
+      }
+    }
+    __syncthreads();
+    PROBE_ACC(6, tq1);
+    const long long tq2 = PROBE_T0();
+    {  // (c) trailing update of tiles (i, k), j < k <= i < 8
+      const int m = NJ - 1 - j, nT = m * (m + 1) / 2, fr = lane & 15, fk = lane >> 4;
+      for (int t = wave; t < nT; t += 4) {
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        const int tk = t - ti * (ti + 1) / 2;
+        const int ri = o + NB * (1 + ti), rk = o + NB * (1 + tk);
+        v4f64 acc;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) acc[rg] = s[(ri + fk + 4 * rg) * PT + rk + fr];
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+          const double av = -s[(ri + fr) * PT + o + 4 * ss + fk];
+          const double bv = s[(rk + fr) * PT + o + 4 * ss + fk];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) s[(ri + fk + 4 * rg) * PT + rk + fr] = acc[rg];
+      }
+    }
+    __syncthreads();
+    PROBE_ACC(7, tq2);
   }
-  // forward substitution riding along: y_p = L_pp^-1 b_p. Every earlier panel's TRSM has already taken its
-  // L[rows p, q] y_q out of b_p (the diagonal tile itself depends on those TRSMs).
-  if (rhs != nullptr && tid < kTile) {
-    double acc = 0.0;
-    for (int k = 0; k <= tid; ++k) acc += s[tid * PT + k] * rhs[k0 + k];
-    yout[k0 + tid] = acc;
+  PROBE(2);
+  // L back to HBM, then the diagonal blocks are replaced by their inverses for the recursive-doubling tail
+  {
+    const int c = tid & 127, rh = tid >> 7;
+#pragma unroll 8
+    for (int r = rh; r < kTile; r += 2)
+      if (c <= r) Mg[(size_t)r * ld + c] = s[r * PT + c];
   }
+  __syncthreads();
+  if (tid < kTile) {  // inverses of the eight 16x16 diagonal blocks, one column per thread (forward substitution on L e_c)
+    const int j = tid >> 4, col = tid & 15, o = NB * j;
+    double xi[NB];
+#pragma unroll
+    for (int rr = 0; rr < NB; ++rr) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < rr; ++k) sum += s[(o + rr) * PT + o + k] * xi[k];
+      xi[rr] = (rr == col) ? sInv[o + rr] : (rr > col ? -sum * sInv[o + rr] : 0.0);
+    }
+#pragma unroll
+    for (int rr = 0; rr < NB; ++rr) sX[(j * NB + rr) * NB + col] = xi[rr];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < NJ * NB * NB; idx += 256) {
+    const int j = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
+    s[(NB * j + rr) * PT + NB * j + cc] = sX[idx];
+  }
+  PROBE(3);
+  potrf_tail(s, Linv_out, rhs, yout, k0);
   PROBE(5);
 }
 
@@ -546,10 +737,12 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   const int T = npad / kTile;
   const size_t ld = (size_t)npad;
   const size_t lds_potrf = (size_t)kTile * (kTile + 1) * sizeof(double);
+  const size_t lds_potrf_blk = lds_potrf + (size_t)(8 * 16 * 16 + kTile) * sizeof(double);
   const size_t lds_gemm = (size_t)2 * kTile * LDT * sizeof(double);
   static std::once_flag attr_once;  // (the pose-graph solve calls this from several host threads at once)
   std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_potrf);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv_blk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_potrf_blk);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_TRSM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_SYRK_TRI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_SYRK_RECT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
@@ -568,8 +761,12 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   hipEvent_t* e3 = e2 + (NP + 1);
   hipEvent_t* eRc = e3 + (NP + 1);
 
+  static const int potrf_kind = [] { const char* e = getenv("COVGPU_POTRF"); return e ? atoi(e) : 2; }();  // 1: per-pivot kernel, 2: blocked (default)
   auto potrf = [&](int t) {
-    hipLaunchKernelGGL(k_potrf_inv, dim3(nbt), dim3(256), lds_potrf, st, S, ld, t * kTile, Linv + (size_t)t * kTile * kTile, flag, b, b + npad, bt.sM, bt.sL, bt.sR);
+    if (potrf_kind == 1)
+      hipLaunchKernelGGL(k_potrf_inv, dim3(nbt), dim3(256), lds_potrf, st, S, ld, t * kTile, Linv + (size_t)t * kTile * kTile, flag, b, b + npad, bt.sM, bt.sL, bt.sR);
+    else
+      hipLaunchKernelGGL(k_potrf_inv_blk, dim3(nbt), dim3(256), lds_potrf_blk, st, S, ld, t * kTile, Linv + (size_t)t * kTile * kTile, flag, b, b + npad, bt.sM, bt.sL, bt.sR);
   };
   // rows [r0, r1) of tile column t:  A <- A Linv_t^T
   // quad: four workgroups per tile (head launches on the serial chain)

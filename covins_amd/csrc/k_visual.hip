@@ -424,6 +424,41 @@ void launch_obs_linearize(const DevProblem& P, double* r, double* Jp, double* Jl
   if (P.O == 0) return;
   hipLaunchKernelGGL(k_obs_linearize, dim3((P.O + 255) / 256), dim3(256), 0, st, P, r, Jp, Jl, cost);
 }
+// Map maintenance after the outlier round, on the device (optimization_be.cpp:270-290 + Map::Clean / RemoveLandmarkOutliers,
+// map_be.cpp:448-454, 698-743): per observation "loss-corrected whitened residual norm > threshold -> erase", per landmark
+// the number of observations it keeps; a landmark left with fewer than two is what RemoveLandmarkOutliers drops. One
+// sub-wave group per landmark like the linearisation, the residual evaluated in place: only O bytes + L ints go back to
+// the host instead of O doubles. counts[0] += erased observations, counts[1] += landmarks left with < 2.
+template <int G>
+__global__ __launch_bounds__(kBuildThreads) void k_lm_outliers(DevProblem P, double th, unsigned char* __restrict__ erase, int* __restrict__ left,
+                                                               unsigned long long* __restrict__ counts) {
+  constexpr int GROUPS = kBuildThreads / G;
+  const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+  const int l = blockIdx.x * GROUPS + grp;
+  const bool lm_ok = l < P.L;
+  const int o0 = lm_ok ? P.lm_obs_ptr[l] : 0;
+  const int nobs = lm_ok ? P.lm_obs_ptr[l + 1] - o0 : 0;
+  double kept = 0.0, bad = 0.0;
+  for (int a = lane; a < nobs; a += G) {
+    ObsLin e;
+    eval_obs<false>(P, P.pose, P.lm, o0 + a, P.obs_kf[o0 + a], l, e);
+    const bool out = sqrt(e.r0 * e.r0 + e.r1 * e.r1) > th;
+    erase[o0 + a] = out ? 1 : 0;
+    kept += out ? 0.0 : 1.0; bad += out ? 1.0 : 0.0;
+  }
+  kept = group_sum<G>(kept); bad = group_sum<G>(bad);
+  if (lm_ok && lane == 0) {
+    left[l] = (int)kept;
+    if (bad > 0.0) atomicAdd(&counts[0], (unsigned long long)bad);   // integer counters: order-independent
+    if (kept < 2.0) atomicAdd(&counts[1], 1ull);
+  }
+}
+void launch_lm_outliers(const DevProblem& P, double th, unsigned char* erase, int* left, unsigned long long* counts, hipStream_t st) {
+  if (P.L == 0) return;
+  constexpr int GROUPS = kBuildThreads / kG;
+  hipLaunchKernelGGL(k_lm_outliers<kG>, dim3((P.L + GROUPS - 1) / GROUPS), dim3(kBuildThreads), 0, st, P, th, erase, left, counts);
+}
+
 void launch_obs_norms(const DevProblem& P, double* norms, hipStream_t st) {
   if (P.O == 0) return;
   hipLaunchKernelGGL(k_obs_norms, dim3((P.O + 255) / 256), dim3(256), 0, st, P, norms);

@@ -933,6 +933,27 @@ extern "C" int covgpu_reprojection_residual_norms(covgpu_context* c, const covgp
   return fetch(c, norms, d, (size_t)c->P.O);
 }
 
+// Outlier decisions + landmark bookkeeping at the RESIDENT estimate (the state covgpu_gba_solve / covgpu_solve_resident
+// left on the device): no re-upload, only flags and counts come back.
+extern "C" int covgpu_outlier_pass(covgpu_context* c, double threshold, uint8_t* obs_erase, int32_t* lm_left, int64_t* counts) {
+  if (!c->have || c->pgo) { g_err = "covgpu_outlier_pass needs a resident GBA problem (call covgpu_gba_solve or covgpu_upload + covgpu_solve_resident first)"; return COVGPU_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  const DevProblem& P = c->P;
+  unsigned char* de = nullptr; int* dl = nullptr; unsigned long long* dc = nullptr;
+  HIPCHK(hipMalloc((void**)&de, (size_t)std::max(P.O, 1))); HIPCHK(hipMalloc((void**)&dl, sizeof(int) * (size_t)std::max(P.L, 1)));
+  HIPCHK(hipMalloc((void**)&dc, 2 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(dc, 0, 2 * sizeof(unsigned long long), c->st));
+  launch_lm_outliers(P, threshold, de, dl, dc, c->st);
+  unsigned long long hc[2] = {0, 0};
+  if (P.O) HIPCHK(hipMemcpyAsync(obs_erase, de, (size_t)P.O, hipMemcpyDeviceToHost, c->st));
+  if (P.L) HIPCHK(hipMemcpyAsync(lm_left, dl, sizeof(int) * (size_t)P.L, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipMemcpyAsync(hc, dc, sizeof(hc), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  (void)hipFree(de); (void)hipFree(dl); (void)hipFree(dc);
+  if (counts) { counts[0] = (int64_t)hc[0]; counts[1] = (int64_t)hc[1]; }
+  return COVGPU_OK;
+}
+
 extern "C" int covgpu_linearize_reprojection(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double* r, double* Jp,
                                              double* Jl, double* cost) {
   covgpu_options o = *opt; o.visual_only = 1;

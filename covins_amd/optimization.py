@@ -46,8 +46,9 @@ class Optimization:
                 prob, idx = mapdata.flatten_gba(map_, visual_only, loop_loss=False, use_loops=True)
                 opt = backend.default_options(strategy=prm.strategy, max_iterations=5, visual_only=int(visual_only))
                 sol, res = ctx.gba_solve(prob, opt)
-                norms = ctx.residual_norms(sol, opt)  # problem.Evaluate applies the loss (opt_be.cpp:270-274)
-                bad = norms > prm.th_gba_outlier_global
+                # problem.Evaluate applies the loss (opt_be.cpp:270-274); decisions taken on the device at the resident estimate
+                bad, lm_left, (n_bad, n_short) = ctx.outlier_pass(prob.O, prob.L, prm.th_gba_outlier_global)
+                info["landmarks_left_short"] = n_short
                 mask = np.zeros(map_.O, bool)
                 mask[idx.obs_rows[bad]] = True
                 map_.erase_observations(mask)

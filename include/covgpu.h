@@ -175,6 +175,16 @@ int covgpu_download(covgpu_context* ctx, covgpu_problem* p);
 int covgpu_reprojection_residual_norms(covgpu_context* ctx, const covgpu_options* opt,
                                        const covgpu_problem* p, double* norms /* [O] */);
 
+/* Map maintenance of the outlier round on the device: the erase decisions of opt_be.cpp:276-289
+ * and the bookkeeping Map::Clean / RemoveLandmarkOutliers needs (map_be.cpp:448-454, 698-743), evaluated at the estimate
+ * RESIDENT on the device after covgpu_gba_solve / covgpu_solve_resident — no second upload, no O doubles over PCIe.
+ *   obs_erase[o] = 1 iff the loss-corrected whitened residual norm of observation o exceeds `threshold`
+ *                  (kf->EraseLandmark + lm->EraseObservation in the reference)
+ *   lm_left[l]   = observations landmark l keeps; < 2 -> RemoveLandmarkOutliers drops it
+ *   counts[0..1] = erased observations, landmarks left with fewer than two                                   */
+int covgpu_outlier_pass(covgpu_context* ctx, double threshold, uint8_t* obs_erase /* [O] */, int32_t* lm_left /* [L] */,
+                        int64_t* counts /* [2] or NULL */);
+
 /* PGO tail (opt_be.cpp:1046-1047, 1066-1081): rotate velocities and re-anchor every landmark to
  * its reference keyframe: p' = T_ws_new(ref) * T_ws_old(ref)^-1 * p.  ref_kf[l] < 0 skips l. */
 int covgpu_pgo_reanchor(covgpu_context* ctx, int32_t num_kf, const double* pose_old /* [K][7] */,

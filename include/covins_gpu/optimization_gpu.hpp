@@ -359,16 +359,19 @@ class OptimizationT {
       covgpu_options o = Options(5, visual_only);  // max_num_iterations = 5 (:262)
       covgpu_result r;
       if (covgpu_gba_solve(ctx, &o, &p, &r) != COVGPU_OK) detail::fatal(covgpu_last_error());
-      std::vector<double> norms(f.obs_kf.size());
-      if (covgpu_reprojection_residual_norms(ctx, &o, &p, norms.data()) != COVGPU_OK) detail::fatal(covgpu_last_error());
+      // problem.Evaluate + threshold (:270-289) on the device at the estimate the solve left resident: flags come back
+      std::vector<uint8_t> erase(f.obs_kf.size() + 1);
+      std::vector<int32_t> lm_left(ix.lms.size() + 1);
+      int64_t counts[2] = {0, 0};
+      if (covgpu_outlier_pass(ctx, params().th_gba_outlier_global, erase.data(), lm_left.data(), counts) != COVGPU_OK) detail::fatal(covgpu_last_error());
       size_t num_bad = 0;
-      for (size_t i = 0; i < norms.size(); ++i)
-        if (norms[i] > params().th_gba_outlier_global) {  // :281-289
+      for (size_t i = 0; i < f.obs_kf.size(); ++i)
+        if (erase[i]) {  // :281-289
           ix.obs[i].first->EraseLandmark(ix.obs[i].second);
           ix.obs_lm[i]->EraseObservation(ix.obs[i].first);
           ++num_bad;
         }
-      std::printf("--> GBA removed %zu of %zu observations\n", num_bad, norms.size() * 2);
+      std::printf("--> GBA removed %zu of %zu observations\n", num_bad, f.obs_kf.size() * 2);
     }
     {  // second round (:296-610)
       detail::Flat f; Index ix;

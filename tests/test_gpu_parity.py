@@ -84,6 +84,23 @@ def test_outlier_norms(ctx, tiny_map):
     assert np.array_equal(n > 0.92, n0 > 0.92)
 
 
+def test_outlier_pass_on_resident_estimate(ctx):
+    """covgpu_outlier_pass (row f3): erase flags and per-landmark remaining counts at the estimate the solve left on the
+    device == thresholding the oracle's residual norms at the downloaded estimate (opt_be.cpp:270-290, map_be.cpp:698-743)."""
+    cfg = synth.config_named("small"); cfg.outlier_frac = 0.03
+    p = mapdata.flatten_gba(synth.make_map(cfg), False, False)[0]
+    g, o = opts(max_iterations=5)
+    sol, _ = ctx.gba_solve(p, g)
+    erase, left, (n_bad, n_short) = ctx.outlier_pass(p.O, p.L, 0.92)
+    n0 = covo.residual_norms(sol, o)
+    margin = np.abs(n0 - 0.92) > 1e-9          # (an observation exactly on the threshold may fall either way)
+    assert np.array_equal(erase[margin], (n0 > 0.92)[margin]) and 0.01 * p.O < erase.sum() < 0.2 * p.O
+    assert n_bad == int(erase.sum())
+    obs_lm = np.repeat(np.arange(p.L), np.diff(p.lm_obs_ptr))
+    assert np.array_equal(left, np.bincount(obs_lm, weights=~erase, minlength=p.L).astype(np.int32))
+    assert n_short == int((left < 2).sum())
+
+
 def test_preintegration(ctx, small_vi):
     g, o = opts()
     d, J, P = ctx.preintegrate(small_vi, g)

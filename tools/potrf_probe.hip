@@ -39,6 +39,28 @@ int main() {
   printf("potrf_inv: best event time %.1f us over %d runs (100 MHz wall clock inside the kernel):\n", best * 1e3, NIT);
   for (int k = 0; k < 5; ++k) { double mn, med; stat(ph[k], mn, med); printf("  %-16s min %.1f  median %.1f us\n", names[k], mn, med); }
   { double mn, med; stat(tot, mn, med); printf("  %-16s min %.1f  median %.1f us\n", "kernel body", mn, med); }
+  {  // the blocked kernel (COVGPU_POTRF=2): same matrix, phases load | (a)(b)(c) loop | L store + diag copy | inverse levels | store
+    const size_t lds2 = lds + (size_t)(8 * 16 * 16 + kTile) * sizeof(double);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv_blk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    std::vector<std::vector<double>> q(8);
+    float best2 = 1e9;
+    for (int it = 0; it < NIT; ++it) {
+      hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
+      { long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)); }
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(k_potrf_inv_blk, dim3(1), dim3(256), lds2, 0, dA, (size_t)n, 0, dL, df, (const double*)nullptr, (double*)nullptr, (size_t)0, (size_t)0, (size_t)0);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best2) best2 = ms;
+      long long pr[8];
+      hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr));
+      q[0].push_back((pr[1] - pr[0]) / 100.0); q[1].push_back((pr[2] - pr[1]) / 100.0); q[2].push_back((pr[3] - pr[2]) / 100.0);
+      q[3].push_back((pr[4] - pr[3]) / 100.0); q[4].push_back(0.0);
+      q[5].push_back(pr[5] / 100.0); q[6].push_back(pr[6] / 100.0); q[7].push_back(pr[7] / 100.0);
+    }
+    const char* nm[8] = {"load", "chol loop", "L store+diag", "inverse levels", "-", "  (a) diag blocks", "  (b) panel rows", "  (c) trailing MFMA"};
+    printf("potrf_inv_blk: best event time %.1f us\n", best2 * 1e3);
+    for (int k = 0; k < 8; ++k) { if (k == 4) continue; double mn, med; stat(q[k], mn, med); printf("  %-20s min %.1f  median %.1f us\n", nm[k], mn, med); }
+  }
   // correctness on the last run: || L L^T - A ||_max and || Linv L - I ||_max
   std::vector<double> L(n * n), Li(n * n);
   hipMemcpy(L.data(), dA, n * n * 8, hipMemcpyDeviceToHost);

@@ -120,3 +120,17 @@ def test_twelve_agent_map_runs_on_one_gpu():
     a0, a1 = synth.ate_rmse(p.kf_pose[:, 4:], truth), synth.ate_rmse(sol.kf_pose[:, 4:], truth)
     print(f"{name}: {res.iterations} iterations in {res.t_solve_s:.2f} s, cost {res.initial_cost:.4e} -> {res.final_cost:.4e}, ATE {a0:.4f} -> {a1:.4f} m")
     assert a1 < 0.5 * a0
+
+
+def test_gba_on_loaded_saved_map(small_map, tmp_path):
+    """BASELINE configs[0]/[1] plumbing: a map saved in the covins_backend on-disk format (Map::SaveToFile layout) is read back
+    by covins_amd.mapio and bundle-adjusted; the result equals the GBA of the in-memory original."""
+    from covins_amd import mapio
+    p = str(tmp_path / "saved")
+    mapio.save_map(p, small_map)
+    a, b = small_map.copy(), mapio.load_map(p)
+    ia = Optimization.GlobalBundleAdjustment(a, 10, -1.0, False, True, False)
+    ib = Optimization.GlobalBundleAdjustment(b, 10, -1.0, False, True, False)
+    assert ia["outliers_removed"] == ib["outliers_removed"] and ia["round2"].iterations == ib["round2"].iterations
+    assert np.abs(a.kf_pose - b.kf_pose).max() < 1e-8 and np.abs(a.kf_velocity - b.kf_velocity).max() < 1e-8
+    assert b.kf_gba_optimized.all() and b.kf_loaded.all()

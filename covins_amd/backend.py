@@ -149,6 +149,21 @@ class Context:
         self._check(lib().covgpu_outlier_pass(self._h, float(threshold), erase.ctypes.data_as(capi._bp), iptr(left), cnt))
         return erase[:n_obs].astype(bool), left[:n_lm], (int(cnt[0]), int(cnt[1]))
 
+    def relpose_batch(self, bt: dict, th_outlier: float = 1.3, min_inliers: int = 12):
+        """Batched Optimization::OptimizeRelativePose (covgpu_relpose_batch). `bt`: dict with ptr, pA, pB, kpA, kpB, sigA, sigB,
+        camA, camB, distA, distB, T0 (see include/covgpu.h). Returns (T_ab [B,7], outlier flags [C], inliers [B])."""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        i = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        keep = dict(ptr=i(bt["ptr"]), pB=f(bt["pB"]), pA=f(bt["pA"]), kA=f(bt["kpA"]), kB=f(bt["kpB"]), sA=f(bt["sigA"]), sB=f(bt["sigB"]),
+                    cA=f(bt["camA"]), cB=f(bt["camB"]), dA=i(bt["distA"]), dB=i(bt["distB"]), T=np.array(bt["T0"], dtype=np.float64, order="C"))
+        B = len(keep["ptr"]) - 1
+        out = np.zeros(max(int(keep["ptr"][-1]), 1), np.uint8); inl = np.zeros(max(B, 1), np.int32)
+        s = capi.RelposeBatch(B, iptr(keep["ptr"]), dptr(keep["pB"]), dptr(keep["pA"]), dptr(keep["kA"]), dptr(keep["kB"]), dptr(keep["sA"]),
+                              dptr(keep["sB"]), dptr(keep["cA"]), dptr(keep["cB"]), iptr(keep["dA"]), iptr(keep["dB"]), dptr(keep["T"]),
+                              out.ctypes.data_as(capi._bp), iptr(inl))
+        self._check(lib().covgpu_relpose_batch(self._h, C.byref(s), float(th_outlier), int(min_inliers)))
+        return keep["T"], out[:int(keep["ptr"][-1])].astype(bool), inl[:B]
+
     def set_profiling(self, on: bool):
         lib().covgpu_set_profiling(self._h, int(on))
 

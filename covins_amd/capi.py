@@ -46,6 +46,12 @@ class ProblemStruct(C.Structure):
     ]
 
 
+class RelposeBatch(C.Structure):
+    _fields_ = [("num_pairs", C.c_int32), ("corr_ptr", _ip), ("p_b", _dp), ("p_a", _dp), ("kp_a", _dp), ("kp_b", _dp), ("sigma_a", _dp),
+                ("sigma_b", _dp), ("cam_a", _dp), ("cam_b", _dp), ("dist_type_a", _ip), ("dist_type_b", _ip), ("T_ab", _dp), ("outlier", _bp),
+                ("inliers", _ip)]
+
+
 class Result(C.Structure):
     _fields_ = [
         ("iterations", C.c_int32), ("accepted", C.c_int32), ("termination", C.c_int32), ("reserved", C.c_int32),
@@ -200,6 +206,7 @@ def declare(lib: C.CDLL, prefix: str) -> None:
         d("pgo_partition", [C.c_int32, C.c_int32, _ip, _ip, _ip], C.c_int32)
         d("gba_partition", [OP, PP, C.c_int32, _ip], C.c_int32)
         d("gn_step", [C.c_void_p, OP, PP, C.c_double, _dp, _dp, _dp])
+        d("relpose_batch", [C.c_void_p, C.POINTER(RelposeBatch), C.c_double, C.c_int32])
         d("outlier_pass", [C.c_void_p, C.c_double, _bp, _ip, C.POINTER(C.c_int64)])
         d("shard_plan", [OP, PP, C.c_int32, _ip, _ip, _ip, _ip, _ip], C.c_int32)
         d("set_shard", [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _ip, C.c_int32, _ip, C.c_void_p, C.c_void_p, C.c_int32])

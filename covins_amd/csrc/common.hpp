@@ -262,6 +262,9 @@ void launch_combine_step(const DevProblem& P, double cg, double cn, hipStream_t 
 void launch_apply_step(const DevProblem& P, hipStream_t st);    // candidate = x (+) step
 void launch_accept(const DevProblem& P, hipStream_t st);        // x = candidate
 void launch_xnorm(const DevProblem& P, hipStream_t st);         // XN2
+void launch_relpose(int num, const int* ptr, const double* pB, const double* pA, const double* kpA, const double* kpB, const double* sigA,
+                    const double* sigB, const double* camA, const int* distA, const double* camB, const int* distB, double th, int min_inliers,
+                    double* T, unsigned char* outlier, int* inliers, hipStream_t st);
 void launch_reanchor(int K, const double* pose_old, const double* pose_new, double* vel, int L, const int* ref, double* lm,
                      hipStream_t st);
 

@@ -8,6 +8,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../../include/covgpu.h"
+
 #define COV_DEV __device__ __forceinline__
 
 namespace covdev {
@@ -122,6 +124,46 @@ COV_DEV double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+
+// R5: pinhole + radtan / equidistant. Returns false if the point is behind the camera (A.2: block zeroed).
+COV_DEV bool project_point(V3 lc, const double* intr, const double* dist, int dist_type, double& u, double& v, double* jpi /*2x3*/) {
+  if (!(lc.z > 1e-10)) return false;
+  const double iz = 1.0 / lc.z, x = lc.x * iz, y = lc.y * iz;
+  const double r2 = x * x + y * y;
+  double xd, yd, dxx, dxy, dyx, dyy;
+  if (dist_type == COVGPU_DIST_RADTAN) {
+    const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3];
+    const double rad = (k1 + k2 * r2) * r2, dr = k1 + 2.0 * k2 * r2;
+    xd = x + x * rad + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+    yd = y + y * rad + 2.0 * p2 * x * y + p1 * (r2 + 2.0 * y * y);
+    const double xy2dr = 2.0 * x * y * dr;
+    dxx = 1.0 + rad + 2.0 * x * x * dr + 2.0 * p1 * y + 6.0 * p2 * x;
+    dxy = xy2dr + 2.0 * p1 * x + 2.0 * p2 * y;
+    dyx = dxy;
+    dyy = 1.0 + rad + 2.0 * y * y * dr + 2.0 * p2 * x + 6.0 * p1 * y;
+  } else {
+    const double rho = sqrt(r2);
+    if (rho < 1e-8) {
+      xd = x; yd = y; dxx = 1.0; dxy = 0.0; dyx = 0.0; dyy = 1.0;
+    } else {
+      const double th = atan(rho), t2 = th * th;
+      const double poly = 1.0 + t2 * (dist[0] + t2 * (dist[1] + t2 * (dist[2] + t2 * dist[3])));
+      const double dpoly = 1.0 + t2 * (3.0 * dist[0] + t2 * (5.0 * dist[1] + t2 * (7.0 * dist[2] + t2 * 9.0 * dist[3])));
+      const double thd = th * poly, sc = thd / rho;
+      const double dsc = (dpoly / (1.0 + r2) * rho - thd) / r2;
+      const double ir = 1.0 / rho;
+      xd = sc * x; yd = sc * y;
+      dxx = sc + x * x * dsc * ir; dxy = x * y * dsc * ir; dyx = dxy; dyy = sc + y * y * dsc * ir;
+    }
+  }
+  u = intr[0] * xd + intr[2];
+  v = intr[1] * yd + intr[3];
+  if (jpi) {
+    jpi[0] = intr[0] * dxx * iz; jpi[1] = intr[0] * dxy * iz; jpi[2] = -intr[0] * (dxx * x + dxy * y) * iz;
+    jpi[3] = intr[1] * dyx * iz; jpi[4] = intr[1] * dyy * iz; jpi[5] = -intr[1] * (dyx * x + dyy * y) * iz;
+  }
+  return true;
 }
 
 }  // namespace covdev

@@ -1104,6 +1104,45 @@ extern "C" int covgpu_solve_reduced(covgpu_context* c, int32_t n, const double* 
   return COVGPU_OK;
 }
 
+extern "C" int covgpu_relpose_batch(covgpu_context* c, const covgpu_relpose_batch_t* bt, double th_outlier, int32_t min_inliers) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!bt || bt->num_pairs < 0 || (bt->num_pairs > 0 && (!bt->corr_ptr || !bt->T_ab || !bt->inliers || !bt->cam_a || !bt->cam_b || !bt->dist_type_a || !bt->dist_type_b))) {
+    g_err = "covgpu_relpose_batch: NULL array"; return COVGPU_ERR_INVALID_ARG;
+  }
+  const int B = bt->num_pairs;
+  if (B == 0) return COVGPU_OK;
+  for (int b = 0; b < B; ++b) if (bt->corr_ptr[b + 1] < bt->corr_ptr[b]) { g_err = "covgpu_relpose_batch: corr_ptr not monotone"; return COVGPU_ERR_INVALID_ARG; }
+  const size_t C = (size_t)bt->corr_ptr[B];
+  if (C > 0 && (!bt->p_a || !bt->p_b || !bt->kp_a || !bt->kp_b || !bt->sigma_a || !bt->sigma_b || !bt->outlier)) { g_err = "covgpu_relpose_batch: NULL correspondence array"; return COVGPU_ERR_INVALID_ARG; }
+  std::vector<void*> tmp;
+  auto up = [&](const void* h, size_t bytes, void** d) -> hipError_t {
+    hipError_t e = hipMalloc(d, bytes ? bytes : 8);
+    if (e != hipSuccess) return e;
+    tmp.push_back(*d);
+    return bytes ? hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, c->st) : hipSuccess;
+  };
+  int *dptr_ = nullptr, *dda = nullptr, *ddb = nullptr, *din = nullptr;
+  double *dpB = nullptr, *dpA = nullptr, *dkA = nullptr, *dkB = nullptr, *dsA = nullptr, *dsB = nullptr, *dcA = nullptr, *dcB = nullptr, *dT = nullptr;
+  unsigned char* dout = nullptr;
+  HIPCHK(up(bt->corr_ptr, sizeof(int) * (B + 1), (void**)&dptr_));
+  HIPCHK(up(bt->p_b, 24 * C, (void**)&dpB)); HIPCHK(up(bt->p_a, 24 * C, (void**)&dpA));
+  HIPCHK(up(bt->kp_a, 16 * C, (void**)&dkA)); HIPCHK(up(bt->kp_b, 16 * C, (void**)&dkB));
+  HIPCHK(up(bt->sigma_a, 8 * C, (void**)&dsA)); HIPCHK(up(bt->sigma_b, 8 * C, (void**)&dsB));
+  HIPCHK(up(bt->cam_a, 64 * (size_t)B, (void**)&dcA)); HIPCHK(up(bt->cam_b, 64 * (size_t)B, (void**)&dcB));
+  HIPCHK(up(bt->dist_type_a, 4 * (size_t)B, (void**)&dda)); HIPCHK(up(bt->dist_type_b, 4 * (size_t)B, (void**)&ddb));
+  HIPCHK(up(bt->T_ab, 56 * (size_t)B, (void**)&dT));
+  HIPCHK(up(nullptr, 0, (void**)&din)); (void)hipFree(din); tmp.pop_back();
+  HIPCHK(hipMalloc((void**)&din, 4 * (size_t)B)); tmp.push_back(din);
+  HIPCHK(hipMalloc((void**)&dout, C ? C : 8)); tmp.push_back(dout);
+  launch_relpose(B, dptr_, dpB, dpA, dkA, dkB, dsA, dsB, dcA, dda, dcB, ddb, th_outlier, min_inliers, dT, dout, din, c->st);
+  HIPCHK(hipMemcpyAsync(bt->T_ab, dT, 56 * (size_t)B, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipMemcpyAsync(bt->inliers, din, 4 * (size_t)B, hipMemcpyDeviceToHost, c->st));
+  if (C) HIPCHK(hipMemcpyAsync(bt->outlier, dout, C, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  for (void* p : tmp) (void)hipFree(p);
+  return COVGPU_OK;
+}
+
 extern "C" int covgpu_pgo_reanchor(covgpu_context* c, int32_t K, const double* pose_old, const double* pose_new, double* velocity, int32_t L,
                                    const int32_t* ref_kf, double* lm_pos) {
   HIPCHK(hipSetDevice(c->device));

@@ -185,6 +185,33 @@ int covgpu_reprojection_residual_norms(covgpu_context* ctx, const covgpu_options
 int covgpu_outlier_pass(covgpu_context* ctx, double threshold, uint8_t* obs_erase /* [O] */, int32_t* lm_left /* [L] */,
                         int64_t* counts /* [2] or NULL */);
 
+/* Batched Optimization::OptimizeRelativePose (optimization_be.cpp:620-831): refines the relative pose
+ * T_AB of MANY keyframe pairs (loop candidates, placerec_be.cpp:116-165) in one launch, one wavefront per pair. Per
+ * correspondence two reprojection residuals — kNormal: pi_A(R_AB P_B + t_AB) vs kp_A, kInverse: pi_B(R_AB^T (P_A - t_AB))
+ * vs kp_B — with sigma = (octave + 1) * 2 and Cauchy(1); DOGLEG 5 iterations, correspondences whose loss-corrected residual
+ * norm exceeds th_outlier in either image are dropped, fewer than min_inliers (reference: 12) left -> inliers = 0 and T_ab
+ * untouched, else 5 more iterations. NB with Cauchy(1) the corrected norm is < 1, so the reference's configured
+ * opt.th_outlier_align = 1.3 never removes anything; that behaviour is reproduced as is.
+ * Pairs b = 0..num-1 own correspondences [corr_ptr[b], corr_ptr[b+1]). cam_* rows: fx fy cx cy d0 d1 d2 d3. All HOST pointers. */
+typedef struct covgpu_relpose_batch_t {
+  int32_t num_pairs;
+  const int32_t* corr_ptr;      /* [num_pairs + 1] */
+  const double*  p_b;           /* [C][3] landmark of kf2 in camera-B frame (opt_be.cpp:655-656) */
+  const double*  p_a;           /* [C][3] landmark of kf1 in camera-A frame (:653-654)           */
+  const double*  kp_a;          /* [C][2] */
+  const double*  kp_b;          /* [C][2] */
+  const double*  sigma_a;       /* [C]    */
+  const double*  sigma_b;       /* [C]    */
+  const double*  cam_a;         /* [num_pairs][8] */
+  const double*  cam_b;         /* [num_pairs][8] */
+  const int32_t* dist_type_a;   /* [num_pairs] COVGPU_DIST_* */
+  const int32_t* dist_type_b;   /* [num_pairs] */
+  double*        T_ab;          /* [num_pairs][7] in/out */
+  uint8_t*       outlier;       /* [C] out: 1 = correspondence removed (matches1[i] = NULL, :807) */
+  int32_t*       inliers;       /* [num_pairs] out: the function's return value per pair */
+} covgpu_relpose_batch_t;
+int covgpu_relpose_batch(covgpu_context* ctx, const covgpu_relpose_batch_t* batch, double th_outlier, int32_t min_inliers);
+
 /* PGO tail (opt_be.cpp:1046-1047, 1066-1081): rotate velocities and re-anchor every landmark to
  * its reference keyframe: p' = T_ws_new(ref) * T_ws_old(ref)^-1 * p.  ref_kf[l] < 0 skips l. */
 int covgpu_pgo_reanchor(covgpu_context* ctx, int32_t num_kf, const double* pose_old /* [K][7] */,

@@ -21,7 +21,7 @@ _SOLVER_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libcovo.so")
-    srcs = [os.path.join(_HERE, f) for f in ("covo_solver.cpp", "covo_residuals.hpp", "covo_math.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("covo_solver.cpp", "covo_relpose.cpp", "covo_residuals.hpp", "covo_math.hpp")]
     srcs.append(os.path.join(_HERE, "..", "include", "covgpu.h"))
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
@@ -56,6 +56,9 @@ def lib() -> C.CDLL:
         ip = capi._ip
         L.covo_schur_sparse.argtypes = [OP, PP, C.c_int, C.c_double, ip, ip, dp, dp, dp]
         L.covo_landmark_hessians.argtypes = [OP, PP, dp]
+        L.covo_relpose.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp, dp, C.c_int, dp, C.c_int, C.c_double, C.c_int, dp, C.POINTER(C.c_ubyte)]
+        L.covo_relpose_residual.argtypes = [dp, dp, dp, dp, dp, C.c_double, C.c_double, dp, C.c_int, dp, C.c_int, dp, dp]
+        L.covo_relpose_residual.restype = None
     return _LIB
 
 
@@ -225,3 +228,22 @@ def pgo_reanchor(pose_old, pose_new, velocity, ref_kf, lm_pos):
     ref = np.ascontiguousarray(ref_kf, dtype=np.int32)
     lib().covo_pgo_reanchor(pose_old.shape[0], _d(pose_old), _d(pose_new), _d(vel), lm.shape[0], capi.iptr(ref), _d(lm))
     return vel, lm
+
+
+def relpose(pB, pA, kpA, kpB, sigA, sigB, camA, distA, camB, distB, T_ab, th_outlier=2.0, min_inliers=12):
+    """Optimization::OptimizeRelativePose for ONE keyframe pair (optimization_be.cpp:620-831): returns (inliers, T_ab, outlier flags)."""
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    pB, pA, kpA, kpB, sigA, sigB, camA, camB = map(f, (pB, pA, kpA, kpB, sigA, sigB, camA, camB))
+    T = np.array(T_ab, dtype=np.float64)
+    out = np.zeros(len(sigA), np.uint8)
+    n = lib().covo_relpose(len(sigA), _d(pB), _d(pA), _d(kpA), _d(kpB), _d(sigA), _d(sigB), _d(camA), int(distA), _d(camB), int(distB),
+                           float(th_outlier), int(min_inliers), _d(T), out.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return int(n), T, out.astype(bool)
+
+
+def relpose_residual(T_ab, pB, pA, kpA, kpB, sigA, sigB, camA, distA, camB, distB, jac=True):
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    r, J = np.zeros(4), np.zeros((4, 6))
+    lib().covo_relpose_residual(_d(f(T_ab)), _d(f(pB)), _d(f(pA)), _d(f(kpA)), _d(f(kpB)), float(sigA), float(sigB), _d(f(camA)), int(distA),
+                                _d(f(camB)), int(distB), _d(r), _d(J) if jac else None)
+    return r, J

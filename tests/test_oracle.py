@@ -14,7 +14,7 @@ from scipy.spatial.transform import Rotation as R
 from covins_amd import capi, mapdata, synth
 from covins_amd.capi import dptr
 from oracle import covo
-from tests.util import truth_map, rel_err
+from tests.util import truth_map, rel_err, rot_angle
 
 RNG = np.random.default_rng(7)
 
@@ -393,3 +393,41 @@ def test_landmark_sensitivity_is_a_property_of_the_problem(small_map):
         covo.lib().covo_set_num_threads(nt)
     qn, _ = covo.gba_solve(p, covo.default_options(max_iterations=3))
     assert np.array_equal(q1.kf_pose, qn.kf_pose) and np.array_equal(q1.lm_pos, qn.lm_pos)
+
+
+def test_relative_pose_oracle():
+    """Oracle of Optimization::OptimizeRelativePose (oracle/covo_relpose.cpp): analytic Jacobian of the kNormal / kInverse
+    residual pair vs central differences through the pose (+), and recovery of the true relative pose with the gross
+    keypoint outliers flagged."""
+    from tests.util import make_relpose_batch
+    for dist_type in (0, 1):
+        bt = make_relpose_batch(6, seed=3 + dist_type, dist_type=dist_type)
+        i = 5
+        T = bt["T0"][0]
+        # (sigma = 1e4 px: |r| ~ 1e-4, so the Cauchy corrector sqrt(rho') is 1 to 1e-8 — the corrector scales J but, by Ceres'
+        #  definition, is not differentiated, which a finite difference of the corrected residual would do)
+        args = (bt["pB"][i], bt["pA"][i], bt["kpA"][i], bt["kpB"][i], 1e4, 1e4, bt["camA"][0], dist_type, bt["camB"][0], dist_type)
+        r, J = covo.relpose_residual(T, *args)
+        Jn = np.zeros((4, 6))
+        for k in range(6):
+            d = np.zeros(6); d[k] = 1e-6
+            Tp, Tm = np.zeros(7), np.zeros(7)
+            covo.lib().covo_pose_plus(covo._d(np.ascontiguousarray(T)), covo._d(d), covo._d(Tp))
+            covo.lib().covo_pose_plus(covo._d(np.ascontiguousarray(T)), covo._d(-d), covo._d(Tm))
+            Jn[:, k] = (covo.relpose_residual(Tp, *args, jac=False)[0] - covo.relpose_residual(Tm, *args, jac=False)[0]) / 2e-6
+        assert np.abs(J - Jn).max() < 2e-5 * np.abs(J).max()
+        for b in range(6):
+            s = slice(bt["ptr"][b], bt["ptr"][b + 1])
+            n_in, T, out = covo.relpose(bt["pB"][s], bt["pA"][s], bt["kpA"][s], bt["kpB"][s], bt["sigA"][s], bt["sigB"][s], bt["camA"][b], dist_type,
+                                        bt["camB"][b], dist_type, bt["T0"][b], th_outlier=0.9)
+            assert n_in == (~out).sum() >= 12 and out.sum() > 0
+            assert np.abs(T[4:] - bt["Ttrue"][b][4:]).max() < 0.05 and rot_angle(T[None, :4], bt["Ttrue"][b][None, :4])[0] < 0.02
+            assert np.abs(bt["T0"][b][4:] - bt["Ttrue"][b][4:]).max() > np.abs(T[4:] - bt["Ttrue"][b][4:]).max()
+    # too few inliers: returns 0 and leaves the pose untouched (optimization_be.cpp:813-815)
+    bt = make_relpose_batch(1, seed=9, nmin=13, nmax=13, outlier_frac=0.5)
+    n_in, T, out = covo.relpose(bt["pB"], bt["pA"], bt["kpA"], bt["kpB"], bt["sigA"], bt["sigB"], bt["camA"][0], 0, bt["camB"][0], 0, bt["T0"][0], th_outlier=0.9)
+    assert n_in == 0 and np.array_equal(T, bt["T0"][0]) and out.sum() >= 2
+    # reference quirk, kept: problem.Evaluate returns LOSS-CORRECTED residuals, |r| / sqrt(1 + |r|^2) < 1 under Cauchy(1), so the
+    # configured opt.th_outlier_align = 1.3 (config_backend.yaml:117) can never be exceeded and nothing is ever removed
+    n_in, T, out = covo.relpose(bt["pB"], bt["pA"], bt["kpA"], bt["kpB"], bt["sigA"], bt["sigB"], bt["camA"][0], 0, bt["camB"][0], 0, bt["T0"][0], th_outlier=1.3)
+    assert n_in == 13 and not out.any()

@@ -51,3 +51,48 @@ def landmark_parity(sol_lm, ref_prob, ref_lm=None, idx=None):
         print(f"landmark_parity: no well-conditioned landmark: |H|max={np.abs(H).max():.3e} cond min={np.nanmin(cond):.3e} "
               f"nan={int(np.isnan(cond).sum())} |d|max={dist.max():.3e} L={len(cond)}")
     return int((~good).sum()), float(dist[good].max() if good.any() else 0.0), float(white.max() if len(white) else 0.0)
+
+
+def make_relpose_batch(num, seed=0, nmin=16, nmax=180, outlier_frac=0.1, dist_type=0):
+    """Synthetic inputs of Optimization::OptimizeRelativePose (optimization_be.cpp:620-831) for `num` keyframe pairs: landmark
+    pairs (P_A in camera A, P_B in camera B — two noisy estimates of the same points), their keypoints in both images
+    (EuRoC pinhole + radtan / equidistant), a perturbed initial T_AB; a fraction of gross keypoint outliers."""
+    from scipy.spatial.transform import Rotation as R
+    from covins_amd import synth
+    rng = np.random.default_rng(seed)
+    dist = synth.DIST if dist_type == 0 else np.array([-0.01, 0.02, -0.005, 0.001])
+    cam = np.concatenate([synth.INTR, dist])
+    ptr, pA, pB, kA, kB, sA, sB, T0, Tt = [0], [], [], [], [], [], [], [], []
+    for b in range(num):
+        n = int(rng.integers(nmin, nmax + 1))
+        Rab = R.from_rotvec(rng.normal(0, 0.15, 3)); tab = rng.normal(0, 0.4, 3)
+        XA = np.stack([rng.uniform(-2.5, 2.5, n), rng.uniform(-1.5, 1.5, n), rng.uniform(3.0, 10.0, n)], 1)   # truth, camera A
+        XB = Rab.inv().apply(XA - tab)                                                                          # truth, camera B
+        XB[:, 2] = np.maximum(XB[:, 2], 1.0)
+        XA = Rab.apply(XB) + tab
+        def proj(X):
+            x, y = X[:, 0] / X[:, 2], X[:, 1] / X[:, 2]
+            r2 = x * x + y * y
+            if dist_type == 0:
+                k1, k2, p1, p2 = dist
+                rad = k1 * r2 + k2 * r2 * r2
+                xd = x + x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x); yd = y + y * rad + 2 * p2 * x * y + p1 * (r2 + 2 * y * y)
+            else:
+                rho = np.sqrt(r2); th = np.arctan(rho); t2 = th * th
+                sc = np.where(rho > 1e-8, th * (1 + dist[0] * t2 + dist[1] * t2 ** 2 + dist[2] * t2 ** 3 + dist[3] * t2 ** 4) / np.maximum(rho, 1e-12), 1.0)
+                xd, yd = sc * x, sc * y
+            return np.stack([cam[0] * xd + cam[2], cam[1] * yd + cam[3]], 1)
+        ka = proj(XA) + rng.normal(0, 0.7, (n, 2)); kb = proj(XB) + rng.normal(0, 0.7, (n, 2))
+        bad = rng.random(n) < outlier_frac
+        ka[bad] += rng.uniform(-1, 1, (int(bad.sum()), 2)) * 40.0
+        pA.append(XA + rng.normal(0, 0.02, (n, 3))); pB.append(XB + rng.normal(0, 0.02, (n, 3)))
+        kA.append(ka.astype(np.float32).astype(np.float64)); kB.append(kb.astype(np.float32).astype(np.float64))
+        sA.append((rng.integers(0, 3, n) + 1) * 2.0); sB.append((rng.integers(0, 3, n) + 1) * 2.0)
+        q = (Rab * R.from_rotvec(rng.normal(0, 0.03, 3))).as_quat(); q = -q if q[3] < 0 else q
+        T0.append(np.concatenate([q, tab + rng.normal(0, 0.05, 3)]))
+        qt = Rab.as_quat(); Tt.append(np.concatenate([qt if qt[3] >= 0 else -qt, tab]))
+        ptr.append(ptr[-1] + n)
+    cat = lambda a: np.ascontiguousarray(np.concatenate(a))
+    return dict(ptr=np.array(ptr, np.int32), pA=cat(pA), pB=cat(pB), kpA=cat(kA), kpB=cat(kB), sigA=cat(sA), sigB=cat(sB),
+                camA=np.tile(cam, (num, 1)), camB=np.tile(cam, (num, 1)), distA=np.full(num, dist_type, np.int32), distB=np.full(num, dist_type, np.int32),
+                T0=np.array(T0), Ttrue=np.array(Tt))

@@ -1131,7 +1131,6 @@ extern "C" int covgpu_relpose_batch(covgpu_context* c, const covgpu_relpose_batc
   HIPCHK(up(bt->cam_a, 64 * (size_t)B, (void**)&dcA)); HIPCHK(up(bt->cam_b, 64 * (size_t)B, (void**)&dcB));
   HIPCHK(up(bt->dist_type_a, 4 * (size_t)B, (void**)&dda)); HIPCHK(up(bt->dist_type_b, 4 * (size_t)B, (void**)&ddb));
   HIPCHK(up(bt->T_ab, 56 * (size_t)B, (void**)&dT));
-  HIPCHK(up(nullptr, 0, (void**)&din)); (void)hipFree(din); tmp.pop_back();
   HIPCHK(hipMalloc((void**)&din, 4 * (size_t)B)); tmp.push_back(din);
   HIPCHK(hipMalloc((void**)&dout, C ? C : 8)); tmp.push_back(dout);
   launch_relpose(B, dptr_, dpB, dpA, dkA, dkB, dsA, dsB, dcA, dda, dcB, ddb, th_outlier, min_inliers, dT, dout, din, c->st);

@@ -38,7 +38,11 @@ def landmark_parity(sol_lm, ref_prob, ref_lm=None, idx=None):
     at most below cond 1e6 but by 1.3e-6 m between 1e6 and 1e8 (tests/test_oracle.py, `small` map). Returns (number of ill-conditioned landmarks, max
     well-conditioned difference, max whitened difference). `idx`: compare only these landmarks (strided goldens)."""
     from oracle import covo
-    H = covo.landmark_hessians(ref_prob, covo.default_options())
+    # H_ll = sum_obs Jl^T Jl from the oracle's per-observation linearisation (loss-corrected, whitened)
+    _, _, Jl, _ = covo.linearize_reprojection(ref_prob, covo.default_options())
+    Jl = Jl.reshape(-1, 2, 3)
+    H = np.zeros((ref_prob.L, 3, 3))
+    np.add.at(H, np.repeat(np.arange(ref_prob.L), np.diff(ref_prob.lm_obs_ptr)), np.einsum("oki,okj->oij", Jl, Jl))
     ref = ref_prob.lm_pos if ref_lm is None else ref_lm
     if idx is not None:
         H = H[idx]

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(64 * kImuWaves) void k_preintegrate(DevProblem P) {
       }
     }
     for (int k = 0; k < 225; ++k) F[k] = 0.0;
+    if (!ok) atomicAdd(P.flag + 1, 1);  // factor carries no weight (covariance not positive definite, e.g. no samples): counted, reported in covgpu_result
     if (ok)
       for (int c = 0; c < 15; ++c) {
         F[16 * c] = 1.0 / C[16 * c];

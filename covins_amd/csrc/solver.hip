@@ -205,10 +205,19 @@ static int dev_upload(covgpu_context* c, T** ptr, const T* host, size_t count) {
   return COVGPU_OK;
 }
 #define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+// no C++ exception may cross the extern "C" boundary (std::bad_alloc from the host staging vectors, std::system_error from
+// std::thread): map them to status codes
+template <typename F>
+static int guarded(F&& body) {
+  try { return body(); }
+  catch (const std::bad_alloc&) { g_err = "host allocation failed"; return COVGPU_ERR_OUT_OF_MEMORY; }
+  catch (const std::exception& e) { g_err = std::string("host exception: ") + e.what(); return COVGPU_ERR_INVALID_ARG; }
+}
 
 static int validate(const covgpu_problem* p, bool pgo, bool vi) {
   auto bad = [](const char* m) { g_err = std::string("invalid problem: ") + m; return COVGPU_ERR_INVALID_ARG; };
   if (!p || p->num_kf <= 0) return bad("no keyframes");
+  if (p->num_cam < 0 || p->num_lm < 0 || p->num_obs < 0 || p->num_imu < 0 || p->num_edge < 0 || p->num_imu_samples < 0) return bad("negative count");
   if (!p->kf_pose || !p->kf_fixed || !p->kf_cam) return bad("NULL keyframe array");
   if (vi && !p->kf_speed_bias) return bad("NULL speed-bias array in visual-inertial mode");
   const int K = p->num_kf;
@@ -218,12 +227,17 @@ static int validate(const covgpu_problem* p, bool pgo, bool vi) {
     if (p->num_lm > 0 && (p->lm_obs_ptr[0] != 0 || p->lm_obs_ptr[p->num_lm] != p->num_obs)) return bad("lm_obs_ptr does not span the observations");
     for (int l = 0; l < p->num_lm; ++l) if (p->lm_obs_ptr[l + 1] < p->lm_obs_ptr[l]) return bad("lm_obs_ptr not monotone");
     for (int o = 0; o < p->num_obs; ++o) if (p->obs_kf[o] < 0 || p->obs_kf[o] >= K) return bad("obs_kf out of range");
+    if (p->num_cam <= 0 || !p->cam_extr || !p->cam_intr || !p->cam_dist || !p->cam_dist_type) return bad("NULL camera array");
     for (int k = 0; k < K; ++k) if (p->kf_cam[k] < 0 || p->kf_cam[k] >= p->num_cam) return bad("kf_cam out of range");
+    for (int a = 0; a < p->num_cam; ++a) if (p->cam_dist_type[a] != COVGPU_DIST_RADTAN && p->cam_dist_type[a] != COVGPU_DIST_EQUIDISTANT) return bad("unknown distortion type");
+    if (vi && p->num_imu > 0 && (!p->imu_kf_i || !p->imu_kf_j || !p->imu_sample_ptr || !p->imu_first)) return bad("NULL IMU array");
+    if (vi && p->num_imu > 0 && p->imu_sample_ptr[p->num_imu] > 0 && !p->imu_samples) return bad("NULL IMU sample array");
     if (vi) for (int f = 0; f < p->num_imu; ++f) {
       if (p->imu_kf_i[f] < 0 || p->imu_kf_i[f] >= K || p->imu_kf_j[f] < 0 || p->imu_kf_j[f] >= K) return bad("imu keyframe out of range");
       if (p->imu_sample_ptr[f + 1] < p->imu_sample_ptr[f]) return bad("imu_sample_ptr not monotone");
     }
   }
+  if (p->num_edge > 0 && (!p->edge_i || !p->edge_j || !p->edge_meas || !p->edge_sqrt_info || !p->edge_loss_a)) return bad("NULL edge array");
   for (int e = 0; e < p->num_edge; ++e)
     if (p->edge_i[e] < 0 || p->edge_i[e] >= K || p->edge_j[e] < 0 || p->edge_j[e] >= K) return bad("edge keyframe out of range");
   return COVGPU_OK;
@@ -692,6 +706,7 @@ static int read_scalars(covgpu_context* c) {
   HIPCHK(hipMemcpyAsync(c->h_scal, c->P.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipMemcpyAsync(c->h_scal + SC_COUNT, c->P.flag, sizeof(int), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
+  HIPCHK(hipGetLastError());  // a failed kernel launch anywhere in the batch just drained surfaces here
   if (c->sharded && c->have && c->P.shard && c->allreduce) {
     // every scalar of the trust-region loop is a sum over residuals / unknowns each counted by exactly one rank
     // (DevProblem::vw), except the gradient max-norm and the Cholesky failure flag (max): all ranks then take the same
@@ -783,6 +798,7 @@ static int solve_impl(covgpu_context* c, const covgpu_options* opt, covgpu_resul
   std::memset(res, 0, sizeof(*res));
   const auto t_begin = std::chrono::steady_clock::now();
   RC(reset_state(c));
+  HIPCHK(hipMemsetAsync(P.flag + 1, 0, sizeof(int), c->st));
   launch_preintegrate(P, c->st);  // R2: repropagate at the initial bias estimate (opt_be.cpp:396)
 
   double radius = o.initial_radius, mu = 1e-8, lm_df = 2.0;
@@ -879,6 +895,11 @@ static int solve_impl(covgpu_context* c, const covgpu_options* opt, covgpu_resul
   }
   (void)need_build;
   HIPCHK(hipStreamSynchronize(c->st));
+  {  // IMU factors whose preintegrated covariance was not positive definite (e.g. zero samples) carry no weight: reported
+    int dropped = 0;
+    HIPCHK(hipMemcpy(&dropped, P.flag + 1, sizeof(int), hipMemcpyDeviceToHost));
+    res->reserved = dropped;
+  }
   res->iterations = it; res->accepted = accepted; res->termination = term;
   res->final_cost = cost;
   res->t_linear_solve_s = t_lin;
@@ -896,9 +917,9 @@ static int download_impl(covgpu_context* c, covgpu_problem* p) {
   return COVGPU_OK;
 }
 
-extern "C" int covgpu_upload(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return upload_impl(c, opt, p, false); }
-extern "C" int covgpu_upload_pgo(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return upload_impl(c, opt, p, true); }
-extern "C" int covgpu_solve_resident(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) { return solve_impl(c, opt, out); }
+extern "C" int covgpu_upload(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return guarded([&] { return upload_impl(c, opt, p, false); }); }
+extern "C" int covgpu_upload_pgo(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return guarded([&] { return upload_impl(c, opt, p, true); }); }
+extern "C" int covgpu_solve_resident(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) { return guarded([&] { return solve_impl(c, opt, out); }); }
 extern "C" int covgpu_download(covgpu_context* c, covgpu_problem* p) { return download_impl(c, p); }
 
 static int full_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out, bool pgo) {
@@ -914,8 +935,8 @@ static int full_solve(covgpu_context* c, const covgpu_options* opt, covgpu_probl
   if (out) *out = local;
   return COVGPU_OK;
 }
-extern "C" int covgpu_gba_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out) { return full_solve(c, opt, p, out, false); }
-extern "C" int covgpu_pgo_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out) { return full_solve(c, opt, p, out, true); }
+extern "C" int covgpu_gba_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out) { return guarded([&] { return full_solve(c, opt, p, out, false); }); }
+extern "C" int covgpu_pgo_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out) { return guarded([&] { return full_solve(c, opt, p, out, true); }); }
 
 // ------------------------------------------------------------------------------------------------ test entry points
 template <typename T>
@@ -1145,6 +1166,8 @@ extern "C" int covgpu_relpose_batch(covgpu_context* c, const covgpu_relpose_batc
 extern "C" int covgpu_pgo_reanchor(covgpu_context* c, int32_t K, const double* pose_old, const double* pose_new, double* velocity, int32_t L,
                                    const int32_t* ref_kf, double* lm_pos) {
   HIPCHK(hipSetDevice(c->device));
+  if (K < 0 || L < 0 || (K > 0 && (!pose_old || !pose_new)) || (L > 0 && (!ref_kf || !lm_pos))) { g_err = "covgpu_pgo_reanchor: NULL array"; return COVGPU_ERR_INVALID_ARG; }
+  for (int l = 0; l < L; ++l) if (ref_kf[l] >= K) { g_err = "covgpu_pgo_reanchor: ref_kf out of range"; return COVGPU_ERR_INVALID_ARG; }
   double *dpo, *dpn, *dv = nullptr, *dl; int* dr;
   std::vector<void*> tmp;
   auto A = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 8); if (e == hipSuccess) tmp.push_back(*p); return e; };

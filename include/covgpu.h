@@ -34,7 +34,7 @@ enum {
   COVGPU_ERR_INVALID_ARG = 1,   /* malformed problem (index out of range, NULL array, ...)   */
   COVGPU_ERR_NO_DEVICE = 2,     /* no HIP device / HIP runtime failure                        */
   COVGPU_ERR_OUT_OF_MEMORY = 3, /* device allocation failed                                   */
-  COVGPU_ERR_NUMERIC = 4,       /* reduced system not positive definite after max damping     */
+  COVGPU_ERR_NUMERIC = 4,       /* single linear solve not positive definite (covgpu_solve_reduced, covgpu_gn_step) */
   COVGPU_ERR_FATAL_MAP = 5      /* conditions on which the reference calls exit(-1)           */
 };
 
@@ -131,8 +131,11 @@ typedef struct covgpu_problem {
 typedef struct covgpu_result {
   int32_t iterations;          /* trust-region iterations executed                          */
   int32_t accepted;            /* of which successful                                       */
-  int32_t termination;         /* 0 max-iter, 1 function tol, 2 parameter tol, 3 gradient tol, 4 failure */
-  int32_t reserved;
+  int32_t termination;         /* 0 max-iter, 1 function tol, 2 parameter tol, 3 gradient tol, 4 failure: the reduced system stayed
+                                * non-positive-definite up to the largest damping. Like ceres::Solve (whose summary the reference
+                                * ignores, opt_be.cpp:567) the call still returns COVGPU_OK and the LAST ACCEPTED estimate; callers that
+                                * care check this field. COVGPU_ERR_NUMERIC is returned by covgpu_solve_reduced / covgpu_gn_step only. */
+  int32_t reserved;            /* IMU factors dropped because their preintegrated covariance was not positive definite (0 samples) */
   double  initial_cost;
   double  final_cost;
   double  t_upload_s;          /* H2D incl. layout build                                    */

@@ -260,6 +260,7 @@ class OptimizationT {
         for (int i = 0; i < n; ++i) {
           double dt, a[3], g[3];
           Types::imu_sample(*kf, i, &dt, a, g);
+          if (dt == 0.0) continue;  // "dt: 0 -- skip measurement" (keyframe_be.cpp:199-202): the buffer may hold the initial reading
           f.samples.push_back(dt); f.samples.insert(f.samples.end(), a, a + 3); f.samples.insert(f.samples.end(), g, g + 3);
         }
         f.imu_ptr.push_back((int32_t)(f.samples.size() / 7));
@@ -381,6 +382,8 @@ class OptimizationT {
       covgpu_options o = Options(interations_limit, visual_only);
       covgpu_result r;
       if (covgpu_gba_solve(ctx, &o, &p, &r) != COVGPU_OK) detail::fatal(covgpu_last_error());
+      if (r.termination == 4) std::fprintf(stderr, "[covins_gpu] GBA: linear solve failed, keeping the last accepted estimate (as ceres::Solve would)\n");
+      if (r.reserved > 0) std::fprintf(stderr, "[covins_gpu] GBA: %d IMU factors without a positive definite covariance carry no weight\n", r.reserved);
       for (size_t k = 0; k < ix.kfs.size(); ++k) {  // :572-595
         KeyframePtr& kf = ix.kfs[k];
         TransformType T;

@@ -1,0 +1,39 @@
+#!/bin/bash
+# HBM-traffic and matrix-pipe counter passes for the dominant kernel of bench.py's default workload (run ON the GPU box:
+#   gpurun -- 'bash tools/pmc_pass.sh r02'), as /opt/skills/guides/MI355X_MICROARCH.md prescribes: one counter per pass,
+# --kernel-trace only (no sys/hip/hsa trace domains), FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B).
+# Writes gpurun_out/<tag>_pmc_*.csv and gpurun_out/pmc_traffic_current.json, stamped with the sha256 of the HIP sources:
+# bench.py reports `roofline.traffic` only from a file whose stamp matches the sources it runs (copy it to profiles/).
+tag=${1:-pmc}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $root/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$ctr
+  rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_$ctr -o pmc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e > $root/gpurun_out/${tag}_pmc_$ctr.log 2>&1
+done
+rm -rf /tmp/pmc_mfma
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d /tmp/pmc_mfma -o pmc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e > $root/gpurun_out/${tag}_pmc_mfma.log 2>&1
+cd $root
+python tools/rocpd_pmc.py FETCH_SIZE=$(ls /tmp/pmc_FETCH_SIZE/*.db | head -1) WRITE_SIZE=$(ls /tmp/pmc_WRITE_SIZE/*.db | head -1) gpurun_out/${tag}_pmc_hbm_traffic.csv > /dev/null
+python tools/rocpd_counters.py $(ls /tmp/pmc_mfma/*.db | head -1) gpurun_out/${tag}_pmc_mfma.csv > /dev/null
+python - <<PY
+import csv, hashlib, json, os, subprocess
+root = "$root"
+h = hashlib.sha256()
+d = os.path.join(root, "covins_amd", "csrc")
+for f in sorted(os.listdir(d)):
+    if f.endswith((".hip", ".hpp")):
+        h.update(open(os.path.join(d, f), "rb").read())
+out = {"workload": "mh12345", "kernels_sha256": h.hexdigest(),
+       "git_sha": subprocess.run(["git", "rev-parse", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip() or "gpu-box snapshot (no .git)"}
+for row in csv.DictReader(open(os.path.join(root, "gpurun_out", "${tag}_pmc_hbm_traffic.csv"))):
+    if "k_gemm_abt<0" in row["Name"]:
+        out.update(kernel=row["Name"], calls=int(row["Calls"]), fetch_bytes_x2=float(row["FETCH_x2_MB_per_call"]) * 1048576.0,
+                   write_bytes=float(row["WRITE_MB_per_call"]) * 1048576.0)
+for row in csv.DictReader(open(os.path.join(root, "gpurun_out", "${tag}_pmc_mfma.csv"))):
+    if "k_gemm_abt<0" in row["Name"] and row.get("MfmaBusy_pct"):
+        out["mfma_busy_frac"] = float(row["MfmaBusy_pct"]) / 100.0
+json.dump(out, open(os.path.join(root, "gpurun_out", "pmc_traffic_current.json"), "w"), indent=1)
+print(json.dumps(out))
+PY

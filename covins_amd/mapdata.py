@@ -187,7 +187,7 @@ def flatten_gba(m: SlamMap, visual_only: bool, loop_loss: bool, use_loops: bool 
         kf_pose=m.kf_pose[kf_rows],
         kf_speed_bias=np.concatenate([m.kf_velocity[kf_rows], m.kf_bias_a[kf_rows], m.kf_bias_g[kf_rows]], axis=1),
         kf_fixed=fixed, kf_cam=m.kf_cam[kf_rows],
-        cam_extr=m.cam_extr, cam_intr=m.cam_intr, cam_dist=m.cam_dist, cam_dist_type=m.cam_dist_type,
+        cam_extr=m.cam_extr.copy(), cam_intr=m.cam_intr.copy(), cam_dist=m.cam_dist.copy(), cam_dist_type=m.cam_dist_type.copy(),  # (the IR owns its arrays)
         lm_pos=m.lm_pos[lm_rows], lm_obs_ptr=lm_obs_ptr,
         obs_kf=remap[m.obs_kf[obs_rows]] if len(obs_rows) else np.zeros(0, np.int32),
         obs_uv=m.obs_uv[obs_rows].astype(np.float64),                     # float -> double (opt_be.cpp:477)
@@ -303,7 +303,7 @@ def flatten_pgo(m: SlamMap, corrected_poses: Dict[int, np.ndarray], prm: PgoPara
         kf_pose=pose,
         kf_speed_bias=np.concatenate([m.kf_velocity[kf_rows], m.kf_bias_a[kf_rows], m.kf_bias_g[kf_rows]], axis=1),
         kf_fixed=fixed, kf_cam=m.kf_cam[kf_rows],
-        cam_extr=m.cam_extr, cam_intr=m.cam_intr, cam_dist=m.cam_dist, cam_dist_type=m.cam_dist_type,
+        cam_extr=m.cam_extr.copy(), cam_intr=m.cam_intr.copy(), cam_dist=m.cam_dist.copy(), cam_dist_type=m.cam_dist_type.copy(),
         edge_i=np.array(ei, np.int32), edge_j=np.array(ej, np.int32),
         edge_meas=np.array(meas).reshape(-1, 7), edge_sqrt_info=np.array(info).reshape(E, 36),
         edge_loss_a=np.array(loss, np.float64),

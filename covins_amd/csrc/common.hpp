@@ -204,6 +204,10 @@ struct CholAux {
   std::vector<hipEvent_t> ev, prof_ev, panel_ev;  // panel_ev: start of every big panel on the main stream (COVGPU_TRACE_PANELS=1)
   std::vector<double> prof_flops;
   std::vector<int> live_h;   // host copy of DevProblem::ar_live (flop accounting of the batched launches)
+  // per big panel of the batched (arrow) factorisation: device list of the LIVE (batch, ti, tj) tiles of its bulk update,
+  // interleaved so that list position p runs on XCD p % 8 and every XCD gets the same number of tiles (k_chol.hip)
+  std::vector<int*> tri_list; std::vector<int> tri_count; int tri_key = -1;
+  void tri_clear();
   // multi-GPU: sum `n` device doubles over all ranks, in place (solver.hip installs it when a shard is set; nullptr = single GPU)
   void (*reduce)(void* ctx, double* dev, size_t n, int op) = nullptr;
   void* reduce_ctx = nullptr;

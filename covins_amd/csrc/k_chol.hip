@@ -73,6 +73,8 @@ struct GemmArgs {
   // with it is zero, so workgroups that would only touch padding exit at once (about half of the batched flops on the
   // 5-agent map, whose agents hold 267 .. 498 interior keyframes).
   const int* live; int tI;
+  // SYRK_TRI on arrow buffers: explicit list of the live tiles, entry = batch << 20 | ti << 10 | tj (-1: no work)
+  const int* tri;
 };
 __device__ __forceinline__ bool tile_live(const GemmArgs& g, int batch, int t) {
   if (g.live == nullptr) return true;
@@ -103,12 +105,17 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
   constexpr int WTR = TSA / WGR, WTC = TSB / WGC;           // wave tile
   constexpr int NMR = WTR / 16, NMC = WTC / 16;             // MFMA tiles per wave
   constexpr int ZQ = (TSA == kTile && TSB == kTile) ? 1 : 4;  // quarter index and batch index share blockIdx.z
-  const int zq = (int)blockIdx.z % ZQ, batch = (MODE == MODE_SYRK_TRI) ? (int)blockIdx.y : (int)blockIdx.z / ZQ;
+  int tri_entry = 0;
+  if (MODE == MODE_SYRK_TRI && g.tri != nullptr) { tri_entry = g.tri[blockIdx.x]; if (tri_entry < 0) return; }
+  const int zq = (int)blockIdx.z % ZQ,
+            batch = (MODE == MODE_SYRK_TRI) ? (g.tri != nullptr ? (tri_entry >> 20) : (int)blockIdx.y) : (int)blockIdx.z / ZQ;
   const int qr = (TSA == kTile) ? 0 : (TSB == kTile ? zq : (zq >> 1));
   const int qc = (TSB == kTile) ? 0 : (zq & 1);
   double* const Mb = g.M + (size_t)batch * g.bsM;
   int ti, tj;
-  if (MODE == MODE_SYRK_TRI) {
+  if (MODE == MODE_SYRK_TRI && g.tri != nullptr) {
+    ti = (tri_entry >> 10) & 1023; tj = tri_entry & 1023;
+  } else if (MODE == MODE_SYRK_TRI) {
     // XCD-aware decode: block b -> XCD (b & 7) (observed dispatch order; placement affects speed only).
     const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
     const int s = (q >> 6) * 8 + xcd, inner = q & 63;
@@ -697,7 +704,12 @@ void CholAux::init() {
   if (!ev_cf) (void)hipEventCreateWithFlags(&ev_cf, hipEventDisableTiming);
   if (!ev_g) (void)hipEventCreateWithFlags(&ev_g, hipEventDisableTiming);
 }
+void CholAux::tri_clear() {
+  for (int* p : tri_list) if (p) (void)hipFree(p);
+  tri_list.clear(); tri_count.clear(); tri_key = -1;
+}
 void CholAux::destroy() {
+  tri_clear();
   if (mid) { (void)hipStreamDestroy(mid); mid = nullptr; }
   if (head) { (void)hipStreamDestroy(head); head = nullptr; }
   for (auto e : ev) (void)hipEventDestroy(e);
@@ -772,14 +784,14 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   // quad: four workgroups per tile (head launches on the serial chain)
   auto trsm = [&](int t, int r0, int r1, hipStream_t s2, bool quad) {
     if (r1 <= r0) return;
-    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, b, b + npad, bt.sM, bt.sL, bt.sR, bt.live, bt.tI};
+    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, b, b + npad, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr};
     if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_TRSM, 32, kTile>), dim3(r1 - r0, 1, 4 * nbt), dim3(256), (size_t)(32 + kTile) * (KCQ + 1) * sizeof(double), s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(r1 - r0, 1, nbt), dim3(256), lds_gemm, s2, g);
   };
   // C tiles (rows [r0, r1), tile columns [tc0, tc0+ntc)) -= A[rows, K] A[tc.., K]^T, K = tiles kt0.. (KD columns); lower part only
   auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2, bool quad) {
     if (r1 <= r0 || ntc <= 0) return;
-    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI};
+    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr};
     if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4 * nbt), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0, nbt), dim3(256), lds_gemm, s2, g);
   };
@@ -798,6 +810,42 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   // its Schur complement (and, with the forward substitution riding along, b's trailing part the reduced right-hand
   // side). Used by the block-arrow pose-graph solve (k_pgo.hip).
   const int Pstop = (tstop >= 0 && tstop < T) ? tstop / 2 : NP;
+  if (bt.live_h != nullptr && ax.tri_key != T * 4096 + nbt) {  // live-tile lists of every panel's bulk update (static per problem)
+    ax.tri_clear();
+    ax.tri_key = T * 4096 + nbt;
+    ax.tri_list.assign(NP, nullptr); ax.tri_count.assign(NP, 0);
+    for (int P = 0; P < NP && P < Pstop; ++P) {
+      const int t0 = 2 * P, tb = t0 + 4;
+      if (tb >= T) break;
+      std::vector<int> q[8];  // per-XCD queues; whole 8x8 supertiles of one batch go to the currently shortest queue
+      for (int a = 0; a < nbt; ++a) {
+        const int nI = bt.live_h[2 * a], nO = bt.live_h[2 * a + 1];
+        if (t0 >= nI) continue;
+        auto live = [&](int t) { return t < nI || (t >= bt.tI && t - bt.tI < nO); };
+        const int nt = T - tb, Ts = (nt + 7) / 8;
+        for (int si = 0; si < Ts; ++si)
+          for (int sj = 0; sj <= si; ++sj) {
+            std::vector<int> grp;
+            for (int i = 8 * si; i < std::min(nt, 8 * si + 8); ++i)
+              for (int j = 8 * sj; j < std::min(i + 1, 8 * sj + 8); ++j)
+                if (live(tb + i) && live(tb + j)) grp.push_back((a << 20) | (i << 10) | j);
+            if (grp.empty()) continue;
+            int best = 0;
+            for (int x = 1; x < 8; ++x) if (q[x].size() < q[best].size()) best = x;
+            q[best].insert(q[best].end(), grp.begin(), grp.end());
+          }
+      }
+      size_t longest = 0;
+      for (int x = 0; x < 8; ++x) longest = std::max(longest, q[x].size());
+      if (longest == 0) continue;
+      std::vector<int> lst(8 * longest, -1);
+      for (int x = 0; x < 8; ++x) for (size_t k = 0; k < q[x].size(); ++k) lst[8 * k + x] = q[x][k];
+      int* d = nullptr;
+      if (hipMalloc((void**)&d, lst.size() * sizeof(int)) != hipSuccess) { ax.tri_clear(); break; }
+      (void)hipMemcpy(d, lst.data(), lst.size() * sizeof(int), hipMemcpyHostToDevice);
+      ax.tri_list[P] = d; ax.tri_count[P] = (int)lst.size();
+    }
+  }
   int Plast = NP - 1;
   for (int P = 0; P < NP; ++P) {
     const int t0 = 2 * P, w = (T - t0 >= 2) ? 2 : 1;
@@ -878,21 +926,29 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     if (P + 1 < NP) wait(B, eRc[P + 1]);
     if (nt > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
-      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI};
-      if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], B);
-      hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, B, g);
-      if (ax.profile) {
-        (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], B);
-        double pairs = 0.0;  // tile pairs that do work: padding rows / panels of a batched arrow buffer exit at once
-        for (int a = 0; a < nbt; ++a) {
-          if (bt.live_h == nullptr) { pairs += (double)nt * (nt + 1) / 2; continue; }
-          const int nI = bt.live_h[2 * a], nO = bt.live_h[2 * a + 1];
-          if (t0 >= nI) continue;
-          int nl = 0;
-          for (int t = tb; t < T; ++t) nl += (t < nI || (t >= bt.tI && t - bt.tI < nO)) ? 1 : 0;
-          pairs += (double)nl * (nl + 1) / 2;
+      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr};
+      // arrow buffers: the live tiles of this panel's update as an explicit, XCD-balanced list (built once per problem).
+      // The implicit triangle grid x batch launched ~2.6k workgroups of which ~400 did work, with every batch's first
+      // supertile on XCD 0: 17 TFLOP/s.
+      const bool listed = bt.live_h != nullptr && P < (int)ax.tri_list.size() && ax.tri_list[P] != nullptr;
+      if (listed) g.tri = ax.tri_list[P];
+      double pairs = 0.0;  // tile pairs that do work
+      for (int a = 0; a < nbt; ++a) {
+        if (bt.live_h == nullptr) { pairs += (double)nt * (nt + 1) / 2; continue; }
+        const int nI = bt.live_h[2 * a], nO = bt.live_h[2 * a + 1];
+        if (t0 >= nI) continue;
+        int nl = 0;
+        for (int t = tb; t < T; ++t) nl += (t < nI || (t >= bt.tI && t - bt.tI < nO)) ? 1 : 0;
+        pairs += (double)nl * (nl + 1) / 2;
+      }
+      if (!listed || ax.tri_count[P] > 0) {
+        if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], B);
+        if (listed) hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(ax.tri_count[P], 1), dim3(256), lds_gemm, B, g);
+        else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, B, g);
+        if (ax.profile) {
+          (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], B);
+          ax.prof_flops.push_back(pairs * 2.0 * kTile * kTile * (w * kTile));
         }
-        ax.prof_flops.push_back(pairs * 2.0 * kTile * kTile * (w * kTile));
       }
     }
     (void)hipEventRecord(eB[P], B);

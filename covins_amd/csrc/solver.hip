@@ -147,6 +147,7 @@ static void free_problem(covgpu_context* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   c->allocs.clear();
   c->alloc_bytes = 0;
+  c->chol.tri_clear(); c->chol.live_h.clear();
   c->have = false;
   c->pgo_plan.active = false;  // its device buffers were in `allocs`
 }
@@ -631,6 +632,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
       for (int a = 0; a < hp.nblk; ++a) { live[2 * a] = (6 * hp.nint[a] + kTile - 1) / kTile; live[2 * a + 1] = (6 * (int)hp.own[a].size() + kTile - 1) / kTile; }
       RC(dev_upload(c, &P.ar_live, live.data(), live.size()));
       c->chol.live_h = live;
+      c->chol.tri_clear();   // the live-tile lists of the bulk updates belong to the previous problem
       RC(dev_alloc(c, &P.ar_M, (size_t)P.ar_nblk * P.ar_ntot * P.ar_ntot)); RC(dev_alloc(c, &P.ar_rhs, (size_t)P.ar_nblk * 2 * P.ar_ntot));
       RC(dev_alloc(c, &P.ar_Linv, (size_t)P.ar_nblk * P.ar_nIpad * kTile));
       RC(dev_alloc(c, &P.ar_Sb, (size_t)P.ar_nb * P.ar_nb + 2 * (size_t)P.ar_nb));  // [C_b | b_b | y_b]: one contiguous all-reduce

@@ -89,6 +89,7 @@ struct DevProblem {
   int* Yld;        // [nchains] leading dimension of each chain's block (6 Kc rounded up to 16)
   int* pos_chain_begin;  // [K] position -> first position of its chain
   int* pos_chain;        // [K] position -> chain index
+  int cc_n; int *cc_chain, *cc_blk;  // work list of k_sb_chain_cols: (chain, 64-column block inside it) per workgroup
   double* zs;      // [9K]  L_A^-1 b_s
   double* xs;      // [9K]  speed-bias solution (chain order)
   double* bp;      // [2 npad] pose right-hand side / solution of the dense stage (+ scratch half)
@@ -256,6 +257,7 @@ bool gba_plan_analyse(int K, int nchains, const int* chain_ptr, int npairs, cons
 // owned_in[q] != 0 iff the keyframe's block belongs to this rank); builds this rank's blocks and own-border lists.
 void gba_plan_build(int K, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
                     const int* epair_i, const int* epair_j, const char* border_in, const char* owned_in, const int* pos_kf, ArrowHostPlan& out);
+void launch_shard_scal(const DevProblem& P, double* mx, int dir, hipStream_t st);  // dir 0: split off [gmax, flag], 1: put them back
 void launch_border_vec(const DevProblem& P, double* buf, int dir, hipStream_t st);  // dir 0: pack [grad | hdiag] of the border pose rows, 1: unpack
 void launch_arrow_zero(const DevProblem& P, hipStream_t st);   // per iteration: clear the buffers, identity on padding rows
 void launch_arrow_solve(const DevProblem& P, hipStream_t st, CholAux& ax);  // P.bp (chain positions) -> solution in place

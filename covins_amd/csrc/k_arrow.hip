@@ -185,6 +185,14 @@ void launch_border_vec(const DevProblem& P, double* buf, int dir, hipStream_t st
   if (P.ar_nbk > 0) hipLaunchKernelGGL(k_border_vec, dim3((6 * P.ar_nbk + 255) / 256), dim3(256), 0, st, P, buf, dir);
 }
 
+// sharded solve: the max-reduced pair (gradient max-norm, Cholesky failure flag) travels apart from the summed scalars
+__global__ void k_shard_scal(DevProblem P, double* mx, int dir) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (dir == 0) { mx[0] = P.scal[SC_GMAX]; mx[1] = (double)P.flag[0]; P.scal[SC_GMAX] = 0.0; }
+  else { P.scal[SC_GMAX] = mx[0]; P.flag[0] = (int)mx[1]; }
+}
+void launch_shard_scal(const DevProblem& P, double* mx, int dir, hipStream_t st) { hipLaunchKernelGGL(k_shard_scal, dim3(1), dim3(64), 0, st, P, mx, dir); }
+
 void launch_arrow_zero(const DevProblem& P, hipStream_t st) {
   if (P.ar_nblk > 0) hipMemsetAsync(P.ar_M, 0, (size_t)P.ar_nblk * P.ar_ntot * P.ar_ntot * sizeof(double), st);
   hipMemsetAsync(P.ar_Sb, 0, (size_t)P.ar_nb * P.ar_nb * sizeof(double), st);

@@ -203,13 +203,9 @@ typedef double v4f64s __attribute__((ext_vector_type(4)));
 struct ColOps { double ls[3], li[3], bi[3]; };
 __global__ __launch_bounds__(256) void k_sb_chain_cols(DevProblem P) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int b = blockIdx.x, c = 0;
-  for (; c < P.nchains; ++c) {  // workgroup -> (chain, block of 64 columns inside it)
-    const int nb = (6 * (P.chain_ptr[c + 1] - P.chain_ptr[c]) + 63) / 64;
-    if (b < nb) break;
-    b -= nb;
-  }
-  if (c >= P.nchains) return;
+  // workgroup -> (chain, block of 64 columns inside it): host-built list (a sharded rank holds thousands of one-keyframe
+  // chains — the keyframes of other ranks' agents — and a linear search over the chains per workgroup cost 0.7 ms each)
+  const int c = P.cc_chain[blockIdx.x], b = P.cc_blk[blockIdx.x];
   const int p0 = P.chain_ptr[c], p1 = P.chain_ptr[c + 1];
   const int col0 = 6 * p0 + (b * 4 + wave) * 16;
   if (col0 >= 6 * p1) return;  // wave-uniform; the kernel has no barrier
@@ -500,7 +496,7 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
   if (P.vi) {
     if (early) { (void)hipStreamWaitEvent(st, ax.ev_cf, 0); ax.cf_pending = false; }
     else hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, st, P);
-    hipLaunchKernelGGL(k_sb_chain_cols, dim3((6 * P.K + 63) / 64 + P.nchains), dim3(256), 0, st, P);  // >= sum of per-chain block counts
+    hipLaunchKernelGGL(k_sb_chain_cols, dim3(P.cc_n), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_pose_rhs, dim3((8 * 6 * P.K + 255) / 256), dim3(256), 0, st, P);
     if (early) (void)hipStreamWaitEvent(st, ax.ev_g, 0);
     else {

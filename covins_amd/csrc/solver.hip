@@ -542,6 +542,13 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
     }
     RC(dev_upload(c, &P.Yoff, yoff.data(), yoff.size())); RC(dev_upload(c, &P.Yld, yld.data(), yld.size()));
     RC(dev_upload(c, &P.pos_chain_begin, cbeg.data(), cbeg.size())); RC(dev_upload(c, &P.pos_chain, cidx.data(), cidx.size()));
+    std::vector<int> wch, wbl;
+    for (int ch = 0; ch < P.nchains; ++ch) {
+      const int nb = (6 * (chain_ptr[ch + 1] - chain_ptr[ch]) + 63) / 64;
+      for (int b = 0; b < nb; ++b) { wch.push_back(ch); wbl.push_back(b); }
+    }
+    P.cc_n = (int)wch.size();
+    RC(dev_upload(c, &P.cc_chain, wch.data(), wch.size())); RC(dev_upload(c, &P.cc_blk, wbl.data(), wbl.size()));
     RC(dev_alloc(c, &P.Y, vi ? ytot : 0));
     if (vi) HIPCHK(hipMemsetAsync(P.Y, 0, ytot * sizeof(double), c->st));  // only the chain trapezoids are ever written
     HIPCHK(hipStreamSynchronize(c->st));
@@ -705,23 +712,19 @@ static int reset_state(covgpu_context* c) {
 }
 
 static int read_scalars(covgpu_context* c) {
+  if (c->sharded && c->have && c->P.shard && c->allreduce) {
+    // every scalar of the trust-region loop is a sum over residuals / unknowns each counted by exactly one rank
+    // (DevProblem::vw), except the gradient max-norm and the Cholesky failure flag (max): reduced ON THE DEVICE buffers
+    // (two small collectives per read-back), so that all ranks then take the same accept / reject decisions
+    launch_shard_scal(c->P, c->d_bvec, 0, c->st);
+    ctx_reduce(c, c->P.scal, SC_COUNT, 0);
+    ctx_reduce(c, c->d_bvec, 2, 1);
+    launch_shard_scal(c->P, c->d_bvec, 1, c->st);
+  }
   HIPCHK(hipMemcpyAsync(c->h_scal, c->P.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipMemcpyAsync(c->h_scal + SC_COUNT, c->P.flag, sizeof(int), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
   HIPCHK(hipGetLastError());  // a failed kernel launch anywhere in the batch just drained surfaces here
-  if (c->sharded && c->have && c->P.shard && c->allreduce) {
-    // every scalar of the trust-region loop is a sum over residuals / unknowns each counted by exactly one rank
-    // (DevProblem::vw), except the gradient max-norm and the Cholesky failure flag (max): all ranks then take the same
-    // accept / reject decisions
-    double* h = c->h_scal;
-    int flag; std::memcpy(&flag, h + SC_COUNT, sizeof(int));
-    double mx[2] = {h[SC_GMAX], (double)flag};
-    h[SC_GMAX] = 0.0;
-    c->allreduce(c->allreduce_user, h, SC_COUNT, 0, 0);
-    c->allreduce(c->allreduce_user, mx, 2, 1, 0);
-    h[SC_GMAX] = mx[0];
-    flag = (int)mx[1]; std::memcpy(h + SC_COUNT, &flag, sizeof(int));
-  }
   return COVGPU_OK;
 }
 static int chol_failed(covgpu_context* c) { int f; std::memcpy(&f, c->h_scal + SC_COUNT, sizeof(int)); return f; }

@@ -201,11 +201,11 @@ def main():
                                "achieved": b_build / (prof["build_ms"] / max(prof["n_build"], 1) * 1e-3) / 1e9 if prof["build_ms"] > 0 else 0.0,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "nnzS_blocks": nnzS,
-                               "note": "whole linearise+Schur pass (a dozen kernels, the serial IMU chain factorisation runs underneath it) "
-                                       "against SURVEY.md 8(d)'s algorithmic bytes (inputs once, H/g blocks, S blocks once). The pass "
-                                       "really moves ~4 GB: 1.4 GB zero-fill of the dense pose system, 0.55 GB of per-observation "
-                                       "records written and 1.4 GB gathered back (what makes it atomic-free, DESIGN.md 4.1); per-kernel "
-                                       "HBM rates from the PMC pass: k_lm_lin 1.9 TB/s, k_pair_blocks 1.7 TB/s, k_yty_semisep 4.2 TB/s"},
+                               "note": "whole linearise+Schur pass (a dozen kernels; the serial IMU chain factorisation runs on the auxiliary stream underneath) "
+                                       "against SURVEY.md 8(d)'s algorithmic bytes (inputs once, H/g blocks, S blocks once). The pass really moves "
+                                       "more: zero-fill of the arrow buffers, 600-B per-observation records written and gathered back by "
+                                       "k_pair_blocks (1.45 GB per launch, profiles/r02f_pmc_hbm_traffic.csv) - the price of the atomic-free, "
+                                       "bit-reproducible build (DESIGN.md 4.1, 6.4)"},
         }
         out["roofline_build"]["frac"] = out["roofline_build"]["achieved"] / HBM_PEAK_GBS
         # whole Optimization::GlobalBundleAdjustment call as backend.cpp:141-156 issues it (outlier round of 5 iterations +
@@ -239,7 +239,12 @@ def main():
             out["delta_ate_gpu_cpu_m"] = abs(out["ate_rmse_m"]["final"] - out["cpu_baseline"]["ate_rmse_m_final"])
             out["max_pose_diff_gpu_cpu_m"] = float(np.abs(sol.kf_pose[:, 4:] - qc.kf_pose[:, 4:]).max())
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        # RCCL prints its version banner through C stdio, which would otherwise be flushed AFTER this line at exit: flush it
+        # first so that the JSON line is the last thing on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
         dist.barrier()

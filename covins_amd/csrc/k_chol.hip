@@ -762,7 +762,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   ax.init();
   const int NP = (T + 1) / 2;  // big panels of two tile columns
   // events per big panel: H rows-h done | B bulk done | C rows-r done | 1 potrf(t0) | 2 X(t0+1,t0) | 3 potrf(t0+1) | Rc next diagonal updated
-  while ((int)ax.ev.size() < 7 * (NP + 1)) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ax.ev.push_back(e); }
+  while ((int)ax.ev.size() < 8 * (NP + 1)) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ax.ev.push_back(e); }
   // (a solve may factorise several matrices — arrow blocks, then the border system: launches accumulate until collect())
   if (ax.profile) while (ax.prof_ev.size() < 2 * (ax.prof_flops.size() + (size_t)NP)) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev.push_back(e); }
   hipEvent_t* eH = ax.ev.data();
@@ -772,6 +772,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   hipEvent_t* e2 = e1 + (NP + 1);
   hipEvent_t* e3 = e2 + (NP + 1);
   hipEvent_t* eRc = e3 + (NP + 1);
+  hipEvent_t* eHp = eRc + (NP + 1);  // rows h updated with column t0 (their last TRSM then runs on the chain's own stream)
 
   static const int potrf_kind = [] { const char* e = getenv("COVGPU_POTRF"); return e ? atoi(e) : 2; }();  // 1: per-pivot kernel, 2: blocked (default)
   auto potrf = [&](int t) {
@@ -872,7 +873,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       break;
     }
     // ---- M: critical chain
-    if (trace_panels && nbt == 1) {
+    if (trace_panels) {
       while ((int)ax.panel_ev.size() <= P + 1) { hipEvent_t e; (void)hipEventCreate(&e); ax.panel_ev.push_back(e); }
       (void)hipEventRecord(ax.panel_ev[P], M);
       ax.panel_n = P + 1;
@@ -893,11 +894,14 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       if (w == 2) {
         wait(H, e2[P]);                        // X(t0+1, t0)
         rect(h0, h1, t0 + 1, 1, t0, kTile, H, true);
-        wait(H, e3[P]);
-        trsm(t0 + 1, h0, h1, H, true);
+        // the LAST kernel of rows h — their TRSM against potrf(t0+1) — gates the next diagonal update: it runs on the chain's
+        // stream right behind that potrf instead of paying a cross-stream event hop (~10 us per big panel un-profiled)
+        (void)hipEventRecord(eHp[P], H);
+        wait(M, eHp[P]);
+        trsm(t0 + 1, h0, h1, M, true);
       }
     }
-    (void)hipEventRecord(eH[P], H);
+    (void)hipEventRecord(eH[P], (h1 > h0 && w == 2) ? M : H);
     // ---- R: rows r
     if (T > h1) {
       wait(R, e1[P]);

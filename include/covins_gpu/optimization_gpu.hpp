@@ -48,6 +48,7 @@ struct Params {
   int pgo_fix_kfs_after_gba = 1;
   int pgo_fix_poses_loaded_maps = 0;
   double wt_kf_r = 10.0, wt_kf_t = 1.0, wt_kf_n1 = 10.0, wt_kf_n23 = 2.0, wt_kf_n45 = 3.0;
+  double th_outlier_align = 1.3;   // opt.th_outlier_align (config_backend.yaml:117), OptimizeRelativePose
   std::string placerec_type = "COVINS";
   int strategy = COVGPU_DOGLEG;  // the reference runs DOGLEG (optimization_be.cpp:261,564,1028)
   int device = 0;
@@ -141,6 +142,16 @@ inline void sqrt_info_from_cov(const double* cov, double* S) {
     }
   }
   for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) S[6 * r + c] = L[c][r];
+}
+
+// C = A B for 4x4 transforms; p_cam = (T_w_c)^-1 p_w
+template <class M>
+inline void mat_mul(const M& A, const M& B, M& C) {
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { double s = 0; for (int k = 0; k < 4; ++k) s += A(r, k) * B(k, c); C(r, c) = s; }
+}
+template <class M, class V>
+inline void to_camera(const M& Twc, const V& pw, double* out3) {
+  for (int r = 0; r < 3; ++r) { double s = 0; for (int k = 0; k < 3; ++k) s += Twc(k, r) * (pw[k] - Twc(k, 3)); out3[r] = s; }
 }
 
 struct Flat {  // owning storage behind one covgpu_problem
@@ -538,6 +549,72 @@ class OptimizationT {
       lms[l]->SetOptimized();
     }
     std::printf("--> PGO END \n");
+  }
+
+  // ---- optimization_be.cpp:620-831, batched: one entry per loop candidate (placerec_be.cpp:116-165 verifies them one by
+  //      one; a batch goes to the device in ONE launch, covgpu_relpose_batch). Semantics per entry are the reference's:
+  //      matches1[i] is reset for removed correspondences, T12 is updated unless fewer than 12 inliers are left, the
+  //      return value is the inlier count (0 = rejected).
+  using LandmarkVector = std::vector<LandmarkPtr>;
+  struct RelPoseJob { KeyframePtr kf1, kf2; LandmarkVector* matches1; TransformType* T12; int result = 0; };
+  static void OptimizeRelativePoseBatch(std::vector<RelPoseJob>& jobs) {
+    const size_t B = jobs.size();
+    if (B == 0) return;
+    std::vector<int32_t> ptr(1, 0), dA(B), dB(B), inl(B);
+    std::vector<double> pB, pA, kA, kB, sA, sB, camA(8 * B), camB(8 * B), T(7 * B);
+    std::vector<std::vector<int>> index(B);   // correspondence -> position in matches1
+    for (size_t b = 0; b < B; ++b) {
+      RelPoseJob& j = jobs[b];
+      int da = 0, db = 0;
+      if (!Types::camera(*j.kf1, &camA[8 * b], &camA[8 * b + 4], &da) || !Types::camera(*j.kf2, &camB[8 * b], &camB[8 * b + 4], &db))
+        detail::fatal("Unknown projection / distortion type.");  // :668-671, 695-697
+      dA[b] = da; dB[b] = db;
+      detail::transform_to_pose(*j.T12, &T[7 * b]);
+      // TcwA = (Tws1 Tsc1)^-1, TcwB = (Tws2 Tsc1)^-1 — the reference uses kf1's extrinsics for both (:640-641)
+      TransformType TwcA, TwcB;
+      detail::mat_mul(j.kf1->GetPoseTws(), j.kf1->GetStateExtrinsics(), TwcA);
+      detail::mat_mul(j.kf2->GetPoseTws(), j.kf1->GetStateExtrinsics(), TwcB);
+      const auto lmsA = j.kf1->GetLandmarks();
+      const int N = (int)j.matches1->size();
+      for (int i = 0; i < N; ++i) {
+        const LandmarkPtr& mb = (*j.matches1)[i];
+        if (!mb) continue;
+        const LandmarkPtr ma = i < (int)lmsA.size() ? lmsA[i] : LandmarkPtr();
+        const int iB = mb->GetFeatureIndex(j.kf2);
+        if (!ma || ma->IsInvalid() || mb->IsInvalid() || iB < 0) continue;        // :648-651
+        double a3[3], b3[3];
+        detail::to_camera(TwcA, ma->GetWorldPos(), a3); detail::to_camera(TwcB, mb->GetWorldPos(), b3);   // :652-656
+        pA.insert(pA.end(), a3, a3 + 3); pB.insert(pB.end(), b3, b3 + 3);
+        kA.push_back((double)j.kf1->keypoints_distorted_[i][0]); kA.push_back((double)j.kf1->keypoints_distorted_[i][1]);
+        kB.push_back((double)j.kf2->keypoints_distorted_[iB][0]); kB.push_back((double)j.kf2->keypoints_distorted_[iB][1]);
+        sA.push_back(((double)j.kf1->keypoints_aors_[i][1] + 1) * 2.0); sB.push_back(((double)j.kf2->keypoints_aors_[iB][1] + 1) * 2.0);   // :658, 717
+        index[b].push_back(i);
+      }
+      ptr.push_back((int32_t)sA.size());
+    }
+    std::vector<uint8_t> out(sA.size() + 1);
+    covgpu_relpose_batch_t bt{};
+    bt.num_pairs = (int32_t)B; bt.corr_ptr = ptr.data(); bt.p_b = pB.data(); bt.p_a = pA.data(); bt.kp_a = kA.data(); bt.kp_b = kB.data();
+    bt.sigma_a = sA.data(); bt.sigma_b = sB.data(); bt.cam_a = camA.data(); bt.cam_b = camB.data(); bt.dist_type_a = dA.data(); bt.dist_type_b = dB.data();
+    bt.T_ab = T.data(); bt.outlier = out.data(); bt.inliers = inl.data();
+    covgpu_context* ctx = Context();
+    if (covgpu_relpose_batch(ctx, &bt, params().th_outlier_align, 12) != COVGPU_OK) detail::fatal(covgpu_last_error());
+    covgpu_destroy(ctx);
+    for (size_t b = 0; b < B; ++b) {
+      RelPoseJob& j = jobs[b];
+      for (size_t c = 0; c < index[b].size(); ++c)
+        if (out[ptr[b] + c]) (*j.matches1)[index[b][c]].reset();   // "matches1[i] = NULL" (:807; the reference indexes by residual, a quirk not copied)
+      j.result = inl[b];
+      if (inl[b] > 0) detail::pose_to_transform(&T[7 * b], *j.T12);  // :820
+    }
+  }
+  // same signature as the reference (th2 is unused there too)
+  static auto OptimizeRelativePose(KeyframePtr kf1, KeyframePtr kf2, LandmarkVector& matches1, TransformType& T12, const double th2) -> int {
+    (void)th2;
+    std::vector<RelPoseJob> jobs(1);
+    jobs[0].kf1 = kf1; jobs[0].kf2 = kf2; jobs[0].matches1 = &matches1; jobs[0].T12 = &T12;
+    OptimizeRelativePoseBatch(jobs);
+    return jobs[0].result;
   }
 };
 

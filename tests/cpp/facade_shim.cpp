@@ -124,6 +124,21 @@ void shim_set_params(int strategy, const char* placerec_type) {
 void shim_set_flatten_threads(int n) { Opt::params().flatten_threads = n; }
 void shim_set_invalid(Handle* h, int kf) { h->kfs[kf]->SetInvalid(); }
 
+// OptimizeRelativePose between two keyframes of the map: matches1[i] = the landmark of kf2 matched to feature i of kf1 (here:
+// the SAME landmark when both observe it), T12 in/out as pose7. Returns the inlier count; removed[] flags per feature of kf1.
+int shim_relpose(Handle* h, int kf1, int kf2, double* T12_pose7, unsigned char* removed) {
+  KeyframePtr a = h->kfs[kf1], b = h->kfs[kf2];
+  std::vector<LandmarkPtr> matches(a->landmarks_.size());
+  for (size_t i = 0; i < matches.size(); ++i)
+    if (a->landmarks_[i] && a->landmarks_[i]->GetFeatureIndex(b) >= 0) matches[i] = a->landmarks_[i];
+  std::vector<LandmarkPtr> before = matches;
+  Mat4 T = pose_to_mat(T12_pose7);
+  const int n = Opt::OptimizeRelativePose(a, b, matches, T, 0.0);
+  covins_gpu::detail::transform_to_pose(T, T12_pose7);
+  for (size_t i = 0; i < matches.size(); ++i) removed[i] = (before[i] && !matches[i]) ? 1 : 0;
+  return n;
+}
+
 void shim_get_state(Handle* h, double* pose, double* vel, double* ba, double* bg, unsigned char* kf_gba, double* lm, unsigned char* lm_invalid,
                     int* lm_nobs) {
   for (size_t k = 0; k < h->kfs.size(); ++k) {

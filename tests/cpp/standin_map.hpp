@@ -66,6 +66,7 @@ class Keyframe : public std::enable_shared_from_this<Keyframe> {
   KeyframePtr GetPredecessor() const { return pred_.lock(); }
   KeyframePtr GetSuccessor() const { return succ_.lock(); }
   void EraseLandmark(size_t index) { if (index < landmarks_.size()) landmarks_[index].reset(); }
+  std::vector<LandmarkPtr> GetLandmarks() const { return landmarks_; }
 
   std::weak_ptr<Keyframe> pred_, succ_;
   bool pose_optimized_ = false, vel_bias_optimized_ = false;
@@ -88,6 +89,7 @@ class Landmark {
   KfObservations GetObservations() const { return observations_; }
   void AddObservation(KeyframePtr kf, size_t idx) { observations_[kf] = idx; }
   void EraseObservation(KeyframePtr kf) { observations_.erase(kf); }
+  int GetFeatureIndex(KeyframePtr kf) const { auto it = observations_.find(kf); return it == observations_.end() ? -1 : (int)it->second; }
   KeyframePtr GetReferenceKeyframe() const { return ref_.lock(); }
   void SetReferenceKeyframe(KeyframePtr kf) { ref_ = kf; }
   void SetOptimized() { optimized_ = true; }

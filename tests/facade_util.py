@@ -87,6 +87,15 @@ class StandinMap:
         poses = np.ascontiguousarray(np.array(list(corrected.values())).reshape(-1, 7), dtype=np.float64)
         lib().shim_pgo(self.h, len(idx), _p(idx, C.c_int), _p(poses))
 
+    def relpose(self, kf1, kf2, T12):
+        """Optimization::OptimizeRelativePose(kf1, kf2, matches1, T12, th2) through the C++ facade; matches = shared landmarks."""
+        T = np.ascontiguousarray(T12, dtype=np.float64).copy()
+        nfeat = int((self.m.obs_kf == kf1).sum())
+        removed = np.zeros(max(nfeat, 1), np.uint8)
+        lib().shim_relpose.restype = C.c_int
+        n = lib().shim_relpose(self.h, int(kf1), int(kf2), _p(T), _p(removed, C.c_ubyte))
+        return int(n), T, removed[:nfeat].astype(bool)
+
     def state(self):
         m = self.m
         out = dict(pose=np.zeros((m.K, 7)), vel=np.zeros((m.K, 3)), ba=np.zeros((m.K, 3)), bg=np.zeros((m.K, 3)), gba=np.zeros(m.K, np.uint8),

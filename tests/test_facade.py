@@ -78,3 +78,29 @@ def test_cpp_pgo_matches_python_facade():
     assert rot_angle(st["pose"][:, :4], mp.kf_pose[:, :4]).max() < 1e-6
     assert np.abs(st["vel"] - mp.kf_velocity).max() < 1e-6
     assert np.abs(st["lm"] - mp.lm_pos).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_cpp_optimize_relative_pose():
+    """The facade's OptimizeRelativePose (reference signature, optimization_be.cpp:620-831) on two consecutive keyframes of the
+    ground-truth map: starting 3 cm / 1.5 deg off, it lands on the true camera-to-camera transform within the pixel noise."""
+    from scipy.spatial.transform import Rotation as R
+    from tests.util import truth_map
+    m = truth_map(synth.make_map(synth.config_named("small")))
+    k1 = int(np.nonzero(m.kf_client == 0)[0][10]); k2 = int(m.kf_succ[k1])
+    def T_w_c(k):
+        Rws = R.from_quat(m.kf_pose[k, :4]); Rsc = R.from_quat(m.cam_extr[m.kf_cam[k], :4])
+        return Rws * Rsc, m.kf_pose[k, 4:] + Rws.apply(m.cam_extr[m.kf_cam[k], 4:])
+    (Ra, ta), (Rb, tb) = T_w_c(k1), T_w_c(k2)
+    Rab = Ra.inv() * Rb; tab = Ra.inv().apply(tb - ta)            # camera B -> camera A
+    q0 = (Rab * R.from_rotvec([0.02, -0.015, 0.01])).as_quat(); q0 = -q0 if q0[3] < 0 else q0
+    T0 = np.concatenate([q0, tab + [0.03, -0.02, 0.01]])
+    sm = StandinMap(m)
+    try:
+        n, T, removed = sm.relpose(k1, k2, T0)
+    finally:
+        sm.close()
+    assert n >= 50 and not removed.any()        # th_outlier_align = 1.3 never removes anything (reference quirk, DESIGN.md §1)
+    qt = Rab.as_quat(); qt = -qt if qt[3] < 0 else qt
+    assert np.abs(T[4:] - tab).max() < 0.01 and rot_angle(T[None, :4], qt[None]) [0] < 3e-3
+    assert np.abs(T0[4:] - tab).max() > 3 * np.abs(T[4:] - tab).max()

@@ -856,6 +856,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     if (P > 0) {
       if (h1 > h0) {
         wait(H, eC[P - 1]);                    // L rows h0.. were rest rows of panel P-1
+        wait(H, eH[P - 1]);                    // B operand: L rows t0, t0+1 — their last TRSM ran on the chain's stream
         if (P >= 2) wait(H, eB[P - 2]);        // bulk(P-2) was the previous writer of these tiles
         rect(h0, h1, t0, w, t0 - 2, 2 * kTile, H, true);
       }

@@ -16,6 +16,8 @@
 //   pose_rhs          b'_p = b_p - Y^T z
 //   (k_chol.hip)      C -= Y^T Y restricted to each tile pair's common chain segment; dense Cholesky of C'
 //   sb_backsolve      x_s = A^-1 (b_s - B x_p) with the stored bidiagonal factor, one wave per chain
+#include <cstdlib>
+
 #include "common.hpp"
 #include "dev_math.hpp"
 
@@ -381,6 +383,25 @@ __global__ __launch_bounds__(256) void k_sb_rhs(DevProblem P) {
   P.xs[t] = w;
 }
 
+// u = L_A^-1 (b_s - B x_p) WITHOUT a sequential sweep: L_A^-1 b_s = z (left by the chain factorisation) and L_A^-1 B = Y (stored
+// for the Schur complement anyway), so u = z - Y x_p is one parallel pass over Y (430 MB on the 5-agent map) instead of the
+// forward half of the 9x9 bidiagonal recursion (440 dependent steps per agent). One wave per row of Y; a row of chain
+// position pos has non-zeros in the columns of poses 0 .. pos+1 of its chain only (trapezoid).
+__global__ __launch_bounds__(256) void k_sb_fwd_matvec(DevProblem P) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= 9 * P.K) return;
+  const int pos = row / 9, a = row - 9 * pos, p0 = P.pos_chain_begin[pos], p1 = P.pos_chain_end[pos], ch = P.pos_chain[pos];
+  const size_t ld = (size_t)P.Yld[ch];
+  const double* y = P.Y + P.Yoff[ch] + (size_t)(9 * (pos - p0) + a) * ld;
+  const int ncol = 6 * (min(pos + 2, p1) - p0);
+  const double* xp = P.bp + 6 * p0;
+  double acc = 0.0;
+  for (int c = lane; c < ncol; c += 64) acc += y[c] * xp[c];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) P.xs[row] = P.zs[row] - acc;
+}
+
 // k_sb_backsolve: forward with (Ldinv, Lsub), backward with their transposes — one wave per chain, ~900 dependent
 // steps of 9x9 work per agent. Lanes 0..8 own one row of the current 9-vector; the previous step's vector is
 // broadcast with v_readlane (no barrier on the chain). The factor blocks are staged through LDS in chunks of
@@ -389,7 +410,7 @@ __global__ __launch_bounds__(256) void k_sb_rhs(DevProblem P) {
 constexpr int kSbChunk = 8;
 constexpr int kSbBlk = 168;  // Lsub 81 | pad 3 | Ldinv 81 | pad 3
 constexpr int kSbPerLane = (kSbChunk * 162 + 63) / 64;
-__global__ __launch_bounds__(64) void k_sb_backsolve(DevProblem P) {
+__global__ __launch_bounds__(64) void k_sb_backsolve(DevProblem P, int do_forward) {
   __shared__ __attribute__((aligned(16))) double sblk[2][kSbChunk][kSbBlk];
   const int tid = threadIdx.x;
   const int lane = tid < 9 ? tid : 8;
@@ -415,10 +436,10 @@ __global__ __launch_bounds__(64) void k_sb_backsolve(DevProblem P) {
       if (q < kSbChunk) sblk[buf][q][e < 81 ? e : e + 3] = stage[i];
     }
   };
-  // ---- forward: u_pos = Linv (w_pos - Lsub u_{pos-1}), stored in xs
+  // ---- forward: u_pos = Linv (w_pos - Lsub u_{pos-1}), stored in xs (skipped when k_sb_fwd_matvec already left u in xs)
   double prev = 0.0;
-  gload(0, +1);
-  for (int c = 0; c < nchunk; ++c) {
+  if (do_forward) gload(0, +1);
+  for (int c = 0; do_forward && c < nchunk; ++c) {
     lstore(c & 1);
     if (c + 1 < nchunk) gload(c + 1, +1);
     __syncthreads();
@@ -509,8 +530,14 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
   else if (P.arrow) launch_arrow_solve(P, st, ax);                // GBA on a fused multi-agent map: block-arrow elimination (k_arrow.hip)
   else dense_cholesky_solve_raw(P.Sred, P.bp, P.Linv, P.flag, P.npad, st, ax);
   if (P.vi) {
-    hipLaunchKernelGGL(k_sb_rhs, dim3((9 * P.K + 255) / 256), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(k_sb_backsolve, dim3(P.nchains), dim3(64), 0, st, P);
+    static const bool fwd_sweep = [] { const char* e = getenv("COVGPU_SB_FWD_SWEEP"); return e && e[0] == '1'; }();  // 1: round-1 sequential forward sweep
+    if (fwd_sweep) {
+      hipLaunchKernelGGL(k_sb_rhs, dim3((9 * P.K + 255) / 256), dim3(256), 0, st, P);
+      hipLaunchKernelGGL(k_sb_backsolve, dim3(P.nchains), dim3(64), 0, st, P, 1);
+    } else {
+      hipLaunchKernelGGL(k_sb_fwd_matvec, dim3((9 * P.K + 3) / 4), dim3(256), 0, st, P);
+      hipLaunchKernelGGL(k_sb_backsolve, dim3(P.nchains), dim3(64), 0, st, P, 0);
+    }
   }
   hipLaunchKernelGGL(k_scatter_solution, dim3((P.n + 255) / 256), dim3(256), 0, st, P, dst);
 }

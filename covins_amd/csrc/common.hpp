@@ -227,6 +227,15 @@ struct DenseBatch { int n = 0; size_t sM = 0, sL = 0, sR = 0; const int* live = 
 void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax, int tstop = -1,
                               bool solve = true, DenseBatch bt = DenseBatch());  // tstop >= 0 (even): eliminate tile columns [0, tstop) only
 void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStream_t st, int tfact, int tend, DenseBatch bt = DenseBatch());
+// 256-column panel chain (k_panel.hip): with it the Linv buffer holds, per tile, the eight 16x16 diagonal-block inverses
+// instead of the 128x128 inverse. COVGPU_PANEL=0 selects the round-2a chain (two 128-column potrf + inverse per panel).
+bool dense_panel_chain();
+void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
+                        hipStream_t st);
+void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
+                     size_t sR, const int* live, int tI, hipStream_t st);
+void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,
+                         size_t sL, size_t sR, hipStream_t st);
 
 // ---- block-arrow pose-graph solve (k_pgo.hip)
 struct PgoHostPlan { std::vector<std::vector<int>> block_kf; std::vector<int> border_kf; };

@@ -743,8 +743,14 @@ void CholAux::collect() {
   prof_flops.clear();
 }
 
+bool dense_panel_chain() {
+  static const bool on = [] { const char* e = getenv("COVGPU_PANEL"); return e ? atoi(e) != 0 : true; }();
+  return on;
+}
+
 void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax, int tstop, bool solve,
                               DenseBatch bt) {
+  const bool panel256 = dense_panel_chain();
   const int nbt = bt.n > 0 ? bt.n : 1;
   const int T = npad / kTile;
   const size_t ld = (size_t)npad;
@@ -859,6 +865,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         wait(H, eH[P - 1]);                    // B operand: L rows t0, t0+1 — their last TRSM ran on the chain's stream
         if (P >= 2) wait(H, eB[P - 2]);        // bulk(P-2) was the previous writer of these tiles
         rect(h0, h1, t0, w, t0 - 2, 2 * kTile, H, true);
+        if (panel256) (void)hipEventRecord(eHp[P], H);
       }
       if (T > h1) {
         wait(R, eH[P - 1]);                    // B operand: L rows t0, t0+1 (rows h of panel P-1)
@@ -879,42 +886,59 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       (void)hipEventRecord(ax.panel_ev[P], M);
       ax.panel_n = P + 1;
     }
-    potrf(t0);
-    (void)hipEventRecord(e1[P], M);
-    if (w == 2) {
-      trsm(t0, t0 + 1, t0 + 2, M, true);
-      (void)hipEventRecord(e2[P], M);
-      rect(t0 + 1, t0 + 2, t0 + 1, 1, t0, kTile, M, true);   // rank-128 update of the second diagonal tile
-      potrf(t0 + 1);
-      (void)hipEventRecord(e3[P], M);
-    }
-    // ---- H: rows h
-    if (h1 > h0) {
-      wait(H, e1[P]);
-      trsm(t0, h0, h1, H, true);
-      if (w == 2) {
-        wait(H, e2[P]);                        // X(t0+1, t0)
-        rect(h0, h1, t0 + 1, 1, t0, kTile, H, true);
-        // the LAST kernel of rows h — their TRSM against potrf(t0+1) — gates the next diagonal update: it runs on the chain's
-        // stream right behind that potrf instead of paying a cross-stream event hop (~10 us per big panel un-profiled)
-        (void)hipEventRecord(eHp[P], H);
-        wait(M, eHp[P]);
-        trsm(t0 + 1, h0, h1, M, true);
+    if (panel256) {
+      // 256-column chain (k_panel.hip): one workgroup factors the whole diagonal block, rows h follow on the same stream by
+      // block substitution, rows r on theirs — three dependent launches per panel instead of six
+      launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M);
+      (void)hipEventRecord(e1[P], M);
+      if (h1 > h0) {
+        if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
+        launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M);
       }
-    }
-    (void)hipEventRecord(eH[P], (h1 > h0 && w == 2) ? M : H);
-    // ---- R: rows r
-    if (T > h1) {
-      wait(R, e1[P]);
-      trsm(t0, h1, T, R, false);
-      if (w == 2) {
-        wait(R, e2[P]);
-        rect(h1, T, t0 + 1, 1, t0, kTile, R, false);
-        wait(R, e3[P]);
-        trsm(t0 + 1, h1, T, R, false);
+      (void)hipEventRecord(eH[P], M);
+      if (T > h1) {
+        wait(R, e1[P]);
+        launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R);
       }
+      (void)hipEventRecord(eC[P], R);
+    } else {
+      potrf(t0);
+      (void)hipEventRecord(e1[P], M);
+      if (w == 2) {
+        trsm(t0, t0 + 1, t0 + 2, M, true);
+        (void)hipEventRecord(e2[P], M);
+        rect(t0 + 1, t0 + 2, t0 + 1, 1, t0, kTile, M, true);   // rank-128 update of the second diagonal tile
+        potrf(t0 + 1);
+        (void)hipEventRecord(e3[P], M);
+      }
+      // ---- H: rows h
+      if (h1 > h0) {
+        wait(H, e1[P]);
+        trsm(t0, h0, h1, H, true);
+        if (w == 2) {
+          wait(H, e2[P]);                        // X(t0+1, t0)
+          rect(h0, h1, t0 + 1, 1, t0, kTile, H, true);
+          // the LAST kernel of rows h — their TRSM against potrf(t0+1) — gates the next diagonal update: it runs on the chain's
+          // stream right behind that potrf instead of paying a cross-stream event hop (~10 us per big panel un-profiled)
+          (void)hipEventRecord(eHp[P], H);
+          wait(M, eHp[P]);
+          trsm(t0 + 1, h0, h1, M, true);
+        }
+      }
+      (void)hipEventRecord(eH[P], (h1 > h0 && w == 2) ? M : H);
+      // ---- R: rows r
+      if (T > h1) {
+        wait(R, e1[P]);
+        trsm(t0, h1, T, R, false);
+        if (w == 2) {
+          wait(R, e2[P]);
+          rect(h1, T, t0 + 1, 1, t0, kTile, R, false);
+          wait(R, e3[P]);
+          trsm(t0 + 1, h1, T, R, false);
+        }
+      }
+      (void)hipEventRecord(eC[P], R);
     }
-    (void)hipEventRecord(eC[P], R);
     // ---- M: look-ahead part of SYRK(P) on the next panel's 2x2 diagonal tiles
     if (P + 1 < NP) {
       const int u0 = t0 + 2, uw = (T - u0 >= 2) ? 2 : 1;
@@ -978,8 +1002,11 @@ void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStrea
     const int ncol = given ? tfact * kTile : p * kTile;
     const int nb = (ncol + 31) / 32;
     if (given && nb == 0) continue;
-    hipLaunchKernelGGL(k_bwd_step, dim3(nb > 0 ? nb : 1, nbt), dim3(256), 0, st, S, ld, p, given ? nullptr : Linv + (size_t)p * kTile * kTile,
-                       b + npad, b, ncol, bt.sM, bt.sL, bt.sR);
+    if (dense_panel_chain())
+      launch_bwd_step_sub(S, ld, p, given ? nullptr : Linv + (size_t)p * kTile * kTile, b + npad, b, ncol, nb > 0 ? nb : 1, nbt, bt.sM, bt.sL, bt.sR, st);
+    else
+      hipLaunchKernelGGL(k_bwd_step, dim3(nb > 0 ? nb : 1, nbt), dim3(256), 0, st, S, ld, p, given ? nullptr : Linv + (size_t)p * kTile * kTile,
+                         b + npad, b, ncol, bt.sM, bt.sL, bt.sR);
   }
 }
 

@@ -1,0 +1,413 @@
+// k_panel.hip — the serial chain of the dense FP64 Cholesky (k_chol.hip), 256 columns per step.
+//
+// Replaces, like k_chol.hip, the linear-algebra half of ceres::Solve(SPARSE_SCHUR) (optimization_be.cpp:560-567,
+// 1024-1031). After the block-arrow elimination the factorisation of the 5-agent map is 40 tile steps
+// of pure latency: per 256-column panel the chain was potrf(128) -> TRSM -> rank-128 update -> potrf(128) -> TRSM ->
+// next-diagonal update, six dependent launches of 20-80 us each with a 128x128 explicit inverse in the middle. Here the
+// same panel is three launches and no large inverse:
+//   k_potrf_panel   ONE workgroup (8 waves) factors the whole 256x256 diagonal block. The trailing 16x16 tiles live in
+//                   REGISTERS in the MFMA accumulator layout for the whole kernel (120 tiles over 7 waves); only the
+//                   current 16-column panel travels through LDS (double-buffered). Per 16 columns: wave 0 factors the
+//                   16x16 diagonal block (row per lane) WHILE the other waves finish the previous panel's trailing update;
+//                   every thread solves one row of the panel by forward substitution; the tiles of the next block column
+//                   are updated first and handed over through LDS, the rest trails behind. The right-hand side rides along as
+//                   one more row. Leaves L in place, y = L^-1 b, and the INVERSES OF THE SIXTEEN 16x16 DIAGONAL BLOCKS.
+//   k_trsm_sub      X = A L^-T for 16-row slabs below the panel, one wave per slab, no LDS, no barrier: block forward
+//                   substitution on Z = X^T kept in accumulator layout — a finished 16x16 block Z_j IS the B operand of the
+//                   trailing updates acc_i -= L_ij Z_j (the C/D layout of v_mfma_f64_16x16x4 equals its B layout), and
+//                   Z_j = Dinv_j acc_j needs only the small block inverses. Exact substitution between blocks: better
+//                   conditioned than the product with a 128x128 explicit inverse it replaces.
+//   k_bwd_step_sub  backward substitution per 128-tile with the same block inverses.
+// A logical row permutation makes every MFMA operand a contiguous 32-byte load: hardware k-slot (lane>>4, step s) carries
+// logical index 4*(lane>>4)+s instead of (lane>>4)+4*s — consistently for A and B, so products are unchanged.
+#include <cstdio>
+#include <cstdlib>
+
+#include "common.hpp"
+#include "dev_math.hpp"
+
+namespace covgpu {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+#ifdef COVGPU_PROBE
+__device__ long long g_pprobe[8];
+#define PPROBE_ACC(i, t0) do { if (threadIdx.x == 0) g_pprobe[i] += wall_clock64() - (t0); } while (0)
+#define PPROBE_T0() wall_clock64()
+#else
+#define PPROBE_ACC(i, t0) do {} while (0)
+#define PPROBE_T0() 0
+#endif
+
+constexpr int PB = 16;                 // block edge
+constexpr int PP = 18;                 // LDS pitch of a panel row (16 doubles + 2: 16-byte aligned rows, spread banks)
+constexpr int PROWS = 256;
+constexpr int NTW = 7;                 // tile-owning waves (waves 1..7; wave 0 factors the diagonal blocks)
+constexpr int NSLOT = 18;              // ceil(120 / 7): tiles (i, k), 1 <= k <= i <= 15, column-major, dealt round-robin
+constexpr size_t kPanelLds = (size_t)(2 * PROWS * PP + 16 * 256 + 256 + 256) * sizeof(double);
+
+COV_DEV double rdlane64p(double v, int srclane) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), srclane);
+  const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), srclane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// acc (tile (i,k), accumulator layout: row = (lane>>4) + 4 reg, col = lane & 15) -= P_i P_k^T for the 16-column panel `pan`
+COV_DEV v4f64 tile_update(v4f64 acc, const double* pan, int i, int k, int fr, int fk) {
+  const double* pa = pan + (PB * i + fr) * PP + 4 * fk;
+  const double* pb = pan + (PB * k + fr) * PP + 4 * fk;
+  const double2 a01 = *reinterpret_cast<const double2*>(pa), a23 = *reinterpret_cast<const double2*>(pa + 2);
+  const double2 b01 = *reinterpret_cast<const double2*>(pb), b23 = *reinterpret_cast<const double2*>(pb + 2);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a01.x, b01.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a01.y, b01.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a23.x, b23.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a23.y, b23.y, acc, 0, 0, 0);
+  return acc;
+}
+
+// Factor the (16 nb)-order diagonal block at (k0, k0), nb = 16 (a 256-column panel) or 8 (a last single tile).
+// Dinv_out: block j at Dinv_out + (j >> 3) * 128*128 + (j & 7) * 256, [16][16] row-major (zeros above the diagonal).
+__global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
+                                                      const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR) {
+  M += (size_t)blockIdx.x * bsM; Dinv_out += (size_t)blockIdx.x * bsL;
+  if (rhs != nullptr) { rhs += (size_t)blockIdx.x * bsR; yout += (size_t)blockIdx.x * bsR; }
+  extern __shared__ __attribute__((aligned(16))) double sP[];  // panel[2][256][PP] | sD[16][256] | sInv[256] | sRhs[256]
+  double* sD = sP + 2 * PROWS * PP;
+  double* sInv = sD + 16 * 256;
+  double* sRhs = sInv + 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fk = lane >> 4;
+  const int n = PB * nb;
+  double* Mg = M + (size_t)k0 * ld + k0;
+  const long long tp0 = PPROBE_T0();
+
+  // ---- tile slots of this wave (wave-uniform)
+  int ti[NSLOT], tk[NSLOT];
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    int t = s * NTW + (wave - 1), k = 1;
+    bool ok = wave >= 1 && t < 120;
+    if (ok) { while (t >= 16 - k) { t -= 16 - k; ++k; } }
+    const int i = k + t;
+    ok = ok && i < nb;
+    ti[s] = ok ? i : 0; tk[s] = ok ? k : 99;
+  }
+  // ---- load: trailing tiles into registers, block column 0 and the right-hand side into LDS
+  // (unconditional loads from a clamped address: a branch per slot would serialise 18 memory latencies)
+  v4f64 acc[NSLOT];
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const bool on = tk[s] != 99;
+    const int ii = on ? ti[s] : 1, kk = on ? tk[s] : 1;
+    const double* src = Mg + (size_t)(PB * ii + fk) * ld + PB * kk + fr;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const double v = src[(size_t)(4 * rg) * ld];
+      acc[s][rg] = (!on || (ii == kk && fr > fk + 4 * rg)) ? 0.0 : v;
+    }
+  }
+  {
+    const int row = tid >> 1, half = tid & 1;
+    if (row < n) {
+      double v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { const int col = 8 * half + c; v[c] = (row >= PB || col <= row) ? Mg[(size_t)row * ld + col] : 0.0; }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) sP[row * PP + 8 * half + c] = v[c];
+    }
+    if (tid < PROWS) sRhs[tid] = (rhs != nullptr && tid < n) ? rhs[k0 + tid] : 0.0;
+  }
+  __syncthreads();
+  PPROBE_ACC(4, tp0);
+
+  for (int j = 0; j < nb; ++j) {
+    double* cur = sP + (j & 1) * PROWS * PP;          // block column j, rows 16 j .. n
+    double* oth = sP + ((j + 1) & 1) * PROWS * PP;    // panel j-1 (read in phase A), then block column j+1 (written in phase C)
+    const int o = PB * j;
+    // ---- phase A: wave 0 factors the diagonal block; the tile waves finish panel j-1's trailing update (columns > j)
+    const long long tq0 = PPROBE_T0();
+    if (wave == 0) {
+      const int r = lane & 15;
+      double x[PB];
+#pragma unroll
+      for (int c = 0; c < PB; ++c) x[c] = (c <= r) ? cur[(o + r) * PP + c] : 0.0;
+      bool bad = false;
+      double mine = 0.0;
+#pragma unroll
+      for (int c = 0; c < PB; ++c) {
+        double d = rdlane64p(x[c], c);
+        if (!(d > 0.0)) { bad = true; d = 1.0; }
+        double inv = __builtin_amdgcn_rsq(d);
+        inv = inv * (1.5 - 0.5 * d * inv * inv);
+        inv = inv * (1.5 - 0.5 * d * inv * inv);
+        mine = (c == r) ? inv : mine;
+        x[c] = (r == c) ? d * inv : x[c] * inv;
+#pragma unroll
+        for (int cc = c + 1; cc < PB; ++cc) x[cc] -= x[c] * rdlane64p(x[c], cc);
+      }
+      if (bad && lane == 0) atomicOr(flag, 1);
+      if (lane < PB) {
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+          const double v = (c <= r) ? x[c] : 0.0;
+          cur[(o + r) * PP + c] = v;
+          sD[j * 256 + r * PB + c] = v;
+        }
+        sInv[o + r] = mine;
+      }
+    }
+    if (j > 0) {  // (wave 0 owns no tile: all its slots are 99)
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s)
+        if (tk[s] > j && tk[s] != 99) {
+          int i = ti[s], k = tk[s];
+          asm volatile("" : "+s"(i), "+s"(k));  // keeps the 36 LDS row addresses from being hoisted out of the j loop (spills)
+          acc[s] = tile_update(acc[s], oth, i, k, fr, fk);
+        }
+    }
+    __syncthreads();
+    PPROBE_ACC(1, tq0);
+    // ---- phase B: rows below the block, x L_jj^T = a, one row per thread; the right-hand side is one more row
+    const long long tq1 = PPROBE_T0();
+    const int nrow = n - o - PB;
+    if (tid <= nrow) {
+      double* rowp = (tid < nrow) ? cur + (o + PB + tid) * PP : sRhs + o;
+      double a[PB];
+#pragma unroll
+      for (int c = 0; c < PB; ++c) a[c] = rowp[c];
+#pragma unroll
+      for (int k = 0; k < PB; ++k) {
+        a[k] *= sInv[o + k];
+#pragma unroll
+        for (int c = k + 1; c < PB; ++c) a[c] -= a[k] * cur[(o + c) * PP + k];
+      }
+#pragma unroll
+      for (int c = 0; c < PB; ++c) rowp[c] = a[c];
+    }
+    __syncthreads();
+    PPROBE_ACC(2, tq1);
+    // ---- phase C: block column j+1 first (handed to the next step through LDS); L and y out; right-hand side update
+    const long long tq2 = PPROBE_T0();
+    {
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s)
+        if (tk[s] == j + 1) {
+          int i = ti[s], k = tk[s];
+          asm volatile("" : "+s"(i), "+s"(k));
+          acc[s] = tile_update(acc[s], cur, i, k, fr, fk);
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) oth[(PB * i + fk + 4 * rg) * PP + fr] = acc[s][rg];
+        }
+    }
+    {
+      const int row = o + (tid >> 1), half = tid & 1;
+      if (row < n) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int col = 8 * half + c;
+          if (row >= o + PB || col <= row - o) Mg[(size_t)row * ld + o + col] = cur[row * PP + col];
+        }
+      }
+      if (tid < nrow) {
+        const int col = o + PB + tid;
+        double t = sRhs[col];
+#pragma unroll
+        for (int c = 0; c < PB; ++c) t -= sRhs[o + c] * cur[col * PP + c];
+        sRhs[col] = t;
+      }
+      if (yout != nullptr && tid >= 448 && tid < 448 + PB) yout[k0 + o + tid - 448] = sRhs[o + tid - 448];
+    }
+    __syncthreads();
+    PPROBE_ACC(3, tq2);
+  }
+  // ---- inverses of the diagonal blocks, one column per thread (forward substitution on L e_c)
+  const long long tp1 = PPROBE_T0();
+  if (tid < PB * nb) {
+    const int j = tid >> 4, col = tid & 15, o = PB * j;
+    const double* Lb = sD + j * 256;
+    double xi[PB];
+#pragma unroll
+    for (int rr = 0; rr < PB; ++rr) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < rr; ++k) sum += Lb[rr * PB + k] * xi[k];
+      xi[rr] = (rr == col) ? sInv[o + rr] : (rr > col ? -sum * sInv[o + rr] : 0.0);
+    }
+    double* dst = Dinv_out + (size_t)(j >> 3) * kTile * kTile + (size_t)(j & 7) * 256;
+#pragma unroll
+    for (int rr = 0; rr < PB; ++rr) dst[rr * PB + col] = xi[rr];
+  }
+  PPROBE_ACC(5, tp1);
+  PPROBE_ACC(6, tp0);
+}
+
+struct TrsmSubArgs {
+  double* M; size_t ld;
+  int k0;                 // first column of the panel
+  int r0;                 // first row (multiple of 16); workgroup x handles rows r0 + 16 x ..
+  const double* Dinv;     // block inverses of the panel's first tile (second tile 128*128 further)
+  double* rhs; const double* yvec;   // forward substitution riding along: rhs[rows] -= X[rows, :] y[k0 ..)
+  size_t bsM, bsL, bsR;
+  const int* live; int tI;           // see GemmArgs (k_chol.hip)
+};
+
+// X = A L^-T on a 16-row slab, L = the (16 NB)-order factor at (k0, k0). One wave, everything in registers.
+// acc[i][reg] at lane (n = lane & 15, fk = lane >> 4) holds Z[16 i + 4 fk + reg][n] = X[row0 + n][k0 + 16 i + 4 fk + reg].
+template <int NB>
+__global__ __launch_bounds__(64) void k_trsm_sub(TrsmSubArgs g) {
+  const int batch = blockIdx.y, lane = threadIdx.x, n = lane & 15, fk = lane >> 4;
+  const int row0 = g.r0 + PB * (int)blockIdx.x;
+  if (g.live != nullptr) {
+    const int nI = g.live[2 * batch], nO = g.live[2 * batch + 1];
+    const int tp = g.k0 / kTile, tr = row0 / kTile;
+    if (!(tp < nI || (tp >= g.tI && tp - g.tI < nO))) return;
+    if (!(tr < nI || (tr >= g.tI && tr - g.tI < nO))) return;
+  }
+  double* Mb = g.M + (size_t)batch * g.bsM;
+  const double* Db = g.Dinv + (size_t)batch * g.bsL;
+  const int pr = 4 * (n & 3) + (n >> 2);  // logical row carried by A-operand lane n
+  double* Arow = Mb + (size_t)(row0 + n) * g.ld + g.k0 + 4 * fk;
+  const double* Lrow = Mb + (size_t)(g.k0 + pr) * g.ld + g.k0 + 4 * fk;
+  const double* Drow = Db + pr * PB + 4 * fk;
+  auto Ltile = [&](int i, int j) { return *reinterpret_cast<const v4f64*>(Lrow + (size_t)(PB * i) * g.ld + PB * j); };
+  auto Dblk = [&](int j) { return *reinterpret_cast<const v4f64*>(Drow + (size_t)(j >> 3) * kTile * kTile + (j & 7) * 256); };
+  v4f64 acc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) acc[i] = *reinterpret_cast<const v4f64*>(Arow + PB * i);
+  v4f64 lbuf[2][NB], dbuf[2];
+  dbuf[0] = Dblk(0);
+#pragma unroll
+  for (int i = 1; i < NB; ++i) lbuf[0][i] = Ltile(i, 0);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if (j + 1 < NB) {  // operands of the next block column: in flight during this one
+      dbuf[(j + 1) & 1] = Dblk(j + 1);
+#pragma unroll
+      for (int i = j + 2; i < NB; ++i) lbuf[(j + 1) & 1][i] = Ltile(i, j + 1);
+    }
+    v4f64 Z = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(dbuf[j & 1][s], acc[j][s], Z, 0, 0, 0);
+    acc[j] = Z;
+    const v4f64 Zn = -Z;
+#pragma unroll
+    for (int i = j + 1; i < NB; ++i)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(lbuf[j & 1][i][s], Zn[s], acc[i], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) *reinterpret_cast<v4f64*>(Arow + PB * i) = acc[i];
+  if (g.rhs != nullptr) {  // rhs[row0 + n] -= sum_k X[n][k] y[k]: lane partial, fixed butterfly over the four lanes sharing n
+    const double* yv = g.yvec + (size_t)batch * g.bsR + g.k0 + 4 * fk;
+    double part = 0.0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const v4f64 y4 = *reinterpret_cast<const v4f64*>(yv + PB * i);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) part += acc[i][s] * y4[s];
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (fk == 0) g.rhs[(size_t)batch * g.bsR + row0 + n] -= part;
+  }
+}
+
+// Backward substitution step for tile p with the 16x16 block inverses (Dinv == nullptr: x_p is given):
+//   x_p = L_pp^-T y_p ; y[cols left of the tile] -= L[tile rows, cols]^T x_p.
+// Thread c < 128 owns unknown c: every entry of L_pp it will need (rows of the blocks below its own) is loaded up front
+// (one memory latency), then eight block steps of two barriers each. Every workgroup of the launch repeats this (cheaper
+// than a separate launch on a launch-bound chain); the column update is split over the workgroups as before.
+__global__ __launch_bounds__(256) void k_bwd_step_sub(const double* __restrict__ M, size_t ld, int p, const double* __restrict__ Dinv,
+                                                       double* __restrict__ y, double* __restrict__ x, int ncol, size_t bsM, size_t bsL, size_t bsR) {
+  M += (size_t)blockIdx.y * bsM; y += (size_t)blockIdx.y * bsR; x += (size_t)blockIdx.y * bsR;
+  if (Dinv != nullptr) Dinv += (size_t)blockIdx.y * bsL;
+  __shared__ double sx[kTile];
+  __shared__ double sv[kTile];
+  __shared__ double part[8][33];
+  const int tid = threadIdx.x, k0 = p * kTile;
+  if (Dinv == nullptr) {
+    if (tid < kTile) sx[tid] = x[k0 + tid];
+    __syncthreads();
+  } else {
+    const int c = tid & 127, jbc = c >> 4, cl = c & 15;
+    const bool act = tid < kTile;
+    double v = act ? y[k0 + c] : 0.0;
+    double dv[PB], Lc[7][PB];
+#pragma unroll
+    for (int r = 0; r < PB; ++r) dv[r] = act ? Dinv[jbc * 256 + r * PB + cl] : 0.0;
+#pragma unroll
+    for (int jb = 1; jb < 8; ++jb)
+#pragma unroll
+      for (int r = 0; r < PB; ++r) Lc[jb - 1][r] = (act && jbc < jb) ? M[(size_t)(k0 + PB * jb + r) * ld + k0 + c] : 0.0;
+#pragma unroll
+    for (int jb = 7; jb >= 0; --jb) {
+      if (act && jbc == jb) sv[c] = v;
+      __syncthreads();
+      if (act && jbc == jb) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int r = 0; r < PB; r += 4) {
+          s0 += dv[r] * sv[PB * jb + r]; s1 += dv[r + 1] * sv[PB * jb + r + 1];
+          s2 += dv[r + 2] * sv[PB * jb + r + 2]; s3 += dv[r + 3] * sv[PB * jb + r + 3];
+        }
+        sx[c] = (s0 + s1) + (s2 + s3);
+      }
+      __syncthreads();
+      if (jb > 0 && act && jbc < jb) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int r = 0; r < PB; r += 4) {
+          s0 += Lc[jb > 0 ? jb - 1 : 0][r] * sx[PB * jb + r]; s1 += Lc[jb > 0 ? jb - 1 : 0][r + 1] * sx[PB * jb + r + 1];
+          s2 += Lc[jb > 0 ? jb - 1 : 0][r + 2] * sx[PB * jb + r + 2]; s3 += Lc[jb > 0 ? jb - 1 : 0][r + 3] * sx[PB * jb + r + 3];
+        }
+        v -= (s0 + s1) + (s2 + s3);
+      }
+    }
+    if (blockIdx.x == 0 && tid < kTile) x[k0 + tid] = sx[tid];
+  }
+  const int cl = tid & 31, rg = tid >> 5;
+  const int col = blockIdx.x * 32 + cl;
+  double acc = 0.0;
+  if (col < ncol) {
+    const double* Lc2 = M + (size_t)(k0 + 16 * rg) * ld + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc += Lc2[(size_t)r * ld] * sx[16 * rg + r];
+  }
+  part[rg][cl] = acc;
+  __syncthreads();
+  if (rg == 0 && col < ncol) {
+    double t = 0.0;
+#pragma unroll
+    for (int g2 = 0; g2 < 8; ++g2) t += part[g2][cl];
+    y[col] -= t;
+  }
+}
+
+// ---- launch wrappers (k_chol.hip schedules them) ----------------------------------------------------------------------
+void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
+                        hipStream_t st) {
+  static bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds);
+    return true;
+  }();
+  (void)once;
+  hipLaunchKernelGGL(k_potrf_panel, dim3(nbt), dim3(512), kPanelLds, st, S, ld, t0 * kTile, 8 * w, Linv + (size_t)t0 * kTile * kTile, flag,
+                     (const double*)b, b ? b + npad : nullptr, sM, sL, sR);
+}
+
+void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
+                     size_t sR, const int* live, int tI, hipStream_t st) {
+  if (r1 <= r0) return;
+  TrsmSubArgs g{S, ld, t0 * kTile, r0 * kTile, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, live, tI};
+  const dim3 grid((r1 - r0) * (kTile / PB), nbt);
+  if (w == 2) hipLaunchKernelGGL(k_trsm_sub<16>, grid, dim3(64), 0, st, g);
+  else hipLaunchKernelGGL(k_trsm_sub<8>, grid, dim3(64), 0, st, g);
+}
+
+void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,
+                         size_t sL, size_t sR, hipStream_t st) {
+  hipLaunchKernelGGL(k_bwd_step_sub, dim3(nblocks, nbt), dim3(256), 0, st, S, ld, p, Linv_p, y, x, ncol, sM, sL, sR);
+}
+
+}  // namespace covgpu

@@ -32,58 +32,77 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 #ifdef COVGPU_PROBE
 __device__ long long g_pprobe[8];
-#define PPROBE_ACC(i, t0) do { if (threadIdx.x == 0) g_pprobe[i] += wall_clock64() - (t0); } while (0)
-#define PPROBE_T0() wall_clock64()
+// (accumulated in registers and written once: a global read-modify-write per phase costs more than the phases themselves)
+#define PPROBE_DECL() long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PPROBE_ACC(i, t0) do { pacc[i] += clock64() - (t0); } while (0)
+#define PPROBE_T0() clock64()
+#define PPROBE_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) g_pprobe[i_] = pacc[i_]; } while (0)
 #else
+#define PPROBE_DECL() do {} while (0)
 #define PPROBE_ACC(i, t0) do {} while (0)
 #define PPROBE_T0() 0
+#define PPROBE_FLUSH() do {} while (0)
 #endif
 
 constexpr int PB = 16;                 // block edge
-constexpr int PP = 18;                 // LDS pitch of a panel row (16 doubles + 2: 16-byte aligned rows, spread banks)
+constexpr int PP = 17;                 // LDS pitch of a panel row: odd -> one row per thread is conflict-free
 constexpr int PROWS = 256;
 constexpr int NTW = 7;                 // tile-owning waves (waves 1..7; wave 0 factors the diagonal blocks)
 constexpr int NSLOT = 18;              // ceil(120 / 7): tiles (i, k), 1 <= k <= i <= 15, column-major, dealt round-robin
-constexpr size_t kPanelLds = (size_t)(2 * PROWS * PP + 16 * 256 + 256 + 256) * sizeof(double);
+constexpr size_t kPanelLds = (size_t)(2 * PROWS * PP + 256 + 256 + 48) * sizeof(double);
 
-COV_DEV double rdlane64p(double v, int srclane) {
-  const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), srclane);
-  const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), srclane);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL store to be
+// acknowledged (s_waitcnt vmcnt(0): ~1 us per step here, where L / Dinv / y stream out while the factorisation goes on
+// and nobody reads them back inside the kernel).
+COV_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // acc (tile (i,k), accumulator layout: row = (lane>>4) + 4 reg, col = lane & 15) -= P_i P_k^T for the 16-column panel `pan`
 COV_DEV v4f64 tile_update(v4f64 acc, const double* pan, int i, int k, int fr, int fk) {
   const double* pa = pan + (PB * i + fr) * PP + 4 * fk;
   const double* pb = pan + (PB * k + fr) * PP + 4 * fk;
-  const double2 a01 = *reinterpret_cast<const double2*>(pa), a23 = *reinterpret_cast<const double2*>(pa + 2);
-  const double2 b01 = *reinterpret_cast<const double2*>(pb), b23 = *reinterpret_cast<const double2*>(pb + 2);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a01.x, b01.x, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a01.y, b01.y, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a23.x, b23.x, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a23.y, b23.y, acc, 0, 0, 0);
+  const double a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3];
+  const double b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3];
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a2, b2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a3, b3, acc, 0, 0, 0);
   return acc;
 }
 
 // Factor the (16 nb)-order diagonal block at (k0, k0), nb = 16 (a 256-column panel) or 8 (a last single tile).
 // Dinv_out: block j at Dinv_out + (j >> 3) * 128*128 + (j & 7) * 256, [16][16] row-major (zeros above the diagonal).
+//
+// Per block column j (three barriers):
+//   A  wave 0 factors the 16x16 diagonal block AND forms its inverse in the same sweep: lane (r = lane>>2, q = lane&3) owns
+//      A[r][4q..4q+3] and W[r][4q..4q+3] (W starts as I). Per pivot c the raw column c of A and row c of W are published in
+//      LDS (one round trip); with t_r = a_rc / d_c every lane does a[r][cc] -= t_r a[cc][c] (cc > c) and, for r > c,
+//      W[r][:] -= t_r W[c][:]  (forward substitution L X = I in outer-product form: L_rc X_c: = a_rc W_c: / d_c).
+//      L = A diag(d)^-1/2 and X = diag(d)^-1/2 W are scaled once at the end. No division or square root of the pivot sits
+//      between two LDS round trips except one reciprocal.  Meanwhile waves 1..7 finish panel j-1's trailing update.
+//   B  X_ij = T_ij Dinv_j^T for the tiles below the block: 4 MFMAs per tile (operands from LDS), result back in place;
+//      y_j = Dinv_j b_j. (Round 1 found the product with a 128x128 explicit inverse too inaccurate for this system; a
+//      16x16 block inverse formed by substitution is the standard blocked-TRSM building block and the full-size parity
+//      tests hold with it.)
+//   C  tiles of block column j+1 first, handed over through LDS; L panel and y out; right-hand side update.
 __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
                                                       const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR) {
   M += (size_t)blockIdx.x * bsM; Dinv_out += (size_t)blockIdx.x * bsL;
   if (rhs != nullptr) { rhs += (size_t)blockIdx.x * bsR; yout += (size_t)blockIdx.x * bsR; }
-  extern __shared__ __attribute__((aligned(16))) double sP[];  // panel[2][256][PP] | sD[16][256] | sInv[256] | sRhs[256]
-  double* sD = sP + 2 * PROWS * PP;
-  double* sInv = sD + 16 * 256;
-  double* sRhs = sInv + 256;
+  extern __shared__ __attribute__((aligned(16))) double sP[];  // panel[2][256][PP] | sDv[16][16] | sRhs[256] | colA[16] rowW[16] sdd[16]
+  double* sDv = sP + 2 * PROWS * PP;
+  double* sRhs = sDv + 256;
+  double* colA = sRhs + 256;   // wave 0 only: LDS operations of one wave execute in order, no barrier needed
+  double* rowW = colA + 16;
+  double* sdd = rowW + 16;      // the block's 16 pivots
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fk = lane >> 4;
   const int n = PB * nb;
   double* Mg = M + (size_t)k0 * ld + k0;
+  PPROBE_DECL();
   const long long tp0 = PPROBE_T0();
 
-  // ---- tile slots of this wave (wave-uniform)
-  int ti[NSLOT], tk[NSLOT];
+  // ---- tile slots of this wave (wave-uniform, packed i | k << 8; k = 99: none)
+  int tik[NSLOT];
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
     int t = s * NTW + (wave - 1), k = 1;
@@ -91,15 +110,15 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
     if (ok) { while (t >= 16 - k) { t -= 16 - k; ++k; } }
     const int i = k + t;
     ok = ok && i < nb;
-    ti[s] = ok ? i : 0; tk[s] = ok ? k : 99;
+    tik[s] = ok ? (i | (k << 8)) : (99 << 8);
   }
   // ---- load: trailing tiles into registers, block column 0 and the right-hand side into LDS
   // (unconditional loads from a clamped address: a branch per slot would serialise 18 memory latencies)
   v4f64 acc[NSLOT];
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
-    const bool on = tk[s] != 99;
-    const int ii = on ? ti[s] : 1, kk = on ? tk[s] : 1;
+    const bool on = (tik[s] >> 8) != 99;
+    const int ii = on ? (tik[s] & 255) : 1, kk = on ? (tik[s] >> 8) : 1;
     const double* src = Mg + (size_t)(PB * ii + fk) * ld + PB * kk + fr;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
@@ -125,82 +144,132 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
     double* cur = sP + (j & 1) * PROWS * PP;          // block column j, rows 16 j .. n
     double* oth = sP + ((j + 1) & 1) * PROWS * PP;    // panel j-1 (read in phase A), then block column j+1 (written in phase C)
     const int o = PB * j;
-    // ---- phase A: wave 0 factors the diagonal block; the tile waves finish panel j-1's trailing update (columns > j)
+    // ---- phase A
     const long long tq0 = PPROBE_T0();
     if (wave == 0) {
-      const int r = lane & 15;
-      double x[PB];
+      __builtin_amdgcn_s_setprio(3);
+      int ln = lane;
+      asm volatile("" : "+v"(ln));  // per-lane invariants of this block are recomputed every step rather than hoisted and spilled
+      const int r = ln >> 2, q = ln & 3;
+      double a[4], w[4];
 #pragma unroll
-      for (int c = 0; c < PB; ++c) x[c] = (c <= r) ? cur[(o + r) * PP + c] : 0.0;
+      for (int e = 0; e < 4; ++e) { a[e] = cur[(o + r) * PP + 4 * q + e]; w[e] = (4 * q + e == r) ? 1.0 : 0.0; }
       bool bad = false;
-      double mine = 0.0;
 #pragma unroll
       for (int c = 0; c < PB; ++c) {
-        double d = rdlane64p(x[c], c);
-        if (!(d > 0.0)) { bad = true; d = 1.0; }
-        double inv = __builtin_amdgcn_rsq(d);
-        inv = inv * (1.5 - 0.5 * d * inv * inv);
-        inv = inv * (1.5 - 0.5 * d * inv * inv);
-        mine = (c == r) ? inv : mine;
-        x[c] = (r == c) ? d * inv : x[c] * inv;
+        const int qc = c >> 2, ec = c & 3;
+        int rr = r, c0 = 4 * q;
+        asm volatile("" : "+v"(rr), "+v"(c0));  // lane masks recomputed per pivot (hoisted they become ~100 spilled SGPR pairs)
+        if (q == qc) colA[r] = a[ec];
+        if (rr == c) {
 #pragma unroll
-        for (int cc = c + 1; cc < PB; ++cc) x[cc] -= x[c] * rdlane64p(x[c], cc);
+          for (int e = 0; e < 4; ++e) rowW[c0 + e] = w[e];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double d = colA[c];
+        const double mr = colA[r];
+        double cv[4], xr[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cv[e] = colA[4 * q + e]; xr[e] = rowW[4 * q + e]; }
+        __builtin_amdgcn_wave_barrier();
+        bad = bad || !(d > 0.0);  // (a non-positive pivot poisons the block with inf/NaN: flagged, the caller discards the solve)
+        if (ln == 0) sdd[c] = d;
+        // 1/d: hardware estimate + two Newton steps arranged as r1 = r + r e, r2 = r1 + r1 e^2 (e = 1 - d r): three dependent
+        // operations after the estimate instead of four — this reciprocal is the only arithmetic between two LDS round trips
+        const double r0 = __builtin_amdgcn_rcp(d);
+        const double e0 = fma(-d, r0, 1.0);
+        const double r1 = fma(r0, e0, r0), e1 = e0 * e0;
+        const double rinv = fma(r1, e1, r1);
+        const double t = mr * rinv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] -= ((c0 + e > c) ? t : 0.0) * cv[e];
+        const double tw = (rr > c) ? t : 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] -= tw * xr[e];
       }
       if (bad && lane == 0) atomicOr(flag, 1);
-      if (lane < PB) {
+      // scale factors 1/sqrt(d) from the saved pivots, once: L = A diag(d)^-1/2 (by column), X = diag(d)^-1/2 W (by row)
+      __builtin_amdgcn_wave_barrier();
+      double rsc[4], rsr;
 #pragma unroll
-        for (int c = 0; c < PB; ++c) {
-          const double v = (c <= r) ? x[c] : 0.0;
-          cur[(o + r) * PP + c] = v;
-          sD[j * 256 + r * PB + c] = v;
-        }
-        sInv[o + r] = mine;
+      for (int e = 0; e < 5; ++e) {
+        double dv = sdd[e < 4 ? 4 * q + e : r];
+        dv = (dv > 0.0) ? dv : 1.0;
+        double rs = __builtin_amdgcn_rsq(dv);
+        rs = rs * (1.5 - 0.5 * dv * rs * rs);
+        rs = rs * (1.5 - 0.5 * dv * rs * rs);
+        if (e < 4) rsc[e] = rs; else rsr = rs;
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool low = 4 * q + e <= r;
+        double lv = low ? a[e] * rsc[e] : 0.0, xv = low ? w[e] * rsr : 0.0;
+        asm volatile("" : "+v"(lv), "+v"(xv));  // selects, not a branch around the stores
+        cur[(o + r) * PP + 4 * q + e] = lv;
+        sDv[r * PB + 4 * q + e] = xv;
+      }
+      __builtin_amdgcn_s_setprio(0);
+      PPROBE_ACC(5, tq0);
     }
+#ifndef PANEL_NO_DEFER
     if (j > 0) {  // (wave 0 owns no tile: all its slots are 99)
 #pragma unroll
-      for (int s = 0; s < NSLOT; ++s)
-        if (tk[s] > j && tk[s] != 99) {
-          int i = ti[s], k = tk[s];
-          asm volatile("" : "+s"(i), "+s"(k));  // keeps the 36 LDS row addresses from being hoisted out of the j loop (spills)
-          acc[s] = tile_update(acc[s], oth, i, k, fr, fk);
-        }
-    }
-    __syncthreads();
-    PPROBE_ACC(1, tq0);
-    // ---- phase B: rows below the block, x L_jj^T = a, one row per thread; the right-hand side is one more row
-    const long long tq1 = PPROBE_T0();
-    const int nrow = n - o - PB;
-    if (tid <= nrow) {
-      double* rowp = (tid < nrow) ? cur + (o + PB + tid) * PP : sRhs + o;
-      double a[PB];
-#pragma unroll
-      for (int c = 0; c < PB; ++c) a[c] = rowp[c];
-#pragma unroll
-      for (int k = 0; k < PB; ++k) {
-        a[k] *= sInv[o + k];
-#pragma unroll
-        for (int c = k + 1; c < PB; ++c) a[c] -= a[k] * cur[(o + c) * PP + k];
+      for (int s = 0; s < NSLOT; ++s) {
+        int pk = tik[s];
+        asm volatile("" : "+s"(pk));  // keeps the LDS row addresses of all slots from being hoisted out of the j loop (spills)
+        const int i = pk & 255, k = pk >> 8;
+        if (k > j && k != 99) acc[s] = tile_update(acc[s], oth, i, k, fr, fk);
       }
-#pragma unroll
-      for (int c = 0; c < PB; ++c) rowp[c] = a[c];
     }
-    __syncthreads();
+#endif
+    lds_barrier();
+    PPROBE_ACC(1, tq0);
+    // ---- phase B: X_ij = T_ij Dinv_j^T on the matrix core, tile rows dealt to waves 1..7; y_j = Dinv_j b_j on wave 0
+    const long long tq1 = PPROBE_T0();
+    if (wave == 0) {
+      if (lane < PB) {
+        double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+#pragma unroll
+        for (int k = 0; k < PB; k += 4) {
+          y0 += sDv[lane * PB + k] * sRhs[o + k]; y1 += sDv[lane * PB + k + 1] * sRhs[o + k + 1];
+          y2 += sDv[lane * PB + k + 2] * sRhs[o + k + 2]; y3 += sDv[lane * PB + k + 3] * sRhs[o + k + 3];
+        }
+        sRhs[o + lane] = (y0 + y1) + (y2 + y3);
+      }
+    } else {
+      for (int i = j + wave; i < nb; i += NTW) {
+        double* tp = cur + (PB * i + fr) * PP + 4 * fk;
+        const double* dp = sDv + fr * PB + 4 * fk;
+        const double a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3];
+        const double b0 = dp[0], b1 = dp[1], b2 = dp[2], b3 = dp[3];
+        v4f64 x = v4f64{0.0, 0.0, 0.0, 0.0};
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, x, 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) cur[(PB * i + fk + 4 * rg) * PP + fr] = x[rg];
+      }
+    }
+    lds_barrier();
     PPROBE_ACC(2, tq1);
     // ---- phase C: block column j+1 first (handed to the next step through LDS); L and y out; right-hand side update
     const long long tq2 = PPROBE_T0();
     {
 #pragma unroll
-      for (int s = 0; s < NSLOT; ++s)
-        if (tk[s] == j + 1) {
-          int i = ti[s], k = tk[s];
-          asm volatile("" : "+s"(i), "+s"(k));
+      for (int s = 0; s < NSLOT; ++s) {
+        int pk = tik[s];
+        asm volatile("" : "+s"(pk));
+        const int i = pk & 255, k = pk >> 8;
+        if (k == j + 1) {
           acc[s] = tile_update(acc[s], cur, i, k, fr, fk);
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) oth[(PB * i + fk + 4 * rg) * PP + fr] = acc[s][rg];
         }
+      }
     }
     {
+      const int nrow = n - o - PB;
       const int row = o + (tid >> 1), half = tid & 1;
       if (row < n) {
 #pragma unroll
@@ -211,35 +280,22 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
       }
       if (tid < nrow) {
         const int col = o + PB + tid;
-        double t = sRhs[col];
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
-        for (int c = 0; c < PB; ++c) t -= sRhs[o + c] * cur[col * PP + c];
-        sRhs[col] = t;
+        for (int c = 0; c < PB; c += 4) {
+          t0 += sRhs[o + c] * cur[col * PP + c]; t1 += sRhs[o + c + 1] * cur[col * PP + c + 1];
+          t2 += sRhs[o + c + 2] * cur[col * PP + c + 2]; t3 += sRhs[o + c + 3] * cur[col * PP + c + 3];
+        }
+        sRhs[col] -= (t0 + t1) + (t2 + t3);
       }
       if (yout != nullptr && tid >= 448 && tid < 448 + PB) yout[k0 + o + tid - 448] = sRhs[o + tid - 448];
+      if (tid < 256) Dinv_out[(size_t)(j >> 3) * kTile * kTile + (size_t)(j & 7) * 256 + tid] = sDv[tid];
     }
-    __syncthreads();
+    lds_barrier();
     PPROBE_ACC(3, tq2);
   }
-  // ---- inverses of the diagonal blocks, one column per thread (forward substitution on L e_c)
-  const long long tp1 = PPROBE_T0();
-  if (tid < PB * nb) {
-    const int j = tid >> 4, col = tid & 15, o = PB * j;
-    const double* Lb = sD + j * 256;
-    double xi[PB];
-#pragma unroll
-    for (int rr = 0; rr < PB; ++rr) {
-      double sum = 0.0;
-#pragma unroll
-      for (int k = 0; k < rr; ++k) sum += Lb[rr * PB + k] * xi[k];
-      xi[rr] = (rr == col) ? sInv[o + rr] : (rr > col ? -sum * sInv[o + rr] : 0.0);
-    }
-    double* dst = Dinv_out + (size_t)(j >> 3) * kTile * kTile + (size_t)(j & 7) * 256;
-#pragma unroll
-    for (int rr = 0; rr < PB; ++rr) dst[rr * PB + col] = xi[rr];
-  }
-  PPROBE_ACC(5, tp1);
   PPROBE_ACC(6, tp0);
+  PPROBE_FLUSH();
 }
 
 struct TrsmSubArgs {

@@ -81,6 +81,7 @@ struct DevProblem {
   double *Ad, *Ae;          // [K][81] speed-bias diagonal / sub-diagonal (pos, pos-1) blocks, by position
   double *Bp, *Bs, *Bn;     // [K][54] speed-bias(pos) x pose(pos-1 | pos | pos+1) blocks (9x6)
   double *Ldinv, *Lsub;       // [K][81] block-bidiagonal Cholesky factor of the speed-bias part: L_kk^-1 and L_{k,k-1}
+  double *Zfwd, *Nback;       // [K][90] operands of the forward / backward chain sweeps, per position a 9x9 matrix | a 9-vector (k_sb_sweep, k_struct.hip)
   double *Mblk, *GI;          // [K][81] propagator M_pos = -Ldinv_pos Lsub_pos | I + Gramian of everything below pos (k_struct.hip)
   double* Y;       // Y = L_A^-1 B, stored PER CHAIN: chain c is a [9 Kc][Yld_c] row-major block at Y + Yoff[c] (speed-bias rows of
                    // the chain x its own pose columns; zero above the trapezoid). A chain couples to its own poses only, so
@@ -195,7 +196,8 @@ struct PgoPlan;
 void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax, PgoPlan* pgo = nullptr);
 // speed-bias chain factorisation on the auxiliary stream as soon as the IMU blocks are final (overlaps the landmark pass)
 void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& ax);
-void launch_zero_system(const DevProblem& P, hipStream_t st);
+void launch_zero_system(const DevProblem& P, hipStream_t st);       // every small per-iteration buffer, one launch
+void launch_zero_pose_system(const DevProblem& P, hipStream_t st);  // arrow buffers / dense pose matrix
 // per-context resources of the dense factorisation: auxiliary stream for the look-ahead, ordering events, and
 // (profiling only) one timed event pair around every bulk trailing-update launch
 struct CholAux {

@@ -144,25 +144,34 @@ void launch_finalize_diag(const DevProblem& P, double mu, int which, hipStream_t
   const int cnt = P.n > P.npad ? P.n : P.npad;
   hipLaunchKernelGGL(k_finalize_diag, dim3((cnt + 255) / 256), dim3(256), 0, st, P, mu, which);
 }
+// One launch clears every small per-iteration buffer: sixteen hipMemsetAsync calls were ~80 us of dispatch latency at the
+// head of every linearisation (each fill kernel runs ~5 us whatever its size).
+struct ZeroList { double* p[16]; size_t n[16]; };
+__global__ __launch_bounds__(256) void k_zero_many(ZeroList z) {
+  double* p = z.p[blockIdx.y];
+  const size_t n = z.n[blockIdx.y];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.0;
+}
 void launch_zero_system(const DevProblem& P, hipStream_t st) {
+  ZeroList z; int m = 0;
+  auto add = [&](double* p, size_t n) { if (p != nullptr && n > 0) { z.p[m] = p; z.n[m] = n; ++m; } };
+  add(P.bred, (size_t)P.n);
+  if (P.vi) {
+    add(P.Ad, (size_t)81 * P.K); add(P.Ae, (size_t)81 * P.K);
+    add(P.Bp, (size_t)54 * P.K); add(P.Bs, (size_t)54 * P.K); add(P.Bn, (size_t)54 * P.K);
+    add(P.imuAd, (size_t)2 * 81 * P.K); add(P.imuBs, (size_t)2 * 54 * P.K); add(P.imuCd, (size_t)3 * 36 * P.K); add(P.imuG, (size_t)2 * 30 * P.K);
+  }
+  add(P.grad, (size_t)P.N); add(P.hdiag, (size_t)P.N);
+  add(P.part + (size_t)SC_COST * P.part_n, (size_t)P.part_n);
+  for (int i = m; i < 16; ++i) { z.p[i] = nullptr; z.n[i] = 0; }
+  hipLaunchKernelGGL(k_zero_many, dim3(128, m), dim3(256), 0, st, z);
+  hipMemsetAsync(P.flag, 0, sizeof(int), st);
+}
+// the pose-pose system (arrow buffers or the dense matrix): the big fill, issued AFTER the inertial kernels so that the serial
+// speed-bias chain factorisation (auxiliary stream) starts that much earlier
+void launch_zero_pose_system(const DevProblem& P, hipStream_t st) {
   if (P.arrow) launch_arrow_zero(P, st);
   else hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), st);
-  hipMemsetAsync(P.bred, 0, (size_t)P.n * sizeof(double), st);
-  if (P.vi) {
-    hipMemsetAsync(P.Ad, 0, (size_t)81 * P.K * sizeof(double), st);
-    hipMemsetAsync(P.Ae, 0, (size_t)81 * P.K * sizeof(double), st);
-    hipMemsetAsync(P.Bp, 0, (size_t)54 * P.K * sizeof(double), st);
-    hipMemsetAsync(P.Bs, 0, (size_t)54 * P.K * sizeof(double), st);
-    hipMemsetAsync(P.Bn, 0, (size_t)54 * P.K * sizeof(double), st);
-    hipMemsetAsync(P.imuAd, 0, (size_t)2 * 81 * P.K * sizeof(double), st);
-    hipMemsetAsync(P.imuBs, 0, (size_t)2 * 54 * P.K * sizeof(double), st);
-    hipMemsetAsync(P.imuCd, 0, (size_t)3 * 36 * P.K * sizeof(double), st);
-    hipMemsetAsync(P.imuG, 0, (size_t)2 * 30 * P.K * sizeof(double), st);
-  }
-  hipMemsetAsync(P.grad, 0, (size_t)P.N * sizeof(double), st);
-  hipMemsetAsync(P.hdiag, 0, (size_t)P.N * sizeof(double), st);
-  launch_part_clear(P, SC_COST, 1, st);
-  hipMemsetAsync(P.flag, 0, sizeof(int), st);
 }
 void launch_part_clear(const DevProblem& P, int slot0, int nslots, hipStream_t st) {
   hipMemsetAsync(P.part + (size_t)slot0 * P.part_n, 0, (size_t)nslots * P.part_n * sizeof(double), st);

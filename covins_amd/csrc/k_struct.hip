@@ -53,140 +53,247 @@ COV_DEV double rdlane64(double v, int srclane) {  // broadcast from a wave-unifo
 // One 64-lane workgroup (a single wave) per chain: the sequential part only — block-bidiagonal Cholesky of the
 // speed-bias system and z = L_A^-1 b_s. Per keyframe: 9x9 Cholesky in registers (row per lane, v_readlane
 // broadcasts), inverse by columns from LDS, next blocks prefetched from HBM one step ahead.
+// Single-wave workgroups: LDS operations of one wave execute in order, so ordering LDS traffic needs no s_barrier — and
+// above all not __syncthreads(), whose s_waitcnt vmcnt(0) also waits for every outstanding GLOBAL store to be acknowledged
+// (~1.5 us per chain step here: the factor blocks stream out while the recurrence goes on, nobody reads them back).
+COV_DEV void wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 constexpr int kCfChunk = 8;                     // positions staged per LDS buffer
-constexpr int kCfBlk = 81 + 81 + 9;             // Ad_pos | Ae_{pos+1} | b_s,pos
-constexpr int kCfPerLane = (kCfChunk * kCfBlk + 63) / 64;
+constexpr int kCfPerLane = (kCfChunk * 81 + 63) / 64;
+// One wave per IMU chain, sequential over keyframes — the block-bidiagonal Cholesky factor only (z = L_A^-1 b_s is a LINEAR
+// recurrence and runs separately, k_sb_sweep). Per position:
+//   S  = Ad - W W^T          (W = Lsub_pos; lower triangle only: 45 entries, one per lane)
+//   L  = chol(S), X = L^-1   in ONE sweep: lanes 0..8 hold the rows of S, lanes 16..24 the columns of an identity; every
+//                            pivot scales register c by 1/sqrt(d) and subtracts x[c] * L[cc][c] (broadcast from lane cc by
+//                            v_readlane) from register cc — for the first group that is the right-looking Cholesky, for
+//                            the second the column-oriented forward substitution L X = I with the very same multipliers:
+//                            the inverse costs no instruction of its own
+//   W' = Ae_{pos+1} X^T      (81 entries, two rounds)
+// Inputs are staged a chunk ahead as plain strided copies of contiguous ranges, results leave through LDS with one coalesced
+// store per chunk (a gather with per-element index arithmetic, and four global stores per step, cost more instructions than
+// the recurrence itself: 3.2 us per position before, measured alone).
 __global__ __launch_bounds__(64) void k_sb_chain_factor(DevProblem P) {
-  __shared__ double sM[81], sX[81], sSub[81];
-  __shared__ double sz[9], sv[9];
-  __shared__ double sIn[2][kCfChunk][kCfBlk];   // operands, staged kCfChunk positions ahead by all 64 lanes
+  __shared__ __attribute__((aligned(16))) double sW[9 * 10], sS[9 * 10], sX[9 * 10];   // pitch 10: rows are 16-byte aligned
+  __shared__ double sAd[2][kCfChunk * 81], sAe[2][kCfChunk * 81];
+  __shared__ double sOutL[kCfChunk * 81], sOutS[kCfChunk * 81];
   const int lane = threadIdx.x;
   const int p0 = P.chain_ptr[blockIdx.x], p1 = P.chain_ptr[blockIdx.x + 1];
-  const int e0 = lane, e1 = lane + 64;  // the two matrix entries this lane owns (e1 valid for lanes < 17)
-  const bool has1 = e1 < 81;
-  for (int e = lane; e < 81; e += 64) sSub[e] = 0.0;
-  if (lane < 9) sz[lane] = 0.0;
-  // Operand loads one step ahead ran at HBM latency under the landmark pass's traffic (5.4 us per step); the next
-  // chunk's loads are now in flight during a whole chunk of steps.
   const int nchunk = (p1 - p0 + kCfChunk - 1) / kCfChunk;
-  double stage[kCfPerLane];
+  // lower-triangle entry of this lane: (ta, tb), tb <= ta (lanes >= 45 idle in that phase)
+  int ta = 0, tb = 0;
+  { int t = lane < 45 ? lane : 44; while (t > ta) { t -= ta + 1; ++ta; } tb = t; }
+  const int e0 = lane, e1 = lane + 64;
+  const int a0 = e0 / 9, b0 = e0 - 9 * a0, a1 = (e1 < 81 ? e1 : 80) / 9, b1 = (e1 < 81 ? e1 : 80) - 9 * a1;
+  for (int e = lane; e < 90; e += 64) { sW[e] = 0.0; sX[e] = 0.0; sS[e] = 0.0; }
+  double stA[kCfPerLane], stE[kCfPerLane];
   auto gload = [&](int c) {
-    const int base = p0 + c * kCfChunk;
+    const int base = p0 + c * kCfChunk, len = min(kCfChunk, p1 - base);
+    const double* srcA = P.Ad + (size_t)81 * base;
+    const double* srcE = P.Ae + (size_t)81 * (base + 1);     // Ae of the NEXT position; none behind the chain's last
+    const int cntA = 81 * len, cntE = 81 * min(len, p1 - base - 1);
 #pragma unroll
     for (int i = 0; i < kCfPerLane; ++i) {
-      const int idx = lane + 64 * i, q = idx / kCfBlk, e = idx - kCfBlk * q, pos = base + q;
-      double v = 0.0;
-      if (q < kCfChunk && pos < p1) {
-        if (e < 81) v = P.Ad[(size_t)81 * pos + e];
-        else if (e < 162) v = (pos + 1 < p1) ? P.Ae[(size_t)81 * (pos + 1) + e - 81] : 0.0;
-        else v = P.xs[(size_t)9 * pos + e - 162];
-      }
-      stage[i] = v;
+      const int idx = lane + 64 * i;
+      stA[i] = (idx < cntA) ? srcA[idx] : 0.0;
+      stE[i] = (idx < cntE) ? srcE[idx] : 0.0;
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < kCfPerLane; ++i) {
-      const int idx = lane + 64 * i, q = idx / kCfBlk, e = idx - kCfBlk * q;
-      if (q < kCfChunk) sIn[buf][q][e] = stage[i];
+      const int idx = lane + 64 * i;
+      if (idx < kCfChunk * 81) { sAd[buf][idx] = stA[i]; sAe[buf][idx] = stE[i]; }
     }
   };
+  bool bad = false;
   gload(0);
   for (int c = 0; c < nchunk; ++c) {
     lstore(c & 1);
     if (c + 1 < nchunk) gload(c + 1);
-    __syncthreads();
+    wave_sync();
     const int base = p0 + c * kCfChunk, len = min(kCfChunk, p1 - base);
     for (int q = 0; q < len; ++q) {
-    const int pos = base + q;
-    const double* in = sIn[c & 1][q];
-    const double* sAe = in + 81;
-    const double ad0 = in[e0], ad1 = has1 ? in[e1] : 0.0;
-    const double bs = (lane < 9) ? in[162 + lane] : 0.0;
-    // M = Ad - Lsub Lsub^T
-    {
-      const int a = e0 / 9, b = e0 - 9 * a;
-      double m = ad0;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) m -= sSub[9 * a + k] * sSub[9 * b + k];
-      sM[e0] = m;
-      if (has1) {
-        const int a1 = e1 / 9, b1 = e1 - 9 * a1;
-        double m1 = ad1;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) m1 -= sSub[9 * a1 + k] * sSub[9 * b1 + k];
-        sM[e1] = m1;
-      }
-    }
-    __syncthreads();
-    // lower Cholesky, row r = lane (lanes >= 9 carry zeros); then X = L^-1 column by column, still in registers:
-    // lane c solves L x = e_c with the entries of L broadcast by v_readlane and the reciprocal pivots the Cholesky
-    // already has (no divisions, no LDS round trip between the two phases)
-    {
-      const int r = lane < 9 ? lane : 8;
-      double x[9], invd[9];
-#pragma unroll
-      for (int c2 = 0; c2 < 9; ++c2) x[c2] = (lane < 9 && c2 <= r) ? sM[9 * r + c2] : 0.0;
-      bool bad = false;
-#pragma unroll
-      for (int c2 = 0; c2 < 9; ++c2) {
-        double d = rdlane64(x[c2], c2);
-        if (!(d > 0.0)) { bad = true; d = 1.0; }
-        const double inv = rsqrt(d);
-        invd[c2] = inv;  // wave-uniform
-        x[c2] = (lane == c2) ? d * inv : x[c2] * inv;
-#pragma unroll
-        for (int cc = c2 + 1; cc < 9; ++cc) x[cc] -= x[c2] * rdlane64(x[c2], cc);  // garbage above the diagonal is never read
-      }
-      if (bad && lane == 0) atomicOr(P.flag, 1);
-      double xi[9];  // column `lane` of X
-#pragma unroll
-      for (int rr = 0; rr < 9; ++rr) {
-        double sum = 0.0;
-#pragma unroll
-        for (int k = 0; k < rr; ++k) sum += rdlane64(x[k], rr) * xi[k];  // L[rr][k]; xi[k] is 0 for k < lane
-        xi[rr] = (rr == lane) ? invd[rr] : (rr > lane ? -sum * invd[rr] : 0.0);
-      }
-      __syncthreads();  // everyone has read sM
-      if (lane < 9) {
-#pragma unroll
-        for (int c2 = 0; c2 < 9; ++c2) sM[9 * lane + c2] = (c2 <= lane) ? x[c2] : 0.0;
-#pragma unroll
-        for (int rr = 0; rr < 9; ++rr) sX[9 * rr + lane] = xi[rr];
-        double v = bs;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) v -= sSub[9 * lane + k] * sz[k];
-        sv[lane] = v;
-      }
-    }
-    __syncthreads();
-    // publish the factor blocks, z, and the next sub-diagonal block L_{pos+1,pos} = Ae_{pos+1} L_kk^-T
-    P.Ldinv[(size_t)81 * pos + e0] = sX[e0]; P.Lsub[(size_t)81 * pos + e0] = sSub[e0];  // (L_kk itself is needed only through its inverse)
-    if (has1) { P.Ldinv[(size_t)81 * pos + e1] = sX[e1]; P.Lsub[(size_t)81 * pos + e1] = sSub[e1]; }
-    double znew = 0.0;
-    if (lane < 9) {
-      for (int k = 0; k <= lane; ++k) znew += sX[9 * lane + k] * sv[k];
-      P.zs[(size_t)9 * pos + lane] = znew;
-    }
-    double nx0 = 0.0, nx1 = 0.0;
-    if (pos + 1 < p1) {
+      const double* Ad = sAd[c & 1] + 81 * q;
+      const double* Ae = sAe[c & 1] + 81 * q;
+      // ---- S = Ad - W W^T, lower triangle
       {
-        const int a = e0 / 9, b = e0 - 9 * a;
+        const double* wa = sW + 10 * ta;
+        const double* wb = sW + 10 * tb;
+        double m0 = Ad[9 * ta + tb], m1 = 0.0, m2 = 0.0;
 #pragma unroll
-        for (int c2 = 0; c2 < 9; ++c2) nx0 += sAe[9 * a + c2] * sX[9 * b + c2];
+        for (int k = 0; k < 9; k += 3) { m0 -= wa[k] * wb[k]; m1 -= wa[k + 1] * wb[k + 1]; m2 -= wa[k + 2] * wb[k + 2]; }
+        if (lane < 45) sS[10 * ta + tb] = (m0 + m1) + m2;
+        // Lsub_pos leaves now (it is overwritten below)
+        sOutS[81 * q + e0] = sW[10 * a0 + b0];
+        if (e1 < 81) sOutS[81 * q + e1] = sW[10 * a1 + b1];
       }
-      if (has1) {
-        const int a = e1 / 9, b = e1 - 9 * a;
+      wave_sync();
+      // ---- Cholesky and inverse in one sweep
+      {
+        const int g = lane >> 4, r = lane & 15;
+        double x[9];
 #pragma unroll
-        for (int c2 = 0; c2 < 9; ++c2) nx1 += sAe[9 * a + c2] * sX[9 * b + c2];
+        for (int k = 0; k < 9; ++k) {
+          const double sv = sS[10 * (r < 9 ? r : 8) + k];
+          x[k] = (g == 0) ? ((r < 9 && k <= r) ? sv : 0.0) : ((g == 1 && k == r) ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          double d = rdlane64(x[k], k);
+          if (!(d > 0.0)) { bad = true; d = 1.0; }
+          double rs = __builtin_amdgcn_rsq(d);
+          rs = rs * (1.5 - 0.5 * d * rs * rs);
+          rs = rs * (1.5 - 0.5 * d * rs * rs);
+          x[k] *= rs;  // (lane k of the first group holds d itself: d * rs = sqrt(d))
+#pragma unroll
+          for (int cc = k + 1; cc < 9; ++cc) x[cc] -= x[k] * rdlane64(x[k], cc);
+        }
+        if (g == 1 && r < 9) {  // column r of X = L^-1: X[k][r] = x[k] (zero above the diagonal)
+#pragma unroll
+          for (int k = 0; k < 9; ++k) { sX[10 * k + r] = x[k]; sOutL[81 * q + 9 * k + r] = x[k]; }
+        }
       }
+      wave_sync();
+      // ---- W' = Ae_{pos+1} X^T (zero behind the chain's last position: Ae staged as zeros)
+      {
+        const double* xa = sX + 10 * b0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; k += 3) { s0 += Ae[9 * a0 + k] * xa[k]; s1 += Ae[9 * a0 + k + 1] * xa[k + 1]; s2 += Ae[9 * a0 + k + 2] * xa[k + 2]; }
+        const double w0 = (s0 + s1) + s2;
+        double w1 = 0.0;
+        if (e1 < 81) {
+          const double* xb = sX + 10 * b1;
+          double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 9; k += 3) { t0 += Ae[9 * a1 + k] * xb[k]; t1 += Ae[9 * a1 + k + 1] * xb[k + 1]; t2 += Ae[9 * a1 + k + 2] * xb[k + 2]; }
+          w1 = (t0 + t1) + t2;
+        }
+        wave_sync();  // every lane has read sW (above) and sX before they change
+        sW[10 * a0 + b0] = w0;
+        if (e1 < 81) sW[10 * a1 + b1] = w1;
+      }
+      wave_sync();
     }
-    __syncthreads();  // sSub, sz, sv are free: every lane has finished reading them
-    sSub[e0] = nx0;
-    if (has1) sSub[e1] = nx1;
-    if (lane < 9) sz[lane] = znew;
-    __syncthreads();
+    // ---- results of the chunk: contiguous ranges of Ldinv and Lsub
+    for (int e = lane; e < 81 * len; e += 64) {
+      P.Ldinv[(size_t)81 * base + e] = sOutL[e];
+      P.Lsub[(size_t)81 * base + e] = sOutS[e];
     }
+    wave_sync();
+  }
+  if (bad && lane == 0) atomicOr(P.flag, 1);
+}
+
+// ---- linear recurrences along a chain as ONE 9x9 matrix-vector product per step -------------------------------------
+//   DIR = +1  z_pos = f_pos - T_pos z_{pos-1},  T_pos = Ldinv_pos Lsub_pos, f_pos = Ldinv_pos b_pos          (z = L_A^-1 b_s)
+//   DIR = -1  x_pos = v_pos - N_pos^T x_{pos+1}, N_pos = Lsub_{pos+1} Ldinv_pos, v_pos = Ldinv_pos^T u_pos   (x_s = L_A^-T u)
+// T / N depend on the factor only (k_sb_sweep_mat, auxiliary stream), f / v are parallel products (k_sb_sweep_vec). The
+// operands of a position are 90 consecutive doubles [9x9 matrix, row i = the coefficients of output i | 9-vector], so a
+// chunk of positions is one contiguous range and its staging a plain strided copy. The two-product form it replaces
+// (k_sb_backsolve) took 0.58 us per position, this one 0.21 (tools/chain_probe.hip).
+constexpr int kBkChunk = 16;      // positions staged per LDS buffer
+constexpr int kBkBlk = 90;        // per position: matrix 81 | vector 9
+constexpr int kBkPerLane = (kBkChunk * kBkBlk + 63) / 64;
+__global__ __launch_bounds__(256) void k_sb_sweep_mat(DevProblem P) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= 81 * P.K) return;
+  const int pos = q / 81, e = q - 81 * pos, i = e / 9, k = e - 9 * i;
+  {  // forward: T[i][k] = sum_{c <= i} Ldinv_pos[i][c] Lsub_pos[c][k]
+    const double* A = P.Ldinv + (size_t)81 * pos + 9 * i;
+    const double* B = P.Lsub + (size_t)81 * pos + k;
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s += (c <= i) ? A[c] * B[9 * c] : 0.0;
+    P.Zfwd[(size_t)kBkBlk * pos + e] = s;
+  }
+  {  // backward: N^T[i][k] = N[k][i] = sum_{c >= i} Lsub_{pos+1}[k][c] Ldinv_pos[c][i]
+    double s = 0.0;
+    if (pos + 1 < P.pos_chain_end[pos]) {
+      const double* A = P.Lsub + (size_t)81 * (pos + 1) + 9 * k;
+      const double* B = P.Ldinv + (size_t)81 * pos + i;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) s += (c >= i) ? A[c] * B[9 * c] : 0.0;
+    }
+    P.Nback[(size_t)kBkBlk * pos + e] = s;
+  }
+}
+template <int DIR>
+__global__ __launch_bounds__(256) void k_sb_sweep_vec(DevProblem P) {  // DIR +1: f = Ldinv b_s (b_s in xs) -> Zfwd | -1: v = Ldinv^T u (u in xs) -> Nback
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= 9 * P.K) return;
+  const int pos = q / 9, i = q - 9 * pos;
+  const double* L = P.Ldinv + (size_t)81 * pos;
+  const double* u = P.xs + (size_t)9 * pos;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s += (DIR > 0) ? ((k <= i) ? L[9 * i + k] * u[k] : 0.0) : ((k >= i) ? L[9 * k + i] * u[k] : 0.0);
+  (DIR > 0 ? P.Zfwd : P.Nback)[(size_t)kBkBlk * pos + 81 + i] = s;
+}
+template <int DIR>
+__global__ __launch_bounds__(64) void k_sb_sweep(DevProblem P) {
+  __shared__ double sblk[2][kBkChunk * kBkBlk];
+  __shared__ double sOut[kBkChunk * 9];
+  const int tid = threadIdx.x;
+  const int lane = tid < 9 ? tid : 8;
+  const int p0 = P.chain_ptr[blockIdx.x], p1 = P.chain_ptr[blockIdx.x + 1];
+  const int nchunk = (p1 - p0 + kBkChunk - 1) / kBkChunk;
+  const double* arr = DIR > 0 ? P.Zfwd : P.Nback;
+  double* out = DIR > 0 ? P.zs : P.xs;
+  // chunk c: DIR +1 positions [p0 + c C, ...), DIR -1 positions [max(p1 - (c+1) C, p0), p1 - c C); slot q = pos - base
+  auto cbase = [&](int c) { return DIR > 0 ? p0 + c * kBkChunk : max(p1 - (c + 1) * kBkChunk, p0); };
+  auto clen = [&](int c) { return DIR > 0 ? min(kBkChunk, p1 - (p0 + c * kBkChunk)) : p1 - c * kBkChunk - max(p1 - (c + 1) * kBkChunk, p0); };
+  double stage[kBkPerLane];
+  auto gload = [&](int c) {
+    const int cnt = clen(c) * kBkBlk;
+    const double* src = arr + (size_t)kBkBlk * cbase(c);
+#pragma unroll
+    for (int i = 0; i < kBkPerLane; ++i) { const int idx = tid + 64 * i; stage[i] = (idx < cnt) ? src[idx] : 0.0; }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < kBkPerLane; ++i) { const int idx = tid + 64 * i; if (idx < kBkChunk * kBkBlk) sblk[buf][idx] = stage[i]; }
+  };
+  double x = 0.0;
+  gload(0);
+  for (int c = 0; c < nchunk; ++c) {
+    lstore(c & 1);
+    if (c + 1 < nchunk) gload(c + 1);
+    wave_sync();
+    const int base = cbase(c), len = clen(c);
+    const int qfirst = DIR > 0 ? 0 : len - 1;
+    double row[9], v;  // operands of the CURRENT step, fetched one step ahead of the dependent chain
+    {
+      const double* L = sblk[c & 1] + kBkBlk * qfirst;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) row[k] = L[9 * lane + k];
+      v = L[81 + lane];
+    }
+    for (int s = 0; s < len; ++s) {
+      const int q = DIR > 0 ? s : len - 1 - s;
+      const int qn = (s + 1 < len) ? q + DIR : q;
+      double nrow[9], nv;
+      const double* Ln = sblk[c & 1] + kBkBlk * qn;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) nrow[k] = Ln[9 * lane + k];
+      nv = Ln[81 + lane];
+      double b[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) b[k] = rdlane64(x, k);  // all nine broadcasts first, then three short accumulation chains
+      const double s0 = fma(row[0], b[0], fma(row[3], b[3], row[6] * b[6]));
+      const double s1 = fma(row[1], b[1], fma(row[4], b[4], row[7] * b[7]));
+      const double s2 = fma(row[2], b[2], fma(row[5], b[5], row[8] * b[8]));
+      x = v - ((s0 + s1) + s2);
+      if (tid < 9) sOut[9 * q + tid] = x;  // (results leave through LDS, one coalesced store per chunk)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) row[k] = nrow[k];
+      v = nv;
+    }
+    wave_sync();
+    for (int e = tid; e < 9 * len; e += 64) out[(size_t)9 * base + e] = sOut[e];
+    wave_sync();
   }
 }
 
@@ -442,7 +549,7 @@ __global__ __launch_bounds__(64) void k_sb_backsolve(DevProblem P, int do_forwar
   for (int c = 0; do_forward && c < nchunk; ++c) {
     lstore(c & 1);
     if (c + 1 < nchunk) gload(c + 1, +1);
-    __syncthreads();
+    wave_sync();
     const int base = chunk_base(c, +1), len = chunk_len(c, +1);
     double wv[kSbChunk];
 #pragma unroll
@@ -464,12 +571,12 @@ __global__ __launch_bounds__(64) void k_sb_backsolve(DevProblem P, int do_forwar
   // ---- backward: x_pos = Linv^T (u_pos - Lsub_{pos+1}^T x_{pos+1}); needs Lsub of the position ABOVE, so a chunk
   //      keeps the previous chunk's buffer alive for its first step (double buffering does that for free)
   prev = 0.0;
-  __syncthreads();
+  __syncthreads();  // (full barrier once: the backward sweep re-reads xs entries the forward sweep stored)
   gload(0, -1);
   for (int c = 0; c < nchunk; ++c) {
     lstore(c & 1);
     if (c + 1 < nchunk) gload(c + 1, -1);
-    __syncthreads();
+    wave_sync();
     const int base = chunk_base(c, -1), len = chunk_len(c, -1);
     double uv[kSbChunk];
 #pragma unroll
@@ -495,6 +602,12 @@ __global__ __launch_bounds__(64) void k_sb_backsolve(DevProblem P, int do_forwar
   }
 }
 
+// right behind the chain factorisation: sweep matrices, f = Ldinv b_s, then z by the forward sweep (xs still holds b_s)
+static void launch_sb_after_factor(const DevProblem& P, hipStream_t st) {
+  hipLaunchKernelGGL(k_sb_sweep_mat, dim3((81 * P.K + 255) / 256), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(k_sb_sweep_vec<1>, dim3((9 * P.K + 255) / 256), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(k_sb_sweep<1>, dim3(P.nchains), dim3(64), 0, st, P);
+}
 void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& ax) {
   if (!P.vi) return;
   ax.init();
@@ -503,8 +616,10 @@ void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& 
   (void)hipStreamWaitEvent(ax.aux, ax.ev_sb, 0);
   hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, ax.aux, P);
   (void)hipEventRecord(ax.ev_cf, ax.aux);
-  // the Gramians need the factor only: they follow on the auxiliary stream, underneath k_sb_chain_cols
+  // z = L_A^-1 b_s (a linear recurrence, k_sb_sweep) and the Gramians need the factor only: they follow on the auxiliary
+  // stream, underneath k_sb_chain_cols
   hipLaunchKernelGGL(k_sb_propagator, dim3((81 * P.K + 255) / 256), dim3(256), 0, ax.aux, P);
+  launch_sb_after_factor(P, ax.aux);
   hipLaunchKernelGGL(k_sb_gram, dim3(P.nchains), dim3(128), 0, ax.aux, P);
   (void)hipEventRecord(ax.ev_g, ax.aux);
   ax.cf_pending = true;
@@ -518,12 +633,13 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
     if (early) { (void)hipStreamWaitEvent(st, ax.ev_cf, 0); ax.cf_pending = false; }
     else hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, st, P);
     hipLaunchKernelGGL(k_sb_chain_cols, dim3(P.cc_n), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(k_pose_rhs, dim3((8 * 6 * P.K + 255) / 256), dim3(256), 0, st, P);
-    if (early) (void)hipStreamWaitEvent(st, ax.ev_g, 0);
+    if (early) (void)hipStreamWaitEvent(st, ax.ev_g, 0);  // z (forward sweep) and the Gramians, both long done by now
     else {
       hipLaunchKernelGGL(k_sb_propagator, dim3((81 * P.K + 255) / 256), dim3(256), 0, st, P);
+      launch_sb_after_factor(P, st);
       hipLaunchKernelGGL(k_sb_gram, dim3(P.nchains), dim3(128), 0, st, P);
     }
+    hipLaunchKernelGGL(k_pose_rhs, dim3((8 * 6 * P.K + 255) / 256), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_yty_semisep, dim3(P.K), dim3(256), 0, st, P);
   }
   if (pgo != nullptr) launch_pgo_block_solve(P, *pgo, st, ax);  // pose graph: block-arrow elimination (k_pgo.hip)
@@ -536,7 +652,12 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
       hipLaunchKernelGGL(k_sb_backsolve, dim3(P.nchains), dim3(64), 0, st, P, 1);
     } else {
       hipLaunchKernelGGL(k_sb_fwd_matvec, dim3((9 * P.K + 3) / 4), dim3(256), 0, st, P);
-      hipLaunchKernelGGL(k_sb_backsolve, dim3(P.nchains), dim3(64), 0, st, P, 0);
+      static const bool two_products = [] { const char* e = getenv("COVGPU_SB_BACK"); return e && e[0] == '0'; }();  // 0: round-2a backward sweep
+      if (two_products) hipLaunchKernelGGL(k_sb_backsolve, dim3(P.nchains), dim3(64), 0, st, P, 0);
+      else {
+        hipLaunchKernelGGL(k_sb_sweep_vec<-1>, dim3((9 * P.K + 255) / 256), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(k_sb_sweep<-1>, dim3(P.nchains), dim3(64), 0, st, P);
+      }
     }
   }
   hipLaunchKernelGGL(k_scatter_solution, dim3((P.n + 255) / 256), dim3(256), 0, st, P, dst);

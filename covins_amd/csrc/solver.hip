@@ -529,6 +529,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_alloc(c, &P.Bp, 54 * Kv)); RC(dev_alloc(c, &P.Bs, 54 * Kv)); RC(dev_alloc(c, &P.Bn, 54 * Kv));
   RC(dev_alloc(c, &P.Ldinv, 81 * Kv)); RC(dev_alloc(c, &P.Lsub, 81 * Kv));
   RC(dev_alloc(c, &P.Mblk, 81 * Kv)); RC(dev_alloc(c, &P.GI, 81 * Kv));
+  RC(dev_alloc(c, &P.Nback, 90 * Kv)); RC(dev_alloc(c, &P.Zfwd, 90 * Kv));
   RC(dev_alloc(c, &P.zs, 9 * Kv)); RC(dev_alloc(c, &P.xs, 9 * Kv));
   {  // Y per chain (common.hpp): [9 Kc][roundup(6 Kc, 16)] blocks back to back
     std::vector<size_t> yoff(P.nchains);
@@ -742,6 +743,7 @@ static void enqueue_build(covgpu_context* c, double mu) {
     launch_finalize_diag(P, mu, 1, c->st);
     launch_sb_chain_factor_early(P, c->st, c->chol);
   }
+  launch_zero_pose_system(P, c->st);
   launch_lm_build(P, mu, c->st);
   launch_imu_gather(P, 0, c->st);  // pose-dimension part: adds onto the blocks k_kf_reduce assigned (fixed order: visual, inertial, loop)
   launch_edge_build(P, c->st);

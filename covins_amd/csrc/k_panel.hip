@@ -311,7 +311,7 @@ struct TrsmSubArgs {
 // X = A L^-T on a 16-row slab, L = the (16 NB)-order factor at (k0, k0). One wave, everything in registers.
 // acc[i][reg] at lane (n = lane & 15, fk = lane >> 4) holds Z[16 i + 4 fk + reg][n] = X[row0 + n][k0 + 16 i + 4 fk + reg].
 template <int NB>
-__global__ __launch_bounds__(64) void k_trsm_sub(TrsmSubArgs g) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trsm_sub(TrsmSubArgs g) {
   const int batch = blockIdx.y, lane = threadIdx.x, n = lane & 15, fk = lane >> 4;
   const int row0 = g.r0 + PB * (int)blockIdx.x;
   if (g.live != nullptr) {
@@ -331,26 +331,33 @@ __global__ __launch_bounds__(64) void k_trsm_sub(TrsmSubArgs g) {
   v4f64 acc[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) acc[i] = *reinterpret_cast<const v4f64*>(Arow + PB * i);
-  v4f64 lbuf[2][NB], dbuf[2];
-  dbuf[0] = Dblk(0);
+  // The L tiles stream through a small ring of registers, fetched RING-1 tiles ahead of their use across block-column
+  // boundaries (every index below is a compile-time constant once the loops are unrolled). With a whole block column
+  // double-buffered the kernel needed 416 VGPRs: a wave then only starts on a SIMD that is EMPTY, and on the serial
+  // chain it queued behind the bulk update's workgroups (18 us alone, 52 us average in the run). ~200 fit beside one.
+  constexpr int RING = 5;
+  v4f64 ring[RING], dcur = Dblk(0), dnxt = dcur;
+  int pi = 1, pj = 0, pt = 0;  // prefetch cursor: next tile (pi, pj) to fetch goes to ring[pt % RING]
 #pragma unroll
-  for (int i = 1; i < NB; ++i) lbuf[0][i] = Ltile(i, 0);
+  for (int k = 0; k < RING - 1; ++k)
+    if (pj < NB - 1) { ring[pt % RING] = Ltile(pi, pj); ++pt; if (++pi >= NB) { ++pj; pi = pj + 1; } }
+  int t = 0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    if (j + 1 < NB) {  // operands of the next block column: in flight during this one
-      dbuf[(j + 1) & 1] = Dblk(j + 1);
-#pragma unroll
-      for (int i = j + 2; i < NB; ++i) lbuf[(j + 1) & 1][i] = Ltile(i, j + 1);
-    }
+    if (j + 1 < NB) dnxt = Dblk(j + 1);
     v4f64 Z = v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(dbuf[j & 1][s], acc[j][s], Z, 0, 0, 0);
+    for (int s = 0; s < 4; ++s) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(dcur[s], acc[j][s], Z, 0, 0, 0);
     acc[j] = Z;
     const v4f64 Zn = -Z;
 #pragma unroll
-    for (int i = j + 1; i < NB; ++i)
+    for (int i = j + 1; i < NB; ++i) {
+      if (pj < NB - 1) { ring[pt % RING] = Ltile(pi, pj); ++pt; if (++pi >= NB) { ++pj; pi = pj + 1; } }
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(lbuf[j & 1][i][s], Zn[s], acc[i], 0, 0, 0);
+      for (int s = 0; s < 4; ++s) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[t % RING][s], Zn[s], acc[i], 0, 0, 0);
+      ++t;
+    }
+    dcur = dnxt;
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i) *reinterpret_cast<v4f64*>(Arow + PB * i) = acc[i];

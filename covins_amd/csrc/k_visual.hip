@@ -229,15 +229,33 @@ __global__ __launch_bounds__(256) void k_cost_finish(DevProblem P, int nparts) {
   if (threadIdx.x == 0) P.part[(size_t)SC_COST * P.part_n + 0] = sc[0];
 }
 
-// one wave per keyframe: fixed-order sum of its observations' records
-__global__ __launch_bounds__(256) void k_kf_reduce(DevProblem P) {
-  const int kf = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (kf >= P.K) return;
+// One wave (= one workgroup) per keyframe: fixed-order sum of its observations' records. Lanes run over the OBSERVATIONS
+// (lane l takes records l, l+64, ...: 64 independent gathers in flight), the 39 partial sums of every lane go through LDS and
+// lane k adds column k in lane order. (The first version had lane = record entry and walked the keyframe's ~400
+// observations one after the other: a chain of dependent gathers at L2 latency, 0.36 ms on the 5-agent map.)
+__global__ __launch_bounds__(64) void k_kf_reduce(DevProblem P) {
+  __shared__ double sp[kRec][65];
+  const int kf = blockIdx.x, lane = threadIdx.x;
   if (P.fixed[kf]) return;  // constant pose block: rows stay empty, finalize_diag turns them into identity
   const int o0 = P.kf_obs_ptr[kf], o1 = P.kf_obs_ptr[kf + 1];
+  double part[kRec];
+#pragma unroll
+  for (int k = 0; k < kRec; ++k) part[k] = 0.0;
+  for (int t = o0 + lane; t < o1; t += 64) {
+    const double* rec = P.obsP + kRec * (size_t)P.kf_obs_idx[t];
+#pragma unroll
+    for (int k = 0; k < kRec; ++k) part[k] += rec[k];
+  }
+#pragma unroll
+  for (int k = 0; k < kRec; ++k) sp[k][lane] = part[k];
+  __syncthreads();
   double acc = 0.0;
-  if (lane < kRec)
-    for (int t = o0; t < o1; ++t) acc += P.obsP[kRec * (size_t)P.kf_obs_idx[t] + lane];
+  if (lane < kRec) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+    for (int t = 0; t < 64; t += 4) { a0 += sp[lane][t]; a1 += sp[lane][t + 1]; a2 += sp[lane][t + 2]; a3 += sp[lane][t + 3]; }
+    acc = (a0 + a1) + (a2 + a3);
+  }
   const double gp = __shfl(acc, (lane >= 33 && lane < 39) ? lane - 6 : lane, 64);  // lanes 33..38 hold yg; fetch the matching gp
   const size_t base = (size_t)P.D * kf;
   const int pos = P.perm[kf];
@@ -255,19 +273,43 @@ __global__ __launch_bounds__(256) void k_kf_reduce(DevProblem P) {
   }
 }
 
-// one wave per covisible keyframe pair: lanes 0..35 = entries of the 6x6 block
-__global__ __launch_bounds__(256) void k_pair_blocks(DevProblem P) {
-  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (p >= P.npairs || lane >= 36) return;
-  const int r = lane / 6, c = lane - 6 * r;
-  const int e0 = P.pair_ptr[p], e1 = P.pair_ptr[p + 1];
-  double acc = 0.0;
-  for (int e = e0; e < e1; ++e) {
-    const double* y = P.obsY + 18 * (size_t)P.pair_oa[e] + 3 * r;
-    const double* w = P.obsW + 18 * (size_t)P.pair_ob[e] + 3 * c;
-    acc += y[0] * w[0] + y[1] * w[1] + y[2] * w[2];
+// Sixteen lanes per covisible keyframe pair (eight pairs per workgroup): C[i,j] = -sum over the common landmarks of Y_i W_j^T.
+// Lanes run over the common LANDMARKS (lane g takes terms g, g+16, ...: each a 6x3 times 3x6 product from two contiguous
+// 144-byte records), the 36 partial sums of every lane go through LDS and lane g adds entries g, g+16, g+32 in lane order.
+// (The first version had lane = block entry, 36 of 64 lanes busy, every lane walking all common landmarks in sequence:
+// 0.78 ms on the 5-agent map, the longest kernel of the linearisation.)
+constexpr int kPairLanes = 16, kPairsPerWg = 8;
+__global__ __launch_bounds__(kPairLanes * kPairsPerWg) void k_pair_blocks(DevProblem P) {
+  __shared__ double sp[kPairsPerWg][36][kPairLanes + 1];
+  const int grp = threadIdx.x / kPairLanes, g = threadIdx.x % kPairLanes;
+  const int p = blockIdx.x * kPairsPerWg + grp;
+  const bool ok = p < P.npairs;
+  const int e0 = ok ? P.pair_ptr[p] : 0, e1 = ok ? P.pair_ptr[p + 1] : 0;
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+  for (int e = e0 + g; e < e1; e += kPairLanes) {
+    const double* y = P.obsY + 18 * (size_t)P.pair_oa[e];
+    const double* w = P.obsW + 18 * (size_t)P.pair_ob[e];
+    double yv[18], wv[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) { yv[k] = y[k]; wv[k] = w[k]; }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[6 * r + c] += yv[3 * r] * wv[3 * c] + yv[3 * r + 1] * wv[3 * c + 1] + yv[3 * r + 2] * wv[3 * c + 2];
   }
-  *c_entry(P, P.pair_i[p], P.pair_j[p], r, c) = -acc;
+#pragma unroll
+  for (int k = 0; k < 36; ++k) sp[grp][k][g] = acc[k];
+  __syncthreads();
+  if (!ok) return;
+  const int pi = P.pair_i[p], pj = P.pair_j[p];
+  for (int k = g; k < 36; k += kPairLanes) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < kPairLanes; t += 2) { a0 += sp[grp][k][t]; a1 += sp[grp][k][t + 1]; }
+    *c_entry(P, pi, pj, k / 6, k % 6) = -(a0 + a1);
+  }
 }
 
 // back-substitution: dl = Hinv (-g_l - sum_a W_a^T dp[kf_a]); written to out_all[n + 3l ..]
@@ -365,8 +407,8 @@ void launch_lm_build(const DevProblem& P, double mu, hipStream_t st) {
   const int groups = kBuildThreads / kG, nblk = (P.L + groups - 1) / groups;
   hipLaunchKernelGGL(k_lm_lin<kG>, dim3(nblk), dim3(kBuildThreads), 0, st, P, mu);
   hipLaunchKernelGGL(k_cost_finish, dim3(1), dim3(256), 0, st, P, nblk);
-  hipLaunchKernelGGL(k_kf_reduce, dim3((P.K + 3) / 4), dim3(256), 0, st, P);
-  if (P.npairs) hipLaunchKernelGGL(k_pair_blocks, dim3((P.npairs + 3) / 4), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(k_kf_reduce, dim3(P.K), dim3(64), 0, st, P);
+  if (P.npairs) hipLaunchKernelGGL(k_pair_blocks, dim3((P.npairs + kPairsPerWg - 1) / kPairsPerWg), dim3(kPairLanes * kPairsPerWg), 0, st, P);
 }
 void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st) {
   if (P.L == 0) return;

@@ -221,12 +221,12 @@ __global__ __launch_bounds__(256) void k_sb_sweep_mat(DevProblem P) {
   }
 }
 template <int DIR>
-__global__ __launch_bounds__(256) void k_sb_sweep_vec(DevProblem P) {  // DIR +1: f = Ldinv b_s (b_s in xs) -> Zfwd | -1: v = Ldinv^T u (u in xs) -> Nback
+__global__ __launch_bounds__(256) void k_sb_sweep_vec(DevProblem P, const double* __restrict__ src) {  // DIR +1: f = Ldinv src -> Zfwd | -1: v = Ldinv^T src -> Nback
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= 9 * P.K) return;
   const int pos = q / 9, i = q - 9 * pos;
   const double* L = P.Ldinv + (size_t)81 * pos;
-  const double* u = P.xs + (size_t)9 * pos;
+  const double* u = src + (size_t)9 * pos;
   double s = 0.0;
 #pragma unroll
   for (int k = 0; k < 9; ++k) s += (DIR > 0) ? ((k <= i) ? L[9 * i + k] * u[k] : 0.0) : ((k >= i) ? L[9 * k + i] * u[k] : 0.0);
@@ -466,6 +466,35 @@ __global__ __launch_bounds__(256) void k_pose_rhs(DevProblem P) {
   if (part == 0 && col < 6 * P.K) P.bp[col] -= acc;
 }
 
+// b'_p = b_p - B^T x0 with x0 = A^-1 b_s (in xs, left by the sweeps behind the chain factorisation): pose j couples to the
+// speed-bias blocks of positions j (Bs), j+1 (through its Bp) and j-1 (through its Bn) of its chain. One thread per entry.
+__global__ __launch_bounds__(256) void k_pose_rhs_sweep(DevProblem P) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 6 * P.K) return;
+  const int j = t / 6, e = t - 6 * j;
+  const int pb = P.pos_chain_begin[j], pe = P.pos_chain_end[j];
+  double acc = 0.0;
+  {
+    const double* B = P.Bs + (size_t)54 * j + e;
+    const double* x = P.xs + (size_t)9 * j;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) acc += B[6 * r] * x[r];
+  }
+  if (j + 1 < pe) {
+    const double* B = P.Bp + (size_t)54 * (j + 1) + e;
+    const double* x = P.xs + (size_t)9 * (j + 1);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) acc += B[6 * r] * x[r];
+  }
+  if (j > pb) {
+    const double* B = P.Bn + (size_t)54 * (j - 1) + e;
+    const double* x = P.xs + (size_t)9 * (j - 1);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) acc += B[6 * r] * x[r];
+  }
+  P.bp[t] -= acc;
+}
+
 // x_s = A^-1 (b_s - B x_p), in two kernels.
 // k_sb_rhs (one thread per speed-bias row, fully parallel): w = b_s - B x_p, in place in xs.
 __global__ __launch_bounds__(256) void k_sb_rhs(DevProblem P) {
@@ -605,8 +634,12 @@ __global__ __launch_bounds__(64) void k_sb_backsolve(DevProblem P, int do_forwar
 // right behind the chain factorisation: sweep matrices, f = Ldinv b_s, then z by the forward sweep (xs still holds b_s)
 static void launch_sb_after_factor(const DevProblem& P, hipStream_t st) {
   hipLaunchKernelGGL(k_sb_sweep_mat, dim3((81 * P.K + 255) / 256), dim3(256), 0, st, P);
-  hipLaunchKernelGGL(k_sb_sweep_vec<1>, dim3((9 * P.K + 255) / 256), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(k_sb_sweep_vec<1>, dim3((9 * P.K + 255) / 256), dim3(256), 0, st, P, (const double*)P.xs);
   hipLaunchKernelGGL(k_sb_sweep<1>, dim3(P.nchains), dim3(64), 0, st, P);
+  // x0 = A^-1 b_s = L_A^-T z by the backward sweep (into xs: b_s is not needed any more), for the reduced pose right-hand
+  // side b_p - B^T x0 (k_pose_rhs_sweep) — the Y^T z product it replaces read all of Y (430 MB, 0.25 ms on the critical path)
+  hipLaunchKernelGGL(k_sb_sweep_vec<-1>, dim3((9 * P.K + 255) / 256), dim3(256), 0, st, P, (const double*)P.zs);
+  hipLaunchKernelGGL(k_sb_sweep<-1>, dim3(P.nchains), dim3(64), 0, st, P);
 }
 void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& ax) {
   if (!P.vi) return;
@@ -639,7 +672,9 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
       launch_sb_after_factor(P, st);
       hipLaunchKernelGGL(k_sb_gram, dim3(P.nchains), dim3(128), 0, st, P);
     }
-    hipLaunchKernelGGL(k_pose_rhs, dim3((8 * 6 * P.K + 255) / 256), dim3(256), 0, st, P);
+    static const bool rhs_from_y = [] { const char* e = getenv("COVGPU_POSE_RHS_Y"); return e && e[0] == '1'; }();  // 1: round-2a product with Y
+    if (rhs_from_y) hipLaunchKernelGGL(k_pose_rhs, dim3((8 * 6 * P.K + 255) / 256), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL(k_pose_rhs_sweep, dim3((6 * P.K + 255) / 256), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_yty_semisep, dim3(P.K), dim3(256), 0, st, P);
   }
   if (pgo != nullptr) launch_pgo_block_solve(P, *pgo, st, ax);  // pose graph: block-arrow elimination (k_pgo.hip)
@@ -655,7 +690,7 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
       static const bool two_products = [] { const char* e = getenv("COVGPU_SB_BACK"); return e && e[0] == '0'; }();  // 0: round-2a backward sweep
       if (two_products) hipLaunchKernelGGL(k_sb_backsolve, dim3(P.nchains), dim3(64), 0, st, P, 0);
       else {
-        hipLaunchKernelGGL(k_sb_sweep_vec<-1>, dim3((9 * P.K + 255) / 256), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(k_sb_sweep_vec<-1>, dim3((9 * P.K + 255) / 256), dim3(256), 0, st, P, (const double*)P.xs);
         hipLaunchKernelGGL(k_sb_sweep<-1>, dim3(P.nchains), dim3(64), 0, st, P);
       }
     }

@@ -56,7 +56,7 @@ int main() {
   }
   // z by the forward sweep (xs holds b_s)
   hipLaunchKernelGGL(k_sb_sweep_mat, dim3((81 * K + 255) / 256), dim3(256), 0, 0, P);
-  hipLaunchKernelGGL(k_sb_sweep_vec<1>, dim3((9 * K + 255) / 256), dim3(256), 0, 0, P);
+  hipLaunchKernelGGL(k_sb_sweep_vec<1>, dim3((9 * K + 255) / 256), dim3(256), 0, 0, P, (const double*)P.xs);
   hipLaunchKernelGGL(k_sb_sweep<1>, dim3(NCH), dim3(64), 0, 0, P);
   hipDeviceSynchronize();
   // host recurrence on chain 0
@@ -99,7 +99,7 @@ int main() {
   hipMemcpy(xa.data(), P.xs, xa.size() * 8, hipMemcpyDeviceToHost);
   hipMemcpy(P.xs, xs.data(), xs.size() * 8, hipMemcpyHostToDevice);
   hipLaunchKernelGGL(k_sb_sweep_mat, dim3((81 * K + 255) / 256), dim3(256), 0, 0, P);
-  hipLaunchKernelGGL(k_sb_sweep_vec<-1>, dim3((9 * K + 255) / 256), dim3(256), 0, 0, P);
+  hipLaunchKernelGGL(k_sb_sweep_vec<-1>, dim3((9 * K + 255) / 256), dim3(256), 0, 0, P, (const double*)P.xs);
   hipLaunchKernelGGL(k_sb_sweep<-1>, dim3(NCH), dim3(64), 0, 0, P);
   hipMemcpy(xb.data(), P.xs, xb.size() * 8, hipMemcpyDeviceToHost);
   double ex = 0, xm = 0;

@@ -36,7 +36,7 @@ __device__ long long g_pprobe[8];
 #define PPROBE_DECL() long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define PPROBE_ACC(i, t0) do { pacc[i] += clock64() - (t0); } while (0)
 #define PPROBE_T0() clock64()
-#define PPROBE_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) g_pprobe[i_] = pacc[i_]; } while (0)
+#define PPROBE_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 6; ++i_) g_pprobe[i_] = pacc[i_]; if (threadIdx.x == 64) { g_pprobe[6] = pacc[6]; g_pprobe[7] = pacc[7]; } } while (0)
 #else
 #define PPROBE_DECL() do {} while (0)
 #define PPROBE_ACC(i, t0) do {} while (0)
@@ -45,11 +45,12 @@ __device__ long long g_pprobe[8];
 #endif
 
 constexpr int PB = 16;                 // block edge
-constexpr int PP = 17;                 // LDS pitch of a panel row: odd -> one row per thread is conflict-free
+constexpr int PP = 18;                 // LDS pitch of a panel row (16 doubles + 2): rows 16-byte aligned, and the 16 lanes of a quarter wave
+                                       // reading 32 bytes of 16 consecutive rows hit all 64 banks once (ds_read_b128, conflict-free)
 constexpr int PROWS = 256;
-constexpr int NTW = 7;                 // tile-owning waves (waves 1..7; wave 0 factors the diagonal blocks)
-constexpr int NSLOT = 18;              // ceil(120 / 7): tiles (i, k), 1 <= k <= i <= 15, column-major, dealt round-robin
-constexpr size_t kPanelLds = (size_t)(2 * PROWS * PP + 256 + 256 + 48) * sizeof(double);
+constexpr int NTW = 7;                 // tile-owning waves (waves 1..7; wave 0 carries the serial chain)
+constexpr int NSLOT = 18;              // 119 / 7 rounded up to even: tiles (i, k), 1 <= k <= i <= 15 except (1,1), column-major, dealt round-robin
+constexpr size_t kPanelLds = (size_t)(2 * PROWS * PP + 256 + 256 + 48 + 16 * PP + 16) * sizeof(double);
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL store to be
 // acknowledged (s_waitcnt vmcnt(0): ~1 us per step here, where L / Dinv / y stream out while the factorisation goes on
@@ -60,13 +61,37 @@ COV_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::
 COV_DEV v4f64 tile_update(v4f64 acc, const double* pan, int i, int k, int fr, int fk) {
   const double* pa = pan + (PB * i + fr) * PP + 4 * fk;
   const double* pb = pan + (PB * k + fr) * PP + 4 * fk;
-  const double a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3];
-  const double b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3];
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a2, b2, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a3, b3, acc, 0, 0, 0);
+  const double2 a01 = *reinterpret_cast<const double2*>(pa), a23 = *reinterpret_cast<const double2*>(pa + 2);
+  const double2 b01 = *reinterpret_cast<const double2*>(pb), b23 = *reinterpret_cast<const double2*>(pb + 2);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a01.x, b01.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a01.y, b01.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a23.x, b23.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a23.y, b23.y, acc, 0, 0, 0);
   return acc;
+}
+
+// Two tiles at once: their (dependent) 4-MFMA chains interleaved, so the matrix pipe sees independent instructions back to
+// back (34 cycles each) instead of one chain at the dependent rate (66). A tile that takes no update this step reads its A
+// operand from a row of zeros (`zrow`): its accumulator is unchanged, and the code has ONE path per pair — the loop body of
+// this kernel has to stay well inside the 64 KiB instruction cache (a version with separate paths for full and partial
+// groups was 100 KiB of code and ran at instruction-fetch speed: 200 us instead of 120; one with 40 tiles per wave on four
+// waves had its accumulators shuttled between VGPRs and AGPRs around every MFMA).
+COV_DEV void tile_update2(v4f64& c0, v4f64& c1, const double* pan, const double* zrow, int pk0, int pk1, bool u0, bool u1, int fr, int fk) {
+  const double* base = pan + fr * PP + 4 * fk;
+  const double* pa0 = u0 ? base + PB * PP * (pk0 & 255) : zrow; const double* pb0 = base + PB * PP * (u0 ? (pk0 >> 8) : 0);
+  const double* pa1 = u1 ? base + PB * PP * (pk1 & 255) : zrow; const double* pb1 = base + PB * PP * (u1 ? (pk1 >> 8) : 0);
+  const double2 a0 = *reinterpret_cast<const double2*>(pa0), a0h = *reinterpret_cast<const double2*>(pa0 + 2);
+  const double2 b0 = *reinterpret_cast<const double2*>(pb0), b0h = *reinterpret_cast<const double2*>(pb0 + 2);
+  const double2 a1 = *reinterpret_cast<const double2*>(pa1), a1h = *reinterpret_cast<const double2*>(pa1 + 2);
+  const double2 b1 = *reinterpret_cast<const double2*>(pb1), b1h = *reinterpret_cast<const double2*>(pb1 + 2);
+  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0.x, b0.x, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1.x, b1.x, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0.y, b0.y, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1.y, b1.y, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0h.x, b0h.x, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1h.x, b1h.x, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0h.y, b0h.y, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1h.y, b1h.y, c1, 0, 0, 0);
 }
 
 // Factor the (16 nb)-order diagonal block at (k0, k0), nb = 16 (a 256-column panel) or 8 (a last single tile).
@@ -88,12 +113,14 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
                                                       const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR) {
   M += (size_t)blockIdx.x * bsM; Dinv_out += (size_t)blockIdx.x * bsL;
   if (rhs != nullptr) { rhs += (size_t)blockIdx.x * bsR; yout += (size_t)blockIdx.x * bsR; }
-  extern __shared__ __attribute__((aligned(16))) double sP[];  // panel[2][256][PP] | sDv[16][16] | sRhs[256] | colA[16] rowW[16] sdd[16]
+  extern __shared__ __attribute__((aligned(16))) double sP[];  // panel[2][256][PP] | sDv[16][16] | sRhs[256] | colA[16] rowW[16] sdd[16] | sDg[16][PP]
   double* sDv = sP + 2 * PROWS * PP;
   double* sRhs = sDv + 256;
   double* colA = sRhs + 256;   // wave 0 only: LDS operations of one wave execute in order, no barrier needed
   double* rowW = colA + 16;
   double* sdd = rowW + 16;      // the block's 16 pivots
+  double* sDg = sdd + 16;       // [16][PP] the diagonal tile wave 0 takes over next (panels before the current one applied)
+  double* sZero = sDg + 16 * PP;  // [16] zeros (A operand of tiles that take no update, tile_update4)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fk = lane >> 4;
   const int n = PB * nb;
@@ -105,7 +132,7 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
   int tik[NSLOT];
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
-    int t = s * NTW + (wave - 1), k = 1;
+    int t = s * NTW + (wave - 1) + 1, k = 1;  // (+1: tile (1,1) belongs to wave 0 from the start, see the loop below)
     bool ok = wave >= 1 && t < 120;
     if (ok) { while (t >= 16 - k) { t -= 16 - k; ++k; } }
     const int i = k + t;
@@ -136,17 +163,29 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
       for (int c = 0; c < 8; ++c) sP[row * PP + 8 * half + c] = v[c];
     }
     if (tid < PROWS) sRhs[tid] = (rhs != nullptr && tid < n) ? rhs[k0 + tid] : 0.0;
+    if (tid < 16) sZero[tid] = 0.0;
+    if (tid < 256 && nb > 1) {  // diagonal tile (1,1): wave 0 takes it over at step 0 (see below)
+      const int rr = tid >> 4, cc = tid & 15;
+      sDg[rr * PP + cc] = (cc <= rr) ? Mg[(size_t)(PB + rr) * ld + PB + cc] : 0.0;
+    }
   }
   __syncthreads();
   PPROBE_ACC(4, tp0);
 
+  // Software pipeline, two barriers per block column. Wave 0 carries the serial chain alone:
+  //     (a) diagonal block j  ->  X(j+1,j) = T(j+1,j) Dinv_j^T  ->  T(j+1,j+1) -= X X^T  ->  (a) diagonal block j+1 ...
+  // and the tile waves work around it: between barriers X(j) and Y(j) the remaining tiles of panel j (i >= j+2) are solved
+  // against Dinv_j; between Y(j) and X(j+1) — while wave 0 already factors block j+1 — they apply panel j to block column
+  // j+1 (handed on through LDS), to the diagonal tile (j+2,j+2) (handed to wave 0 through sDg one step ahead) and to the
+  // rest of the trailing tiles, and stream L, y out. (With three phases in lock step — factor | solve | update — every step
+  // cost the sum of the three, 6.4 us; now it costs wave 0's chain, ~4.)
   for (int j = 0; j < nb; ++j) {
     double* cur = sP + (j & 1) * PROWS * PP;          // block column j, rows 16 j .. n
-    double* oth = sP + ((j + 1) & 1) * PROWS * PP;    // panel j-1 (read in phase A), then block column j+1 (written in phase C)
+    double* oth = sP + ((j + 1) & 1) * PROWS * PP;    // block column j+1 (being assembled)
     const int o = PB * j;
-    // ---- phase A
     const long long tq0 = PPROBE_T0();
     if (wave == 0) {
+      // ---- (a): factor the diagonal block and form its inverse
       __builtin_amdgcn_s_setprio(3);
       int ln = lane;
       asm volatile("" : "+v"(ln));  // per-lane invariants of this block are recomputed every step rather than hoisted and spilled
@@ -200,6 +239,7 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
         rs = rs * (1.5 - 0.5 * dv * rs * rs);
         if (e < 4) rsc[e] = rs; else rsr = rs;
       }
+      double* dst = Dinv_out + (size_t)(j >> 3) * kTile * kTile + (size_t)(j & 7) * 256 + r * PB + 4 * q;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const bool low = 4 * q + e <= r;
@@ -207,27 +247,16 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
         asm volatile("" : "+v"(lv), "+v"(xv));  // selects, not a branch around the stores
         cur[(o + r) * PP + 4 * q + e] = lv;
         sDv[r * PB + 4 * q + e] = xv;
+        dst[e] = xv;
       }
       __builtin_amdgcn_s_setprio(0);
       PPROBE_ACC(5, tq0);
     }
-#ifndef PANEL_NO_DEFER
-    if (j > 0) {  // (wave 0 owns no tile: all its slots are 99)
-#pragma unroll
-      for (int s = 0; s < NSLOT; ++s) {
-        int pk = tik[s];
-        asm volatile("" : "+s"(pk));  // keeps the LDS row addresses of all slots from being hoisted out of the j loop (spills)
-        const int i = pk & 255, k = pk >> 8;
-        if (k > j && k != 99) acc[s] = tile_update(acc[s], oth, i, k, fr, fk);
-      }
-    }
-#endif
-    lds_barrier();
+    lds_barrier();  // ---- X(j): L_jj, Dinv_j in LDS; block column j complete in `cur`; trailing tiles carry panels < j
     PPROBE_ACC(1, tq0);
-    // ---- phase B: X_ij = T_ij Dinv_j^T on the matrix core, tile rows dealt to waves 1..7; y_j = Dinv_j b_j on wave 0
     const long long tq1 = PPROBE_T0();
     if (wave == 0) {
-      if (lane < PB) {
+      if (lane < PB) {  // y_j = Dinv_j b_j
         double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
 #pragma unroll
         for (int k = 0; k < PB; k += 4) {
@@ -236,12 +265,34 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
         }
         sRhs[o + lane] = (y0 + y1) + (y2 + y3);
       }
+      if (j + 1 < nb) {
+        // X(j+1,j) = T(j+1,j) Dinv_j^T (in place in `cur`), then the next diagonal tile T(j+1,j+1) (in sDg, panels < j
+        // applied) -= X X^T, into `oth` where (a) of the next step reads it
+        double* tp = cur + (o + PB + fr) * PP + 4 * fk;
+        const double* dp = sDv + fr * PB + 4 * fk;
+        const double2 ta = *reinterpret_cast<const double2*>(tp), tc = *reinterpret_cast<const double2*>(tp + 2);
+        const double2 tb = *reinterpret_cast<const double2*>(dp), td = *reinterpret_cast<const double2*>(dp + 2);
+        const double a0 = ta.x, a1 = ta.y, a2 = tc.x, a3 = tc.y, b0 = tb.x, b1 = tb.y, b2 = td.x, b3 = td.y;
+        v4f64 x = v4f64{0.0, 0.0, 0.0, 0.0};
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, x, 0, 0, 0);
+        v4f64 dg;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) { cur[(o + PB + fk + 4 * rg) * PP + fr] = x[rg]; dg[rg] = sDg[(fk + 4 * rg) * PP + fr]; }
+        __builtin_amdgcn_wave_barrier();
+        dg = tile_update(dg, cur, j + 1, j + 1, fr, fk);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) oth[(o + PB + fk + 4 * rg) * PP + fr] = dg[rg];
+      }
     } else {
-      for (int i = j + wave; i < nb; i += NTW) {
+      for (int i = j + 1 + wave; i < nb; i += NTW) {  // X(i,j) for i >= j+2
         double* tp = cur + (PB * i + fr) * PP + 4 * fk;
         const double* dp = sDv + fr * PB + 4 * fk;
-        const double a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3];
-        const double b0 = dp[0], b1 = dp[1], b2 = dp[2], b3 = dp[3];
+        const double2 ta = *reinterpret_cast<const double2*>(tp), tc = *reinterpret_cast<const double2*>(tp + 2);
+        const double2 tb = *reinterpret_cast<const double2*>(dp), td = *reinterpret_cast<const double2*>(dp + 2);
+        const double a0 = ta.x, a1 = ta.y, a2 = tc.x, a3 = tc.y, b0 = tb.x, b1 = tb.y, b2 = td.x, b3 = td.y;
         v4f64 x = v4f64{0.0, 0.0, 0.0, 0.0};
         x = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, x, 0, 0, 0);
         x = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, x, 0, 0, 0);
@@ -251,50 +302,68 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
         for (int rg = 0; rg < 4; ++rg) cur[(PB * i + fk + 4 * rg) * PP + fr] = x[rg];
       }
     }
-    lds_barrier();
+    lds_barrier();  // ---- Y(j): panel j complete in `cur`, the next diagonal tile in `oth`
     PPROBE_ACC(2, tq1);
-    // ---- phase C: block column j+1 first (handed to the next step through LDS); L and y out; right-hand side update
     const long long tq2 = PPROBE_T0();
-    {
+    if (wave != 0) {
+      // panel j onto every trailing tile of this wave (one pass, four slots at a time); block column j+1 goes on to `oth`
+      // and the diagonal tile (j+2,j+2) to sDg on the way. Tile (j+1,j+1) is wave 0's already.
 #pragma unroll
-      for (int s = 0; s < NSLOT; ++s) {
-        int pk = tik[s];
-        asm volatile("" : "+s"(pk));
-        const int i = pk & 255, k = pk >> 8;
-        if (k == j + 1) {
-          acc[s] = tile_update(acc[s], cur, i, k, fr, fk);
+      for (int s = 0; s < NSLOT; s += 2) {
+        int pk[2]; bool u[2];
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) oth[(PB * i + fk + 4 * rg) * PP + fr] = acc[s][rg];
+        for (int e = 0; e < 2; ++e) {
+          pk[e] = tik[s + e];
+          asm volatile("" : "+s"(pk[e]));  // keeps the LDS row addresses of all slots from being hoisted out of the j loop (spills)
+          const int i = pk[e] & 255, k = pk[e] >> 8;
+          u[e] = k >= j + 1 && k != 99 && !(k == j + 1 && i == k);
+        }
+#ifdef PANEL_W4_IDLE
+        if (wave == 4) { u[0] = false; u[1] = false; }
+#endif
+        if (u[0] || u[1]) {
+          tile_update2(acc[s], acc[s + 1], cur, sZero + 4 * fk, pk[0], pk[1], u[0], u[1], fr, fk);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int i = pk[e] & 255, k = pk[e] >> 8;
+            if (u[e] && (k == j + 1 || (k == j + 2 && i == k))) {
+              double* dstp = (i == k) ? sDg + fk * PP + fr : oth + (PB * i + fk) * PP + fr;
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) dstp[4 * rg * PP] = acc[s + e][rg];
+            }
+          }
         }
       }
+      PPROBE_ACC(6, tq2);
+      const long long tq3 = PPROBE_T0();
+      {  // L panel, y, right-hand side update (waves 1..7: 448 threads)
+        const int u = tid - 64;
+        // rows below the diagonal block: 64 bytes per thread, branch-free; the block's own rows (lower part) by 256 threads
+        for (int row = o + PB + (u >> 1); row < n; row += 224) {
+          const double2* src = reinterpret_cast<const double2*>(cur + row * PP + 8 * (u & 1));
+          double2* dst = reinterpret_cast<double2*>(Mg + (size_t)row * ld + o + 8 * (u & 1));
+          const double2 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+          dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+        }
+        if (u < 256) {
+          const int rr = u >> 4, cc = u & 15;
+          if (cc <= rr) Mg[(size_t)(o + rr) * ld + o + cc] = cur[(o + rr) * PP + cc];
+        }
+        for (int col = o + PB + u; col < n; col += 448) {
+          double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+          for (int c = 0; c < PB; c += 4) {
+            t0 += sRhs[o + c] * cur[col * PP + c]; t1 += sRhs[o + c + 1] * cur[col * PP + c + 1];
+            t2 += sRhs[o + c + 2] * cur[col * PP + c + 2]; t3 += sRhs[o + c + 3] * cur[col * PP + c + 3];
+          }
+          sRhs[col] -= (t0 + t1) + (t2 + t3);
+        }
+        if (yout != nullptr && u >= 384 && u < 384 + PB) yout[k0 + o + u - 384] = sRhs[o + u - 384];
+      }
+      PPROBE_ACC(7, tq3);
     }
-    {
-      const int nrow = n - o - PB;
-      const int row = o + (tid >> 1), half = tid & 1;
-      if (row < n) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const int col = 8 * half + c;
-          if (row >= o + PB || col <= row - o) Mg[(size_t)row * ld + o + col] = cur[row * PP + col];
-        }
-      }
-      if (tid < nrow) {
-        const int col = o + PB + tid;
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-#pragma unroll
-        for (int c = 0; c < PB; c += 4) {
-          t0 += sRhs[o + c] * cur[col * PP + c]; t1 += sRhs[o + c + 1] * cur[col * PP + c + 1];
-          t2 += sRhs[o + c + 2] * cur[col * PP + c + 2]; t3 += sRhs[o + c + 3] * cur[col * PP + c + 3];
-        }
-        sRhs[col] -= (t0 + t1) + (t2 + t3);
-      }
-      if (yout != nullptr && tid >= 448 && tid < 448 + PB) yout[k0 + o + tid - 448] = sRhs[o + tid - 448];
-      if (tid < 256) Dinv_out[(size_t)(j >> 3) * kTile * kTile + (size_t)(j & 7) * 256 + tid] = sDv[tid];
-    }
-    lds_barrier();
     PPROBE_ACC(3, tq2);
   }
-  PPROBE_ACC(6, tp0);
   PPROBE_FLUSH();
 }
 

@@ -65,7 +65,7 @@ int main() {
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
       long long pr[8]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_pprobe), sizeof(pr));
-      for (int k = 1; k <= 6; ++k) ph[k] = std::min(ph[k], pr[k] / 2400.0);  // shader cycles at 2.4 GHz
+      for (int k = 1; k <= 7; ++k) ph[k] = std::min(ph[k], pr[k] / 2400.0);  // shader cycles at 2.4 GHz
     }
     for (int nbt : {1, 2, 5}) {  // is the batch concurrent? (needs NBT >= nbt matrices: reuse the first)
       float bq = 1e9;
@@ -82,8 +82,8 @@ int main() {
     hipMemcpy(db, b.data(), b.size() * 8, hipMemcpyHostToDevice);
     launch_potrf_panel(dA, N, t0, w, dD, df, db, N, NBT, sM, sL, sR, 0);
     hipDeviceSynchronize();
-    printf("k_potrf_panel nb=%d (x%d batched): best %.1f us; phases (sum over %d steps) A %.1f (wave 0's diagonal block alone %.1f)  B %.1f  C %.1f us; prologue %.1f  body %.1f us\n",
-           nb, NBT, best * 1e3, nb, ph[1], ph[5], ph[2], ph[3], ph[4], ph[6]);
+    printf("k_potrf_panel nb=%d (x%d batched): best %.1f us; phases (sum over %d steps) A %.1f (wave 0's diagonal block alone %.1f)  B %.1f  C %.1f us; prologue %.1f us; wave 1: tile updates %.1f  L store + rhs %.1f us\n",
+           nb, NBT, best * 1e3, nb, ph[1], ph[5], ph[2], ph[3], ph[4], ph[6], ph[7]);
     // rows below by block substitution
     float bestT = 1e9;
     std::vector<double> Apost(A.size());

@@ -340,9 +340,22 @@ __global__ __launch_bounds__(256) void k_sb_chain_cols(DevProblem P) {
     }
     return o;
   };
+  // Head: the positions where some column of the tile is still being injected (pose q enters at q-1, q, q+1) — the full
+  // two-product form. Tail: every column obeys y(pos) = M_pos y(pos-1) with the propagator M_pos = -Ldinv_pos Lsub_pos
+  // (k_sb_propagator, right behind the chain factorisation): ONE product per position, three operand loads instead of
+  // nine, fetched eight positions ahead through a ring of registers (loop unrolled by the ring size: no copies).
+  const int ptail = min((col0 + 15) / 6 + 2, p1);  // first position at which no column of the tile is injected any more
   ColOps o0 = fetch(pfirst), o1 = fetch(pfirst + 1), o2 = fetch(pfirst + 2), o3 = fetch(pfirst + 3);
   v4f64s y = {0.0, 0.0, 0.0, 0.0};
-  for (int pos = pfirst; pos < p1; ++pos) {
+  auto store = [&](int pos) {
+    if (live && pos >= pstart) {
+      double* Yp = Yc + (size_t)(9 * (pos - p0) + kq) * ld + (col - 6 * p0);
+      Yp[0] = y[0];
+      Yp[4 * ld] = y[1];
+      if (kq == 0) Yp[8 * ld] = y[2];
+    }
+  };
+  for (int pos = pfirst; pos < ptail; ++pos) {
     const ColOps o = o0;
     o0 = o1; o1 = o2; o2 = o3; o3 = fetch(pos + 4);
     v4f64s t = {o.bi[0], o.bi[1], o.bi[2], 0.0};
@@ -354,11 +367,32 @@ __global__ __launch_bounds__(256) void k_sb_chain_cols(DevProblem P) {
     yn = __builtin_amdgcn_mfma_f64_16x16x4f64(o.li[1], t[1], yn, 0, 0, 0);
     yn = __builtin_amdgcn_mfma_f64_16x16x4f64(o.li[2], t[2], yn, 0, 0, 0);
     y = yn;
-    if (live && pos >= pstart) {
-      double* Yp = Yc + (size_t)(9 * (pos - p0) + kq) * ld + (col - 6 * p0);
-      Yp[0] = y[0];
-      Yp[4 * ld] = y[1];
-      if (kq == 0) Yp[8 * ld] = y[2];
+    store(pos);
+  }
+  constexpr int RING = 8;
+  double mr[RING][3];
+  auto mfetch = [&](int pos, double* m) {
+    const bool in = pos < p1;
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+      const int k = kq + 4 * s2;
+      m[s2] = (in && n < 9 && k < 9) ? P.Mblk[(size_t)81 * pos + 9 * n + k] : 0.0;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < RING; ++i) mfetch(ptail + i, mr[i]);
+  for (int pos = ptail; pos < p1; pos += RING) {
+#pragma unroll
+    for (int i = 0; i < RING; ++i) {
+      if (pos + i < p1) {  // wave-uniform
+        v4f64s yn = {0.0, 0.0, 0.0, 0.0};
+        yn = __builtin_amdgcn_mfma_f64_16x16x4f64(mr[i][0], y[0], yn, 0, 0, 0);
+        yn = __builtin_amdgcn_mfma_f64_16x16x4f64(mr[i][1], y[1], yn, 0, 0, 0);
+        yn = __builtin_amdgcn_mfma_f64_16x16x4f64(mr[i][2], y[2], yn, 0, 0, 0);
+        y = yn;
+        mfetch(pos + i + RING, mr[i]);
+        store(pos + i);
+      }
     }
   }
 }
@@ -648,10 +682,10 @@ void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& 
   (void)hipEventRecord(ax.ev_sb, st);
   (void)hipStreamWaitEvent(ax.aux, ax.ev_sb, 0);
   hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, ax.aux, P);
+  hipLaunchKernelGGL(k_sb_propagator, dim3((81 * P.K + 255) / 256), dim3(256), 0, ax.aux, P);  // k_sb_chain_cols' tail marches with it
   (void)hipEventRecord(ax.ev_cf, ax.aux);
   // z = L_A^-1 b_s (a linear recurrence, k_sb_sweep) and the Gramians need the factor only: they follow on the auxiliary
   // stream, underneath k_sb_chain_cols
-  hipLaunchKernelGGL(k_sb_propagator, dim3((81 * P.K + 255) / 256), dim3(256), 0, ax.aux, P);
   launch_sb_after_factor(P, ax.aux);
   hipLaunchKernelGGL(k_sb_gram, dim3(P.nchains), dim3(128), 0, ax.aux, P);
   (void)hipEventRecord(ax.ev_g, ax.aux);
@@ -664,11 +698,13 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
   hipLaunchKernelGGL(k_gather_rhs, dim3((cnt + 255) / 256), dim3(256), 0, st, P, early ? 0 : 2);
   if (P.vi) {
     if (early) { (void)hipStreamWaitEvent(st, ax.ev_cf, 0); ax.cf_pending = false; }
-    else hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, st, P);
+    else {
+      hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, st, P);
+      hipLaunchKernelGGL(k_sb_propagator, dim3((81 * P.K + 255) / 256), dim3(256), 0, st, P);
+    }
     hipLaunchKernelGGL(k_sb_chain_cols, dim3(P.cc_n), dim3(256), 0, st, P);
     if (early) (void)hipStreamWaitEvent(st, ax.ev_g, 0);  // z (forward sweep) and the Gramians, both long done by now
     else {
-      hipLaunchKernelGGL(k_sb_propagator, dim3((81 * P.K + 255) / 256), dim3(256), 0, st, P);
       launch_sb_after_factor(P, st);
       hipLaunchKernelGGL(k_sb_gram, dim3(P.nchains), dim3(128), 0, st, P);
     }

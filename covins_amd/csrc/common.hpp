@@ -202,7 +202,7 @@ void launch_zero_pose_system(const DevProblem& P, hipStream_t st);  // arrow buf
 // (profiling only) one timed event pair around every bulk trailing-update launch
 struct CholAux {
   hipStream_t aux = nullptr, mid = nullptr, head = nullptr;
-  hipEvent_t ev_sb = nullptr, ev_cf = nullptr, ev_g = nullptr;  // speed-bias rows ready | chain factor done | Gramians done (early, on aux)
+  hipEvent_t ev_sb = nullptr, ev_cf = nullptr, ev_g = nullptr, ev_z = nullptr;  // speed-bias rows ready | chain factor done | Gramians done (mid) | chain sweeps done (aux)
   bool cf_pending = false;
   std::vector<hipEvent_t> ev, prof_ev, panel_ev;  // panel_ev: start of every big panel on the main stream (COVGPU_TRACE_PANELS=1)
   std::vector<double> prof_flops;

@@ -60,6 +60,7 @@ COV_DEV void wave_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
+COV_DEV void lds_barrier2() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr int kCfChunk = 8;                     // positions staged per LDS buffer
 constexpr int kCfPerLane = (kCfChunk * 81 + 63) / 64;
 // One wave per IMU chain, sequential over keyframes — the block-bidiagonal Cholesky factor only (z = L_A^-1 b_s is a LINEAR
@@ -432,12 +433,12 @@ __global__ __launch_bounds__(128) void k_sb_gram(DevProblem P) {
     double (&M)[81] = sM[it & 1];
     if (act) M[tid] = m0;
     m0 = m1; m1 = m2; m2 = m3; m3 = mload(q - 3);
-    __syncthreads();
+    lds_barrier2();  // LDS traffic only: the GI stores of the previous step need not be acknowledged
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) t += sG[9 * a + k] * M[9 * k + b];   // T = (I + G_{q+1}) M
     if (act) sT[tid] = t;
-    __syncthreads();
+    lds_barrier2();  // LDS traffic only: the GI stores of the previous step need not be acknowledged
     double g = eye;
 #pragma unroll
     for (int k = 0; k < 9; ++k) g += M[9 * k + a] * sT[9 * k + b];   // I + M^T T
@@ -684,11 +685,13 @@ void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& 
   hipLaunchKernelGGL(k_sb_chain_factor, dim3(P.nchains), dim3(64), 0, ax.aux, P);
   hipLaunchKernelGGL(k_sb_propagator, dim3((81 * P.K + 255) / 256), dim3(256), 0, ax.aux, P);  // k_sb_chain_cols' tail marches with it
   (void)hipEventRecord(ax.ev_cf, ax.aux);
-  // z = L_A^-1 b_s (a linear recurrence, k_sb_sweep) and the Gramians need the factor only: they follow on the auxiliary
-  // stream, underneath k_sb_chain_cols
+  // z = L_A^-1 b_s, x0 = A^-1 b_s (linear recurrences, k_sb_sweep) and the Gramians need the factor only: the sweeps follow
+  // on the auxiliary stream, the Gramians run beside them on a third one, both underneath k_sb_chain_cols
   launch_sb_after_factor(P, ax.aux);
-  hipLaunchKernelGGL(k_sb_gram, dim3(P.nchains), dim3(128), 0, ax.aux, P);
-  (void)hipEventRecord(ax.ev_g, ax.aux);
+  (void)hipEventRecord(ax.ev_z, ax.aux);
+  (void)hipStreamWaitEvent(ax.mid, ax.ev_cf, 0);
+  hipLaunchKernelGGL(k_sb_gram, dim3(P.nchains), dim3(128), 0, ax.mid, P);
+  (void)hipEventRecord(ax.ev_g, ax.mid);
   ax.cf_pending = true;
 }
 
@@ -703,15 +706,16 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
       hipLaunchKernelGGL(k_sb_propagator, dim3((81 * P.K + 255) / 256), dim3(256), 0, st, P);
     }
     hipLaunchKernelGGL(k_sb_chain_cols, dim3(P.cc_n), dim3(256), 0, st, P);
-    if (early) (void)hipStreamWaitEvent(st, ax.ev_g, 0);  // z (forward sweep) and the Gramians, both long done by now
+    if (early) (void)hipStreamWaitEvent(st, ax.ev_g, 0);  // Gramians (third stream)
     else {
       launch_sb_after_factor(P, st);
       hipLaunchKernelGGL(k_sb_gram, dim3(P.nchains), dim3(128), 0, st, P);
     }
+    hipLaunchKernelGGL(k_yty_semisep, dim3(P.K), dim3(256), 0, st, P);
+    if (early) (void)hipStreamWaitEvent(st, ax.ev_z, 0);  // z, x0 (chain sweeps, auxiliary stream)
     static const bool rhs_from_y = [] { const char* e = getenv("COVGPU_POSE_RHS_Y"); return e && e[0] == '1'; }();  // 1: round-2a product with Y
     if (rhs_from_y) hipLaunchKernelGGL(k_pose_rhs, dim3((8 * 6 * P.K + 255) / 256), dim3(256), 0, st, P);
     else hipLaunchKernelGGL(k_pose_rhs_sweep, dim3((6 * P.K + 255) / 256), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(k_yty_semisep, dim3(P.K), dim3(256), 0, st, P);
   }
   if (pgo != nullptr) launch_pgo_block_solve(P, *pgo, st, ax);  // pose graph: block-arrow elimination (k_pgo.hip)
   else if (P.arrow) launch_arrow_solve(P, st, ax);                // GBA on a fused multi-agent map: block-arrow elimination (k_arrow.hip)

@@ -165,7 +165,7 @@ enum { SC_COST = 0, SC_JV2 = 1, SC_GG = 2, SC_GN2 = 3, SC_GDOT = 4, SC_GMAX = 5,
 
 struct CholAux;
 // ---- launchers (each enqueues on `st`, no synchronisation)
-void launch_lm_build(const DevProblem& P, double mu, hipStream_t st);     // reprojection -> Hll, g, S (Schur), bred, cost
+void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared = nullptr);  // reprojection -> Hll, g, S (Schur), bred, cost
 void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st);
 void launch_obs_jvp(const DevProblem& P, const double* v_all, hipStream_t st);  // scal[SC_JV2] += sum |J v|^2
 void launch_obs_cost(const DevProblem& P, const double* pose, const double* lm, hipStream_t st);  // scal[SC_COST] +=
@@ -202,6 +202,7 @@ void launch_zero_pose_system(const DevProblem& P, hipStream_t st);  // arrow buf
 // (profiling only) one timed event pair around every bulk trailing-update launch
 struct CholAux {
   hipStream_t aux = nullptr, mid = nullptr, head = nullptr;
+  hipEvent_t ev_fill = nullptr;  // pose system cleared (head stream, beside the linearisation)
   hipEvent_t ev_sb = nullptr, ev_cf = nullptr, ev_g = nullptr, ev_z = nullptr;  // speed-bias rows ready | chain factor done | Gramians done (mid) | chain sweeps done (aux)
   bool cf_pending = false;
   std::vector<hipEvent_t> ev, prof_ev, panel_ev;  // panel_ev: start of every big panel on the main stream (COVGPU_TRACE_PANELS=1)

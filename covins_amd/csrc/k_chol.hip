@@ -704,6 +704,7 @@ void CholAux::init() {
   if (!ev_cf) (void)hipEventCreateWithFlags(&ev_cf, hipEventDisableTiming);
   if (!ev_g) (void)hipEventCreateWithFlags(&ev_g, hipEventDisableTiming);
   if (!ev_z) (void)hipEventCreateWithFlags(&ev_z, hipEventDisableTiming);
+  if (!ev_fill) (void)hipEventCreateWithFlags(&ev_fill, hipEventDisableTiming);
 }
 void CholAux::tri_clear() {
   for (int* p : tri_list) if (p) (void)hipFree(p);
@@ -722,6 +723,7 @@ void CholAux::destroy() {
   if (ev_cf) { (void)hipEventDestroy(ev_cf); ev_cf = nullptr; }
   if (ev_g) { (void)hipEventDestroy(ev_g); ev_g = nullptr; }
   if (ev_z) { (void)hipEventDestroy(ev_z); ev_z = nullptr; }
+  if (ev_fill) { (void)hipEventDestroy(ev_fill); ev_fill = nullptr; }
   cf_pending = false;
   if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
 }

@@ -10,6 +10,8 @@
 //   gemm_abt<SYRK>   A22 <- A22 - A21 A21^T, one 128x128 tile per workgroup, v_mfma_f64_16x16x4_f64,
 //                    4 waves x (4x4) MFMA tiles, K staged through LDS in chunks of 32 with register prefetch.
 // Triangular solves reuse the stored L_pp^-1 blocks: one small launch per panel.
+#include <algorithm>
+
 #include "common.hpp"
 #include "dev_math.hpp"
 #include "reduce.hpp"
@@ -42,15 +44,19 @@ __global__ __launch_bounds__(256) void k_finalize_diag(DevProblem P, double mu, 
 }
 
 // fixed-order sum of one slot's partials -> scal[slot]
-__global__ __launch_bounds__(256) void k_part_finish(DevProblem P, int slot0) {
-  __shared__ double sc[256];
+// (1024 threads, four independent partial sums each: with 256 threads walking ~73 partials apiece in one dependent chain
+//  this tiny kernel took 20 us, five times per trust-region iteration)
+__global__ __launch_bounds__(1024) void k_part_finish(DevProblem P, int slot0) {
+  __shared__ double sc[1024];
   const int slot = slot0 + blockIdx.x;
   const double* src = P.part + (size_t)slot * P.part_n;
-  double acc = 0.0;
-  for (int k = threadIdx.x; k < P.part_n; k += 256) acc += src[k];
-  sc[threadIdx.x] = acc;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int k = threadIdx.x;
+  for (; k + 3072 < P.part_n; k += 4096) { a0 += src[k]; a1 += src[k + 1024]; a2 += src[k + 2048]; a3 += src[k + 3072]; }
+  for (; k < P.part_n; k += 1024) a0 += src[k];
+  sc[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+  for (int s2 = 512; s2 > 0; s2 >>= 1) {
     if (threadIdx.x < s2) sc[threadIdx.x] += sc[threadIdx.x + s2];
     __syncthreads();
   }
@@ -177,12 +183,13 @@ void launch_part_clear(const DevProblem& P, int slot0, int nslots, hipStream_t s
   hipMemsetAsync(P.part + (size_t)slot0 * P.part_n, 0, (size_t)nslots * P.part_n * sizeof(double), st);
 }
 void launch_part_finish(const DevProblem& P, int slot0, int nslots, hipStream_t st) {
-  hipLaunchKernelGGL(k_part_finish, dim3(nslots), dim3(256), 0, st, P, slot0);
+  hipLaunchKernelGGL(k_part_finish, dim3(nslots), dim3(1024), 0, st, P, slot0);
 }
 void launch_dogleg_stats(const DevProblem& P, hipStream_t st) {
   launch_part_clear(P, SC_GG, 3, st);                       // GG, GN2, GDOT are adjacent slots
   hipMemsetAsync(P.scal + SC_GMAX, 0, sizeof(double), st);
-  hipLaunchKernelGGL(k_dogleg_stats, dim3(vec_grid(P.N)), dim3(256), 0, st, P);
+  // (at most 256 workgroups: every wave ends with an atomic max on one address — 4500 of them took 45 us)
+  hipLaunchKernelGGL(k_dogleg_stats, dim3(std::min(vec_grid(P.N), 256)), dim3(256), 0, st, P);
   launch_part_finish(P, SC_GG, 3, st);
 }
 void launch_cauchy_vec(const DevProblem& P, hipStream_t st) {

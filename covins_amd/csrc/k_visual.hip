@@ -402,11 +402,12 @@ static inline int stream_grid(int n) {
 
 constexpr int kG = 16;
 
-void launch_lm_build(const DevProblem& P, double mu, hipStream_t st) {
-  if (P.L == 0) return;
+void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared) {
+  if (P.L == 0) { if (pose_system_cleared) (void)hipStreamWaitEvent(st, pose_system_cleared, 0); return; }
   const int groups = kBuildThreads / kG, nblk = (P.L + groups - 1) / groups;
-  hipLaunchKernelGGL(k_lm_lin<kG>, dim3(nblk), dim3(kBuildThreads), 0, st, P, mu);
+  hipLaunchKernelGGL(k_lm_lin<kG>, dim3(nblk), dim3(kBuildThreads), 0, st, P, mu);  // writes per-observation records only
   hipLaunchKernelGGL(k_cost_finish, dim3(1), dim3(256), 0, st, P, nblk);
+  if (pose_system_cleared) (void)hipStreamWaitEvent(st, pose_system_cleared, 0);     // first writers of the pose system follow
   hipLaunchKernelGGL(k_kf_reduce, dim3(P.K), dim3(64), 0, st, P);
   if (P.npairs) hipLaunchKernelGGL(k_pair_blocks, dim3((P.npairs + kPairsPerWg - 1) / kPairsPerWg), dim3(kPairLanes * kPairsPerWg), 0, st, P);
 }

@@ -734,6 +734,14 @@ static int chol_failed(covgpu_context* c) { int f; std::memcpy(&f, c->h_scal + S
 static void enqueue_build(covgpu_context* c, double mu) {
   const DevProblem& P = c->P;
   if (c->profiling) (void)hipEventRecord(c->ev[0], c->st);
+  // the big fill of the pose system (0.6 GB of arrow buffers on the 5-agent map) runs on its own stream beside the inertial
+  // kernels and the landmark linearisation, which only write per-factor / per-observation records; its first writers
+  // (k_kf_reduce ...) wait for it. Every reader of the previous system has finished: each linear solve ends with a host sync.
+  c->chol.init();
+  (void)hipEventRecord(c->chol.ev_fill, c->st);
+  (void)hipStreamWaitEvent(c->chol.head, c->chol.ev_fill, 0);
+  launch_zero_pose_system(P, c->chol.head);
+  (void)hipEventRecord(c->chol.ev_fill, c->chol.head);
   launch_zero_system(P, c->st);
   // inertial factors first: the speed-bias blocks are then final, and the (serial, one wave per IMU chain) chain
   // factorisation runs on the auxiliary stream underneath the landmark pass
@@ -743,8 +751,7 @@ static void enqueue_build(covgpu_context* c, double mu) {
     launch_finalize_diag(P, mu, 1, c->st);
     launch_sb_chain_factor_early(P, c->st, c->chol);
   }
-  launch_zero_pose_system(P, c->st);
-  launch_lm_build(P, mu, c->st);
+  launch_lm_build(P, mu, c->st, c->chol.ev_fill);
   launch_imu_gather(P, 0, c->st);  // pose-dimension part: adds onto the blocks k_kf_reduce assigned (fixed order: visual, inertial, loop)
   launch_edge_build(P, c->st);
   launch_edge_gather(P, c->st);

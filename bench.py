@@ -201,11 +201,11 @@ def main():
                                "achieved": b_build / (prof["build_ms"] / max(prof["n_build"], 1) * 1e-3) / 1e9 if prof["build_ms"] > 0 else 0.0,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "nnzS_blocks": nnzS,
-                               "note": "whole linearise+Schur pass (a dozen kernels; the serial IMU chain factorisation runs on the auxiliary stream underneath) "
-                                       "against SURVEY.md 8(d)'s algorithmic bytes (inputs once, H/g blocks, S blocks once). The pass really moves "
-                                       "more: zero-fill of the arrow buffers, 600-B per-observation records written and gathered back by "
-                                       "k_pair_blocks (1.45 GB per launch, profiles/r02f_pmc_hbm_traffic.csv) - the price of the atomic-free, "
-                                       "bit-reproducible build (DESIGN.md 4.1, 6.4)"},
+                               "note": "whole linearise+Schur pass (a dozen kernels; the serial IMU chain factorisation runs on the auxiliary stream underneath, "
+                                       "the 0.6 GB fill of the arrow buffers on a third) against SURVEY.md 8(d)'s algorithmic bytes (inputs once, H/g "
+                                       "blocks, S blocks once). The pass really moves more: the fill, 600-B per-observation records written by k_lm_lin "
+                                       "and gathered back by k_kf_reduce / k_pair_blocks (~1.5 GB per iteration) - the price of the atomic-free, "
+                                       "bit-reproducible build (DESIGN.md 4.1, 6)"},
         }
         out["roofline_build"]["frac"] = out["roofline_build"]["achieved"] / HBM_PEAK_GBS
         # whole Optimization::GlobalBundleAdjustment call as backend.cpp:141-156 issues it (outlier round of 5 iterations +

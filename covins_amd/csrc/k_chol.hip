@@ -8,9 +8,11 @@
 //   * tiles are 128 x 128; big panels are 256 wide (two tile columns). A rank-256 trailing update reads and
 //     writes every C tile once per 8.4 MFLOP (16 flop/B on the C stream) — a rank-128 update (8 flop/B)
 //     would be HBM-bound below ~60 % of the FP64 MFMA peak.
-//   * panel factorisation: potrf_inv (one workgroup: register-resident Cholesky of the 128x128 diagonal block and
-//     its explicit inverse) -> TRSM as an MFMA GEMM against L11^-1 -> rank-128 update of the panel's second tile
-//     column -> potrf_inv -> TRSM.
+//   * panel factorisation (default, k_panel.hip): ONE workgroup factors the whole 256x256 diagonal block (register-resident
+//     16x16 tiles, software-pipelined around a single wave that carries the serial chain), the rows below follow by block
+//     forward substitution against the sixteen 16x16 block inverses it leaves — three dependent launches per panel.
+//     COVGPU_PANEL=0 selects the earlier chain kept in this file: potrf_inv (128x128 block + explicit inverse) -> TRSM as an
+//     MFMA GEMM against L11^-1 -> rank-128 update of the panel's second tile column -> potrf_inv -> TRSM (six launches).
 //   * trailing update k_gemm_abt<SYRK_TRI>: C -= A_i A_j^T, one 128x128 tile per workgroup, 4 waves x (4x4)
 //     v_mfma_f64_16x16x4_f64 tiles, accumulators initialised FROM the C tile (so the epilogue is store-only),
 //     K staged through LDS in chunks of 16 with register prefetch. Workgroup ids are decoded XCD-aware: the 64

@@ -10,12 +10,17 @@
 // 15.6x fewer. This is what a fill-reducing sparse Cholesky (the reference's SPARSE_SCHUR -> CHOLMOD,
 // optimization_be.cpp:561) obtains from the same sparsity; the result is the exact solve, just reordered.
 //
-//   sb_chain_factor   one wave per IMU chain, sequential over keyframes: L_kk L_kk^T = Ad_k - Lsub Lsub^T,
-//                     Lsub_{k+1} = Ae_{k+1} L_kk^-T, z = L_A^-1 b_s (operands staged through LDS a chunk ahead)
-//   sb_chain_cols     Y = L_A^-1 B, one thread per pose dimension marching down its chain (K-major, coalesced)
-//   pose_rhs          b'_p = b_p - Y^T z
-//   (k_chol.hip)      C -= Y^T Y restricted to each tile pair's common chain segment; dense Cholesky of C'
-//   sb_backsolve      x_s = A^-1 (b_s - B x_p) with the stored bidiagonal factor, one wave per chain
+//   sb_chain_factor   one wave per IMU chain, sequential over keyframes, the factor only: L_kk L_kk^T = Ad_k - Lsub Lsub^T
+//                     and L_kk^-1 in one sweep, Lsub_{k+1} = Ae_{k+1} L_kk^-T (operands staged through LDS a chunk ahead)
+//   sb_sweep<+1|-1>   the two LINEAR recurrences along a chain as one 9x9 product per step: z = L_A^-1 b_s (forward) and
+//                     x = L_A^-T u (backward); their matrices depend on the factor only (sb_sweep_mat), the vectors are
+//                     parallel products (sb_sweep_vec)
+//   sb_chain_cols     Y = L_A^-1 B on the matrix core, one wave per 16-column tile marching down its chain; past the
+//                     injection rows with the propagator M_pos = -Ldinv_pos Lsub_pos (one product per position)
+//   pose_rhs_sweep    b'_p = b_p - B^T A^-1 b_s from the sweeps (no pass over Y)
+//   sb_gram, yty_semisep   C -= Y^T Y through the semiseparable structure (O(K^2), one pass over Y)
+//   (k_chol.hip, k_panel.hip, k_arrow.hip)   dense / block-arrow Cholesky of C'
+//   sb_fwd_matvec + sb_sweep<-1>   x_s = A^-1 (b_s - B x_p): u = z - Y x_p in parallel, then the backward sweep
 #include <cstdlib>
 
 #include "common.hpp"

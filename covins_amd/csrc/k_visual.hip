@@ -11,12 +11,13 @@
 //   k_lm_lin       one G-lane sub-wave group per landmark (G = 16: tracks average ~10 observations), lane = observation.
 //                  Jacobians live in VGPRs only; H_ll / g_l are reduced with shuffle butterflies inside the group; per
 //                  observation one record {W = Jp^T Jl, Y = W H_ll^-1, D = Jp^T Jp - Y W^T, diag, Jp^T r, Y g_l} goes to HBM.
-//   k_kf_reduce    one wave per keyframe: fixed-order sum of its observations' records -> diagonal 6x6 block of the pose
-//                  system, gradient, reduced right-hand side, diag(J^T J).
-//   k_pair_blocks  one wave per covisible keyframe pair (host-built lists, static per problem): C[i,j] = -sum Y_i W_j^T
-//                  with plain stores. Every entry has exactly one writer and a fixed summation order: two solves of the
-//                  same problem are bit-identical. (The first version accumulated the 6x6 blocks with FP64 atomics:
-//                  11.1 ms and run-to-run rounding differences; these three passes take 1.6 ms.)
+//   k_kf_reduce    one wave per keyframe, lanes over its observations: fixed-order sum of their records -> diagonal 6x6 block
+//                  of the pose system, gradient, reduced right-hand side, diag(J^T J).
+//   k_pair_blocks  sixteen lanes per covisible keyframe pair (host-built lists, static per problem), lanes over the common
+//                  landmarks: C[i,j] = -sum Y_i W_j^T with plain stores. Every entry has exactly one writer and a fixed
+//                  summation order: two solves of the same problem are bit-identical. (The first version accumulated the
+//                  6x6 blocks with FP64 atomics: 11.1 ms and run-to-run rounding differences; these three passes take
+//                  0.66 ms on the 5-agent map.)
 //   obs_*          one thread per observation over the SoA stream (cost, J*v products, test dumps).
 // All writes to the pose system go through c_entry (common.hpp): dense matrix or block-arrow buffers.
 #include "common.hpp"
@@ -106,9 +107,9 @@ constexpr int kBuildThreads = 256;
 // Landmark elimination in three deterministic, atomic-free passes:
 //   k_lm_lin      (landmark-major) per landmark H_ll, g_l reduced in-group, damped inverse; per observation a
 //                 record {W_a = Jp^T Jl, Y_a = W_a Hinv, D_a = Jp^T Jp - Y_a W_a^T, diag(Jp^T Jp), Jp^T r, Y_a g_l}
-//   k_kf_reduce   (keyframe-major) one wave per keyframe sums its observations' records in a fixed order ->
-//                 diagonal block of C, gradient, reduced right-hand side, diag(J^T J)
-//   k_pair_blocks (covisible keyframe pair-major) one wave per pair (i > j in chain-major order):
+//   k_kf_reduce   (keyframe-major) one wave per keyframe sums its observations' records in a fixed order (lane = observation,
+//                 partial sums through LDS) -> diagonal block of C, gradient, reduced right-hand side, diag(J^T J)
+//   k_pair_blocks (covisible keyframe pair-major) sixteen lanes per pair (i > j in chain-major order), lane = common landmark:
 //                 C[i,j] = -sum over common landmarks of Y_i W_j^T, written with plain stores
 // Every entry of C is produced by exactly one wave in a fixed summation order: run-to-run bit-identical
 // (SURVEY.md §7 "irregular graph": determinism needed for parity tests) and no FP64 atomic contention.

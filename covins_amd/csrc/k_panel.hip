@@ -57,6 +57,14 @@ constexpr size_t kPanelLds = (size_t)(2 * PROWS * PP + 256 + 256 + 48 + 16 * PP 
 // and nobody reads them back inside the kernel).
 COV_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// lane id from the hardware, inside a volatile asm: it is re-issued where it is used (two VALU instructions) instead of being
+// computed once, hoisted out of the step loop and reloaded from scratch — a memory latency on the serial chain per reload
+COV_DEV int hw_lane_id() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 // acc (tile (i,k), accumulator layout: row = (lane>>4) + 4 reg, col = lane & 15) -= P_i P_k^T for the 16-column panel `pan`
 COV_DEV v4f64 tile_update(v4f64 acc, const double* pan, int i, int k, int fr, int fk) {
   const double* pa = pan + (PB * i + fr) * PP + 4 * fk;
@@ -121,8 +129,8 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
   double* sdd = rowW + 16;      // the block's 16 pivots
   double* sDg = sdd + 16;       // [16][PP] the diagonal tile wave 0 takes over next (panels before the current one applied)
   double* sZero = sDg + 16 * PP;  // [16] zeros (A operand of tiles that take no update, tile_update4)
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = lane & 15, fk = lane >> 4;
+  const int tid0 = threadIdx.x, lane = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int fr0 = lane & 15, fk0 = lane >> 4;
   const int n = PB * nb;
   double* Mg = M + (size_t)k0 * ld + k0;
   PPROBE_DECL();
@@ -132,8 +140,12 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
   int tik[NSLOT];
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
-    int t = s * NTW + (wave - 1) + 1, k = 1;  // (+1: tile (1,1) belongs to wave 0 from the start, see the loop below)
-    bool ok = wave >= 1 && t < 120;
+    // Wave 4 shares SIMD 0 with the chain wave: it gets the first eleven tiles only (block column 1: one update each, 2 % of
+    // the work), the other six waves deal the remaining 108 round-robin — the chain wave's sweep runs 15 % faster for it.
+    int t, k = 1;
+    bool ok;
+    if (wave == 4) { t = s + 1; ok = s < 11; }
+    else { const int h = wave < 4 ? wave - 1 : wave - 2; t = 11 + s * 6 + h + 1; ok = wave >= 1 && t < 120; }
     if (ok) { while (t >= 16 - k) { t -= 16 - k; ++k; } }
     const int i = k + t;
     ok = ok && i < nb;
@@ -146,15 +158,15 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
   for (int s = 0; s < NSLOT; ++s) {
     const bool on = (tik[s] >> 8) != 99;
     const int ii = on ? (tik[s] & 255) : 1, kk = on ? (tik[s] >> 8) : 1;
-    const double* src = Mg + (size_t)(PB * ii + fk) * ld + PB * kk + fr;
+    const double* src = Mg + (size_t)(PB * ii + fk0) * ld + PB * kk + fr0;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const double v = src[(size_t)(4 * rg) * ld];
-      acc[s][rg] = (!on || (ii == kk && fr > fk + 4 * rg)) ? 0.0 : v;
+      acc[s][rg] = (!on || (ii == kk && fr0 > fk0 + 4 * rg)) ? 0.0 : v;
     }
   }
   {
-    const int row = tid >> 1, half = tid & 1;
+    const int row = tid0 >> 1, half = tid0 & 1;
     if (row < n) {
       double v[8];
 #pragma unroll
@@ -162,10 +174,10 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
 #pragma unroll
       for (int c = 0; c < 8; ++c) sP[row * PP + 8 * half + c] = v[c];
     }
-    if (tid < PROWS) sRhs[tid] = (rhs != nullptr && tid < n) ? rhs[k0 + tid] : 0.0;
-    if (tid < 16) sZero[tid] = 0.0;
-    if (tid < 256 && nb > 1) {  // diagonal tile (1,1): wave 0 takes it over at step 0 (see below)
-      const int rr = tid >> 4, cc = tid & 15;
+    if (tid0 < PROWS) sRhs[tid0] = (rhs != nullptr && tid0 < n) ? rhs[k0 + tid0] : 0.0;
+    if (tid0 < 16) sZero[tid0] = 0.0;
+    if (tid0 < 256 && nb > 1) {  // diagonal tile (1,1): wave 0 takes it over at step 0 (see below)
+      const int rr = tid0 >> 4, cc = tid0 & 15;
       sDg[rr * PP + cc] = (cc <= rr) ? Mg[(size_t)(PB + rr) * ld + PB + cc] : 0.0;
     }
   }
@@ -183,12 +195,17 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
     double* cur = sP + (j & 1) * PROWS * PP;          // block column j, rows 16 j .. n
     double* oth = sP + ((j + 1) & 1) * PROWS * PP;    // block column j+1 (being assembled)
     const int o = PB * j;
+    // every per-lane constant of the step is rebuilt from the hardware lane id here: kept across the loop they are spilled
+    // (the accumulator tiles take the registers) and every reload is a memory latency, several of them on wave 0's chain
+    const int lq = hw_lane_id();
+    const int fr = lq & 15, fk = lq >> 4, tid = 64 * wave + lq;
     const long long tq0 = PPROBE_T0();
     if (wave == 0) {
       // ---- (a): factor the diagonal block and form its inverse
       __builtin_amdgcn_s_setprio(3);
-      int ln = lane;
-      asm volatile("" : "+v"(ln));  // per-lane invariants of this block are recomputed every step rather than hoisted and spilled
+      // lane id from the hardware (v_mbcnt): per-lane invariants of this block are recomputed every step rather than hoisted and
+      // spilled — a reload from scratch at the head of every step costs the chain a memory latency
+      const int ln = hw_lane_id();
       const int r = ln >> 2, q = ln & 3;
       double a[4], w[4];
 #pragma unroll
@@ -226,7 +243,7 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] -= tw * xr[e];
       }
-      if (bad && lane == 0) atomicOr(flag, 1);
+      if (bad && ln == 0) atomicOr(flag, 1);
       // scale factors 1/sqrt(d) from the saved pivots, once: L = A diag(d)^-1/2 (by column), X = diag(d)^-1/2 W (by row)
       __builtin_amdgcn_wave_barrier();
       double rsc[4], rsr;
@@ -256,14 +273,14 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
     PPROBE_ACC(1, tq0);
     const long long tq1 = PPROBE_T0();
     if (wave == 0) {
-      if (lane < PB) {  // y_j = Dinv_j b_j
+      if (lq < PB) {  // y_j = Dinv_j b_j
         double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
 #pragma unroll
         for (int k = 0; k < PB; k += 4) {
-          y0 += sDv[lane * PB + k] * sRhs[o + k]; y1 += sDv[lane * PB + k + 1] * sRhs[o + k + 1];
-          y2 += sDv[lane * PB + k + 2] * sRhs[o + k + 2]; y3 += sDv[lane * PB + k + 3] * sRhs[o + k + 3];
+          y0 += sDv[lq * PB + k] * sRhs[o + k]; y1 += sDv[lq * PB + k + 1] * sRhs[o + k + 1];
+          y2 += sDv[lq * PB + k + 2] * sRhs[o + k + 2]; y3 += sDv[lq * PB + k + 3] * sRhs[o + k + 3];
         }
-        sRhs[o + lane] = (y0 + y1) + (y2 + y3);
+        sRhs[o + lq] = (y0 + y1) + (y2 + y3);
       }
       if (j + 1 < nb) {
         // X(j+1,j) = T(j+1,j) Dinv_j^T (in place in `cur`), then the next diagonal tile T(j+1,j+1) (in sDg, panels < j
@@ -327,7 +344,9 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
           for (int e = 0; e < 2; ++e) {
             const int i = pk[e] & 255, k = pk[e] >> 8;
             if (u[e] && (k == j + 1 || (k == j + 2 && i == k))) {
-              double* dstp = (i == k) ? sDg + fk * PP + fr : oth + (PB * i + fk) * PP + fr;
+              const int l2 = hw_lane_id();  // (not a spilled copy of the lane id)
+              const int fr2 = l2 & 15, fk2 = l2 >> 4;
+              double* dstp = (i == k) ? sDg + fk2 * PP + fr2 : oth + (PB * i + fk2) * PP + fr2;
 #pragma unroll
               for (int rg = 0; rg < 4; ++rg) dstp[4 * rg * PP] = acc[s + e][rg];
             }

@@ -67,6 +67,24 @@ __device__ __forceinline__ void diag_block(double* cur, double* colA, double* ro
     if (!(VAR & 1)) sDv[r * PB + 4 * q + e] = low ? w[e] * rsr : 0.0;
   }
 }
+// VAR 5: L only in the sweep (scale factors at the end), then X = L^-1 by column-parallel forward substitution: lane c owns
+// column c, every L entry is a broadcast LDS read, no cross-lane traffic
+__device__ __forceinline__ void inverse_after(const double* cur, const double* sinv, double* sDv, int lane) {
+  const int c = lane & 15;
+  double x[PB];
+#pragma unroll
+  for (int r = 0; r < PB; ++r) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < r; k += 2) { s0 += cur[r * PP + k] * x[k]; if (k + 1 < r) s1 += cur[r * PP + k + 1] * x[k + 1]; }
+    const double iv = sinv[r];
+    x[r] = (r == c) ? iv : (r > c ? -(s0 + s1) * iv : 0.0);
+  }
+  if (lane < PB) {
+#pragma unroll
+    for (int r = 0; r < PB; ++r) sDv[r * PB + c] = x[r];
+  }
+}
 // VAR 4: the round-2a formulation (row per lane, v_readlane broadcasts), no inverse
 __device__ __forceinline__ double rdl(double v, int l) {
   const long long b = __double_as_longlong(v);
@@ -105,7 +123,14 @@ __global__ __launch_bounds__(64) void k_diag(const double* A, double* Lout, doub
     __syncthreads();
     double x = cur[lane];
     const long long t0 = tick(x);
-    if (VAR == 4) diag_block_rl(cur, lane); else diag_block<VAR>(cur, colA, rowW, sDv, sdd, lane);
+    if (VAR == 4) diag_block_rl(cur, lane);
+    else if (VAR == 5) {
+      diag_block<3>(cur, colA, rowW, sDv, sdd, lane);
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 16) { double d = sdd[lane]; double rs = __builtin_amdgcn_rsq(d); rs = rs * (1.5 - 0.5 * d * rs * rs); colA[lane] = rs * (1.5 - 0.5 * d * rs * rs); }
+      __builtin_amdgcn_wave_barrier();
+      inverse_after(cur, colA, sDv, lane);
+    } else diag_block<VAR>(cur, colA, rowW, sDv, sdd, lane);
     __syncthreads();
     x = cur[lane] + x;
     const long long t1 = tick(x);
@@ -126,8 +151,8 @@ int main() {
   double *dA, *dL, *dX; long long* dc;
   hipMalloc(&dA, 2048); hipMalloc(&dL, 2048); hipMalloc(&dX, 2048); hipMalloc(&dc, 64);
   hipMemcpy(dA, A.data(), 2048, hipMemcpyHostToDevice);
-  const char* nm[5] = {"LDS-column form, L + inverse (k_panel v2)", "LDS-column form, L only", "v2 with scale factors at the end", "L only, scale factors at the end", "row per lane + v_readlane, L only (round 2a)"};
-  for (int v = 0; v < 5; ++v) {
+  const char* nm[6] = {"LDS-column form, L + inverse (k_panel v2)", "LDS-column form, L only", "v2 with scale factors at the end", "L only, scale factors at the end", "row per lane + v_readlane, L only (round 2a)", "L only in the sweep, inverse by column substitution after it"};
+  for (int v = 0; v < 6; ++v) {
     hipMemset(dX, 0, 2048);
     switch (v) {
       case 0: hipLaunchKernelGGL(k_diag<0>, dim3(1), dim3(64), 0, 0, dA, dL, dX, dc); break;
@@ -135,13 +160,14 @@ int main() {
       case 2: hipLaunchKernelGGL(k_diag<2>, dim3(1), dim3(64), 0, 0, dA, dL, dX, dc); break;
       case 3: hipLaunchKernelGGL(k_diag<3>, dim3(1), dim3(64), 0, 0, dA, dL, dX, dc); break;
       case 4: hipLaunchKernelGGL(k_diag<4>, dim3(1), dim3(64), 0, 0, dA, dL, dX, dc); break;
+      case 5: hipLaunchKernelGGL(k_diag<5>, dim3(1), dim3(64), 0, 0, dA, dL, dX, dc); break;
     }
     hipDeviceSynchronize();
     std::vector<double> L(256), X(256); long long c;
     hipMemcpy(L.data(), dL, 2048, hipMemcpyDeviceToHost); hipMemcpy(X.data(), dX, 2048, hipMemcpyDeviceToHost); hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
     double eL = 0, eX = 0;
     for (int r = 0; r < 16; ++r) for (int cc = 0; cc <= r; ++cc) eL = fmax(eL, fabs(L[r * 16 + cc] - H[r * 16 + cc]));
-    if (!(v & 1) && v != 4) for (int r = 0; r < 16; ++r) for (int cc = 0; cc < 16; ++cc) { double s = 0; for (int k = 0; k < 16; ++k) s += X[r * 16 + k] * (k >= cc ? H[k * 16 + cc] : 0.0); eX = fmax(eX, fabs(s - (r == cc))); }
+    if ((!(v & 1) && v != 4) || v == 5) for (int r = 0; r < 16; ++r) for (int cc = 0; cc < 16; ++cc) { double s = 0; for (int k = 0; k < 16; ++k) s += X[r * 16 + k] * (k >= cc ? H[k * 16 + cc] : 0.0); eX = fmax(eX, fabs(s - (r == cc))); }
     printf("%-48s %6lld cycles = %.2f us   max|L-L_host| %.2e  max|X L - I| %.2e\n", nm[v], c, c / 2400.0, eL, eX);
   }
   return 0;

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <vector>
 #include "../covins_amd/csrc/k_chol.hip"
+#include "../covins_amd/csrc/k_panel.hip"  // (k_chol.hip schedules its kernels)
 
 using namespace covgpu;
 

@@ -70,6 +70,7 @@ struct DevProblem {
 
   // keyframe ordering of the linear system: IMU chains (one per agent) laid out back to back
   int nchains;
+  int max_chain_len;  // keyframes of the longest chain (grid of k_yty_semisep)
   int* perm;        // [K]   keyframe -> position in chain-major order (identity when !vi)
   int* pos_kf;      // [K]   position -> keyframe
   int* chain_ptr;   // [nchains+1] positions of each chain

@@ -452,12 +452,16 @@ __global__ __launch_bounds__(128) void k_sb_gram(DevProblem P) {
   }
 }
 
-// One workgroup per pose j: C[rows 6j..6j+5, cols of poses <= j in the chain] -= W_j^T Y[rows 9(j-1) .. 9(j+2), cols]
-// with W_j = [y_j(j-1); y_j(j); (I + G_{j+1}) y_j(j+1)] (27 x 6, built in LDS first).
+// Workgroup (j, chunk): C[rows 6j..6j+5, 256 columns of the poses <= j in the chain] -= W_j^T Y[rows 9(j-1) .. 9(j+2), cols]
+// with W_j = [y_j(j-1); y_j(j); (I + G_{j+1}) y_j(j+1)] (27 x 6, built in LDS first — every chunk rebuilds it, 162 short
+// dot products against 256 x 27 loads). One workgroup per pose walked up to twelve column chunks for the last poses of a
+// chain and one for the first: the launch ended with a long tail of a few busy workgroups.
 __global__ __launch_bounds__(256) void k_yty_semisep(DevProblem P) {
   __shared__ double sW[27][6];
   const int j = blockIdx.x, tid = threadIdx.x;
   const int p1 = P.pos_chain_end[j], p0 = P.pos_chain_begin[j], ch = P.pos_chain[j];
+  const int c = 6 * p0 + 256 * (int)blockIdx.y + tid;
+  if (c - tid >= 6 * (j + 1)) return;  // whole chunk right of the pose's own columns (workgroup-uniform)
   const size_t ld = (size_t)P.Yld[ch];
   const double* const Yc = P.Y + P.Yoff[ch] - (size_t)9 * p0 * ld - (size_t)6 * p0;  // addressed with GLOBAL (row, column) below
   if (tid < 162) {
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(256) void k_yty_semisep(DevProblem P) {
   }
   __syncthreads();
   const int r0 = (j - 1 >= p0) ? 0 : 9, r1 = (j + 1 < p1) ? 27 : 18;  // row groups that exist in this chain
-  for (int c = 6 * p0 + tid; c < 6 * (j + 1); c += 256) {
+  if (c < 6 * (j + 1)) {
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int r = r0; r < r1; ++r) {
       const double y = Yc[(size_t)(9 * (j - 1) + r) * ld + c];
@@ -716,7 +720,7 @@ void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, C
       launch_sb_after_factor(P, st);
       hipLaunchKernelGGL(k_sb_gram, dim3(P.nchains), dim3(128), 0, st, P);
     }
-    hipLaunchKernelGGL(k_yty_semisep, dim3(P.K), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_yty_semisep, dim3(P.K, (6 * P.max_chain_len + 255) / 256), dim3(256), 0, st, P);
     if (early) (void)hipStreamWaitEvent(st, ax.ev_z, 0);  // z, x0 (chain sweeps, auxiliary stream)
     static const bool rhs_from_y = [] { const char* e = getenv("COVGPU_POSE_RHS_Y"); return e && e[0] == '1'; }();  // 1: round-2a product with Y
     if (rhs_from_y) hipLaunchKernelGGL(k_pose_rhs, dim3((8 * 6 * P.K + 255) / 256), dim3(256), 0, st, P);

@@ -376,6 +376,8 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(build_chains(p, vi, perm, pos_kf, chain_ptr));
   std::vector<int> chain_end(P.K);
   P.nchains = (int)chain_ptr.size() - 1;
+  P.max_chain_len = 1;
+  for (int ci = 0; ci < P.nchains; ++ci) P.max_chain_len = std::max(P.max_chain_len, chain_ptr[ci + 1] - chain_ptr[ci]);
   for (int c = 0; c < P.nchains; ++c)
     for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) chain_end[q] = chain_ptr[c + 1];
   P.reproj_loss_a = opt->reproj_loss_a; P.gravity = opt->gravity;

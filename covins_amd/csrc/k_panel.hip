@@ -207,19 +207,22 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
       // spilled — a reload from scratch at the head of every step costs the chain a memory latency
       const int ln = hw_lane_id();
       const int r = ln >> 2, q = ln & 3;
-      double a[4], w[4];
+      double a[4], w[4], lfin[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int e = 0; e < 4; ++e) { a[e] = cur[(o + r) * PP + 4 * q + e]; w[e] = (4 * q + e == r) ? 1.0 : 0.0; }
       bool bad = false;
 #pragma unroll
       for (int c = 0; c < PB; ++c) {
         const int qc = c >> 2, ec = c & 3;
-        int rr = r, c0 = 4 * q;
-        asm volatile("" : "+v"(rr), "+v"(c0));  // lane masks recomputed per pivot (hoisted they become ~100 spilled SGPR pairs)
-        if (q == qc) colA[r] = a[ec];
+        int rr = r, qq = q;
+        asm volatile("" : "+v"(rr), "+v"(qq));  // lane masks recomputed per pivot (hoisted they become ~100 spilled SGPR pairs)
+        // column c is final now: the lanes that own it publish it and keep their entry aside (lfin) — after that the
+        // register may be overwritten, so the trailing update below needs no per-column mask at all: entries of finished
+        // columns and of the strict upper triangle turn into garbage that is only ever read back into such entries
+        if (qq == qc) { colA[r] = a[ec]; lfin[ec] = a[ec]; }
         if (rr == c) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) rowW[c0 + e] = w[e];
+          for (int e = 0; e < 4; ++e) rowW[4 * q + e] = w[e];
         }
         __builtin_amdgcn_wave_barrier();
         const double d = colA[c];
@@ -238,8 +241,8 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
         const double rinv = fma(r1, e1, r1);
         const double t = mr * rinv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] -= ((c0 + e > c) ? t : 0.0) * cv[e];
-        const double tw = (rr > c) ? t : 0.0;
+        for (int e = 0; e < 4; ++e) a[e] -= t * cv[e];
+        const double tw = (rr > c) ? t : 0.0;  // rows <= c of W are final rows of the inverse
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] -= tw * xr[e];
       }
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const bool low = 4 * q + e <= r;
-        double lv = low ? a[e] * rsc[e] : 0.0, xv = low ? w[e] * rsr : 0.0;
+        double lv = low ? lfin[e] * rsc[e] : 0.0, xv = low ? w[e] * rsr : 0.0;
         asm volatile("" : "+v"(lv), "+v"(xv));  // selects, not a branch around the stores
         cur[(o + r) * PP + 4 * q + e] = lv;
         sDv[r * PB + 4 * q + e] = xv;

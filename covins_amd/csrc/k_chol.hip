@@ -107,6 +107,7 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
   constexpr int WTR = TSA / WGR, WTC = TSB / WGC;           // wave tile
   constexpr int NMR = WTR / 16, NMC = WTC / 16;             // MFMA tiles per wave
   constexpr int ZQ = (TSA == kTile && TSB == kTile) ? 1 : 4;  // quarter index and batch index share blockIdx.z
+  if (ZQ == 4) __builtin_amdgcn_s_setprio(3);  // quarter forms run on the serial chain only, beside bulk waves: issue priority over them
   int tri_entry = 0;
   if (MODE == MODE_SYRK_TRI && g.tri != nullptr) { tri_entry = g.tri[blockIdx.x]; if (tri_entry < 0) return; }
   const int zq = (int)blockIdx.z % ZQ,
@@ -899,7 +900,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       (void)hipEventRecord(e1[P], M);
       if (h1 > h0) {
         if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
-        launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M);
+        launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true);
       }
       (void)hipEventRecord(eH[P], M);
       if (T > h1) {

@@ -397,6 +397,7 @@ struct TrsmSubArgs {
   double* rhs; const double* yvec;   // forward substitution riding along: rhs[rows] -= X[rows, :] y[k0 ..)
   size_t bsM, bsL, bsR;
   const int* live; int tI;           // see GemmArgs (k_chol.hip)
+  int chain;                         // 1: launched on the serial chain — its waves raise their issue priority over the bulk update's
 };
 
 // X = A L^-T on a 16-row slab, L = the (16 NB)-order factor at (k0, k0). One wave, everything in registers.
@@ -405,6 +406,7 @@ template <int NB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trsm_sub(TrsmSubArgs g) {
   const int batch = blockIdx.y, lane = threadIdx.x, n = lane & 15, fk = lane >> 4;
   const int row0 = g.r0 + PB * (int)blockIdx.x;
+  if (g.chain) __builtin_amdgcn_s_setprio(3);  // resident beside bulk-update waves that keep the matrix pipe busy: without it the slab runs 2.5x longer
   if (g.live != nullptr) {
     const int nI = g.live[2 * batch], nO = g.live[2 * batch + 1];
     const int tp = g.k0 / kTile, tr = row0 / kTile;
@@ -551,9 +553,9 @@ void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* 
 }
 
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
-                     size_t sR, const int* live, int tI, hipStream_t st) {
+                     size_t sR, const int* live, int tI, hipStream_t st, bool chain) {
   if (r1 <= r0) return;
-  TrsmSubArgs g{S, ld, t0 * kTile, r0 * kTile, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, live, tI};
+  TrsmSubArgs g{S, ld, t0 * kTile, r0 * kTile, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, live, tI, chain ? 1 : 0};
   const dim3 grid((r1 - r0) * (kTile / PB), nbt);
   if (w == 2) hipLaunchKernelGGL(k_trsm_sub<16>, grid, dim3(64), 0, st, g);
   else hipLaunchKernelGGL(k_trsm_sub<8>, grid, dim3(64), 0, st, g);

@@ -6,12 +6,13 @@
 // next-diagonal update, six dependent launches of 20-80 us each with a 128x128 explicit inverse in the middle. Here the
 // same panel is three launches and no large inverse:
 //   k_potrf_panel   ONE workgroup (8 waves) factors the whole 256x256 diagonal block. The trailing 16x16 tiles live in
-//                   REGISTERS in the MFMA accumulator layout for the whole kernel (120 tiles over 7 waves); only the
-//                   current 16-column panel travels through LDS (double-buffered). Per 16 columns: wave 0 factors the
-//                   16x16 diagonal block (row per lane) WHILE the other waves finish the previous panel's trailing update;
-//                   every thread solves one row of the panel by forward substitution; the tiles of the next block column
-//                   are updated first and handed over through LDS, the rest trails behind. The right-hand side rides along as
-//                   one more row. Leaves L in place, y = L^-1 b, and the INVERSES OF THE SIXTEEN 16x16 DIAGONAL BLOCKS.
+//                   REGISTERS in the MFMA accumulator layout for the whole kernel (119 tiles over 7 waves); only the
+//                   current 16-column panel travels through LDS (double-buffered). A software pipeline, two barriers per
+//                   block column: wave 0 carries the serial chain alone (diagonal block + its inverse in one sweep ->
+//                   the tile below it -> the next diagonal tile), the other waves solve the rest of the panel against the
+//                   block inverse on the matrix core, apply the panel to every trailing tile and stream L / y out. The
+//                   right-hand side rides along as one more row. Leaves L in place, y = L^-1 b, and the INVERSES OF THE
+//                   SIXTEEN 16x16 DIAGONAL BLOCKS.
 //   k_trsm_sub      X = A L^-T for 16-row slabs below the panel, one wave per slab, no LDS, no barrier: block forward
 //                   substitution on Z = X^T kept in accumulator layout — a finished 16x16 block Z_j IS the B operand of the
 //                   trailing updates acc_i -= L_ij Z_j (the C/D layout of v_mfma_f64_16x16x4 equals its B layout), and
@@ -105,18 +106,14 @@ COV_DEV void tile_update2(v4f64& c0, v4f64& c1, const double* pan, const double*
 // Factor the (16 nb)-order diagonal block at (k0, k0), nb = 16 (a 256-column panel) or 8 (a last single tile).
 // Dinv_out: block j at Dinv_out + (j >> 3) * 128*128 + (j & 7) * 256, [16][16] row-major (zeros above the diagonal).
 //
-// Per block column j (three barriers):
-//   A  wave 0 factors the 16x16 diagonal block AND forms its inverse in the same sweep: lane (r = lane>>2, q = lane&3) owns
-//      A[r][4q..4q+3] and W[r][4q..4q+3] (W starts as I). Per pivot c the raw column c of A and row c of W are published in
-//      LDS (one round trip); with t_r = a_rc / d_c every lane does a[r][cc] -= t_r a[cc][c] (cc > c) and, for r > c,
-//      W[r][:] -= t_r W[c][:]  (forward substitution L X = I in outer-product form: L_rc X_c: = a_rc W_c: / d_c).
-//      L = A diag(d)^-1/2 and X = diag(d)^-1/2 W are scaled once at the end. No division or square root of the pivot sits
-//      between two LDS round trips except one reciprocal.  Meanwhile waves 1..7 finish panel j-1's trailing update.
-//   B  X_ij = T_ij Dinv_j^T for the tiles below the block: 4 MFMAs per tile (operands from LDS), result back in place;
-//      y_j = Dinv_j b_j. (Round 1 found the product with a 128x128 explicit inverse too inaccurate for this system; a
-//      16x16 block inverse formed by substitution is the standard blocked-TRSM building block and the full-size parity
-//      tests hold with it.)
-//   C  tiles of block column j+1 first, handed over through LDS; L panel and y out; right-hand side update.
+// The diagonal-block sweep of wave 0 ((a) in the loop below): lane (r = lane>>2, q = lane&3) owns A[r][4q..4q+3] and
+// W[r][4q..4q+3] (W starts as I). Per pivot c the raw column c of A and row c of W are published in LDS (one round trip);
+// with t_r = a_rc / d_c every lane does a[r][cc] -= t_r a[cc][c] and, for r > c, W[r][:] -= t_r W[c][:] — the forward
+// substitution L X = I in outer-product form with the same multipliers (L_rc X_c: = a_rc W_c: / d_c). L = A diag(d)^-1/2 and
+// X = diag(d)^-1/2 W are scaled once at the end: between two LDS round trips sits one reciprocal, no square root.
+// The rest of the panel is X_ij = T_ij Dinv_j^T, 4 MFMAs per tile. (Round 1 found the product with a 128x128 explicit inverse
+// too inaccurate for this system; a 16x16 block inverse formed by substitution is the standard blocked-TRSM building block
+// and tests/test_gpu_parity.py::test_mfma_cholesky_ill_conditioned_blocks and the full-size parity tests hold with it.)
 __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
                                                       const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR) {
   M += (size_t)blockIdx.x * bsM; Dinv_out += (size_t)blockIdx.x * bsL;
@@ -128,7 +125,7 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
   double* rowW = colA + 16;
   double* sdd = rowW + 16;      // the block's 16 pivots
   double* sDg = sdd + 16;       // [16][PP] the diagonal tile wave 0 takes over next (panels before the current one applied)
-  double* sZero = sDg + 16 * PP;  // [16] zeros (A operand of tiles that take no update, tile_update4)
+  double* sZero = sDg + 16 * PP;  // [16] zeros (A operand of tiles that take no update, tile_update2)
   const int tid0 = threadIdx.x, lane = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int fr0 = lane & 15, fk0 = lane >> 4;
   const int n = PB * nb;

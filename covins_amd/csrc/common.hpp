@@ -134,6 +134,20 @@ struct DevProblem {
   double* ar_dummy;  // [36] sink for writes addressed at keyframes of other shards (their local contributions are exactly 0)
   double *ar_M, *ar_rhs, *ar_Linv;     // [nblk][ntot][ntot] | [nblk][2 ntot] | [nblk][nIpad/128][128][128]
   double *ar_Sb, *ar_rhsb, *ar_Linvb;  // [nb][nb] | [2 nb] | [nb/128][128][128]
+
+  // ---- multifrontal layout of the WHOLE reduced camera system (k_front.hip, nd_plan.hpp). nd == 0: the forms above.
+  // Variables: 2 pos = pose block (6), 2 pos + 1 = speed-bias block (9) of chain position pos. Every variable is owned by one
+  // node of the nested-dissection tree; a node's front is a dense lower-triangular matrix over [own variables, padded to the
+  // level's interior order nI | the ancestor variables its subtree couples to]. The linearisation kernels write straight
+  // into the fronts (nd_entry below): the entry between two variables lives in the front of the DEEPER owner.
+  int nd, nd_nnodes, nd_nlev, nd_maxd;
+  int *nd_vnode, *nd_voff, *nd_vord;   // [2K] owner node | scalar offset inside the owner's own columns | ordinal inside the owner
+  int *nd_ndepth, *nd_nI;              // [nodes] depth (root 0) | padded interior order of the node's level
+  long long* nd_ntab;                  // [nodes][2] element offset of the front in nd_M | leading dimension (level order: a level's rows are its batch table)
+  int* nd_abase;                       // [nodes][maxd] base into nd_fidx of the ancestor at that depth
+  int* nd_fidx;                        // front row of an ancestor's variable (by ordinal), -1: not in this front
+  double *nd_M, *nd_rhs, *nd_Linv;     // all fronts | per level [batch][2 ntot] | per level [batch][nI/128][128][128]
+  double* nd_dummy;                    // sink for structurally impossible writes (never read)
 };
 
 // address of entry (r, c) of the 6x6 pose-pose block (pi, pj), chain positions pi >= pj; for pi == pj only c <= r is stored.
@@ -141,7 +155,26 @@ struct DevProblem {
 // (interior, border) pair is stored at (border row, interior column) — transposed if the interior keyframe has the
 // higher position (the border rows come last in every arrow buffer); a border-border pair is stored below the diagonal
 // of the border system in BORDER-index order.
+// address of the entry between scalar ra of variable va and scalar rb of variable vb in the multifrontal layout
+__device__ __forceinline__ double* nd_entry(const DevProblem& P, int va, int vb, int ra, int rb) {
+  const int na = P.nd_vnode[va], nb = P.nd_vnode[vb];
+  if (na == nb) {
+    const int oa = P.nd_voff[va] + ra, ob = P.nd_voff[vb] + rb;
+    const int hi = oa > ob ? oa : ob, lo = oa > ob ? ob : oa;
+    return P.nd_M + P.nd_ntab[2 * na] + (size_t)hi * (size_t)P.nd_ntab[2 * na + 1] + lo;
+  }
+  const int da = P.nd_ndepth[na], db = P.nd_ndepth[nb];
+  // the deeper owner's front holds it: row = the ancestor variable's border row, column = the own variable's column
+  const int no = da > db ? na : nb, vo = da > db ? va : vb, ro = da > db ? ra : rb;
+  const int vA = da > db ? vb : va, rA = da > db ? rb : ra, dA = da > db ? db : da;
+  const int base = P.nd_abase[(size_t)no * P.nd_maxd + dA];
+  const int row = base < 0 ? -1 : P.nd_fidx[base + P.nd_vord[vA]];
+  if (row < 0) return P.nd_dummy;
+  return P.nd_M + P.nd_ntab[2 * no] + (size_t)(row + rA) * (size_t)P.nd_ntab[2 * no + 1] + (P.nd_voff[vo] + ro);
+}
+
 __device__ __forceinline__ double* c_entry(const DevProblem& P, int pi, int pj, int r, int c) {
+  if (P.nd) return nd_entry(P, 2 * pi, 2 * pj, r, c);
   if (!P.arrow) return P.Sred + (size_t)(6 * pi + r) * P.npad + (6 * pj + c);
   const int bi = P.ar_blk[pi], bj = P.ar_blk[pj], li = P.ar_loc[pi], lj = P.ar_loc[pj];
   const size_t nt = (size_t)P.ar_ntot;
@@ -194,7 +227,8 @@ void launch_edge_gather(const DevProblem& P, hipStream_t st);
 // structured solve of the damped reduced system: speed-bias chains -> dense pose system -> back-substitution.
 // Solution (IR layout, D per keyframe) is written to dst[0..n).
 struct PgoPlan;
-void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax, PgoPlan* pgo = nullptr);
+struct NdDev;
+void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax, PgoPlan* pgo = nullptr, NdDev* nd = nullptr);
 // speed-bias chain factorisation on the auxiliary stream as soon as the IMU blocks are final (overlaps the landmark pass)
 void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& ax);
 void launch_zero_system(const DevProblem& P, hipStream_t st);       // every small per-iteration buffer, one launch
@@ -211,7 +245,9 @@ struct CholAux {
   std::vector<int> live_h;   // host copy of DevProblem::ar_live (flop accounting of the batched launches)
   // per big panel of the batched (arrow) factorisation: device list of the LIVE (batch, ti, tj) tiles of its bulk update,
   // interleaved so that list position p runs on XCD p % 8 and every XCD gets the same number of tiles (k_chol.hip)
-  std::vector<int*> tri_list; std::vector<int> tri_count; int tri_key = -1;
+  struct TriCache { std::vector<int*> list; std::vector<int> count; int key = -1; void clear(); };
+  TriCache tri0;                  // block-arrow batches (k_arrow.hip, k_pgo.hip)
+  std::vector<TriCache> tri_lev;  // one per level of the multifrontal solve (k_front.hip), selected by DenseBatch::tri_slot
   void tri_clear();
   // multi-GPU: sum `n` device doubles over all ranks, in place (solver.hip installs it when a shard is set; nullptr = single GPU)
   void (*reduce)(void* ctx, double* dev, size_t n, int op) = nullptr;
@@ -227,7 +263,12 @@ struct CholAux {
 // dense SPD solve of Sred x = bred in place (lower Cholesky on the FP64 MFMA path); flag[0] != 0 on failure
 // batched form: n independent systems of identical shape; sM / sL / sR = elements between consecutive matrices, Linv
 // sets and right-hand sides. The same launches serve all of them (one more grid dimension).
-struct DenseBatch { int n = 0; size_t sM = 0, sL = 0, sR = 0; const int* live = nullptr; int tI = 0; const int* live_h = nullptr; };  // live / tI: see GemmArgs (k_chol.hip)
+struct DenseBatch {
+  int n = 0; size_t sM = 0, sL = 0, sR = 0;
+  const int* live = nullptr; int tI = 0; const int* live_h = nullptr;  // live / tI: see GemmArgs (k_chol.hip)
+  const long long* tab = nullptr;  // per-matrix (element offset, leading dimension): fronts of unequal order in one batch (GemmArgs::btab)
+  int tri_slot = -1;               // which CholAux::tri_lev entry caches the live-tile lists of this batch's bulk updates
+};
 void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax, int tstop = -1,
                               bool solve = true, DenseBatch bt = DenseBatch());  // tstop >= 0 (even): eliminate tile columns [0, tstop) only
 void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStream_t st, int tfact, int tend, DenseBatch bt = DenseBatch());
@@ -235,11 +276,11 @@ void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStrea
 // instead of the 128x128 inverse. COVGPU_PANEL=0 selects the round-2a chain (two 128-column potrf + inverse per panel).
 bool dense_panel_chain();
 void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
-                        hipStream_t st);
+                        hipStream_t st, const long long* btab = nullptr);
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
-                     size_t sR, const int* live, int tI, hipStream_t st, bool chain = false);
+                     size_t sR, const int* live, int tI, hipStream_t st, bool chain = false, const long long* btab = nullptr);
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,
-                         size_t sL, size_t sR, hipStream_t st);
+                         size_t sL, size_t sR, hipStream_t st, const long long* btab = nullptr, const int* live = nullptr, int tI = 0);
 
 // ---- block-arrow pose-graph solve (k_pgo.hip)
 struct PgoHostPlan { std::vector<std::vector<int>> block_kf; std::vector<int> border_kf; };
@@ -274,6 +315,35 @@ void launch_shard_scal(const DevProblem& P, double* mx, int dir, hipStream_t st)
 void launch_border_vec(const DevProblem& P, double* buf, int dir, hipStream_t st);  // dir 0: pack [grad | hdiag] of the border pose rows, 1: unpack
 void launch_arrow_zero(const DevProblem& P, hipStream_t st);   // per iteration: clear the buffers, identity on padding rows
 void launch_arrow_solve(const DevProblem& P, hipStream_t st, CholAux& ax);  // P.bp (chain positions) -> solution in place
+
+// ---- multifrontal solve of the whole reduced camera system (k_front.hip)
+struct NdHostPlan;
+struct NdLevel {
+  int n = 0, nI = 0, ntot = 0;          // fronts in the batch | padded interior order | largest front order of the batch
+  int first = 0;                          // first node (level order) = row of nd_ntab where this level's batch table starts
+  size_t rhs_off = 0, linv_off = 0;       // element offsets of the level's right-hand sides / block inverses
+  int* live = nullptr;                    // [n][2] device: real interior tiles | real border tiles (GemmArgs::live)
+  std::vector<int> live_h;
+};
+struct NdDev {
+  bool active = false;
+  std::vector<NdLevel> lev;
+  // device tables of the assembly kernels (owned by the context's allocation list)
+  int *lev_node = nullptr;                 // [nodes] level order -> node
+  int *own_dims = nullptr, *st_dims = nullptr, *own_g = nullptr, *st_g = nullptr;  // [nodes] sizes | offsets into gidx
+  int *gidx = nullptr;                     // solution index D kf + component of every own / border scalar of every node
+  int *cptr = nullptr, *cidx = nullptr;    // [nodes + 1], children (node ids)
+  int *inv_off = nullptr, *inv = nullptr;  // [nodes] offset of the node's map parent front row -> own front row (-1: none)
+  int *rhs_node = nullptr;                 // [nodes] element offset of the node's right-hand side in nd_rhs
+  // host staging of the tables (filled by nd_tables, uploaded by solver.hip)
+  std::vector<int> h_vnode, h_voff, h_vord, h_ndepth, h_nI, h_abase, h_fidx, h_lev_node, h_own_dims, h_st_dims, h_own_g, h_st_g, h_gidx, h_cptr, h_cidx,
+      h_inv_off, h_inv, h_rhs_node;
+  std::vector<long long> h_ntab;
+  size_t M_elems = 0, rhs_elems = 0, linv_elems = 0;
+};
+void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, NdDev& dev);  // host tables + level shapes from the plan
+void launch_nd_zero(const DevProblem& P, const NdDev& nd, hipStream_t st);    // per iteration: clear the live tiles, identity on interior padding
+void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, hipStream_t st, CholAux& ax);  // damped system in the fronts + bred -> dst (IR layout)
 
 void launch_dogleg_stats(const DevProblem& P, hipStream_t st);  // GG, GN2, GDOT, GMAX from grad/hdiag/gn
 void launch_cauchy_vec(const DevProblem& P, hipStream_t st);    // vtmp = grad / d^2

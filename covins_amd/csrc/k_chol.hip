@@ -77,6 +77,9 @@ struct GemmArgs {
   const int* live; int tI;
   // SYRK_TRI on arrow buffers: explicit list of the live tiles, entry = batch << 20 | ti << 10 | tj (-1: no work)
   const int* tri;
+  // fronts of unequal order in one batch (k_front.hip): btab[2 batch] = element offset of the matrix, btab[2 batch + 1] = its
+  // leading dimension; nullptr = the uniform bsM / ld above
+  const long long* btab;
 };
 __device__ __forceinline__ bool tile_live(const GemmArgs& g, int batch, int t) {
   if (g.live == nullptr) return true;
@@ -114,7 +117,7 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
             batch = (MODE == MODE_SYRK_TRI) ? (g.tri != nullptr ? (tri_entry >> 20) : (int)blockIdx.y) : (int)blockIdx.z / ZQ;
   const int qr = (TSA == kTile) ? 0 : (TSB == kTile ? zq : (zq >> 1));
   const int qc = (TSB == kTile) ? 0 : (zq & 1);
-  double* const Mb = g.M + (size_t)batch * g.bsM;
+  double* const Mb = g.M + (g.btab != nullptr ? (size_t)g.btab[2 * batch] : (size_t)batch * g.bsM);
   int ti, tj;
   if (MODE == MODE_SYRK_TRI && g.tri != nullptr) {
     ti = (tri_entry >> 10) & 1023; tj = tri_entry & 1023;
@@ -145,7 +148,7 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
   double (*sB)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + TSA * LDT);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WGC, wc = wave % WGC;
-  const size_t ld = g.ld;
+  const size_t ld = g.btab != nullptr ? (size_t)g.btab[2 * batch + 1] : g.ld;
   // wave-uniform bases (the tile of a workgroup spans < 2^32 bytes: per-lane offsets are 32-bit byte offsets)
   const char* Ag = reinterpret_cast<const char*>(Mb + (size_t)(g.ra0 + ti * kTile + qr * TSA) * ld + g.kcol0);
   const char* Bg = (MODE == MODE_TRSM) ? reinterpret_cast<const char*>(g.Linv + (size_t)batch * g.bsL)
@@ -709,9 +712,13 @@ void CholAux::init() {
   if (!ev_z) (void)hipEventCreateWithFlags(&ev_z, hipEventDisableTiming);
   if (!ev_fill) (void)hipEventCreateWithFlags(&ev_fill, hipEventDisableTiming);
 }
+void CholAux::TriCache::clear() {
+  for (int* p : list) if (p) (void)hipFree(p);
+  list.clear(); count.clear(); key = -1;
+}
 void CholAux::tri_clear() {
-  for (int* p : tri_list) if (p) (void)hipFree(p);
-  tri_list.clear(); tri_count.clear(); tri_key = -1;
+  tri0.clear();
+  for (auto& t : tri_lev) t.clear();
 }
 void CholAux::destroy() {
   tri_clear();
@@ -798,14 +805,14 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   // quad: four workgroups per tile (head launches on the serial chain)
   auto trsm = [&](int t, int r0, int r1, hipStream_t s2, bool quad) {
     if (r1 <= r0) return;
-    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, b, b + npad, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr};
+    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, b, b + npad, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab};
     if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_TRSM, 32, kTile>), dim3(r1 - r0, 1, 4 * nbt), dim3(256), (size_t)(32 + kTile) * (KCQ + 1) * sizeof(double), s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(r1 - r0, 1, nbt), dim3(256), lds_gemm, s2, g);
   };
   // C tiles (rows [r0, r1), tile columns [tc0, tc0+ntc)) -= A[rows, K] A[tc.., K]^T, K = tiles kt0.. (KD columns); lower part only
   auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2, bool quad) {
     if (r1 <= r0 || ntc <= 0) return;
-    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr};
+    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab};
     if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4 * nbt), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0, nbt), dim3(256), lds_gemm, s2, g);
   };
@@ -824,10 +831,12 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   // its Schur complement (and, with the forward substitution riding along, b's trailing part the reduced right-hand
   // side). Used by the block-arrow pose-graph solve (k_pgo.hip).
   const int Pstop = (tstop >= 0 && tstop < T) ? tstop / 2 : NP;
-  if (bt.live_h != nullptr && ax.tri_key != T * 4096 + nbt) {  // live-tile lists of every panel's bulk update (static per problem)
-    ax.tri_clear();
-    ax.tri_key = T * 4096 + nbt;
-    ax.tri_list.assign(NP, nullptr); ax.tri_count.assign(NP, 0);
+  if (bt.tri_slot >= (int)ax.tri_lev.size()) ax.tri_lev.resize(bt.tri_slot + 1);
+  CholAux::TriCache& tc = bt.tri_slot >= 0 ? ax.tri_lev[bt.tri_slot] : ax.tri0;
+  if (bt.live_h != nullptr && tc.key != T * 4096 + nbt) {  // live-tile lists of every panel's bulk update (static per problem)
+    tc.clear();
+    tc.key = T * 4096 + nbt;
+    tc.list.assign(NP, nullptr); tc.count.assign(NP, 0);
     for (int P = 0; P < NP && P < Pstop; ++P) {
       const int t0 = 2 * P, tb = t0 + 4;
       if (tb >= T) break;
@@ -855,9 +864,9 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       std::vector<int> lst(8 * longest, -1);
       for (int x = 0; x < 8; ++x) for (size_t k = 0; k < q[x].size(); ++k) lst[8 * k + x] = q[x][k];
       int* d = nullptr;
-      if (hipMalloc((void**)&d, lst.size() * sizeof(int)) != hipSuccess) { ax.tri_clear(); break; }
+      if (hipMalloc((void**)&d, lst.size() * sizeof(int)) != hipSuccess) { tc.clear(); break; }
       (void)hipMemcpy(d, lst.data(), lst.size() * sizeof(int), hipMemcpyHostToDevice);
-      ax.tri_list[P] = d; ax.tri_count[P] = (int)lst.size();
+      tc.list[P] = d; tc.count[P] = (int)lst.size();
     }
   }
   int Plast = NP - 1;
@@ -896,16 +905,16 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     if (panel256) {
       // 256-column chain (k_panel.hip): one workgroup factors the whole diagonal block, rows h follow on the same stream by
       // block substitution, rows r on theirs — three dependent launches per panel instead of six
-      launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M);
+      launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab);
       (void)hipEventRecord(e1[P], M);
       if (h1 > h0) {
         if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
-        launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true);
+        launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab);
       }
       (void)hipEventRecord(eH[P], M);
       if (T > h1) {
         wait(R, e1[P]);
-        launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R);
+        launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab);
       }
       (void)hipEventRecord(eC[P], R);
     } else {
@@ -962,12 +971,12 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     if (P + 1 < NP) wait(B, eRc[P + 1]);
     if (nt > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
-      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr};
+      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab};
       // arrow buffers: the live tiles of this panel's update as an explicit, XCD-balanced list (built once per problem).
       // The implicit triangle grid x batch launched ~2.6k workgroups of which ~400 did work, with every batch's first
       // supertile on XCD 0: 17 TFLOP/s.
-      const bool listed = bt.live_h != nullptr && P < (int)ax.tri_list.size() && ax.tri_list[P] != nullptr;
-      if (listed) g.tri = ax.tri_list[P];
+      const bool listed = bt.live_h != nullptr && P < (int)tc.list.size() && tc.list[P] != nullptr;
+      if (listed) g.tri = tc.list[P];
       double pairs = 0.0;  // tile pairs that do work
       for (int a = 0; a < nbt; ++a) {
         if (bt.live_h == nullptr) { pairs += (double)nt * (nt + 1) / 2; continue; }
@@ -977,9 +986,9 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         for (int t = tb; t < T; ++t) nl += (t < nI || (t >= bt.tI && t - bt.tI < nO)) ? 1 : 0;
         pairs += (double)nl * (nl + 1) / 2;
       }
-      if (!listed || ax.tri_count[P] > 0) {
+      if (!listed || tc.count[P] > 0) {
         if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], B);
-        if (listed) hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(ax.tri_count[P], 1), dim3(256), lds_gemm, B, g);
+        if (listed) hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(tc.count[P], 1), dim3(256), lds_gemm, B, g);
         else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, B, g);
         if (ax.profile) {
           (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], B);
@@ -1010,7 +1019,8 @@ void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStrea
     const int nb = (ncol + 31) / 32;
     if (given && nb == 0) continue;
     if (dense_panel_chain())
-      launch_bwd_step_sub(S, ld, p, given ? nullptr : Linv + (size_t)p * kTile * kTile, b + npad, b, ncol, nb > 0 ? nb : 1, nbt, bt.sM, bt.sL, bt.sR, st);
+      launch_bwd_step_sub(S, ld, p, given ? nullptr : Linv + (size_t)p * kTile * kTile, b + npad, b, ncol, nb > 0 ? nb : 1, nbt, bt.sM, bt.sL, bt.sR, st, bt.tab,
+                          bt.live, bt.tI);
     else
       hipLaunchKernelGGL(k_bwd_step, dim3(nb > 0 ? nb : 1, nbt), dim3(256), 0, st, S, ld, p, given ? nullptr : Linv + (size_t)p * kTile * kTile,
                          b + npad, b, ncol, bt.sM, bt.sL, bt.sR);

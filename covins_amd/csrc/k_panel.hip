@@ -115,8 +115,11 @@ COV_DEV void tile_update2(v4f64& c0, v4f64& c1, const double* pan, const double*
 // too inaccurate for this system; a 16x16 block inverse formed by substitution is the standard blocked-TRSM building block
 // and tests/test_gpu_parity.py::test_mfma_cholesky_ill_conditioned_blocks and the full-size parity tests hold with it.)
 __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
-                                                      const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR) {
-  M += (size_t)blockIdx.x * bsM; Dinv_out += (size_t)blockIdx.x * bsL;
+                                                      const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR,
+                                                      const long long* __restrict__ btab) {
+  if (btab != nullptr) { M += (size_t)btab[2 * blockIdx.x]; ld = (size_t)btab[2 * blockIdx.x + 1]; }  // fronts of unequal order (GemmArgs::btab)
+  else M += (size_t)blockIdx.x * bsM;
+  Dinv_out += (size_t)blockIdx.x * bsL;
   if (rhs != nullptr) { rhs += (size_t)blockIdx.x * bsR; yout += (size_t)blockIdx.x * bsR; }
   extern __shared__ __attribute__((aligned(16))) double sP[];  // panel[2][256][PP] | sDv[16][16] | sRhs[256] | colA[16] rowW[16] sdd[16] | sDg[16][PP]
   double* sDv = sP + 2 * PROWS * PP;
@@ -395,6 +398,7 @@ struct TrsmSubArgs {
   size_t bsM, bsL, bsR;
   const int* live; int tI;           // see GemmArgs (k_chol.hip)
   int chain;                         // 1: launched on the serial chain — its waves raise their issue priority over the bulk update's
+  const long long* btab;             // see GemmArgs (k_chol.hip)
 };
 
 // X = A L^-T on a 16-row slab, L = the (16 NB)-order factor at (k0, k0). One wave, everything in registers.
@@ -410,13 +414,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (!(tp < nI || (tp >= g.tI && tp - g.tI < nO))) return;
     if (!(tr < nI || (tr >= g.tI && tr - g.tI < nO))) return;
   }
-  double* Mb = g.M + (size_t)batch * g.bsM;
+  double* Mb = g.M + (g.btab != nullptr ? (size_t)g.btab[2 * batch] : (size_t)batch * g.bsM);
+  const size_t ld = g.btab != nullptr ? (size_t)g.btab[2 * batch + 1] : g.ld;
   const double* Db = g.Dinv + (size_t)batch * g.bsL;
   const int pr = 4 * (n & 3) + (n >> 2);  // logical row carried by A-operand lane n
-  double* Arow = Mb + (size_t)(row0 + n) * g.ld + g.k0 + 4 * fk;
-  const double* Lrow = Mb + (size_t)(g.k0 + pr) * g.ld + g.k0 + 4 * fk;
+  double* Arow = Mb + (size_t)(row0 + n) * ld + g.k0 + 4 * fk;
+  const double* Lrow = Mb + (size_t)(g.k0 + pr) * ld + g.k0 + 4 * fk;
   const double* Drow = Db + pr * PB + 4 * fk;
-  auto Ltile = [&](int i, int j) { return *reinterpret_cast<const v4f64*>(Lrow + (size_t)(PB * i) * g.ld + PB * j); };
+  auto Ltile = [&](int i, int j) { return *reinterpret_cast<const v4f64*>(Lrow + (size_t)(PB * i) * ld + PB * j); };
   auto Dblk = [&](int j) { return *reinterpret_cast<const v4f64*>(Drow + (size_t)(j >> 3) * kTile * kTile + (j & 7) * 256); };
   v4f64 acc[NB];
 #pragma unroll
@@ -472,8 +477,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // (one memory latency), then eight block steps of two barriers each. Every workgroup of the launch repeats this (cheaper
 // than a separate launch on a launch-bound chain); the column update is split over the workgroups as before.
 __global__ __launch_bounds__(256) void k_bwd_step_sub(const double* __restrict__ M, size_t ld, int p, const double* __restrict__ Dinv,
-                                                       double* __restrict__ y, double* __restrict__ x, int ncol, size_t bsM, size_t bsL, size_t bsR) {
-  M += (size_t)blockIdx.y * bsM; y += (size_t)blockIdx.y * bsR; x += (size_t)blockIdx.y * bsR;
+                                                       double* __restrict__ y, double* __restrict__ x, int ncol, size_t bsM, size_t bsL, size_t bsR,
+                                                       const long long* __restrict__ btab, const int* __restrict__ live, int tI) {
+  if (live != nullptr) {  // padding tile of this front: x_p = 0 contributes nothing (GemmArgs::live)
+    const int nI = live[2 * blockIdx.y], nO = live[2 * blockIdx.y + 1];
+    if (!(p < nI || (p >= tI && p - tI < nO))) return;
+  }
+  if (btab != nullptr) { M += (size_t)btab[2 * blockIdx.y]; ld = (size_t)btab[2 * blockIdx.y + 1]; }
+  else M += (size_t)blockIdx.y * bsM;
+  y += (size_t)blockIdx.y * bsR; x += (size_t)blockIdx.y * bsR;
   if (Dinv != nullptr) Dinv += (size_t)blockIdx.y * bsL;
   __shared__ double sx[kTile];
   __shared__ double sv[kTile];
@@ -539,28 +551,28 @@ __global__ __launch_bounds__(256) void k_bwd_step_sub(const double* __restrict__
 
 // ---- launch wrappers (k_chol.hip schedules them) ----------------------------------------------------------------------
 void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
-                        hipStream_t st) {
+                        hipStream_t st, const long long* btab) {
   static bool once = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds);
     return true;
   }();
   (void)once;
   hipLaunchKernelGGL(k_potrf_panel, dim3(nbt), dim3(512), kPanelLds, st, S, ld, t0 * kTile, 8 * w, Linv + (size_t)t0 * kTile * kTile, flag,
-                     (const double*)b, b ? b + npad : nullptr, sM, sL, sR);
+                     (const double*)b, b ? b + npad : nullptr, sM, sL, sR, btab);
 }
 
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
-                     size_t sR, const int* live, int tI, hipStream_t st, bool chain) {
+                     size_t sR, const int* live, int tI, hipStream_t st, bool chain, const long long* btab) {
   if (r1 <= r0) return;
-  TrsmSubArgs g{S, ld, t0 * kTile, r0 * kTile, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, live, tI, chain ? 1 : 0};
+  TrsmSubArgs g{S, ld, t0 * kTile, r0 * kTile, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, live, tI, chain ? 1 : 0, btab};
   const dim3 grid((r1 - r0) * (kTile / PB), nbt);
   if (w == 2) hipLaunchKernelGGL(k_trsm_sub<16>, grid, dim3(64), 0, st, g);
   else hipLaunchKernelGGL(k_trsm_sub<8>, grid, dim3(64), 0, st, g);
 }
 
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,
-                         size_t sL, size_t sR, hipStream_t st) {
-  hipLaunchKernelGGL(k_bwd_step_sub, dim3(nblocks, nbt), dim3(256), 0, st, S, ld, p, Linv_p, y, x, ncol, sM, sL, sR);
+                         size_t sL, size_t sR, hipStream_t st, const long long* btab, const int* live, int tI) {
+  hipLaunchKernelGGL(k_bwd_step_sub, dim3(nblocks, nbt), dim3(256), 0, st, S, ld, p, Linv_p, y, x, ncol, sM, sL, sR, btab, live, tI);
 }
 
 }  // namespace covgpu

@@ -704,7 +704,8 @@ void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& 
   ax.cf_pending = true;
 }
 
-void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax, PgoPlan* pgo) {
+void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax, PgoPlan* pgo, NdDev* nd) {
+  if (nd != nullptr && P.nd) { launch_nd_solve(P, *nd, dst, st, ax); return; }  // multifrontal form (k_front.hip): the whole system at once
   const int cnt = P.npad > 9 * P.K ? P.npad : 9 * P.K;
   const bool early = P.vi && ax.cf_pending;  // chain factor (and z in xs) already under way on the auxiliary stream
   hipLaunchKernelGGL(k_gather_rhs, dim3((cnt + 255) / 256), dim3(256), 0, st, P, early ? 0 : 2);

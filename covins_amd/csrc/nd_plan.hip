@@ -1,0 +1,179 @@
+// nd_plan.hip — host-only: nested-dissection tree + symbolic factorisation of the reduced camera system (nd_plan.hpp).
+// No device code here; the file is a .hip only so that the one Makefile rule builds it.
+#include "nd_plan.hpp"
+
+#include <algorithm>
+#include <queue>
+#include <tuple>
+
+namespace covgpu {
+namespace {
+
+struct Builder {
+  const int K;
+  const bool vi;
+  const int leaf_dims;
+  const std::vector<std::vector<int>>& adj;
+  const std::vector<int>& chain_of;  // by position
+  NdHostPlan& out;
+  std::vector<int> reg, deg;
+  std::vector<int> side;
+  std::vector<char> inS;
+  int regid = 0;
+
+  Builder(int K_, bool vi_, int leaf, const std::vector<std::vector<int>>& adj_, const std::vector<int>& chain_of_, NdHostPlan& o)
+      : K(K_), vi(vi_), leaf_dims(leaf), adj(adj_), chain_of(chain_of_), out(o), reg(2 * (size_t)K_, -1), deg(2 * (size_t)K_, 0),
+        side(2 * (size_t)K_, 0), inS(2 * (size_t)K_, 0) {}
+
+  int new_node(std::vector<int>& own, int parent) {
+    // speed-bias blocks first (inside a leaf they form the block-tridiagonal part that fills least), then poses, by position
+    std::sort(own.begin(), own.end(), [](int a, int b) { return std::make_pair(1 - (a & 1), a >> 1) < std::make_pair(1 - (b & 1), b >> 1); });
+    const int n = out.nnodes++;
+    out.parent.push_back(parent);
+    out.depth.push_back(parent < 0 ? 0 : out.depth[parent] + 1);
+    out.child.emplace_back();
+    if (parent >= 0) out.child[parent].push_back(n);
+    int off = 0, ord = 0;
+    for (int v : own) { out.vnode[v] = n; out.voff[v] = off; out.vord[v] = ord++; off += NdHostPlan::vdim(v); }
+    out.own_dims.push_back(off);
+    out.own.push_back(own);
+    return n;
+  }
+
+  void build(std::vector<int>& vars, int parent) {
+    if (vars.empty()) return;
+    int dims = 0;
+    for (int v : vars) dims += NdHostPlan::vdim(v);
+    if (dims <= leaf_dims) { new_node(vars, parent); return; }
+    // ---- parts of the cut. Several agents: one part per agent — ONE cover of all cross-agent couplings (loop-closure
+    //      zones are hot spots where several agents meet: a keyframe there covers links to all of them at once; pairwise
+    //      agent cuts needed 1.5x more separator unknowns on the 5-agent map). One agent: two halves of its time axis.
+    std::vector<int> chains;
+    for (int v : vars) chains.push_back(chain_of[v >> 1]);
+    std::sort(chains.begin(), chains.end());
+    chains.erase(std::unique(chains.begin(), chains.end()), chains.end());
+    int nparts = 2;
+    if (chains.size() >= 2) {
+      nparts = (int)chains.size();
+      for (int v : vars) side[v] = (int)(std::lower_bound(chains.begin(), chains.end(), chain_of[v >> 1]) - chains.begin());
+    } else {
+      std::vector<int> pos;
+      for (int v : vars) pos.push_back(v >> 1);
+      std::sort(pos.begin(), pos.end());
+      pos.erase(std::unique(pos.begin(), pos.end()), pos.end());
+      if (pos.size() < 2) { new_node(vars, parent); return; }
+      const int m = pos[pos.size() / 2];
+      for (int v : vars) side[v] = (v >> 1) >= m;
+    }
+    // ---- greedy vertex cover of the couplings that cross the cut: highest remaining crossing degree first
+    //      (ties: pose blocks before speed-bias blocks, then the lower variable index) — deterministic
+    ++regid;
+    for (int v : vars) { reg[v] = regid; inS[v] = 0; }
+    std::priority_queue<std::tuple<int, int, int>> heap;
+    for (int v : vars) {
+      int d = 0;
+      for (int w : adj[v]) d += (reg[w] == regid && side[w] != side[v]) ? 1 : 0;
+      deg[v] = d;
+      if (d) heap.push(std::make_tuple(d, 1 - (v & 1), -v));
+    }
+    std::vector<int> S;
+    while (!heap.empty()) {
+      const auto top = heap.top(); heap.pop();
+      const int v = -std::get<2>(top);
+      if (inS[v] || std::get<0>(top) != deg[v] || deg[v] == 0) continue;
+      inS[v] = 1; S.push_back(v);
+      for (int w : adj[v])
+        if (reg[w] == regid && side[w] != side[v] && !inS[w] && deg[w] > 0) { if (--deg[w]) heap.push(std::make_tuple(deg[w], 1 - (w & 1), -w)); }
+      deg[v] = 0;
+    }
+    std::vector<std::vector<int>> parts(nparts);
+    for (int v : vars) if (!inS[v]) parts[side[v]].push_back(v);
+    const int n = S.empty() ? parent : new_node(S, parent);  // parts that do not touch: no separator node
+    for (auto& pt : parts) build(pt, n);
+  }
+};
+
+}  // namespace
+
+bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
+                   const int* epair_i, const int* epair_j, int leaf_dims, NdHostPlan& out) {
+  out = NdHostPlan();
+  out.K = K; out.vi = vi ? 1 : 0; out.nvar = 2 * K;
+  out.vnode.assign(2 * (size_t)K, -1); out.voff.assign(2 * (size_t)K, 0); out.vord.assign(2 * (size_t)K, -1);
+  if (K <= 0) return false;
+  std::vector<int> chain_of(K, 0);
+  for (int c = 0; c < nchains; ++c) for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) chain_of[q] = c;
+  // ---- coupling graph over the variables
+  std::vector<std::vector<int>> adj(2 * (size_t)K);
+  auto link = [&](int a, int b) { if (a != b) { adj[a].push_back(b); adj[b].push_back(a); } };
+  for (int p = 0; p < npairs; ++p) link(2 * pair_i[p], 2 * pair_j[p]);
+  for (int p = 0; p < nepairs; ++p) link(2 * epair_i[p], 2 * epair_j[p]);
+  if (vi)
+    for (int c = 0; c < nchains; ++c)
+      for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) {
+        link(2 * q + 1, 2 * q);
+        if (q > chain_ptr[c]) {
+          const int v[4] = {2 * (q - 1), 2 * (q - 1) + 1, 2 * q, 2 * q + 1};
+          for (int a = 0; a < 4; ++a) for (int b = a + 1; b < 4; ++b) link(v[a], v[b]);
+        }
+      }
+  for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+  // ---- tree
+  std::vector<int> all;
+  for (int q = 0; q < K; ++q) { all.push_back(2 * q); if (vi) all.push_back(2 * q + 1); }
+  Builder bld(K, vi, leaf_dims, adj, chain_of, out);
+  bld.build(all, -1);
+  const int nn = out.nnodes;
+  auto is_proper_ancestor = [&](int a, int n) {  // a above n?
+    if (out.depth[a] >= out.depth[n]) return false;
+    while (out.depth[n] > out.depth[a]) n = out.parent[n];
+    return n == a;
+  };
+  // ---- symbolic factorisation, children before parents (a child's index is always above its parent's)
+  out.strct.assign(nn, {});
+  out.st_dims.assign(nn, 0);
+  std::vector<int> stamp(2 * (size_t)K, -1);
+  for (int n = nn - 1; n >= 0; --n) {
+    std::vector<int>& st = out.strct[n];
+    auto add = [&](int w) { if (stamp[w] != n) { stamp[w] = n; st.push_back(w); } };
+    for (int v : out.own[n])
+      for (int w : adj[v]) {
+        const int m = out.vnode[w];
+        if (m == n) continue;
+        if (is_proper_ancestor(m, n)) add(w);
+        else if (!is_proper_ancestor(n, m)) return false;  // separator property violated: a coupling joins two branches
+      }
+    for (int c : out.child[n])
+      for (int w : out.strct[c]) if (out.vnode[w] != n) add(w);
+    std::sort(st.begin(), st.end(), [&](int a, int b) {  // nearest ancestor first, then its own order
+      return std::make_pair(-out.depth[out.vnode[a]], out.vord[a]) < std::make_pair(-out.depth[out.vnode[b]], out.vord[b]);
+    });
+    int d = 0;
+    for (int w : st) d += NdHostPlan::vdim(w);
+    out.st_dims[n] = d;
+  }
+  // ---- batches: nodes of equal height
+  out.level.assign(nn, 0); out.slot.assign(nn, 0);
+  for (int n = nn - 1; n >= 0; --n)
+    for (int c : out.child[n]) out.level[n] = std::max(out.level[n], out.level[c] + 1);
+  out.nlev = 0; out.maxdepth = 0;
+  for (int n = 0; n < nn; ++n) { out.nlev = std::max(out.nlev, out.level[n] + 1); out.maxdepth = std::max(out.maxdepth, out.depth[n] + 1); }
+  out.lev_nodes.assign(out.nlev, {});
+  for (int n = 0; n < nn; ++n) { out.slot[n] = (int)out.lev_nodes[out.level[n]].size(); out.lev_nodes[out.level[n]].push_back(n); }
+  out.lev_nI.assign(out.nlev, 0); out.lev_nO.assign(out.nlev, 0); out.lev_ntot.assign(out.nlev, 0);
+  for (int l = 0; l < out.nlev; ++l) {
+    int mo = 0, ms = 0;
+    for (int n : out.lev_nodes[l]) { mo = std::max(mo, out.own_dims[n]); ms = std::max(ms, out.st_dims[n]); }
+    out.lev_nI[l] = std::max(256, ((mo + 255) / 256) * 256);
+    out.lev_nO[l] = ((ms + 127) / 128) * 128;
+    out.lev_ntot[l] = out.lev_nI[l] + out.lev_nO[l];
+    out.front_elems += (size_t)out.lev_nodes[l].size() * out.lev_ntot[l] * out.lev_ntot[l];
+  }
+  for (int n = 0; n < nn; ++n) {
+    const double m = out.own_dims[n], b = out.st_dims[n];
+    out.flops += m * m * m / 3.0 + m * m * b + m * b * b;
+  }
+  return true;
+}
+
+}  // namespace covgpu

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "nd_plan.hpp"
 
 using namespace covgpu;
 
@@ -50,6 +51,7 @@ struct covgpu_context {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   CholAux chol;
   PgoPlan pgo_plan;  // block-arrow pose-graph solve (k_pgo.hip)
+  NdDev nd;          // multifrontal GBA solve (k_front.hip)
   // agent-sharded solve: global plan + this rank's identity + the caller's all-reduce
   bool sharded = false;
   int rank = 0, world = 1, stage_on_host = 0;
@@ -150,6 +152,7 @@ static void free_problem(covgpu_context* c) {
   c->chol.tri_clear(); c->chol.live_h.clear();
   c->have = false;
   c->pgo_plan.active = false;  // its device buffers were in `allocs`
+  c->nd = NdDev();
 }
 
 extern "C" void covgpu_destroy(covgpu_context* c) {
@@ -183,6 +186,11 @@ extern "C" void covgpu_get_layout(covgpu_context* c, int64_t* out) {
   const DevProblem& P = c->P;
   out[0] = P.arrow; out[1] = P.ar_nblk; out[2] = P.ar_nbk; out[3] = P.arrow ? P.ar_nIpad / 6 : 0; out[4] = P.ar_ntot; out[5] = P.ar_nb;
   out[6] = P.npad; out[7] = P.npairs; out[8] = P.nepairs; out[9] = P.nchains; out[10] = (int64_t)(c->alloc_bytes >> 20);
+  if (P.nd) {  // multifrontal form: nodes, levels, serial 256-column panels (sum of the levels' interior orders / 256), root order, front bytes (MiB)
+    out[11] = P.nd_nnodes; out[12] = P.nd_nlev;
+    for (const NdLevel& L : c->nd.lev) out[13] += L.nI / 256;
+    out[14] = c->nd.lev.empty() ? 0 : c->nd.lev.back().nI; out[15] = (int64_t)((c->nd.M_elems * sizeof(double)) >> 20);
+  }
 }
 
 template <typename T>
@@ -271,15 +279,10 @@ static int build_chains(const covgpu_problem* p, bool vi, std::vector<int>& perm
   return COVGPU_OK;
 }
 
-// Host-only: the block partition of the GBA pose system (k_arrow.hip). block_of_kf[k] >= 0: block (= agent) whose
-// interior holds keyframe k; -1: border ("shared") keyframe. Returns the number of blocks, 0 if the dense form is kept.
-extern "C" int32_t covgpu_gba_partition(const covgpu_options* opt, const covgpu_problem* p, int32_t force, int32_t* block_of_kf) {
-  const bool vi = !opt->visual_only;
-  for (int k = 0; k < p->num_kf; ++k) block_of_kf[k] = -1;
-  if (validate(p, false, vi) != COVGPU_OK || !vi) return 0;
-  std::vector<int> perm, pos_kf, chain_ptr;
-  if (build_chains(p, vi, perm, pos_kf, chain_ptr) != COVGPU_OK) return 0;
-  // unique covisible pairs (free keyframes only) and edge pairs, as chain-major positions i > j
+// unique covisible pairs (free keyframes only) and edge pairs, as chain-major positions i > j (host-only plan functions;
+// upload_impl builds the same pair list with the per-pair observation lists the device needs)
+static bool host_pairs(const covgpu_problem* p, const std::vector<int>& perm, std::vector<int>& pi, std::vector<int>& pj, std::vector<int>& ei,
+                       std::vector<int>& ej) {
   std::vector<long long> keys;
   for (int l = 0; l < p->num_lm; ++l)
     for (int a = p->lm_obs_ptr[l]; a < p->lm_obs_ptr[l + 1]; ++a) {
@@ -291,19 +294,87 @@ extern "C" int32_t covgpu_gba_partition(const covgpu_options* opt, const covgpu_
       }
     }
   std::sort(keys.begin(), keys.end()); keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-  std::vector<int> pi(keys.size()), pj(keys.size()), ei, ej;
+  pi.resize(keys.size()); pj.resize(keys.size()); ei.clear(); ej.clear();
   for (size_t q = 0; q < keys.size(); ++q) { pi[q] = (int)(keys[q] >> 32); pj[q] = (int)(keys[q] & 0xffffffffll); }
   for (int e = 0; e < p->num_edge; ++e) {
     const int a = perm[p->edge_i[e]], b = perm[p->edge_j[e]];
-    if (a == b) return 0;
+    if (a == b) return false;
     ei.push_back(std::max(a, b)); ej.push_back(std::min(a, b));
   }
+  return true;
+}
+
+// Host-only: the block partition of the GBA pose system (k_arrow.hip). block_of_kf[k] >= 0: block (= agent) whose
+// interior holds keyframe k; -1: border ("shared") keyframe. Returns the number of blocks, 0 if the dense form is kept.
+extern "C" int32_t covgpu_gba_partition(const covgpu_options* opt, const covgpu_problem* p, int32_t force, int32_t* block_of_kf) {
+  const bool vi = !opt->visual_only;
+  for (int k = 0; k < p->num_kf; ++k) block_of_kf[k] = -1;
+  if (validate(p, false, vi) != COVGPU_OK || !vi) return 0;
+  std::vector<int> perm, pos_kf, chain_ptr;
+  if (build_chains(p, vi, perm, pos_kf, chain_ptr) != COVGPU_OK) return 0;
+  std::vector<int> pi, pj, ei, ej;
+  if (!host_pairs(p, perm, pi, pj, ei, ej)) return 0;
   ArrowHostPlan hp;
   if (!gba_plan_analyse(p->num_kf, (int)chain_ptr.size() - 1, chain_ptr.data(), (int)pi.size(), pi.data(), pj.data(), (int)ei.size(), ei.data(), ej.data(),
                         force != 0, pos_kf.data(), hp))
     return 0;
   for (int k = 0; k < p->num_kf; ++k) block_of_kf[k] = hp.blk[perm[k]];
   return hp.nblk;
+}
+
+// Host-only: the nested-dissection plan of the reduced camera system (nd_plan.hpp, k_front.hip) for inspection and the CPU
+// tests (tests/test_nd_plan.py replays the elimination in numpy on the oracle's system).
+struct covgpu_nd_plan { NdHostPlan hp; std::vector<int> pos_kf; };
+static int nd_leaf_dims(int requested) {
+  if (requested > 0) return requested;
+  const char* e = getenv("COVGPU_ND_LEAF");
+  const int v = e ? atoi(e) : 0;
+  return v > 0 ? v : 900;
+}
+extern "C" int covgpu_nd_plan_create(const covgpu_options* opt, const covgpu_problem* p, int32_t leaf_dims, covgpu_nd_plan** out) {
+  return guarded([&] {
+    const bool vi = !opt->visual_only;
+    *out = nullptr;
+    RC(validate(p, false, vi));
+    std::vector<int> perm, pos_kf, chain_ptr, pi, pj, ei, ej;
+    RC(build_chains(p, vi, perm, pos_kf, chain_ptr));
+    if (!host_pairs(p, perm, pi, pj, ei, ej)) { g_err = "invalid problem: self edge"; return (int)COVGPU_ERR_INVALID_ARG; }
+    covgpu_nd_plan* pl = new covgpu_nd_plan();
+    pl->pos_kf = pos_kf;
+    if (!nd_plan_build(p->num_kf, vi, (int)chain_ptr.size() - 1, chain_ptr.data(), (int)pi.size(), pi.data(), pj.data(), (int)ei.size(), ei.data(), ej.data(),
+                       nd_leaf_dims(leaf_dims), pl->hp)) {
+      delete pl; g_err = "nested-dissection plan: a coupling joins two branches"; return (int)COVGPU_ERR_INVALID_ARG;
+    }
+    *out = pl;
+    return (int)COVGPU_OK;
+  });
+}
+extern "C" void covgpu_nd_plan_destroy(covgpu_nd_plan* pl) { delete pl; }
+// out[16] = { nodes, levels, depth, own entries, front-structure entries, front elements (all batches), flops, largest own dims,
+//             largest border dims, root own dims, 0 ... }
+extern "C" void covgpu_nd_plan_info(const covgpu_nd_plan* pl, int64_t* out) {
+  for (int i = 0; i < 16; ++i) out[i] = 0;
+  const NdHostPlan& h = pl->hp;
+  out[0] = h.nnodes; out[1] = h.nlev; out[2] = h.maxdepth;
+  for (int n = 0; n < h.nnodes; ++n) {
+    out[3] += (int64_t)h.own[n].size(); out[4] += (int64_t)h.strct[n].size();
+    out[7] = std::max<int64_t>(out[7], h.own_dims[n]); out[8] = std::max<int64_t>(out[8], h.st_dims[n]);
+    if (h.parent[n] < 0) out[9] = std::max<int64_t>(out[9], h.own_dims[n]);
+  }
+  out[5] = (int64_t)h.front_elems; out[6] = (int64_t)h.flops;
+}
+// per node: parent, level, own_ptr / st_ptr [nodes + 1]; variables as 2 * IR keyframe + (0 pose | 1 speed-bias)
+extern "C" void covgpu_nd_plan_arrays(const covgpu_nd_plan* pl, int32_t* parent, int32_t* level, int32_t* own_ptr, int32_t* own_var, int32_t* st_ptr,
+                                      int32_t* st_var) {
+  const NdHostPlan& h = pl->hp;
+  int o = 0, s = 0;
+  auto ir = [&](int v) { return 2 * pl->pos_kf[v >> 1] + (v & 1); };
+  for (int n = 0; n < h.nnodes; ++n) {
+    parent[n] = h.parent[n]; level[n] = h.level[n]; own_ptr[n] = o; st_ptr[n] = s;
+    for (int v : h.own[n]) own_var[o++] = ir(v);
+    for (int v : h.strct[n]) st_var[s++] = ir(v);
+  }
+  own_ptr[h.nnodes] = o; st_ptr[h.nnodes] = s;
 }
 
 // Host-only: the multi-GPU split of ONE map. The global block-arrow plan plus the owner of
@@ -381,6 +452,12 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   for (int c = 0; c < P.nchains; ++c)
     for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) chain_end[q] = chain_ptr[c + 1];
   P.reproj_loss_a = opt->reproj_loss_a; P.gravity = opt->gravity;
+  // ---- form of the reduced camera system. Default: multifrontal fronts over a nested-dissection tree (k_front.hip).
+  //      COVGPU_GBA_DENSE=1: the same code with ONE front = the dense system (equality tests). The round-2 forms (IMU-chain
+  //      elimination + block-arrow / dense pose system) remain for the agent-sharded solve, the pose graph and covgpu_schur.
+  const char* e_dense = getenv("COVGPU_GBA_DENSE");
+  const char* e_legacy = getenv("COVGPU_GBA_LEGACY");
+  const bool use_nd = !pgo && !c->sharded && allow_arrow && dense_panel_chain() && !(e_legacy && e_legacy[0] == '1');
   const size_t K = P.K;
   RC(dev_upload(c, &P.pose0, p->kf_pose, 7 * K));
   if (p->kf_speed_bias) RC(dev_upload(c, &P.sb0, p->kf_speed_bias, 9 * K)); else { RC(dev_alloc(c, &P.sb0, 9 * K)); HIPCHK(hipMemsetAsync(P.sb0, 0, 9 * K * sizeof(double), c->st)); }
@@ -526,13 +603,13 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_upload(c, &P.pos_chain_end, chain_end.data(), K));
   RC(dev_alloc(c, &P.bred, (size_t)P.n));
   RC(dev_alloc(c, &P.bp, (size_t)2 * P.npad));
-  const size_t Kv = vi ? K : 0;
+  const size_t Kv = vi ? K : 0, Kc = (vi && !use_nd) ? K : 0;  // Kc: buffers of the IMU-chain elimination (k_struct.hip) only
   RC(dev_alloc(c, &P.Ad, 81 * Kv)); RC(dev_alloc(c, &P.Ae, 81 * Kv));
   RC(dev_alloc(c, &P.Bp, 54 * Kv)); RC(dev_alloc(c, &P.Bs, 54 * Kv)); RC(dev_alloc(c, &P.Bn, 54 * Kv));
-  RC(dev_alloc(c, &P.Ldinv, 81 * Kv)); RC(dev_alloc(c, &P.Lsub, 81 * Kv));
-  RC(dev_alloc(c, &P.Mblk, 81 * Kv)); RC(dev_alloc(c, &P.GI, 81 * Kv));
-  RC(dev_alloc(c, &P.Nback, 90 * Kv)); RC(dev_alloc(c, &P.Zfwd, 90 * Kv));
-  RC(dev_alloc(c, &P.zs, 9 * Kv)); RC(dev_alloc(c, &P.xs, 9 * Kv));
+  RC(dev_alloc(c, &P.Ldinv, 81 * Kc)); RC(dev_alloc(c, &P.Lsub, 81 * Kc));
+  RC(dev_alloc(c, &P.Mblk, 81 * Kc)); RC(dev_alloc(c, &P.GI, 81 * Kc));
+  RC(dev_alloc(c, &P.Nback, 90 * Kc)); RC(dev_alloc(c, &P.Zfwd, 90 * Kc));
+  RC(dev_alloc(c, &P.zs, 9 * Kc)); RC(dev_alloc(c, &P.xs, 9 * Kc));
   {  // Y per chain (common.hpp): [9 Kc][roundup(6 Kc, 16)] blocks back to back
     std::vector<size_t> yoff(P.nchains);
     std::vector<int> yld(P.nchains), cbeg(P.K), cidx(P.K);
@@ -552,8 +629,8 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
     }
     P.cc_n = (int)wch.size();
     RC(dev_upload(c, &P.cc_chain, wch.data(), wch.size())); RC(dev_upload(c, &P.cc_blk, wbl.data(), wbl.size()));
-    RC(dev_alloc(c, &P.Y, vi ? ytot : 0));
-    if (vi) HIPCHK(hipMemsetAsync(P.Y, 0, ytot * sizeof(double), c->st));  // only the chain trapezoids are ever written
+    RC(dev_alloc(c, &P.Y, Kc ? ytot : 0));
+    if (Kc) HIPCHK(hipMemsetAsync(P.Y, 0, ytot * sizeof(double), c->st));  // only the chain trapezoids are ever written
     HIPCHK(hipStreamSynchronize(c->st));
   }
   RC(dev_alloc(c, &P.grad, (size_t)P.N)); RC(dev_alloc(c, &P.hdiag, (size_t)P.N));
@@ -599,12 +676,44 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
     // ---- where does the pose-pose system live? Fused multi-agent maps: block-arrow buffers (k_arrow.hip); else dense.
     //      COVGPU_GBA_DENSE=1 keeps the dense form, COVGPU_GBA_ARROW=1 forces the arrow form whenever a plan exists (tests).
     ArrowHostPlan hp;
-    const char* e_dense = getenv("COVGPU_GBA_DENSE");
     const char* e_arrow = getenv("COVGPU_GBA_ARROW");
     const bool force = e_arrow && e_arrow[0] == '1';
     bool have_plan = false;
     std::vector<char> own_pose(P.K, 1), own_chain(P.K, 1);  // by IR keyframe: does THIS rank count the pose / the speed-bias rows
-    if (c->sharded && !pgo) {
+    if (use_nd) {
+      NdHostPlan nhp;
+      const bool one_front = e_dense && e_dense[0] == '1';
+      if (!nd_plan_build(P.K, vi, P.nchains, chain_ptr.data(), (int)h_pair_i.size(), h_pair_i.data(), h_pair_j.data(), P.nepairs, ei.data(), ej.data(),
+                         one_front ? 0x3fffffff : nd_leaf_dims(0), nhp)) {
+        g_err = "nested-dissection plan: a coupling joins two branches"; return COVGPU_ERR_INVALID_ARG;
+      }
+      if (nhp.maxdepth > 64) { g_err = "nested-dissection plan: tree deeper than 64 levels"; return COVGPU_ERR_INVALID_ARG; }
+      NdDev& nd = c->nd;
+      nd_tables(nhp, pos_kf.data(), P.D, nd);
+      P.nd = 1; P.nd_nnodes = nhp.nnodes; P.nd_nlev = nhp.nlev; P.nd_maxd = nhp.maxdepth;
+      RC(dev_upload(c, &P.nd_vnode, nd.h_vnode.data(), nd.h_vnode.size())); RC(dev_upload(c, &P.nd_voff, nd.h_voff.data(), nd.h_voff.size()));
+      RC(dev_upload(c, &P.nd_vord, nd.h_vord.data(), nd.h_vord.size()));
+      RC(dev_upload(c, &P.nd_ndepth, nd.h_ndepth.data(), nd.h_ndepth.size())); RC(dev_upload(c, &P.nd_nI, nd.h_nI.data(), nd.h_nI.size()));
+      RC(dev_upload(c, &P.nd_ntab, nd.h_ntab.data(), nd.h_ntab.size()));
+      RC(dev_upload(c, &P.nd_abase, nd.h_abase.data(), nd.h_abase.size())); RC(dev_upload(c, &P.nd_fidx, nd.h_fidx.data(), nd.h_fidx.size()));
+      RC(dev_upload(c, &nd.own_dims, nd.h_own_dims.data(), nd.h_own_dims.size())); RC(dev_upload(c, &nd.st_dims, nd.h_st_dims.data(), nd.h_st_dims.size()));
+      RC(dev_upload(c, &nd.own_g, nd.h_own_g.data(), nd.h_own_g.size())); RC(dev_upload(c, &nd.st_g, nd.h_st_g.data(), nd.h_st_g.size()));
+      RC(dev_upload(c, &nd.gidx, nd.h_gidx.data(), nd.h_gidx.size()));
+      RC(dev_upload(c, &nd.cptr, nd.h_cptr.data(), nd.h_cptr.size())); RC(dev_upload(c, &nd.cidx, nd.h_cidx.data(), nd.h_cidx.size()));
+      RC(dev_upload(c, &nd.inv_off, nd.h_inv_off.data(), nd.h_inv_off.size())); RC(dev_upload(c, &nd.inv, nd.h_inv.data(), nd.h_inv.size()));
+      RC(dev_upload(c, &nd.rhs_node, nd.h_rhs_node.data(), nd.h_rhs_node.size()));
+      for (NdLevel& L : nd.lev) RC(dev_upload(c, &L.live, L.live_h.data(), L.live_h.size()));
+      RC(dev_alloc(c, &P.nd_M, nd.M_elems)); RC(dev_alloc(c, &P.nd_rhs, nd.rhs_elems)); RC(dev_alloc(c, &P.nd_Linv, nd.linv_elems));
+      RC(dev_alloc(c, &P.nd_dummy, (size_t)64));
+      c->chol.tri_clear();   // the live-tile lists of the bulk updates belong to the previous problem
+      HIPCHK(hipStreamSynchronize(c->st));
+      if (opt->verbose) {
+        int panels = 0;
+        for (const NdLevel& L : nd.lev) panels += L.nI / 256;
+        std::printf("[covgpu] multifrontal plan: %d fronts in %d levels (%d serial 256-column panels), root order %d, %.2e flops, fronts %.2f GB\n", nhp.nnodes,
+                    nhp.nlev, panels, nd.lev.back().nI, nhp.flops, nd.M_elems * 8e-9);
+      }
+    } else if (c->sharded && !pgo) {
       // global plan given (covgpu_shard_plan): border and block of every keyframe; this rank owns the blocks of its agents
       if (!vi || (int)c->shard_block_of_kf.size() != P.K) { g_err = "sharded solve needs the visual-inertial problem the shard plan was made for"; return COVGPU_ERR_INVALID_ARG; }
       std::vector<char> border(P.K), owned(P.K);
@@ -621,7 +730,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
         for (int q = chain_ptr[ch]; q < chain_ptr[ch + 1]; ++q) own_chain[pos_kf[q]] = mine;
       }
       for (int q = 0; q < P.K; ++q) own_pose[pos_kf[q]] = border[q] ? (c->rank == 0) : owned[q];
-    } else if (vi && allow_arrow && !(e_dense && e_dense[0] == '1')) {
+    } else if (vi && allow_arrow) {
       have_plan = gba_plan_analyse(P.K, P.nchains, chain_ptr.data(), (int)h_pair_i.size(), h_pair_i.data(), h_pair_j.data(), P.nepairs, ei.data(), ej.data(),
                                    force, pos_kf.data(), hp);
     }
@@ -663,7 +772,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
       if (opt->verbose)
         std::printf("[covgpu] arrow plan: %d blocks (largest interior %d keyframes, own border <= %d), border %d keyframes; buffers %.2f GB\n",
                     hp.nblk, hp.max_int, hp.max_own, hp.nbk, ((double)P.ar_nblk * P.ar_ntot * P.ar_ntot + (double)P.ar_nb * P.ar_nb) * 8e-9);
-    } else {
+    } else if (!P.nd) {
       RC(dev_alloc(c, &P.Sred, (size_t)P.npad * P.npad));
       RC(dev_alloc(c, &P.Linv, (size_t)(P.npad / kTile) * kTile * kTile));
     }
@@ -742,7 +851,8 @@ static void enqueue_build(covgpu_context* c, double mu) {
   c->chol.init();
   (void)hipEventRecord(c->chol.ev_fill, c->st);
   (void)hipStreamWaitEvent(c->chol.head, c->chol.ev_fill, 0);
-  launch_zero_pose_system(P, c->chol.head);
+  if (P.nd) launch_nd_zero(P, c->nd, c->chol.head);
+  else launch_zero_pose_system(P, c->chol.head);
   (void)hipEventRecord(c->chol.ev_fill, c->chol.head);
   launch_zero_system(P, c->st);
   // inertial factors first: the speed-bias blocks are then final, and the (serial, one wave per IMU chain) chain
@@ -751,7 +861,7 @@ static void enqueue_build(covgpu_context* c, double mu) {
   if (P.vi) {
     launch_imu_gather(P, 1, c->st);
     launch_finalize_diag(P, mu, 1, c->st);
-    launch_sb_chain_factor_early(P, c->st, c->chol);
+    if (!P.nd) launch_sb_chain_factor_early(P, c->st, c->chol);  // (multifrontal form: the speed-bias blocks are front columns like any other)
   }
   launch_lm_build(P, mu, c->st, c->chol.ev_fill);
   launch_imu_gather(P, 0, c->st);  // pose-dimension part: adds onto the blocks k_kf_reduce assigned (fixed order: visual, inertial, loop)
@@ -774,7 +884,7 @@ static void enqueue_solve(covgpu_context* c, double* dst_all) {
   // with profiling on, every bulk trailing-update (SYRK) launch gets its own event pair on its stream so that
   // bench.py can quote the dominant kernel's duration
   if (c->profiling) (void)hipEventRecord(c->ev[2], c->st);
-  launch_structured_solve(P, dst_all, c->st, c->chol, c->pgo_plan.active ? &c->pgo_plan : nullptr);
+  launch_structured_solve(P, dst_all, c->st, c->chol, c->pgo_plan.active ? &c->pgo_plan : nullptr, c->nd.active ? &c->nd : nullptr);
   if (c->profiling) (void)hipEventRecord(c->ev[3], c->st);
   launch_lm_backsub(P, dst_all, dst_all, c->st);
 }

@@ -283,6 +283,22 @@ int32_t covgpu_pgo_partition(int32_t num_kf, int32_t num_edge, const int32_t* ed
  * skips the pay-off test). Invariant: no covisible pair and no loop edge joins the interiors of two blocks. */
 int32_t covgpu_gba_partition(const covgpu_options* opt, const covgpu_problem* p, int32_t force, int32_t* block_of_kf);
 
+/* Host-only (no device needed): the nested-dissection plan of the reduced camera system — the elimination tree the
+ * multifrontal MFMA Cholesky (covins_amd/csrc/k_front.hip) runs, i.e. what the reference gets from CHOLMOD's fill-reducing
+ * ordering inside ceres::Solve(SPARSE_SCHUR) (optimization_be.cpp:560-565). Unknowns are, per keyframe, a 6-dim pose block
+ * (variable 2k) and a 9-dim speed-bias block (variable 2k+1, visual-inertial only). Every tree node owns some variables
+ * (eliminated there) and carries the ancestor variables its subtree couples to; nodes of equal height form one batch.
+ * leaf_dims <= 0: default (COVGPU_ND_LEAF or 900 scalar unknowns per leaf). tests/test_nd_plan.py replays the plan in numpy. */
+typedef struct covgpu_nd_plan covgpu_nd_plan;
+int  covgpu_nd_plan_create(const covgpu_options* opt, const covgpu_problem* p, int32_t leaf_dims, covgpu_nd_plan** out);
+void covgpu_nd_plan_destroy(covgpu_nd_plan* plan);
+/* out16 = { nodes, levels, depth, own entries, front-structure entries, front elements over all batches, flops of the partial
+ *           factorisations, largest own dims, largest border dims, largest root, 0... } */
+void covgpu_nd_plan_info(const covgpu_nd_plan* plan, int64_t* out16);
+/* parent / level [nodes]; own_ptr / st_ptr [nodes + 1]; own_var / st_var: 2 * keyframe + (0 pose | 1 speed-bias) */
+void covgpu_nd_plan_arrays(const covgpu_nd_plan* plan, int32_t* parent, int32_t* level, int32_t* own_ptr, int32_t* own_var,
+                           int32_t* st_ptr, int32_t* st_var);
+
 /* ---------------------------------------------------------------- multi-GPU: ONE map sharded by agent
  * BASELINE.json north star: "the merged multi-agent map shards by agent/sub-map across the GPUs of one node with RCCL
  * all-reduce over xGMI on the shared-pose Hessian blocks at each LM iteration". One process and one context per GPU.

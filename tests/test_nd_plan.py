@@ -1,0 +1,138 @@
+"""Nested-dissection plan of the multifrontal GBA solve (covgpu_nd_plan_*, covins_amd/csrc/nd_plan.hip): host-only.
+
+The plan is replayed in numpy on the ORACLE's reduced camera system (oracle/covo.schur): fronts are assembled from the
+system's entries exactly where the device kernels put them (entry between two variables -> front of the deeper owner),
+factorised partially, extend-added into their parents and back-substituted top-down. The result must equal the dense
+solve: this pins the separator property, the symbolic structure (no fill outside the fronts) and the batch levels."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from covins_amd import backend, mapdata, synth
+from oracle import covo
+
+
+def _plan(prob, opt, leaf):
+    lib = backend.lib()
+    h = C.c_void_p()
+    s = prob.as_struct()
+    rc = lib.covgpu_nd_plan_create(C.byref(opt), C.byref(s), leaf, C.byref(h))
+    assert rc == 0, lib.covgpu_last_error()
+    info = (C.c_int64 * 16)()
+    lib.covgpu_nd_plan_info(h, info)
+    nn = info[0]
+    parent = np.zeros(nn, np.int32); level = np.zeros(nn, np.int32)
+    optr = np.zeros(nn + 1, np.int32); sptr = np.zeros(nn + 1, np.int32)
+    ov = np.zeros(max(info[3], 1), np.int32); sv = np.zeros(max(info[4], 1), np.int32)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    lib.covgpu_nd_plan_arrays(h, ip(parent), ip(level), ip(optr), ip(ov), ip(sptr), ip(sv))
+    lib.covgpu_nd_plan_destroy(h)
+    own = [ov[optr[n]:optr[n + 1]] for n in range(nn)]
+    st = [sv[sptr[n]:sptr[n + 1]] for n in range(nn)]
+    return list(info), parent, level, own, st
+
+
+def _scalars(vs, D):
+    """IR rows of a list of variables (2 kf = pose rows 0..5, 2 kf + 1 = speed-bias rows 6..14)."""
+    out = []
+    for v in vs:
+        kf, t = int(v) >> 1, int(v) & 1
+        out.extend(range(D * kf + (6 if t else 0), D * kf + (15 if t else 6)))
+    return np.array(out, int)
+
+
+def _replay(S, b, parent, level, own, st, D):
+    nn = len(parent)
+    n = S.shape[0]
+    node_of = -np.ones(n, int)
+    rows_own = [_scalars(own[k], D) for k in range(nn)]
+    rows_st = [_scalars(st[k], D) for k in range(nn)]
+    for k in range(nn):
+        assert np.all(node_of[rows_own[k]] == -1)
+        node_of[rows_own[k]] = k
+    assert np.all(node_of >= 0), "every unknown is owned by exactly one node"
+    depth = np.zeros(nn, int)
+    for k in range(nn):
+        if parent[k] >= 0:
+            assert parent[k] < k
+            depth[k] = depth[parent[k]] + 1
+    # every structural non-zero must be representable: between two own rows of one node, or own row x border row of the deeper owner
+    covered = np.zeros_like(S, dtype=bool)
+    fronts = []
+    for k in range(nn):
+        idx = np.r_[rows_own[k], rows_st[k]]
+        assert np.all(depth[node_of[rows_st[k]]] < depth[k])
+        F = np.zeros((len(idx), len(idx)))
+        m = len(rows_own[k])
+        F[:m, :m] = S[np.ix_(rows_own[k], rows_own[k])]
+        F[m:, :m] = S[np.ix_(rows_st[k], rows_own[k])]
+        F[:m, m:] = F[m:, :m].T
+        covered[np.ix_(rows_own[k], idx)] = True
+        covered[np.ix_(idx, rows_own[k])] = True
+        fronts.append((idx, m, F, np.r_[b[rows_own[k]], np.zeros(len(rows_st[k]))]))
+    assert not np.any((S != 0) & ~covered), "a non-zero of the system has no place in any front"
+    x = np.zeros(n)
+    order = np.argsort(level, kind="stable")
+    facs = {}
+    for k in order:                      # bottom-up: children are at lower levels
+        idx, m, F, r = fronts[k]
+        L11 = np.linalg.cholesky(F[:m, :m])
+        L21 = np.linalg.solve(L11, F[:m, m:]).T
+        y1 = np.linalg.solve(L11, r[:m])
+        U = F[m:, m:] - L21 @ L21.T      # Schur complement on the border (original border-border entries live higher up: zero here)
+        rb = r[m:] - L21 @ y1
+        facs[k] = (L11, L21, y1)
+        p = parent[k]
+        if p >= 0:
+            pidx = fronts[p][0]
+            where = {int(g): i for i, g in enumerate(pidx)}
+            loc = np.array([where[int(g)] for g in idx[m:]], dtype=int)   # KeyError here = fill outside the parent's front
+            fronts[p][2][np.ix_(loc, loc)] += U
+            fronts[p][3][loc] += rb
+        else:
+            assert len(idx) == m
+    for k in order[::-1]:                # top-down
+        idx, m, F, r = fronts[k]
+        L11, L21, y1 = facs[k]
+        x[idx[:m]] = np.linalg.solve(L11.T, y1 - L21.T @ x[idx[m:]])
+    return x
+
+
+@pytest.mark.parametrize("leaf", [90, 200, 100000])
+def test_replay_equals_dense_solve(small_map, leaf):
+    prob, _ = mapdata.flatten_gba(small_map, visual_only=False, loop_loss=True)
+    opt = covo.default_options()
+    S, bvec, _ = covo.schur(prob, opt, 1e-4)
+    info, parent, level, own, st = _plan(prob, backend.default_options(), leaf)
+    if leaf >= 100000:
+        assert info[0] == 1 and info[1] == 1     # one front = the dense system
+    else:
+        assert info[0] > 3 and info[1] >= 2
+    x = _replay(S, bvec, parent, level, own, st, 15)
+    xd = np.linalg.solve(S, bvec)
+    assert np.abs(x - xd).max() <= 1e-9 * np.abs(xd).max()
+
+
+def test_visual_only_plan(tiny_map):
+    prob, _ = mapdata.flatten_gba(tiny_map, visual_only=True, loop_loss=True)
+    opt = covo.default_options(visual_only=1)
+    S, bvec, _ = covo.schur(prob, opt, 1e-3)
+    info, parent, level, own, st = _plan(prob, backend.default_options(visual_only=1), 40)
+    assert all((v & 1) == 0 for o in own for v in o)
+    x = _replay(S, bvec, parent, level, own, st, 6)
+    xd = np.linalg.solve(S, bvec)
+    assert np.abs(x - xd).max() <= 1e-9 * np.abs(xd).max()
+
+
+def test_plan_is_deterministic_and_levels_are_heights(small_map):
+    prob, _ = mapdata.flatten_gba(small_map, visual_only=False, loop_loss=True)
+    a = _plan(prob, backend.default_options(), 150)
+    b = _plan(prob, backend.default_options(), 150)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+    parent, level = a[1], a[2]
+    h = np.zeros(len(parent), int)
+    for k in range(len(parent) - 1, -1, -1):
+        if parent[k] >= 0:
+            h[parent[k]] = max(h[parent[k]], h[k] + 1)
+    assert np.array_equal(h, level)

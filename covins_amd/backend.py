@@ -177,7 +177,7 @@ class Context:
         out = (C.c_int64 * 16)()
         lib().covgpu_get_layout(self._h, out)
         keys = ("arrow", "blocks", "border_kf", "interior_kf_padded", "arrow_order", "border_order", "dense_order", "covisible_pairs",
-                "edge_pairs", "chains", "device_mib")
+                "edge_pairs", "chains", "device_mib", "nd_fronts", "nd_levels", "nd_serial_panels", "nd_root_order", "nd_front_mib")
         return {k: int(out[i]) for i, k in enumerate(keys)}
 
     # ---- per-kernel entry points (tests)

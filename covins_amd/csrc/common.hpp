@@ -253,6 +253,11 @@ struct CholAux {
   void (*reduce)(void* ctx, double* dev, size_t n, int op) = nullptr;
   void* reduce_ctx = nullptr;
   int panel_n = 0;
+  std::vector<int> panel_tag;
+  // dev aid (COVGPU_TRACE_PANELS=1): timestamp on stream s, printed by collect() relative to the first mark of the solve. Tags:
+  // >= 0 start of big panel `tag` of a factorisation | -1 solve begins | -2 fronts assembled | -3 extend-add done | -4 level factored |
+  // -5 level back-substituted | -6 solve ends
+  void mark(hipStream_t s, int tag);
   bool profile = false;
   double syrk_ms = 0, syrk_flops = 0;
   long n_syrk = 0;
@@ -268,6 +273,9 @@ struct DenseBatch {
   const int* live = nullptr; int tI = 0; const int* live_h = nullptr;  // live / tI: see GemmArgs (k_chol.hip)
   const long long* tab = nullptr;  // per-matrix (element offset, leading dimension): fronts of unequal order in one batch (GemmArgs::btab)
   int tri_slot = -1;               // which CholAux::tri_lev entry caches the live-tile lists of this batch's bulk updates
+  int own_max = 0;                 // > 0: largest real interior order over the batch — columns beyond it are identity padding in EVERY
+                                   // matrix (L = I, block inverses = I, y = 0 already in place), so the panel kernel factors only the
+                                   // 16-column blocks that hold a real column and skips all-padding panels
 };
 void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax, int tstop = -1,
                               bool solve = true, DenseBatch bt = DenseBatch());  // tstop >= 0 (even): eliminate tile columns [0, tstop) only
@@ -276,7 +284,9 @@ void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStrea
 // instead of the 128x128 inverse. COVGPU_PANEL=0 selects the round-2a chain (two 128-column potrf + inverse per panel).
 bool dense_panel_chain();
 void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
-                        hipStream_t st, const long long* btab = nullptr);
+                        hipStream_t st, const long long* btab = nullptr, int nb = -1);  // nb: 16-column blocks to factor (-1: the whole panel)
+void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, double* x, int ncol, int nbt, size_t sM, size_t sR, hipStream_t st,
+                      const long long* btab, const int* live, int tI);
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
                      size_t sR, const int* live, int tI, hipStream_t st, bool chain = false, const long long* btab = nullptr);
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,
@@ -324,6 +334,8 @@ struct NdLevel {
   size_t rhs_off = 0, linv_off = 0;       // element offsets of the level's right-hand sides / block inverses
   int* live = nullptr;                    // [n][2] device: real interior tiles | real border tiles (GemmArgs::live)
   std::vector<int> live_h;
+  int own_max = 0;                        // largest real interior order of the batch (DenseBatch::own_max)
+  int ext_first = 0, ext_count = 0;       // this level's slice of the extend-add work list (NdDev::ext)
 };
 struct NdDev {
   bool active = false;
@@ -335,13 +347,15 @@ struct NdDev {
   int *cptr = nullptr, *cidx = nullptr;    // [nodes + 1], children (node ids)
   int *inv_off = nullptr, *inv = nullptr;  // [nodes] offset of the node's map parent front row -> own front row (-1: none)
   int *rhs_node = nullptr;                 // [nodes] element offset of the node's right-hand side in nd_rhs
+  int *ext = nullptr;                      // extend-add work list: (node, tile row, tile column) of 64x64 tiles, level by level
   // host staging of the tables (filled by nd_tables, uploaded by solver.hip)
   std::vector<int> h_vnode, h_voff, h_vord, h_ndepth, h_nI, h_abase, h_fidx, h_lev_node, h_own_dims, h_st_dims, h_own_g, h_st_g, h_gidx, h_cptr, h_cidx,
-      h_inv_off, h_inv, h_rhs_node;
+      h_inv_off, h_inv, h_rhs_node, h_ext;
   std::vector<long long> h_ntab;
   size_t M_elems = 0, rhs_elems = 0, linv_elems = 0;
 };
 void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, NdDev& dev);  // host tables + level shapes from the plan
+void launch_nd_init(const DevProblem& P, const NdDev& nd, hipStream_t st);    // once per upload: identity block inverses for the padding columns
 void launch_nd_zero(const DevProblem& P, const NdDev& nd, hipStream_t st);    // per iteration: clear the live tiles, identity on interior padding
 void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, hipStream_t st, CholAux& ax);  // damped system in the fronts + bred -> dst (IR layout)
 

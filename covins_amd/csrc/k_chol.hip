@@ -26,6 +26,7 @@
 //     with given trailing unknowns — the block-arrow pose-graph solve (k_pgo.hip) is built from these.
 // Forward substitution rides along with the factorisation (potrf forms y_p, every TRSM takes its tile's product
 // with y_p out of the right-hand side); the backward solve reuses the stored L_pp^-1 blocks, one launch per panel.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -737,17 +738,25 @@ void CholAux::destroy() {
   cf_pending = false;
   if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
 }
+void CholAux::mark(hipStream_t s, int tag) {
+  static const bool trace_panels = getenv("COVGPU_TRACE_PANELS") != nullptr;
+  if (!trace_panels) return;
+  while ((int)panel_ev.size() <= panel_n) { hipEvent_t e; (void)hipEventCreate(&e); panel_ev.push_back(e); }
+  if ((int)panel_tag.size() <= panel_n) panel_tag.resize(panel_n + 1);
+  (void)hipEventRecord(panel_ev[panel_n], s);
+  panel_tag[panel_n++] = tag;
+}
 // after the streams have been synchronised: accumulate the bracketed trailing-update launches
 void CholAux::collect() {
-  if (panel_n > 1) {  // un-profiled progression of the last factorisation: when did each big panel's chain start?
-    fprintf(stderr, "covgpu panel starts [us]:");
+  if (panel_n > 1) {  // un-profiled progression of the last solve: when did each big panel's chain start?
+    fprintf(stderr, "covgpu marks [us]:");
     for (int i = 1; i < panel_n; ++i) {
       float ms = 0;
-      if (hipEventElapsedTime(&ms, panel_ev[0], panel_ev[i]) == hipSuccess) fprintf(stderr, " %.0f", ms * 1e3);
+      if (hipEventElapsedTime(&ms, panel_ev[0], panel_ev[i]) == hipSuccess) fprintf(stderr, " %d:%.0f", panel_tag[i], ms * 1e3);
     }
     fprintf(stderr, "\n");
-    panel_n = 0;
   }
+  panel_n = 0;
   if (!profile) return;
   for (size_t i = 0; i < prof_flops.size(); ++i) {
     float ms = 0;
@@ -811,7 +820,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   };
   // C tiles (rows [r0, r1), tile columns [tc0, tc0+ntc)) -= A[rows, K] A[tc.., K]^T, K = tiles kt0.. (KD columns); lower part only
   auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2, bool quad) {
-    if (r1 <= r0 || ntc <= 0) return;
+    if (r1 <= r0 || ntc <= 0 || KD <= 0) return;
     GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab};
     if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4 * nbt), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0, nbt), dim3(256), lds_gemm, s2, g);
@@ -825,12 +834,18 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   //   R  rows r = everything below (t0+4 ..): full-tile kernels, needed one panel later;
   //   B  the bulk rank-256 trailing update (triangle from tile t0+4).
   hipStream_t M = st, H = ax.head, R = ax.mid, B = ax.aux;
-  static const bool trace_panels = getenv("COVGPU_TRACE_PANELS") != nullptr;  // dev aid: DESIGN.md §4.5, un-profiled timeline
   auto wait = [](hipStream_t s2, hipEvent_t e) { (void)hipStreamWaitEvent(s2, e, 0); };
   // Partial factorisation (tstop >= 0, even): eliminate tile columns [0, tstop) only; the trailing block then holds
   // its Schur complement (and, with the forward substitution riding along, b's trailing part the reduced right-hand
   // side). Used by the block-arrow pose-graph solve (k_pgo.hip).
   const int Pstop = (tstop >= 0 && tstop < T) ? tstop / 2 : NP;
+  // K range of big panel Pp's rank update: its columns beyond the batch's largest real interior order are identity padding
+  // with zeros below (DenseBatch::own_max) — multiples of 32 (chunk of the quarter-tile kernels); 0: nothing to apply
+  auto kd = [&](int Pp) {
+    const int full = std::min(2, T - 2 * Pp) * kTile;
+    if (bt.own_max <= 0) return full;
+    return std::max(0, std::min(full, ((bt.own_max - 2 * Pp * kTile + 31) / 32) * 32));
+  };
   if (bt.tri_slot >= (int)ax.tri_lev.size()) ax.tri_lev.resize(bt.tri_slot + 1);
   CholAux::TriCache& tc = bt.tri_slot >= 0 ? ax.tri_lev[bt.tri_slot] : ax.tri0;
   if (bt.live_h != nullptr && tc.key != T * 4096 + nbt) {  // live-tile lists of every panel's bulk update (static per problem)
@@ -880,13 +895,13 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         wait(H, eC[P - 1]);                    // L rows h0.. were rest rows of panel P-1
         wait(H, eH[P - 1]);                    // B operand: L rows t0, t0+1 — their last TRSM ran on the chain's stream
         if (P >= 2) wait(H, eB[P - 2]);        // bulk(P-2) was the previous writer of these tiles
-        rect(h0, h1, t0, w, t0 - 2, 2 * kTile, H, true);
+        rect(h0, h1, t0, w, t0 - 2, kd(P - 1), H, true);
         if (panel256) (void)hipEventRecord(eHp[P], H);
       }
       if (T > h1) {
         wait(R, eH[P - 1]);                    // B operand: L rows t0, t0+1 (rows h of panel P-1)
         if (P >= 2) wait(R, eB[P - 2]);
-        rect(h1, T, t0, w, t0 - 2, 2 * kTile, R, false);
+        rect(h1, T, t0, w, t0 - 2, kd(P - 1), R, false);
       }
     }
     if (P == Pstop) {  // only the look-ahead updates of the last eliminated panel; nothing of this panel is factored
@@ -897,15 +912,12 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       break;
     }
     // ---- M: critical chain
-    if (trace_panels) {
-      while ((int)ax.panel_ev.size() <= P + 1) { hipEvent_t e; (void)hipEventCreate(&e); ax.panel_ev.push_back(e); }
-      (void)hipEventRecord(ax.panel_ev[P], M);
-      ax.panel_n = P + 1;
-    }
+    ax.mark(M, P);
     if (panel256) {
       // 256-column chain (k_panel.hip): one workgroup factors the whole diagonal block, rows h follow on the same stream by
       // block substitution, rows r on theirs — three dependent launches per panel instead of six
-      launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab);
+      const int nbp = bt.own_max > 0 ? std::max(0, std::min(8 * w, (bt.own_max - t0 * kTile + 15) / 16)) : -1;
+      launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp);
       (void)hipEventRecord(e1[P], M);
       if (h1 > h0) {
         if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
@@ -960,7 +972,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       const int u0 = t0 + 2, uw = (T - u0 >= 2) ? 2 : 1;
       wait(M, eH[P]);                          // L rows u0, u0+1
       if (P >= 1) wait(M, eB[P - 1]);          // bulk(P-1) was the previous writer of these tiles
-      rect(u0, u0 + uw, u0, uw, t0, 2 * kTile, M, true);
+      rect(u0, u0 + uw, u0, uw, t0, kd(P), M, true);
       (void)hipEventRecord(eRc[P + 1], M);
     }
     // ---- B: bulk of SYRK(P), triangle starting two tile columns further (those belong to the look-ahead)
@@ -969,9 +981,9 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     // A bulk launched at the same instant as the next diagonal update takes every workgroup slot first and the
     // chain waits ~75 us for the first round of tiles to retire: the bulk starts after that small kernel.
     if (P + 1 < NP) wait(B, eRc[P + 1]);
-    if (nt > 0) {
+    if (nt > 0 && kd(P) > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
-      GemmArgs g{S, ld, t0 * kTile, w * kTile, tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab};
+      GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab};
       // arrow buffers: the live tiles of this panel's update as an explicit, XCD-balanced list (built once per problem).
       // The implicit triangle grid x batch launched ~2.6k workgroups of which ~400 did work, with every batch's first
       // supertile on XCD 0: 17 TFLOP/s.
@@ -992,7 +1004,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, B, g);
         if (ax.profile) {
           (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], B);
-          ax.prof_flops.push_back(pairs * 2.0 * kTile * kTile * (w * kTile));
+          ax.prof_flops.push_back(pairs * 2.0 * kTile * kTile * kd(P));
         }
       }
     }
@@ -1013,6 +1025,11 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
 void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStream_t st, int tfact, int tend, DenseBatch bt) {
   const int nbt = bt.n > 0 ? bt.n : 1;
   const size_t ld = (size_t)npad;
+  if (dense_panel_chain() && tend > tfact) {  // all given rows in one launch (k_panel.hip)
+    launch_bwd_given(S, ld, tfact * kTile, tend * kTile, b + npad, b, tfact * kTile, nbt, bt.sM, bt.sR, st, bt.tab, bt.live, bt.tI);
+    tend = tfact;
+  }
+  if (bt.own_max > 0 && tend <= tfact) tend = std::min(tend, (bt.own_max + kTile - 1) / kTile);  // all-padding interior tiles: x = 0
   for (int p = tend - 1; p >= 0; --p) {
     const bool given = p >= tfact;
     const int ncol = given ? tfact * kTile : p * kTile;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_finalize_diag(DevProblem P, double mu, 
     }
   }
   const int pad = 6 * P.K + q;  // padding rows of C
-  if (which != 1 && !P.arrow && q < P.npad - 6 * P.K) P.Sred[(size_t)pad * P.npad + pad] = 1.0;  // (arrow layout: k_arrow_init)
+  if (which != 1 && !P.arrow && !P.nd && q < P.npad - 6 * P.K) P.Sred[(size_t)pad * P.npad + pad] = 1.0;  // (arrow layout: k_arrow_init; fronts: k_nd_zero)
 }
 
 // fixed-order sum of one slot's partials -> scal[slot]

@@ -99,6 +99,31 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, NdDev& dev) {
       row += NdHostPlan::vdim(v);
     }
   }
+  // extend-add work lists: per level the 64x64 tiles of the parents' fronts that receive something from a child
+  for (int l = 0; l < hp.nlev; ++l) {
+    NdLevel& L = dev.lev[l];
+    L.ext_first = (int)dev.h_ext.size() / 3;
+    for (int k = 0; k < L.n; ++k) {
+      const int i = L.first + k, n = order[i];
+      const int T = (ld[i] + 63) / 64;
+      std::vector<char> mark((size_t)T * T, 0);
+      for (int c : hp.child[n]) {
+        const int ic = newid[c];
+        const int* inv = dev.h_inv.data() + dev.h_inv_off[ic];
+        std::vector<int> rows;
+        for (int t = 0; t < T; ++t) {
+          bool any = false;
+          for (int r = 64 * t; r < std::min(ld[i], 64 * t + 64) && !any; ++r) any = inv[r] >= 0;
+          if (any) rows.push_back(t);
+        }
+        for (int a : rows) for (int b : rows) if (b <= a) mark[(size_t)a * T + b] = 1;
+      }
+      for (int a = 0; a < T; ++a) for (int b = 0; b <= a; ++b) if (mark[(size_t)a * T + b]) { dev.h_ext.push_back(i); dev.h_ext.push_back(a); dev.h_ext.push_back(b); }
+    }
+    L.ext_count = (int)dev.h_ext.size() / 3 - L.ext_first;
+    L.own_max = 0;
+    for (int n : hp.lev_nodes[l]) L.own_max = std::max(L.own_max, hp.own_dims[n]);
+  }
   dev.active = true;
 }
 
@@ -165,31 +190,55 @@ __global__ __launch_bounds__(256) void k_nd_assemble(DevProblem P, const int* __
   }
 }
 
-// parent front += children's Schur complements, parent right-hand side += children's reduced right-hand sides, in child order
-__global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, const int* __restrict__ rhs_off) {
-  const int node = a.first + blockIdx.z;
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = blockIdx.y * 16 + (threadIdx.x >> 4);
-  if (c > r) return;
-  const int own = a.own_dims[node], nI = a.nI, sd = a.st_dims[node];
-  if (r >= nI + sd || (r >= own && r < nI) || (c >= own && c < nI)) return;
+// parent front += children's Schur complements, parent right-hand side += children's reduced right-hand sides, in child order.
+// One workgroup per 64x64 tile of a host-built list (only tiles some child contributes to); a thread owns a 4x4 sub-grid.
+__global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, const int* __restrict__ rhs_off, const int* __restrict__ work) {
+  const int node = work[3 * blockIdx.x], tr = work[3 * blockIdx.x + 1], tc = work[3 * blockIdx.x + 2];
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   const size_t ld = (size_t)P.nd_ntab[2 * node + 1];
-  double* dst = P.nd_M + P.nd_ntab[2 * node] + (size_t)r * ld + c;
-  double v = *dst, rv = 0.0;
-  bool any = false;
+  double* F = P.nd_M + P.nd_ntab[2 * node];
+  const int nrow = (int)ld;
+  int rr[4], cc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { rr[i] = 64 * tr + ty + 16 * i; cc[i] = 64 * tc + tx + 16 * i; }
+  double v[4][4], rv[4] = {0.0, 0.0, 0.0, 0.0};
+  bool hit[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[i][j] = 0.0; hit[i][j] = false; }
   for (int k = a.cptr[node]; k < a.cptr[node + 1]; ++k) {
     const int ch = a.cidx[k];
     const int* inv = a.inv + a.inv_off[ch];
-    const int ir = inv[r];
-    if (ir < 0) continue;
-    if (c == r) rv += P.nd_rhs[rhs_off[ch] + ir];
-    const int ic = inv[c];
-    if (ic < 0) continue;
     const size_t ldc = (size_t)P.nd_ntab[2 * ch + 1];
-    v += P.nd_M[P.nd_ntab[2 * ch] + (size_t)(ir > ic ? ir : ic) * ldc + (ir > ic ? ic : ir)];
-    any = true;
+    const double* C = P.nd_M + P.nd_ntab[2 * ch];
+    int ir[4], ic[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ir[i] = rr[i] < nrow ? inv[rr[i]] : -1; ic[i] = cc[i] < nrow ? inv[cc[i]] : -1; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (ir[i] < 0) continue;
+      if (tr == tc && tx == 0) rv[i] += P.nd_rhs[rhs_off[ch] + ir[i]];  // (diagonal tiles: lane tx == 0 of a row folds the right-hand side)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (ic[j] < 0 || cc[j] > rr[i]) continue;
+        v[i][j] += C[(size_t)(ir[i] > ic[j] ? ir[i] : ic[j]) * ldc + (ir[i] > ic[j] ? ic[j] : ir[i])];
+        hit[i][j] = true;
+      }
+    }
   }
-  if (any) *dst = v;
-  if (c == r && rv != 0.0) P.nd_rhs[rhs_off[node] + r] += rv;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (hit[i][j]) F[(size_t)rr[i] * ld + cc[j]] += v[i][j];
+    if (rv[i] != 0.0) P.nd_rhs[rhs_off[node] + rr[i]] += rv[i];
+  }
+}
+
+// block inverses of the padding columns are the identity once and for all (the panel kernel never writes them: DenseBatch::own_max)
+__global__ __launch_bounds__(256) void k_nd_linv_init(double* __restrict__ Linv, size_t n) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (q < n) { const int e = (int)(q & 255); Linv[q] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0; }
 }
 
 // dir 0: border unknowns of every front of the level <- solution vector (ancestors are solved); dir 1: own unknowns -> solution
@@ -206,6 +255,10 @@ static NdLevArgs lev_args(const DevProblem& P, const NdDev& nd, int l) {
   return NdLevArgs{L.first, L.n, L.nI, L.ntot, P.nd_rhs + L.rhs_off, nd.own_dims, nd.st_dims, nd.own_g, nd.st_g, nd.gidx, nd.cptr, nd.cidx, nd.inv_off, nd.inv};
 }
 
+void launch_nd_init(const DevProblem& P, const NdDev& nd, hipStream_t st) {
+  if (nd.linv_elems) hipLaunchKernelGGL(k_nd_linv_init, dim3((unsigned)((nd.linv_elems + 255) / 256)), dim3(256), 0, st, P.nd_Linv, nd.linv_elems);
+}
+
 void launch_nd_zero(const DevProblem& P, const NdDev& nd, hipStream_t st) {
   for (size_t l = 0; l < nd.lev.size(); ++l) {
     const NdLevel& L = nd.lev[l];
@@ -216,26 +269,28 @@ void launch_nd_zero(const DevProblem& P, const NdDev& nd, hipStream_t st) {
 
 void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, hipStream_t st, CholAux& ax) {
   const int nlev = (int)nd.lev.size();
+  ax.mark(st, -1);
   hipMemsetAsync(P.nd_rhs, 0, nd.rhs_elems * sizeof(double), st);
   {
     const int cnt = std::max(P.vi ? 324 * P.K : 0, P.n);
     hipLaunchKernelGGL(k_nd_assemble, dim3((cnt + 255) / 256), dim3(256), 0, st, P, (const int*)nd.rhs_node);
   }
+  ax.mark(st, -2);
   auto batch = [&](int l) {
     const NdLevel& L = nd.lev[l];
     DenseBatch bt;
     bt.n = L.n; bt.sM = 0; bt.sL = (size_t)L.nI * kTile; bt.sR = (size_t)2 * L.ntot;
     bt.live = L.live; bt.tI = L.nI / kTile; bt.live_h = L.live_h.data();
-    bt.tab = P.nd_ntab + 2 * (size_t)L.first; bt.tri_slot = l;
+    bt.tab = P.nd_ntab + 2 * (size_t)L.first; bt.tri_slot = l; bt.own_max = L.own_max;
     return bt;
   };
   for (int l = 0; l < nlev; ++l) {
     const NdLevel& L = nd.lev[l];
-    if (l > 0) {
-      const int T16 = L.ntot / 16;
-      hipLaunchKernelGGL(k_nd_extend, dim3(T16, T16, L.n), dim3(256), 0, st, P, lev_args(P, nd, l), (const int*)nd.rhs_node);
-    }
+    if (L.ext_count > 0)
+      hipLaunchKernelGGL(k_nd_extend, dim3(L.ext_count), dim3(256), 0, st, P, lev_args(P, nd, l), (const int*)nd.rhs_node, (const int*)(nd.ext + 3 * (size_t)L.ext_first));
+    ax.mark(st, -3);
     dense_cholesky_solve_raw(P.nd_M, P.nd_rhs + L.rhs_off, P.nd_Linv + L.linv_off, P.flag, L.ntot, st, ax, L.nI / kTile, false, batch(l));
+    ax.mark(st, -4);
   }
   for (int l = nlev - 1; l >= 0; --l) {
     const NdLevel& L = nd.lev[l];
@@ -243,7 +298,9 @@ void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, hipStream_t st
     if (L.ntot > L.nI) hipLaunchKernelGGL(k_nd_xfer, dim3((L.ntot - L.nI + 255) / 256, L.n), dim3(256), 0, st, P, a, dst, 0);
     dense_backward_solve(P.nd_M, P.nd_rhs + L.rhs_off, P.nd_Linv + L.linv_off, L.ntot, st, L.nI / kTile, L.ntot / kTile, batch(l));
     hipLaunchKernelGGL(k_nd_xfer, dim3((L.nI + 255) / 256, L.n), dim3(256), 0, st, P, a, dst, 1);
+    ax.mark(st, -5);
   }
+  ax.mark(st, -6);
 }
 
 }  // namespace covgpu

@@ -549,15 +549,63 @@ __global__ __launch_bounds__(256) void k_bwd_step_sub(const double* __restrict__
   }
 }
 
+// Backward substitution, all GIVEN tile rows of a front at once (the ancestors' unknowns of a multifrontal front, the border
+// of an arrow block): y[c] -= sum_{r in [r0, r1)} L[r][c] x[r] for the factored columns c < ncol. One workgroup per 128
+// columns; its four waves take every fourth row (a row segment = 1 KiB, 16 rows in flight per wave), partial sums are added in
+// wave order: deterministic. Replaces one launch per given tile (12 dependent launches for a 1.5k-row border).
+__global__ __launch_bounds__(256) void k_bwd_given(const double* __restrict__ M, size_t ld, int r0, int r1, double* __restrict__ y,
+                                                    const double* __restrict__ x, int ncol, size_t bsM, size_t bsR, const long long* __restrict__ btab,
+                                                    const int* __restrict__ live, int tI) {
+  const int batch = blockIdx.y;
+  if (live != nullptr) {  // rows beyond the front's real border are padding (x = 0); a front without interior columns has nothing to update
+    r1 = min(r1, (tI + live[2 * batch + 1]) * kTile);
+    if (live[2 * batch] == 0) return;
+  }
+  if (btab != nullptr) { M += (size_t)btab[2 * batch]; ld = (size_t)btab[2 * batch + 1]; }
+  else M += (size_t)batch * bsM;
+  y += (size_t)batch * bsR; x += (size_t)batch * bsR;
+  __shared__ double2 part[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col = blockIdx.x * 128 + 2 * lane;
+  double2 acc = {0.0, 0.0};
+  if (col < ncol) {
+    const double* Lp = M + col;
+    int r = r0 + wv;
+    for (; r + 28 < r1; r += 32) {
+      double2 v[8]; double xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { v[u] = *reinterpret_cast<const double2*>(Lp + (size_t)(r + 4 * u) * ld); xv[u] = x[r + 4 * u]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += v[u].x * xv[u]; acc.y += v[u].y * xv[u]; }
+    }
+    for (; r < r1; r += 4) { const double2 v = *reinterpret_cast<const double2*>(Lp + (size_t)r * ld); const double xv = x[r]; acc.x += v.x * xv; acc.y += v.y * xv; }
+  }
+  part[wv][lane] = acc;
+  __syncthreads();
+  if (wv == 0 && col < ncol) {
+    const double2 a = part[0][lane], b = part[1][lane], c = part[2][lane], d = part[3][lane];
+    y[col] -= ((a.x + b.x) + c.x) + d.x;
+    y[col + 1] -= ((a.y + b.y) + c.y) + d.y;
+  }
+}
+
 // ---- launch wrappers (k_chol.hip schedules them) ----------------------------------------------------------------------
+void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, double* x, int ncol, int nbt, size_t sM, size_t sR, hipStream_t st,
+                      const long long* btab, const int* live, int tI) {
+  if (r1 <= r0 || ncol <= 0) return;
+  hipLaunchKernelGGL(k_bwd_given, dim3((ncol + 127) / 128, nbt), dim3(256), 0, st, S, ld, r0, r1, y, (const double*)x, ncol, sM, sR, btab, live, tI);
+}
+
 void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
-                        hipStream_t st, const long long* btab) {
+                        hipStream_t st, const long long* btab, int nb) {
+  if (nb < 0) nb = 8 * w;
+  if (nb == 0) return;  // an all-padding panel of every front of the batch: L = I, Dinv = I, y = 0 are in place
   static bool once = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds);
     return true;
   }();
   (void)once;
-  hipLaunchKernelGGL(k_potrf_panel, dim3(nbt), dim3(512), kPanelLds, st, S, ld, t0 * kTile, 8 * w, Linv + (size_t)t0 * kTile * kTile, flag,
+  hipLaunchKernelGGL(k_potrf_panel, dim3(nbt), dim3(512), kPanelLds, st, S, ld, t0 * kTile, nb, Linv + (size_t)t0 * kTile * kTile, flag,
                      (const double*)b, b ? b + npad : nullptr, sM, sL, sR, btab);
 }
 

@@ -329,7 +329,7 @@ static int nd_leaf_dims(int requested) {
   if (requested > 0) return requested;
   const char* e = getenv("COVGPU_ND_LEAF");
   const int v = e ? atoi(e) : 0;
-  return v > 0 ? v : 900;
+  return v > 0 ? v : 600;
 }
 extern "C" int covgpu_nd_plan_create(const covgpu_options* opt, const covgpu_problem* p, int32_t leaf_dims, covgpu_nd_plan** out) {
   return guarded([&] {
@@ -702,9 +702,11 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
       RC(dev_upload(c, &nd.cptr, nd.h_cptr.data(), nd.h_cptr.size())); RC(dev_upload(c, &nd.cidx, nd.h_cidx.data(), nd.h_cidx.size()));
       RC(dev_upload(c, &nd.inv_off, nd.h_inv_off.data(), nd.h_inv_off.size())); RC(dev_upload(c, &nd.inv, nd.h_inv.data(), nd.h_inv.size()));
       RC(dev_upload(c, &nd.rhs_node, nd.h_rhs_node.data(), nd.h_rhs_node.size()));
+      RC(dev_upload(c, &nd.ext, nd.h_ext.data(), nd.h_ext.size()));
       for (NdLevel& L : nd.lev) RC(dev_upload(c, &L.live, L.live_h.data(), L.live_h.size()));
       RC(dev_alloc(c, &P.nd_M, nd.M_elems)); RC(dev_alloc(c, &P.nd_rhs, nd.rhs_elems)); RC(dev_alloc(c, &P.nd_Linv, nd.linv_elems));
       RC(dev_alloc(c, &P.nd_dummy, (size_t)64));
+      launch_nd_init(P, nd, c->st);
       c->chol.tri_clear();   // the live-tile lists of the bulk updates belong to the previous problem
       HIPCHK(hipStreamSynchronize(c->st));
       if (opt->verbose) {
@@ -890,6 +892,7 @@ static void enqueue_solve(covgpu_context* c, double* dst_all) {
 }
 
 static void collect_profile(covgpu_context* c, bool built, bool solved) {
+  if (solved && !c->profiling) c->chol.collect();  // (prints the COVGPU_TRACE_PANELS marks; nothing else without profiling)
   if (!c->profiling) return;
   float ms = 0;
   if (built && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) { c->prof.t_build_ms += ms; c->prof.n_build++; }

@@ -288,7 +288,7 @@ int32_t covgpu_gba_partition(const covgpu_options* opt, const covgpu_problem* p,
  * ordering inside ceres::Solve(SPARSE_SCHUR) (optimization_be.cpp:560-565). Unknowns are, per keyframe, a 6-dim pose block
  * (variable 2k) and a 9-dim speed-bias block (variable 2k+1, visual-inertial only). Every tree node owns some variables
  * (eliminated there) and carries the ancestor variables its subtree couples to; nodes of equal height form one batch.
- * leaf_dims <= 0: default (COVGPU_ND_LEAF or 900 scalar unknowns per leaf). tests/test_nd_plan.py replays the plan in numpy. */
+ * leaf_dims <= 0: default (COVGPU_ND_LEAF or 600 scalar unknowns per leaf). tests/test_nd_plan.py replays the plan in numpy. */
 typedef struct covgpu_nd_plan covgpu_nd_plan;
 int  covgpu_nd_plan_create(const covgpu_options* opt, const covgpu_problem* p, int32_t leaf_dims, covgpu_nd_plan** out);
 void covgpu_nd_plan_destroy(covgpu_nd_plan* plan);

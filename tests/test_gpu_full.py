@@ -104,19 +104,25 @@ def test_single_linearisation_at_full_size(ctx, name):
     assert rel < max(100 * rel0, 1e-9) and err < 1e-6
 
 
-def test_arrow_solve_equals_dense_solve(ctx):
-    """Block-arrow elimination (k_arrow.hip) is the same Cholesky solve in a different elimination order: the full GBA
-    of the 3-agent map must land where the dense pose-system path lands."""
+def test_multifrontal_solve_equals_one_front_solve(ctx):
+    """The nested-dissection multifrontal elimination (k_front.hip) is the same Cholesky solve in a different elimination
+    order: the full GBA of the 3-agent map must land where ONE front — the dense 15K-order system, COVGPU_GBA_DENSE=1 —
+    lands."""
     m, p = problem("mh123")
-    assert backend.gba_partition(p, backend.default_options())[1] == 3
     out = {}
-    for mode in ("COVGPU_GBA_DENSE", "COVGPU_GBA_ARROW"):
-        os.environ[mode] = "1"
+    for mode in ("COVGPU_GBA_DENSE", ""):
+        if mode:
+            os.environ[mode] = "1"
         try:
-            out[mode] = ctx.gba_solve(p, backend.default_options(max_iterations=6))
+            ctx.upload(p, backend.default_options(max_iterations=6))
+            lay = ctx.layout()
+            res = ctx.solve_resident(backend.default_options(max_iterations=6))
+            out[mode] = (ctx.download(), res, lay)
         finally:
-            del os.environ[mode]
-    (sd, rd), (sa, ra) = out["COVGPU_GBA_DENSE"], out["COVGPU_GBA_ARROW"]
+            if mode:
+                del os.environ[mode]
+    (sd, rd, ld), (sa, ra, la) = out["COVGPU_GBA_DENSE"], out[""]
+    assert ld["nd_fronts"] == 1 and la["nd_fronts"] > 20 and la["nd_levels"] >= 4
     assert rd.iterations == ra.iterations and list(rd.accepted_trace[:6]) == list(ra.accepted_trace[:6])
     assert np.allclose(np.array(ra.cost_trace[:6]), np.array(rd.cost_trace[:6]), rtol=1e-9)
     assert np.abs(sd.kf_pose - sa.kf_pose).max() < 1e-8 and np.abs(sd.kf_speed_bias - sa.kf_speed_bias).max() < 1e-8
@@ -127,11 +133,11 @@ def test_arrow_solve_equals_dense_solve(ctx):
 def test_arrow_solve_small_forced(ctx, small_map):
     """Forced arrow plan on a small 3-agent map (one agent entirely shared: a chain without a block), against the oracle."""
     p = mapdata.flatten_gba(small_map, False, True)[0]
-    os.environ["COVGPU_GBA_ARROW"] = "1"
+    os.environ["COVGPU_GBA_ARROW"] = "1"; os.environ["COVGPU_GBA_LEGACY"] = "1"
     try:
         sol, res = ctx.gba_solve(p, backend.default_options())
     finally:
-        del os.environ["COVGPU_GBA_ARROW"]
+        del os.environ["COVGPU_GBA_ARROW"]; del os.environ["COVGPU_GBA_LEGACY"]
     ref, rres = covo.gba_solve(p, covo.default_options())
     assert res.iterations == rres.iterations and abs(res.final_cost - rres.final_cost) <= 1e-8 * rres.final_cost
     assert np.abs(sol.kf_pose[:, 4:] - ref.kf_pose[:, 4:]).max() < 1e-6

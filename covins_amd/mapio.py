@@ -169,6 +169,13 @@ def load_map(path: str) -> SlamMap:
     kf_cam = np.zeros(K, np.int32)
     for i, k in enumerate(kfs):
         c = k["calibration"]
+        # KeyframeBase's constructor exits on anything but pinhole / omni x radtan / equidistant (keyframe_base.cpp:58-82); omni
+        # needs a 5-parameter unified-projection camera this back-end does not implement: refuse, do not
+        # silently flatten such a map as pinhole + radtan
+        if c["cam_model"] != 0:
+            raise ValueError(f"keyframe {k['id']}: camera model {c['cam_model']} is not PINHOLE(0): unsupported")
+        if c["dist_model"] not in (0, 1):
+            raise ValueError(f"keyframe {k['id']}: distortion model {c['dist_model']} is neither RADTAN(0) nor EQUI(1): unsupported")
         key = (k["id"][1], c["dist_model"], tuple(c["intrinsics"]), tuple(c["dist_coeffs"][:4]), tuple(k["T_s_c"].reshape(-1)),
                c["sigma_a_c"], c["sigma_g_c"], c["sigma_aw_c"], c["sigma_gw_c"], c["g"])
         if key not in cam_rows:
@@ -206,7 +213,7 @@ def load_map(path: str) -> SlamMap:
         cam_extr=np.array([_pose_row(k["T_s_c"]) for k, _ in cams]).reshape(A, 7),
         cam_intr=np.array([c["intrinsics"][:4] for _, c in cams]).reshape(A, 4),
         cam_dist=np.array([np.pad(c["dist_coeffs"], (0, 4))[:4] for _, c in cams]).reshape(A, 4),
-        cam_dist_type=np.array([max(c["dist_model"], 0) for _, c in cams], np.int32),
+        cam_dist_type=np.array([c["dist_model"] for _, c in cams], np.int32),
         cam_imu_calib=np.array([[c["sigma_a_c"], c["sigma_g_c"], c["sigma_aw_c"], c["sigma_gw_c"], c["g"]] for _, c in cams]).reshape(A, 5),
         imu_ptr=imu_ptr, imu_samples=np.concatenate(chunks) if chunks else np.zeros((0, 7)),
         imu_first=np.array([np.concatenate([k["lin_acc_init"], k["ang_vel_init"]]) for k in kfs]).reshape(K, 6),

@@ -452,6 +452,8 @@ def config_named(name: str, seed: int = 0) -> SynthConfig:
     if name == "tiny":            # CPU tests
         return SynthConfig(agents=(1, 3), max_kf_per_agent=14, new_lm_per_kf=14, track_window=5, fuse_window=3,
                            loops_per_pair=1, seed=seed)
+    if name == "micro":           # tests/golden/refmap: the saved map written by the reference's own cereal code (tools/make_ref_cereal_fixture.py)
+        return SynthConfig(agents=(1, 3), max_kf_per_agent=6, new_lm_per_kf=10, track_window=3, fuse_window=2, loops_per_pair=1, seed=7)
     if name == "small":           # GPU parity tests / smoke
         return SynthConfig(agents=(1, 2, 3), max_kf_per_agent=60, new_lm_per_kf=30, track_window=8, seed=seed)
     raise KeyError(name)

@@ -1,12 +1,106 @@
 """Saved-map reader (covins_amd/mapio.py): byte layout of the cereal binary archives that
 Map::SaveToFile writes (map_be.cpp:813-922; field order msg_keyframe.hpp:129-146, msg_landmark.hpp:66-71, map_be.hpp:126-136)
 and a full save -> load round trip whose flattened GBA / PGO problems equal the original's."""
+import json
 import os
+import shutil
 import struct
+import subprocess
 
 import numpy as np
+import pytest
 
-from covins_amd import mapdata, mapio
+from covins_amd import mapdata, mapio, synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def micro_map():
+    return synth.make_map(synth.config_named("micro"))
+
+
+def _same_problem(a, b):
+    for k, v in a.__dict__.items():
+        w = getattr(b, k)
+        assert v.shape == w.shape, k
+        assert np.allclose(v, w, rtol=0, atol=1e-12), k
+
+
+def test_reads_a_map_written_by_the_reference_serializer(micro_map):
+    """tests/golden/refmap/ was written by the REFERENCE's MsgKeyframe / MsgLandmark / MsgMap save() through its vendored
+    cereal::BinaryOutputArchive (oracle/ref_cereal_roundtrip.cpp, tools/make_ref_cereal_fixture.py): the reader must turn
+    those bytes back into the map they were made from, down to the optimiser's flattened inputs."""
+    m2 = mapio.load_map(os.path.join(GOLD, "refmap"))
+    m = micro_map
+    assert m2.K == m.K and m2.kf_loaded.all()
+    assert np.array_equal(m2.kf_id, m.kf_id) and np.array_equal(m2.kf_client, m.kf_client)
+    assert np.array_equal(m2.kf_pred, m.kf_pred) and np.array_equal(m2.kf_succ, m.kf_succ)
+    assert np.allclose(m2.kf_pose, m.kf_pose, atol=1e-12) and np.array_equal(m2.imu_samples, m.imu_samples)
+    assert len(m2.loops) == len(m.loops) and len(m.loops) >= 1
+    _same_problem(mapdata.flatten_gba(m, False, True)[0], mapdata.flatten_gba(m2, False, True)[0])
+    pa, _ = mapdata.flatten_pgo(m, {}, mapdata.PgoParams())
+    pb, _ = mapdata.flatten_pgo(m2, {}, mapdata.PgoParams())
+    assert np.array_equal(pa.edge_i, pb.edge_i) and np.allclose(pa.edge_meas, pb.edge_meas, atol=1e-12)
+
+
+def test_writer_bytes_equal_the_reference_serializer_bytes(micro_map, tmp_path):
+    """File by file, mapio.save_map == what the reference's save() wrote for the same content (so every fixture the other
+    tests make with the writer is a byte stream the reference would have produced)."""
+    p = str(tmp_path / "m")
+    mapio.save_map(p, micro_map)
+    n = 0
+    for r, _, fs in os.walk(os.path.join(GOLD, "refmap")):
+        for f in fs:
+            rel = os.path.relpath(os.path.join(r, f), os.path.join(GOLD, "refmap"))
+            assert open(os.path.join(r, f), "rb").read() == open(os.path.join(p, rel), "rb").read(), rel
+            n += 1
+    assert n == sum(len(fs) for _, _, fs in os.walk(p)) and n > 50
+
+
+def test_values_decoded_by_the_reference_loader(micro_map):
+    """What the reference's load() (cereal::BinaryInputArchive + MsgKeyframe(true), map_be.cpp:560-566) read out of the
+    writer's bytes, recorded by oracle/ref_cereal_roundtrip.cpp: ids, poses, calibration, counts, links."""
+    ref = json.load(open(os.path.join(GOLD, "refmap_decoded_by_reference.json")))
+    m = micro_map
+    assert len(ref["keyframes"]) == m.K
+    obs_per_kf = np.bincount(m.obs_kf, minlength=m.K)
+    for i in range(m.K):
+        k = ref["keyframes"][f"keyframes{i}.txt"]
+        assert k["id"] == [int(m.kf_id[i]), int(m.kf_client[i])] and k["timestamp"] == float(m.kf_time[i])
+        T = np.array(k["T_w_s"]).reshape(4, 4)
+        assert np.allclose(T[:3, 3], m.kf_pose[i, 4:], atol=1e-15) and np.allclose(T, mapio._pose_mat(m.kf_pose[i]), atol=1e-15)
+        assert np.allclose(k["velocity"], m.kf_velocity[i]) and np.allclose(k["bias_accel"], m.kf_bias_a[i]) and np.allclose(k["bias_gyro"], m.kf_bias_g[i])
+        cam = int(m.kf_cam[i])
+        assert np.allclose(k["intrinsics"], m.cam_intr[cam]) and np.allclose(k["dist_coeffs"], m.cam_dist[cam])
+        assert k["cam_model"] == 0 and k["dist_model"] == int(m.cam_dist_type[cam]) and k["g"] == m.cam_imu_calib[cam][4]
+        assert k["n_keypoints"] == obs_per_kf[i] == k["n_landmarks"] == k["desc_rows"] and k["desc_cols"] == 32
+        assert k["n_imu"] == m.imu_ptr[i + 1] - m.imu_ptr[i]
+        pred = [int(m.kf_id[m.kf_pred[i]]), int(m.kf_client[m.kf_pred[i]])] if m.kf_pred[i] >= 0 else list(mapio.DEFPAIR)
+        assert k["pred"] == pred
+    saved = [l for l in range(m.L) if m.lm_obs_ptr[l + 1] - m.lm_obs_ptr[l] >= 2 and m.lm_ref_kf[l] >= 0]
+    assert len(ref["mappoints"]) == len(saved)
+    for l in saved:
+        r = ref["mappoints"][f"mappoints{l}.txt"]
+        assert r["id"] == [l, 0] and np.allclose(r["pos_w"], m.lm_pos[l]) and r["n_obs"] == m.lm_obs_ptr[l + 1] - m.lm_obs_ptr[l]
+        assert r["obs"] == sorted(r["obs"])          # std::map<idpair,int>: key order
+    assert ref["mapdata"]["id_map"] == m.id_map and ref["mapdata"]["n_loops"] == len(m.loops)
+    assert np.allclose(np.array(ref["mapdata"]["cov_0"]).reshape(6, 6), m.loops[0].cov)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree only exists in the development container")
+def test_reference_code_round_trips_a_larger_map_live(tiny_map, tmp_path):
+    """Development container only: the reference's load() -> save(), compiled from /root/reference (oracle/Makefile target
+    `ref`), reproduces the writer's bytes for the 28-keyframe map too."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL)
+    src, dst = str(tmp_path / "ours"), str(tmp_path / "ref")
+    mapio.save_map(src, tiny_map)
+    subprocess.check_output([os.path.join(ROOT, "oracle", "_ref", "cereal_roundtrip"), src, dst])
+    for r, _, fs in os.walk(src):
+        for f in fs:
+            rel = os.path.relpath(os.path.join(r, f), src)
+            assert open(os.path.join(r, f), "rb").read() == open(os.path.join(dst, rel), "rb").read(), rel
 
 
 def test_primitive_layouts():
@@ -74,3 +168,18 @@ def test_round_trip_equals_original(tiny_map, tmp_path):
     pa, _ = mapdata.flatten_pgo(tiny_map, {}, mapdata.PgoParams())
     pb, _ = mapdata.flatten_pgo(m2, {}, mapdata.PgoParams())
     assert np.array_equal(pa.edge_i, pb.edge_i) and np.allclose(pa.edge_meas, pb.edge_meas, atol=1e-12)
+
+
+def test_unsupported_camera_models_are_refused(micro_map, tmp_path):
+    """An OMNI / NOTSET / PLUMBBOB map must not be flattened as pinhole + radtan (keyframe_base.cpp:58-82 exits)."""
+    p = str(tmp_path / "m")
+    mapio.save_map(p, micro_map)
+    f = os.path.join(p, "keyframes", "keyframes2.txt")
+    raw = bytearray(open(f, "rb").read())
+    off = 8 + 16 + (8 + 16 * 8)          # timestamp, id, T_SC (i32 rows, i32 cols, 16 doubles) -> cam_model, dist_model
+    assert struct.unpack_from("<ii", raw, off) == (0, 0)
+    for cam, dist in ((1, 0), (0, 2), (0, -1)):
+        struct.pack_into("<ii", raw, off, cam, dist)
+        open(f, "wb").write(bytes(raw))
+        with pytest.raises(ValueError):
+            mapio.load_map(p)

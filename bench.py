@@ -31,27 +31,51 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X FP64 vector/matrix peak (BASELINE.md, 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(prob, strategy: int, iterations: int, truth_xyz):
-    """Oracle (CPU port of the same algorithm) on THE SAME problem, timed on this box's host cores in this run. The
-    reference binary itself cannot be built here (Ceres / robopt / aslam absent). Linearisation and the
-    landmark Schur complement run on all OpenMP threads; the block-sparse reduced camera system (what Ceres hands to
-    CHOLMOD) is solved by scipy's SuperLU (one thread)."""
-    from covins_amd import synth
-    from oracle import covo
-    covo.use_sparse_solver(min_n=3000)
+def cpu_baseline(prob, strategy: int, iterations: int, truth_xyz, reps: int = 3):
+    """Oracle (CPU port of the same algorithm) on THE SAME problem, timed on this box's host cores in this run, `reps`
+    repetitions, median. The reference binary itself cannot be built here (Ceres / robopt / aslam absent,
+    SURVEY.md §8c). Linearisation and the landmark Schur complement run on all OpenMP threads; the block-sparse reduced
+    camera system (what Ceres hands to CHOLMOD with opt threads, optimization_be.cpp:258-262) is solved by the threaded CPU
+    port of the multifrontal solve (oracle/covo_mf.py: fronts of one tree level concurrently, LAPACK per front)."""
+    from covins_amd import backend, synth
+    from oracle import covo, covo_mf
+    threads = int(covo.lib().covo_num_threads())
+    covo_mf.set_problem(prob, backend.default_options(), threads)
+    covo.use_sparse_solver(min_n=3000, kind="multifrontal")
     o = covo.default_options(max_iterations=iterations, strategy=strategy)
-    covo.solver_stats.update(calls=0, seconds=0.0)
-    t0 = time.perf_counter()
-    q, res = covo.gba_solve(prob, o)
-    dt = time.perf_counter() - t0
+    times, solver_s = [], []
+    q = res = None
+    for _ in range(reps):
+        covo_mf.stats.update(calls=0, seconds=0.0)
+        t0 = time.perf_counter()
+        q, res = covo.gba_solve(prob, o)
+        times.append(time.perf_counter() - t0); solver_s.append(covo_mf.stats["seconds"])
+    covo.use_sparse_solver(min_n=3000)   # back to SuperLU (parity legs)
+    dt = float(np.median(times))
     return q, {
-        "value": res.iterations / dt, "unit": "GBA iterations/s", "cores": int(covo.lib().covo_num_threads()),
-        "kind": "port",
+        "value": res.iterations / dt, "unit": "GBA iterations/s", "cores": threads, "reps": reps, "times_s": [round(t, 3) for t in times],
+        "kind": "port", "solver": f"multifrontal Cholesky, {covo_mf.stats['fronts']} fronts in {covo_mf.stats['levels']} levels", "solver_threads": threads,
+        "threads_per_phase": {"linearise+landmark Schur (OpenMP)": threads, "reduced system (thread pool x LAPACK)": threads},
         "sample": f"the timed workload itself: K={prob.K} L={prob.L} O={prob.O} (15K={15 * prob.K}), all {res.iterations} "
-                  f"trust-region iterations, {dt:.1f} s of which {covo.solver_stats['seconds']:.1f} s in SuperLU (serial)",
+                  f"trust-region iterations, median of {reps}: {dt:.1f} s of which {float(np.median(solver_s)):.1f} s in the reduced-system solve",
         "kf_per_s": prob.K * res.iterations / dt, "final_cost": res.final_cost,
         "ate_rmse_m_final": synth.ate_rmse(q.kf_pose[:, 4:], truth_xyz),
     }
+
+
+def cpu_baseline_pgo(pgo_prob, iterations: int, reps: int = 3):
+    """Oracle PoseGraphOptimization on the same pose graph (sparse system through scipy's SuperLU), median of `reps`."""
+    from oracle import covo
+    covo.use_sparse_solver(min_n=3000)
+    o = covo.default_options(max_iterations=iterations)
+    times = []
+    q = res = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        q, res = covo.gba_solve(pgo_prob, o, pgo=True)
+        times.append(time.perf_counter() - t0)
+    return q, res, {"t_call_s": float(np.median(times)), "reps": reps, "cores": 1, "kind": "port",
+                    "sample": f"the same pose graph (K={pgo_prob.K}, E={pgo_prob.E}), all {res.iterations} iterations; 6K-order sparse system by SuperLU (serial)"}
 
 
 def _kernels_digest():
@@ -167,10 +191,11 @@ def main():
             "timed_region": "profiling events off; phase / kernel figures below come from one extra un-timed step",
             "config": {"workload": f"{args.workload}: {len(cfg.agents)}-agent EuRoC MH-shaped merged map, visual-inertial GBA "
                                    f"(K={prob.K} keyframes, L={prob.L} landmarks, O={prob.O} observations, I={prob.I} IMU factors, "
-                                   f"E={prob.E} loop edges; reduced camera system 15K={n}: speed-bias chains eliminated block-tridiagonally, "
-                                   + (f"pose system 6K={6 * prob.K} as {lay['blocks']} agent blocks (<= {lay['interior_kf_padded']} interior keyframes) + "
-                                      f"{lay['border_kf']} shared keyframes, batched MFMA Cholesky + dense border solve)" if lay["arrow"] else
-                                      f"dense MFMA Cholesky on the 6K={6 * prob.K} pose system)"),
+                                   f"E={prob.E} loop edges; reduced camera system 15K={n}: "
+                                   + (f"multifrontal MFMA Cholesky over a nested-dissection tree of {lay['nd_fronts']} fronts in {lay['nd_levels']} levels, "
+                                      f"{lay['nd_serial_panels']} serial 256-column panels, root front of order {lay['nd_root_order']})" if lay["nd_fronts"] else
+                                      (f"speed-bias chains eliminated block-tridiagonally, pose system 6K={6 * prob.K} as {lay['blocks']} agent blocks + "
+                                       f"{lay['border_kf']} shared keyframes)" if lay["arrow"] else f"dense MFMA Cholesky on the 6K={6 * prob.K} pose system)")),
                        "layout": lay,
                        "nnzS_fill": (2 * prof["offdiag_blocks"] + prob.K) / float(prob.K) ** 2,
                        "strategy": args.strategy, "iterations_per_step": args.iterations,
@@ -187,27 +212,23 @@ def main():
                            "final_sim3": synth.ate_rmse(sol.kf_pose[:, 4:], truth, with_scale=True)},  # evo_ape -va / -vas
             "phase_ms_per_iteration": {"linearise+schur": prof["build_ms"] / max(prof["n_build"], 1),
                                        "factor+solve": prof["factor_ms"] / max(prof["n_factor"], 1)},
-            "roofline": {"kernel": "k_gemm_abt<SYRK_TRI> (rank-256 trailing update of the dense FP64 Cholesky, v_mfma_f64_16x16x4_f64)",
+            "roofline": {"kernel": "k_gemm_abt<SYRK_TRI> (rank-256 trailing update of the batched front factorisation, v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
                          "mfma_busy_frac_pmc": mfma_busy,
                          "traffic_note": ("HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from tools/pmc_pass.sh at " + str(traffic_src)) if traffic is not None
                                          else "null: no counter pass of these kernel sources (tools/pmc_pass.sh writes profiles/pmc_traffic_current.json)",
                          "launches": prof["n_syrk"], "avg_launch_ms": prof["syrk_ms"] / max(prof["n_syrk"], 1),
-                         "dense_stage_order": 6 * prob.K,
-                         # (6K)^3/3 flops of the DENSE factorisation over this solve's factor+solve time: with the block-arrow form
-                         # (6x fewer flops) a speed-up figure, not a utilisation — it may exceed the peak
-                         "dense_equivalent_tflops_of_factor_and_solve": ((6.0 * prob.K) ** 3 / 3.0) / (prof["factor_ms"] / max(prof["n_factor"], 1) * 1e-3) / 1e12
-                         if prof["factor_ms"] > 0 else 0.0},
+                         "note": "the one MFMA-bound kernel; the factor+solve phase as a whole is bound by the serial panel chain "
+                                 "(k_potrf_panel, one workgroup per front and panel: latency, no roofline), see DESIGN.md 4.6"},
             "roofline_build": {"kernel": "linearise + landmark Schur pass (k_lm_lin, k_kf_reduce, k_pair_blocks, k_imu_*, k_edge_*)", "bound": "hbm",
                                "achieved": b_build / (prof["build_ms"] / max(prof["n_build"], 1) * 1e-3) / 1e9 if prof["build_ms"] > 0 else 0.0,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "nnzS_blocks": nnzS,
-                               "note": "whole linearise+Schur pass (a dozen kernels; the serial IMU chain factorisation runs on the auxiliary stream underneath, "
-                                       "the 0.6 GB fill of the arrow buffers on a third) against SURVEY.md 8(d)'s algorithmic bytes (inputs once, H/g "
-                                       "blocks, S blocks once). The pass really moves more: the fill, 600-B per-observation records written by k_lm_lin "
-                                       "and gathered back by k_kf_reduce / k_pair_blocks (~1.5 GB per iteration) - the price of the atomic-free, "
-                                       "bit-reproducible build (DESIGN.md 4.1, 6)"},
+                               "note": "whole linearise+Schur pass (a dozen kernels; the clearing of the fronts' live tiles runs on a second stream "
+                                       "underneath) against SURVEY.md 8(d)'s algorithmic bytes (inputs once, H/g blocks, S blocks once). The pass "
+                                       "really moves more: the fill and the per-observation records of the atomic-free, bit-reproducible build "
+                                       "(DESIGN.md 4.1, 6)"},
         }
         out["roofline_build"]["frac"] = out["roofline_build"]["achieved"] / HBM_PEAK_GBS
         # whole Optimization::GlobalBundleAdjustment call as backend.cpp:141-156 issues it (outlier round of 5 iterations +
@@ -230,9 +251,17 @@ def main():
             popt = backend.default_options(max_iterations=pgo_prm.pgo_iteration_limit, device=local_rank)
             ctx.pgo_solve(pgo_prob, popt)
             t_p = time.perf_counter()
-            _, pres = ctx.pgo_solve(pgo_prob, popt)
-            out["pgo_call"] = {"t_call_s": time.perf_counter() - t_p, "iterations": pres.iterations, "edges": int(pgo_prob.E),
-                               "initial_cost": pres.initial_cost, "final_cost": pres.final_cost}
+            psol, pres = ctx.pgo_solve(pgo_prob, popt)
+            out["pgo_call"] = {"t_call_s": time.perf_counter() - t_p, "iterations": pres.iterations, "edges": int(pgo_prob.E), "keyframes": int(pgo_prob.K),
+                               "initial_cost": pres.initial_cost, "final_cost": pres.final_cost,
+                               "phase_s": {"upload (plan + H2D)": pres.t_upload_s, "solve": pres.t_solve_s, "of which linear solves": pres.t_linear_solve_s,
+                                           "download": pres.t_download_s},
+                               "critical_path": "k_potrf_panel chain of the block-arrow pose-graph solve (k_pgo.hip): latency-bound, no roofline",
+                               "what": "covgpu_pgo_solve: whole PoseGraphOptimization solve (optimization_be.cpp:1024-1031) incl. plan, H2D, D2H"}
+            if not args.no_cpu_baseline:
+                pq, pr, out["pgo_call"]["cpu_baseline"] = cpu_baseline_pgo(pgo_prob, pgo_prm.pgo_iteration_limit)
+                out["pgo_call"]["max_pose_diff_gpu_cpu_m"] = float(np.abs(psol.kf_pose[:, 4:] - pq.kf_pose[:, 4:]).max())
+                out["pgo_call"]["gpu_over_cpu"] = out["pgo_call"]["cpu_baseline"]["t_call_s"] / out["pgo_call"]["t_call_s"]
         if not args.no_cpu_baseline and prob.K > 5000:
             out["cpu_baseline"] = {"value": None, "unit": "GBA iterations/s", "cores": 0, "kind": "port",
                                    "sample": f"not run: the CPU port does not finish K={prob.K} within minutes (its 5-agent time is in the default bench line)"}

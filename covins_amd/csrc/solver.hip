@@ -60,6 +60,7 @@ struct covgpu_context {
   void* allreduce_user = nullptr;
   double* h_stage = nullptr; size_t h_stage_n = 0;  // pinned staging buffer (stage_on_host)
   double* d_bvec = nullptr;                          // [12 nbk] border [grad | hdiag] exchange buffer
+  double* d_scal_tmp = nullptr;                      // [SC_COUNT] scratch the scalar all-reduce works on (read_scalars)
 };
 
 // sum (op 0) / max (op 1) of `n` device doubles over all ranks, in place; the stream is drained first so the data is final
@@ -241,6 +242,7 @@ static int validate(const covgpu_problem* p, bool pgo, bool vi) {
     for (int a = 0; a < p->num_cam; ++a) if (p->cam_dist_type[a] != COVGPU_DIST_RADTAN && p->cam_dist_type[a] != COVGPU_DIST_EQUIDISTANT) return bad("unknown distortion type");
     if (vi && p->num_imu > 0 && (!p->imu_kf_i || !p->imu_kf_j || !p->imu_sample_ptr || !p->imu_first)) return bad("NULL IMU array");
     if (vi && p->num_imu > 0 && p->imu_sample_ptr[p->num_imu] > 0 && !p->imu_samples) return bad("NULL IMU sample array");
+    if (vi && p->num_imu > 0 && (p->imu_sample_ptr[0] != 0 || p->imu_sample_ptr[p->num_imu] != p->num_imu_samples)) return bad("imu_sample_ptr does not span the IMU samples");
     if (vi) for (int f = 0; f < p->num_imu; ++f) {
       if (p->imu_kf_i[f] < 0 || p->imu_kf_i[f] >= K || p->imu_kf_j[f] < 0 || p->imu_kf_j[f] >= K) return bad("imu keyframe out of range");
       if (p->imu_sample_ptr[f + 1] < p->imu_sample_ptr[f]) return bad("imu_sample_ptr not monotone");
@@ -769,6 +771,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
         }
         RC(dev_upload(c, &P.vw, vw.data(), vw.size()));
         RC(dev_alloc(c, &c->d_bvec, (size_t)12 * std::max(hp.nbk, 1)));
+        RC(dev_alloc(c, &c->d_scal_tmp, (size_t)SC_COUNT));
       }
       HIPCHK(hipStreamSynchronize(c->st));
       if (opt->verbose)
@@ -830,10 +833,19 @@ static int read_scalars(covgpu_context* c) {
     // every scalar of the trust-region loop is a sum over residuals / unknowns each counted by exactly one rank
     // (DevProblem::vw), except the gradient max-norm and the Cholesky failure flag (max): reduced ON THE DEVICE buffers
     // (two small collectives per read-back), so that all ranks then take the same accept / reject decisions
+    // The sums are taken on a SCRATCH copy: slots that were not recomputed since the previous read-back already hold global
+    // sums, and reducing P.scal in place would multiply them by the world size on every call.
     launch_shard_scal(c->P, c->d_bvec, 0, c->st);
-    ctx_reduce(c, c->P.scal, SC_COUNT, 0);
+    HIPCHK(hipMemcpyAsync(c->d_scal_tmp, c->P.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+    ctx_reduce(c, c->d_scal_tmp, SC_COUNT, 0);
     ctx_reduce(c, c->d_bvec, 2, 1);
-    launch_shard_scal(c->P, c->d_bvec, 1, c->st);
+    launch_shard_scal(c->P, c->d_bvec, 1, c->st);   // gradient max-norm and failure flag back into P.scal / P.flag
+    HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal_tmp, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(c->h_scal + SC_GMAX, c->P.scal + SC_GMAX, sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(c->h_scal + SC_COUNT, c->P.flag, sizeof(int), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());
+    return COVGPU_OK;
   }
   HIPCHK(hipMemcpyAsync(c->h_scal, c->P.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipMemcpyAsync(c->h_scal + SC_COUNT, c->P.flag, sizeof(int), hipMemcpyDeviceToHost, c->st));
@@ -923,7 +935,7 @@ static int solve_impl(covgpu_context* c, const covgpu_options* opt, covgpu_resul
   HIPCHK(hipSetDevice(c->device));
   DevProblem& P = c->P;
   const covgpu_options& o = *opt;
-  P.reproj_loss_a = o.reproj_loss_a; P.gravity = o.gravity;
+  P.reproj_loss_a = o.reproj_loss_a;  // (IMU noise / gravity: per factor, bound at upload — covgpu.h)
   std::memset(res, 0, sizeof(*res));
   const auto t_begin = std::chrono::steady_clock::now();
   RC(reset_state(c));
@@ -1049,7 +1061,7 @@ static int download_impl(covgpu_context* c, covgpu_problem* p) {
 extern "C" int covgpu_upload(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return guarded([&] { return upload_impl(c, opt, p, false); }); }
 extern "C" int covgpu_upload_pgo(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return guarded([&] { return upload_impl(c, opt, p, true); }); }
 extern "C" int covgpu_solve_resident(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) { return guarded([&] { return solve_impl(c, opt, out); }); }
-extern "C" int covgpu_download(covgpu_context* c, covgpu_problem* p) { return download_impl(c, p); }
+extern "C" int covgpu_download(covgpu_context* c, covgpu_problem* p) { return guarded([&] { return download_impl(c, p); }); }
 
 static int full_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out, bool pgo) {
   covgpu_result local;

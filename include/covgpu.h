@@ -114,7 +114,9 @@ typedef struct covgpu_problem {
   /* Per-factor IMU calibration [sigma_a, sigma_g, sigma_aw, sigma_gw, gravity]: the reference builds every keyframe's
    * preintegrator from THAT keyframe's own calibration (keyframe_be.cpp:187-195: sigma_a_c, sigma_g_c, sigma_aw_c,
    * sigma_gw_c, g), so mixed agents / IMUs keep their own weights. NULL: the five values of covgpu_options apply to
-   * every factor. A row with a non-positive sigma or gravity < 9 (keyframe_base.cpp:51-55) is COVGPU_ERR_INVALID_ARG. */
+   * every factor. A row with a non-positive sigma or gravity < 9 (keyframe_base.cpp:51-55) is COVGPU_ERR_INVALID_ARG.
+   * The values (given or taken from the options) are captured by covgpu_upload / covgpu_gba_solve: the sigma_* / gravity
+   * fields of the options passed to a later covgpu_solve_resident are not read again. */
   const double*  imu_noise;      /* [I][5] or NULL */
 
   /* SE3 between factors (robopt SixDofBetweenError, kImu): measurement T_s1_s2 as [q(4), t(3)],

@@ -98,10 +98,16 @@ def _superlu_solve(n, D, K, ptr, col, blocks, rhs, x):
         solver_stats["seconds"] += time.perf_counter() - t0
 
 
-def use_sparse_solver(min_n: int = 3000, enable: bool = True) -> None:
-    """Route reduced systems with >= min_n unknowns through scipy's SuperLU (smaller ones keep the dense Cholesky)."""
+def use_sparse_solver(min_n: int = 3000, enable: bool = True, kind: str = "superlu") -> None:
+    """Route reduced systems with >= min_n unknowns through scipy's SuperLU (smaller ones keep the dense Cholesky).
+    kind="multifrontal": the threaded CPU port of the product's multifrontal solve (oracle/covo_mf.py) — the cpu_baseline
+    leg of bench.py; call covo_mf.set_problem(prob, opt, threads) before the solve."""
     global _solver_keepalive
-    if enable:
+    if enable and kind == "multifrontal":
+        from oracle import covo_mf
+        _solver_keepalive = _SOLVER_FN(covo_mf.solve)
+        lib().covo_set_sparse_solver(_solver_keepalive, int(min_n))
+    elif enable:
         _solver_keepalive = _SOLVER_FN(_superlu_solve)
         lib().covo_set_sparse_solver(_solver_keepalive, int(min_n))
     else:

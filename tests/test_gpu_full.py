@@ -73,6 +73,30 @@ def test_full_size_solve_matches_oracle_golden(ctx, name, sname, strategy):
     assert abs(ate_gpu - ate_cpu) < 1e-3  # north-star acceptance: final ATE within 1e-3 m of the CPU path (printed: ~1e-9)
 
 
+@pytest.mark.parametrize("name", ["mh123", "mh12345"])
+@pytest.mark.parametrize("sname,strategy", [("dogleg", capi.COVGPU_DOGLEG), ("lm", capi.COVGPU_LM)])
+def test_full_size_pgo_matches_oracle_golden(ctx, name, sname, strategy):
+    """PoseGraphOptimization (optimization_be.cpp:833-1086) at configs[2] / configs[3] size against the oracle's committed
+    result (tests/golden/pgo_*.npz, tools/make_golden_pgo.py): the ~6K-edge graph of :947-1021, Cauchy(0.5) on the loop edges,
+    10 iterations; same accept sequence, cost trace 1e-6, poses 1e-6 m / 1e-7 rad."""
+    G = np.load(os.path.join(GOLD, f"pgo_{name}.npz"))
+    m, _ = problem(name)
+    p = mapdata.flatten_pgo(m, {}, mapdata.PgoParams())[0]
+    assert digest(p) == str(G["in_digest"]), "regenerated inputs differ from the ones the golden was made on"
+    assert p.E >= 5 * p.K
+    sol, res = ctx.pgo_solve(p, backend.default_options(strategy=strategy, max_iterations=10))
+    n = res.iterations
+    assert n == len(G[f"{sname}_trace"]) and res.termination == int(G[f"{sname}_term"])
+    assert list(res.accepted_trace[:n]) == list(G[f"{sname}_acc"])
+    assert np.allclose(np.array(res.cost_trace[:n]), G[f"{sname}_trace"], rtol=1e-6, atol=0)
+    assert abs(res.initial_cost - G[f"{sname}_cost"][0]) <= 1e-9 * G[f"{sname}_cost"][0]
+    dp = np.abs(sol.kf_pose[:, 4:] - G[f"{sname}_pose"][:, 4:]).max()
+    da = rot_angle(sol.kf_pose[:, :4], G[f"{sname}_pose"][:, :4]).max()
+    ate_gpu = synth.ate_rmse(sol.kf_pose[:, 4:], G["truth_xyz"]); ate_cpu = synth.ate_rmse(G[f"{sname}_pose"][:, 4:], G["truth_xyz"])
+    print(f"pgo {name}/{sname}: K={p.K} E={p.E} max|dp|={dp:.2e} m, max angle={da:.2e} rad, ATE gpu {ate_gpu:.6f} cpu {ate_cpu:.6f}")
+    assert dp < 1e-6 and da < 1e-7 and abs(ate_gpu - ate_cpu) < 1e-3
+
+
 def _spmv(ptr, col, blocks, x, D):
     import scipy.sparse as sp
     n = D * (len(ptr) - 1)

@@ -269,12 +269,15 @@ def test_gba_solve_matches_oracle(ctx, tiny_vi, strategy, visual_only):
     assert np.array_equal(sol.kf_pose[fx], tiny_vi.kf_pose[fx])
 
 
-def test_gba_solve_small_map(ctx, small_vi):
+def test_gba_solve_small_map(ctx, small_vi, small_map):
     g, o = opts()
     sol, res = ctx.gba_solve(small_vi, g)
     ref, rres = covo.gba_solve(small_vi, o)
     _compare_solution(sol, ref, res, rres, o)
-    assert res.final_cost < 0.05 * res.initial_cost
+    # converged where the problem allows: down to the cost of the ground-truth state (measurement noise + the robust loss
+    # leave a floor there; since round 2 the generator's initial cost is no longer inflated by white bias noise, so a fixed
+    # fraction of the initial cost is not a meaningful bound)
+    assert res.final_cost < res.initial_cost and res.final_cost <= 1.1 * covo.cost(mapdata.flatten_gba(truth_map(small_map), False, True)[0], o)
 
 
 def test_resident_solve_restarts_from_upload(ctx, tiny_vi):
@@ -365,7 +368,6 @@ def test_gba_full_size_properties(ctx):
     sol, res = ctx.gba_solve(p, g)
     tr = np.array(res.cost_trace[:res.iterations])
     assert np.all(np.diff(tr) <= 1e-9 * tr[:-1])                      # monotone trust-region steps
-    assert res.final_cost < 0.05 * res.initial_cost
     pt = mapdata.flatten_gba(truth_map(m), False, True)[0]
     assert res.final_cost < 1.1 * covo.cost(pt, covo.default_options())  # at least as good as the ground truth state
     ate0 = synth.ate_rmse(p.kf_pose[:, 4:], pt.kf_pose[:, 4:]); ate1 = synth.ate_rmse(sol.kf_pose[:, 4:], pt.kf_pose[:, 4:])

@@ -431,3 +431,25 @@ def test_relative_pose_oracle():
     # configured opt.th_outlier_align = 1.3 (config_backend.yaml:117) can never be exceeded and nothing is ever removed
     n_in, T, out = covo.relpose(bt["pB"], bt["pA"], bt["kpA"], bt["kpB"], bt["sigA"], bt["sigB"], bt["camA"][0], 0, bt["camB"][0], 0, bt["T0"][0], th_outlier=1.3)
     assert n_in == 13 and not out.any()
+
+
+def test_threaded_multifrontal_solver_equals_superlu(small_map):
+    """oracle/covo_mf.py (the cpu_baseline leg's threaded reduced-system solve over the nested-dissection plan) against the
+    SuperLU path the goldens were made with: same trust-region trajectory, poses to round-off."""
+    from covins_amd import backend
+    from oracle import covo_mf
+    p = mapdata.flatten_gba(small_map, False, True)[0]
+    o = covo.default_options(max_iterations=4)
+    try:
+        covo.use_sparse_solver(min_n=100)
+        q0, r0 = covo.gba_solve(p, o)
+        covo_mf.set_problem(p, backend.default_options(), 4)
+        covo.use_sparse_solver(min_n=100, kind="multifrontal")
+        covo_mf.stats.update(calls=0)
+        q1, r1 = covo.gba_solve(p, o)
+    finally:
+        covo.use_sparse_solver(enable=False)
+    assert covo_mf.stats["calls"] >= 4 and covo_mf.stats["fronts"] >= 1
+    assert r0.iterations == r1.iterations and list(r0.accepted_trace[:4]) == list(r1.accepted_trace[:4])
+    assert abs(r0.final_cost - r1.final_cost) <= 1e-9 * r0.final_cost
+    assert np.abs(q0.kf_pose - q1.kf_pose).max() < 1e-9 and np.abs(q0.kf_speed_bias - q1.kf_speed_bias).max() < 1e-8

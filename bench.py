@@ -254,7 +254,7 @@ def main():
             psol, pres = ctx.pgo_solve(pgo_prob, popt)
             out["pgo_call"] = {"t_call_s": time.perf_counter() - t_p, "iterations": pres.iterations, "edges": int(pgo_prob.E), "keyframes": int(pgo_prob.K),
                                "initial_cost": pres.initial_cost, "final_cost": pres.final_cost,
-                               "phase_s": {"upload (plan + H2D)": pres.t_upload_s, "solve": pres.t_solve_s, "of which linear solves": pres.t_linear_solve_s,
+                               "phase_s": {"upload (plan + H2D)": pres.t_upload_s, "solve": pres.t_solve_s,
                                            "download": pres.t_download_s},
                                "critical_path": "k_potrf_panel chain of the block-arrow pose-graph solve (k_pgo.hip): latency-bound, no roofline",
                                "what": "covgpu_pgo_solve: whole PoseGraphOptimization solve (optimization_be.cpp:1024-1031) incl. plan, H2D, D2H"}

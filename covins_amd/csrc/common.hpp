@@ -50,8 +50,8 @@ struct DevProblem {
   int npairs;
   int *pair_ptr, *pair_i, *pair_j;          // [npairs+1], [npairs] chain-major positions, i > j
   int *pair_oa, *pair_ob;                   // [sum] observation of keyframe i / keyframe j of each common landmark
-  double *obsW, *obsY;                      // [O][18] per-observation W = Jp^T Jl and Y = W Hll^-1
-  double *obsP;                             // [O][39] per-observation pose-side record (k_visual.hip)
+  double *obsZ;                             // [O][18] per-observation Z = (Jp^T Jl) R with Hll^-1 = R R^T: the one record of the landmark elimination (k_visual.hip)
+  double *lmRT;                             // [L][9] per landmark: lower factor R (6) | t = R^T g_l (3)
   double *cost_part;                        // per-block cost partials
 
   // IMU factors
@@ -148,6 +148,20 @@ struct DevProblem {
   int* nd_fidx;                        // front row of an ancestor's variable (by ordinal), -1: not in this front
   double *nd_M, *nd_rhs, *nd_Linv;     // all fronts | per level [batch][2 ntot] | per level [batch][nI/128][128][128]
   double* nd_dummy;                    // sink for structurally impossible writes (never read)
+
+  // ---- trust-region state on the device (k_dense.hip: k_tr_*): radius, damping, costs, dogleg coefficients, verdicts.
+  // The step logic of Ceres' TrustRegionMinimizer / DoglegStrategy / LevenbergMarquardtStrategy runs in
+  // one-thread kernels between the vector kernels, so an iteration needs ONE host read-back (at its end) instead of three.
+  double* tr;                          // [TR_COUNT]
+};
+
+enum {
+  TR_RADIUS = 0, TR_MU, TR_LMDF, TR_COST, TR_ALPHA, TR_GG, TR_GN2, TR_GDOT, TR_DNORM, TR_CG, TR_CN, TR_MODEL, TR_SN, TR_RHO, TR_COSTNEW,
+  TR_OK, TR_VALID, TR_ACC, TR_TERM, TR_FNCONV, TR_RETRY, TR_FIRST, TR_INITCOST, TR_REUSE, TR_COUNT = 32
+};
+struct TrConsts {  // options the device-side step logic needs
+  int strategy;
+  double max_radius, min_relative_decrease, function_tolerance, parameter_tolerance, gradient_tolerance;
 };
 
 // address of entry (r, c) of the 6x6 pose-pose block (pi, pj), chain positions pi >= pj; for pi == pj only c <= r is stored.
@@ -362,6 +376,11 @@ void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, hipStream_t st
 void launch_dogleg_stats(const DevProblem& P, hipStream_t st);  // GG, GN2, GDOT, GMAX from grad/hdiag/gn
 void launch_cauchy_vec(const DevProblem& P, hipStream_t st);    // vtmp = grad / d^2
 void launch_combine_step(const DevProblem& P, double cg, double cn, hipStream_t st);  // step = cg*grad/d^2 + cn*gn ; GS, SN2
+// device-side trust region (one-thread kernels on P.tr, see DevProblem::tr)
+void launch_tr_after_solve(const DevProblem& P, TrConsts tc, int fresh, hipStream_t st);  // verdict on the linear solve, dogleg coefficients (fresh = 0: rejected dogleg step, same linearisation)
+void launch_combine_step_dev(const DevProblem& P, hipStream_t st);                          // combine_step with the coefficients in P.tr
+void launch_tr_after_model(const DevProblem& P, TrConsts tc, hipStream_t st);               // model decrease, step norm, validity, parameter tolerance
+void launch_tr_decide(const DevProblem& P, TrConsts tc, hipStream_t st);                    // rho test, radius / damping update, accept: x = candidate
 void launch_apply_step(const DevProblem& P, hipStream_t st);    // candidate = x (+) step
 void launch_accept(const DevProblem& P, hipStream_t st);        // x = candidate
 void launch_xnorm(const DevProblem& P, hipStream_t st);         // XN2

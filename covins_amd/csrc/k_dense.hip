@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void k_cauchy_vec(DevProblem P) {
 }
 
 // step = cg * g / d^2 + cn * gn ;  GS = g.step, SN2 = |step|^2
-__global__ __launch_bounds__(256) void k_combine_step(DevProblem P, double cg, double cn) {
+__global__ __launch_bounds__(256) void k_combine_step(DevProblem P, double cg, double cn, int from_dev) {
+  if (from_dev) { cg = P.tr[TR_CG]; cn = P.tr[TR_CN]; }
   double gs = 0, sn = 0;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < P.N; q += gridDim.x * blockDim.x) {
     const double g = P.grad[q], d = clamp_diag(P.hdiag[q]);
@@ -107,6 +108,101 @@ __global__ __launch_bounds__(256) void k_combine_step(DevProblem P, double cg, d
   }
   vec_reduce(P, gs, SC_GS);
   vec_reduce(P, sn, SC_SN2);
+}
+
+// ---- device-side trust region (Ceres 1.x TrustRegionMinimizer + DoglegStrategy / LevenbergMarquardtStrategy) ----
+// Same decisions, same order as the host loop they replace (solver.hip keeps that loop for the agent-sharded solve, whose
+// scalars pass through the caller's collective): one thread, a few dozen flops, between the vector kernels of the step.
+__global__ void k_tr_after_solve(DevProblem P, TrConsts tc, int fresh) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double* t = P.tr;
+  t[TR_RETRY] = 0.0; t[TR_VALID] = 0.0; t[TR_ACC] = 0.0; t[TR_FNCONV] = 0.0; t[TR_MODEL] = 0.0; t[TR_SN] = 0.0;
+  if (fresh) {
+    if (t[TR_FIRST] != 0.0) { t[TR_COST] = P.scal[SC_COST]; t[TR_INITCOST] = P.scal[SC_COST]; t[TR_FIRST] = 0.0; }
+    const bool ok = P.flag[0] == 0;
+    t[TR_OK] = ok ? 1.0 : 0.0;
+    if (!ok && tc.strategy == COVGPU_DOGLEG && t[TR_MU] * 10.0 < 1.0) { t[TR_MU] *= 10.0; t[TR_RETRY] = 1.0; return; }  // ComputeGaussNewtonStep: raise mu, solve again
+    if (!ok && tc.strategy == COVGPU_DOGLEG) t[TR_MU] *= 10.0;
+    if (P.scal[SC_GMAX] <= tc.gradient_tolerance) { t[TR_TERM] = 3.0; return; }
+    t[TR_GG] = P.scal[SC_GG]; t[TR_GN2] = P.scal[SC_GN2]; t[TR_GDOT] = P.scal[SC_GDOT];
+    if (tc.strategy == COVGPU_DOGLEG) t[TR_ALPHA] = P.scal[SC_GG] / P.scal[SC_JV2];
+  }
+  double cg = 0.0, cn = 1.0;
+  if (tc.strategy == COVGPU_DOGLEG) {
+    const double radius = t[TR_RADIUS], alpha = t[TR_ALPHA], GG = t[TR_GG], GN2 = t[TR_GN2], GDOT = t[TR_GDOT];
+    const double gn_norm = sqrt(GN2), g_norm = sqrt(GG);
+    if (gn_norm <= radius) { cg = 0.0; cn = 1.0; t[TR_DNORM] = gn_norm; }
+    else if (g_norm * alpha >= radius) { cg = -radius / g_norm; cn = 0.0; t[TR_DNORM] = radius; }
+    else {
+      const double b_dot_a = -alpha * GDOT, a_sq = alpha * alpha * GG;
+      const double bma = GN2 - 2.0 * b_dot_a + a_sq, cc = b_dot_a - a_sq;
+      const double dd = sqrt(cc * cc + bma * (radius * radius - a_sq));
+      const double beta = (cc <= 0.0) ? (dd - cc) / bma : (radius * radius - a_sq) / (dd + cc);
+      cg = -alpha * (1.0 - beta); cn = beta; t[TR_DNORM] = radius;
+    }
+  }
+  t[TR_CG] = cg; t[TR_CN] = cn;
+}
+
+__global__ void k_tr_after_model(DevProblem P, TrConsts tc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double* t = P.tr;
+  if (t[TR_RETRY] != 0.0 || t[TR_TERM] != 0.0) return;
+  const bool ok = t[TR_OK] != 0.0;
+  const double model = ok ? -(P.scal[SC_GS] + 0.5 * P.scal[SC_JV2]) : 0.0, sn = ok ? sqrt(P.scal[SC_SN2]) : 0.0;
+  t[TR_MODEL] = model; t[TR_SN] = sn;
+  const bool valid = ok && model > 0.0;
+  t[TR_VALID] = valid ? 1.0 : 0.0;
+  if (valid && sn <= tc.parameter_tolerance * (sqrt(P.scal[SC_XN2]) + tc.parameter_tolerance)) t[TR_TERM] = 2.0;
+}
+
+// rho test + updates; k_tr_accept (launched right behind) copies the candidate into the state when the step was accepted
+__global__ void k_tr_decide(DevProblem P, TrConsts tc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  {
+    double* t = P.tr;
+    int acc = 0;
+    {
+      if (t[TR_RETRY] == 0.0 && t[TR_TERM] == 0.0) {
+        const bool lm = tc.strategy == COVGPU_LM;
+        if (t[TR_VALID] == 0.0) {  // invalid step: failed factorisation or no model decrease
+          if (lm) { t[TR_RADIUS] /= t[TR_LMDF]; t[TR_LMDF] *= 2.0; }
+          else t[TR_MU] *= 10.0;
+          t[TR_REUSE] = 0.0;
+          if (t[TR_MU] >= 1.0 && t[TR_OK] == 0.0) t[TR_TERM] = 4.0;
+        } else {
+          const double cost = t[TR_COST], cost_new = P.scal[SC_COST];
+          const double rho = (cost - cost_new) / t[TR_MODEL];
+          t[TR_RHO] = rho; t[TR_COSTNEW] = cost_new;
+          acc = rho > tc.min_relative_decrease;
+          if (acc) {
+            t[TR_FNCONV] = fabs(cost - cost_new) <= tc.function_tolerance * cost ? 1.0 : 0.0;
+            t[TR_COST] = cost_new;
+            if (lm) {
+              const double u = 2.0 * rho - 1.0;
+              t[TR_RADIUS] = fmin(tc.max_radius, t[TR_RADIUS] / fmax(1.0 / 3.0, 1.0 - u * u * u));
+              t[TR_LMDF] = 2.0;
+            } else {
+              if (rho < 0.25) t[TR_RADIUS] *= 0.5;
+              if (rho > 0.75) t[TR_RADIUS] = fmax(t[TR_RADIUS], 3.0 * t[TR_DNORM]);
+              t[TR_MU] = fmax(1e-8, 2.0 * t[TR_MU] / 10.0);
+            }
+            t[TR_REUSE] = 0.0;
+          } else if (lm) { t[TR_RADIUS] /= t[TR_LMDF]; t[TR_LMDF] *= 2.0; t[TR_REUSE] = 0.0; }
+          else { t[TR_RADIUS] *= 0.5; t[TR_REUSE] = 1.0; }
+          if (t[TR_FNCONV] != 0.0) t[TR_TERM] = 1.0;
+        }
+        t[TR_ACC] = acc ? 1.0 : 0.0;
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_tr_accept(DevProblem P) {
+  if (P.tr[TR_ACC] == 0.0) return;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t q = t0; q < (size_t)7 * P.K; q += stride) P.pose[q] = P.pose_c[q];
+  if (P.vi) for (size_t q = t0; q < (size_t)9 * P.K; q += stride) P.sb[q] = P.sb_c[q];
+  for (size_t q = t0; q < (size_t)3 * P.L; q += stride) P.lm[q] = P.lm_c[q];
 }
 
 // candidate = x (+) step   (R1: q+ = q (x) Exp(dtheta), renormalised; p+ = p + dp; plain addition elsewhere)
@@ -197,8 +293,20 @@ void launch_cauchy_vec(const DevProblem& P, hipStream_t st) {
 }
 void launch_combine_step(const DevProblem& P, double cg, double cn, hipStream_t st) {
   launch_part_clear(P, SC_GS, 2, st);                       // GS, SN2 adjacent
-  hipLaunchKernelGGL(k_combine_step, dim3(vec_grid(P.N)), dim3(256), 0, st, P, cg, cn);
+  hipLaunchKernelGGL(k_combine_step, dim3(vec_grid(P.N)), dim3(256), 0, st, P, cg, cn, 0);
   launch_part_finish(P, SC_GS, 2, st);
+}
+void launch_combine_step_dev(const DevProblem& P, hipStream_t st) {
+  launch_part_clear(P, SC_GS, 2, st);
+  hipLaunchKernelGGL(k_combine_step, dim3(vec_grid(P.N)), dim3(256), 0, st, P, 0.0, 0.0, 1);
+  launch_part_finish(P, SC_GS, 2, st);
+}
+void launch_tr_after_solve(const DevProblem& P, TrConsts tc, int fresh, hipStream_t st) { hipLaunchKernelGGL(k_tr_after_solve, dim3(1), dim3(64), 0, st, P, tc, fresh); }
+void launch_tr_after_model(const DevProblem& P, TrConsts tc, hipStream_t st) { hipLaunchKernelGGL(k_tr_after_model, dim3(1), dim3(64), 0, st, P, tc); }
+void launch_tr_decide(const DevProblem& P, TrConsts tc, hipStream_t st) {
+  hipLaunchKernelGGL(k_tr_decide, dim3(1), dim3(64), 0, st, P, tc);
+  const size_t n = std::max((size_t)9 * P.K, (size_t)3 * P.L);
+  hipLaunchKernelGGL(k_tr_accept, dim3(vec_grid((int)std::min<size_t>(n, 1u << 30))), dim3(256), 0, st, P);
 }
 void launch_apply_step(const DevProblem& P, hipStream_t st) {
   const int n = P.K > 3 * P.L ? P.K : 3 * P.L;

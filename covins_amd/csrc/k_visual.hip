@@ -9,12 +9,16 @@
 //
 // Kernel shapes — three deterministic, atomic-free passes:
 //   k_lm_lin       one G-lane sub-wave group per landmark (G = 16: tracks average ~10 observations), lane = observation.
-//                  Jacobians live in VGPRs only; H_ll / g_l are reduced with shuffle butterflies inside the group; per
-//                  observation one record {W = Jp^T Jl, Y = W H_ll^-1, D = Jp^T Jp - Y W^T, diag, Jp^T r, Y g_l} goes to HBM.
-//   k_kf_reduce    one wave per keyframe, lanes over its observations: fixed-order sum of their records -> diagonal 6x6 block
-//                  of the pose system, gradient, reduced right-hand side, diag(J^T J).
+//                  Jacobians live in VGPRs only; H_ll / g_l are reduced with shuffle butterflies inside the group. With the
+//                  Cholesky factor of the damped inverse, H_ll^-1 = R R^T, ONE 6x3 record per observation goes to HBM:
+//                  Z = (Jp^T Jl) R — then W H_ll^-1 W'^T = Z Z'^T for any two observations of the landmark. (Rounds 1-2 wrote
+//                  W, Y = W H_ll^-1 and a 39-double pose-side record: 600 B per observation instead of 144.)
+//   k_kf_reduce    one wave per keyframe, lanes over its observations: every observation is RE-LINEARISED (pose and landmark
+//                  rows are cache resident, the flops are free next to the 312-B record this replaces), D = Jp^T Jp - Z Z^T,
+//                  gradient and right-hand side terms summed in a fixed order -> diagonal 6x6 block, gradient, reduced
+//                  right-hand side, diag(J^T J).
 //   k_pair_blocks  sixteen lanes per covisible keyframe pair (host-built lists, static per problem), lanes over the common
-//                  landmarks: C[i,j] = -sum Y_i W_j^T with plain stores. Every entry has exactly one writer and a fixed
+//                  landmarks: C[i,j] = -sum Z_i Z_j^T with plain stores. Every entry has exactly one writer and a fixed
 //                  summation order: two solves of the same problem are bit-identical. (The first version accumulated the
 //                  6x6 blocks with FP64 atomics: 11.1 ms and run-to-run rounding differences; these three passes take
 //                  0.66 ms on the 5-agent map.)
@@ -114,7 +118,28 @@ constexpr int kBuildThreads = 256;
 // Every entry of C is produced by exactly one wave in a fixed summation order: run-to-run bit-identical
 // (SURVEY.md §7 "irregular graph": determinism needed for parity tests) and no FP64 atomic contention.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kRec = 39;  // per-observation pose-side record: D(21, lower row-major) hd(6) gp(6) yg(6)
+constexpr int kRec = 39;  // per-keyframe sums of k_kf_reduce: D(21, lower row-major) hd(6) gp(6) yg(6)
+
+// lower Cholesky factor of the symmetric positive definite 3x3 h = (xx xy xz yy yz zz): r = (r00 r10 r11 r20 r21 r22); a
+// non-positive pivot (never for a damped inverse) gives zeros
+COV_DEV void chol3(const double* h, double* r) {
+  const double r00 = h[0] > 0.0 ? sqrt(h[0]) : 0.0, i00 = r00 > 0.0 ? 1.0 / r00 : 0.0;
+  const double r10 = h[1] * i00, r20 = h[2] * i00;
+  const double d1 = h[3] - r10 * r10, r11 = d1 > 0.0 ? sqrt(d1) : 0.0, i11 = r11 > 0.0 ? 1.0 / r11 : 0.0;
+  const double r21 = (h[4] - r20 * r10) * i11;
+  const double d2 = h[5] - r20 * r20 - r21 * r21, r22 = d2 > 0.0 ? sqrt(d2) : 0.0;
+  r[0] = r00; r[1] = r10; r[2] = r11; r[3] = r20; r[4] = r21; r[5] = r22;
+}
+// Z = W R for W = Jp^T Jl (6x3) and the lower factor R
+COV_DEV void z_of(const ObsLin& e, const double* R, double* Z) {
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const double w0 = e.jp[r] * e.jl[0] + e.jp[6 + r] * e.jl[3], w1 = e.jp[r] * e.jl[1] + e.jp[6 + r] * e.jl[4], w2 = e.jp[r] * e.jl[2] + e.jp[6 + r] * e.jl[5];
+    Z[3 * r] = w0 * R[0] + w1 * R[1] + w2 * R[3];
+    Z[3 * r + 1] = w1 * R[2] + w2 * R[4];
+    Z[3 * r + 2] = w2 * R[5];
+  }
+}
 
 template <int G>
 __global__ __launch_bounds__(kBuildThreads) void k_lm_lin(DevProblem P, double mu) {
@@ -157,6 +182,8 @@ __global__ __launch_bounds__(kBuildThreads) void k_lm_lin(DevProblem P, double m
     hd[0] += mu * d0 * d0; hd[3] += mu * d1 * d1; hd[5] += mu * d2 * d2;
     inv3sym(hd, hi);
   }
+  double R[6];
+  chol3(hi, R);
   if (lm_ok && lane == 0) {
     double* gg = P.grad + P.n + 3 * (size_t)l;
     double* hh = P.hdiag + P.n + 3 * (size_t)l;
@@ -165,6 +192,12 @@ __global__ __launch_bounds__(kBuildThreads) void k_lm_lin(DevProblem P, double m
     double* hv = P.HllInv + 6 * (size_t)l;
 #pragma unroll
     for (int k = 0; k < 6; ++k) hv[k] = hi[k];
+    double* rt = P.lmRT + 9 * (size_t)l;  // R (6) | t = R^T g_l (3): what k_kf_reduce needs of this landmark
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rt[k] = R[k];
+    rt[6] = R[0] * gl[0] + R[1] * gl[1] + R[3] * gl[2];
+    rt[7] = R[2] * gl[1] + R[4] * gl[2];
+    rt[8] = R[5] * gl[2];
   }
   // per-block cost partial (summed in a fixed order by k_cost_finish)
   cost = wave_sum(cost);
@@ -185,34 +218,11 @@ __global__ __launch_bounds__(kBuildThreads) void k_lm_lin(DevProblem P, double m
       kf = P.obs_kf[o0 + a];
       eval_obs<true>(P, P.pose, P.lm, o0 + a, kf, l, e);
     }
-    double W[18], Y[18];
+    double Z[18];
+    z_of(e, R, Z);
+    double2* zo = reinterpret_cast<double2*>(P.obsZ + 18 * (size_t)(o0 + a));  // 144-byte record, 16-byte aligned
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) W[3 * r + cc] = e.jp[r] * e.jl[cc] + e.jp[6 + r] * e.jl[3 + cc];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      Y[3 * r + 0] = W[3 * r] * hi[0] + W[3 * r + 1] * hi[1] + W[3 * r + 2] * hi[2];
-      Y[3 * r + 1] = W[3 * r] * hi[1] + W[3 * r + 1] * hi[3] + W[3 * r + 2] * hi[4];
-      Y[3 * r + 2] = W[3 * r] * hi[2] + W[3 * r + 1] * hi[4] + W[3 * r + 2] * hi[5];
-    }
-    double* wo = P.obsW + 18 * (size_t)(o0 + a);
-    double* yo = P.obsY + 18 * (size_t)(o0 + a);
-#pragma unroll
-    for (int k = 0; k < 18; ++k) { wo[k] = W[k]; yo[k] = Y[k]; }
-    double* rec = P.obsP + kRec * (size_t)(o0 + a);
-    int q = 0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int cc = 0; cc <= r; ++cc)
-        rec[q++] = e.jp[r] * e.jp[cc] + e.jp[6 + r] * e.jp[6 + cc] - (Y[3 * r] * W[3 * cc] + Y[3 * r + 1] * W[3 * cc + 1] + Y[3 * r + 2] * W[3 * cc + 2]);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      rec[21 + r] = e.jp[r] * e.jp[r] + e.jp[6 + r] * e.jp[6 + r];
-      rec[27 + r] = e.jp[r] * e.r0 + e.jp[6 + r] * e.r1;
-      rec[33 + r] = Y[3 * r] * gl[0] + Y[3 * r + 1] * gl[1] + Y[3 * r + 2] * gl[2];
-    }
+    for (int k = 0; k < 9; ++k) zo[k] = double2{Z[2 * k], Z[2 * k + 1]};
   }
 }
 
@@ -230,10 +240,9 @@ __global__ __launch_bounds__(256) void k_cost_finish(DevProblem P, int nparts) {
   if (threadIdx.x == 0) P.part[(size_t)SC_COST * P.part_n + 0] = sc[0];
 }
 
-// One wave (= one workgroup) per keyframe: fixed-order sum of its observations' records. Lanes run over the OBSERVATIONS
-// (lane l takes records l, l+64, ...: 64 independent gathers in flight), the 39 partial sums of every lane go through LDS and
-// lane k adds column k in lane order. (The first version had lane = record entry and walked the keyframe's ~400
-// observations one after the other: a chain of dependent gathers at L2 latency, 0.36 ms on the 5-agent map.)
+// One wave (= one workgroup) per keyframe: fixed-order sum over its observations. Lanes run over the OBSERVATIONS (lane l takes
+// observations l, l+64, ...), each re-linearised from the cache-resident pose / landmark rows plus the landmark's factor R and
+// t = R^T g_l (72 B); the 39 partial sums of every lane go through LDS and lane k adds column k in lane order.
 __global__ __launch_bounds__(64) void k_kf_reduce(DevProblem P) {
   __shared__ double sp[kRec][65];
   const int kf = blockIdx.x, lane = threadIdx.x;
@@ -243,9 +252,27 @@ __global__ __launch_bounds__(64) void k_kf_reduce(DevProblem P) {
 #pragma unroll
   for (int k = 0; k < kRec; ++k) part[k] = 0.0;
   for (int t = o0 + lane; t < o1; t += 64) {
-    const double* rec = P.obsP + kRec * (size_t)P.kf_obs_idx[t];
+    const int o = P.kf_obs_idx[t], l = P.obs_lm[o];
+    ObsLin e;
+    eval_obs<true>(P, P.pose, P.lm, o, kf, l, e);
+    const double* rt = P.lmRT + 9 * (size_t)l;
+    double R[6], Z[18];
 #pragma unroll
-    for (int k = 0; k < kRec; ++k) part[k] += rec[k];
+    for (int k = 0; k < 6; ++k) R[k] = rt[k];
+    const double t0 = rt[6], t1 = rt[7], t2 = rt[8];
+    z_of(e, R, Z);
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int cc = 0; cc <= r; ++cc)
+        part[q++] += e.jp[r] * e.jp[cc] + e.jp[6 + r] * e.jp[6 + cc] - (Z[3 * r] * Z[3 * cc] + Z[3 * r + 1] * Z[3 * cc + 1] + Z[3 * r + 2] * Z[3 * cc + 2]);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      part[21 + r] += e.jp[r] * e.jp[r] + e.jp[6 + r] * e.jp[6 + r];
+      part[27 + r] += e.jp[r] * e.r0 + e.jp[6 + r] * e.r1;
+      part[33 + r] += Z[3 * r] * t0 + Z[3 * r + 1] * t1 + Z[3 * r + 2] * t2;
+    }
   }
 #pragma unroll
   for (int k = 0; k < kRec; ++k) sp[k][lane] = part[k];
@@ -274,7 +301,7 @@ __global__ __launch_bounds__(64) void k_kf_reduce(DevProblem P) {
   }
 }
 
-// Sixteen lanes per covisible keyframe pair (eight pairs per workgroup): C[i,j] = -sum over the common landmarks of Y_i W_j^T.
+// Sixteen lanes per covisible keyframe pair (eight pairs per workgroup): C[i,j] = -sum over the common landmarks of Z_i Z_j^T.
 // Lanes run over the common LANDMARKS (lane g takes terms g, g+16, ...: each a 6x3 times 3x6 product from two contiguous
 // 144-byte records), the 36 partial sums of every lane go through LDS and lane g adds entries g, g+16, g+32 in lane order.
 // (The first version had lane = block entry, 36 of 64 lanes busy, every lane walking all common landmarks in sequence:
@@ -290,11 +317,11 @@ __global__ __launch_bounds__(kPairLanes * kPairsPerWg) void k_pair_blocks(DevPro
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
   for (int e = e0 + g; e < e1; e += kPairLanes) {
-    const double* y = P.obsY + 18 * (size_t)P.pair_oa[e];
-    const double* w = P.obsW + 18 * (size_t)P.pair_ob[e];
+    const double2* y = reinterpret_cast<const double2*>(P.obsZ + 18 * (size_t)P.pair_oa[e]);
+    const double2* w = reinterpret_cast<const double2*>(P.obsZ + 18 * (size_t)P.pair_ob[e]);
     double yv[18], wv[18];
 #pragma unroll
-    for (int k = 0; k < 18; ++k) { yv[k] = y[k]; wv[k] = w[k]; }
+    for (int k = 0; k < 9; ++k) { const double2 a2 = y[k], b2 = w[k]; yv[2 * k] = a2.x; yv[2 * k + 1] = a2.y; wv[2 * k] = b2.x; wv[2 * k + 1] = b2.y; }
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll

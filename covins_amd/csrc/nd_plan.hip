@@ -86,6 +86,15 @@ struct Builder {
         if (reg[w] == regid && side[w] != side[v] && !inS[w] && deg[w] > 0) { if (--deg[w]) heap.push(std::make_tuple(deg[w], 1 - (w & 1), -w)); }
       deg[v] = 0;
     }
+    // prune: a separator vertex all of whose crossing neighbours are in the separator too is redundant (greedy covers
+    // contain such vertices); latest picks first, one pass — deterministic
+    for (size_t q = S.size(); q-- > 0;) {
+      const int v = S[q];
+      bool needed = false;
+      for (int w : adj[v]) if (reg[w] == regid && side[w] != side[v] && !inS[w]) { needed = true; break; }
+      if (!needed) { inS[v] = 0; S[q] = -1; }
+    }
+    S.erase(std::remove(S.begin(), S.end(), -1), S.end());
     std::vector<std::vector<int>> parts(nparts);
     for (int v : vars) if (!inS[v]) parts[side[v]].push_back(v);
     const int n = S.empty() ? parent : new_node(S, parent);  // parts that do not touch: no separator node

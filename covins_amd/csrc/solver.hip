@@ -46,6 +46,7 @@ struct covgpu_context {
   std::vector<void*> allocs;
   size_t alloc_bytes = 0;  // device bytes behind `allocs` (the footprint covgpu_get_layout reports)
   double* h_scal = nullptr;  // pinned mirror of P.scal + flag
+  double* h_tr = nullptr;    // pinned mirror of P.tr (device-side trust region)
   int profiling = 0;
   covgpu_profile_t prof;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -140,6 +141,7 @@ extern "C" int covgpu_create(const covgpu_options* opt, covgpu_context** out) {
     HIPCHK(hipStreamCreateWithPriority(&c->st, hipStreamDefault, hi));
   }
   HIPCHK(hipHostMalloc((void**)&c->h_scal, (SC_COUNT + 4) * sizeof(double), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&c->h_tr, TR_COUNT * sizeof(double), hipHostMallocDefault));
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   std::memset(&c->P, 0, sizeof(c->P));
   *out = c;
@@ -163,6 +165,7 @@ extern "C" void covgpu_destroy(covgpu_context* c) {
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   c->chol.destroy();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->h_tr) (void)hipHostFree(c->h_tr);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
@@ -565,7 +568,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
     RC(dev_upload(c, &P.pair_ptr, pptr.data(), pptr.size()));
     RC(dev_upload(c, &P.pair_i, pi.data(), pi.size())); RC(dev_upload(c, &P.pair_j, pj.data(), pj.size()));
     RC(dev_upload(c, &P.pair_oa, oa.data(), oa.size())); RC(dev_upload(c, &P.pair_ob, ob.data(), ob.size()));
-    RC(dev_alloc(c, &P.obsW, (size_t)18 * P.O)); RC(dev_alloc(c, &P.obsY, (size_t)18 * P.O)); RC(dev_alloc(c, &P.obsP, (size_t)39 * P.O));
+    RC(dev_alloc(c, &P.obsZ, (size_t)18 * P.O)); RC(dev_alloc(c, &P.lmRT, (size_t)9 * P.L));
     RC(dev_alloc(c, &P.cost_part, (size_t)(P.L / 4 + 64)));
     HIPCHK(hipStreamSynchronize(c->st));
     h_pair_i.swap(pi); h_pair_j.swap(pj);
@@ -639,6 +642,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_alloc(c, &P.HllInv, (size_t)6 * P.L));
   RC(dev_alloc(c, &P.gn, (size_t)P.N)); RC(dev_alloc(c, &P.step, (size_t)P.N)); RC(dev_alloc(c, &P.vtmp, (size_t)P.N));
   RC(dev_alloc(c, &P.scal, (size_t)SC_COUNT)); RC(dev_alloc(c, &P.flag, (size_t)4));
+  RC(dev_alloc(c, &P.tr, (size_t)TR_COUNT));
   // deterministic reductions / scatters
   P.part_imu = 8192; P.part_edge = P.part_imu + ((P.I + 3) / 4) * 4; P.part_vec = P.part_edge + (P.E + 63) / 64;
   P.part_n = P.part_vec + 8192;
@@ -1048,6 +1052,72 @@ static int solve_impl(covgpu_context* c, const covgpu_options* opt, covgpu_resul
   return COVGPU_OK;
 }
 
+// Trust-region loop with the step logic on the device (k_dense.hip: k_tr_*): ONE host read-back per iteration — what the
+// host needs to enqueue the next one (rebuild or reuse, damping value) and the trace. Same decisions as solve_impl above,
+// which stays for the agent-sharded solve (its scalars pass through the caller's collective between the kernels).
+static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_result* res) {
+  if (!c->have) { g_err = "no problem uploaded"; return COVGPU_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  DevProblem& P = c->P;
+  const covgpu_options& o = *opt;
+  P.reproj_loss_a = o.reproj_loss_a;
+  std::memset(res, 0, sizeof(*res));
+  const auto t_begin = std::chrono::steady_clock::now();
+  RC(reset_state(c));
+  HIPCHK(hipMemsetAsync(P.flag + 1, 0, sizeof(int), c->st));
+  launch_preintegrate(P, c->st);  // R2: repropagate at the initial bias estimate (opt_be.cpp:396)
+  double* h = c->h_tr;
+  std::memset(h, 0, TR_COUNT * sizeof(double));
+  h[TR_RADIUS] = o.initial_radius; h[TR_MU] = 1e-8; h[TR_LMDF] = 2.0; h[TR_FIRST] = 1.0; h[TR_OK] = 1.0;
+  HIPCHK(hipMemcpyAsync(P.tr, h, TR_COUNT * sizeof(double), hipMemcpyHostToDevice, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));  // (h is reused as the read-back mirror below)
+  const TrConsts tc{o.strategy, o.max_radius, o.min_relative_decrease, o.function_tolerance, o.parameter_tolerance, o.gradient_tolerance};
+  bool reuse = false, got_initial = false;
+  int it = 0, accepted = 0, term = 0;
+  while (it < o.max_iterations) {
+    if (!reuse) {
+      const double damp = (o.strategy == COVGPU_LM) ? 1.0 / h[TR_RADIUS] : h[TR_MU];
+      enqueue_build(c, damp);
+      if (o.strategy == COVGPU_DOGLEG) { launch_cauchy_vec(P, c->st); enqueue_jvp(c, P.vtmp); }
+      enqueue_solve(c, P.gn);
+      launch_dogleg_stats(P, c->st);
+    }
+    launch_tr_after_solve(P, tc, reuse ? 0 : 1, c->st);
+    launch_combine_step_dev(P, c->st);
+    enqueue_jvp(c, P.step);
+    launch_xnorm(P, c->st);
+    launch_tr_after_model(P, tc, c->st);
+    launch_apply_step(P, c->st);
+    enqueue_cost_candidate(c);
+    launch_tr_decide(P, tc, c->st);
+    HIPCHK(hipMemcpyAsync(h, P.tr, TR_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());  // a failed kernel launch anywhere in the batch just drained surfaces here
+    collect_profile(c, !reuse, !reuse);
+    if (!got_initial) { res->initial_cost = h[TR_INITCOST]; got_initial = true; }
+    if (h[TR_RETRY] != 0.0) { reuse = false; continue; }  // factorisation failed: same iteration again with the raised damping
+    term = (int)h[TR_TERM];
+    if (term == 3 || term == 2) break;
+    const int acc = h[TR_ACC] != 0.0;
+    accepted += acc;
+    if (it < COVGPU_MAX_TRACE) { res->cost_trace[it] = h[TR_COST]; res->radius_trace[it] = h[TR_RADIUS]; res->accepted_trace[it] = acc; }
+    if (o.verbose) std::printf("[covgpu] it %2d cost %.9e rho %.3f radius %.3e %s\n", it, h[TR_COST], h[TR_RHO], h[TR_RADIUS], acc ? "ok" : "rej");
+    reuse = h[TR_REUSE] != 0.0;
+    ++it;
+    if (term == 1 || term == 4) break;
+  }
+  {  // IMU factors whose preintegrated covariance was not positive definite (e.g. zero samples) carry no weight: reported
+    int dropped = 0;
+    HIPCHK(hipMemcpy(&dropped, P.flag + 1, sizeof(int), hipMemcpyDeviceToHost));
+    res->reserved = dropped;
+  }
+  res->iterations = it; res->accepted = accepted; res->termination = term;
+  res->final_cost = h[TR_COST];
+  res->t_solve_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  res->t_linear_solve_s = 0.0;  // (not separable without extra synchronisation: covgpu_get_profile has the phase times)
+  return COVGPU_OK;
+}
+
 static int download_impl(covgpu_context* c, covgpu_problem* p) {
   if (!c->have) { g_err = "no problem uploaded"; return COVGPU_ERR_INVALID_ARG; }
   const DevProblem& P = c->P;
@@ -1060,7 +1130,11 @@ static int download_impl(covgpu_context* c, covgpu_problem* p) {
 
 extern "C" int covgpu_upload(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return guarded([&] { return upload_impl(c, opt, p, false); }); }
 extern "C" int covgpu_upload_pgo(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return guarded([&] { return upload_impl(c, opt, p, true); }); }
-extern "C" int covgpu_solve_resident(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) { return guarded([&] { return solve_impl(c, opt, out); }); }
+static int solve_any(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) {
+  static const bool host_tr = [] { const char* e = getenv("COVGPU_HOST_TR"); return e && e[0] == '1'; }();  // dev aid: A/B of the two loops
+  return ((c->sharded && c->have && c->P.shard) || host_tr) ? solve_impl(c, opt, out) : solve_impl_dev(c, opt, out);
+}
+extern "C" int covgpu_solve_resident(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) { return guarded([&] { return solve_any(c, opt, out); }); }
 extern "C" int covgpu_download(covgpu_context* c, covgpu_problem* p) { return guarded([&] { return download_impl(c, p); }); }
 
 static int full_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out, bool pgo) {
@@ -1068,7 +1142,7 @@ static int full_solve(covgpu_context* c, const covgpu_options* opt, covgpu_probl
   auto t0 = std::chrono::steady_clock::now();
   RC(upload_impl(c, opt, p, pgo));
   const double t_up = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  RC(solve_impl(c, opt, &local));
+  RC(solve_any(c, opt, &local));
   t0 = std::chrono::steady_clock::now();
   RC(download_impl(c, p));
   local.t_download_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -282,11 +282,20 @@ struct CholAux {
 // dense SPD solve of Sred x = bred in place (lower Cholesky on the FP64 MFMA path); flag[0] != 0 on failure
 // batched form: n independent systems of identical shape; sM / sL / sR = elements between consecutive matrices, Linv
 // sets and right-hand sides. The same launches serve all of them (one more grid dimension).
+// multifrontal fronts: the backward substitution reads the given (ancestor) unknowns straight from the solution vector and
+// writes the front's own unknowns there — no separate gather / scatter launches (k_panel.hip: k_bwd_given, k_bwd_step_sub)
+struct BwdXfer {
+  const int* gidx = nullptr;                   // solution index of every own / border scalar of every front (nullptr: disabled)
+  const int *own_g = nullptr, *st_g = nullptr, *own_dims = nullptr, *st_dims = nullptr;   // per front (level order)
+  double* x = nullptr;                         // solution vector
+  int first = 0;                               // first front of the batch
+};
 struct DenseBatch {
   int n = 0; size_t sM = 0, sL = 0, sR = 0;
   const int* live = nullptr; int tI = 0; const int* live_h = nullptr;  // live / tI: see GemmArgs (k_chol.hip)
   const long long* tab = nullptr;  // per-matrix (element offset, leading dimension): fronts of unequal order in one batch (GemmArgs::btab)
   int tri_slot = -1;               // which CholAux::tri_lev entry caches the live-tile lists of this batch's bulk updates
+  BwdXfer xfer;                    // dense_backward_solve only
   int own_max = 0;                 // > 0: largest real interior order over the batch — columns beyond it are identity padding in EVERY
                                    // matrix (L = I, block inverses = I, y = 0 already in place), so the panel kernel factors only the
                                    // 16-column blocks that hold a real column and skips all-padding panels
@@ -300,11 +309,12 @@ bool dense_panel_chain();
 void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
                         hipStream_t st, const long long* btab = nullptr, int nb = -1);  // nb: 16-column blocks to factor (-1: the whole panel)
 void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, double* x, int ncol, int nbt, size_t sM, size_t sR, hipStream_t st,
-                      const long long* btab, const int* live, int tI);
+                      const long long* btab, const int* live, int tI, BwdXfer xf = BwdXfer());
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
                      size_t sR, const int* live, int tI, hipStream_t st, bool chain = false, const long long* btab = nullptr);
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,
-                         size_t sL, size_t sR, hipStream_t st, const long long* btab = nullptr, const int* live = nullptr, int tI = 0);
+                         size_t sL, size_t sR, hipStream_t st, const long long* btab = nullptr, const int* live = nullptr, int tI = 0,
+                         BwdXfer xf = BwdXfer());  // xf.gidx != nullptr (pass it with p == 0 only): the front's own unknowns go to the solution vector
 
 // ---- block-arrow pose-graph solve (k_pgo.hip)
 struct PgoHostPlan { std::vector<std::vector<int>> block_kf; std::vector<int> border_kf; };

@@ -853,7 +853,8 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     tc.key = T * 4096 + nbt;
     tc.list.assign(NP, nullptr); tc.count.assign(NP, 0);
     for (int P = 0; P < NP && P < Pstop; ++P) {
-      const int t0 = 2 * P, tb = t0 + 4;
+      // (the LAST panel of a partial factorisation applies its whole trailing update in one launch: triangle from t0 + 2)
+      const int t0 = 2 * P, tb = (panel256 && Pstop < NP && P == Pstop - 1) ? t0 + 2 : t0 + 4;
       if (tb >= T) break;
       std::vector<int> q[8];  // per-XCD queues; whole 8x8 supertiles of one batch go to the currently shortest queue
       for (int a = 0; a < nbt; ++a) {
@@ -902,6 +903,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         wait(R, eH[P - 1]);                    // B operand: L rows t0, t0+1 (rows h of panel P-1)
         if (P >= 2) wait(R, eB[P - 2]);
         rect(h1, T, t0, w, t0 - 2, kd(P - 1), R, false);
+        if (panel256) (void)hipEventRecord(e2[P], R);  // (e2 is free in the 256-column chain: rows r carry panel P-1's update)
       }
     }
     if (P == Pstop) {  // only the look-ahead updates of the last eliminated panel; nothing of this panel is factored
@@ -913,6 +915,48 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     }
     // ---- M: critical chain
     ax.mark(M, P);
+    if (panel256 && Pstop < NP && P == Pstop - 1) {
+      // LAST panel of a partial factorisation (every multifrontal front, every arrow block): nothing is factored after it, so
+      // the look-ahead split of its trailing update (next panel's rows / diagonal / rest rows / bulk: four launches on three
+      // streams, ~100 us of event hops per front level) buys nothing — factor, solve ALL rows below, update the WHOLE trailing
+      // triangle, three dependent launches on the chain's own stream.
+      const int nbp = bt.own_max > 0 ? std::max(0, std::min(8 * w, (bt.own_max - t0 * kTile + 15) / 16)) : -1;
+      launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp);
+      (void)hipEventRecord(e1[P], M);
+      if (T > h0) {
+        if (P > 0) { if (h1 > h0) wait(M, eHp[P]); if (T > h1) wait(M, e2[P]); }
+        launch_trsm_sub(S, ld, t0, w, h0, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab);
+        if (P >= 1) wait(M, eB[P - 1]);  // bulk(P-1) was the previous writer of the trailing tiles
+        const int tb = h0, nt = T - tb;
+        if (kd(P) > 0) {
+          const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
+          GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab};
+          const bool listed = bt.live_h != nullptr && P < (int)tc.list.size() && tc.list[P] != nullptr;
+          if (listed) g.tri = tc.list[P];
+          if (!listed || tc.count[P] > 0) {
+            double pairs = 0.0;
+            for (int a = 0; a < nbt; ++a) {
+              if (bt.live_h == nullptr) { pairs += (double)nt * (nt + 1) / 2; continue; }
+              const int nI = bt.live_h[2 * a], nO = bt.live_h[2 * a + 1];
+              if (t0 >= nI) continue;
+              int nl = 0;
+              for (int t = tb; t < T; ++t) nl += (t < nI || (t >= bt.tI && t - bt.tI < nO)) ? 1 : 0;
+              pairs += (double)nl * (nl + 1) / 2;
+            }
+            if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], M);
+            if (listed) hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(tc.count[P], 1), dim3(256), lds_gemm, M, g);
+            else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, M, g);
+            if (ax.profile) {
+              (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], M);
+              ax.prof_flops.push_back(pairs * 2.0 * kTile * kTile * kd(P));
+            }
+          }
+        }
+      }
+      (void)hipEventRecord(eH[P], M); (void)hipEventRecord(eC[P], M); (void)hipEventRecord(eB[P], M);
+      Plast = P;
+      break;
+    }
     if (panel256) {
       // 256-column chain (k_panel.hip): one workgroup factors the whole diagonal block, rows h follow on the same stream by
       // block substitution, rows r on theirs — three dependent launches per panel instead of six
@@ -1026,7 +1070,7 @@ void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStrea
   const int nbt = bt.n > 0 ? bt.n : 1;
   const size_t ld = (size_t)npad;
   if (dense_panel_chain() && tend > tfact) {  // all given rows in one launch (k_panel.hip)
-    launch_bwd_given(S, ld, tfact * kTile, tend * kTile, b + npad, b, tfact * kTile, nbt, bt.sM, bt.sR, st, bt.tab, bt.live, bt.tI);
+    launch_bwd_given(S, ld, tfact * kTile, tend * kTile, b + npad, b, tfact * kTile, nbt, bt.sM, bt.sR, st, bt.tab, bt.live, bt.tI, bt.xfer);
     tend = tfact;
   }
   if (bt.own_max > 0 && tend <= tfact) tend = std::min(tend, (bt.own_max + kTile - 1) / kTile);  // all-padding interior tiles: x = 0
@@ -1037,7 +1081,7 @@ void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStrea
     if (given && nb == 0) continue;
     if (dense_panel_chain())
       launch_bwd_step_sub(S, ld, p, given ? nullptr : Linv + (size_t)p * kTile * kTile, b + npad, b, ncol, nb > 0 ? nb : 1, nbt, bt.sM, bt.sL, bt.sR, st, bt.tab,
-                          bt.live, bt.tI);
+                          bt.live, bt.tI, p == 0 ? bt.xfer : BwdXfer());
     else
       hipLaunchKernelGGL(k_bwd_step, dim3(nb > 0 ? nb : 1, nbt), dim3(256), 0, st, S, ld, p, given ? nullptr : Linv + (size_t)p * kTile * kTile,
                          b + npad, b, ncol, bt.sM, bt.sL, bt.sR);

@@ -241,14 +241,6 @@ __global__ __launch_bounds__(256) void k_nd_linv_init(double* __restrict__ Linv,
   if (q < n) { const int e = (int)(q & 255); Linv[q] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0; }
 }
 
-// dir 0: border unknowns of every front of the level <- solution vector (ancestors are solved); dir 1: own unknowns -> solution
-__global__ __launch_bounds__(256) void k_nd_xfer(DevProblem P, NdLevArgs a, double* __restrict__ x, int dir) {
-  const int node = a.first + blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-  double* rhs = a.rhs + (size_t)blockIdx.y * 2 * a.ntot;
-  if (dir == 0) { if (i < a.st_dims[node]) rhs[a.nI + i] = x[a.gidx[a.st_g[node] + i]]; }
-  else if (i < a.own_dims[node]) x[a.gidx[a.own_g[node] + i]] = rhs[i];
-}
-
 // ------------------------------------------------------------------------------------------------ launchers
 static NdLevArgs lev_args(const DevProblem& P, const NdDev& nd, int l) {
   const NdLevel& L = nd.lev[l];
@@ -293,11 +285,13 @@ void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, hipStream_t st
     ax.mark(st, -4);
   }
   for (int l = nlev - 1; l >= 0; --l) {
+    // top-down: the ancestors' unknowns are read from `dst` by the first launch of the level, the fronts' own unknowns are
+    // written there by its last (BwdXfer)
     const NdLevel& L = nd.lev[l];
-    const NdLevArgs a = lev_args(P, nd, l);
-    if (L.ntot > L.nI) hipLaunchKernelGGL(k_nd_xfer, dim3((L.ntot - L.nI + 255) / 256, L.n), dim3(256), 0, st, P, a, dst, 0);
-    dense_backward_solve(P.nd_M, P.nd_rhs + L.rhs_off, P.nd_Linv + L.linv_off, L.ntot, st, L.nI / kTile, L.ntot / kTile, batch(l));
-    hipLaunchKernelGGL(k_nd_xfer, dim3((L.nI + 255) / 256, L.n), dim3(256), 0, st, P, a, dst, 1);
+    DenseBatch bt = batch(l);
+    bt.xfer.gidx = nd.gidx; bt.xfer.own_g = nd.own_g; bt.xfer.st_g = nd.st_g; bt.xfer.own_dims = nd.own_dims; bt.xfer.st_dims = nd.st_dims;
+    bt.xfer.x = dst; bt.xfer.first = L.first;
+    dense_backward_solve(P.nd_M, P.nd_rhs + L.rhs_off, P.nd_Linv + L.linv_off, L.ntot, st, L.nI / kTile, L.ntot / kTile, bt);
     ax.mark(st, -5);
   }
   ax.mark(st, -6);

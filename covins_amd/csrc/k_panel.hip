@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // than a separate launch on a launch-bound chain); the column update is split over the workgroups as before.
 __global__ __launch_bounds__(256) void k_bwd_step_sub(const double* __restrict__ M, size_t ld, int p, const double* __restrict__ Dinv,
                                                        double* __restrict__ y, double* __restrict__ x, int ncol, size_t bsM, size_t bsL, size_t bsR,
-                                                       const long long* __restrict__ btab, const int* __restrict__ live, int tI) {
+                                                       const long long* __restrict__ btab, const int* __restrict__ live, int tI, BwdXfer xf) {
   if (live != nullptr) {  // padding tile of this front: x_p = 0 contributes nothing (GemmArgs::live)
     const int nI = live[2 * blockIdx.y], nO = live[2 * blockIdx.y + 1];
     if (!(p < nI || (p >= tI && p - tI < nO))) return;
@@ -530,6 +530,11 @@ __global__ __launch_bounds__(256) void k_bwd_step_sub(const double* __restrict__
       }
     }
     if (blockIdx.x == 0 && tid < kTile) x[k0 + tid] = sx[tid];
+    if (xf.gidx != nullptr && blockIdx.x == 0) {  // last step of a multifrontal front: its own unknowns -> solution vector
+      const int node = xf.first + blockIdx.y, n = xf.own_dims[node];
+      const int* gi = xf.gidx + xf.own_g[node];
+      for (int i = tid; i < n; i += 256) xf.x[gi[i]] = (i < kTile) ? sx[i] : x[i];   // (tile 0 from LDS: p == 0 here)
+    }
   }
   const int cl = tid & 31, rg = tid >> 5;
   const int col = blockIdx.x * 32 + cl;
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(256) void k_bwd_step_sub(const double* __restrict__
 // wave order: deterministic. Replaces one launch per given tile (12 dependent launches for a 1.5k-row border).
 __global__ __launch_bounds__(256) void k_bwd_given(const double* __restrict__ M, size_t ld, int r0, int r1, double* __restrict__ y,
                                                     const double* __restrict__ x, int ncol, size_t bsM, size_t bsR, const long long* __restrict__ btab,
-                                                    const int* __restrict__ live, int tI) {
+                                                    const int* __restrict__ live, int tI, BwdXfer xf) {
   const int batch = blockIdx.y;
   if (live != nullptr) {  // rows beyond the front's real border are padding (x = 0); a front without interior columns has nothing to update
     r1 = min(r1, (tI + live[2 * batch + 1]) * kTile);
@@ -565,8 +570,19 @@ __global__ __launch_bounds__(256) void k_bwd_given(const double* __restrict__ M,
   else M += (size_t)batch * bsM;
   y += (size_t)batch * bsR; x += (size_t)batch * bsR;
   __shared__ double2 part[4][64];
+  extern __shared__ double sxg[];  // [r1 - r0] the given unknowns, staged once (a gather through the index list inside the row loop doubled its latency)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int col = blockIdx.x * 128 + 2 * lane;
+  // multifrontal front: the given unknowns come straight from the solution vector (row r0 + i = border scalar i of the front)
+  if (xf.gidx != nullptr) {
+    const int node = xf.first + batch;
+    const int* gi = xf.gidx + xf.st_g[node];
+    r1 = min(r1, r0 + xf.st_dims[node]);
+    for (int i = threadIdx.x; i < r1 - r0; i += 256) sxg[i] = xf.x[gi[i]];
+  } else {
+    for (int i = threadIdx.x; i < r1 - r0; i += 256) sxg[i] = x[r0 + i];
+  }
+  __syncthreads();
   double2 acc = {0.0, 0.0};
   if (col < ncol) {
     const double* Lp = M + col;
@@ -574,11 +590,11 @@ __global__ __launch_bounds__(256) void k_bwd_given(const double* __restrict__ M,
     for (; r + 28 < r1; r += 32) {
       double2 v[8]; double xv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { v[u] = *reinterpret_cast<const double2*>(Lp + (size_t)(r + 4 * u) * ld); xv[u] = x[r + 4 * u]; }
+      for (int u = 0; u < 8; ++u) { v[u] = *reinterpret_cast<const double2*>(Lp + (size_t)(r + 4 * u) * ld); xv[u] = sxg[r + 4 * u - r0]; }
 #pragma unroll
       for (int u = 0; u < 8; ++u) { acc.x += v[u].x * xv[u]; acc.y += v[u].y * xv[u]; }
     }
-    for (; r < r1; r += 4) { const double2 v = *reinterpret_cast<const double2*>(Lp + (size_t)r * ld); const double xv = x[r]; acc.x += v.x * xv; acc.y += v.y * xv; }
+    for (; r < r1; r += 4) { const double2 v = *reinterpret_cast<const double2*>(Lp + (size_t)r * ld); const double xv = sxg[r - r0]; acc.x += v.x * xv; acc.y += v.y * xv; }
   }
   part[wv][lane] = acc;
   __syncthreads();
@@ -591,9 +607,10 @@ __global__ __launch_bounds__(256) void k_bwd_given(const double* __restrict__ M,
 
 // ---- launch wrappers (k_chol.hip schedules them) ----------------------------------------------------------------------
 void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, double* x, int ncol, int nbt, size_t sM, size_t sR, hipStream_t st,
-                      const long long* btab, const int* live, int tI) {
+                      const long long* btab, const int* live, int tI, BwdXfer xf) {
   if (r1 <= r0 || ncol <= 0) return;
-  hipLaunchKernelGGL(k_bwd_given, dim3((ncol + 127) / 128, nbt), dim3(256), 0, st, S, ld, r0, r1, y, (const double*)x, ncol, sM, sR, btab, live, tI);
+  hipLaunchKernelGGL(k_bwd_given, dim3((ncol + 127) / 128, nbt), dim3(256), (size_t)(r1 - r0) * sizeof(double), st, S, ld, r0, r1, y, (const double*)x, ncol, sM,
+                     sR, btab, live, tI, xf);
 }
 
 void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
@@ -619,8 +636,8 @@ void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const 
 }
 
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,
-                         size_t sL, size_t sR, hipStream_t st, const long long* btab, const int* live, int tI) {
-  hipLaunchKernelGGL(k_bwd_step_sub, dim3(nblocks, nbt), dim3(256), 0, st, S, ld, p, Linv_p, y, x, ncol, sM, sL, sR, btab, live, tI);
+                         size_t sL, size_t sR, hipStream_t st, const long long* btab, const int* live, int tI, BwdXfer xf) {
+  hipLaunchKernelGGL(k_bwd_step_sub, dim3(nblocks, nbt), dim3(256), 0, st, S, ld, p, Linv_p, y, x, ncol, sM, sL, sR, btab, live, tI, xf);
 }
 
 }  // namespace covgpu

@@ -311,7 +311,7 @@ void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* 
 void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, double* x, int ncol, int nbt, size_t sM, size_t sR, hipStream_t st,
                       const long long* btab, const int* live, int tI, BwdXfer xf = BwdXfer());
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
-                     size_t sR, const int* live, int tI, hipStream_t st, bool chain = false, const long long* btab = nullptr);
+                     size_t sR, const int* live, int tI, hipStream_t st, bool chain = false, const long long* btab = nullptr, int nb = -1);
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,
                          size_t sL, size_t sR, hipStream_t st, const long long* btab = nullptr, const int* live = nullptr, int tI = 0,
                          BwdXfer xf = BwdXfer());  // xf.gidx != nullptr (pass it with p == 0 only): the front's own unknowns go to the solution vector

@@ -925,7 +925,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       (void)hipEventRecord(e1[P], M);
       if (T > h0) {
         if (P > 0) { if (h1 > h0) wait(M, eHp[P]); if (T > h1) wait(M, e2[P]); }
-        launch_trsm_sub(S, ld, t0, w, h0, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab);
+        launch_trsm_sub(S, ld, t0, w, h0, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp);
         if (P >= 1) wait(M, eB[P - 1]);  // bulk(P-1) was the previous writer of the trailing tiles
         const int tb = h0, nt = T - tb;
         if (kd(P) > 0) {
@@ -965,12 +965,12 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       (void)hipEventRecord(e1[P], M);
       if (h1 > h0) {
         if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
-        launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab);
+        launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp);
       }
       (void)hipEventRecord(eH[P], M);
       if (T > h1) {
         wait(R, e1[P]);
-        launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab);
+        launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab, nbp);
       }
       (void)hipEventRecord(eC[P], R);
     } else {

@@ -201,12 +201,18 @@ __global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, co
   int rr[4], cc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { rr[i] = 64 * tr + ty + 16 * i; cc[i] = 64 * tc + tx + 16 * i; }
+  // what the front holds already: only columns of the front's OWN unknowns carry original entries (a border x border entry
+  // belongs to an ancestor's front) — those are read up front, beside the index loads, the rest starts from zero
   double v[4][4], rv[4] = {0.0, 0.0, 0.0, 0.0};
   bool hit[4][4];
+  const bool own_cols = 64 * tc < a.nI;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { v[i][j] = 0.0; hit[i][j] = false; }
+    for (int j = 0; j < 4; ++j) {
+      v[i][j] = (own_cols && rr[i] < nrow && cc[j] <= rr[i]) ? F[(size_t)rr[i] * ld + cc[j]] : 0.0;
+      hit[i][j] = false;
+    }
   for (int k = a.cptr[node]; k < a.cptr[node + 1]; ++k) {
     const int ch = a.cidx[k];
     const int* inv = a.inv + a.inv_off[ch];
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, co
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (hit[i][j]) F[(size_t)rr[i] * ld + cc[j]] += v[i][j];
+    for (int j = 0; j < 4; ++j) if (hit[i][j]) F[(size_t)rr[i] * ld + cc[j]] = v[i][j];
     if (rv[i] != 0.0) P.nd_rhs[rhs_off[node] + rr[i]] += rv[i];
   }
 }

@@ -24,6 +24,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <algorithm>
+
 #include "common.hpp"
 #include "dev_math.hpp"
 
@@ -627,12 +629,16 @@ void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* 
 }
 
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
-                     size_t sR, const int* live, int tI, hipStream_t st, bool chain, const long long* btab) {
-  if (r1 <= r0) return;
+                     size_t sR, const int* live, int tI, hipStream_t st, bool chain, const long long* btab, int nb) {
+  if (r1 <= r0 || nb == 0) return;
   TrsmSubArgs g{S, ld, t0 * kTile, r0 * kTile, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, live, tI, chain ? 1 : 0, btab};
   const dim3 grid((r1 - r0) * (kTile / PB), nbt);
-  if (w == 2) hipLaunchKernelGGL(k_trsm_sub<16>, grid, dim3(64), 0, st, g);
-  else hipLaunchKernelGGL(k_trsm_sub<8>, grid, dim3(64), 0, st, g);
+  // nb: 16-column blocks of the panel that hold real columns (the rest is identity padding with zeros below: X = A there)
+  const int need = nb > 0 ? std::min(nb, 8 * w) : 8 * w;
+  if (need <= 4) hipLaunchKernelGGL(k_trsm_sub<4>, grid, dim3(64), 0, st, g);
+  else if (need <= 8) hipLaunchKernelGGL(k_trsm_sub<8>, grid, dim3(64), 0, st, g);
+  else if (need <= 12) hipLaunchKernelGGL(k_trsm_sub<12>, grid, dim3(64), 0, st, g);
+  else hipLaunchKernelGGL(k_trsm_sub<16>, grid, dim3(64), 0, st, g);
 }
 
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,

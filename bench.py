@@ -103,12 +103,10 @@ def main():
     args = ap.parse_args()
 
     import torch
-    torch.cuda.init()  # torch's bundled HIP runtime must come up BEFORE libcovgpu loads /opt/rocm's (else "No HIP GPUs")
+    torch.cuda.init()  # torch's bundled HIP runtime must come up BEFORE libcovgpu loads /opt/rocm's (else "No HIP GPUs"); torch is used for nothing else here
     from covins_amd import backend, capi, distrib, mapdata, synth
     rank, local_rank, world = distrib.env_ranks()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
-    dist = distrib.init("nccl", local_rank, force=args.force_shard)
-    dev = f"cuda:{local_rank}"
     strategy = capi.COVGPU_DOGLEG if args.strategy == "dogleg" else capi.COVGPU_LM
     cfg = synth.config_named(args.workload)   # ONE map, the same on every rank (seeded generator); N > 1 shards it by agent
     m = synth.make_map(cfg)
@@ -117,33 +115,34 @@ def main():
     pgo_prob, _ = mapdata.flatten_pgo(m, {}, pgo_prm)  # the pose graph of the same (still drifted) map, for the side figure below
     opt = backend.default_options(strategy=strategy, max_iterations=args.iterations, device=local_rank)
     ctx = backend.Context(local_rank)
-    plan, reducer = None, None
+    plan, keep = None, None
     prob = full
     sharded = world > 1 or args.force_shard
     if sharded:
-        # agent-sharded solve of the ONE map: same plan on every rank, each keeps its agents' share; the
-        # library's collectives (shared-pose gradient rows, shared-pose system, scalars) run over RCCL on device pointers
+        # sub-map-sharded solve of the ONE map: same plan on every rank, each keeps the residuals of its subtrees
+        # of the elimination tree; the collectives (top fronts + gradient rows once per linear solve, three scalar exchanges)
+        # are issued by libcovgpu itself over RCCL on its own stream — no Python, no torch on the data path
         plan = distrib.shard_plan(full, opt, world)
-        assert plan is not None, "this map does not split by agent (single agent): run it on one GPU"
+        assert plan is not None, "this map does not split"
         prob = distrib.shard_problem(full, plan, rank)
-        reducer = distrib.TorchReducer(dist, dev)
-        ctx.set_shard(plan, rank, reducer.callback(), stage_on_host=False)
+        keep = distrib.attach(ctx, plan, rank, world, force_single=args.force_shard)
     t_up = time.perf_counter()
     ctx.upload(prob, opt)  # inputs resident in HBM before the timed region
     t_up = time.perf_counter() - t_up
 
     for _ in range(args.warmup):
         ctx.solve_resident(opt)
-    distrib.barrier(dist, dev)
+    distrib.barrier(ctx, sharded)
     t0 = time.perf_counter()
     iters = 0
     res = None
     for _ in range(args.steps):
         res = ctx.solve_resident(opt)  # returns after its stream has drained
         iters += res.iterations        # (sharded: every rank executes the SAME iterations of the one solve)
-    distrib.barrier(dist, dev)
+    distrib.barrier(ctx, sharded)
     dt = time.perf_counter() - t0
-    dt, iters_all = distrib.aggregate(dt, iters, dist, dev)
+    dt, iters_all = distrib.aggregate(dt, iters, ctx, sharded)
+    shard_stats = ctx.shard_stats()
     # one more step, NOT timed, with HIP events around the build pass, the factor+solve and every trailing-update launch
     ctx.set_profiling(True)
     ctx.solve_resident(opt)
@@ -152,8 +151,7 @@ def main():
     lay = ctx.layout()
     sol = ctx.download()
     if sharded:  # assemble the optimised map from the ranks' pieces (small: poses, speed-bias, landmark positions)
-        pieces = [None] * world
-        dist.all_gather_object(pieces, (sol.kf_pose, sol.kf_speed_bias, sol.lm_pos))
+        pieces = distrib.gather_solutions(sol, rank, world, keep[0]) if world > 1 else [(sol.kf_pose, sol.kf_speed_bias, sol.lm_pos)]
         parts = []
         for r, (kp, ks, lp) in enumerate(pieces):
             q = distrib.shard_problem(full, plan, r) if r != rank else prob
@@ -200,9 +198,11 @@ def main():
                        "nnzS_fill": (2 * prof["offdiag_blocks"] + prob.K) / float(prob.K) ** 2,
                        "strategy": args.strategy, "iterations_per_step": args.iterations,
                        "sharding": ("none (1 GPU)" if not sharded else
-                                    f"ONE map sharded by agent over {world} ranks: blocks->ranks {plan.block_rank.tolist()}, {int((plan.block_of_kf < 0).sum())} shared keyframes; "
-                                    f"RCCL all-reduce of the shared-pose system + gradient rows + scalars: {reducer.calls} collectives, "
-                                    f"{reducer.bytes / 1e6:.1f} MB on rank 0 over the whole run")},
+                                    f"ONE map sharded over {world} ranks: {plan.subtrees} subtrees of the elimination tree dealt to the ranks, "
+                                    f"{lay['top_unknowns']} scalar unknowns in the replicated top ({int((plan.pose_rank < 0).sum())} shared keyframe poses); "
+                                    f"{'RCCL' if world > 1 else 'in-process one-rank group'} all-reduce (issued by libcovgpu on its own stream) of the top fronts + right-hand sides + gradient rows ({lay['allreduce_kib'] / 1024:.1f} MiB per linear solve) "
+                                    f"and 3 scalar exchanges per iteration: {shard_stats['collectives']} collectives, {shard_stats['bytes'] / 1e6:.1f} MB on rank 0 "
+                                    f"in the timed steps + warm-up")},
             "kf_per_s": k_free * iters_all / dt,
             "iterations_executed": iters_all,
             "final_cost": res.final_cost, "initial_cost": res.initial_cost,
@@ -276,10 +276,8 @@ def main():
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+    distrib.barrier(ctx, sharded)
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

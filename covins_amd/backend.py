@@ -62,15 +62,6 @@ def pgo_partition(num_kf: int, edge_i, edge_j):
     return out, int(n)
 
 
-def gba_partition(prob: FlatProblem, opt: Options, force: bool = False):
-    """Host-only: block index per keyframe (-1 = border / shared keyframe) and the number of blocks (0 = dense form) of
-    the block-arrow GBA solve (covgpu_gba_partition, include/covgpu.h)."""
-    out = np.empty(prob.K, np.int32)
-    s = prob.as_struct()
-    n = lib().covgpu_gba_partition(C.byref(opt), C.byref(s), int(force), out.ctypes.data_as(capi._ip))
-    return out, int(n)
-
-
 def default_options(**kw) -> Options:
     o = Options()
     lib().covgpu_default_options(C.byref(o))
@@ -131,17 +122,31 @@ class Context:
         self._check(lib().covgpu_download(self._h, C.byref(s)))
         return q
 
-    def set_shard(self, plan, rank: int, callback, stage_on_host: bool):
-        """Agent-sharded solve (covgpu_set_shard): `plan` = distrib.ShardPlan, `callback` = a distrib.ALLREDUCE_FN object
-        (kept alive here). plan=None returns to the single-GPU form."""
-        if plan is None:
-            self._check(lib().covgpu_set_shard(self._h, 0, 1, 0, None, 0, None, None, None, 0))
-            self._shard_keep = None
-            return
-        bk = np.ascontiguousarray(plan.block_of_kf, np.int32); br = np.ascontiguousarray(plan.block_rank, np.int32)
-        self._shard_keep = (bk, br, callback)
-        self._check(lib().covgpu_set_shard(self._h, int(rank), int(plan.world), len(bk), iptr(bk), int(plan.num_blocks), iptr(br),
-                                           C.cast(callback, C.c_void_p), None, int(stage_on_host)))
+    def set_shard_group(self, plan, rank: int, group):
+        """Agent-sharded solve among host threads of THIS process (virtual ranks): `plan` = distrib.ShardPlan, `group` = distrib.Group."""
+        self._check(lib().covgpu_set_shard_group(self._h, plan.handle, int(rank), group.handle))
+        self._shard_keep = (plan, group)
+
+    def set_shard_rccl(self, plan, rank: int, world: int, unique_id: bytes):
+        """Agent-sharded solve, one process per GPU: RCCL communicator from rank 0's covgpu_rccl_unique_id."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(lib().covgpu_set_shard_rccl(self._h, plan.handle, int(rank), int(world), buf))
+        self._shard_keep = (plan,)
+
+    def set_shard_none(self):
+        self._check(lib().covgpu_set_shard_none(self._h))
+        self._shard_keep = None
+
+    def allreduce_host(self, a: np.ndarray, op: int = 0) -> np.ndarray:
+        """Sum (0) / max (1) of a small host vector over the ranks of the context's collective (identity without one)."""
+        a = np.ascontiguousarray(a, dtype=np.float64).copy()
+        self._check(lib().covgpu_allreduce_host(self._h, dptr(a), a.size, int(op)))
+        return a
+
+    def shard_stats(self) -> dict:
+        out = (C.c_int64 * 4)()
+        lib().covgpu_shard_stats(self._h, out)
+        return {"collectives": int(out[0]), "bytes": int(out[1]), "rank": int(out[2]), "world": int(out[3])}
 
     def outlier_pass(self, n_obs: int, n_lm: int, threshold: float):
         """Outlier flags and per-landmark remaining-observation counts at the resident estimate (covgpu_outlier_pass)."""
@@ -176,7 +181,7 @@ class Context:
     def layout(self) -> dict:
         out = (C.c_int64 * 16)()
         lib().covgpu_get_layout(self._h, out)
-        keys = ("arrow", "blocks", "border_kf", "interior_kf_padded", "arrow_order", "border_order", "dense_order", "covisible_pairs",
+        keys = ("shard_world", "shard_rank", "top_unknowns", "top_levels", "allreduce_kib", "reserved", "dense_order", "covisible_pairs",
                 "edge_pairs", "chains", "device_mib", "nd_fronts", "nd_levels", "nd_serial_panels", "nd_root_order", "nd_front_mib")
         return {k: int(out[i]) for i, k in enumerate(keys)}
 

@@ -204,7 +204,6 @@ def declare(lib: C.CDLL, prefix: str) -> None:
         d("schur", [C.c_void_p, OP, PP, C.c_double, _dp, _dp, _dp])
         d("solve_reduced", [C.c_void_p, C.c_int32, _dp, _dp, _dp])
         d("pgo_partition", [C.c_int32, C.c_int32, _ip, _ip, _ip], C.c_int32)
-        d("gba_partition", [OP, PP, C.c_int32, _ip], C.c_int32)
         d("gn_step", [C.c_void_p, OP, PP, C.c_double, _dp, _dp, _dp])
         d("relpose_batch", [C.c_void_p, C.POINTER(RelposeBatch), C.c_double, C.c_int32])
         d("outlier_pass", [C.c_void_p, C.c_double, _bp, _ip, C.POINTER(C.c_int64)])
@@ -212,8 +211,18 @@ def declare(lib: C.CDLL, prefix: str) -> None:
         d("nd_plan_destroy", [C.c_void_p], None)
         d("nd_plan_info", [C.c_void_p, C.POINTER(C.c_int64)], None)
         d("nd_plan_arrays", [C.c_void_p, _ip, _ip, _ip, _ip, _ip, _ip], None)
-        d("shard_plan", [OP, PP, C.c_int32, _ip, _ip, _ip, _ip, _ip], C.c_int32)
-        d("set_shard", [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _ip, C.c_int32, _ip, C.c_void_p, C.c_void_p, C.c_int32])
+        d("shard_plan", [OP, PP, C.c_int32, C.POINTER(C.c_void_p), _ip, _ip, _ip], C.c_int32)
+        d("nd_plan_owner", [C.c_void_p, _ip, _ip], None)
+        d("nd_plan_ranks", [C.c_void_p, _ip], None)
+        d("group_create", [C.c_int32, C.POINTER(C.c_void_p)])
+        d("group_destroy", [C.c_void_p], None)
+        d("group_abort", [C.c_void_p], None)
+        d("set_shard_group", [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p])
+        d("rccl_unique_id", [_bp])
+        d("set_shard_rccl", [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _bp])
+        d("set_shard_none", [C.c_void_p])
+        d("allreduce_host", [C.c_void_p, _dp, C.c_int64, C.c_int32])
+        d("shard_stats", [C.c_void_p, C.POINTER(C.c_int64)], None)
 
 
 def dptr(a: Optional[np.ndarray]):

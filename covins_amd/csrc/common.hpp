@@ -70,7 +70,7 @@ struct DevProblem {
 
   // keyframe ordering of the linear system: IMU chains (one per agent) laid out back to back
   int nchains;
-  int max_chain_len;  // keyframes of the longest chain (grid of k_yty_semisep)
+  int max_chain_len;  // keyframes of the longest chain
   int* perm;        // [K]   keyframe -> position in chain-major order (identity when !vi)
   int* pos_kf;      // [K]   position -> keyframe
   int* chain_ptr;   // [nchains+1] positions of each chain
@@ -81,19 +81,7 @@ struct DevProblem {
   double* bred;    // [n] right-hand side in IR layout (D per keyframe); solution is written to gn
   double *Ad, *Ae;          // [K][81] speed-bias diagonal / sub-diagonal (pos, pos-1) blocks, by position
   double *Bp, *Bs, *Bn;     // [K][54] speed-bias(pos) x pose(pos-1 | pos | pos+1) blocks (9x6)
-  double *Ldinv, *Lsub;       // [K][81] block-bidiagonal Cholesky factor of the speed-bias part: L_kk^-1 and L_{k,k-1}
-  double *Zfwd, *Nback;       // [K][90] operands of the forward / backward chain sweeps, per position a 9x9 matrix | a 9-vector (k_sb_sweep, k_struct.hip)
-  double *Mblk, *GI;          // [K][81] propagator M_pos = -Ldinv_pos Lsub_pos | I + Gramian of everything below pos (k_struct.hip)
-  double* Y;       // Y = L_A^-1 B, stored PER CHAIN: chain c is a [9 Kc][Yld_c] row-major block at Y + Yoff[c] (speed-bias rows of
-                   // the chain x its own pose columns; zero above the trapezoid). A chain couples to its own poses only, so
-                   // the footprint is sum 54 Kc^2 doubles instead of 54 K^2 (12 agents x 1667 keyframes: 14 GB instead of 173 GB)
-  size_t* Yoff;    // [nchains] element offset of each chain's block
-  int* Yld;        // [nchains] leading dimension of each chain's block (6 Kc rounded up to 16)
   int* pos_chain_begin;  // [K] position -> first position of its chain
-  int* pos_chain;        // [K] position -> chain index
-  int cc_n; int *cc_chain, *cc_blk;  // work list of k_sb_chain_cols: (chain, 64-column block inside it) per workgroup
-  double* zs;      // [9K]  L_A^-1 b_s
-  double* xs;      // [9K]  speed-bias solution (chain order)
   double* bp;      // [2 npad] pose right-hand side / solution of the dense stage (+ scratch half)
   double* grad;    // [N]  J^T r           (pose part, then landmark part)
   double* hdiag;   // [N]  diag(J^T J)
@@ -115,25 +103,10 @@ struct DevProblem {
   int *epair_ptr, *epair_i, *epair_j, *epair_ent;  // unique pose pairs (chain-major positions i > j) -> edges (edge*2 + transposed)
   int* flag;       // [4]  device flags (Cholesky failure)
 
-  // ---- block-arrow layout of the pose-pose system (k_arrow.hip). arrow == 0: the dense Sred above.
-  // Agents couple with each other only where landmarks were fused / loops closed; a vertex cover of those cross-agent
-  // links (the "shared" keyframes) forms the border, every agent's remaining keyframes one independent block. The
-  // pose system is BUILT directly into [interior | own border] arrow buffers and the border system: no dense C.
-  int arrow;
-  int ar_nblk, ar_ntot, ar_nIpad, ar_nb, ar_nbk;  // blocks | padded order of one arrow buffer | padded interior order | padded border order | border keyframes
-  int* ar_blk;     // [K] by chain position: block id >= 0 (interior) | -1 border | -2 keyframe of another shard (never touched here)
-  int* ar_loc;     // [K] by chain position: pose index inside its block (interior) | border index (border)
-  int* ar_own;     // [nblk][nbk] border index -> pose index inside the block's own-border part, or -1
-  int* ar_nint;    // [nblk] interior keyframes per block
-  int* ar_bpos;    // [nbk] border index -> chain position
-  int* ar_live;    // [nblk][2] real interior tiles | real own-border tiles of each arrow buffer (the rest is padding)
   // ---- agent-sharded solve of one map over several GPUs. shard == 0: everything is owned here.
-  int shard;       // 1: this context holds one rank's share (its agents' blocks, landmarks, IMU factors, edges)
-  double* vw;      // [N] weight of every unknown in the trust-region norms: 1 if this rank counts it (own interior poses,
-                   //     own chains' speed-bias blocks, own landmarks, border poses on rank 0 only), else 0; nullptr = all 1
-  double* ar_dummy;  // [36] sink for writes addressed at keyframes of other shards (their local contributions are exactly 0)
-  double *ar_M, *ar_rhs, *ar_Linv;     // [nblk][ntot][ntot] | [nblk][2 ntot] | [nblk][nIpad/128][128][128]
-  double *ar_Sb, *ar_rhsb, *ar_Linvb;  // [nb][nb] | [2 nb] | [nb/128][128][128]
+  int shard;       // 1: this context holds one rank's share (its subtrees of the elimination tree + the replicated top; its landmarks, IMU factors, edges)
+  double* vw;      // [N] weight of every unknown in the trust-region norms: 1 if this rank counts it (unknowns of its own subtrees,
+                   //     its landmarks, the top unknowns on rank 0 only), else 0; nullptr = all 1
 
   // ---- multifrontal layout of the WHOLE reduced camera system (k_front.hip, nd_plan.hpp). nd == 0: the forms above.
   // Variables: 2 pos = pose block (6), 2 pos + 1 = speed-bias block (9) of chain position pos. Every variable is owned by one
@@ -141,7 +114,8 @@ struct DevProblem {
   // level's interior order nI | the ancestor variables its subtree couples to]. The linearisation kernels write straight
   // into the fronts (nd_entry below): the entry between two variables lives in the front of the DEEPER owner.
   int nd, nd_nnodes, nd_nlev, nd_maxd;
-  int *nd_vnode, *nd_voff, *nd_vord;   // [2K] owner node | scalar offset inside the owner's own columns | ordinal inside the owner
+  int *nd_vnode, *nd_voff, *nd_vord;   // [2K] owner node (-1: another rank's) | scalar offset inside the owner's own columns | ordinal inside the owner
+  int *nd_vown;                        // [2K] 0 another rank's unknown | 1 this rank's | 2 top unknown (replicated; damped after the all-reduce)
   int *nd_ndepth, *nd_nI;              // [nodes] depth (root 0) | padded interior order of the node's level
   long long* nd_ntab;                  // [nodes][2] element offset of the front in nd_M | leading dimension (level order: a level's rows are its batch table)
   int* nd_abase;                       // [nodes][maxd] base into nd_fidx of the ancestor at that depth
@@ -153,6 +127,7 @@ struct DevProblem {
   // The step logic of Ceres' TrustRegionMinimizer / DoglegStrategy / LevenbergMarquardtStrategy runs in
   // one-thread kernels between the vector kernels, so an iteration needs ONE host read-back (at its end) instead of three.
   double* tr;                          // [TR_COUNT]
+  double* scal_r; int* flag_r;         // the scalars / factorisation flag the step logic reads: P.scal / P.flag, or (sharded solve) their all-reduced copies
 };
 
 enum {
@@ -164,14 +139,10 @@ struct TrConsts {  // options the device-side step logic needs
   double max_radius, min_relative_decrease, function_tolerance, parameter_tolerance, gradient_tolerance;
 };
 
-// address of entry (r, c) of the 6x6 pose-pose block (pi, pj), chain positions pi >= pj; for pi == pj only c <= r is stored.
-// Arrow layout: interior indices follow chain position, so interior-interior blocks keep their orientation; an
-// (interior, border) pair is stored at (border row, interior column) — transposed if the interior keyframe has the
-// higher position (the border rows come last in every arrow buffer); a border-border pair is stored below the diagonal
-// of the border system in BORDER-index order.
 // address of the entry between scalar ra of variable va and scalar rb of variable vb in the multifrontal layout
 __device__ __forceinline__ double* nd_entry(const DevProblem& P, int va, int vb, int ra, int rb) {
   const int na = P.nd_vnode[va], nb = P.nd_vnode[vb];
+  if (na < 0 || nb < 0) return P.nd_dummy;  // an unknown of another rank's subtree (its residuals never meet this rank's)
   if (na == nb) {
     const int oa = P.nd_voff[va] + ra, ob = P.nd_voff[vb] + rb;
     const int hi = oa > ob ? oa : ob, lo = oa > ob ? ob : oa;
@@ -187,25 +158,11 @@ __device__ __forceinline__ double* nd_entry(const DevProblem& P, int va, int vb,
   return P.nd_M + P.nd_ntab[2 * no] + (size_t)(row + rA) * (size_t)P.nd_ntab[2 * no + 1] + (P.nd_voff[vo] + ro);
 }
 
+// address of entry (r, c) of the 6x6 pose-pose block (pi, pj), chain positions pi >= pj; for pi == pj only c <= r is stored:
+// in the fronts (GBA) or in the dense row-major lower-triangular matrix Sred (pose graph, covgpu_schur)
 __device__ __forceinline__ double* c_entry(const DevProblem& P, int pi, int pj, int r, int c) {
   if (P.nd) return nd_entry(P, 2 * pi, 2 * pj, r, c);
-  if (!P.arrow) return P.Sred + (size_t)(6 * pi + r) * P.npad + (6 * pj + c);
-  const int bi = P.ar_blk[pi], bj = P.ar_blk[pj], li = P.ar_loc[pi], lj = P.ar_loc[pj];
-  const size_t nt = (size_t)P.ar_ntot;
-  if (bi == -2 || bj == -2) return P.ar_dummy + 6 * r + c;
-  if (bi >= 0) {
-    double* M = P.ar_M + (size_t)bi * nt * nt;
-    if (bj >= 0) return M + (size_t)(6 * li + r) * nt + (6 * lj + c);  // same block (plan invariant: no link joins two interiors)
-    const int o = P.ar_own[(size_t)bi * P.ar_nbk + lj];
-    return M + (size_t)(P.ar_nIpad + 6 * o + c) * nt + (6 * li + r);
-  }
-  if (bj >= 0) {
-    const int o = P.ar_own[(size_t)bj * P.ar_nbk + li];
-    return P.ar_M + (size_t)bj * nt * nt + (size_t)(P.ar_nIpad + 6 * o + r) * nt + (6 * lj + c);
-  }
-  // border x border: border indices follow the IR keyframe order (the same on every rank), not the chain positions
-  if (li >= lj) return P.ar_Sb + (size_t)(6 * li + r) * P.ar_nb + (6 * lj + c);
-  return P.ar_Sb + (size_t)(6 * lj + c) * P.ar_nb + (6 * li + r);
+  return P.Sred + (size_t)(6 * pi + r) * P.npad + (6 * pj + c);
 }
 
 // ---- scalar slots in DevProblem::scal
@@ -241,12 +198,9 @@ void launch_edge_gather(const DevProblem& P, hipStream_t st);
 // structured solve of the damped reduced system: speed-bias chains -> dense pose system -> back-substitution.
 // Solution (IR layout, D per keyframe) is written to dst[0..n).
 struct PgoPlan;
-struct NdDev;
-void launch_structured_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax, PgoPlan* pgo = nullptr, NdDev* nd = nullptr);
-// speed-bias chain factorisation on the auxiliary stream as soon as the IMU blocks are final (overlaps the landmark pass)
-void launch_sb_chain_factor_early(const DevProblem& P, hipStream_t st, CholAux& ax);
+// pose graph: the system assembled in P.Sred / P.bred -> dst (IR layout); block-arrow elimination (k_pgo.hip) or plain dense Cholesky
+void launch_pose_graph_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax, PgoPlan* pgo);
 void launch_zero_system(const DevProblem& P, hipStream_t st);       // every small per-iteration buffer, one launch
-void launch_zero_pose_system(const DevProblem& P, hipStream_t st);  // arrow buffers / dense pose matrix
 // per-context resources of the dense factorisation: auxiliary stream for the look-ahead, ordering events, and
 // (profiling only) one timed event pair around every bulk trailing-update launch
 struct CholAux {
@@ -256,15 +210,15 @@ struct CholAux {
   bool cf_pending = false;
   std::vector<hipEvent_t> ev, prof_ev, panel_ev;  // panel_ev: start of every big panel on the main stream (COVGPU_TRACE_PANELS=1)
   std::vector<double> prof_flops;
-  std::vector<int> live_h;   // host copy of DevProblem::ar_live (flop accounting of the batched launches)
   // per big panel of the batched (arrow) factorisation: device list of the LIVE (batch, ti, tj) tiles of its bulk update,
   // interleaved so that list position p runs on XCD p % 8 and every XCD gets the same number of tiles (k_chol.hip)
   struct TriCache { std::vector<int*> list; std::vector<int> count; int key = -1; void clear(); };
-  TriCache tri0;                  // block-arrow batches (k_arrow.hip, k_pgo.hip)
+  TriCache tri0;                  // block-arrow batches of the pose-graph solve (k_pgo.hip)
   std::vector<TriCache> tri_lev;  // one per level of the multifrontal solve (k_front.hip), selected by DenseBatch::tri_slot
   void tri_clear();
   // multi-GPU: sum `n` device doubles over all ranks, in place (solver.hip installs it when a shard is set; nullptr = single GPU)
-  void (*reduce)(void* ctx, double* dev, size_t n, int op) = nullptr;
+  // (stream-ordered: the call enqueues the collective on `st`; no host synchronisation is implied)
+  void (*reduce)(void* ctx, double* dev, size_t n, int op, hipStream_t st) = nullptr;
   void* reduce_ctx = nullptr;
   int panel_n = 0;
   std::vector<int> panel_tag;
@@ -305,7 +259,6 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
 void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStream_t st, int tfact, int tend, DenseBatch bt = DenseBatch());
 // 256-column panel chain (k_panel.hip): with it the Linv buffer holds, per tile, the eight 16x16 diagonal-block inverses
 // instead of the 128x128 inverse. COVGPU_PANEL=0 selects the round-2a chain (two 128-column potrf + inverse per panel).
-bool dense_panel_chain();
 void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
                         hipStream_t st, const long long* btab = nullptr, int nb = -1);  // nb: 16-column blocks to factor (-1: the whole panel)
 void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, double* x, int ncol, int nbt, size_t sM, size_t sR, hipStream_t st,
@@ -330,58 +283,45 @@ struct PgoPlan {
 };
 void launch_pgo_block_solve(const DevProblem& P, PgoPlan& plan, hipStream_t st, CholAux& ax);
 
-// ---- block-arrow GBA solve (k_arrow.hip)
-struct ArrowHostPlan {
-  int nblk = 0, nbk = 0, max_int = 0, max_own = 0;
-  std::vector<int> blk, loc;            // by chain position (see DevProblem::ar_blk / ar_loc)
-  std::vector<int> nint, bpos;          // interior keyframes per block | border index -> position
-  std::vector<std::vector<int>> own;    // per block: border indices of its own-border part, ascending
-};
-// positions are chain-major; pair / epair lists are the covisible and edge keyframe pairs (i > j). Returns false when the
-// arrow form does not pay (single chain, tiny system, border too large): the caller keeps the dense pose system.
-bool gba_plan_analyse(int K, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
-                      const int* epair_i, const int* epair_j, bool force, const int* pos_kf, ArrowHostPlan& out);
-// shard form: the border and the block of every keyframe are GIVEN (global plan, by position: border_in[q] != 0,
-// owned_in[q] != 0 iff the keyframe's block belongs to this rank); builds this rank's blocks and own-border lists.
-void gba_plan_build(int K, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
-                    const int* epair_i, const int* epair_j, const char* border_in, const char* owned_in, const int* pos_kf, ArrowHostPlan& out);
-void launch_shard_scal(const DevProblem& P, double* mx, int dir, hipStream_t st);  // dir 0: split off [gmax, flag], 1: put them back
-void launch_border_vec(const DevProblem& P, double* buf, int dir, hipStream_t st);  // dir 0: pack [grad | hdiag] of the border pose rows, 1: unpack
-void launch_arrow_zero(const DevProblem& P, hipStream_t st);   // per iteration: clear the buffers, identity on padding rows
-void launch_arrow_solve(const DevProblem& P, hipStream_t st, CholAux& ax);  // P.bp (chain positions) -> solution in place
-
 // ---- multifrontal solve of the whole reduced camera system (k_front.hip)
 struct NdHostPlan;
 struct NdLevel {
-  int n = 0, nI = 0, ntot = 0;          // fronts in the batch | padded interior order | largest front order of the batch
+  int n = 0, nI = 0, ntot = 0;          // fronts in the batch (0: nothing of this level on this rank) | padded interior order | largest front order
   int first = 0;                          // first node (level order) = row of nd_ntab where this level's batch table starts
   size_t rhs_off = 0, linv_off = 0;       // element offsets of the level's right-hand sides / block inverses
   int* live = nullptr;                    // [n][2] device: real interior tiles | real border tiles (GemmArgs::live)
   std::vector<int> live_h;
   int own_max = 0;                        // largest real interior order of the batch (DenseBatch::own_max)
-  int ext_first = 0, ext_count = 0;       // this level's slice of the extend-add work list (NdDev::ext)
+  int ext_first = 0, ext_count = 0;       // extend-add work list (NdDev::ext) for the SUBTREE children of this level's fronts
+  int ext2_first = 0, ext2_count = 0;     // ... for their TOP children (top levels of a sharded solve only)
 };
 struct NdDev {
   bool active = false;
+  int nnodes = 0;                          // local fronts
+  int top_lev0 = 0;                        // first top level (== lev.size(): none — single GPU)
   std::vector<NdLevel> lev;
   // device tables of the assembly kernels (owned by the context's allocation list)
-  int *lev_node = nullptr;                 // [nodes] level order -> node
   int *own_dims = nullptr, *st_dims = nullptr, *own_g = nullptr, *st_g = nullptr;  // [nodes] sizes | offsets into gidx
   int *gidx = nullptr;                     // solution index D kf + component of every own / border scalar of every node
-  int *cptr = nullptr, *cidx = nullptr;    // [nodes + 1], children (node ids)
+  int *cptr = nullptr, *cidx = nullptr;    // [nodes + 1], children that are subtree nodes (all children on a single GPU)
+  int *cptr2 = nullptr, *cidx2 = nullptr;  // [nodes + 1], children that are top nodes
   int *inv_off = nullptr, *inv = nullptr;  // [nodes] offset of the node's map parent front row -> own front row (-1: none)
   int *rhs_node = nullptr;                 // [nodes] element offset of the node's right-hand side in nd_rhs
-  int *ext = nullptr;                      // extend-add work list: (node, tile row, tile column) of 64x64 tiles, level by level
+  int *ext = nullptr;                      // extend-add work lists: (node, tile row, tile column) of 64x64 tiles
+  int *top_var = nullptr, *top_r = nullptr, *top_g = nullptr;  // per scalar unknown of the top nodes: variable | component | solution index
+  int ntop = 0;
+  // sharded solve: [top fronts | top right-hand sides | grad, hdiag of the top unknowns] is ONE contiguous range of the buffer
+  size_t M_sub = 0, rhs_top = 0, gh_off = 0;   // elements of the subtree fronts | of the top levels' right-hand sides | offset of [grad | hdiag] in nd_rhs
   // host staging of the tables (filled by nd_tables, uploaded by solver.hip)
-  std::vector<int> h_vnode, h_voff, h_vord, h_ndepth, h_nI, h_abase, h_fidx, h_lev_node, h_own_dims, h_st_dims, h_own_g, h_st_g, h_gidx, h_cptr, h_cidx,
-      h_inv_off, h_inv, h_rhs_node, h_ext;
+  std::vector<int> h_vnode, h_voff, h_vord, h_vown, h_ndepth, h_nI, h_abase, h_fidx, h_own_dims, h_st_dims, h_own_g, h_st_g, h_gidx, h_cptr, h_cidx, h_cptr2,
+      h_cidx2, h_inv_off, h_inv, h_rhs_node, h_ext, h_top_var, h_top_r, h_top_g;
   std::vector<long long> h_ntab;
   size_t M_elems = 0, rhs_elems = 0, linv_elems = 0;
 };
-void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, NdDev& dev);  // host tables + level shapes from the plan
+void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& dev);  // host tables + level shapes from the plan
 void launch_nd_init(const DevProblem& P, const NdDev& nd, hipStream_t st);    // once per upload: identity block inverses for the padding columns
 void launch_nd_zero(const DevProblem& P, const NdDev& nd, hipStream_t st);    // per iteration: clear the live tiles, identity on interior padding
-void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, hipStream_t st, CholAux& ax);  // damped system in the fronts + bred -> dst (IR layout)
+void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hipStream_t st, CholAux& ax);  // damped system in the fronts + bred -> dst (IR layout)
 
 void launch_dogleg_stats(const DevProblem& P, hipStream_t st);  // GG, GN2, GDOT, GMAX from grad/hdiag/gn
 void launch_cauchy_vec(const DevProblem& P, hipStream_t st);    // vtmp = grad / d^2

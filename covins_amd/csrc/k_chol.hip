@@ -249,432 +249,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) { gemm_abt_body
 template <int MODE, int TSA, int TSB>
 __global__ __launch_bounds__(256, 2) void k_gemm_abt_q(GemmArgs g) { gemm_abt_body<MODE, TSA, TSB, KCQ>(g); }
 
-COV_DEV double rdlane64c(double v, int srclane) {  // broadcast from a wave-uniform lane through SGPRs
-  const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), srclane);
-  const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), srclane);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// Shared tail of the potrf kernels. On entry `s` ([128][129] in LDS) holds, in its 16x16 diagonal blocks, the INVERSES of
-// the factor's diagonal blocks and, below them, the factor L itself; on exit Linv_out = L^-1 and (optionally) y = L^-1 rhs.
-// one level of the recursive-doubling inverse, NQ tiles per wave advanced in lockstep: NQ independent accumulator chains
-// keep the matrix pipe busy where a single dependent chain of v_mfma_f64 left it idle most of the time (tools/potrf_probe:
-// 20 us for the three levels with one chain per wave)
-template <int NQ>
-COV_DEV void inv_level(double* s, int h, int wave, int fr, int fk) {
-  constexpr int PT = kTile + 1;
-  const int hb = h >> 4, tpp = hb * hb;
-  int base[NQ], tr[NQ], tc[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int t = wave + 4 * q, pr = t / tpp, rem = t - pr * tpp;
-    tr[q] = rem / hb; tc[q] = rem - tr[q] * hb; base[q] = 2 * pr * h;
-  }
-  __syncthreads();
-  {  // T = C A^-1   (A^-1 lower: rows k >= c only); parked in the mirrored upper block
-    v4f64 acc[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = v4f64{0.0, 0.0, 0.0, 0.0};
-    for (int kk = 0; kk < h; kk += 4) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        if (kk < tc[q] * 16) continue;  // wave-uniform
-        const int k = kk + fk, c = tc[q] * 16 + fr;
-        const double av = s[(base[q] + h + tr[q] * 16 + fr) * PT + base[q] + k];
-        const double bv = (k >= c) ? s[(base[q] + k) * PT + base[q] + c] : 0.0;
-        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) s[(base[q] + tc[q] * 16 + fr) * PT + base[q] + h + tr[q] * 16 + fk + 4 * rg] = acc[q][rg];
-  }
-  __syncthreads();
-  {  // X21 = -B^-1 T   (B^-1 lower: k <= r only); X overwrites the C block (no longer needed)
-    v4f64 acc[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = v4f64{0.0, 0.0, 0.0, 0.0};
-    for (int kk = 0; kk < h; kk += 4) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        if (kk >= tr[q] * 16 + 16) continue;
-        const int k = kk + fk, r = tr[q] * 16 + fr;
-        const double av = (k <= r) ? s[(base[q] + h + r) * PT + base[q] + h + k] : 0.0;
-        const double bv = s[(base[q] + tc[q] * 16 + fr) * PT + base[q] + h + k];
-        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) s[(base[q] + h + tr[q] * 16 + fk + 4 * rg) * PT + base[q] + tc[q] * 16 + fr] = -acc[q][rg];
-  }
-}
-
-// Shared tail of the potrf kernels. On entry `s` ([128][129] in LDS) holds, in its 16x16 diagonal blocks, the INVERSES of
-// the factor's diagonal blocks and, below them, the factor L itself; on exit Linv_out = L^-1 and (optionally) y = L^-1 rhs.
-COV_DEV void potrf_tail(double* s, double* __restrict__ Linv_out, const double* __restrict__ rhs, double* __restrict__ yout, int k0) {
-  constexpr int PT = kTile + 1;
-  const int tid = threadIdx.x;
-  // levels h = 16, 32, 64 on the matrix core: both products are small GEMMs (triangular operands masked to zero);
-  // 4, 8, 16 output tiles per level = 1, 2, 4 per wave
-  {
-    const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
-    inv_level<1>(s, 16, wave, fr, fk);
-    inv_level<2>(s, 32, wave, fr, fk);
-    inv_level<4>(s, 64, wave, fr, fk);
-  }
-  __syncthreads();
-  PROBE(4);
-  for (int idx = tid; idx < kTile * kTile; idx += 256) {
-    const int r = idx >> 7, c = idx & 127;
-    Linv_out[idx] = (c <= r) ? s[r * PT + c] : 0.0;
-  }
-  // forward substitution riding along: y_p = L_pp^-1 b_p. Every earlier panel's TRSM has already taken its
-  // L[rows p, q] y_q out of b_p (the diagonal tile itself depends on those TRSMs).
-  if (rhs != nullptr && tid < kTile) {
-    double acc = 0.0;
-    for (int k = 0; k <= tid; ++k) acc += s[tid * PT + k] * rhs[k0 + k];
-    yout[k0 + tid] = acc;
-  }
-}
-
-// Factor the 128x128 diagonal block at (k0,k0) (lower Cholesky) and form its inverse.
-// L (lower incl. diagonal) is written back into M; L^-1 (lower, zeros above) goes to Linv_out [128][128].
-//
-// Cholesky: right-looking, the matrix lives in REGISTERS — thread (ty,tx) of the 16x16 grid owns the 8x8 elements
-// (r = ty + 16 i, c = tx + 16 k); only the pivot column travels through LDS each step. (Keeping the matrix in LDS
-// and updating it in place serialises on LDS read-after-write: measured 260 us per block instead of ~40.)
-__global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ M, size_t ld, int k0, double* __restrict__ Linv_out, int* flag,
-                                                    const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR) {
-  M += (size_t)blockIdx.x * bsM; Linv_out += (size_t)blockIdx.x * bsL;  // batched form: one workgroup per matrix
-  if (rhs != nullptr) { rhs += (size_t)blockIdx.x * bsR; yout += (size_t)blockIdx.x * bsR; }
-  extern __shared__ __attribute__((aligned(16))) double s[];  // [128][129]
-  __shared__ __attribute__((aligned(16))) double colb[2][16][8];
-  constexpr int PT = kTile + 1;
-  const int tid = threadIdx.x;
-  const int ty = tid >> 4, tx = tid & 15;
-  double* Mg = M + (size_t)k0 * ld + k0;
-  double a[8][8];
-  PROBE(0);
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int r = ty + 16 * i, c = tx + 16 * k;
-      a[i][k] = (c <= r) ? Mg[(size_t)r * ld + c] : 0.0;
-    }
-  PROBE(1);
-  // (A variant that retires FOUR pivot columns per barrier pair — 4x4 diagonal block factored redundantly by every
-  //  thread, panel rows by forward substitution on values broadcast inside each 16-lane row group — was measured
-  //  SLOWER: 91 us against 61 us for this phase. One wave per SIMD is instruction-issue bound, and the four chained
-  //  rsqrt plus 64 ds_bpermute per step cost more than the three barrier pairs they save.)
-  // One barrier per pivot column: every thread keeps its own copy dd[k] of the diagonal entries of ITS columns
-  // (updated with the same fused multiply-adds as the matrix entry itself, so the copies are bit-identical); the
-  // owners of column j therefore know the pivot without a broadcast. The scaled column is double-buffered in LDS,
-  // stored so that a thread's 8 row values (and its 8 column values) are contiguous: [r & 15][r >> 4].
-  double dd[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) dd[k] = Mg[(size_t)(tx + 16 * k) * ld + tx + 16 * k];
-#pragma unroll
-  for (int jb = 0; jb < 8; ++jb) {  // unrolled: static register indices; the 16-step inner loop must stay rolled
-#pragma unroll 1                    // (fully unrolled it is 22k instructions — far beyond the 64 KiB instruction cache)
-    for (int jj = 0; jj < 16; ++jj) {
-      const int j = 16 * jb + jj;
-      double (*cb)[8] = colb[jj & 1];
-      if (tx == jj) {  // owners of column j
-        double d = dd[jb];
-        if (!(d > 0.0)) { if (ty == 0) atomicOr(flag, 1); d = 1.0; }
-        const double inv = rsqrt(d), sd = d * inv;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int r = ty + 16 * i;
-          if (r == j) a[i][jb] = sd;
-          else if (r > j) a[i][jb] *= inv;
-          cb[ty][i] = (r > j) ? a[i][jb] : 0.0;
-        }
-      }
-      __syncthreads();
-      double cr[8], cc[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double2 u = *reinterpret_cast<const double2*>(&cb[ty][2 * q]);
-        const double2 v = *reinterpret_cast<const double2*>(&cb[tx][2 * q]);
-        cr[2 * q] = u.x; cr[2 * q + 1] = u.y; cc[2 * q] = v.x; cc[2 * q + 1] = v.y;
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int k = 0; k < 8; ++k)  // columns c > j only (the column is 0 for rows <= j); register tiles with k > i lie above the diagonal
-          if (k <= i && (k > jb || (k == jb && tx > jj))) a[i][k] -= cr[i] * cc[k];
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (k >= jb) dd[k] -= cc[k] * cc[k];
-    }
-  }
-  PROBE(2);
-  // L -> LDS (lower) and back to HBM
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int r = ty + 16 * i, c = tx + 16 * k;
-      s[r * PT + c] = (c <= r) ? a[i][k] : 0.0;
-      if (c <= r) Mg[(size_t)r * ld + c] = a[i][k];
-    }
-  __syncthreads();
-  PROBE(3);
-  // ---- inverse by recursive doubling: 8x8 diagonal blocks in registers, then for h = 8,16,32,64 every pair
-  //      [[A,0],[C,B]] -> [[A^-1,0],[-B^-1 C A^-1, B^-1]]. T = C A^-1 is parked in the (unused) mirrored upper
-  //      block, X21 overwrites C. All dot products are independent: no serial LDS chain longer than h.
-  {
-    double Lb[8][8];
-    const int c = tid & 127, cb = c & ~7, lc = c & 7;
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-      for (int k = 0; k <= r; ++k) Lb[r][k] = s[(cb + r) * PT + cb + k];
-    __syncthreads();
-    if (tid < kTile) {
-      double x[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        double sum = 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) sum += Lb[r][k] * x[k];
-        x[r] = (r == lc) ? 1.0 / Lb[r][r] : (r > lc ? -sum / Lb[r][r] : 0.0);
-      }
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-        if (r >= lc) s[(cb + r) * PT + c] = x[r];
-    }
-  }
-  {  // level h = 8 (8 pairs of 8x8 blocks): scalar dot products
-    constexpr int h = 8;
-    __syncthreads();
-    for (int idx = tid; idx < 64 * h; idx += 256) {  // T = C A^-1
-      const int pr = idx >> 6, rem = idx & 63, r = rem >> 3, c = rem & 7, base = 2 * pr * h;
-      const double* Crow = s + (base + h + r) * PT + base;
-      double sum = 0.0;
-#pragma unroll
-      for (int k = 0; k < h; ++k) sum += (k >= c) ? Crow[k] * s[(base + k) * PT + base + c] : 0.0;
-      s[(base + c) * PT + base + h + r] = sum;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 64 * h; idx += 256) {  // X21 = -B^-1 T
-      const int pr = idx >> 6, rem = idx & 63, r = rem >> 3, c = rem & 7, base = 2 * pr * h;
-      const double* Brow = s + (base + h + r) * PT + base + h;
-      const double* Tcol = s + (base + c) * PT + base + h;
-      double sum = 0.0;
-#pragma unroll
-      for (int k = 0; k < h; ++k) sum += (k <= r) ? Brow[k] * Tcol[k] : 0.0;
-      s[(base + h + r) * PT + base + c] = -sum;
-    }
-  }
-  potrf_tail(s, Linv_out, rhs, yout, k0);
-  PROBE(5);
-}
-
-// Blocked form of the same kernel (COVGPU_POTRF=2): the 128 pivot steps of k_potrf_inv cost 0.47 us each — one barrier,
-// one LDS round trip and a 64-FMA register update per pivot — and 40 of these kernels sit on the serial chain of every
-// linear solve. Here the tile stays in LDS and is factored 16 columns at a time:
-//   (a) wave 0 factors the 16x16 diagonal block in registers (row per lane, v_readlane broadcasts — no barrier inside) and
-//       leaves the reciprocal pivots; the eight block inverses the recursive-doubling tail starts from are formed at
-//       the end, one column per thread, all blocks at once;
-//   (b) every thread solves ONE row of the 16-column panel by forward substitution against that block (broadcast LDS
-//       reads; a product with the explicit inverse would be cheaper but loses the backward stability the ill-conditioned
-//       reduced camera system needs — k_potrf_inv's header records that dead end);
-//   (c) the trailing tiles are updated on the matrix core, C_ik -= L_ij L_kj^T, read-modify-write in LDS.
-// Three barriers per 16 pivots instead of sixteen; the serial part is the diagonal blocks only.
-__global__ __launch_bounds__(256) void k_potrf_inv_blk(double* __restrict__ M, size_t ld, int k0, double* __restrict__ Linv_out, int* flag,
-                                                        const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR) {
-  M += (size_t)blockIdx.x * bsM; Linv_out += (size_t)blockIdx.x * bsL;
-  if (rhs != nullptr) { rhs += (size_t)blockIdx.x * bsR; yout += (size_t)blockIdx.x * bsR; }
-  extern __shared__ __attribute__((aligned(16))) double s[];  // [128][129] | sX [8][16][16] | sInv [128]
-  constexpr int PT = kTile + 1, NB = 16, NJ = kTile / NB;
-  double* sX = s + kTile * PT;
-  double* sInv = sX + NJ * NB * NB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* Mg = M + (size_t)k0 * ld + k0;
-  PROBE(0);
-  {  // lower triangle in, zeros above: 16 independent loads in flight per thread (one at a time took 26 us)
-    const int c = tid & 127, rh = tid >> 7;
-#pragma unroll 1
-    for (int r0 = 0; r0 < kTile; r0 += 32) {
-      double v[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { const int r = r0 + 2 * i + rh; v[i] = (c <= r) ? Mg[(size_t)r * ld + c] : 0.0; }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[(r0 + 2 * i + rh) * PT + c] = v[i];
-    }
-  }
-  __syncthreads();
-  PROBE(1);
-  for (int j = 0; j < NJ; ++j) {
-    const int o = NB * j;
-    const long long tq0 = PROBE_T0();
-    if (wave == 0) {  // (a) diagonal block: lane r (mod 16) owns row r; lanes 16..63 compute duplicates and do not store
-      // (Measured alternative, tools/potrf_probe: every lane factoring the block redundantly in its own registers as 2x2 of
-      //  8x8 blocks — no cross-lane traffic at all — takes 5.9 us per block against 4.5 us here: ~1000 dependent FP64 FMAs
-      //  at one wave per SIMD cost more than the 30 v_readlane per pivot they replace.)
-      const int r = lane & 15;
-      double x[NB], invd[NB];
-#pragma unroll
-      for (int c = 0; c < NB; ++c) x[c] = (c <= r) ? s[(o + r) * PT + o + c] : 0.0;
-      bool bad = false;
-#pragma unroll
-      for (int c = 0; c < NB; ++c) {
-        double d = rdlane64c(x[c], c);
-        if (!(d > 0.0)) { bad = true; d = 1.0; }
-        double inv = __builtin_amdgcn_rsq(d);   // hardware estimate + two Newton steps: full double precision for the
-        inv = inv * (1.5 - 0.5 * d * inv * inv);  // positive, normal-range pivots of an SPD tile
-        inv = inv * (1.5 - 0.5 * d * inv * inv);
-        invd[c] = inv;
-        x[c] = (r == c) ? d * inv : x[c] * inv;
-#pragma unroll
-        for (int cc = c + 1; cc < NB; ++cc) x[cc] -= x[c] * rdlane64c(x[c], cc);  // entries above the diagonal are never read
-      }
-      if (bad && lane == 0) atomicOr(flag, 1);
-      if (lane < NB) {
-#pragma unroll
-        for (int c = 0; c < NB; ++c) s[(o + r) * PT + o + c] = (c <= r) ? x[c] : 0.0;
-        double mine = 0.0;  // reciprocal pivot of row r
-#pragma unroll
-        for (int c = 0; c < NB; ++c) mine = (c == r) ? invd[c] : mine;
-        sInv[o + r] = mine;
-      }
-    }
-    __syncthreads();
-    PROBE_ACC(5, tq0);
-    const long long tq1 = PROBE_T0();
-    {  // (b) panel rows below the block: x L_D^T = a, one row per thread
-      const int row = o + NB + tid;
-      if (row < kTile) {
-        double a[NB];
-#pragma unroll
-        for (int c = 0; c < NB; ++c) a[c] = s[row * PT + o + c];
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-          a[k] *= sInv[o + k];
-#pragma unroll
-          for (int c = k + 1; c < NB; ++c) a[c] -= a[k] * s[(o + c) * PT + o + k];
-        }
-#pragma unroll
-        for (int c = 0; c < NB; ++c) s[row * PT + o + c] = a[c];
-      }
-    }
-    __syncthreads();
-    PROBE_ACC(6, tq1);
-    const long long tq2 = PROBE_T0();
-    {  // (c) trailing update of tiles (i, k), j < k <= i < 8
-      const int m = NJ - 1 - j, nT = m * (m + 1) / 2, fr = lane & 15, fk = lane >> 4;
-      for (int t = wave; t < nT; t += 4) {
-        int ti = 0;
-        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-        const int tk = t - ti * (ti + 1) / 2;
-        const int ri = o + NB * (1 + ti), rk = o + NB * (1 + tk);
-        v4f64 acc;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) acc[rg] = s[(ri + fk + 4 * rg) * PT + rk + fr];
-#pragma unroll
-        for (int ss = 0; ss < 4; ++ss) {
-          const double av = -s[(ri + fr) * PT + o + 4 * ss + fk];
-          const double bv = s[(rk + fr) * PT + o + 4 * ss + fk];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) s[(ri + fk + 4 * rg) * PT + rk + fr] = acc[rg];
-      }
-    }
-    __syncthreads();
-    PROBE_ACC(7, tq2);
-  }
-  PROBE(2);
-  // L back to HBM, then the diagonal blocks are replaced by their inverses for the recursive-doubling tail
-  {
-    const int c = tid & 127, rh = tid >> 7;
-#pragma unroll 8
-    for (int r = rh; r < kTile; r += 2)
-      if (c <= r) Mg[(size_t)r * ld + c] = s[r * PT + c];
-  }
-  __syncthreads();
-  if (tid < kTile) {  // inverses of the eight 16x16 diagonal blocks, one column per thread (forward substitution on L e_c)
-    const int j = tid >> 4, col = tid & 15, o = NB * j;
-    double xi[NB];
-#pragma unroll
-    for (int rr = 0; rr < NB; ++rr) {
-      double sum = 0.0;
-#pragma unroll
-      for (int k = 0; k < rr; ++k) sum += s[(o + rr) * PT + o + k] * xi[k];
-      xi[rr] = (rr == col) ? sInv[o + rr] : (rr > col ? -sum * sInv[o + rr] : 0.0);
-    }
-#pragma unroll
-    for (int rr = 0; rr < NB; ++rr) sX[(j * NB + rr) * NB + col] = xi[rr];
-  }
-  __syncthreads();
-  for (int idx = tid; idx < NJ * NB * NB; idx += 256) {
-    const int j = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
-    s[(NB * j + rr) * PT + NB * j + cc] = sX[idx];
-  }
-  PROBE(3);
-  potrf_tail(s, Linv_out, rhs, yout, k0);
-  PROBE(5);
-}
-
-// backward substitution step for panel p:  x_p = Linv_p^T y_p ; y[cols left of the panel] -= L[panel rows, cols]^T x_p
-// Block = 32 columns x 8 row groups (16 panel rows each): 8x more loads in flight than one thread per column
-// (that version was latency-bound: 50 us per step), partial sums combined through LDS in a fixed order.
-// Linv == nullptr: x_p is given (block-arrow solve: a border tile); ncol = number of columns to update (p*128 normally).
-__global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, size_t ld, int p, const double* __restrict__ Linv,
-                                                   double* __restrict__ y, double* __restrict__ x, int ncol, size_t bsM, size_t bsL, size_t bsR) {
-  M += (size_t)blockIdx.y * bsM; y += (size_t)blockIdx.y * bsR; x += (size_t)blockIdx.y * bsR;  // batched form
-  if (Linv != nullptr) Linv += (size_t)blockIdx.y * bsL;
-  __shared__ double sx[kTile];
-  __shared__ double sy[kTile];
-  __shared__ double part[8][33];
-  const int tid = threadIdx.x, k0 = p * kTile;
-  if (Linv == nullptr) {
-    if (tid < kTile) sx[tid] = x[k0 + tid];
-    __syncthreads();
-  } else {  // x_p = Linv^T y_p : thread (i, half) sums half of the rows j >= i
-    if (tid < kTile) sy[tid] = y[k0 + tid];
-    __syncthreads();
-    const int i = tid & 127, half = tid >> 7;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    const double* Lc = Linv + i;
-    const int j0 = half * 64, j1 = j0 + 64;
-#pragma unroll 4
-    for (int j = j0; j < j1; j += 4) {  // Linv is zero above the diagonal: no j >= i test needed
-      s0 += Lc[(size_t)j * kTile] * sy[j]; s1 += Lc[(size_t)(j + 1) * kTile] * sy[j + 1];
-      s2 += Lc[(size_t)(j + 2) * kTile] * sy[j + 2]; s3 += Lc[(size_t)(j + 3) * kTile] * sy[j + 3];
-    }
-    const double v = (s0 + s1) + (s2 + s3);
-    if (half == 1) sx[i] = v;
-    __syncthreads();
-    if (half == 0) { sx[i] += v; }
-    __syncthreads();
-    if (blockIdx.x == 0 && tid < kTile) x[k0 + tid] = sx[tid];
-  }
-  const int cl = tid & 31, rg = tid >> 5;
-  const int col = blockIdx.x * 32 + cl;
-  double acc = 0.0;
-  if (col < ncol) {
-    const double* Lc = M + (size_t)(k0 + 16 * rg) * ld + col;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc += Lc[(size_t)r * ld] * sx[16 * rg + r];
-  }
-  part[rg][cl] = acc;
-  __syncthreads();
-  if (rg == 0 && col < ncol) {
-    double t = 0.0;
-#pragma unroll
-    for (int g2 = 0; g2 < 8; ++g2) t += part[g2][cl];
-    y[col] -= t;
-  }
-}
-
 // The single-workgroup potrf (133 KB LDS + 174 VGPRs x 256 threads: needs an EMPTY CU) starves for the whole duration
 // of a bulk trailing update when every CU holds two bulk workgroups: 400-800 us instead of ~100 us (profiles/r01q,
 // timeline in profiles/r01y_timeline_*.csv). Creating the bulk (aux) and rest-row (mid) streams with a CU mask that
@@ -766,25 +340,14 @@ void CholAux::collect() {
   prof_flops.clear();
 }
 
-bool dense_panel_chain() {
-  static const bool on = [] { const char* e = getenv("COVGPU_PANEL"); return e ? atoi(e) != 0 : true; }();
-  return on;
-}
-
 void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax, int tstop, bool solve,
                               DenseBatch bt) {
-  const bool panel256 = dense_panel_chain();
   const int nbt = bt.n > 0 ? bt.n : 1;
   const int T = npad / kTile;
   const size_t ld = (size_t)npad;
-  const size_t lds_potrf = (size_t)kTile * (kTile + 1) * sizeof(double);
-  const size_t lds_potrf_blk = lds_potrf + (size_t)(8 * 16 * 16 + kTile) * sizeof(double);
   const size_t lds_gemm = (size_t)2 * kTile * LDT * sizeof(double);
   static std::once_flag attr_once;  // (the pose-graph solve calls this from several host threads at once)
   std::call_once(attr_once, [&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_potrf);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv_blk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_potrf_blk);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_TRSM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_SYRK_TRI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_SYRK_RECT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
   });
@@ -803,21 +366,6 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   hipEvent_t* eRc = e3 + (NP + 1);
   hipEvent_t* eHp = eRc + (NP + 1);  // rows h updated with column t0 (their last TRSM then runs on the chain's own stream)
 
-  static const int potrf_kind = [] { const char* e = getenv("COVGPU_POTRF"); return e ? atoi(e) : 2; }();  // 1: per-pivot kernel, 2: blocked (default)
-  auto potrf = [&](int t) {
-    if (potrf_kind == 1)
-      hipLaunchKernelGGL(k_potrf_inv, dim3(nbt), dim3(256), lds_potrf, st, S, ld, t * kTile, Linv + (size_t)t * kTile * kTile, flag, b, b + npad, bt.sM, bt.sL, bt.sR);
-    else
-      hipLaunchKernelGGL(k_potrf_inv_blk, dim3(nbt), dim3(256), lds_potrf_blk, st, S, ld, t * kTile, Linv + (size_t)t * kTile * kTile, flag, b, b + npad, bt.sM, bt.sL, bt.sR);
-  };
-  // rows [r0, r1) of tile column t:  A <- A Linv_t^T
-  // quad: four workgroups per tile (head launches on the serial chain)
-  auto trsm = [&](int t, int r0, int r1, hipStream_t s2, bool quad) {
-    if (r1 <= r0) return;
-    GemmArgs g{S, ld, t * kTile, kTile, r0 * kTile, 0, t * kTile, r1 - r0, Linv + (size_t)t * kTile * kTile, b, b + npad, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab};
-    if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_TRSM, 32, kTile>), dim3(r1 - r0, 1, 4 * nbt), dim3(256), (size_t)(32 + kTile) * (KCQ + 1) * sizeof(double), s2, g);
-    else hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(r1 - r0, 1, nbt), dim3(256), lds_gemm, s2, g);
-  };
   // C tiles (rows [r0, r1), tile columns [tc0, tc0+ntc)) -= A[rows, K] A[tc.., K]^T, K = tiles kt0.. (KD columns); lower part only
   auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2, bool quad) {
     if (r1 <= r0 || ntc <= 0 || KD <= 0) return;
@@ -854,7 +402,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     tc.list.assign(NP, nullptr); tc.count.assign(NP, 0);
     for (int P = 0; P < NP && P < Pstop; ++P) {
       // (the LAST panel of a partial factorisation applies its whole trailing update in one launch: triangle from t0 + 2)
-      const int t0 = 2 * P, tb = (panel256 && Pstop < NP && P == Pstop - 1) ? t0 + 2 : t0 + 4;
+      const int t0 = 2 * P, tb = (Pstop < NP && P == Pstop - 1) ? t0 + 2 : t0 + 4;
       if (tb >= T) break;
       std::vector<int> q[8];  // per-XCD queues; whole 8x8 supertiles of one batch go to the currently shortest queue
       for (int a = 0; a < nbt; ++a) {
@@ -897,13 +445,13 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         wait(H, eH[P - 1]);                    // B operand: L rows t0, t0+1 — their last TRSM ran on the chain's stream
         if (P >= 2) wait(H, eB[P - 2]);        // bulk(P-2) was the previous writer of these tiles
         rect(h0, h1, t0, w, t0 - 2, kd(P - 1), H, true);
-        if (panel256) (void)hipEventRecord(eHp[P], H);
+        (void)hipEventRecord(eHp[P], H);
       }
       if (T > h1) {
         wait(R, eH[P - 1]);                    // B operand: L rows t0, t0+1 (rows h of panel P-1)
         if (P >= 2) wait(R, eB[P - 2]);
         rect(h1, T, t0, w, t0 - 2, kd(P - 1), R, false);
-        if (panel256) (void)hipEventRecord(e2[P], R);  // (e2 is free in the 256-column chain: rows r carry panel P-1's update)
+        (void)hipEventRecord(e2[P], R);  // rows r carry panel P-1's update
       }
     }
     if (P == Pstop) {  // only the look-ahead updates of the last eliminated panel; nothing of this panel is factored
@@ -915,7 +463,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     }
     // ---- M: critical chain
     ax.mark(M, P);
-    if (panel256 && Pstop < NP && P == Pstop - 1) {
+    if (Pstop < NP && P == Pstop - 1) {
       // LAST panel of a partial factorisation (every multifrontal front, every arrow block): nothing is factored after it, so
       // the look-ahead split of its trailing update (next panel's rows / diagonal / rest rows / bulk: four launches on three
       // streams, ~100 us of event hops per front level) buys nothing — factor, solve ALL rows below, update the WHOLE trailing
@@ -957,7 +505,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       Plast = P;
       break;
     }
-    if (panel256) {
+    {
       // 256-column chain (k_panel.hip): one workgroup factors the whole diagonal block, rows h follow on the same stream by
       // block substitution, rows r on theirs — three dependent launches per panel instead of six
       const int nbp = bt.own_max > 0 ? std::max(0, std::min(8 * w, (bt.own_max - t0 * kTile + 15) / 16)) : -1;
@@ -971,43 +519,6 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       if (T > h1) {
         wait(R, e1[P]);
         launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab, nbp);
-      }
-      (void)hipEventRecord(eC[P], R);
-    } else {
-      potrf(t0);
-      (void)hipEventRecord(e1[P], M);
-      if (w == 2) {
-        trsm(t0, t0 + 1, t0 + 2, M, true);
-        (void)hipEventRecord(e2[P], M);
-        rect(t0 + 1, t0 + 2, t0 + 1, 1, t0, kTile, M, true);   // rank-128 update of the second diagonal tile
-        potrf(t0 + 1);
-        (void)hipEventRecord(e3[P], M);
-      }
-      // ---- H: rows h
-      if (h1 > h0) {
-        wait(H, e1[P]);
-        trsm(t0, h0, h1, H, true);
-        if (w == 2) {
-          wait(H, e2[P]);                        // X(t0+1, t0)
-          rect(h0, h1, t0 + 1, 1, t0, kTile, H, true);
-          // the LAST kernel of rows h — their TRSM against potrf(t0+1) — gates the next diagonal update: it runs on the chain's
-          // stream right behind that potrf instead of paying a cross-stream event hop (~10 us per big panel un-profiled)
-          (void)hipEventRecord(eHp[P], H);
-          wait(M, eHp[P]);
-          trsm(t0 + 1, h0, h1, M, true);
-        }
-      }
-      (void)hipEventRecord(eH[P], (h1 > h0 && w == 2) ? M : H);
-      // ---- R: rows r
-      if (T > h1) {
-        wait(R, e1[P]);
-        trsm(t0, h1, T, R, false);
-        if (w == 2) {
-          wait(R, e2[P]);
-          rect(h1, T, t0 + 1, 1, t0, kTile, R, false);
-          wait(R, e3[P]);
-          trsm(t0 + 1, h1, T, R, false);
-        }
       }
       (void)hipEventRecord(eC[P], R);
     }
@@ -1069,7 +580,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
 void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStream_t st, int tfact, int tend, DenseBatch bt) {
   const int nbt = bt.n > 0 ? bt.n : 1;
   const size_t ld = (size_t)npad;
-  if (dense_panel_chain() && tend > tfact) {  // all given rows in one launch (k_panel.hip)
+  if (tend > tfact) {  // all given rows in one launch (k_panel.hip)
     launch_bwd_given(S, ld, tfact * kTile, tend * kTile, b + npad, b, tfact * kTile, nbt, bt.sM, bt.sR, st, bt.tab, bt.live, bt.tI, bt.xfer);
     tend = tfact;
   }
@@ -1079,12 +590,8 @@ void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStrea
     const int ncol = given ? tfact * kTile : p * kTile;
     const int nb = (ncol + 31) / 32;
     if (given && nb == 0) continue;
-    if (dense_panel_chain())
       launch_bwd_step_sub(S, ld, p, given ? nullptr : Linv + (size_t)p * kTile * kTile, b + npad, b, ncol, nb > 0 ? nb : 1, nbt, bt.sM, bt.sL, bt.sR, st, bt.tab,
                           bt.live, bt.tI, p == 0 ? bt.xfer : BwdXfer());
-    else
-      hipLaunchKernelGGL(k_bwd_step, dim3(nb > 0 ? nb : 1, nbt), dim3(256), 0, st, S, ld, p, given ? nullptr : Linv + (size_t)p * kTile * kTile,
-                         b + npad, b, ncol, bt.sM, bt.sL, bt.sR);
   }
 }
 

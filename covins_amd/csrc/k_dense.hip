@@ -20,27 +20,28 @@ namespace covgpu {
 using namespace covdev;
 
 // ------------------------------------------------------------------------------------------- vector kernels
-// add the trust-region damping mu * clamp(diag)^2 to every active diagonal entry of the structured system;
+// add the trust-region damping mu * clamp(diag)^2 to every active diagonal entry of the reduced camera system;
 // constant / unconstrained dimensions (diag(J^T J) == 0) become identity rows with zero right-hand side (A.6)
-// which: 0 = pose rows (+ the padding rows of C), 1 = speed-bias rows, 2 = both. The speed-bias rows are complete as
-// soon as the IMU factors are in, so their part runs early and the chain factorisation overlaps the landmark pass.
+// which: 0 = pose rows (+ the padding rows of the dense pose-graph matrix), 1 = speed-bias rows (in P.Ad, before k_nd_assemble
+// copies them into the fronts), 2 = both.
 __global__ __launch_bounds__(256) void k_finalize_diag(DevProblem P, double mu, int which) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < P.n) {
     const int kf = q / P.D, r = q - kf * P.D, pos = P.perm[kf];
     if (which == 2 || (which == 0) == (r < 6)) {
-      double* d = (r < 6) ? c_entry(P, pos, pos, r, r) : P.Ad + (size_t)81 * pos + 10 * (r - 6);
-      const double h = P.hdiag[q];
-      // sharded solve: a border row's damping / identity is added by the one rank that counts the row (the all-reduce
-      // of the border system sums the ranks' parts); rows of other shards' keyframes are not this rank's business
-      const bool mine = r >= 6 || P.vw == nullptr || P.vw[q] != 0.0;  // (speed-bias rows are never shared: always local)
-      if (!mine) { if (h == 0.0) P.bred[q] = 0.0; }
-      else if (h == 0.0) { *d = 1.0; P.bred[q] = 0.0; }
-      else { const double c = clamp_diag(h); *d += mu * c * c; }
+      // agent-sharded solve: unknowns of other ranks' subtrees are not this rank's business; the top (replicated) unknowns get
+      // their damping after the all-reduce, from the all-reduced diag(J^T J) (k_nd_top_damp, k_front.hip)
+      const int own = P.nd_vown != nullptr ? P.nd_vown[2 * pos + (r < 6 ? 0 : 1)] : 1;
+      if (own == 1) {
+        double* d = (r < 6) ? c_entry(P, pos, pos, r, r) : P.Ad + (size_t)81 * pos + 10 * (r - 6);
+        const double h = P.hdiag[q];
+        if (h == 0.0) { *d = 1.0; P.bred[q] = 0.0; }
+        else { const double c = clamp_diag(h); *d += mu * c * c; }
+      }
     }
   }
-  const int pad = 6 * P.K + q;  // padding rows of C
-  if (which != 1 && !P.arrow && !P.nd && q < P.npad - 6 * P.K) P.Sred[(size_t)pad * P.npad + pad] = 1.0;  // (arrow layout: k_arrow_init; fronts: k_nd_zero)
+  const int pad = 6 * P.K + q;  // padding rows of the dense pose-graph matrix (the fronts: k_nd_zero)
+  if (which != 1 && !P.nd && q < P.npad - 6 * P.K) P.Sred[(size_t)pad * P.npad + pad] = 1.0;
 }
 
 // fixed-order sum of one slot's partials -> scal[slot]
@@ -118,14 +119,14 @@ __global__ void k_tr_after_solve(DevProblem P, TrConsts tc, int fresh) {
   double* t = P.tr;
   t[TR_RETRY] = 0.0; t[TR_VALID] = 0.0; t[TR_ACC] = 0.0; t[TR_FNCONV] = 0.0; t[TR_MODEL] = 0.0; t[TR_SN] = 0.0;
   if (fresh) {
-    if (t[TR_FIRST] != 0.0) { t[TR_COST] = P.scal[SC_COST]; t[TR_INITCOST] = P.scal[SC_COST]; t[TR_FIRST] = 0.0; }
-    const bool ok = P.flag[0] == 0;
+    if (t[TR_FIRST] != 0.0) { t[TR_COST] = P.scal_r[SC_COST]; t[TR_INITCOST] = P.scal_r[SC_COST]; t[TR_FIRST] = 0.0; }
+    const bool ok = P.flag_r[0] == 0;
     t[TR_OK] = ok ? 1.0 : 0.0;
     if (!ok && tc.strategy == COVGPU_DOGLEG && t[TR_MU] * 10.0 < 1.0) { t[TR_MU] *= 10.0; t[TR_RETRY] = 1.0; return; }  // ComputeGaussNewtonStep: raise mu, solve again
     if (!ok && tc.strategy == COVGPU_DOGLEG) t[TR_MU] *= 10.0;
-    if (P.scal[SC_GMAX] <= tc.gradient_tolerance) { t[TR_TERM] = 3.0; return; }
-    t[TR_GG] = P.scal[SC_GG]; t[TR_GN2] = P.scal[SC_GN2]; t[TR_GDOT] = P.scal[SC_GDOT];
-    if (tc.strategy == COVGPU_DOGLEG) t[TR_ALPHA] = P.scal[SC_GG] / P.scal[SC_JV2];
+    if (P.scal_r[SC_GMAX] <= tc.gradient_tolerance) { t[TR_TERM] = 3.0; return; }
+    t[TR_GG] = P.scal_r[SC_GG]; t[TR_GN2] = P.scal_r[SC_GN2]; t[TR_GDOT] = P.scal_r[SC_GDOT];
+    if (tc.strategy == COVGPU_DOGLEG) t[TR_ALPHA] = P.scal_r[SC_GG] / P.scal_r[SC_JV2];
   }
   double cg = 0.0, cn = 1.0;
   if (tc.strategy == COVGPU_DOGLEG) {
@@ -149,11 +150,11 @@ __global__ void k_tr_after_model(DevProblem P, TrConsts tc) {
   double* t = P.tr;
   if (t[TR_RETRY] != 0.0 || t[TR_TERM] != 0.0) return;
   const bool ok = t[TR_OK] != 0.0;
-  const double model = ok ? -(P.scal[SC_GS] + 0.5 * P.scal[SC_JV2]) : 0.0, sn = ok ? sqrt(P.scal[SC_SN2]) : 0.0;
+  const double model = ok ? -(P.scal_r[SC_GS] + 0.5 * P.scal_r[SC_JV2]) : 0.0, sn = ok ? sqrt(P.scal_r[SC_SN2]) : 0.0;
   t[TR_MODEL] = model; t[TR_SN] = sn;
   const bool valid = ok && model > 0.0;
   t[TR_VALID] = valid ? 1.0 : 0.0;
-  if (valid && sn <= tc.parameter_tolerance * (sqrt(P.scal[SC_XN2]) + tc.parameter_tolerance)) t[TR_TERM] = 2.0;
+  if (valid && sn <= tc.parameter_tolerance * (sqrt(P.scal_r[SC_XN2]) + tc.parameter_tolerance)) t[TR_TERM] = 2.0;
 }
 
 // rho test + updates; k_tr_accept (launched right behind) copies the candidate into the state when the step was accepted
@@ -171,7 +172,7 @@ __global__ void k_tr_decide(DevProblem P, TrConsts tc) {
           t[TR_REUSE] = 0.0;
           if (t[TR_MU] >= 1.0 && t[TR_OK] == 0.0) t[TR_TERM] = 4.0;
         } else {
-          const double cost = t[TR_COST], cost_new = P.scal[SC_COST];
+          const double cost = t[TR_COST], cost_new = P.scal_r[SC_COST];
           const double rho = (cost - cost_new) / t[TR_MODEL];
           t[TR_RHO] = rho; t[TR_COSTNEW] = cost_new;
           acc = rho > tc.min_relative_decrease;
@@ -268,12 +269,6 @@ void launch_zero_system(const DevProblem& P, hipStream_t st) {
   for (int i = m; i < 16; ++i) { z.p[i] = nullptr; z.n[i] = 0; }
   hipLaunchKernelGGL(k_zero_many, dim3(128, m), dim3(256), 0, st, z);
   hipMemsetAsync(P.flag, 0, sizeof(int), st);
-}
-// the pose-pose system (arrow buffers or the dense matrix): the big fill, issued AFTER the inertial kernels so that the serial
-// speed-bias chain factorisation (auxiliary stream) starts that much earlier
-void launch_zero_pose_system(const DevProblem& P, hipStream_t st) {
-  if (P.arrow) launch_arrow_zero(P, st);
-  else hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), st);
 }
 void launch_part_clear(const DevProblem& P, int slot0, int nslots, hipStream_t st) {
   hipMemsetAsync(P.part + (size_t)slot0 * P.part_n, 0, (size_t)nslots * P.part_n * sizeof(double), st);

@@ -16,36 +16,57 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "dev_math.hpp"
 #include "nd_plan.hpp"
 
 namespace covgpu {
 
 // ------------------------------------------------------------------------------------------------ host tables
-void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, NdDev& dev) {
+// rank: this context's rank in an agent-sharded solve (hp.node_rank non-empty); fronts exist for the rank's own subtrees and for
+// the TOP nodes (replicated). Batches = levels: subtree nodes by height, then the top nodes by their height inside the top.
+void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& dev) {
   dev = NdDev();
   const int nn = hp.nnodes, K = hp.K;
-  // nodes renumbered in level order: a level's slice of nd_ntab is its batch table
-  std::vector<int> order, newid(nn);
-  for (int l = 0; l < hp.nlev; ++l) for (int n : hp.lev_nodes[l]) order.push_back(n);
-  for (int i = 0; i < nn; ++i) newid[order[i]] = i;
-  dev.h_vnode.assign(2 * (size_t)K, 0); dev.h_voff.assign(2 * (size_t)K, 0); dev.h_vord.assign(2 * (size_t)K, 0);
+  const bool sh = !hp.node_rank.empty();
+  auto is_top = [&](int n) { return sh && hp.node_rank[n] < 0; };
+  auto is_local = [&](int n) { return !sh || hp.node_rank[n] < 0 || hp.node_rank[n] == rank; };
+  int Hs = 0;
+  for (int n = 0; n < nn; ++n) if (!is_top(n)) Hs = std::max(Hs, hp.level[n] + 1);
+  std::vector<int> lev(nn), toph(nn, 0);
+  for (int n = nn - 1; n >= 0; --n) if (is_top(n)) for (int c : hp.child[n]) if (is_top(c)) toph[n] = std::max(toph[n], toph[c] + 1);
+  int nlev = Hs;
+  for (int n = 0; n < nn; ++n) { lev[n] = is_top(n) ? Hs + toph[n] : hp.level[n]; nlev = std::max(nlev, lev[n] + 1); }
+  std::vector<std::vector<int>> lnodes(nlev);
+  for (int n = 0; n < nn; ++n) if (is_local(n)) lnodes[lev[n]].push_back(n);
+  // local nodes renumbered in level order: a level's slice of nd_ntab is its batch table; foreign nodes have no id
+  std::vector<int> order, newid(nn, -1);
+  for (int l = 0; l < nlev; ++l) for (int n : lnodes[l]) { newid[n] = (int)order.size(); order.push_back(n); }
+  const int nl = (int)order.size();
+  dev.nnodes = nl; dev.top_lev0 = Hs;
+  dev.h_vnode.assign(2 * (size_t)K, -1); dev.h_voff.assign(2 * (size_t)K, 0); dev.h_vord.assign(2 * (size_t)K, 0); dev.h_vown.assign(2 * (size_t)K, 0);
   for (int v = 0; v < 2 * K; ++v)
-    if (hp.vnode[v] >= 0) { dev.h_vnode[v] = newid[hp.vnode[v]]; dev.h_voff[v] = hp.voff[v]; dev.h_vord[v] = hp.vord[v]; }
-  dev.h_lev_node.resize(nn);
-  dev.h_ndepth.resize(nn); dev.h_nI.resize(nn); dev.h_ntab.resize(2 * (size_t)nn);
-  dev.h_own_dims.resize(nn); dev.h_st_dims.resize(nn); dev.h_own_g.resize(nn); dev.h_st_g.resize(nn);
-  dev.lev.resize(hp.nlev);
-  size_t moff = 0, roff = 0, loff = 0;
+    if (hp.vnode[v] >= 0) {
+      const int n = hp.vnode[v];
+      dev.h_vnode[v] = newid[n]; dev.h_voff[v] = hp.voff[v]; dev.h_vord[v] = hp.vord[v];
+      dev.h_vown[v] = !is_local(n) ? 0 : (is_top(n) ? 2 : 1);
+    }
+  dev.h_ndepth.resize(nl); dev.h_nI.resize(nl); dev.h_ntab.resize(2 * (size_t)nl);
+  dev.h_own_dims.resize(nl); dev.h_st_dims.resize(nl); dev.h_own_g.resize(nl); dev.h_st_g.resize(nl);
+  dev.lev.resize(nlev);
   auto gidx_of = [&](int v, int r) { return D * pos_kf[v >> 1] + ((v & 1) ? 6 + r : r); };
-  std::vector<int> ld(nn);
-  for (int l = 0, i = 0; l < hp.nlev; ++l) {
+  std::vector<int> ld(nl);
+  size_t moff = 0, loff = 0;
+  for (int l = 0, i = 0; l < nlev; ++l) {
     NdLevel& L = dev.lev[l];
-    L.n = (int)hp.lev_nodes[l].size(); L.nI = hp.lev_nI[l]; L.first = i; L.ntot = hp.lev_nI[l];
-    for (int n : hp.lev_nodes[l]) {
+    L.n = (int)lnodes[l].size(); L.first = i; L.nI = 256; L.own_max = 0;
+    for (int n : lnodes[l]) L.own_max = std::max(L.own_max, hp.own_dims[n]);
+    L.nI = std::max(256, ((L.own_max + 255) / 256) * 256);
+    L.ntot = L.nI;
+    if (l == Hs) dev.M_sub = moff;
+    for (int n : lnodes[l]) {
       const int nO = ((hp.st_dims[n] + kTile - 1) / kTile) * kTile;
       ld[i] = L.nI + nO;
       L.ntot = std::max(L.ntot, ld[i]);
-      dev.h_lev_node[i] = i;
       dev.h_ndepth[i] = hp.depth[n]; dev.h_nI[i] = L.nI;
       dev.h_ntab[2 * (size_t)i] = (long long)moff; dev.h_ntab[2 * (size_t)i + 1] = ld[i];
       moff += (size_t)ld[i] * ld[i];
@@ -56,17 +77,31 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, NdDev& dev) {
       for (int v : hp.strct[n]) for (int r = 0; r < NdHostPlan::vdim(v); ++r) dev.h_gidx.push_back(gidx_of(v, r));
       L.live_h.push_back((hp.own_dims[n] + kTile - 1) / kTile);
       L.live_h.push_back(nO / kTile);
+      if (is_top(n))
+        for (int v : hp.own[n]) for (int r = 0; r < NdHostPlan::vdim(v); ++r) { dev.h_top_var.push_back(v); dev.h_top_r.push_back(r); dev.h_top_g.push_back(gidx_of(v, r)); }
       ++i;
     }
-    L.rhs_off = roff;
-    for (int k = 0; k < L.n; ++k) dev.h_rhs_node.push_back((int)(roff + (size_t)k * 2 * L.ntot));
-    roff += (size_t)L.n * 2 * L.ntot;
     L.linv_off = loff; loff += (size_t)L.n * L.nI * kTile;
   }
-  dev.M_elems = moff; dev.rhs_elems = roff; dev.linv_elems = loff;
+  if (Hs >= nlev) dev.M_sub = moff;
+  dev.M_elems = moff; dev.linv_elems = loff;
+  // right-hand sides: [top levels | grad, hdiag of the top unknowns | subtree levels] — with the top fronts right in front of them
+  // (solver.hip puts both in ONE allocation) the whole all-reduced region is contiguous
+  dev.h_rhs_node.assign(nl, 0);
+  size_t roff = 0;
+  auto place = [&](int l) {
+    NdLevel& L = dev.lev[l];
+    L.rhs_off = roff;
+    for (int k = 0; k < L.n; ++k) dev.h_rhs_node[L.first + k] = (int)(roff + (size_t)k * 2 * L.ntot);
+    roff += (size_t)L.n * 2 * L.ntot;
+  };
+  for (int l = Hs; l < nlev; ++l) place(l);
+  dev.rhs_top = roff; dev.gh_off = roff; roff += 2 * dev.h_top_g.size();
+  for (int l = 0; l < Hs; ++l) place(l);
+  dev.rhs_elems = roff;
   // front row of every ancestor variable a node's subtree couples to: nd_fidx[nd_abase[node][depth of the ancestor] + ordinal]
-  dev.h_abase.assign((size_t)nn * hp.maxdepth, -1);
-  for (int i = 0; i < nn; ++i) {
+  dev.h_abase.assign((size_t)nl * hp.maxdepth, -1);
+  for (int i = 0; i < nl; ++i) {
     const int n = order[i];
     for (int a = hp.parent[n]; a >= 0; a = hp.parent[a]) {
       dev.h_abase[(size_t)i * hp.maxdepth + hp.depth[a]] = (int)dev.h_fidx.size();
@@ -79,15 +114,19 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, NdDev& dev) {
       row += NdHostPlan::vdim(v);
     }
   }
-  // children + the map (parent front row -> child front row) the extend-add gathers through
-  dev.h_cptr.assign(nn + 1, 0); dev.h_inv_off.assign(nn, -1);
-  for (int i = 0; i < nn; ++i) {
+  // children (subtree children | top children, see NdDev) + the map (parent front row -> child front row) the extend-add gathers through
+  dev.h_cptr.assign(nl + 1, 0); dev.h_cptr2.assign(nl + 1, 0); dev.h_inv_off.assign(nl, -1);
+  for (int i = 0; i < nl; ++i) {
     const int n = order[i];
-    dev.h_cptr[i + 1] = dev.h_cptr[i] + (int)hp.child[n].size();
-    for (int c : hp.child[n]) dev.h_cidx.push_back(newid[c]);
+    dev.h_cptr[i + 1] = dev.h_cptr[i]; dev.h_cptr2[i + 1] = dev.h_cptr2[i];
+    for (int c : hp.child[n]) {
+      if (!is_local(c)) continue;   // another rank's subtree: its contribution arrives through the all-reduce of the top fronts
+      if (is_top(c)) { dev.h_cidx2.push_back(newid[c]); ++dev.h_cptr2[i + 1]; }
+      else { dev.h_cidx.push_back(newid[c]); ++dev.h_cptr[i + 1]; }
+    }
     const int p = hp.parent[n];
     if (p < 0) continue;
-    const int ip = newid[p];
+    const int ip = newid[p];   // (a local node's parent is local: own subtree or top)
     dev.h_inv_off[i] = (int)dev.h_inv.size();
     dev.h_inv.resize(dev.h_inv.size() + ld[ip], -1);
     int* inv = dev.h_inv.data() + dev.h_inv_off[i];
@@ -99,17 +138,16 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, NdDev& dev) {
       row += NdHostPlan::vdim(v);
     }
   }
-  // extend-add work lists: per level the 64x64 tiles of the parents' fronts that receive something from a child
-  for (int l = 0; l < hp.nlev; ++l) {
+  // extend-add work lists: per level the 64x64 tiles of the parents' fronts that receive something from a child of either kind
+  auto worklist = [&](int l, const std::vector<int>& cptr, const std::vector<int>& cidx, int& first, int& count) {
     NdLevel& L = dev.lev[l];
-    L.ext_first = (int)dev.h_ext.size() / 3;
+    first = (int)dev.h_ext.size() / 3;
     for (int k = 0; k < L.n; ++k) {
-      const int i = L.first + k, n = order[i];
+      const int i = L.first + k;
       const int T = (ld[i] + 63) / 64;
       std::vector<char> mark((size_t)T * T, 0);
-      for (int c : hp.child[n]) {
-        const int ic = newid[c];
-        const int* inv = dev.h_inv.data() + dev.h_inv_off[ic];
+      for (int q = cptr[i]; q < cptr[i + 1]; ++q) {
+        const int* inv = dev.h_inv.data() + dev.h_inv_off[cidx[q]];
         std::vector<int> rows;
         for (int t = 0; t < T; ++t) {
           bool any = false;
@@ -120,9 +158,11 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, NdDev& dev) {
       }
       for (int a = 0; a < T; ++a) for (int b = 0; b <= a; ++b) if (mark[(size_t)a * T + b]) { dev.h_ext.push_back(i); dev.h_ext.push_back(a); dev.h_ext.push_back(b); }
     }
-    L.ext_count = (int)dev.h_ext.size() / 3 - L.ext_first;
-    L.own_max = 0;
-    for (int n : hp.lev_nodes[l]) L.own_max = std::max(L.own_max, hp.own_dims[n]);
+    count = (int)dev.h_ext.size() / 3 - first;
+  };
+  for (int l = 0; l < nlev; ++l) {
+    worklist(l, dev.h_cptr, dev.h_cidx, dev.lev[l].ext_first, dev.lev[l].ext_count);
+    worklist(l, dev.h_cptr2, dev.h_cidx2, dev.lev[l].ext2_first, dev.lev[l].ext2_count);
   }
   dev.active = true;
 }
@@ -131,7 +171,7 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, NdDev& dev) {
 struct NdLevArgs {
   int first, n, nI, ntot;
   double* rhs;  // the level's right-hand sides: [n][2 ntot]
-  const int *own_dims, *st_dims, *own_g, *st_g, *gidx, *cptr, *cidx, *inv_off, *inv;
+  const int *own_dims, *st_dims, *own_g, *st_g, *gidx, *inv_off, *inv;
 };
 
 // clear the tiles the factorisation will touch and put the identity on the interior padding rows. One workgroup per 128x128
@@ -186,13 +226,14 @@ __global__ __launch_bounds__(256) void k_nd_assemble(DevProblem P, const int* __
     const int kf = t / P.D, r = t - kf * P.D, pos = P.perm[kf];
     const int v = r < 6 ? 2 * pos : 2 * pos + 1, rr = r < 6 ? r : r - 6;
     const int node = P.nd_vnode[v];
-    P.nd_rhs[rhs_off[node] + P.nd_voff[v] + rr] = P.bred[t];
+    if (node >= 0) P.nd_rhs[rhs_off[node] + P.nd_voff[v] + rr] = P.bred[t];  // (node < 0: an unknown of another rank's subtree)
   }
 }
 
 // parent front += children's Schur complements, parent right-hand side += children's reduced right-hand sides, in child order.
 // One workgroup per 64x64 tile of a host-built list (only tiles some child contributes to); a thread owns a 4x4 sub-grid.
-__global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, const int* __restrict__ rhs_off, const int* __restrict__ work) {
+__global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, const int* __restrict__ rhs_off, const int* __restrict__ work,
+                                                    const int* __restrict__ cptr, const int* __restrict__ cidx, int second_pass) {
   const int node = work[3 * blockIdx.x], tr = work[3 * blockIdx.x + 1], tc = work[3 * blockIdx.x + 2];
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   const size_t ld = (size_t)P.nd_ntab[2 * node + 1];
@@ -205,7 +246,8 @@ __global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, co
   // belongs to an ancestor's front) — those are read up front, beside the index loads, the rest starts from zero
   double v[4][4], rv[4] = {0.0, 0.0, 0.0, 0.0};
   bool hit[4][4];
-  const bool own_cols = 64 * tc < a.nI;
+  // (second_pass: the top fronts of a sharded solve take their top children after the all-reduce — everything is read then)
+  const bool own_cols = second_pass != 0 || 64 * tc < a.nI;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -213,8 +255,8 @@ __global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, co
       v[i][j] = (own_cols && rr[i] < nrow && cc[j] <= rr[i]) ? F[(size_t)rr[i] * ld + cc[j]] : 0.0;
       hit[i][j] = false;
     }
-  for (int k = a.cptr[node]; k < a.cptr[node + 1]; ++k) {
-    const int ch = a.cidx[k];
+  for (int k = cptr[node]; k < cptr[node + 1]; ++k) {
+    const int ch = cidx[k];
     const int* inv = a.inv + a.inv_off[ch];
     const size_t ldc = (size_t)P.nd_ntab[2 * ch + 1];
     const double* C = P.nd_M + P.nd_ntab[2 * ch];
@@ -247,10 +289,31 @@ __global__ __launch_bounds__(256) void k_nd_linv_init(double* __restrict__ Linv,
   if (q < n) { const int e = (int)(q & 255); Linv[q] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0; }
 }
 
+// sharded solve: [grad | hdiag] of the top unknowns <-> the tail of the all-reduced range (dir 0: pack, 1: unpack)
+__global__ __launch_bounds__(256) void k_nd_gh(DevProblem P, const int* __restrict__ top_g, int ntop, double* __restrict__ buf, int dir) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntop) return;
+  const int q = top_g[i];
+  if (dir == 0) { buf[i] = P.grad[q]; buf[ntop + i] = P.hdiag[q]; }
+  else { P.grad[q] = buf[i]; P.hdiag[q] = buf[ntop + i]; }
+}
+// sharded solve: trust-region damping of the top unknowns, applied to the all-reduced top fronts with the all-reduced
+// diag(J^T J) (k_finalize_diag leaves them out: every rank holds only its part of their rows before the exchange)
+__global__ __launch_bounds__(256) void k_nd_top_damp(DevProblem P, const int* __restrict__ top_var, const int* __restrict__ top_r,
+                                                      const int* __restrict__ top_g, int ntop, const int* __restrict__ rhs_off, double mu) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntop) return;
+  const int v = top_var[i], r = top_r[i];
+  const double h = P.hdiag[top_g[i]];
+  double* d = nd_entry(P, v, v, r, r);
+  if (h == 0.0) { *d = 1.0; P.nd_rhs[rhs_off[P.nd_vnode[v]] + P.nd_voff[v] + r] = 0.0; }
+  else { const double c = covdev::clamp_diag(h); *d += mu * c * c; }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 static NdLevArgs lev_args(const DevProblem& P, const NdDev& nd, int l) {
   const NdLevel& L = nd.lev[l];
-  return NdLevArgs{L.first, L.n, L.nI, L.ntot, P.nd_rhs + L.rhs_off, nd.own_dims, nd.st_dims, nd.own_g, nd.st_g, nd.gidx, nd.cptr, nd.cidx, nd.inv_off, nd.inv};
+  return NdLevArgs{L.first, L.n, L.nI, L.ntot, P.nd_rhs + L.rhs_off, nd.own_dims, nd.st_dims, nd.own_g, nd.st_g, nd.gidx, nd.inv_off, nd.inv};
 }
 
 void launch_nd_init(const DevProblem& P, const NdDev& nd, hipStream_t st) {
@@ -260,13 +323,14 @@ void launch_nd_init(const DevProblem& P, const NdDev& nd, hipStream_t st) {
 void launch_nd_zero(const DevProblem& P, const NdDev& nd, hipStream_t st) {
   for (size_t l = 0; l < nd.lev.size(); ++l) {
     const NdLevel& L = nd.lev[l];
+    if (L.n == 0) continue;
     const int T = L.ntot / kTile;
     hipLaunchKernelGGL(k_nd_zero, dim3(T, T, L.n), dim3(256), 0, st, P, lev_args(P, nd, (int)l));
   }
 }
 
-void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, hipStream_t st, CholAux& ax) {
-  const int nlev = (int)nd.lev.size();
+void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hipStream_t st, CholAux& ax) {
+  const int nlev = (int)nd.lev.size(), ltop = nd.top_lev0;
   ax.mark(st, -1);
   hipMemsetAsync(P.nd_rhs, 0, nd.rhs_elems * sizeof(double), st);
   {
@@ -282,18 +346,41 @@ void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, hipStream_t st
     bt.tab = P.nd_ntab + 2 * (size_t)L.first; bt.tri_slot = l; bt.own_max = L.own_max;
     return bt;
   };
-  for (int l = 0; l < nlev; ++l) {
+  auto extend = [&](int l, bool top_children) {
     const NdLevel& L = nd.lev[l];
-    if (L.ext_count > 0)
-      hipLaunchKernelGGL(k_nd_extend, dim3(L.ext_count), dim3(256), 0, st, P, lev_args(P, nd, l), (const int*)nd.rhs_node, (const int*)(nd.ext + 3 * (size_t)L.ext_first));
+    const int first = top_children ? L.ext2_first : L.ext_first, count = top_children ? L.ext2_count : L.ext_count;
+    if (count > 0)
+      hipLaunchKernelGGL(k_nd_extend, dim3(count), dim3(256), 0, st, P, lev_args(P, nd, l), (const int*)nd.rhs_node, (const int*)(nd.ext + 3 * (size_t)first),
+                         (const int*)(top_children ? nd.cptr2 : nd.cptr), (const int*)(top_children ? nd.cidx2 : nd.cidx), top_children ? 1 : 0);
+  };
+  auto factor = [&](int l) {
+    const NdLevel& L = nd.lev[l];
     ax.mark(st, -3);
-    dense_cholesky_solve_raw(P.nd_M, P.nd_rhs + L.rhs_off, P.nd_Linv + L.linv_off, P.flag, L.ntot, st, ax, L.nI / kTile, false, batch(l));
+    if (L.n > 0) dense_cholesky_solve_raw(P.nd_M, P.nd_rhs + L.rhs_off, P.nd_Linv + L.linv_off, P.flag, L.ntot, st, ax, L.nI / kTile, false, batch(l));
     ax.mark(st, -4);
+  };
+  // ---- the subtrees of this rank (single GPU: the whole tree), level by level
+  for (int l = 0; l < ltop; ++l) { extend(l, false); factor(l); }
+  if (ltop < nlev) {
+    // ---- agent-sharded solve: the top fronts so far hold THIS rank's residuals and subtrees only. One
+    //      all-reduce over [top fronts | their right-hand sides | grad, hdiag of the top unknowns] (contiguous), then the
+    //      damping of the top unknowns; from here on every rank runs the top of the tree redundantly, with no further exchange.
+    for (int l = ltop; l < nlev; ++l) extend(l, false);
+    double* gh = P.nd_rhs + nd.gh_off;
+    if (nd.ntop > 0) hipLaunchKernelGGL(k_nd_gh, dim3((nd.ntop + 255) / 256), dim3(256), 0, st, P, (const int*)nd.top_g, nd.ntop, gh, 0);
+    if (ax.reduce != nullptr) ax.reduce(ax.reduce_ctx, P.nd_M + nd.M_sub, (nd.M_elems - nd.M_sub) + nd.rhs_top + 2 * (size_t)nd.ntop, 0, st);
+    if (nd.ntop > 0) {
+      hipLaunchKernelGGL(k_nd_gh, dim3((nd.ntop + 255) / 256), dim3(256), 0, st, P, (const int*)nd.top_g, nd.ntop, gh, 1);
+      hipLaunchKernelGGL(k_nd_top_damp, dim3((nd.ntop + 255) / 256), dim3(256), 0, st, P, (const int*)nd.top_var, (const int*)nd.top_r, (const int*)nd.top_g, nd.ntop,
+                         (const int*)nd.rhs_node, mu);
+    }
+    for (int l = ltop; l < nlev; ++l) { extend(l, true); factor(l); }
   }
   for (int l = nlev - 1; l >= 0; --l) {
     // top-down: the ancestors' unknowns are read from `dst` by the first launch of the level, the fronts' own unknowns are
     // written there by its last (BwdXfer)
     const NdLevel& L = nd.lev[l];
+    if (L.n == 0) continue;
     DenseBatch bt = batch(l);
     bt.xfer.gidx = nd.gidx; bt.xfer.own_g = nd.own_g; bt.xfer.st_g = nd.st_g; bt.xfer.own_dims = nd.own_dims; bt.xfer.st_dims = nd.st_dims;
     bt.xfer.x = dst; bt.xfer.first = L.first;

@@ -219,4 +219,28 @@ void launch_pgo_block_solve(const DevProblem& P, PgoPlan& plan, hipStream_t st, 
   hipLaunchKernelGGL(k_pgo_scatter, dim3((nIpad + 255) / 256, nblk), dim3(256), 0, st, plan.rhs, plan.idx, ntot, nIpad, P.bp);
 }
 
+// right-hand side of the pose-graph system into bp (padded), solution back into the IR layout
+__global__ __launch_bounds__(256) void k_pg_gather_rhs(DevProblem P) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= P.npad) return;
+  double v = 0.0;
+  if (q < 6 * P.K) { const int pos = q / 6, r = q - 6 * pos; v = P.bred[(size_t)P.D * P.pos_kf[pos] + r]; }
+  P.bp[q] = v;
+}
+__global__ __launch_bounds__(256) void k_pg_scatter_solution(DevProblem P, double* __restrict__ dst) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= P.n) return;
+  const int kf = q / P.D, r = q - kf * P.D;
+  dst[q] = P.bp[6 * P.perm[kf] + r];
+}
+
+// PoseGraphOptimization's linear solve (ceres::Solve at optimization_be.cpp:1024-1031: no landmarks, so SPARSE_SCHUR
+// degenerates to a sparse Cholesky on the poses): block-arrow elimination when a plan exists, else the plain dense Cholesky
+void launch_pose_graph_solve(const DevProblem& P, double* dst, hipStream_t st, CholAux& ax, PgoPlan* pgo) {
+  hipLaunchKernelGGL(k_pg_gather_rhs, dim3((P.npad + 255) / 256), dim3(256), 0, st, P);
+  if (pgo != nullptr) launch_pgo_block_solve(P, *pgo, st, ax);
+  else dense_cholesky_solve_raw(P.Sred, P.bp, P.Linv, P.flag, P.npad, st, ax);
+  hipLaunchKernelGGL(k_pg_scatter_solution, dim3((P.n + 255) / 256), dim3(256), 0, st, P, dst);
+}
+
 }  // namespace covgpu

@@ -185,4 +185,52 @@ bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs
   return true;
 }
 
+void nd_shard_assign(NdHostPlan& hp, int world) {
+  const int nn = hp.nnodes;
+  hp.node_rank.assign(nn, -1);
+  hp.nsub = 0;
+  std::vector<double> w(nn, 0.0), sub(nn, 0.0);
+  for (int n = 0; n < nn; ++n) { const double m = hp.own_dims[n], b = hp.st_dims[n]; w[n] = m * m * m / 3.0 + m * m * b + m * b * b + 1.0; }
+  for (int n = nn - 1; n >= 0; --n) { sub[n] += w[n]; if (hp.parent[n] >= 0) sub[hp.parent[n]] += sub[n]; }  // children have higher indices
+  std::vector<char> top(nn, 0);
+  std::vector<int> cand;
+  for (int n = 0; n < nn; ++n) if (hp.parent[n] < 0) { top[n] = 1; for (int c : hp.child[n]) cand.push_back(c); }
+  for (int it = 0; it < 256; ++it) {
+    if (cand.empty()) break;
+    std::sort(cand.begin(), cand.end(), [&](int a, int b) { return sub[a] != sub[b] ? sub[a] > sub[b] : a < b; });
+    double tot = 0.0;
+    for (int c : cand) tot += sub[c];
+    if ((int)cand.size() >= 2 * world && sub[cand[0]] <= 0.6 * tot / world) break;
+    int pick = -1;
+    for (size_t q = 0; q < cand.size() && pick < 0; ++q) if (!hp.child[cand[q]].empty()) pick = (int)q;  // heaviest that can still be opened
+    if (pick < 0) break;
+    const int c = cand[pick];
+    cand.erase(cand.begin() + pick);
+    top[c] = 1;
+    for (int d : hp.child[c]) cand.push_back(d);
+  }
+  std::sort(cand.begin(), cand.end(), [&](int a, int b) { return sub[a] != sub[b] ? sub[a] > sub[b] : a < b; });
+  std::vector<double> load(world, 0.0);
+  std::vector<int> owner(nn, -1);
+  for (int c : cand) {
+    int best = 0;
+    for (int r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
+    owner[c] = best; load[best] += sub[c];
+  }
+  hp.nsub = (int)cand.size();
+  for (int n = 0; n < nn; ++n) {  // parents come first: a node below a dealt subtree root inherits its rank
+    if (top[n]) { hp.node_rank[n] = -1; continue; }
+    hp.node_rank[n] = owner[n] >= 0 ? owner[n] : hp.node_rank[hp.parent[n]];
+  }
+}
+
+void nd_plan_remap(NdHostPlan& hp, const std::vector<int>& var_map) {
+  std::vector<int> vnode(hp.vnode.size(), -1), voff(hp.voff.size(), 0), vord(hp.vord.size(), -1);
+  for (size_t v = 0; v < hp.vnode.size(); ++v)
+    if (hp.vnode[v] >= 0) { const int u = var_map[v]; vnode[u] = hp.vnode[v]; voff[u] = hp.voff[v]; vord[u] = hp.vord[v]; }
+  hp.vnode.swap(vnode); hp.voff.swap(voff); hp.vord.swap(vord);
+  for (auto& l : hp.own) for (int& v : l) v = var_map[v];
+  for (auto& l : hp.strct) for (int& v : l) v = var_map[v];
+}
+
 }  // namespace covgpu

@@ -24,6 +24,10 @@ struct NdHostPlan {
   std::vector<int> vnode, voff, vord;                // per variable: node | scalar offset inside the node's own columns | ordinal inside the node (-1: absent)
   std::vector<std::vector<int>> lev_nodes;           // per level: its nodes, batch order
   std::vector<int> lev_nI, lev_nO, lev_ntot;         // per level: padded interior order (multiple of 256) | padded border order (multiple of 128) | sum
+  // agent-sharded solve of one map over several GPUs (nd_shard_assign): per node the owning rank, -1 = TOP node (replicated:
+  // every rank holds its front, the ranks' contributions are all-reduced once per linear solve). Empty: single GPU.
+  std::vector<int> node_rank;
+  int nsub = 0;                                      // subtrees hanging below the top nodes (the units dealt to the ranks)
   double flops = 0;                                  // partial factorisations, dense count on the real (unpadded) sizes
   size_t front_elems = 0;                            // sum over levels of batch x ntot^2
   static int vdim(int v) { return (v & 1) ? 9 : 6; }
@@ -33,5 +37,12 @@ struct NdHostPlan {
 // leaf_dims: a region of at most this many scalar unknowns is not cut further. Returns false on an inconsistent input.
 bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
                    const int* epair_i, const int* epair_j, int leaf_dims, NdHostPlan& out);
+
+// Multi-GPU split of the tree: the top of the tree is replicated, the subtrees below it are dealt to the
+// ranks by longest-processing-time-first on their factorisation flops. Top = the roots, grown downwards (heaviest subtree
+// first) until there are at least 2 x world subtrees and none outweighs a rank's fair share. Deterministic.
+void nd_shard_assign(NdHostPlan& hp, int world);
+// variable ids -> var_map[old id] (chain positions of one problem -> IR keyframes -> chain positions of a rank's sub-problem)
+void nd_plan_remap(NdHostPlan& hp, const std::vector<int>& var_map);
 
 }  // namespace covgpu

@@ -6,8 +6,13 @@
 // complement, the reduced system and every vector of the step live in HBM for the whole solve.
 // Loop structure and constants follow SURVEY.md A.6 (Ceres 1.x TrustRegionMinimizer + DoglegStrategy /
 // LevenbergMarquardtStrategy defaults).
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -53,48 +58,182 @@ struct covgpu_context {
   CholAux chol;
   PgoPlan pgo_plan;  // block-arrow pose-graph solve (k_pgo.hip)
   NdDev nd;          // multifrontal GBA solve (k_front.hip)
-  // agent-sharded solve: global plan + this rank's identity + the caller's all-reduce
+  // agent-sharded solve: the global plan (variables as 2 * IR keyframe + kind, node -> rank), this rank's
+  // identity and its collective
   bool sharded = false;
-  int rank = 0, world = 1, stage_on_host = 0;
-  std::vector<int32_t> shard_block_of_kf, shard_block_rank;
-  covgpu_allreduce_fn allreduce = nullptr;
-  void* allreduce_user = nullptr;
-  double* h_stage = nullptr; size_t h_stage_n = 0;  // pinned staging buffer (stage_on_host)
-  double* d_bvec = nullptr;                          // [12 nbk] border [grad | hdiag] exchange buffer
-  double* d_scal_tmp = nullptr;                      // [SC_COUNT] scratch the scalar all-reduce works on (read_scalars)
+  int rank = 0, world = 1;
+  std::shared_ptr<NdHostPlan> shard_plan;
+  struct Reducer* reducer = nullptr;
+  double* d_red = nullptr;     // [SC_COUNT + 2 world] scratch of the scalar all-reduce
+  double cur_damp = 0.0;       // damping of the system being built (the top unknowns get theirs after the all-reduce)
 };
 
-// sum (op 0) / max (op 1) of `n` device doubles over all ranks, in place; the stream is drained first so the data is final
-static void ctx_reduce(void* vc, double* dev, size_t n, int op) {
-  covgpu_context* c = (covgpu_context*)vc;
-  if (!c->allreduce || n == 0) return;
-  (void)hipStreamSynchronize(c->st);
-  if (c->stage_on_host) {
-    if (c->h_stage_n < n) { if (c->h_stage) (void)hipHostFree(c->h_stage); (void)hipHostMalloc((void**)&c->h_stage, n * sizeof(double), hipHostMallocDefault); c->h_stage_n = n; }
-    (void)hipMemcpy(c->h_stage, dev, n * sizeof(double), hipMemcpyDeviceToHost);
-    c->allreduce(c->allreduce_user, c->h_stage, (int64_t)n, op, 0);
-    (void)hipMemcpy(dev, c->h_stage, n * sizeof(double), hipMemcpyHostToDevice);
-  } else {
-    c->allreduce(c->allreduce_user, dev, (int64_t)n, op, 1);
+// ---------------------------------------------------------------------------------------------------- collectives
+// sum (op 0) / max (op 1) of n device doubles over all ranks, in place, ENQUEUED on the stream (no host synchronisation in
+// the RCCL form). Two native forms: RCCL (one process per GPU, or several devices in one process) and an in-process group
+// of host threads whose contexts share one device (virtual ranks: how the sharded path runs on a one-GPU test box).
+struct Reducer {
+  int rank = 0, world = 1;
+  size_t calls = 0, bytes = 0;
+  virtual ~Reducer() {}
+  virtual int allreduce(double* dev, size_t n, int op, hipStream_t st) = 0;
+};
+
+struct GroupPtrs { double* p[16]; };
+__global__ __launch_bounds__(256) void k_group_reduce(GroupPtrs g, int world, size_t n, int op, double* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    double v = g.p[0][i];
+    for (int r = 1; r < world; ++r) v = op == 0 ? v + g.p[r][i] : fmax(v, g.p[r][i]);  // rank order: identical on every rank
+    out[i] = v;
   }
 }
-
-extern "C" int covgpu_set_shard(covgpu_context* c, int32_t rank, int32_t world, int32_t num_kf, const int32_t* block_of_kf, int32_t num_blocks,
-                                const int32_t* block_rank, covgpu_allreduce_fn fn, void* user, int32_t stage_on_host) {
-  if (world < 1 || fn == nullptr) {  // back to the single-GPU form (world == 1 WITH a callback is allowed: the collectives become identities, which exercises the whole sharded path on one GPU)
-    c->sharded = false; c->rank = 0; c->world = 1; c->allreduce = nullptr; c->chol.reduce = nullptr;
-    return COVGPU_OK;
+struct covgpu_group {
+  int world = 1;
+  std::mutex m; std::condition_variable cv; int count = 0; long gen = 0; bool broken = false;
+  GroupPtrs ptrs;
+  bool wait() {  // barrier of the group's host threads; false if a member gave up
+    std::unique_lock<std::mutex> lk(m);
+    const long g0 = gen;
+    if (++count == world) { count = 0; ++gen; cv.notify_all(); return !broken; }
+    cv.wait_for(lk, std::chrono::seconds(600), [&] { return gen != g0 || broken; });
+    if (gen == g0) { broken = true; cv.notify_all(); return false; }
+    return !broken;
   }
-  if (rank < 0 || rank >= world || !block_of_kf || !block_rank || num_blocks <= 0) { g_err = "covgpu_set_shard: bad arguments"; return COVGPU_ERR_INVALID_ARG; }
-  for (int k = 0; k < num_kf; ++k) if (block_of_kf[k] < -1 || block_of_kf[k] >= num_blocks) { g_err = "covgpu_set_shard: block_of_kf out of range"; return COVGPU_ERR_INVALID_ARG; }
-  for (int b = 0; b < num_blocks; ++b) if (block_rank[b] < 0 || block_rank[b] >= world) { g_err = "covgpu_set_shard: block_rank out of range"; return COVGPU_ERR_INVALID_ARG; }
-  c->sharded = true; c->rank = rank; c->world = world; c->stage_on_host = stage_on_host;
-  c->shard_block_of_kf.assign(block_of_kf, block_of_kf + num_kf); c->shard_block_rank.assign(block_rank, block_rank + num_blocks);
-  c->allreduce = fn; c->allreduce_user = user;
+};
+struct GroupReducer : Reducer {
+  covgpu_group* g = nullptr;
+  double* scratch = nullptr; size_t scratch_n = 0;
+  ~GroupReducer() override { if (scratch) (void)hipFree(scratch); }
+  int allreduce(double* dev, size_t n, int op, hipStream_t st) override {
+    if (n == 0) return 0;
+    if (scratch_n < n) { if (scratch) (void)hipFree(scratch); if (hipMalloc((void**)&scratch, n * sizeof(double)) != hipSuccess) return 1; scratch_n = n; }
+    (void)hipStreamSynchronize(st);  // this rank's contribution is final
+    { std::lock_guard<std::mutex> lk(g->m); g->ptrs.p[rank] = dev; }
+    if (!g->wait()) return 1;
+    hipLaunchKernelGGL(k_group_reduce, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, g->ptrs, world, n, op, scratch);
+    (void)hipStreamSynchronize(st);
+    if (!g->wait()) return 1;        // everybody has read everybody's buffer
+    (void)hipMemcpyAsync(dev, scratch, n * sizeof(double), hipMemcpyDeviceToDevice, st);
+    ++calls; bytes += n * sizeof(double);
+    return 0;
+  }
+};
+
+// RCCL, loaded at run time: the single-GPU path of libcovgpu has no dependency on it
+struct RcclApi {
+  void* h = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, struct RcclId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+struct RcclId { char internal[128]; };   // ncclUniqueId (rccl.h:40-43)
+static RcclApi* rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { api.h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (api.h) break; }
+    if (!api.h) return;
+    api.GetUniqueId = (int (*)(void*))dlsym(api.h, "ncclGetUniqueId");
+    api.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(api.h, "ncclCommInitRank");
+    api.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(api.h, "ncclAllReduce");
+    api.CommDestroy = (int (*)(void*))dlsym(api.h, "ncclCommDestroy");
+    api.GetErrorString = (const char* (*)(int))dlsym(api.h, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) { dlclose(api.h); api.h = nullptr; }
+  });
+  return api.h ? &api : nullptr;
+}
+struct RcclReducer : Reducer {
+  void* comm = nullptr;
+  ~RcclReducer() override { if (comm && rccl_api()) rccl_api()->CommDestroy(comm); }
+  int allreduce(double* dev, size_t n, int op, hipStream_t st) override {
+    if (n == 0) return 0;
+    ++calls; bytes += n * sizeof(double);
+    return rccl_api()->AllReduce(dev, dev, n, /*ncclFloat64*/ 8, op == 0 ? /*ncclSum*/ 0 : /*ncclMax*/ 2, comm, st);
+  }
+};
+
+static void ctx_reduce(void* vc, double* dev, size_t n, int op, hipStream_t st) {
+  covgpu_context* c = (covgpu_context*)vc;
+  if (c->reducer && n) (void)c->reducer->allreduce(dev, n, op, st);
+}
+static void clear_shard(covgpu_context* c) {
+  delete c->reducer; c->reducer = nullptr;
+  c->sharded = false; c->rank = 0; c->world = 1; c->shard_plan.reset();
+  c->chol.reduce = nullptr; c->chol.reduce_ctx = nullptr;
+}
+extern "C" int covgpu_set_shard_none(covgpu_context* c) { clear_shard(c); return COVGPU_OK; }
+
+extern "C" int covgpu_group_create(int32_t world, covgpu_group** out) {
+  if (world < 1 || world > 16) { g_err = "covgpu_group_create: world must be 1..16"; return COVGPU_ERR_INVALID_ARG; }
+  covgpu_group* g = new covgpu_group(); g->world = world;
+  for (auto& q : g->ptrs.p) q = nullptr;
+  *out = g;
+  return COVGPU_OK;
+}
+extern "C" void covgpu_group_destroy(covgpu_group* g) { delete g; }
+extern "C" void covgpu_group_abort(covgpu_group* g) { std::lock_guard<std::mutex> lk(g->m); g->broken = true; g->cv.notify_all(); }
+
+struct covgpu_nd_plan { NdHostPlan hp; std::vector<int> pos_kf; };
+static int set_shard_common(covgpu_context* c, const covgpu_nd_plan* plan, int rank, int world, Reducer* red) {
+  if (!plan || plan->hp.node_rank.empty()) { delete red; g_err = "covgpu_set_shard: the plan carries no rank assignment (use covgpu_shard_plan)"; return COVGPU_ERR_INVALID_ARG; }
+  if (rank < 0 || rank >= world) { delete red; g_err = "covgpu_set_shard: rank out of range"; return COVGPU_ERR_INVALID_ARG; }
+  for (int r : plan->hp.node_rank) if (r >= world) { delete red; g_err = "covgpu_set_shard: the plan was made for more ranks"; return COVGPU_ERR_INVALID_ARG; }
+  clear_shard(c);
+  // keep the plan in IR terms (variable = 2 * keyframe + kind): a rank's sub-problem orders its keyframes differently
+  auto hp = std::make_shared<NdHostPlan>(plan->hp);
+  std::vector<int> to_ir(2 * (size_t)hp->K);
+  for (int q = 0; q < hp->K; ++q) { to_ir[2 * q] = 2 * plan->pos_kf[q]; to_ir[2 * q + 1] = 2 * plan->pos_kf[q] + 1; }
+  nd_plan_remap(*hp, to_ir);
+  c->shard_plan = hp;
+  red->rank = rank; red->world = world;
+  c->reducer = red; c->sharded = true; c->rank = rank; c->world = world;
   c->chol.reduce = ctx_reduce; c->chol.reduce_ctx = c;
   return COVGPU_OK;
 }
-
+extern "C" int covgpu_set_shard_group(covgpu_context* c, const covgpu_nd_plan* plan, int32_t rank, covgpu_group* g) {
+  if (!g) { g_err = "covgpu_set_shard_group: NULL group"; return COVGPU_ERR_INVALID_ARG; }
+  GroupReducer* r = new GroupReducer(); r->g = g;
+  return set_shard_common(c, plan, rank, g->world, r);
+}
+extern "C" int covgpu_rccl_unique_id(uint8_t* out128) {
+  RcclApi* api = rccl_api();
+  if (!api) { g_err = "librccl could not be loaded"; return COVGPU_ERR_NO_DEVICE; }
+  RcclId id;
+  const int rc = api->GetUniqueId(&id);
+  if (rc != 0) { g_err = std::string("ncclGetUniqueId: ") + (api->GetErrorString ? api->GetErrorString(rc) : "error"); return COVGPU_ERR_NO_DEVICE; }
+  std::memcpy(out128, id.internal, 128);
+  return COVGPU_OK;
+}
+extern "C" int covgpu_set_shard_rccl(covgpu_context* c, const covgpu_nd_plan* plan, int32_t rank, int32_t world, const uint8_t* id128) {
+  RcclApi* api = rccl_api();
+  if (!api) { g_err = "librccl could not be loaded"; return COVGPU_ERR_NO_DEVICE; }
+  HIPCHK(hipSetDevice(c->device));
+  RcclId id; std::memcpy(id.internal, id128, 128);
+  RcclReducer* r = new RcclReducer();
+  const int rc = api->CommInitRank(&r->comm, world, id, rank);
+  if (rc != 0) { delete r; g_err = std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(rc) : "error"); return COVGPU_ERR_NO_DEVICE; }
+  return set_shard_common(c, plan, rank, world, r);
+}
+// host convenience through the context's collective (barriers / timing aggregates of a multi-process run): in place
+extern "C" int covgpu_allreduce_host(covgpu_context* c, double* host, int64_t n, int32_t op) {
+  if (!c->reducer || n <= 0) return COVGPU_OK;
+  HIPCHK(hipSetDevice(c->device));
+  double* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, n * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(d, host, n * sizeof(double), hipMemcpyHostToDevice, c->st));
+  const int rc = c->reducer->allreduce(d, (size_t)n, op, c->st);
+  HIPCHK(hipMemcpyAsync(host, d, n * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  (void)hipFree(d);
+  if (rc != 0) { g_err = "all-reduce failed"; return COVGPU_ERR_NO_DEVICE; }
+  return COVGPU_OK;
+}
+// out[4] = { collectives issued, bytes all-reduced (per rank), rank, world }
+extern "C" void covgpu_shard_stats(covgpu_context* c, int64_t* out) {
+  out[0] = c->reducer ? (int64_t)c->reducer->calls : 0; out[1] = c->reducer ? (int64_t)c->reducer->bytes : 0; out[2] = c->rank; out[3] = c->world;
+}
 
 extern "C" void covgpu_default_options(covgpu_options* o) {
   std::memset(o, 0, sizeof(*o));
@@ -152,7 +291,7 @@ static void free_problem(covgpu_context* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   c->allocs.clear();
   c->alloc_bytes = 0;
-  c->chol.tri_clear(); c->chol.live_h.clear();
+  c->chol.tri_clear();
   c->have = false;
   c->pgo_plan.active = false;  // its device buffers were in `allocs`
   c->nd = NdDev();
@@ -166,7 +305,7 @@ extern "C" void covgpu_destroy(covgpu_context* c) {
   c->chol.destroy();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_tr) (void)hipHostFree(c->h_tr);
-  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  clear_shard(c);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
 }
@@ -188,7 +327,9 @@ extern "C" void covgpu_get_layout(covgpu_context* c, int64_t* out) {
   for (int i = 0; i < 16; ++i) out[i] = 0;
   if (!c->have) return;
   const DevProblem& P = c->P;
-  out[0] = P.arrow; out[1] = P.ar_nblk; out[2] = P.ar_nbk; out[3] = P.arrow ? P.ar_nIpad / 6 : 0; out[4] = P.ar_ntot; out[5] = P.ar_nb;
+  out[0] = c->sharded ? c->world : 0; out[1] = c->sharded ? c->rank : 0; out[2] = c->nd.ntop;   // ranks | rank | scalar unknowns of the replicated top nodes
+  out[3] = (int64_t)c->nd.lev.size() - c->nd.top_lev0;                                          // top levels
+  out[4] = (int64_t)(((c->nd.M_elems - c->nd.M_sub) + c->nd.rhs_top + 2 * (size_t)c->nd.ntop) * sizeof(double)) >> 10;  // KiB all-reduced per linear solve
   out[6] = P.npad; out[7] = P.npairs; out[8] = P.nepairs; out[9] = P.nchains; out[10] = (int64_t)(c->alloc_bytes >> 20);
   if (P.nd) {  // multifrontal form: nodes, levels, serial 256-column panels (sum of the levels' interior orders / 256), root order, front bytes (MiB)
     out[11] = P.nd_nnodes; out[12] = P.nd_nlev;
@@ -309,27 +450,8 @@ static bool host_pairs(const covgpu_problem* p, const std::vector<int>& perm, st
   return true;
 }
 
-// Host-only: the block partition of the GBA pose system (k_arrow.hip). block_of_kf[k] >= 0: block (= agent) whose
-// interior holds keyframe k; -1: border ("shared") keyframe. Returns the number of blocks, 0 if the dense form is kept.
-extern "C" int32_t covgpu_gba_partition(const covgpu_options* opt, const covgpu_problem* p, int32_t force, int32_t* block_of_kf) {
-  const bool vi = !opt->visual_only;
-  for (int k = 0; k < p->num_kf; ++k) block_of_kf[k] = -1;
-  if (validate(p, false, vi) != COVGPU_OK || !vi) return 0;
-  std::vector<int> perm, pos_kf, chain_ptr;
-  if (build_chains(p, vi, perm, pos_kf, chain_ptr) != COVGPU_OK) return 0;
-  std::vector<int> pi, pj, ei, ej;
-  if (!host_pairs(p, perm, pi, pj, ei, ej)) return 0;
-  ArrowHostPlan hp;
-  if (!gba_plan_analyse(p->num_kf, (int)chain_ptr.size() - 1, chain_ptr.data(), (int)pi.size(), pi.data(), pj.data(), (int)ei.size(), ei.data(), ej.data(),
-                        force != 0, pos_kf.data(), hp))
-    return 0;
-  for (int k = 0; k < p->num_kf; ++k) block_of_kf[k] = hp.blk[perm[k]];
-  return hp.nblk;
-}
-
 // Host-only: the nested-dissection plan of the reduced camera system (nd_plan.hpp, k_front.hip) for inspection and the CPU
 // tests (tests/test_nd_plan.py replays the elimination in numpy on the oracle's system).
-struct covgpu_nd_plan { NdHostPlan hp; std::vector<int> pos_kf; };
 static int nd_leaf_dims(int requested) {
   if (requested > 0) return requested;
   const char* e = getenv("COVGPU_ND_LEAF");
@@ -382,55 +504,65 @@ extern "C" void covgpu_nd_plan_arrays(const covgpu_nd_plan* pl, int32_t* parent,
   own_ptr[h.nnodes] = o; st_ptr[h.nnodes] = s;
 }
 
-// Host-only: the multi-GPU split of ONE map. The global block-arrow plan plus the owner of
-// every block, landmark, IMU factor and between factor:
-//   * blocks (agents' interiors) -> ranks by longest-processing-time-first on their observation counts;
-//   * a landmark -> the rank of the one block whose INTERIOR keyframes observe it (no landmark is seen from two
-//     interiors: that is the plan's invariant), else the rank of its first observer's agent;
-//   * an IMU factor -> the rank of its agent (IMU chains are intra-agent, optimization_be.cpp:369);
-//   * a between factor -> the rank of an interior endpoint, else of kf1's agent.
-// With this assignment every contribution a rank computes lands in its own arrow buffers or in the border system — the
-// only part that is all-reduced. Returns the number of blocks (0: map does not split; arrays untouched).
-extern "C" int32_t covgpu_shard_plan(const covgpu_options* opt, const covgpu_problem* p, int32_t world, int32_t* block_of_kf, int32_t* block_rank,
-                                     int32_t* lm_rank, int32_t* imu_rank, int32_t* edge_rank) {
+// Host-only: the multi-GPU split of ONE map = the nested-dissection plan of the FULL problem
+// plus, per tree node, the rank that owns it (nd_shard_assign: top of the tree replicated, subtrees dealt to the ranks), and
+// the owner of every landmark / IMU factor / between factor: the rank of the DEEPEST tree node among the unknowns the
+// residual touches (those unknowns form a clique of the coupling graph, so they lie on one root path: everything a residual
+// contributes lands in fronts of its owner's subtrees or in top fronts — the only part that is all-reduced); residuals that
+// touch top unknowns only are dealt round-robin. Returns the number of subtrees (0: nothing to split).
+extern "C" int32_t covgpu_shard_plan(const covgpu_options* opt, const covgpu_problem* p, int32_t world, covgpu_nd_plan** plan_out, int32_t* lm_rank,
+                                     int32_t* imu_rank, int32_t* edge_rank) {
+  *plan_out = nullptr;
   if (world < 1) return 0;
-  const int32_t nblk = covgpu_gba_partition(opt, p, 1, block_of_kf);
-  if (nblk <= 0) return 0;
-  const int K = p->num_kf;
-  // agent (IMU chain) of every keyframe, and the block of every agent
-  std::vector<int> perm, pos_kf, chain_ptr;
-  if (build_chains(p, true, perm, pos_kf, chain_ptr) != COVGPU_OK) return 0;
-  const int nch = (int)chain_ptr.size() - 1;
-  std::vector<int> chain_of_kf(K), block_of_chain(nch, -1);
-  for (int ch = 0; ch < nch; ++ch)
-    for (int q = chain_ptr[ch]; q < chain_ptr[ch + 1]; ++q) { chain_of_kf[pos_kf[q]] = ch; if (block_of_kf[pos_kf[q]] >= 0) block_of_chain[ch] = block_of_kf[pos_kf[q]]; }
-  // LPT: heaviest block first onto the least loaded rank
-  std::vector<long long> w(nblk, 0), load(world, 0);
-  for (int o = 0; o < p->num_obs; ++o) { const int b = block_of_kf[p->obs_kf[o]]; if (b >= 0) w[b]++; }
-  std::vector<int> order(nblk);
-  for (int b = 0; b < nblk; ++b) order[b] = b;
-  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return w[x] > w[y]; });
-  for (int b : order) {
-    int best = 0;
-    for (int r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
-    block_rank[b] = best; load[best] += w[b];
-  }
-  auto rank_of_chain = [&](int ch) { return block_of_chain[ch] >= 0 ? block_rank[block_of_chain[ch]] : 0; };
+  covgpu_nd_plan* pl = nullptr;
+  if (covgpu_nd_plan_create(opt, p, 0, &pl) != COVGPU_OK) return 0;
+  NdHostPlan& hp = pl->hp;
+  nd_shard_assign(hp, world);
+  if (hp.nsub == 0) { delete pl; return 0; }
+  const bool vi = !opt->visual_only;
+  std::vector<int> perm(p->num_kf);
+  for (int q = 0; q < p->num_kf; ++q) perm[pl->pos_kf[q]] = q;
+  // owner of a set of variables (position-based ids): rank of the deepest node, -1 if they are all top
+  auto owner = [&](std::initializer_list<int> vars) {
+    int best = -1, depth = -1;
+    for (int v : vars) { const int n = hp.vnode[v]; if (n >= 0 && hp.depth[n] > depth) { depth = hp.depth[n]; best = n; } }
+    return best < 0 ? -1 : hp.node_rank[best];
+  };
   for (int l = 0; l < p->num_lm; ++l) {
-    int r = -1;
-    for (int o = p->lm_obs_ptr[l]; o < p->lm_obs_ptr[l + 1] && r < 0; ++o) {
-      const int kf = p->obs_kf[o], b = block_of_kf[kf];
-      if (b >= 0 && !p->kf_fixed[kf]) r = block_rank[b];  // (a constant keyframe has no pose block: it binds nobody)
+    int best = -1, depth = -1;
+    for (int o = p->lm_obs_ptr[l]; o < p->lm_obs_ptr[l + 1]; ++o) {
+      const int kf = p->obs_kf[o];
+      if (p->kf_fixed[kf]) continue;  // (a constant keyframe has no pose unknown: it binds nobody)
+      const int n = hp.vnode[2 * perm[kf]];
+      if (hp.depth[n] > depth) { depth = hp.depth[n]; best = n; }
     }
-    if (r < 0) r = p->lm_obs_ptr[l + 1] > p->lm_obs_ptr[l] ? rank_of_chain(chain_of_kf[p->obs_kf[p->lm_obs_ptr[l]]]) : 0;
-    lm_rank[l] = r;
+    const int r = best < 0 ? -1 : hp.node_rank[best];
+    lm_rank[l] = r >= 0 ? r : l % world;
   }
-  for (int f = 0; f < p->num_imu; ++f) imu_rank[f] = rank_of_chain(chain_of_kf[p->imu_kf_j[f]]);
+  for (int f = 0; f < p->num_imu; ++f) {
+    const int a = perm[p->imu_kf_i[f]], b = perm[p->imu_kf_j[f]];
+    const int r = vi ? owner({2 * a, 2 * a + 1, 2 * b, 2 * b + 1}) : -1;
+    imu_rank[f] = r >= 0 ? r : f % world;
+  }
   for (int e = 0; e < p->num_edge; ++e) {
-    const int bi = p->kf_fixed[p->edge_i[e]] ? -1 : block_of_kf[p->edge_i[e]], bj = p->kf_fixed[p->edge_j[e]] ? -1 : block_of_kf[p->edge_j[e]];
-    edge_rank[e] = bi >= 0 ? block_rank[bi] : (bj >= 0 ? block_rank[bj] : rank_of_chain(chain_of_kf[p->edge_i[e]]));
+    const int r = owner({2 * perm[p->edge_i[e]], 2 * perm[p->edge_j[e]]});
+    edge_rank[e] = r >= 0 ? r : e % world;
   }
-  return nblk;
+  *plan_out = pl;
+  return hp.nsub;
+}
+extern "C" void covgpu_nd_plan_ranks(const covgpu_nd_plan* pl, int32_t* node_rank) {  // per tree node: owning rank, -1 = top (replicated); all 0 without an assignment
+  for (int n = 0; n < pl->hp.nnodes; ++n) node_rank[n] = pl->hp.node_rank.empty() ? 0 : pl->hp.node_rank[n];
+}
+// after a sharded solve: which rank's download holds keyframe k's pose / speed-bias (-1: a top unknown — identical on every rank)
+extern "C" void covgpu_nd_plan_owner(const covgpu_nd_plan* pl, int32_t* pose_rank, int32_t* sb_rank) {
+  const NdHostPlan& hp = pl->hp;
+  for (int q = 0; q < hp.K; ++q) {
+    const int kf = pl->pos_kf[q];
+    const int np = hp.vnode[2 * q], ns = hp.vnode[2 * q + 1];
+    pose_rank[kf] = (np >= 0 && !hp.node_rank.empty()) ? hp.node_rank[np] : -1;
+    sb_rank[kf] = (ns >= 0 && !hp.node_rank.empty()) ? hp.node_rank[ns] : -1;
+  }
 }
 
 static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, bool pgo, bool allow_arrow = true) {
@@ -457,12 +589,12 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   for (int c = 0; c < P.nchains; ++c)
     for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) chain_end[q] = chain_ptr[c + 1];
   P.reproj_loss_a = opt->reproj_loss_a; P.gravity = opt->gravity;
-  // ---- form of the reduced camera system. Default: multifrontal fronts over a nested-dissection tree (k_front.hip).
-  //      COVGPU_GBA_DENSE=1: the same code with ONE front = the dense system (equality tests). The round-2 forms (IMU-chain
-  //      elimination + block-arrow / dense pose system) remain for the agent-sharded solve, the pose graph and covgpu_schur.
+  // ---- form of the reduced camera system: multifrontal fronts over a nested-dissection tree (k_front.hip) for every GBA.
+  //      COVGPU_GBA_DENSE=1: the same code with ONE front = the dense system (equality tests). The dense row-major matrix
+  //      Sred remains for the pose graph (k_pgo.hip builds its own block plan on it) and for covgpu_schur (reads it back).
   const char* e_dense = getenv("COVGPU_GBA_DENSE");
-  const char* e_legacy = getenv("COVGPU_GBA_LEGACY");
-  const bool use_nd = !pgo && !c->sharded && allow_arrow && dense_panel_chain() && !(e_legacy && e_legacy[0] == '1');
+  const bool use_nd = !pgo && allow_arrow;
+  if (c->sharded && !use_nd) { g_err = "the agent-sharded solve is for GBA problems (covgpu_upload)"; return COVGPU_ERR_INVALID_ARG; }
   const size_t K = P.K;
   RC(dev_upload(c, &P.pose0, p->kf_pose, 7 * K));
   if (p->kf_speed_bias) RC(dev_upload(c, &P.sb0, p->kf_speed_bias, 9 * K)); else { RC(dev_alloc(c, &P.sb0, 9 * K)); HIPCHK(hipMemsetAsync(P.sb0, 0, 9 * K * sizeof(double), c->st)); }
@@ -608,41 +740,24 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_upload(c, &P.pos_chain_end, chain_end.data(), K));
   RC(dev_alloc(c, &P.bred, (size_t)P.n));
   RC(dev_alloc(c, &P.bp, (size_t)2 * P.npad));
-  const size_t Kv = vi ? K : 0, Kc = (vi && !use_nd) ? K : 0;  // Kc: buffers of the IMU-chain elimination (k_struct.hip) only
+  const size_t Kv = vi ? K : 0;
   RC(dev_alloc(c, &P.Ad, 81 * Kv)); RC(dev_alloc(c, &P.Ae, 81 * Kv));
   RC(dev_alloc(c, &P.Bp, 54 * Kv)); RC(dev_alloc(c, &P.Bs, 54 * Kv)); RC(dev_alloc(c, &P.Bn, 54 * Kv));
-  RC(dev_alloc(c, &P.Ldinv, 81 * Kc)); RC(dev_alloc(c, &P.Lsub, 81 * Kc));
-  RC(dev_alloc(c, &P.Mblk, 81 * Kc)); RC(dev_alloc(c, &P.GI, 81 * Kc));
-  RC(dev_alloc(c, &P.Nback, 90 * Kc)); RC(dev_alloc(c, &P.Zfwd, 90 * Kc));
-  RC(dev_alloc(c, &P.zs, 9 * Kc)); RC(dev_alloc(c, &P.xs, 9 * Kc));
-  {  // Y per chain (common.hpp): [9 Kc][roundup(6 Kc, 16)] blocks back to back
-    std::vector<size_t> yoff(P.nchains);
-    std::vector<int> yld(P.nchains), cbeg(P.K), cidx(P.K);
-    size_t ytot = 0;
-    for (int ch = 0; ch < P.nchains; ++ch) {
-      const int kc = chain_ptr[ch + 1] - chain_ptr[ch];
-      yld[ch] = ((6 * kc + 15) / 16) * 16; yoff[ch] = ytot;
-      ytot += (size_t)9 * kc * yld[ch];
-      for (int q = chain_ptr[ch]; q < chain_ptr[ch + 1]; ++q) { cbeg[q] = chain_ptr[ch]; cidx[q] = ch; }
-    }
-    RC(dev_upload(c, &P.Yoff, yoff.data(), yoff.size())); RC(dev_upload(c, &P.Yld, yld.data(), yld.size()));
-    RC(dev_upload(c, &P.pos_chain_begin, cbeg.data(), cbeg.size())); RC(dev_upload(c, &P.pos_chain, cidx.data(), cidx.size()));
-    std::vector<int> wch, wbl;
-    for (int ch = 0; ch < P.nchains; ++ch) {
-      const int nb = (6 * (chain_ptr[ch + 1] - chain_ptr[ch]) + 63) / 64;
-      for (int b = 0; b < nb; ++b) { wch.push_back(ch); wbl.push_back(b); }
-    }
-    P.cc_n = (int)wch.size();
-    RC(dev_upload(c, &P.cc_chain, wch.data(), wch.size())); RC(dev_upload(c, &P.cc_blk, wbl.data(), wbl.size()));
-    RC(dev_alloc(c, &P.Y, Kc ? ytot : 0));
-    if (Kc) HIPCHK(hipMemsetAsync(P.Y, 0, ytot * sizeof(double), c->st));  // only the chain trapezoids are ever written
+  {
+    std::vector<int> cbeg(P.K);
+    for (int ch = 0; ch < P.nchains; ++ch) for (int q = chain_ptr[ch]; q < chain_ptr[ch + 1]; ++q) cbeg[q] = chain_ptr[ch];
+    RC(dev_upload(c, &P.pos_chain_begin, cbeg.data(), cbeg.size()));
     HIPCHK(hipStreamSynchronize(c->st));
   }
   RC(dev_alloc(c, &P.grad, (size_t)P.N)); RC(dev_alloc(c, &P.hdiag, (size_t)P.N));
   RC(dev_alloc(c, &P.HllInv, (size_t)6 * P.L));
   RC(dev_alloc(c, &P.gn, (size_t)P.N)); RC(dev_alloc(c, &P.step, (size_t)P.N)); RC(dev_alloc(c, &P.vtmp, (size_t)P.N));
+  // (sharded solve: the entries of other ranks' unknowns are never written — they must read as 0, not as what hipMalloc left)
+  HIPCHK(hipMemsetAsync(P.gn, 0, (size_t)P.N * sizeof(double), c->st)); HIPCHK(hipMemsetAsync(P.step, 0, (size_t)P.N * sizeof(double), c->st));
+  HIPCHK(hipMemsetAsync(P.vtmp, 0, (size_t)P.N * sizeof(double), c->st));
   RC(dev_alloc(c, &P.scal, (size_t)SC_COUNT)); RC(dev_alloc(c, &P.flag, (size_t)4));
   RC(dev_alloc(c, &P.tr, (size_t)TR_COUNT));
+  P.scal_r = P.scal; P.flag_r = P.flag;  // what the device-side trust region reads (sharded solve: the all-reduced copies, set below)
   // deterministic reductions / scatters
   P.part_imu = 8192; P.part_edge = P.part_imu + ((P.I + 3) / 4) * 4; P.part_vec = P.part_edge + (P.E + 63) / 64;
   P.part_n = P.part_vec + 8192;
@@ -679,26 +794,31 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
     RC(dev_upload(c, &P.epair_ptr, eptr.data(), eptr.size())); RC(dev_upload(c, &P.epair_i, ei.data(), ei.size()));
     RC(dev_upload(c, &P.epair_j, ej.data(), ej.size())); RC(dev_upload(c, &P.epair_ent, eent.data(), eent.size()));
     HIPCHK(hipStreamSynchronize(c->st));
-    // ---- where does the pose-pose system live? Fused multi-agent maps: block-arrow buffers (k_arrow.hip); else dense.
-    //      COVGPU_GBA_DENSE=1 keeps the dense form, COVGPU_GBA_ARROW=1 forces the arrow form whenever a plan exists (tests).
-    ArrowHostPlan hp;
-    const char* e_arrow = getenv("COVGPU_GBA_ARROW");
-    const bool force = e_arrow && e_arrow[0] == '1';
-    bool have_plan = false;
-    std::vector<char> own_pose(P.K, 1), own_chain(P.K, 1);  // by IR keyframe: does THIS rank count the pose / the speed-bias rows
     if (use_nd) {
       NdHostPlan nhp;
-      const bool one_front = e_dense && e_dense[0] == '1';
-      if (!nd_plan_build(P.K, vi, P.nchains, chain_ptr.data(), (int)h_pair_i.size(), h_pair_i.data(), h_pair_j.data(), P.nepairs, ei.data(), ej.data(),
-                         one_front ? 0x3fffffff : nd_leaf_dims(0), nhp)) {
-        g_err = "nested-dissection plan: a coupling joins two branches"; return COVGPU_ERR_INVALID_ARG;
+      if (c->sharded) {
+        // the global plan (covgpu_shard_plan on the FULL problem, the same on every rank), from IR keyframes to this
+        // sub-problem's chain positions; this rank holds the fronts of its subtrees and of the replicated top nodes
+        if ((int)c->shard_plan->K != P.K || (c->shard_plan->vi != 0) != vi) { g_err = "sharded solve: the problem does not match the shard plan"; return COVGPU_ERR_INVALID_ARG; }
+        nhp = *c->shard_plan;
+        std::vector<int> to_pos(2 * (size_t)P.K);
+        for (int k = 0; k < P.K; ++k) { to_pos[2 * k] = 2 * perm[k]; to_pos[2 * k + 1] = 2 * perm[k] + 1; }
+        nd_plan_remap(nhp, to_pos);
+      } else {
+        const bool one_front = e_dense && e_dense[0] == '1';
+        if (!nd_plan_build(P.K, vi, P.nchains, chain_ptr.data(), (int)h_pair_i.size(), h_pair_i.data(), h_pair_j.data(), P.nepairs, ei.data(), ej.data(),
+                           one_front ? 0x3fffffff : nd_leaf_dims(0), nhp)) {
+          g_err = "nested-dissection plan: a coupling joins two branches"; return COVGPU_ERR_INVALID_ARG;
+        }
       }
       if (nhp.maxdepth > 64) { g_err = "nested-dissection plan: tree deeper than 64 levels"; return COVGPU_ERR_INVALID_ARG; }
       NdDev& nd = c->nd;
-      nd_tables(nhp, pos_kf.data(), P.D, nd);
-      P.nd = 1; P.nd_nnodes = nhp.nnodes; P.nd_nlev = nhp.nlev; P.nd_maxd = nhp.maxdepth;
+      nd_tables(nhp, pos_kf.data(), P.D, c->rank, nd);
+      P.nd = 1; P.nd_nnodes = nd.nnodes; P.nd_nlev = (int)nd.lev.size(); P.nd_maxd = nhp.maxdepth;
+      nd.ntop = (int)nd.h_top_g.size();
       RC(dev_upload(c, &P.nd_vnode, nd.h_vnode.data(), nd.h_vnode.size())); RC(dev_upload(c, &P.nd_voff, nd.h_voff.data(), nd.h_voff.size()));
       RC(dev_upload(c, &P.nd_vord, nd.h_vord.data(), nd.h_vord.size()));
+      if (c->sharded) RC(dev_upload(c, &P.nd_vown, nd.h_vown.data(), nd.h_vown.size()));
       RC(dev_upload(c, &P.nd_ndepth, nd.h_ndepth.data(), nd.h_ndepth.size())); RC(dev_upload(c, &P.nd_nI, nd.h_nI.data(), nd.h_nI.size()));
       RC(dev_upload(c, &P.nd_ntab, nd.h_ntab.data(), nd.h_ntab.size()));
       RC(dev_upload(c, &P.nd_abase, nd.h_abase.data(), nd.h_abase.size())); RC(dev_upload(c, &P.nd_fidx, nd.h_fidx.data(), nd.h_fidx.size()));
@@ -706,82 +826,43 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
       RC(dev_upload(c, &nd.own_g, nd.h_own_g.data(), nd.h_own_g.size())); RC(dev_upload(c, &nd.st_g, nd.h_st_g.data(), nd.h_st_g.size()));
       RC(dev_upload(c, &nd.gidx, nd.h_gidx.data(), nd.h_gidx.size()));
       RC(dev_upload(c, &nd.cptr, nd.h_cptr.data(), nd.h_cptr.size())); RC(dev_upload(c, &nd.cidx, nd.h_cidx.data(), nd.h_cidx.size()));
+      RC(dev_upload(c, &nd.cptr2, nd.h_cptr2.data(), nd.h_cptr2.size())); RC(dev_upload(c, &nd.cidx2, nd.h_cidx2.data(), nd.h_cidx2.size()));
       RC(dev_upload(c, &nd.inv_off, nd.h_inv_off.data(), nd.h_inv_off.size())); RC(dev_upload(c, &nd.inv, nd.h_inv.data(), nd.h_inv.size()));
       RC(dev_upload(c, &nd.rhs_node, nd.h_rhs_node.data(), nd.h_rhs_node.size()));
       RC(dev_upload(c, &nd.ext, nd.h_ext.data(), nd.h_ext.size()));
+      RC(dev_upload(c, &nd.top_var, nd.h_top_var.data(), nd.h_top_var.size())); RC(dev_upload(c, &nd.top_r, nd.h_top_r.data(), nd.h_top_r.size()));
+      RC(dev_upload(c, &nd.top_g, nd.h_top_g.data(), nd.h_top_g.size()));
       for (NdLevel& L : nd.lev) RC(dev_upload(c, &L.live, L.live_h.data(), L.live_h.size()));
-      RC(dev_alloc(c, &P.nd_M, nd.M_elems)); RC(dev_alloc(c, &P.nd_rhs, nd.rhs_elems)); RC(dev_alloc(c, &P.nd_Linv, nd.linv_elems));
+      // one allocation: [subtree fronts | top fronts][top right-hand sides | grad, hdiag of the top unknowns | subtree right-hand
+      // sides] — what a sharded solve all-reduces is one contiguous range of it
+      RC(dev_alloc(c, &P.nd_M, nd.M_elems + nd.rhs_elems));
+      P.nd_rhs = P.nd_M + nd.M_elems;
+      RC(dev_alloc(c, &P.nd_Linv, nd.linv_elems));
       RC(dev_alloc(c, &P.nd_dummy, (size_t)64));
       launch_nd_init(P, nd, c->st);
       c->chol.tri_clear();   // the live-tile lists of the bulk updates belong to the previous problem
+      if (c->sharded) {
+        P.shard = 1;
+        // weight of every unknown in the trust-region norms: counted by exactly one rank (own subtree: here; top: rank 0)
+        std::vector<double> vw((size_t)P.N, 1.0);  // landmarks: all mine (the sub-problem holds this rank's landmarks only)
+        for (int k = 0; k < P.K; ++k) {
+          const int op = nd.h_vown[2 * perm[k]], os = nd.h_vown[2 * perm[k] + 1];
+          const double wp = op == 1 ? 1.0 : (op == 2 && c->rank == 0 ? 1.0 : 0.0), ws = os == 1 ? 1.0 : (os == 2 && c->rank == 0 ? 1.0 : 0.0);
+          for (int r = 0; r < 6; ++r) vw[(size_t)P.D * k + r] = wp;
+          for (int r = 6; r < P.D; ++r) vw[(size_t)P.D * k + r] = ws;
+        }
+        RC(dev_upload(c, &P.vw, vw.data(), vw.size()));
+        RC(dev_alloc(c, &c->d_red, (size_t)SC_COUNT + 2 * (size_t)c->world));
+        RC(dev_alloc(c, &P.scal_r, (size_t)SC_COUNT)); RC(dev_alloc(c, &P.flag_r, (size_t)4));
+      }
       HIPCHK(hipStreamSynchronize(c->st));
       if (opt->verbose) {
         int panels = 0;
         for (const NdLevel& L : nd.lev) panels += L.nI / 256;
-        std::printf("[covgpu] multifrontal plan: %d fronts in %d levels (%d serial 256-column panels), root order %d, %.2e flops, fronts %.2f GB\n", nhp.nnodes,
-                    nhp.nlev, panels, nd.lev.back().nI, nhp.flops, nd.M_elems * 8e-9);
+        std::printf("[covgpu] multifrontal plan: %d fronts in %d levels (%d serial 256-column panels), %.2e flops, fronts %.2f GB%s\n", nd.nnodes,
+                    (int)nd.lev.size(), panels, nhp.flops, nd.M_elems * 8e-9, c->sharded ? " (this rank's share)" : "");
       }
-    } else if (c->sharded && !pgo) {
-      // global plan given (covgpu_shard_plan): border and block of every keyframe; this rank owns the blocks of its agents
-      if (!vi || (int)c->shard_block_of_kf.size() != P.K) { g_err = "sharded solve needs the visual-inertial problem the shard plan was made for"; return COVGPU_ERR_INVALID_ARG; }
-      std::vector<char> border(P.K), owned(P.K);
-      for (int q = 0; q < P.K; ++q) {
-        const int b = c->shard_block_of_kf[pos_kf[q]];
-        border[q] = b < 0; owned[q] = b >= 0 && c->shard_block_rank[b] == c->rank;
-      }
-      gba_plan_build(P.K, P.nchains, chain_ptr.data(), (int)h_pair_i.size(), h_pair_i.data(), h_pair_j.data(), P.nepairs, ei.data(), ej.data(),
-                     border.data(), owned.data(), pos_kf.data(), hp);
-      have_plan = true;
-      // a chain (agent) is eliminated by the rank that holds its IMU factors: chains of length > 1 here are mine
-      for (int ch = 0; ch < P.nchains; ++ch) {
-        const bool mine = chain_ptr[ch + 1] - chain_ptr[ch] > 1;
-        for (int q = chain_ptr[ch]; q < chain_ptr[ch + 1]; ++q) own_chain[pos_kf[q]] = mine;
-      }
-      for (int q = 0; q < P.K; ++q) own_pose[pos_kf[q]] = border[q] ? (c->rank == 0) : owned[q];
-    } else if (vi && allow_arrow) {
-      have_plan = gba_plan_analyse(P.K, P.nchains, chain_ptr.data(), (int)h_pair_i.size(), h_pair_i.data(), h_pair_j.data(), P.nepairs, ei.data(), ej.data(),
-                                   force, pos_kf.data(), hp);
-    }
-    if (have_plan) {
-      P.arrow = 1;
-      P.ar_nblk = hp.nblk; P.ar_nbk = hp.nbk;
-      P.ar_nIpad = ((6 * hp.max_int + 2 * kTile - 1) / (2 * kTile)) * (2 * kTile);  // whole big panels (tstop is even)
-      const int nown = std::max(kTile, ((6 * hp.max_own + kTile - 1) / kTile) * kTile);
-      P.ar_ntot = P.ar_nIpad + nown;
-      P.ar_nb = std::max(kTile, ((6 * hp.nbk + kTile - 1) / kTile) * kTile);
-      std::vector<int> own((size_t)hp.nblk * std::max(hp.nbk, 1), -1);
-      for (int a = 0; a < hp.nblk; ++a)
-        for (size_t o = 0; o < hp.own[a].size(); ++o) own[(size_t)a * hp.nbk + hp.own[a][o]] = (int)o;
-      RC(dev_upload(c, &P.ar_blk, hp.blk.data(), hp.blk.size())); RC(dev_upload(c, &P.ar_loc, hp.loc.data(), hp.loc.size()));
-      RC(dev_upload(c, &P.ar_own, own.data(), own.size())); RC(dev_upload(c, &P.ar_nint, hp.nint.data(), hp.nint.size()));
-      RC(dev_upload(c, &P.ar_bpos, hp.bpos.data(), hp.bpos.size()));
-      std::vector<int> live(2 * (size_t)hp.nblk);
-      for (int a = 0; a < hp.nblk; ++a) { live[2 * a] = (6 * hp.nint[a] + kTile - 1) / kTile; live[2 * a + 1] = (6 * (int)hp.own[a].size() + kTile - 1) / kTile; }
-      RC(dev_upload(c, &P.ar_live, live.data(), live.size()));
-      c->chol.live_h = live;
-      c->chol.tri_clear();   // the live-tile lists of the bulk updates belong to the previous problem
-      RC(dev_alloc(c, &P.ar_M, (size_t)P.ar_nblk * P.ar_ntot * P.ar_ntot)); RC(dev_alloc(c, &P.ar_rhs, (size_t)P.ar_nblk * 2 * P.ar_ntot));
-      RC(dev_alloc(c, &P.ar_Linv, (size_t)P.ar_nblk * P.ar_nIpad * kTile));
-      RC(dev_alloc(c, &P.ar_Sb, (size_t)P.ar_nb * P.ar_nb + 2 * (size_t)P.ar_nb));  // [C_b | b_b | y_b]: one contiguous all-reduce
-      P.ar_rhsb = P.ar_Sb + (size_t)P.ar_nb * P.ar_nb;
-      RC(dev_alloc(c, &P.ar_Linvb, (size_t)P.ar_nb * kTile));
-      RC(dev_alloc(c, &P.ar_dummy, (size_t)64));
-      if (c->sharded) {
-        P.shard = 1;
-        std::vector<double> vw((size_t)P.N, 1.0);  // landmarks: all mine (the sub-problem holds this rank's landmarks only)
-        for (int k = 0; k < P.K; ++k) {
-          for (int r = 0; r < 6; ++r) vw[(size_t)P.D * k + r] = own_pose[k] ? 1.0 : 0.0;
-          for (int r = 6; r < P.D; ++r) vw[(size_t)P.D * k + r] = own_chain[k] ? 1.0 : 0.0;
-        }
-        RC(dev_upload(c, &P.vw, vw.data(), vw.size()));
-        RC(dev_alloc(c, &c->d_bvec, (size_t)12 * std::max(hp.nbk, 1)));
-        RC(dev_alloc(c, &c->d_scal_tmp, (size_t)SC_COUNT));
-      }
-      HIPCHK(hipStreamSynchronize(c->st));
-      if (opt->verbose)
-        std::printf("[covgpu] arrow plan: %d blocks (largest interior %d keyframes, own border <= %d), border %d keyframes; buffers %.2f GB\n",
-                    hp.nblk, hp.max_int, hp.max_own, hp.nbk, ((double)P.ar_nblk * P.ar_ntot * P.ar_ntot + (double)P.ar_nb * P.ar_nb) * 8e-9);
-    } else if (!P.nd) {
+    } else {
       RC(dev_alloc(c, &P.Sred, (size_t)P.npad * P.npad));
       RC(dev_alloc(c, &P.Linv, (size_t)(P.npad / kTile) * kTile * kTile));
     }
@@ -833,24 +914,6 @@ static int reset_state(covgpu_context* c) {
 }
 
 static int read_scalars(covgpu_context* c) {
-  if (c->sharded && c->have && c->P.shard && c->allreduce) {
-    // every scalar of the trust-region loop is a sum over residuals / unknowns each counted by exactly one rank
-    // (DevProblem::vw), except the gradient max-norm and the Cholesky failure flag (max): reduced ON THE DEVICE buffers
-    // (two small collectives per read-back), so that all ranks then take the same accept / reject decisions
-    // The sums are taken on a SCRATCH copy: slots that were not recomputed since the previous read-back already hold global
-    // sums, and reducing P.scal in place would multiply them by the world size on every call.
-    launch_shard_scal(c->P, c->d_bvec, 0, c->st);
-    HIPCHK(hipMemcpyAsync(c->d_scal_tmp, c->P.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToDevice, c->st));
-    ctx_reduce(c, c->d_scal_tmp, SC_COUNT, 0);
-    ctx_reduce(c, c->d_bvec, 2, 1);
-    launch_shard_scal(c->P, c->d_bvec, 1, c->st);   // gradient max-norm and failure flag back into P.scal / P.flag
-    HIPCHK(hipMemcpyAsync(c->h_scal, c->d_scal_tmp, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipMemcpyAsync(c->h_scal + SC_GMAX, c->P.scal + SC_GMAX, sizeof(double), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipMemcpyAsync(c->h_scal + SC_COUNT, c->P.flag, sizeof(int), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipGetLastError());
-    return COVGPU_OK;
-  }
   HIPCHK(hipMemcpyAsync(c->h_scal, c->P.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipMemcpyAsync(c->h_scal + SC_COUNT, c->P.flag, sizeof(int), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
@@ -862,6 +925,7 @@ static int chol_failed(covgpu_context* c) { int f; std::memcpy(&f, c->h_scal + S
 // linearise at the current state and form the damped reduced system (A.6): cost, grad, hdiag, Sred, bred
 static void enqueue_build(covgpu_context* c, double mu) {
   const DevProblem& P = c->P;
+  c->cur_damp = mu;
   if (c->profiling) (void)hipEventRecord(c->ev[0], c->st);
   // the big fill of the pose system (0.6 GB of arrow buffers on the 5-agent map) runs on its own stream beside the inertial
   // kernels and the landmark linearisation, which only write per-factor / per-observation records; its first writers
@@ -870,7 +934,7 @@ static void enqueue_build(covgpu_context* c, double mu) {
   (void)hipEventRecord(c->chol.ev_fill, c->st);
   (void)hipStreamWaitEvent(c->chol.head, c->chol.ev_fill, 0);
   if (P.nd) launch_nd_zero(P, c->nd, c->chol.head);
-  else launch_zero_pose_system(P, c->chol.head);
+  else (void)hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), c->chol.head);
   (void)hipEventRecord(c->chol.ev_fill, c->chol.head);
   launch_zero_system(P, c->st);
   // inertial factors first: the speed-bias blocks are then final, and the (serial, one wave per IMU chain) chain
@@ -879,19 +943,11 @@ static void enqueue_build(covgpu_context* c, double mu) {
   if (P.vi) {
     launch_imu_gather(P, 1, c->st);
     launch_finalize_diag(P, mu, 1, c->st);
-    if (!P.nd) launch_sb_chain_factor_early(P, c->st, c->chol);  // (multifrontal form: the speed-bias blocks are front columns like any other)
   }
   launch_lm_build(P, mu, c->st, c->chol.ev_fill);
   launch_imu_gather(P, 0, c->st);  // pose-dimension part: adds onto the blocks k_kf_reduce assigned (fixed order: visual, inertial, loop)
   launch_edge_build(P, c->st);
   launch_edge_gather(P, c->st);
-  if (P.shard) {
-    // shared poses: gradient and diag(J^T J) rows of the border keyframes are sums over all ranks' residuals — needed
-    // before the damping (finalize_diag) and by every norm of the trust-region step
-    launch_border_vec(P, c->d_bvec, 0, c->st);
-    ctx_reduce(c, c->d_bvec, (size_t)12 * P.ar_nbk, 0);
-    launch_border_vec(P, c->d_bvec, 1, c->st);
-  }
   launch_finalize_diag(P, mu, P.vi ? 0 : 2, c->st);
   launch_part_finish(P, SC_COST, 1, c->st);
   if (c->profiling) (void)hipEventRecord(c->ev[1], c->st);
@@ -902,7 +958,8 @@ static void enqueue_solve(covgpu_context* c, double* dst_all) {
   // with profiling on, every bulk trailing-update (SYRK) launch gets its own event pair on its stream so that
   // bench.py can quote the dominant kernel's duration
   if (c->profiling) (void)hipEventRecord(c->ev[2], c->st);
-  launch_structured_solve(P, dst_all, c->st, c->chol, c->pgo_plan.active ? &c->pgo_plan : nullptr, c->nd.active ? &c->nd : nullptr);
+  if (P.nd) launch_nd_solve(P, c->nd, dst_all, c->cur_damp, c->st, c->chol);              // GBA: multifrontal solve of the whole system (k_front.hip)
+  else launch_pose_graph_solve(P, dst_all, c->st, c->chol, c->pgo_plan.active ? &c->pgo_plan : nullptr);  // pose graph (k_pgo.hip)
   if (c->profiling) (void)hipEventRecord(c->ev[3], c->st);
   launch_lm_backsub(P, dst_all, dst_all, c->st);
 }
@@ -934,127 +991,35 @@ static void enqueue_cost_candidate(covgpu_context* c) {
   launch_part_finish(P, SC_COST, 1, c->st);
 }
 
-static int solve_impl(covgpu_context* c, const covgpu_options* opt, covgpu_result* res) {
-  if (!c->have) { g_err = "no problem uploaded"; return COVGPU_ERR_INVALID_ARG; }
-  HIPCHK(hipSetDevice(c->device));
-  DevProblem& P = c->P;
-  const covgpu_options& o = *opt;
-  P.reproj_loss_a = o.reproj_loss_a;  // (IMU noise / gravity: per factor, bound at upload — covgpu.h)
-  std::memset(res, 0, sizeof(*res));
-  const auto t_begin = std::chrono::steady_clock::now();
-  RC(reset_state(c));
-  HIPCHK(hipMemsetAsync(P.flag + 1, 0, sizeof(int), c->st));
-  launch_preintegrate(P, c->st);  // R2: repropagate at the initial bias estimate (opt_be.cpp:396)
-
-  double radius = o.initial_radius, mu = 1e-8, lm_df = 2.0;
-  bool reuse = false, need_build = true;
-  double cost = 0, alpha = 0, GG = 0, GN2 = 0, GDOT = 0, dogleg_step_norm = 0;
-  int it = 0, accepted = 0, term = 0;
-  bool first = true;
-  double t_lin = 0;
-  double* h = c->h_scal;
-  for (; it < o.max_iterations; ++it) {
-    bool ok = true;
-    if (!reuse) {
-      // ---- linearise (if the state changed or the damping must change) + Gauss-Newton / LM solve
-      for (;;) {
-        const double damp = (o.strategy == COVGPU_LM) ? 1.0 / radius : mu;
-        enqueue_build(c, damp);
-        if (o.strategy == COVGPU_DOGLEG) { launch_cauchy_vec(P, c->st); enqueue_jvp(c, P.vtmp); }
-        const auto t0 = std::chrono::steady_clock::now();
-        enqueue_solve(c, P.gn);
-        launch_dogleg_stats(P, c->st);
-        RC(read_scalars(c));
-        t_lin += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        collect_profile(c, true, true);
-        need_build = false;
-        if (first) { cost = h[SC_COST]; res->initial_cost = cost; first = false; }
-        ok = !chol_failed(c);
-        if (ok || o.strategy == COVGPU_LM) break;
-        mu *= 10.0;  // DoglegStrategy::ComputeGaussNewtonStep: raise mu until the factorisation succeeds
-        if (!(mu < 1.0)) break;
-      }
-      if (h[SC_GMAX] <= o.gradient_tolerance) { term = 3; break; }
-      GG = h[SC_GG]; GN2 = h[SC_GN2]; GDOT = h[SC_GDOT];
-      if (o.strategy == COVGPU_DOGLEG) alpha = GG / h[SC_JV2];
-    }
-    double model = 0, sn = 0;
-    if (ok) {
-      double cg = 0, cn = 1;
-      if (o.strategy == COVGPU_DOGLEG) {
-        const double gn_norm = std::sqrt(GN2), g_norm = std::sqrt(GG);
-        if (gn_norm <= radius) { cg = 0; cn = 1; dogleg_step_norm = gn_norm; }
-        else if (g_norm * alpha >= radius) { cg = -radius / g_norm; cn = 0; dogleg_step_norm = radius; }
-        else {
-          const double b_dot_a = -alpha * GDOT, a_sq = alpha * alpha * GG;
-          const double bma = GN2 - 2 * b_dot_a + a_sq, cc = b_dot_a - a_sq;
-          const double dd = std::sqrt(cc * cc + bma * (radius * radius - a_sq));
-          const double beta = (cc <= 0) ? (dd - cc) / bma : (radius * radius - a_sq) / (dd + cc);
-          cg = -alpha * (1 - beta); cn = beta; dogleg_step_norm = radius;
-        }
-      }
-      launch_combine_step(P, cg, cn, c->st);
-      enqueue_jvp(c, P.step);
-      launch_xnorm(P, c->st);
-      RC(read_scalars(c));
-      model = -(h[SC_GS] + 0.5 * h[SC_JV2]);
-      sn = std::sqrt(h[SC_SN2]);
-    }
-    if (!ok || !(model > 0.0)) {  // invalid step
-      if (o.strategy == COVGPU_LM) { radius /= lm_df; lm_df *= 2; } else { mu *= 10.0; }
-      reuse = false;
-      if (it < COVGPU_MAX_TRACE) { res->cost_trace[it] = cost; res->radius_trace[it] = radius; res->accepted_trace[it] = 0; }
-      if (mu >= 1.0 && !ok) { term = 4; ++it; break; }
-      continue;
-    }
-    if (sn <= o.parameter_tolerance * (std::sqrt(h[SC_XN2]) + o.parameter_tolerance)) { term = 2; break; }
-    launch_apply_step(P, c->st);
-    enqueue_cost_candidate(c);
-    RC(read_scalars(c));
-    const double cost_new = h[SC_COST];
-    const double rho = (cost - cost_new) / model;
-    const bool acc = rho > o.min_relative_decrease;
-    bool fn_conv = false;
-    if (acc) {
-      ++accepted;
-      fn_conv = std::fabs(cost - cost_new) <= o.function_tolerance * cost;
-      launch_accept(P, c->st);
-      cost = cost_new;
-      if (o.strategy == COVGPU_LM) {
-        const double t = 2 * rho - 1;
-        radius = std::min(o.max_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
-        lm_df = 2.0;
-      } else {
-        if (rho < 0.25) radius *= 0.5;
-        if (rho > 0.75) radius = std::max(radius, 3.0 * dogleg_step_norm);
-        mu = std::max(1e-8, 2.0 * mu / 10.0);
-      }
-      reuse = false; need_build = true;
-    } else {
-      if (o.strategy == COVGPU_LM) { radius /= lm_df; lm_df *= 2; reuse = false; }
-      else { radius *= 0.5; reuse = true; }
-    }
-    if (it < COVGPU_MAX_TRACE) { res->cost_trace[it] = cost; res->radius_trace[it] = radius; res->accepted_trace[it] = acc; }
-    if (o.verbose) std::printf("[covgpu] it %2d cost %.9e rho %.3f radius %.3e %s\n", it, cost, rho, radius, acc ? "ok" : "rej");
-    if (fn_conv) { term = 1; ++it; break; }
+// sharded solve: the scalars the device-side trust region is about to read are sums over residuals / unknowns each counted
+// by exactly one rank (DevProblem::vw), the gradient max-norm and the factorisation flag are maxima: ONE small all-reduce
+// (sum) of [16 scalars | one slot per rank for the max-norm | one slot per rank for the flag] on a scratch copy, enqueued
+// on the stream; the reduced values go to P.scal_r / P.flag_r, the rank's own partial sums in P.scal stay untouched.
+__global__ void k_shard_scal_pack(DevProblem P, double* buf, int rank, int world) {
+  const int t = threadIdx.x;
+  if (t < SC_COUNT) buf[t] = (t == SC_GMAX) ? 0.0 : P.scal[t];
+  if (t < world) { buf[SC_COUNT + t] = t == rank ? P.scal[SC_GMAX] : 0.0; buf[SC_COUNT + world + t] = t == rank ? (double)P.flag[0] : 0.0; }
+}
+__global__ void k_shard_scal_unpack(DevProblem P, const double* buf, int world) {
+  const int t = threadIdx.x;
+  if (t < SC_COUNT && t != SC_GMAX) P.scal_r[t] = buf[t];
+  if (t == 0) {
+    double gm = 0.0, fl = 0.0;
+    for (int r = 0; r < world; ++r) { gm = fmax(gm, buf[SC_COUNT + r]); fl = fmax(fl, buf[SC_COUNT + world + r]); }
+    P.scal_r[SC_GMAX] = gm; P.flag_r[0] = fl != 0.0 ? 1 : 0;
   }
-  (void)need_build;
-  HIPCHK(hipStreamSynchronize(c->st));
-  {  // IMU factors whose preintegrated covariance was not positive definite (e.g. zero samples) carry no weight: reported
-    int dropped = 0;
-    HIPCHK(hipMemcpy(&dropped, P.flag + 1, sizeof(int), hipMemcpyDeviceToHost));
-    res->reserved = dropped;
-  }
-  res->iterations = it; res->accepted = accepted; res->termination = term;
-  res->final_cost = cost;
-  res->t_linear_solve_s = t_lin;
-  res->t_solve_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-  return COVGPU_OK;
+}
+static void reduce_scalars(covgpu_context* c) {
+  if (!c->sharded || !c->reducer) return;
+  hipLaunchKernelGGL(k_shard_scal_pack, dim3(1), dim3(64), 0, c->st, c->P, c->d_red, c->rank, c->world);
+  (void)c->reducer->allreduce(c->d_red, (size_t)SC_COUNT + 2 * (size_t)c->world, 0, c->st);
+  hipLaunchKernelGGL(k_shard_scal_unpack, dim3(1), dim3(64), 0, c->st, c->P, (const double*)c->d_red, c->world);
 }
 
 // Trust-region loop with the step logic on the device (k_dense.hip: k_tr_*): ONE host read-back per iteration — what the
-// host needs to enqueue the next one (rebuild or reuse, damping value) and the trace. Same decisions as solve_impl above,
-// which stays for the agent-sharded solve (its scalars pass through the caller's collective between the kernels).
+// host needs to enqueue the next one (rebuild or reuse, damping value) and the trace. Sharded solve: the same loop on every
+// rank; four collectives per iteration (the top of the tree inside the linear solve, three scalar exchanges), all enqueued on
+// the stream.
 static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_result* res) {
   if (!c->have) { g_err = "no problem uploaded"; return COVGPU_ERR_INVALID_ARG; }
   HIPCHK(hipSetDevice(c->device));
@@ -1078,17 +1043,21 @@ static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_r
     if (!reuse) {
       const double damp = (o.strategy == COVGPU_LM) ? 1.0 / h[TR_RADIUS] : h[TR_MU];
       enqueue_build(c, damp);
-      if (o.strategy == COVGPU_DOGLEG) { launch_cauchy_vec(P, c->st); enqueue_jvp(c, P.vtmp); }
       enqueue_solve(c, P.gn);
+      // (Cauchy direction after the solve: a sharded solve completes gradient and diag(J^T J) of the top unknowns inside it)
+      if (o.strategy == COVGPU_DOGLEG) { launch_cauchy_vec(P, c->st); enqueue_jvp(c, P.vtmp); }
       launch_dogleg_stats(P, c->st);
+      reduce_scalars(c);
     }
     launch_tr_after_solve(P, tc, reuse ? 0 : 1, c->st);
     launch_combine_step_dev(P, c->st);
     enqueue_jvp(c, P.step);
     launch_xnorm(P, c->st);
+    reduce_scalars(c);
     launch_tr_after_model(P, tc, c->st);
     launch_apply_step(P, c->st);
     enqueue_cost_candidate(c);
+    reduce_scalars(c);
     launch_tr_decide(P, tc, c->st);
     HIPCHK(hipMemcpyAsync(h, P.tr, TR_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
@@ -1130,10 +1099,7 @@ static int download_impl(covgpu_context* c, covgpu_problem* p) {
 
 extern "C" int covgpu_upload(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return guarded([&] { return upload_impl(c, opt, p, false); }); }
 extern "C" int covgpu_upload_pgo(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return guarded([&] { return upload_impl(c, opt, p, true); }); }
-static int solve_any(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) {
-  static const bool host_tr = [] { const char* e = getenv("COVGPU_HOST_TR"); return e && e[0] == '1'; }();  // dev aid: A/B of the two loops
-  return ((c->sharded && c->have && c->P.shard) || host_tr) ? solve_impl(c, opt, out) : solve_impl_dev(c, opt, out);
-}
+static int solve_any(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) { return solve_impl_dev(c, opt, out); }
 extern "C" int covgpu_solve_resident(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) { return guarded([&] { return solve_any(c, opt, out); }); }
 extern "C" int covgpu_download(covgpu_context* c, covgpu_problem* p) { return guarded([&] { return download_impl(c, p); }); }
 

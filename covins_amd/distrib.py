@@ -1,109 +1,78 @@
-"""Multi-GPU GBA of ONE merged map, sharded by agent (BASELINE.json north star: "the merged
+"""Multi-GPU GBA of ONE merged map, sharded by sub-map (BASELINE.json north star: "the merged
 multi-agent map shards by agent/sub-map across the GPUs of one node with RCCL all-reduce over xGMI on the shared-pose
 Hessian blocks at each LM iteration").
 
-One process per GPU (`torch.distributed`, backend "nccl" = RCCL on ROCm). Every rank
+The unit of the split is a SUBTREE of the multifrontal elimination tree (covins_amd/csrc/nd_plan.hip): an agent, or a
+stretch of an agent's trajectory. The top of the tree — the separators that join the sub-maps, i.e. the shared poses — is
+replicated. Every rank
   1. computes the SAME global plan from the full flat problem (`shard_plan`, host-only C entry point covgpu_shard_plan):
-     agents' interiors = blocks owned by ranks, cross-agent "shared" keyframes = border, owner of every landmark /
-     IMU factor / between factor;
-  2. keeps its share (`shard_problem`: all K keyframes stay, residuals are filtered) and uploads it;
-  3. runs the same trust-region loop; the library calls back into `reducer` for the three collectives of a linear
-     solve (shared-pose gradient rows, the shared-pose system after the local interior eliminations, 16 scalars);
+     tree node -> rank (or top), owner of every landmark / IMU factor / between factor;
+  2. keeps its share (`shard_problem`: all K keyframes stay, residuals are filtered), attaches the native collective
+     (`attach`: RCCL inside libcovgpu — one process per GPU, unique id passed through a torch TCPStore — or an in-process
+     `Group` of host threads for VIRTUAL ranks on one GPU, which is how the sharded path is verified on single-GPU boxes) and
+     uploads it;
+  3. runs the same device-side trust-region loop; per iteration the library enqueues four all-reduces on its own stream
+     (top fronts + right-hand sides + gradient rows once per linear solve, three small scalar exchanges);
   4. `merge_solution` assembles the optimised map from the ranks' pieces.
-The reducers: `TorchReducer` (RCCL on device pointers / gloo on host arrays) for real ranks, `ThreadReducer` for
-VIRTUAL ranks — several contexts on one GPU driven by host threads, which is how the sharded path is verified on the
-single-GPU test boxes.
+No Python code sits on the data path: the collectives are issued by libcovgpu (solver.hip: RcclReducer / GroupReducer).
 """
 from __future__ import annotations
 
 import ctypes as C
 import os
-import threading
 from dataclasses import dataclass
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
 from . import capi
 from .capi import FlatProblem, Options
 
-ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int32, C.c_int32)
-
 
 def env_ranks() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend: str = "nccl", local_rank: int = 0, force: bool = False):
-    """Returns the torch.distributed module (initialised) or None for a single process (force: a one-rank group)."""
-    _, _, world = env_ranks()
-    if world <= 1 and not force:
-        return None
-    if world <= 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-    import torch
-    import torch.distributed as dist
-    if backend == "nccl":
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist.init_process_group(backend=backend)
-    return dist
-
-
-def barrier(dist, device: Optional[str] = None) -> None:
-    import torch
-    if device is not None and device.startswith("cuda"):
-        torch.cuda.synchronize(device)
-    if dist is not None:
-        dist.barrier()
-        if device is not None and device.startswith("cuda"):
-            torch.cuda.synchronize(device)
-
-
-def aggregate(dt: float, iterations: float, dist, device: str = "cpu") -> Tuple[float, float]:
-    """(max over ranks of the wall time, max over ranks of the executed iterations — every rank runs the SAME
-    iterations of the one sharded solve, so this is the job's iteration count, not a sum)."""
-    if dist is None:
-        return float(dt), float(iterations)
-    import torch
-    t = torch.tensor([dt, float(iterations)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t[0].item()), float(t[1].item())
-
-
-def throughput(dt_max: float, iterations: float) -> float:
-    """Whole-job GBA iterations per second."""
-    return iterations / dt_max
-
-
 # ------------------------------------------------------------------------------------------------ plan / shards
-@dataclass
 class ShardPlan:
-    world: int
-    num_blocks: int
-    block_of_kf: np.ndarray   # [K]  block (agent interior) of a keyframe, -1 = shared (border) keyframe
-    block_rank: np.ndarray    # [num_blocks]
-    lm_rank: np.ndarray       # [L]
-    imu_rank: np.ndarray      # [I]
-    edge_rank: np.ndarray     # [E]
+    """Global plan of a sharded solve: owns the native covgpu_nd_plan (tree + node -> rank)."""
 
-    def pose_owner(self) -> np.ndarray:
-        """rank whose result holds keyframe k's pose (shared keyframes: identical on every rank; take rank 0)."""
-        return np.where(self.block_of_kf >= 0, self.block_rank[np.maximum(self.block_of_kf, 0)], 0).astype(np.int32)
+    def __init__(self, handle, world: int, subtrees: int, lm_rank, imu_rank, edge_rank, pose_rank, sb_rank, node_rank):
+        self.handle, self.world, self.subtrees = handle, world, subtrees
+        self.lm_rank, self.imu_rank, self.edge_rank = lm_rank, imu_rank, edge_rank
+        self.pose_rank, self.sb_rank = pose_rank, sb_rank   # [K] rank whose result holds the keyframe's pose / speed-bias, -1 = top (every rank)
+        self.node_rank = node_rank                          # [tree nodes] owning rank, -1 = top (replicated)
+
+    def close(self):
+        if self.handle:
+            from . import backend
+            backend.lib().covgpu_nd_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_plan(prob: FlatProblem, opt: Options, world: int) -> Optional[ShardPlan]:
     """Host-only and deterministic: every rank computes the same plan from the same full problem."""
     from . import backend
-    bk = np.empty(prob.K, np.int32); br = np.zeros(max(prob.K, 1), np.int32)
+    lib = backend.lib()
     lr = np.zeros(max(prob.L, 1), np.int32); ir = np.zeros(max(prob.I, 1), np.int32); er = np.zeros(max(prob.E, 1), np.int32)
     s = prob.as_struct()
-    n = backend.lib().covgpu_shard_plan(C.byref(opt), C.byref(s), int(world), capi.iptr(bk), capi.iptr(br), capi.iptr(lr), capi.iptr(ir), capi.iptr(er))
-    if n <= 0:
+    h = C.c_void_p()
+    n = lib.covgpu_shard_plan(C.byref(opt), C.byref(s), int(world), C.byref(h), capi.iptr(lr), capi.iptr(ir), capi.iptr(er))
+    if n <= 0 or not h:
         return None
-    return ShardPlan(world, int(n), bk, br[:n].copy(), lr[:prob.L].copy(), ir[:prob.I].copy(), er[:prob.E].copy())
+    pr = np.zeros(prob.K, np.int32); sr = np.zeros(prob.K, np.int32)
+    lib.covgpu_nd_plan_owner(h, capi.iptr(pr), capi.iptr(sr))
+    info = (C.c_int64 * 16)()
+    lib.covgpu_nd_plan_info(h, info)
+    nr = np.zeros(int(info[0]), np.int32)
+    lib.covgpu_nd_plan_ranks(h, capi.iptr(nr))
+    return ShardPlan(h, int(world), int(n), lr[:prob.L].copy(), ir[:prob.I].copy(), er[:prob.E].copy(), pr, sr, nr)
 
 
 def shard_problem(prob: FlatProblem, plan: ShardPlan, rank: int) -> FlatProblem:
@@ -128,18 +97,11 @@ def shard_problem(prob: FlatProblem, plan: ShardPlan, rank: int) -> FlatProblem:
         edge_loss_a=prob.edge_loss_a[ed])
 
 
-def chain_owner(prob: FlatProblem, plan: ShardPlan) -> np.ndarray:
-    """rank that holds keyframe k's speed-bias block: the rank of its agent's IMU factors."""
-    own = np.zeros(prob.K, np.int32)
-    own[prob.imu_kf_j] = plan.imu_rank
-    own[prob.imu_kf_i] = plan.imu_rank  # (a chain's first keyframe only appears as predecessor)
-    return own
-
-
 def merge_solution(prob: FlatProblem, plan: ShardPlan, parts: Sequence[FlatProblem]) -> FlatProblem:
-    """Optimised full problem from the ranks' solved shares (parts[r] = rank r's downloaded sub-problem)."""
+    """Optimised full problem from the ranks' solved shares (parts[r] = rank r's downloaded sub-problem). Top unknowns are
+    identical on every rank: rank 0's copy is taken."""
     out = prob.copy()
-    po, so = plan.pose_owner(), chain_owner(prob, plan)
+    po = np.where(plan.pose_rank < 0, 0, plan.pose_rank); so = np.where(plan.sb_rank < 0, 0, plan.sb_rank)
     for r, q in enumerate(parts):
         out.kf_pose[po == r] = q.kf_pose[po == r]
         out.kf_speed_bias[so == r] = q.kf_speed_bias[so == r]
@@ -147,63 +109,79 @@ def merge_solution(prob: FlatProblem, plan: ShardPlan, parts: Sequence[FlatProbl
     return out
 
 
-# ------------------------------------------------------------------------------------------------ reducers
-class ThreadReducer:
-    """All-reduce among VIRTUAL ranks = host threads of one process (each driving its own context, possibly on the same
-    GPU). Host buffers only (covgpu_set_shard(..., stage_on_host=1)). The sum is formed in rank order by every thread:
-    deterministic and identical everywhere."""
+# ------------------------------------------------------------------------------------------------ collectives
+class Group:
+    """In-process group of ranks = host threads, each driving its own context on a shared device (covgpu_group_*)."""
 
     def __init__(self, world: int):
+        from . import backend
         self.world = world
-        self._bar = threading.Barrier(world)
-        self._slots: List[Optional[np.ndarray]] = [None] * world
-        self.calls = 0
-        self.bytes = 0
+        self.handle = C.c_void_p()
+        rc = backend.lib().covgpu_group_create(int(world), C.byref(self.handle))
+        if rc != 0:
+            raise backend.CovGpuError(backend.lib().covgpu_last_error().decode())
 
-    def callback(self, rank: int):
-        def fn(user, buf, n, op, on_device):
-            assert not on_device, "ThreadReducer needs stage_on_host=1"
-            a = np.ctypeslib.as_array(buf, (int(n),))
-            self._slots[rank] = a.copy()
-            self._bar.wait()
-            res = self._slots[0].copy()
-            for r in range(1, self.world):
-                res = res + self._slots[r] if op == 0 else np.maximum(res, self._slots[r])
-            a[:] = res
-            if rank == 0:
-                self.calls += 1; self.bytes += 8 * int(n)
-            self._bar.wait()
-        return ALLREDUCE_FN(fn)
+    def abort(self):
+        from . import backend
+        backend.lib().covgpu_group_abort(self.handle)
+
+    def close(self):
+        if self.handle:
+            from . import backend
+            backend.lib().covgpu_group_destroy(self.handle)
+            self.handle = None
 
 
-class TorchReducer:
-    """All-reduce over a torch.distributed process group: RCCL on device pointers (bench.py: the buffer stays in HBM, the
-    library has drained its stream before the call) and, for host buffers (the 16 scalars), through a small staging tensor
-    on the group's device — or plain gloo on CPU."""
+def attach(ctx, plan: ShardPlan, rank: int, world: int, force_single: bool = False, group: Optional[Group] = None):
+    """Gives `ctx` its collective. Real ranks (world > 1, one process per GPU): RCCL inside libcovgpu; rank 0 creates the
+    unique id and passes it to the others through a torch.distributed TCPStore on MASTER_ADDR:MASTER_PORT (key exchange
+    only — no torch process group, no tensor ever touches it). A one-rank run with force_single exercises the whole sharded
+    path through an in-process group of one. Returns the objects that must stay alive with the context."""
+    if group is not None:
+        ctx.set_shard_group(plan, rank, group)
+        return (group,)
+    if world <= 1:
+        g = Group(1)
+        ctx.set_shard_group(plan, 0, g)
+        return (g,)
+    from . import backend
+    from torch.distributed import TCPStore
+    import datetime
+    store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")), world, rank == 0,
+                     timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+    if rank == 0:
+        buf = (C.c_uint8 * 128)()
+        rc = backend.lib().covgpu_rccl_unique_id(buf)
+        if rc != 0:
+            raise backend.CovGpuError(backend.lib().covgpu_last_error().decode())
+        store.set("covgpu_rccl_id", bytes(buf))
+    uid = store.get("covgpu_rccl_id")
+    ctx.set_shard_rccl(plan, rank, world, bytes(uid))
+    return (store,)
 
-    def __init__(self, dist, device: str):
-        self.dist, self.device = dist, device
-        self.calls = 0
-        self.bytes = 0
 
-    def callback(self):
-        import torch
+def barrier(ctx, sharded: bool) -> None:
+    """All ranks have drained their work (an all-reduce of one number through the context's collective)."""
+    if sharded:
+        ctx.allreduce_host(np.zeros(1), 0)
 
-        class _Dev:  # zero-copy view of a raw device pointer
-            def __init__(self, ptr, n):
-                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
-        def fn(user, buf, n, op, on_device):
-            n = int(n)
-            rop = self.dist.ReduceOp.SUM if op == 0 else self.dist.ReduceOp.MAX
-            if on_device:
-                t = torch.as_tensor(_Dev(C.cast(buf, C.c_void_p).value, n), device=self.device)
-                self.dist.all_reduce(t, op=rop)
-                torch.cuda.synchronize(self.device)
-            else:
-                a = np.ctypeslib.as_array(buf, (n,))
-                t = torch.from_numpy(a.copy()).to(self.device)
-                self.dist.all_reduce(t, op=rop)
-                a[:] = t.cpu().numpy()
-            self.calls += 1; self.bytes += 8 * n
-        return ALLREDUCE_FN(fn)
+def aggregate(dt: float, iterations: float, ctx, sharded: bool) -> Tuple[float, float]:
+    """(max over ranks of the wall time, max over ranks of the executed iterations — every rank runs the SAME iterations
+    of the one sharded solve, so this is the job's iteration count, not a sum)."""
+    if not sharded:
+        return float(dt), float(iterations)
+    r = ctx.allreduce_host(np.array([dt, float(iterations)]), 1)
+    return float(r[0]), float(r[1])
+
+
+def throughput(dt_max: float, iterations: float) -> float:
+    """Whole-job GBA iterations per second."""
+    return iterations / dt_max
+
+
+def gather_solutions(sol: FlatProblem, rank: int, world: int, store) -> Sequence:
+    """All ranks' (poses, speed-bias, landmarks) on every rank, through the TCPStore of `attach` (small: a few MB)."""
+    import pickle
+    store.set(f"covgpu_sol_{rank}", pickle.dumps((sol.kf_pose, sol.kf_speed_bias, sol.lm_pos)))
+    return [pickle.loads(store.get(f"covgpu_sol_{r}")) for r in range(world)]

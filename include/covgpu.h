@@ -276,15 +276,6 @@ int32_t covgpu_reduced_dim(const covgpu_options* opt, const covgpu_problem* p);
  * system; block_of_kf is then all -1). No edge joins two different blocks. Needs no device. */
 int32_t covgpu_pgo_partition(int32_t num_kf, int32_t num_edge, const int32_t* edge_i, const int32_t* edge_j, int32_t* block_of_kf);
 
-/* Host-only: the block partition the GBA solve uses on fused multi-agent maps (block-arrow elimination of the reduced
- * camera system, DESIGN.md 4.5b — and the unit of the multi-GPU split). After the speed-bias chains are
- * eliminated every agent's pose block is dense, but agents couple only through fused landmarks and loop edges
- * (optimization_be.cpp:538-556); a vertex cover of those cross-agent links is the border ("shared poses").
- * block_of_kf[k] = block (>= 0) whose interior holds keyframe k, or -1 for a border keyframe. Returns the number of
- * blocks, or 0 when the dense form is kept (single agent, small system, or a border too large to pay; force != 0
- * skips the pay-off test). Invariant: no covisible pair and no loop edge joins the interiors of two blocks. */
-int32_t covgpu_gba_partition(const covgpu_options* opt, const covgpu_problem* p, int32_t force, int32_t* block_of_kf);
-
 /* Host-only (no device needed): the nested-dissection plan of the reduced camera system — the elimination tree the
  * multifrontal MFMA Cholesky (covins_amd/csrc/k_front.hip) runs, i.e. what the reference gets from CHOLMOD's fill-reducing
  * ordering inside ceres::Solve(SPARSE_SCHUR) (optimization_be.cpp:560-565). Unknowns are, per keyframe, a 6-dim pose block
@@ -301,26 +292,35 @@ void covgpu_nd_plan_info(const covgpu_nd_plan* plan, int64_t* out16);
 void covgpu_nd_plan_arrays(const covgpu_nd_plan* plan, int32_t* parent, int32_t* level, int32_t* own_ptr, int32_t* own_var,
                            int32_t* st_ptr, int32_t* st_var);
 
-/* ---------------------------------------------------------------- multi-GPU: ONE map sharded by agent
+/* ---------------------------------------------------------------- multi-GPU: ONE map sharded by sub-map
  * BASELINE.json north star: "the merged multi-agent map shards by agent/sub-map across the GPUs of one node with RCCL
- * all-reduce over xGMI on the shared-pose Hessian blocks at each LM iteration". One process and one context per GPU.
- *   1. every rank calls covgpu_shard_plan on the FULL problem (host-only, deterministic: same answer everywhere);
- *   2. rank r keeps the landmarks / IMU factors / between factors with *_rank == r (all keyframes stay: K is unchanged)
- *      and calls covgpu_set_shard, then covgpu_upload / covgpu_solve_resident / covgpu_download on that sub-problem;
- *   3. per linear solve the library all-reduces (a) gradient and diag(J^T J) of the shared keyframes' pose rows
- *      (12 doubles per shared keyframe), (b) the shared-pose system [C_b | b_b] after every rank has eliminated the
- *      interiors of its own agents, and per scalar read-back (c) 16 doubles. Everything else stays on its rank.
- *   4. after the solve a keyframe's pose is valid on the rank that owns its block (shared keyframes: on every rank), its
- *      speed-bias on the rank that holds its agent's IMU factors, a landmark on its lm_rank.
- * The collective is the CALLER's (RCCL through torch.distributed in bench.py, a host sum in the tests): `fn` must sum
- * (op 0) or max (op 1) `n` doubles over all ranks in place and return when the result is there. on_device = 1: `buf` is a
- * device pointer of this context's GPU (stream already drained); 0: host memory. stage_on_host != 0: the library
- * stages device buffers through pinned host memory and only ever hands `fn` host pointers. */
-typedef void (*covgpu_allreduce_fn)(void* user, double* buf, int64_t n, int32_t op, int32_t on_device);
-int32_t covgpu_shard_plan(const covgpu_options* opt, const covgpu_problem* p, int32_t world, int32_t* block_of_kf /* [K] */,
-                          int32_t* block_rank /* [<= K] */, int32_t* lm_rank /* [L] */, int32_t* imu_rank /* [I] */, int32_t* edge_rank /* [E] */);
-int covgpu_set_shard(covgpu_context* ctx, int32_t rank, int32_t world, int32_t num_kf, const int32_t* block_of_kf, int32_t num_blocks,
-                     const int32_t* block_rank, covgpu_allreduce_fn fn, void* user, int32_t stage_on_host);
+ * all-reduce over xGMI on the shared-pose Hessian blocks at each LM iteration". One context per GPU (one process per GPU, or
+ * several contexts in one process). The unit of the split is a SUBTREE of the elimination tree (an agent, or a stretch of an
+ * agent's trajectory); the top of the tree — the separators that join the sub-maps: the "shared" poses — is replicated.
+ *   1. every rank calls covgpu_shard_plan on the FULL problem (host-only, deterministic: the same answer everywhere);
+ *   2. rank r keeps the landmarks / IMU factors / between factors with *_rank == r (all keyframes stay: K is unchanged),
+ *      attaches a collective (covgpu_set_shard_rccl: RCCL, unique id from covgpu_rccl_unique_id on rank 0 passed to the
+ *      others by the caller; covgpu_set_shard_group: host threads of one process whose contexts share a device), then
+ *      covgpu_upload / covgpu_solve_resident / covgpu_download on that sub-problem;
+ *   3. per trust-region iteration the library issues FOUR all-reduces, all enqueued on the context's stream (no host
+ *      synchronisation): inside the linear solve ONE over [top fronts | their right-hand sides | gradient and diag(J^T J) of
+ *      the top unknowns] after every rank has eliminated its own subtrees, and three of 16 + 2 x world scalars;
+ *   4. after the solve an unknown is valid on the rank that owns its tree node (covgpu_nd_plan_owner; top unknowns: on
+ *      every rank), a landmark on its lm_rank. */
+int32_t covgpu_shard_plan(const covgpu_options* opt, const covgpu_problem* p, int32_t world, covgpu_nd_plan** plan_out,
+                          int32_t* lm_rank /* [L] */, int32_t* imu_rank /* [I] */, int32_t* edge_rank /* [E] */);  /* returns the number of subtrees, 0: no split */
+void covgpu_nd_plan_owner(const covgpu_nd_plan* plan, int32_t* pose_rank /* [K] */, int32_t* sb_rank /* [K] */);   /* -1: top unknown */
+void covgpu_nd_plan_ranks(const covgpu_nd_plan* plan, int32_t* node_rank /* [nodes] */);                          /* -1: top node */
+typedef struct covgpu_group covgpu_group;   /* in-process group of ranks (host threads), at most 16 */
+int  covgpu_group_create(int32_t world, covgpu_group** out);
+void covgpu_group_destroy(covgpu_group* g);
+void covgpu_group_abort(covgpu_group* g);   /* a failing member releases the others from their barrier */
+int  covgpu_set_shard_group(covgpu_context* ctx, const covgpu_nd_plan* plan, int32_t rank, covgpu_group* g);
+int  covgpu_rccl_unique_id(uint8_t* out128);   /* ncclGetUniqueId; librccl is loaded on first use */
+int  covgpu_set_shard_rccl(covgpu_context* ctx, const covgpu_nd_plan* plan, int32_t rank, int32_t world, const uint8_t* id128);
+int  covgpu_set_shard_none(covgpu_context* ctx);   /* back to the single-GPU form */
+int  covgpu_allreduce_host(covgpu_context* ctx, double* host, int64_t n, int32_t op /* 0 sum, 1 max */);  /* through the context's collective */
+void covgpu_shard_stats(covgpu_context* ctx, int64_t* out4);  /* collectives issued, bytes all-reduced, rank, world */
 
 /* ---------------------------------------------------------------- measurement hooks (bench.py)
  * With profiling on, covgpu_solve_resident brackets the linearise+Schur pass, the whole factor+solve and
@@ -328,9 +328,10 @@ int covgpu_set_shard(covgpu_context* ctx, int32_t rank, int32_t world, int32_t n
  * out[8] = { build ms, #builds, factor+solve ms, #factorisations, SYRK ms, #SYRK launches, SYRK flops,
  *           #off-diagonal 6x6 pose-pose blocks of the reduced system (covisible + loop-edge keyframe pairs) } */
 void covgpu_set_profiling(covgpu_context* ctx, int on);
-/* layout of the uploaded problem: out[16] = { arrow form (0/1), blocks, border keyframes, padded interior order / 6,
- * arrow buffer order, border system order, dense pose order (padded), covisible keyframe pairs, edge pairs, IMU chains,
- * device MiB allocated for the problem (from the allocator, not by hand), 0 ... } */
+/* layout of the uploaded problem: out[16] = { ranks of a sharded solve (0: single GPU), this rank, scalar unknowns of the
+ * replicated top nodes, top levels, KiB all-reduced per linear solve, 0, dense pose order (padded), covisible keyframe pairs,
+ * edge pairs, IMU chains, device MiB allocated for the problem (from the allocator, not by hand), fronts, levels, serial
+ * 256-column panels, order of the last level's fronts, MiB of fronts } */
 void covgpu_get_layout(covgpu_context* ctx, int64_t* out16);
 void covgpu_get_profile(covgpu_context* ctx, double* out8);
 

@@ -1,9 +1,10 @@
-"""Agent-sharded multi-GPU solve (covins_amd/distrib.py, covgpu_shard_plan / covgpu_set_shard) — CPU part.
-  * the plan: every residual has exactly one owner, a landmark's interior observers all belong to its owner's blocks,
-    sub-problems partition the full problem, block loads are balanced (LPT);
-  * world_size-2 `gloo`: each rank linearises ITS share with the oracle, packs the shared-pose (border) Hessian blocks and
-    gradient rows exactly as the device layout orders them, all-reduces the packed buffers with the reducer bench.py uses,
-    and obtains the shared-pose blocks of the FULL problem — the identity the device path relies on."""
+"""Sub-map-sharded multi-GPU solve (covins_amd/distrib.py, covgpu_shard_plan) — CPU part.
+  * the plan: every residual has exactly one owner; what a rank's residuals touch lies in its own subtrees or in the replicated
+    top of the elimination tree; the sub-problems partition the full problem; loads are balanced (LPT over subtrees);
+  * world_size-2 `gloo`: each rank linearises ITS share with the oracle; the rows / blocks of the reduced camera system that
+    belong to the TOP unknowns are summed across the ranks with a gloo all-reduce and must equal the full problem's, while
+    every other block of the system is produced by exactly one rank — the identity the device path relies on (one
+    all-reduce over the top fronts per linear solve, nothing else exchanged)."""
 import os
 
 import numpy as np
@@ -21,28 +22,30 @@ def _problem(name="small"):
 def test_shard_plan_invariants():
     p = _problem("mh123")
     o = backend.default_options()
-    for world in (2, 3, 4):
+    for world in (1, 2, 3, 4, 8):
         pl = distrib.shard_plan(p, o, world)
-        assert pl is not None and pl.num_blocks == 3 and pl.block_rank.max() < world
+        assert pl is not None and pl.subtrees >= min(2 * world, 6)
+        assert pl.node_rank.max() < world and (pl.node_rank == -1).any()
         # deterministic
         pl2 = distrib.shard_plan(p, o, world)
-        assert np.array_equal(pl.block_of_kf, pl2.block_of_kf) and np.array_equal(pl.lm_rank, pl2.lm_rank)
+        assert np.array_equal(pl.node_rank, pl2.node_rank) and np.array_equal(pl.lm_rank, pl2.lm_rank) and np.array_equal(pl.pose_rank, pl2.pose_rank)
         subs = [distrib.shard_problem(p, pl, r) for r in range(world)]
         assert sum(s.L for s in subs) == p.L and sum(s.O for s in subs) == p.O
         assert sum(s.I for s in subs) == p.I and sum(s.E for s in subs) == p.E
-        pose_rank = pl.pose_owner()
-        shared = (pl.block_of_kf < 0) | p.kf_fixed.astype(bool)   # (a constant keyframe has no pose block: it binds nobody)
+        fixed = p.kf_fixed.astype(bool)
         for r, s in enumerate(subs):
             assert s.K == p.K
-            # my landmarks are seen from my interiors and from shared keyframes only
+            # my landmarks are seen from keyframes whose pose is mine or top (a constant keyframe has no pose unknown: it binds nobody)
             seen = np.unique(s.obs_kf)
-            assert np.all(shared[seen] | (pose_rank[seen] == r))
-            # my IMU factors and between factors touch my interiors and shared keyframes only
-            for arr in (s.imu_kf_i, s.imu_kf_j, s.edge_i, s.edge_j):
-                assert np.all(shared[arr] | (pose_rank[arr] == r))
-        # LPT: with as many ranks as blocks every rank gets exactly one
-        if world == 3:
-            assert sorted(pl.block_rank.tolist()) == [0, 1, 2]
+            assert np.all(fixed[seen] | (pl.pose_rank[seen] == r) | (pl.pose_rank[seen] < 0))
+            # my IMU factors touch poses and speed-bias blocks that are mine or top; my between factors likewise
+            for arr in (s.imu_kf_i, s.imu_kf_j):
+                assert np.all((pl.pose_rank[arr] == r) | (pl.pose_rank[arr] < 0)) and np.all((pl.sb_rank[arr] == r) | (pl.sb_rank[arr] < 0))
+            for arr in (s.edge_i, s.edge_j):
+                assert np.all(fixed[arr] | (pl.pose_rank[arr] == r) | (pl.pose_rank[arr] < 0))
+        if world > 1:   # balance: no rank carries more than 1.6x its fair share of the observations
+            load = np.array([s.O for s in subs], float)
+            assert load.max() <= 1.6 * load.sum() / world + 0.1 * load.sum()
     # merge puts every piece back where its owner had it
     pl = distrib.shard_plan(p, o, 2)
     parts = []
@@ -51,56 +54,60 @@ def test_shard_plan_invariants():
         s.kf_pose[:] = r + 1.0; s.kf_speed_bias[:] = r + 1.0; s.lm_pos[:] = r + 1.0
         parts.append(s)
     mg = distrib.merge_solution(p, pl, parts)
-    assert np.array_equal(mg.kf_pose[:, 0], pl.pose_owner() + 1.0)
+    assert np.array_equal(mg.kf_pose[:, 0], np.where(pl.pose_rank < 0, 0, pl.pose_rank) + 1.0)
     assert np.array_equal(mg.lm_pos[:, 0], pl.lm_rank + 1.0)
-    assert np.array_equal(mg.kf_speed_bias[:, 0], distrib.chain_owner(p, pl) + 1.0)
-    # a single agent does not split
-    assert distrib.shard_plan(_problem("mh01"), o, 2) is None
+    assert np.array_equal(mg.kf_speed_bias[:, 0], np.where(pl.sb_rank < 0, 0, pl.sb_rank) + 1.0)
+    # a single agent splits too (the units are subtrees of the elimination tree, not agents)
+    p1 = distrib.shard_plan(_problem("mh01"), o, 2)
+    assert p1 is not None and p1.subtrees >= 2
 
 
-def _pack_border(p, pl, ptr, col, blocks, b):
-    """[C_b lower (nb x nb, border order = IR keyframe order) | b_b] like the device's contiguous border buffer; rows that
-    no residual of this share touches carry the oracle's placeholder diagonal 1 — removed, as the device leaves them 0."""
-    bk = np.nonzero(pl.block_of_kf < 0)[0]
-    idx = -np.ones(p.K, np.int64); idx[bk] = np.arange(len(bk))
-    nb = 6 * len(bk)
-    Cb = np.zeros((nb, nb)); bb = np.zeros(nb)
-    for i in bk:
+def _rows(rank_of, D, want):
+    """IR rows (15 per keyframe) of the unknowns whose owner satisfies `want`: rank_of = (pose_rank, sb_rank)."""
+    pr, sr = rank_of
+    out = []
+    for k in range(len(pr)):
+        if want(pr[k]): out.extend(range(D * k, D * k + 6))
+        if want(sr[k]): out.extend(range(D * k + 6, D * k + 15))
+    return np.array(out, int)
+
+
+def _dense(p, prob):
+    ptr, col, blocks, b, _ = covo.schur_sparse(prob, covo.default_options(), 0.0)
+    n = 15 * p.K
+    S = np.zeros((n, n))
+    for i in range(p.K):
         for q in range(ptr[i], ptr[i + 1]):
-            j = col[q]
-            if idx[j] < 0 or idx[j] > idx[i]:
-                continue
-            Cb[6 * idx[i]:6 * idx[i] + 6, 6 * idx[j]:6 * idx[j] + 6] = blocks[q][:6, :6]
-        bb[6 * idx[i]:6 * idx[i] + 6] = b[15 * i:15 * i + 6]
-    Cb = np.tril(Cb)
-    d = np.diag(Cb).copy()
-    untouched = (d == 1.0) & (np.abs(Cb - np.diag(d)).sum(1) == 0) & (bb == 0)
-    Cb[np.diag_indices(nb)] = np.where(untouched, 0.0, d)
-    return np.concatenate([Cb.reshape(-1), bb])
+            S[15 * i:15 * i + 15, 15 * col[q]:15 * col[q] + 15] = blocks[q]
+    # rows no residual of this share touches carry the oracle's placeholder diagonal 1 (the device leaves them 0 until the
+    # damping is applied after the exchange): removed
+    d = np.diag(S).copy()
+    untouched = (d == 1.0) & (np.abs(S - np.diag(d)).sum(1) == 0) & (b == 0)
+    S[np.diag_indices(n)] = np.where(untouched, 0.0, d)
+    return S, b
 
 
 def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    import ctypes as C
-    dist = distrib.init("gloo")
-    assert dist is not None and dist.get_world_size() == world
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
+    assert dist.get_world_size() == world
     p = _problem("small")
-    o = backend.default_options()
-    pl = distrib.shard_plan(p, o, world)       # same plan on every rank, no communication
+    pl = distrib.shard_plan(p, backend.default_options(), world)       # same plan on every rank, no communication
     mine = distrib.shard_problem(p, pl, rank)
-    buf = _pack_border(p, pl, *covo.schur_sparse(mine, covo.default_options(), 0.0)[:4])
-    red = distrib.TorchReducer(dist, "cpu")
-    cb = red.callback()
-    cb(None, buf.ctypes.data_as(C.POINTER(C.c_double)), len(buf), 0, 0)   # the call libcovgpu makes (stage_on_host form)
-    mx = np.array([float(rank), 7.0 - rank])
-    cb(None, mx.ctypes.data_as(C.POINTER(C.c_double)), 2, 1, 0)
-    dt, its = distrib.aggregate(1.0 + rank, 10, dist, "cpu")
-    q.put((rank, buf, mx, dt, its, mine.L))
-    distrib.barrier(dist, "cpu")
+    S, b = _dense(p, mine)
+    top = _rows((pl.pose_rank, pl.sb_rank), 15, lambda r: r < 0)
+    buf = np.concatenate([S[np.ix_(top, top)].reshape(-1), b[top]])   # what the device all-reduces: the top fronts' own blocks + right-hand side
+    t = torch.from_numpy(buf)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    own = _rows((pl.pose_rank, pl.sb_rank), 15, lambda r: r == rank)
+    q.put((rank, buf, S[np.ix_(own, own)], S[np.ix_(own, top)], b[own], mine.L))
+    dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_border_reduction():
+def test_two_rank_gloo_top_front_reduction():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
@@ -109,17 +116,25 @@ def test_two_rank_gloo_border_reduction():
     out = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
     for pr in procs: pr.join(timeout=60)
     assert all(pr.exitcode == 0 for pr in procs)
-    (_, b0, m0, dt0, it0, l0), (_, b1, m1, dt1, it1, l1) = out
-    assert np.array_equal(b0, b1) and np.array_equal(m0, m1) and list(m0) == [1.0, 7.0]
-    assert dt0 == dt1 == 2.0 and it0 == it1 == 10.0   # MAX of time; every rank ran the SAME 10 iterations
     p = _problem("small")
     pl = distrib.shard_plan(p, backend.default_options(), 2)
-    assert l0 + l1 == p.L and l0 > 0 and l1 > 0
-    full = _pack_border(p, pl, *covo.schur_sparse(p, covo.default_options(), 0.0)[:4])
+    S, b = _dense(p, p)
+    top = _rows((pl.pose_rank, pl.sb_rank), 15, lambda r: r < 0)
+    full = np.concatenate([S[np.ix_(top, top)].reshape(-1), b[top]])
     scale = np.abs(full).max()
-    assert np.abs(b0 - full).max() <= 1e-12 * scale
+    assert len(top) > 0 and np.array_equal(out[0][1], out[1][1])            # both ranks hold the same reduced top blocks
+    assert np.abs(out[0][1] - full).max() <= 1e-12 * scale                   # ... and they are the full problem's
+    for r, _, Soo, Sot, bo, L in out:                                        # everything else is complete on its one owner
+        own = _rows((pl.pose_rank, pl.sb_rank), 15, lambda x: x == r)
+        assert L > 0 and len(own) > 0
+        assert np.abs(Soo - S[np.ix_(own, own)]).max() <= 1e-12 * scale
+        assert np.abs(Sot - S[np.ix_(own, top)]).max() <= 1e-12 * scale
+        assert np.abs(bo - b[own]).max() <= 1e-12 * max(np.abs(b).max(), 1.0)
+    # and unknowns of different ranks never couple
+    o0 = _rows((pl.pose_rank, pl.sb_rank), 15, lambda x: x == 0); o1 = _rows((pl.pose_rank, pl.sb_rank), 15, lambda x: x == 1)
+    assert not S[np.ix_(o0, o1)].any()
 
 
 def test_single_process_is_identity():
-    assert distrib.aggregate(0.5, 7, None) == (0.5, 7.0)
+    assert distrib.aggregate(0.5, 7, None, False) == (0.5, 7.0)
     assert distrib.throughput(2.0, 10.0) == 5.0

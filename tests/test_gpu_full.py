@@ -3,7 +3,7 @@ for configs[1] (mh01), configs[2]'s GBA (mh123) and the metric's 5-agent map (mh
 (tests/golden/*.npz, made by tools/make_golden_full.py; oracle = block-sparse reduced system solved by scipy's SuperLU).
 Tolerances: poses 1e-6 m / 1e-7 rad, speed-bias 1e-6, cost trace 1e-6 relative, identical accept/reject sequence;
 landmarks by tests/util.landmark_parity. Plus one linearisation at full size: the device Gauss-Newton step must solve the
-ORACLE's reduced system (||S dx - b||), and the block-arrow solve must equal the dense solve."""
+ORACLE's reduced system (||S dx - b||), and the multifrontal solve must equal the one-front (dense) solve."""
 import hashlib
 import os
 
@@ -105,7 +105,7 @@ def _spmv(ptr, col, blocks, x, D):
 
 @pytest.mark.parametrize("name", ["mh01", "mh12345"])
 def test_single_linearisation_at_full_size(ctx, name):
-    """The device Gauss-Newton step (structured speed-bias elimination + arrow / dense MFMA Cholesky + landmark
+    """The device Gauss-Newton step (multifrontal MFMA Cholesky of the reduced camera system + landmark
     back-substitution) must solve the reduced system the ORACLE assembles: ||S dx - b|| / ||b|| small, and dx equal to the
     SuperLU solution of the same system."""
     import scipy.sparse as sp
@@ -152,17 +152,3 @@ def test_multifrontal_solve_equals_one_front_solve(ctx):
     assert np.abs(sd.kf_pose - sa.kf_pose).max() < 1e-8 and np.abs(sd.kf_speed_bias - sa.kf_speed_bias).max() < 1e-8
     n_ill, d_good, d_white = landmark_parity(sa.lm_pos, sd)
     assert d_good < 1e-6 and d_white < 1e-4
-
-
-def test_arrow_solve_small_forced(ctx, small_map):
-    """Forced arrow plan on a small 3-agent map (one agent entirely shared: a chain without a block), against the oracle."""
-    p = mapdata.flatten_gba(small_map, False, True)[0]
-    os.environ["COVGPU_GBA_ARROW"] = "1"; os.environ["COVGPU_GBA_LEGACY"] = "1"
-    try:
-        sol, res = ctx.gba_solve(p, backend.default_options())
-    finally:
-        del os.environ["COVGPU_GBA_ARROW"]; del os.environ["COVGPU_GBA_LEGACY"]
-    ref, rres = covo.gba_solve(p, covo.default_options())
-    assert res.iterations == rres.iterations and abs(res.final_cost - rres.final_cost) <= 1e-8 * rres.final_cost
-    assert np.abs(sol.kf_pose[:, 4:] - ref.kf_pose[:, 4:]).max() < 1e-6
-    assert np.abs(sol.kf_speed_bias - ref.kf_speed_bias).max() < 1e-6

@@ -1,7 +1,8 @@
-"""Agent-sharded solve on VIRTUAL ranks: R contexts on the one GPU of the test box, each
-holding one rank's share of the SAME map, driven in lockstep by host threads; the library's three collectives per linear
-solve go through distrib.ThreadReducer (host sum in rank order). The sharded result must equal the unsharded one:
-one Gauss-Newton step to 1e-10 (relative, system metric) and the full 10-iteration solve to 1e-8 m."""
+"""Sub-map-sharded solve on VIRTUAL ranks: R contexts on the one GPU of the test box, each holding one rank's
+share of the SAME map (its subtrees of the elimination tree + the replicated top), driven in lockstep by host threads; the
+library's collectives run through its native in-process group (solver.hip GroupReducer: sums in rank order on the device).
+The sharded result must equal the unsharded one: one Gauss-Newton step to 1e-9 (relative) and the full 10-iteration solve
+to 1e-8 m with the identical accept sequence; four collectives per trust-region iteration."""
 import threading
 
 import numpy as np
@@ -14,13 +15,6 @@ pytestmark = pytest.mark.gpu
 _cache = {}
 
 
-@pytest.fixture(autouse=True)
-def _same_elimination_order(monkeypatch):
-    # the sharded solve still runs the round-2 agent-block form; its unsharded reference uses the same form so that the comparison
-    # isolates the sharding (the multifrontal form is compared with the oracle and the one-front solve in test_gpu_full.py)
-    monkeypatch.setenv("COVGPU_GBA_LEGACY", "1")
-
-
 def problem(name):
     if name not in _cache:
         m = synth.make_map(synth.config_named(name))
@@ -29,72 +23,117 @@ def problem(name):
 
 
 def run_virtual_ranks(prob, plan, job):
-    """job(ctx, sub_problem, rank) on every virtual rank, concurrently; returns the list of results."""
-    red = distrib.ThreadReducer(plan.world)
-    out, err = [None] * plan.world, []
+    """job(ctx, sub_problem, rank) on every virtual rank, concurrently; returns the list of results and rank 0's shard stats."""
+    grp = distrib.Group(plan.world)
+    out, stats, err = [None] * plan.world, [None] * plan.world, []
 
     def work(r):
         try:
             ctx = backend.Context(0)
-            cb = red.callback(r)
-            ctx.set_shard(plan, r, cb, stage_on_host=True)
+            distrib.attach(ctx, plan, r, plan.world, group=grp)
             out[r] = job(ctx, distrib.shard_problem(prob, plan, r), r)
+            stats[r] = (ctx.shard_stats(), ctx.layout())
             ctx.close()
         except Exception as e:  # a failing rank must not leave the others waiting at the barrier forever
             err.append(e)
-            red._bar.abort()
+            grp.abort()
 
     th = [threading.Thread(target=work, args=(r,)) for r in range(plan.world)]
     for t in th: t.start()
     for t in th: t.join(timeout=600)
     assert not err, err
-    return out, red
+    grp.close()
+    return out, stats[0]
 
 
-@pytest.mark.parametrize("name,world", [("mh123", 2), ("mh123", 3), ("mh123", 4), ("mh12345", 2), ("mh12345", 4), ("mh12345", 5), ("mh12345", 8)])
+@pytest.mark.parametrize("name,world", [("mh123", 2), ("mh123", 3), ("mh123", 4), ("mh12345", 2), ("mh12345", 4), ("mh12345", 5), ("mh12345", 8), ("mh01", 2)])
 def test_sharded_gauss_newton_step_equals_unsharded(name, world):
     p = problem(name)
     o = backend.default_options()
     plan = distrib.shard_plan(p, o, world)
-    assert plan is not None   # (world > number of agents: the surplus ranks own nothing and only take part in the reductions)
+    assert plan is not None and plan.subtrees >= world   # (a single agent splits too: the units are subtrees, not agents)
     ctx = backend.Context(0)
     dx0, dl0, c0 = ctx.gn_step(p, o, 1e-8)
     ctx.close()
-    parts, red = run_virtual_ranks(p, plan, lambda ctx, sub, r: ctx.gn_step(sub, o, 1e-8))
-    po, so = plan.pose_owner(), distrib.chain_owner(p, plan)
+    parts, (st, lay) = run_virtual_ranks(p, plan, lambda ctx, sub, r: ctx.gn_step(sub, o, 1e-8))
+    po, so = np.where(plan.pose_rank < 0, 0, plan.pose_rank), np.where(plan.sb_rank < 0, 0, plan.sb_rank)
     dx = np.zeros_like(dx0); dl = np.zeros_like(dl0)
     X = dx.reshape(p.K, 15)
-    cost = 0.0
     for r, (dxr, dlr, cr) in enumerate(parts):
         Xr = dxr.reshape(p.K, 15)
         X[po == r, :6] = Xr[po == r, :6]
         X[so == r, 6:] = Xr[so == r, 6:]
         dl[plan.lm_rank == r] = dlr
-        assert abs(cr - c0) <= 1e-12 * c0          # the all-reduced cost is the full cost on every rank
-    # shared keyframes: identical on every rank (the border system is solved redundantly from identical data)
-    sh = plan.block_of_kf < 0
+    # top unknowns: identical on every rank (the top of the tree is factorised redundantly from identical all-reduced data)
+    tp, ts = plan.pose_rank < 0, plan.sb_rank < 0
+    assert tp.any()
     for dxr, _, _ in parts[1:]:
-        assert np.array_equal(dxr.reshape(p.K, 15)[sh, :6], parts[0][0].reshape(p.K, 15)[sh, :6])
+        assert np.array_equal(dxr.reshape(p.K, 15)[tp, :6], parts[0][0].reshape(p.K, 15)[tp, :6])
+        assert np.array_equal(dxr.reshape(p.K, 15)[ts, 6:], parts[0][0].reshape(p.K, 15)[ts, 6:])
     scale = np.abs(dx0).max()
-    print(f"{name} world {world}: step difference {np.abs(dx - dx0).max() / scale:.2e} (relative), landmarks {np.abs(dl - dl0).max():.2e} m, "
-          f"{red.calls} collectives, {red.bytes / 1e6:.1f} MB")
+    print(f"{name} world {world}: {plan.subtrees} subtrees, step difference {np.abs(dx - dx0).max() / scale:.2e} (relative), landmarks "
+          f"{np.abs(dl - dl0).max():.2e} m, {st['collectives']} collectives, {st['bytes'] / 1e6:.1f} MB, top unknowns {lay['top_unknowns']}")
     assert np.abs(dx - dx0).max() <= 1e-9 * scale
     assert np.abs(dl - dl0).max() <= 1e-9 * max(np.abs(dl0).max(), 1.0)
+    assert st["collectives"] == 1    # one exchange per linear solve (covgpu_gn_step reads no trust-region scalars)
 
 
-@pytest.mark.parametrize("name,world", [("mh123", 3), ("mh12345", 5)])
-def test_sharded_solve_equals_unsharded(name, world):
+@pytest.mark.parametrize("name,world,strategy", [("mh123", 3, 0), ("mh12345", 5, 0), ("mh12345", 4, 1), ("mh01", 2, 0)])
+def test_sharded_solve_equals_unsharded(name, world, strategy):
     p = problem(name)
-    o = backend.default_options(max_iterations=10)
+    o = backend.default_options(max_iterations=10, strategy=strategy)
     plan = distrib.shard_plan(p, o, world)
     ctx = backend.Context(0)
     s0, r0 = ctx.gba_solve(p, o)
     ctx.close()
-    parts, red = run_virtual_ranks(p, plan, lambda ctx, sub, r: ctx.gba_solve(sub, o))
+    parts, (st, lay) = run_virtual_ranks(p, plan, lambda ctx, sub, r: ctx.gba_solve(sub, o))
     sol = distrib.merge_solution(p, plan, [q for q, _ in parts])
     for _, res in parts:   # every rank took the same decisions
         assert res.iterations == r0.iterations and list(res.accepted_trace[:10]) == list(r0.accepted_trace[:10])
         assert np.allclose(np.array(res.cost_trace[:res.iterations]), np.array(r0.cost_trace[:r0.iterations]), rtol=1e-9)
     dp = np.abs(sol.kf_pose - s0.kf_pose).max(); ds = np.abs(sol.kf_speed_bias - s0.kf_speed_bias).max(); dl = np.abs(sol.lm_pos - s0.lm_pos).max()
-    print(f"{name} world {world}: pose {dp:.2e} speed-bias {ds:.2e} landmarks {dl:.2e}; {red.calls} collectives, {red.bytes / 1e6:.1f} MB per solve")
+    per_it = st["collectives"] / max(r0.iterations, 1)
+    print(f"{name} world {world}: pose {dp:.2e} speed-bias {ds:.2e} landmarks {dl:.2e}; {st['collectives']} collectives ({per_it:.1f} per iteration), "
+          f"{st['bytes'] / 1e6:.1f} MB per solve, {lay['allreduce_kib'] / 1024:.1f} MiB per linear solve")
     assert dp < 1e-8 and ds < 1e-8 and dl < 1e-6
+    assert per_it <= 4.0
+
+
+def test_one_rank_group_is_the_unsharded_solve():
+    """The whole sharded path in a one-rank group (what `bench.py --force-shard` times): same result as the plain solve."""
+    p = problem("mh123")
+    o = backend.default_options(max_iterations=6)
+    plan = distrib.shard_plan(p, o, 1)
+    ctx = backend.Context(0)
+    s0, r0 = ctx.gba_solve(p, o)
+    keep = distrib.attach(ctx, plan, 0, 1, force_single=True)
+    s1, r1 = ctx.gba_solve(distrib.shard_problem(p, plan, 0), o)
+    assert ctx.layout()["shard_world"] == 1 and ctx.layout()["top_levels"] >= 1
+    ctx.set_shard_none()
+    ctx.close()
+    del keep
+    assert r0.iterations == r1.iterations and list(r0.accepted_trace[:6]) == list(r1.accepted_trace[:6])
+    assert np.abs(s0.kf_pose - s1.kf_pose).max() < 1e-8 and np.abs(s0.lm_pos - s1.lm_pos).max() < 1e-6
+
+
+def test_rccl_collective_in_a_one_rank_communicator():
+    """The RCCL form of the collective (librccl loaded by libcovgpu at run time, ncclCommInitRank from a unique id,
+    ncclAllReduce enqueued on the context's stream) in a communicator of ONE rank — all a one-GPU box can host (RCCL refuses two
+    ranks on one device): the plumbing the multi-process run uses, and the same result as the plain solve."""
+    import ctypes as C
+    p = problem("mh123")
+    o = backend.default_options(max_iterations=4)
+    plan = distrib.shard_plan(p, o, 1)
+    ctx = backend.Context(0)
+    s0, r0 = ctx.gba_solve(p, o)
+    uid = (C.c_uint8 * 128)()
+    assert backend.lib().covgpu_rccl_unique_id(uid) == 0, backend.lib().covgpu_last_error()
+    ctx.set_shard_rccl(plan, 0, 1, bytes(uid))
+    s1, r1 = ctx.gba_solve(distrib.shard_problem(p, plan, 0), o)
+    st = ctx.shard_stats()
+    assert np.allclose(ctx.allreduce_host(np.array([1.5, -2.0]), 0), [1.5, -2.0])
+    ctx.set_shard_none()
+    ctx.close()
+    assert st["collectives"] == 4 * r1.iterations and st["world"] == 1
+    assert r0.iterations == r1.iterations and list(r0.accepted_trace[:4]) == list(r1.accepted_trace[:4])
+    assert np.abs(s0.kf_pose - s1.kf_pose).max() < 1e-8 and np.abs(s0.lm_pos - s1.lm_pos).max() < 1e-6

@@ -154,36 +154,3 @@ def test_tum_writer(tmp_path, tiny_map):
     mapdata.write_tum(str(f), tiny_map, client=0)
     rows = np.loadtxt(f)
     assert rows.shape == ((tiny_map.kf_client == 0).sum(), 8) and np.all(np.diff(rows[:, 0]) > 0)
-
-
-def test_gba_partition_invariants(small_map):
-    """covgpu_gba_partition (host-only): blocks are the agents' interiors, every cross-agent link (fused landmark or
-    loop edge) has an endpoint in the border, no structural pair joins two interiors."""
-    from covins_amd import backend
-    for m in (small_map, synth.make_map(synth.config_named("mh123"))):
-        p, _ = mapdata.flatten_gba(m, False, True)
-        o = backend.default_options()
-        blk, n = backend.gba_partition(p, o, force=True)
-        agents = m.kf_client[~m.kf_invalid]
-        assert 2 <= n <= len(np.unique(agents)) and blk.max() == n - 1  # (an agent whose keyframes are all shared has no block)
-        for a in range(n):  # one block per agent
-            assert len(np.unique(agents[blk == a])) == 1
-        free = ~p.kf_fixed.astype(bool)
-        obs_lm = np.repeat(np.arange(p.L), np.diff(p.lm_obs_ptr))
-        # covisible pairs through sparse incidence
-        import scipy.sparse as sp
-        B = sp.csr_matrix((np.ones(p.O), (obs_lm, p.obs_kf)), shape=(p.L, p.K))
-        Cv = (B.T @ B).tocoo()
-        i, j = Cv.row, Cv.col
-        keep = free[i] & free[j] & (i != j)
-        i, j = np.concatenate([i[keep], p.edge_i]), np.concatenate([j[keep], p.edge_j])
-        both_interior = (blk[i] >= 0) & (blk[j] >= 0)
-        assert np.all(blk[i][both_interior] == blk[j][both_interior])
-        nb = int((blk < 0).sum())
-        assert 0 < nb < p.K
-        # the pay-off rule: small maps keep the dense form unless forced
-        if p.K < 400:
-            assert backend.gba_partition(p, o)[1] == 0
-    # a single agent has nothing to split
-    p1, _ = mapdata.flatten_gba(synth.make_map(synth.config_named("mh01")), False, True)
-    assert backend.gba_partition(p1, backend.default_options(), force=True)[1] == 0

@@ -1119,6 +1119,126 @@ static int full_solve(covgpu_context* c, const covgpu_options* opt, covgpu_probl
 extern "C" int covgpu_gba_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out) { return guarded([&] { return full_solve(c, opt, p, out, false); }); }
 extern "C" int covgpu_pgo_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out) { return guarded([&] { return full_solve(c, opt, p, out, true); }); }
 
+// ------------------------------------------------------------------------------------------------ in-process multi-GPU solve
+// What a covins_backend process (one process, several GPUs) calls: the whole sharded GlobalBundleAdjustment solve behind one
+// C entry point — plan on the full problem, one context and one host thread per rank, the native collective (RCCL when the
+// ranks sit on different devices; the in-process group when they share one: virtual ranks, the one-GPU test form), merge.
+// Optionally also the outlier decisions of optimization_be.cpp:270-290 at the estimate the solve left resident on each rank.
+namespace {
+struct SubProblem {
+  std::vector<double> lm_pos, obs_uv, obs_sigma, imu_samples, imu_first, imu_noise, edge_meas, edge_info, edge_loss, pose, sb;
+  std::vector<int32_t> lm_obs_ptr, obs_kf, imu_i, imu_j, imu_ptr, edge_i, edge_j, lm_id, obs_id;
+  covgpu_problem view;
+};
+void make_sub(const covgpu_problem& p, int r, const int32_t* lm_rank, const int32_t* imu_rank, const int32_t* edge_rank, SubProblem& s) {
+  s.pose.assign(p.kf_pose, p.kf_pose + 7 * (size_t)p.num_kf);
+  if (p.kf_speed_bias) s.sb.assign(p.kf_speed_bias, p.kf_speed_bias + 9 * (size_t)p.num_kf);
+  s.lm_obs_ptr.assign(1, 0);
+  for (int l = 0; l < p.num_lm; ++l) {
+    if (lm_rank[l] != r) continue;
+    s.lm_id.push_back(l);
+    s.lm_pos.insert(s.lm_pos.end(), p.lm_pos + 3 * (size_t)l, p.lm_pos + 3 * (size_t)l + 3);
+    for (int o = p.lm_obs_ptr[l]; o < p.lm_obs_ptr[l + 1]; ++o) {
+      s.obs_id.push_back(o); s.obs_kf.push_back(p.obs_kf[o]);
+      s.obs_uv.push_back(p.obs_uv[2 * (size_t)o]); s.obs_uv.push_back(p.obs_uv[2 * (size_t)o + 1]); s.obs_sigma.push_back(p.obs_sigma[o]);
+    }
+    s.lm_obs_ptr.push_back((int32_t)s.obs_kf.size());
+  }
+  s.imu_ptr.assign(1, 0);
+  for (int f = 0; f < p.num_imu; ++f) {
+    if (imu_rank[f] != r) continue;
+    s.imu_i.push_back(p.imu_kf_i[f]); s.imu_j.push_back(p.imu_kf_j[f]);
+    s.imu_samples.insert(s.imu_samples.end(), p.imu_samples + 7 * (size_t)p.imu_sample_ptr[f], p.imu_samples + 7 * (size_t)p.imu_sample_ptr[f + 1]);
+    s.imu_ptr.push_back((int32_t)(s.imu_samples.size() / 7));
+    s.imu_first.insert(s.imu_first.end(), p.imu_first + 6 * (size_t)f, p.imu_first + 6 * (size_t)f + 6);
+    if (p.imu_noise) s.imu_noise.insert(s.imu_noise.end(), p.imu_noise + 5 * (size_t)f, p.imu_noise + 5 * (size_t)f + 5);
+  }
+  for (int e = 0; e < p.num_edge; ++e) {
+    if (edge_rank[e] != r) continue;
+    s.edge_i.push_back(p.edge_i[e]); s.edge_j.push_back(p.edge_j[e]);
+    s.edge_meas.insert(s.edge_meas.end(), p.edge_meas + 7 * (size_t)e, p.edge_meas + 7 * (size_t)e + 7);
+    s.edge_info.insert(s.edge_info.end(), p.edge_sqrt_info + 36 * (size_t)e, p.edge_sqrt_info + 36 * (size_t)e + 36);
+    s.edge_loss.push_back(p.edge_loss_a[e]);
+  }
+  covgpu_problem& v = s.view;
+  v = p;
+  v.kf_pose = s.pose.data(); v.kf_speed_bias = p.kf_speed_bias ? s.sb.data() : nullptr;
+  v.num_lm = (int32_t)s.lm_id.size(); v.num_obs = (int32_t)s.obs_kf.size(); v.num_imu = (int32_t)s.imu_i.size(); v.num_edge = (int32_t)s.edge_i.size();
+  v.num_imu_samples = (int32_t)(s.imu_samples.size() / 7);
+  v.lm_pos = s.lm_pos.data(); v.lm_obs_ptr = s.lm_obs_ptr.data(); v.obs_kf = s.obs_kf.data(); v.obs_uv = s.obs_uv.data(); v.obs_sigma = s.obs_sigma.data();
+  v.imu_kf_i = s.imu_i.data(); v.imu_kf_j = s.imu_j.data(); v.imu_sample_ptr = s.imu_ptr.data(); v.imu_samples = s.imu_samples.data();
+  v.imu_first = s.imu_first.data(); v.imu_noise = p.imu_noise ? s.imu_noise.data() : nullptr;
+  v.edge_i = s.edge_i.data(); v.edge_j = s.edge_j.data(); v.edge_meas = s.edge_meas.data(); v.edge_sqrt_info = s.edge_info.data(); v.edge_loss_a = s.edge_loss.data();
+}
+}  // namespace
+
+extern "C" int covgpu_gba_solve_multi(const covgpu_options* opt, covgpu_problem* p, covgpu_result* out, int32_t n_ranks, const int32_t* devices,
+                                      double outlier_threshold, uint8_t* obs_erase, int32_t* lm_left, int64_t* counts) {
+  return guarded([&] {
+    if (n_ranks < 1 || n_ranks > 16 || !devices) { g_err = "covgpu_gba_solve_multi: 1..16 ranks with a device each"; return (int)COVGPU_ERR_INVALID_ARG; }
+    std::vector<int32_t> lm_rank(std::max(p->num_lm, 1)), imu_rank(std::max(p->num_imu, 1)), edge_rank(std::max(p->num_edge, 1));
+    covgpu_nd_plan* plan = nullptr;
+    const int nsub = covgpu_shard_plan(opt, p, n_ranks, &plan, lm_rank.data(), imu_rank.data(), edge_rank.data());
+    if (nsub <= 0) { g_err = "covgpu_gba_solve_multi: the problem does not split (" + g_err + ")"; return (int)COVGPU_ERR_INVALID_ARG; }
+    bool shared_device = false;
+    for (int a = 0; a < n_ranks; ++a) for (int b = 0; b < a; ++b) shared_device |= devices[a] == devices[b];
+    covgpu_group* grp = nullptr;
+    uint8_t uid[128];
+    if (shared_device || n_ranks == 1) { RC(covgpu_group_create(n_ranks, &grp)); }
+    else { const int rc = covgpu_rccl_unique_id(uid); if (rc) { covgpu_nd_plan_destroy(plan); return rc; } }
+    std::vector<SubProblem> sub(n_ranks);
+    for (int r = 0; r < n_ranks; ++r) make_sub(*p, r, lm_rank.data(), imu_rank.data(), edge_rank.data(), sub[r]);
+    std::vector<covgpu_result> res(n_ranks);
+    std::vector<int> rcs(n_ranks, COVGPU_OK);
+    std::vector<std::string> errs(n_ranks);
+    std::vector<std::vector<uint8_t>> er(n_ranks);
+    std::vector<std::vector<int32_t>> ll(n_ranks);
+    std::vector<int64_t> cnt(2 * (size_t)n_ranks, 0);
+    auto work = [&](int r) {
+      covgpu_context* c = nullptr;
+      covgpu_options o = *opt; o.device = devices[r];
+      int rc = covgpu_create(&o, &c);
+      if (!rc) rc = grp ? covgpu_set_shard_group(c, plan, r, grp) : covgpu_set_shard_rccl(c, plan, r, n_ranks, uid);
+      if (!rc) rc = covgpu_gba_solve(c, &o, &sub[r].view, &res[r]);
+      if (!rc && obs_erase) {
+        er[r].assign(sub[r].obs_kf.size() + 1, 0); ll[r].assign(sub[r].lm_id.size() + 1, 0);
+        rc = covgpu_outlier_pass(c, outlier_threshold, er[r].data(), ll[r].data(), &cnt[2 * (size_t)r]);
+      }
+      if (rc) { errs[r] = covgpu_last_error(); if (grp) covgpu_group_abort(grp); }
+      rcs[r] = rc;
+      if (c) covgpu_destroy(c);
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < n_ranks; ++r) th.emplace_back(work, r);
+    work(0);
+    for (auto& t : th) t.join();
+    if (grp) covgpu_group_destroy(grp);
+    int rc = COVGPU_OK;
+    for (int r = 0; r < n_ranks; ++r) if (rcs[r]) { rc = rcs[r]; g_err = "rank " + std::to_string(r) + ": " + errs[r]; break; }
+    if (!rc) {
+      std::vector<int32_t> pr(p->num_kf), sr(p->num_kf);
+      covgpu_nd_plan_owner(plan, pr.data(), sr.data());
+      for (int k = 0; k < p->num_kf; ++k) {
+        const int a = pr[k] < 0 ? 0 : pr[k], b = sr[k] < 0 ? 0 : sr[k];
+        std::memcpy(p->kf_pose + 7 * (size_t)k, sub[a].pose.data() + 7 * (size_t)k, 7 * sizeof(double));
+        if (p->kf_speed_bias) std::memcpy(p->kf_speed_bias + 9 * (size_t)k, sub[b].sb.data() + 9 * (size_t)k, 9 * sizeof(double));
+      }
+      if (counts) { counts[0] = 0; counts[1] = 0; }
+      for (int r = 0; r < n_ranks; ++r) {
+        for (size_t i = 0; i < sub[r].lm_id.size(); ++i) {
+          std::memcpy(p->lm_pos + 3 * (size_t)sub[r].lm_id[i], sub[r].lm_pos.data() + 3 * i, 3 * sizeof(double));
+          if (obs_erase && lm_left) lm_left[sub[r].lm_id[i]] = ll[r][i];
+        }
+        if (obs_erase) for (size_t i = 0; i < sub[r].obs_id.size(); ++i) obs_erase[sub[r].obs_id[i]] = er[r][i];
+        if (counts) { counts[0] += cnt[2 * (size_t)r]; counts[1] += cnt[2 * (size_t)r + 1]; }
+      }
+      if (out) *out = res[0];
+    }
+    covgpu_nd_plan_destroy(plan);
+    return rc;
+  });
+}
+
 // ------------------------------------------------------------------------------------------------ test entry points
 template <typename T>
 static int fetch(covgpu_context* c, T* host, const T* dev, size_t count) {

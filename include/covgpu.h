@@ -319,6 +319,13 @@ int  covgpu_set_shard_group(covgpu_context* ctx, const covgpu_nd_plan* plan, int
 int  covgpu_rccl_unique_id(uint8_t* out128);   /* ncclGetUniqueId; librccl is loaded on first use */
 int  covgpu_set_shard_rccl(covgpu_context* ctx, const covgpu_nd_plan* plan, int32_t rank, int32_t world, const uint8_t* id128);
 int  covgpu_set_shard_none(covgpu_context* ctx);   /* back to the single-GPU form */
+/* The whole sharded solve behind one call, for a host process that drives several GPUs itself (covins_backend is one
+ * process: backend.cpp:141-156): plan on the full problem, one context + one host thread per rank on devices[r], RCCL
+ * between them (the in-process group if ranks share a device: virtual ranks), results merged into `p`; `out` = the common
+ * trust-region record. obs_erase != NULL: also the outlier decisions of optimization_be.cpp:270-290 at the resident
+ * estimate, merged over the ranks (obs_erase [O], lm_left [L], counts[2] as covgpu_outlier_pass). */
+int  covgpu_gba_solve_multi(const covgpu_options* opt, covgpu_problem* p, covgpu_result* out, int32_t n_ranks, const int32_t* devices,
+                            double outlier_threshold, uint8_t* obs_erase, int32_t* lm_left, int64_t* counts);
 int  covgpu_allreduce_host(covgpu_context* ctx, double* host, int64_t n, int32_t op /* 0 sum, 1 max */);  /* through the context's collective */
 void covgpu_shard_stats(covgpu_context* ctx, int64_t* out4);  /* collectives issued, bytes all-reduced, rank, world */
 

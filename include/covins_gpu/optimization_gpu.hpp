@@ -52,6 +52,11 @@ struct Params {
   std::string placerec_type = "COVINS";
   int strategy = COVGPU_DOGLEG;  // the reference runs DOGLEG (optimization_be.cpp:261,564,1028)
   int device = 0;
+  // multi-GPU GlobalBundleAdjustment inside this one process (covgpu_gba_solve_multi): ranks > 1 shards the ONE map by sub-map
+  // over `ranks` contexts; rank r runs on HIP device devices[r] (empty: devices 0 .. ranks-1). Ranks on different devices talk
+  // over RCCL; ranks that share a device (a one-GPU box: the test form) over the library's in-process group.
+  int n_gpus = 1;
+  std::vector<int> devices;
   int flatten_threads = 0;  // host threads of the Map -> IR walk over landmarks; 0 = sys.threads_server-like default (hardware, <= 16)
   // (IMU noise and gravity are NOT parameters: every IMU factor carries its keyframe's own VICalibration values,
   //  Types::imu_calib, as the reference's per-keyframe preintegrators do — keyframe_be.cpp:187-195.)
@@ -351,11 +356,39 @@ class OptimizationT {
     return o;
   }
 
+  // One context per calling thread and device, created on first use and kept (streams, pinned buffers, the device context):
+  // the reference calls these functions per loop closure (placerec_be.cpp:327) and per loop candidate (OptimizeRelativePose) —
+  // creating and destroying a context for every call cost more than the single-pair solve it wrapped.
+  struct ContextHolder {
+    covgpu_context* ctx = nullptr; int device = -1;
+    ~ContextHolder() { if (ctx) covgpu_destroy(ctx); }
+  };
   static covgpu_context* Context() {
-    covgpu_context* ctx = nullptr;
-    covgpu_options o = Options(1, false);
-    if (covgpu_create(&o, &ctx) != COVGPU_OK) detail::fatal(covgpu_last_error());
-    return ctx;
+    static thread_local ContextHolder h;
+    const int dev = params().device;
+    if (h.ctx != nullptr && h.device != dev) { covgpu_destroy(h.ctx); h.ctx = nullptr; }
+    if (h.ctx == nullptr) {
+      covgpu_options o = Options(1, false);
+      if (covgpu_create(&o, &h.ctx) != COVGPU_OK) detail::fatal(covgpu_last_error());
+      h.device = dev;
+    }
+    return h.ctx;
+  }
+  // one GBA solve (+ optionally the outlier decisions at its estimate): one GPU through the thread's context, or sharded
+  static void SolveGBA(covgpu_context* ctx, covgpu_options& o, covgpu_problem& p, covgpu_result& r, std::vector<uint8_t>* erase,
+                       std::vector<int32_t>* lm_left, int64_t* counts) {
+    const Params& prm = params();
+    if (prm.n_gpus > 1) {
+      std::vector<int32_t> dev(prm.n_gpus);
+      for (int i = 0; i < prm.n_gpus; ++i) dev[i] = i < (int)prm.devices.size() ? prm.devices[i] : i;
+      if (covgpu_gba_solve_multi(&o, &p, &r, prm.n_gpus, dev.data(), prm.th_gba_outlier_global, erase ? erase->data() : nullptr,
+                                 lm_left ? lm_left->data() : nullptr, counts) != COVGPU_OK)
+        detail::fatal(covgpu_last_error());
+      return;
+    }
+    if (covgpu_gba_solve(ctx, &o, &p, &r) != COVGPU_OK) detail::fatal(covgpu_last_error());
+    // problem.Evaluate + threshold (:270-289) on the device at the estimate the solve left resident: flags come back
+    if (erase && covgpu_outlier_pass(ctx, prm.th_gba_outlier_global, erase->data(), lm_left->data(), counts) != COVGPU_OK) detail::fatal(covgpu_last_error());
   }
 
   // ---- optimization_be.cpp:56-618
@@ -370,12 +403,10 @@ class OptimizationT {
       covgpu_problem p = f.view();
       covgpu_options o = Options(5, visual_only);  // max_num_iterations = 5 (:262)
       covgpu_result r;
-      if (covgpu_gba_solve(ctx, &o, &p, &r) != COVGPU_OK) detail::fatal(covgpu_last_error());
-      // problem.Evaluate + threshold (:270-289) on the device at the estimate the solve left resident: flags come back
       std::vector<uint8_t> erase(f.obs_kf.size() + 1);
       std::vector<int32_t> lm_left(ix.lms.size() + 1);
       int64_t counts[2] = {0, 0};
-      if (covgpu_outlier_pass(ctx, params().th_gba_outlier_global, erase.data(), lm_left.data(), counts) != COVGPU_OK) detail::fatal(covgpu_last_error());
+      SolveGBA(ctx, o, p, r, &erase, &lm_left, counts);
       size_t num_bad = 0;
       for (size_t i = 0; i < f.obs_kf.size(); ++i)
         if (erase[i]) {  // :281-289
@@ -392,7 +423,7 @@ class OptimizationT {
       covgpu_problem p = f.view();
       covgpu_options o = Options(interations_limit, visual_only);
       covgpu_result r;
-      if (covgpu_gba_solve(ctx, &o, &p, &r) != COVGPU_OK) detail::fatal(covgpu_last_error());
+      SolveGBA(ctx, o, p, r, nullptr, nullptr, nullptr);
       if (r.termination == 4) std::fprintf(stderr, "[covins_gpu] GBA: linear solve failed, keeping the last accepted estimate (as ceres::Solve would)\n");
       if (r.reserved > 0) std::fprintf(stderr, "[covins_gpu] GBA: %d IMU factors without a positive definite covariance carry no weight\n", r.reserved);
       for (size_t k = 0; k < ix.kfs.size(); ++k) {  // :572-595
@@ -419,7 +450,6 @@ class OptimizationT {
         ix.lms[l]->is_gba_optimized_ = true;
       }
     }
-    covgpu_destroy(ctx);
     std::printf("--> Clean Map\n");
     map->Clean();  // :614
     std::printf("--> done.\n+++ GBA: End +++\n");
@@ -532,7 +562,6 @@ class OptimizationT {
     if (covgpu_pgo_reanchor(ctx, (int32_t)kfs.size(), pose_old.data(), f.pose.data(), vel.data(), (int32_t)lms.size(), ref.data(),
                             lmp.data()) != COVGPU_OK)
       detail::fatal(covgpu_last_error());
-    covgpu_destroy(ctx);
     for (size_t k = 0; k < kfs.size(); ++k) {
       TransformType T;
       detail::pose_to_transform(&f.pose[7 * k], T);
@@ -599,7 +628,6 @@ class OptimizationT {
     bt.T_ab = T.data(); bt.outlier = out.data(); bt.inliers = inl.data();
     covgpu_context* ctx = Context();
     if (covgpu_relpose_batch(ctx, &bt, params().th_outlier_align, 12) != COVGPU_OK) detail::fatal(covgpu_last_error());
-    covgpu_destroy(ctx);
     for (size_t b = 0; b < B; ++b) {
       RelPoseJob& j = jobs[b];
       for (size_t c = 0; c < index[b].size(); ++c)

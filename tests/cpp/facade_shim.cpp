@@ -122,6 +122,8 @@ void shim_set_params(int strategy, const char* placerec_type) {
   Opt::params().placerec_type = placerec_type;
 }
 void shim_set_flatten_threads(int n) { Opt::params().flatten_threads = n; }
+// n > 1: GlobalBundleAdjustment shards the map over n in-process ranks, all on HIP device `device` (virtual ranks: the one-GPU form)
+void shim_set_gpus(int n, int device) { Opt::params().n_gpus = n; Opt::params().devices.assign((size_t)(n > 1 ? n : 0), device); }
 void shim_set_invalid(Handle* h, int kf) { h->kfs[kf]->SetInvalid(); }
 
 // OptimizeRelativePose between two keyframes of the map: matches1[i] = the landmark of kf2 matched to feature i of kf1 (here:

@@ -26,6 +26,7 @@ def lib():
         _LIB.shim_gba.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         _LIB.shim_set_params.argtypes = [C.c_int, C.c_char_p]
         _LIB.shim_set_flatten_threads.argtypes = [C.c_int]
+        _LIB.shim_set_gpus.argtypes = [C.c_int, C.c_int]
         _LIB.shim_set_invalid.argtypes = [C.c_void_p, C.c_int]
     return _LIB
 

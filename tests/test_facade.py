@@ -61,6 +61,32 @@ def test_cpp_gba_matches_python_facade():
 
 
 @pytest.mark.gpu
+def test_cpp_gba_sharded_over_two_in_process_ranks():
+    """Params::n_gpus = 2: the C++ facade's GlobalBundleAdjustment through covgpu_gba_solve_multi — two contexts in this
+    process (both on the one GPU of the test box: virtual ranks, the library's in-process collective), both rounds incl. the
+    merged outlier decisions. Must leave the map where the single-context facade leaves it."""
+    from tests.facade_util import lib as shim_lib
+    cfg = synth.config_named("small"); cfg.outlier_frac = 0.03
+    m = synth.make_map(cfg)
+    out = []
+    for n in (1, 2):
+        shim_lib().shim_set_gpus(n, 0)
+        sm = StandinMap(m)
+        try:
+            sm.gba(10, visual_only=False, outlier_removal=True)
+            out.append(sm.state())
+        finally:
+            sm.close()
+            shim_lib().shim_set_gpus(1, 0)
+    a, b = out
+    assert np.abs(a["pose"][:, 4:] - b["pose"][:, 4:]).max() < 1e-8 and rot_angle(a["pose"][:, :4], b["pose"][:, :4]).max() < 1e-7
+    assert np.abs(a["vel"] - b["vel"]).max() < 1e-7
+    assert np.array_equal(a["lm_nobs"], b["lm_nobs"]) and np.array_equal(a["lm_invalid"], b["lm_invalid"])   # same observations erased
+    d = np.abs(a["lm"] - b["lm"]).max(axis=1)
+    assert np.median(d) < 1e-9 and d.max() < 1e-4
+
+
+@pytest.mark.gpu
 def test_cpp_pgo_matches_python_facade():
     from covins_amd.optimization import Optimization
     cfg = synth.config_named("tiny"); cfg.drift_trans = 0.05; cfg.drift_yaw_deg = 0.5

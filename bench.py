@@ -244,6 +244,7 @@ def main():
             out["e2e_call"] = {"t_call_s": t_call, "kf_per_s_e2e": k_free / t_call,
                                "iterations": info["round1"].iterations + info["round2"].iterations,
                                "outliers_removed": info["outliers_removed"],
+                               "stages_s": {k: round(v, 4) for k, v in info["stages_s"].items()},
                                "what": "covins_amd.optimization.Optimization.GlobalBundleAdjustment(map, 10, outlier_removal=True) "
                                        "on the same map, host flattening in numpy"}
         if not args.no_e2e:

@@ -154,6 +154,16 @@ class Context:
         self._check(lib().covgpu_outlier_pass(self._h, float(threshold), erase.ctypes.data_as(capi._bp), iptr(left), cnt))
         return erase[:n_obs].astype(bool), left[:n_lm], (int(cnt[0]), int(cnt[1]))
 
+    def covisibility(self, threshold: int):
+        """Covisibility recount on the resident problem (covgpu_covisibility): (kf_i, kf_j, weight) with kf_i > kf_j, weight >= threshold."""
+        cap = 1 << 16
+        while True:
+            ki = np.zeros(cap, np.int32); kj = np.zeros(cap, np.int32); w = np.zeros(cap, np.int32); n = C.c_int64()
+            self._check(lib().covgpu_covisibility(self._h, int(threshold), cap, iptr(ki), iptr(kj), iptr(w), C.byref(n)))
+            if n.value <= cap:
+                return ki[:n.value], kj[:n.value], w[:n.value]
+            cap = int(n.value)
+
     def relpose_batch(self, bt: dict, th_outlier: float = 1.3, min_inliers: int = 12):
         """Batched Optimization::OptimizeRelativePose (covgpu_relpose_batch). `bt`: dict with ptr, pA, pB, kpA, kpB, sigA, sigB,
         camA, camB, distA, distB, T0 (see include/covgpu.h). Returns (T_ab [B,7], outlier flags [C], inliers [B])."""

@@ -207,6 +207,8 @@ def declare(lib: C.CDLL, prefix: str) -> None:
         d("gn_step", [C.c_void_p, OP, PP, C.c_double, _dp, _dp, _dp])
         d("relpose_batch", [C.c_void_p, C.POINTER(RelposeBatch), C.c_double, C.c_int32])
         d("outlier_pass", [C.c_void_p, C.c_double, _bp, _ip, C.POINTER(C.c_int64)])
+        d("covisibility", [C.c_void_p, C.c_int32, C.c_int64, _ip, _ip, _ip, C.POINTER(C.c_int64)])
+        d("gba_solve_multi", [OP, PP, RP, C.c_int32, _ip, C.c_double, _bp, _ip, C.POINTER(C.c_int64)])
         d("nd_plan_create", [OP, PP, C.c_int32, C.POINTER(C.c_void_p)])
         d("nd_plan_destroy", [C.c_void_p], None)
         d("nd_plan_info", [C.c_void_p, C.POINTER(C.c_int64)], None)

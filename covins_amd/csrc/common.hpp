@@ -283,6 +283,14 @@ struct PgoPlan {
 };
 void launch_pgo_block_solve(const DevProblem& P, PgoPlan& plan, hipStream_t st, CholAux& ax);
 
+// ---- covisible keyframe pairs on the device (k_pairs.hip)
+struct PairLists {
+  int npairs = 0; size_t nent = 0;
+  int *pair_ptr = nullptr, *pair_i = nullptr, *pair_j = nullptr;   // [npairs + 1] | [npairs] row keyframe (i > j) | column keyframe, sorted by (i, j)
+  int *pair_oa = nullptr, *pair_ob = nullptr;                      // [nent] observation of keyframe i / of keyframe j of every common landmark, landmark order
+};
+bool build_pairs_device(int L, int K, const int* d_lm_obs_ptr, const int* d_obs_kf, const int* d_key_of_kf, bool want_obs, hipStream_t st, PairLists& out);
+
 // ---- multifrontal solve of the whole reduced camera system (k_front.hip)
 struct NdHostPlan;
 struct NdLevel {

@@ -468,6 +468,8 @@ extern "C" int covgpu_nd_plan_create(const covgpu_options* opt, const covgpu_pro
     if (!host_pairs(p, perm, pi, pj, ei, ej)) { g_err = "invalid problem: self edge"; return (int)COVGPU_ERR_INVALID_ARG; }
     covgpu_nd_plan* pl = new covgpu_nd_plan();
     pl->pos_kf = pos_kf;
+    const auto t_pl = std::chrono::steady_clock::now();
+    struct PT { std::chrono::steady_clock::time_point t0; ~PT() { if (getenv("COVGPU_PLAN_TIMING")) std::fprintf(stderr, "[covgpu] nd_plan_build %.1f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3); } } pt{t_pl};
     if (!nd_plan_build(p->num_kf, vi, (int)chain_ptr.size() - 1, chain_ptr.data(), (int)pi.size(), pi.data(), pj.data(), (int)ei.size(), ei.data(), ej.data(),
                        nd_leaf_dims(leaf_dims), pl->hp)) {
       delete pl; g_err = "nested-dissection plan: a coupling joins two branches"; return (int)COVGPU_ERR_INVALID_ARG;
@@ -567,6 +569,15 @@ extern "C" void covgpu_nd_plan_owner(const covgpu_nd_plan* pl, int32_t* pose_ran
 
 static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, bool pgo, bool allow_arrow = true) {
   HIPCHK(hipSetDevice(c->device));
+  // dev aid (COVGPU_PLAN_TIMING=1): where the host side of an upload goes
+  static const bool tm_on = getenv("COVGPU_PLAN_TIMING") != nullptr;
+  auto tm_last = std::chrono::steady_clock::now();
+  auto tm = [&](const char* what) {
+    if (!tm_on) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[covgpu] upload: %-28s %.2f ms\n", what, std::chrono::duration<double>(now - tm_last).count() * 1e3);
+    tm_last = now;
+  };
   const bool vi = !pgo && !opt->visual_only;
   RC(validate(p, pgo, vi));
   free_problem(c);
@@ -620,91 +631,37 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_upload(c, &P.obs_u, u.data(), (size_t)P.O));
   RC(dev_upload(c, &P.obs_v, v.data(), (size_t)P.O));
   RC(dev_upload(c, &P.obs_sigma, p->obs_sigma, (size_t)P.O));
+  tm("validate, chains, states, observation stream");
   // keyframe-major observation lists + covisible pair lists (fixed keyframes carry no pose block -> excluded)
-  std::vector<int> h_pair_i, h_pair_j;  // kept for the arrow plan below
+  std::vector<int> h_pair_i, h_pair_j;  // kept for the plan below
   {
     std::vector<int> kptr(P.K + 1, 0), kidx(P.O);
     for (int o = 0; o < P.O; ++o) kptr[p->obs_kf[o] + 1]++;
     for (int k = 0; k < P.K; ++k) kptr[k + 1] += kptr[k];
     { std::vector<int> cur(kptr.begin(), kptr.end() - 1); for (int o = 0; o < P.O; ++o) kidx[cur[p->obs_kf[o]]++] = o; }
-    // bucket pairs by row position i (landmark order inside a bucket), then sort each bucket by column position j.
-    // Host threads: landmark ranges for the two passes over sum n_l^2 entries, rows for the sorts. Every thread owns
-    // a fixed sub-range of each bucket, so the result does not depend on the thread count (the summation order of
-    // k_pair_blocks is part of the bit-reproducibility contract).
-    const int nth = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
-    auto parallel = [&](auto&& fn) {  // fn(thread index)
-      std::vector<std::thread> th;
-      for (int t = 1; t < nth; ++t) th.emplace_back(fn, t);
-      fn(0);
-      for (auto& x : th) x.join();
-    };
-    auto lm_lo = [&](int t) { return (int)((long long)P.L * t / nth); };
-    std::vector<std::vector<int>> tcnt(nth, std::vector<int>(P.K, 0));
-    parallel([&](int t) {
-      std::vector<int>& cnt = tcnt[t];
-      for (int l = lm_lo(t); l < lm_lo(t + 1); ++l)
-        for (int a = p->lm_obs_ptr[l]; a < p->lm_obs_ptr[l + 1]; ++a) {
-          if (p->kf_fixed[p->obs_kf[a]]) continue;
-          const int pa = perm[p->obs_kf[a]];
-          for (int b = p->lm_obs_ptr[l]; b < p->lm_obs_ptr[l + 1]; ++b)
-            if (!p->kf_fixed[p->obs_kf[b]] && perm[p->obs_kf[b]] < pa) cnt[pa]++;
-        }
-    });
-    std::vector<int> rowcnt(P.K + 1, 0);
-    for (int k = 0; k < P.K; ++k) {  // bucket layout: row k = [thread 0's entries | thread 1's | ...]
-      int acc = rowcnt[k];
-      for (int t = 0; t < nth; ++t) { const int c2 = tcnt[t][k]; tcnt[t][k] = acc; acc += c2; }
-      rowcnt[k + 1] = acc;
-    }
-    const size_t nent = (size_t)rowcnt[P.K];
-    struct Ent { int j, oa, ob; };
-    std::vector<Ent> ent(nent);
-    parallel([&](int t) {
-      std::vector<int>& cur = tcnt[t];
-      for (int l = lm_lo(t); l < lm_lo(t + 1); ++l)
-        for (int a = p->lm_obs_ptr[l]; a < p->lm_obs_ptr[l + 1]; ++a) {
-          if (p->kf_fixed[p->obs_kf[a]]) continue;
-          const int pa = perm[p->obs_kf[a]];
-          for (int b = p->lm_obs_ptr[l]; b < p->lm_obs_ptr[l + 1]; ++b) {
-            if (p->kf_fixed[p->obs_kf[b]]) continue;
-            const int pb = perm[p->obs_kf[b]];
-            if (pb < pa) ent[cur[pa]++] = Ent{pb, a, b};
-          }
-        }
-    });
-    std::vector<int> npair_row(P.K + 1, 0);
-    parallel([&](int t) {
-      for (int i = t; i < P.K; i += nth) {
-        auto b0 = ent.begin() + rowcnt[i], b1 = ent.begin() + rowcnt[i + 1];
-        std::stable_sort(b0, b1, [](const Ent& x, const Ent& y) { return x.j < y.j; });  // stable: landmark order kept -> fixed summation order
-        int np = 0;
-        for (auto it = b0; it != b1; ++it) if (it == b0 || it->j != (it - 1)->j) ++np;
-        npair_row[i + 1] = np;
-      }
-    });
-    for (int i = 0; i < P.K; ++i) npair_row[i + 1] += npair_row[i];
-    const int npairs = npair_row[P.K];
-    std::vector<int> pptr(npairs + 1), pi(npairs), pj(npairs), oa(nent), ob(nent);
-    parallel([&](int t) {
-      for (int i = t; i < P.K; i += nth) {
-        int q = npair_row[i];
-        for (int e = rowcnt[i]; e < rowcnt[i + 1]; ++e) {
-          if (e == rowcnt[i] || ent[e].j != ent[e - 1].j) { pptr[q] = e; pi[q] = i; pj[q] = ent[e].j; ++q; }
-          oa[e] = ent[e].oa; ob[e] = ent[e].ob;
-        }
-      }
-    });
-    pptr[npairs] = (int)nent;
-    P.npairs = (int)pi.size();
     RC(dev_upload(c, &P.kf_obs_ptr, kptr.data(), kptr.size())); RC(dev_upload(c, &P.kf_obs_idx, kidx.data(), kidx.size()));
-    RC(dev_upload(c, &P.pair_ptr, pptr.data(), pptr.size()));
-    RC(dev_upload(c, &P.pair_i, pi.data(), pi.size())); RC(dev_upload(c, &P.pair_j, pj.data(), pj.size()));
-    RC(dev_upload(c, &P.pair_oa, oa.data(), oa.size())); RC(dev_upload(c, &P.pair_ob, ob.data(), ob.size()));
+    // covisible pairs (i > j in chain-major positions, free keyframes only) with, per pair, the observations of every common
+    // landmark in landmark order: built on the device (k_pairs.hip: key emission + one stable radix sort + run-length encoding)
+    std::vector<int> key(P.K);
+    for (int k = 0; k < P.K; ++k) key[k] = p->kf_fixed[k] ? -1 : perm[k];
+    int* d_key = nullptr;
+    RC(dev_upload(c, &d_key, key.data(), key.size()));
+    PairLists pl;
+    if (!build_pairs_device(P.L, P.K, P.lm_obs_ptr, P.obs_kf, d_key, true, c->st, pl)) { g_err = "covisible pair lists: device allocation failed (or more than 2^31 entries)"; return COVGPU_ERR_OUT_OF_MEMORY; }
+    for (int* q : {pl.pair_ptr, pl.pair_i, pl.pair_j, pl.pair_oa, pl.pair_ob}) if (q) c->allocs.push_back(q);
+    c->alloc_bytes += ((size_t)pl.npairs * 3 + 1 + 2 * pl.nent) * sizeof(int);
+    P.npairs = pl.npairs; P.pair_ptr = pl.pair_ptr; P.pair_i = pl.pair_i; P.pair_j = pl.pair_j; P.pair_oa = pl.pair_oa; P.pair_ob = pl.pair_ob;
+    std::vector<int> pi(P.npairs), pj(P.npairs);
+    if (P.npairs) {
+      HIPCHK(hipMemcpyAsync(pi.data(), P.pair_i, (size_t)P.npairs * sizeof(int), hipMemcpyDeviceToHost, c->st));
+      HIPCHK(hipMemcpyAsync(pj.data(), P.pair_j, (size_t)P.npairs * sizeof(int), hipMemcpyDeviceToHost, c->st));
+    }
     RC(dev_alloc(c, &P.obsZ, (size_t)18 * P.O)); RC(dev_alloc(c, &P.lmRT, (size_t)9 * P.L));
     RC(dev_alloc(c, &P.cost_part, (size_t)(P.L / 4 + 64)));
     HIPCHK(hipStreamSynchronize(c->st));
     h_pair_i.swap(pi); h_pair_j.swap(pj);
   }
+  tm("covisible pair lists");
   // IMU
   RC(dev_upload(c, &P.imu_i, (const int*)p->imu_kf_i, (size_t)P.I));
   RC(dev_upload(c, &P.imu_j, (const int*)p->imu_kf_j, (size_t)P.I));
@@ -794,6 +751,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
     RC(dev_upload(c, &P.epair_ptr, eptr.data(), eptr.size())); RC(dev_upload(c, &P.epair_i, ei.data(), ei.size()));
     RC(dev_upload(c, &P.epair_j, ej.data(), ej.size())); RC(dev_upload(c, &P.epair_ent, eent.data(), eent.size()));
     HIPCHK(hipStreamSynchronize(c->st));
+    tm("IMU, edges, vectors");
     if (use_nd) {
       NdHostPlan nhp;
       if (c->sharded) {
@@ -812,8 +770,10 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
         }
       }
       if (nhp.maxdepth > 64) { g_err = "nested-dissection plan: tree deeper than 64 levels"; return COVGPU_ERR_INVALID_ARG; }
+      tm("nested-dissection plan");
       NdDev& nd = c->nd;
       nd_tables(nhp, pos_kf.data(), P.D, c->rank, nd);
+      tm("front tables");
       P.nd = 1; P.nd_nnodes = nd.nnodes; P.nd_nlev = (int)nd.lev.size(); P.nd_maxd = nhp.maxdepth;
       nd.ntop = (int)nd.h_top_g.size();
       RC(dev_upload(c, &P.nd_vnode, nd.h_vnode.data(), nd.h_vnode.size())); RC(dev_upload(c, &P.nd_voff, nd.h_voff.data(), nd.h_voff.size()));
@@ -841,6 +801,8 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
       RC(dev_alloc(c, &P.nd_dummy, (size_t)64));
       launch_nd_init(P, nd, c->st);
       c->chol.tri_clear();   // the live-tile lists of the bulk updates belong to the previous problem
+      HIPCHK(hipStreamSynchronize(c->st));
+      tm("table upload, front allocation");
       if (c->sharded) {
         P.shard = 1;
         // weight of every unknown in the trust-region norms: counted by exactly one rank (own subtree: here; top: rank 0)
@@ -1274,6 +1236,44 @@ extern "C" int covgpu_outlier_pass(covgpu_context* c, double threshold, uint8_t*
   (void)hipFree(de); (void)hipFree(dl); (void)hipFree(dc);
   if (counts) { counts[0] = (int64_t)hc[0]; counts[1] = (int64_t)hc[1]; }
   return COVGPU_OK;
+}
+
+// Covisibility recount on the RESIDENT problem (Keyframe::UpdateCovisibilityConnections, keyframe_be.cpp:559-608, which
+// backend.cpp:164-167 runs over every keyframe after a GBA): weight(i, j) = number of landmarks both keyframes observe; pairs
+// with weight >= threshold (sys.covis_thres) come back as (kf_i > kf_j, weight), sorted by (kf_i, kf_j). All keyframes take
+// part, constant ones included. The counting runs on the device (k_pairs.hip); *count = pairs found (may exceed capacity).
+extern "C" int covgpu_covisibility(covgpu_context* c, int32_t threshold, int64_t capacity, int32_t* kf_i, int32_t* kf_j, int32_t* weight, int64_t* count) {
+  return guarded([&]() -> int {
+    if (!c->have || c->pgo) { g_err = "covgpu_covisibility needs a resident GBA problem"; return (int)COVGPU_ERR_INVALID_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const DevProblem& P = c->P;
+    std::vector<int> iota(P.K);
+    for (int k = 0; k < P.K; ++k) iota[k] = k;
+    int* d_key = nullptr;
+    HIPCHK(hipMalloc((void**)&d_key, sizeof(int) * (size_t)P.K));
+    HIPCHK(hipMemcpyAsync(d_key, iota.data(), sizeof(int) * (size_t)P.K, hipMemcpyHostToDevice, c->st));
+    PairLists pl;
+    const bool ok = build_pairs_device(P.L, P.K, P.lm_obs_ptr, P.obs_kf, d_key, false, c->st, pl);
+    (void)hipFree(d_key);
+    if (!ok) { g_err = "covgpu_covisibility: device allocation failed"; return (int)COVGPU_ERR_OUT_OF_MEMORY; }
+    std::vector<int> pi(pl.npairs), pj(pl.npairs), pp((size_t)pl.npairs + 1);
+    if (pl.npairs) {
+      HIPCHK(hipMemcpyAsync(pi.data(), pl.pair_i, sizeof(int) * (size_t)pl.npairs, hipMemcpyDeviceToHost, c->st));
+      HIPCHK(hipMemcpyAsync(pj.data(), pl.pair_j, sizeof(int) * (size_t)pl.npairs, hipMemcpyDeviceToHost, c->st));
+    }
+    HIPCHK(hipMemcpyAsync(pp.data(), pl.pair_ptr, sizeof(int) * ((size_t)pl.npairs + 1), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    for (int* q : {pl.pair_ptr, pl.pair_i, pl.pair_j}) if (q) (void)hipFree(q);
+    int64_t n = 0;
+    for (int q = 0; q < pl.npairs; ++q) {
+      const int w = pp[q + 1] - pp[q];
+      if (w < threshold) continue;
+      if (n < capacity) { kf_i[n] = pi[q]; kf_j[n] = pj[q]; weight[n] = w; }
+      ++n;
+    }
+    *count = n;
+    return (int)COVGPU_OK;
+  });
 }
 
 extern "C" int covgpu_linearize_reprojection(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double* r, double* Jp,

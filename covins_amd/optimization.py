@@ -37,27 +37,49 @@ class Optimization:
                                outlier_removal: bool = True, estimate_bias: bool = False, *, params: Optional[OptParams] = None,
                                ctx: Optional[backend.Context] = None) -> Dict[str, object]:
         """`time_limit` and `estimate_bias` are accepted and ignored, exactly like the reference (never read)."""
+        import time
         prm = params or OptParams()
         own = ctx is None
         ctx = ctx or backend.Context()
         info: Dict[str, object] = {}
+        st: Dict[str, float] = {}   # stage seconds of this call (bench.py e2e_call)
+        info["stages_s"] = st
+
+        def add(key, t0):
+            st[key] = st.get(key, 0.0) + time.perf_counter() - t0
+
+        def solve(prob, opt):
+            sol, res = ctx.gba_solve(prob, opt)
+            st["upload (host plan + H2D)"] = st.get("upload (host plan + H2D)", 0.0) + res.t_upload_s
+            st["solve"] = st.get("solve", 0.0) + res.t_solve_s
+            st["download"] = st.get("download", 0.0) + res.t_download_s
+            return sol, res
         try:
             if outlier_removal:  # first round (opt_be.cpp:62-293): 5 iterations, loop edges without loss, then erase outliers
+                t0 = time.perf_counter()
                 prob, idx = mapdata.flatten_gba(map_, visual_only, loop_loss=False, use_loops=True)
+                add("flatten", t0)
                 opt = backend.default_options(strategy=prm.strategy, max_iterations=5, visual_only=int(visual_only))
-                sol, res = ctx.gba_solve(prob, opt)
+                sol, res = solve(prob, opt)
                 # problem.Evaluate applies the loss (opt_be.cpp:270-274); decisions taken on the device at the resident estimate
+                t0 = time.perf_counter()
                 bad, lm_left, (n_bad, n_short) = ctx.outlier_pass(prob.O, prob.L, prm.th_gba_outlier_global)
+                add("outlier pass", t0)
                 info["landmarks_left_short"] = n_short
+                t0 = time.perf_counter()
                 mask = np.zeros(map_.O, bool)
                 mask[idx.obs_rows[bad]] = True
                 map_.erase_observations(mask)
+                add("erase observations", t0)
                 info["outliers_removed"] = int(bad.sum()); info["round1"] = res
                 # NB: the outlier round's estimate is discarded — round 2 restarts from the map state (opt_be.cpp:327,454)
+            t0 = time.perf_counter()
             prob, idx = mapdata.flatten_gba(map_, visual_only, loop_loss=True, use_loops=prm.gba_use_map_loop_constraints,
                                             fix_loaded=prm.gba_fix_poses_loaded_maps)
+            add("flatten", t0)
             opt = backend.default_options(strategy=prm.strategy, max_iterations=int(interations_limit), visual_only=int(visual_only))
-            sol, res = ctx.gba_solve(prob, opt)
+            sol, res = solve(prob, opt)
+            t0 = time.perf_counter()
             info["round2"] = res; info["problem"] = (prob.K, prob.L, prob.O, prob.I, prob.E)
             # write-back (opt_be.cpp:572-609); Ceres2Transform normalises q (utils_base.cpp:38-40)
             q = sol.kf_pose[:, :4] / np.linalg.norm(sol.kf_pose[:, :4], axis=1, keepdims=True)
@@ -70,7 +92,10 @@ class Optimization:
             map_.kf_gba_optimized[idx.kf_rows] = True
             map_.lm_pos[idx.lm_rows] = sol.lm_pos
             map_.lm_gba_optimized[idx.lm_rows] = True
+            add("write-back", t0)
+            t0 = time.perf_counter()
             info["cleaned"] = map_.clean()  # map->Clean() (opt_be.cpp:614)
+            add("Map::Clean", t0)
         finally:
             if own:
                 ctx.close()

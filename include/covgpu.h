@@ -190,6 +190,13 @@ int covgpu_reprojection_residual_norms(covgpu_context* ctx, const covgpu_options
 int covgpu_outlier_pass(covgpu_context* ctx, double threshold, uint8_t* obs_erase /* [O] */, int32_t* lm_left /* [L] */,
                         int64_t* counts /* [2] or NULL */);
 
+/* Covisibility recount on the resident problem (Keyframe::UpdateCovisibilityConnections, keyframe_be.cpp:559-608; run over all
+ * keyframes after a GBA, backend.cpp:164-167): weight(i, j) = number of landmarks both keyframes observe.
+ * Pairs with weight >= threshold (sys.covis_thres) are returned as kf_i > kf_j, sorted by (kf_i, kf_j); constant keyframes
+ * take part. *count = pairs found (call again with a larger capacity if it exceeds it). Counted on the device (k_pairs.hip). */
+int covgpu_covisibility(covgpu_context* ctx, int32_t threshold, int64_t capacity, int32_t* kf_i, int32_t* kf_j, int32_t* weight,
+                        int64_t* count);
+
 /* Batched Optimization::OptimizeRelativePose (optimization_be.cpp:620-831): refines the relative pose
  * T_AB of MANY keyframe pairs (loop candidates, placerec_be.cpp:116-165) in one launch, one wavefront per pair. Per
  * correspondence two reprojection residuals — kNormal: pi_A(R_AB P_B + t_AB) vs kp_A, kInverse: pi_B(R_AB^T (P_A - t_AB))

@@ -402,3 +402,20 @@ def test_batched_relative_pose_matches_oracle(ctx, dist_type):
         if inl[b] == 0:
             assert np.array_equal(T[b], few["T0"][b])
     assert (inl == 0).any()
+
+
+def test_covisibility_recount(ctx, small_map):
+    """covgpu_covisibility (Keyframe::UpdateCovisibilityConnections, keyframe_be.cpp:559-608) against the definition: weight =
+    number of common landmarks = (A^T A)_ij of the landmark x keyframe incidence matrix, threshold sys.covis_thres."""
+    import scipy.sparse as sp
+    p = mapdata.flatten_gba(small_map, False, True)[0]
+    g, _ = opts()
+    ctx.upload(p, g)
+    obs_lm = np.repeat(np.arange(p.L), np.diff(p.lm_obs_ptr))
+    A = sp.csr_matrix((np.ones(p.O), (obs_lm, p.obs_kf)), shape=(p.L, p.K))
+    W = (A.T @ A).toarray().astype(int)
+    for th in (1, 15, 40):
+        ki, kj, w = ctx.covisibility(th)
+        ref = [(i, j, W[i, j]) for i in range(p.K) for j in range(i) if W[i, j] >= th]
+        assert len(ref) > 0 or th == 40
+        assert list(zip(ki.tolist(), kj.tolist(), w.tolist())) == ref

@@ -40,11 +40,24 @@ struct Builder {
     return n;
   }
 
+  // A region that is not cut further becomes TWO fronts: its pose blocks (parent) and, below them, its speed-bias blocks.
+  // Speed-bias blocks couple to their own and the neighbouring keyframes' poses and speed-bias blocks only — never to the far
+  // border a trajectory segment carries (separators, shared keyframes of other agents). In one front [V | P | border] the
+  // dense kernels would run the V columns through the whole border (zeros): 60 % of a leaf's columns. As a child front the V
+  // chain is a small system of its own and the pose front above it is a single 256-column panel.
+  void leaf(std::vector<int>& vars, int parent) {
+    std::vector<int> P, V;
+    for (int v : vars) ((v & 1) ? V : P).push_back(v);
+    if (P.empty() || V.empty() || leaf_dims >= (1 << 29)) { new_node(vars, parent); return; }  // (COVGPU_GBA_DENSE: one front = the dense system)
+    const int np = new_node(P, parent);
+    new_node(V, np);
+  }
+
   void build(std::vector<int>& vars, int parent) {
     if (vars.empty()) return;
     int dims = 0;
     for (int v : vars) dims += NdHostPlan::vdim(v);
-    if (dims <= leaf_dims) { new_node(vars, parent); return; }
+    if (dims <= leaf_dims) { leaf(vars, parent); return; }
     // ---- parts of the cut. Several agents: one part per agent — ONE cover of all cross-agent couplings (loop-closure
     //      zones are hot spots where several agents meet: a keyframe there covers links to all of them at once; pairwise
     //      agent cuts needed 1.5x more separator unknowns on the 5-agent map). One agent: two halves of its time axis.
@@ -61,7 +74,7 @@ struct Builder {
       for (int v : vars) pos.push_back(v >> 1);
       std::sort(pos.begin(), pos.end());
       pos.erase(std::unique(pos.begin(), pos.end()), pos.end());
-      if (pos.size() < 2) { new_node(vars, parent); return; }
+      if (pos.size() < 2) { leaf(vars, parent); return; }
       const int m = pos[pos.size() / 2];
       for (int v : vars) side[v] = (v >> 1) >= m;
     }

@@ -99,14 +99,16 @@ def _replay(S, b, parent, level, own, st, D):
     return x
 
 
-@pytest.mark.parametrize("leaf", [90, 200, 100000])
+@pytest.mark.parametrize("leaf", [90, 200, 100000, 0x3fffffff])
 def test_replay_equals_dense_solve(small_map, leaf):
     prob, _ = mapdata.flatten_gba(small_map, visual_only=False, loop_loss=True)
     opt = covo.default_options()
     S, bvec, _ = covo.schur(prob, opt, 1e-4)
     info, parent, level, own, st = _plan(prob, backend.default_options(), leaf)
-    if leaf >= 100000:
-        assert info[0] == 1 and info[1] == 1     # one front = the dense system
+    if leaf >= 0x3fffffff:
+        assert info[0] == 1 and info[1] == 1     # one front = the dense system (COVGPU_GBA_DENSE)
+    elif leaf >= 100000:
+        assert info[0] == 2 and info[1] == 2     # nothing is cut: the pose front and, below it, the speed-bias front
     else:
         assert info[0] > 3 and info[1] >= 2
     x = _replay(S, bvec, parent, level, own, st, 15)

@@ -15,7 +15,7 @@ for name in names:
     prob, _ = mapdata.flatten_gba(m, visual_only=False, loop_loss=True)
     dxo, dlo = covo.step(prob, covo.default_options(), 1e-6, dense=False) if prob.K < 400 else (None, None)
     co = covo.cost(prob, covo.default_options()) if prob.K < 400 else None
-    for leaf in ["100000", "150", "300", "900"]:
+    for leaf in ["100000", "150", "300", "600"]:
         os.environ["COVGPU_ND_LEAF"] = leaf
         ctx = backend.Context(0)
         try:

@@ -207,19 +207,24 @@ void nd_shard_assign(NdHostPlan& hp, int world) {
   for (int n = nn - 1; n >= 0; --n) { sub[n] += w[n]; if (hp.parent[n] >= 0) sub[hp.parent[n]] += sub[n]; }  // children have higher indices
   std::vector<char> top(nn, 0);
   std::vector<int> cand;
-  for (int n = 0; n < nn; ++n) if (hp.parent[n] < 0) { top[n] = 1; for (int c : hp.child[n]) cand.push_back(c); }
+  double top_bytes = 0.0;
+  for (int n = 0; n < nn; ++n)
+    if (hp.parent[n] < 0) { top[n] = 1; top_bytes += 8.0 * (double)hp.own_dims[n] * hp.own_dims[n]; for (int c : hp.child[n]) cand.push_back(c); }
   for (int it = 0; it < 256; ++it) {
     if (cand.empty()) break;
     std::sort(cand.begin(), cand.end(), [&](int a, int b) { return sub[a] != sub[b] ? sub[a] > sub[b] : a < b; });
     double tot = 0.0;
     for (int c : cand) tot += sub[c];
-    if ((int)cand.size() >= 2 * world && sub[cand[0]] <= 0.6 * tot / world) break;
+    // enough pieces and none much heavier than a rank's fair share: stop. Opening a node makes it a TOP node — its whole front
+    // joins the all-reduced range and its factorisation is replicated — so the top is also capped at 96 MiB of fronts.
+    if ((int)cand.size() >= world && sub[cand[0]] <= 1.25 * tot / world) break;
+    if ((int)cand.size() >= world && top_bytes > 96.0 * 1048576.0) break;
     int pick = -1;
     for (size_t q = 0; q < cand.size() && pick < 0; ++q) if (!hp.child[cand[q]].empty()) pick = (int)q;  // heaviest that can still be opened
     if (pick < 0) break;
     const int c = cand[pick];
     cand.erase(cand.begin() + pick);
-    top[c] = 1;
+    top[c] = 1; top_bytes += 8.0 * (double)(hp.own_dims[c] + hp.st_dims[c]) * (double)(hp.own_dims[c] + hp.st_dims[c]);
     for (int d : hp.child[c]) cand.push_back(d);
   }
   std::sort(cand.begin(), cand.end(), [&](int a, int b) { return sub[a] != sub[b] ? sub[a] > sub[b] : a < b; });

@@ -5,12 +5,15 @@
 A "step" = one pass of the hot path over one map = one `covgpu_solve_resident` call, i.e. the whole
 ceres::Solve replacement of GlobalBundleAdjustment (optimization_be.cpp:560-567) with the reference's
 iteration cap (opt.gba_iteration_limit = 10): preintegration, then per trust-region iteration
-linearise + Schur + dense MFMA Cholesky + step + cost evaluation. Inputs are uploaded to HBM before the
-timed region; every step restarts from the same uploaded initial estimate.
+linearise + landmark Schur + multifrontal MFMA Cholesky of the reduced camera system + trust-region step + cost evaluation.
+Inputs are uploaded to HBM before the timed region; every step restarts from the same uploaded initial estimate. With
+--gpus N (one process per GPU) the ONE map is sharded by subtree of the elimination tree and every rank runs the same
+iterations (strong scaling); the collectives are issued by libcovgpu over RCCL.
 
 The timed region runs WITHOUT profiling events; one extra, un-timed step with profiling on supplies the phase times
 and the per-launch kernel durations of the `roofline` object. `cpu_baseline` runs the oracle (CPU port of the same
-algorithm; block-sparse reduced system solved by scipy's SuperLU) on THE SAME workload in the same run and
+algorithm on all host threads; reduced system by the threaded multifrontal port) on THE SAME workload in the same run, three
+repetitions, median, and
 `delta_ate_gpu_cpu_m` compares the two final trajectories (north star: within 1e-3 m).
 
 Prints ONE JSON line on rank 0.

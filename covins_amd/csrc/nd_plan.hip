@@ -48,9 +48,24 @@ struct Builder {
   void leaf(std::vector<int>& vars, int parent) {
     std::vector<int> P, V;
     for (int v : vars) ((v & 1) ? V : P).push_back(v);
-    if (P.empty() || V.empty() || leaf_dims >= (1 << 29)) { new_node(vars, parent); return; }  // (COVGPU_GBA_DENSE: one front = the dense system)
+    if (V.empty() || (P.empty() && V.size() <= 28) || leaf_dims >= (1 << 29)) { new_node(vars, parent); return; }  // (COVGPU_GBA_DENSE: one front = the dense system)
+    // The speed-bias chain is cut into segments of at most 28 blocks (252 unknowns: ONE 256-column panel for the whole
+    // bottom level instead of up to three): a cut block joins the pose front — it is the separator of its two neighbours.
+    std::sort(V.begin(), V.end());
+    const int nV = (int)V.size(), pd = 6 * (int)P.size();
+    int s = (nV + 1 + 28) / 29;
+    while (s > 1 && pd <= 256 && pd + 9 * (s - 1) > 256) --s;   // keep the pose front a single panel
+    std::vector<std::vector<int>> seg(s);
+    {
+      const int rest = nV - (s - 1), base = rest / s, extra = rest % s;
+      int q = 0;
+      for (int k = 0; k < s; ++k) {
+        for (int i = 0; i < base + (k < extra ? 1 : 0); ++i) seg[k].push_back(V[q++]);
+        if (k + 1 < s) P.push_back(V[q++]);
+      }
+    }
     const int np = new_node(P, parent);
-    new_node(V, np);
+    for (auto& sg : seg) if (!sg.empty()) new_node(sg, np);
   }
 
   void build(std::vector<int>& vars, int parent) {
@@ -151,6 +166,47 @@ bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs
     while (out.depth[n] > out.depth[a]) n = out.parent[n];
     return n == a;
   };
+  // ---- panel balance. The levels (node heights) run one after the other and a level costs one serial panel chain per 256
+  //      columns of its WIDEST front. Where the widest fronts of a level exceed a panel boundary by little, the excess
+  //      unknowns move up into the parent's front (an ancestor's separator may always take more vertices: they leave the
+  //      child's region) — if that does not push the parent's level over a boundary of its own.
+  {
+    std::vector<int> hgt(nn, 0);
+    int nlev = 0;
+    for (int n = nn - 1; n >= 0; --n) { for (int c : out.child[n]) hgt[n] = std::max(hgt[n], hgt[c] + 1); nlev = std::max(nlev, hgt[n] + 1); }
+    auto panels = [](int d) { return std::max(1, (d + 255) / 256); };
+    std::vector<int> levc(nlev, 1);
+    for (int n = 0; n < nn; ++n) levc[hgt[n]] = std::max(levc[hgt[n]], panels(out.own_dims[n]));
+    for (int l = 0; l + 1 < nlev; ++l) {
+      const int m = levc[l];
+      if (m < 2) continue;
+      std::vector<std::pair<int, int>> moves;  // (node, number of trailing own variables that move up)
+      std::vector<int> extra(nn, 0);
+      bool ok = true;
+      for (int n = 0; n < nn && ok; ++n) {
+        if (hgt[n] != l || panels(out.own_dims[n]) < m) continue;
+        const int need = out.own_dims[n] - 256 * (m - 1);
+        int cnt = 0, mv = 0;
+        for (size_t q = out.own[n].size(); q-- > 0 && mv < need;) { mv += NdHostPlan::vdim(out.own[n][q]); ++cnt; }
+        if (need > 64 || out.parent[n] < 0 || cnt >= (int)out.own[n].size()) { ok = false; break; }
+        moves.emplace_back(n, cnt); extra[out.parent[n]] += mv;
+      }
+      for (int n = 0; n < nn && ok; ++n) if (extra[n] && panels(out.own_dims[n] + extra[n]) > levc[hgt[n]]) ok = false;
+      if (!ok) continue;
+      for (auto& mvp : moves) {
+        const int n = mvp.first, pn = out.parent[n];
+        std::vector<int> up(out.own[n].end() - mvp.second, out.own[n].end());
+        out.own[n].resize(out.own[n].size() - mvp.second);
+        for (int v : up) out.own[pn].push_back(v);
+        for (int node : {n, pn}) {
+          int off = 0, ord = 0;
+          for (int v : out.own[node]) { out.vnode[v] = node; out.voff[v] = off; out.vord[v] = ord++; off += NdHostPlan::vdim(v); }
+          out.own_dims[node] = off;
+        }
+      }
+      levc[l] = m - 1;
+    }
+  }
   // ---- symbolic factorisation, children before parents (a child's index is always above its parent's)
   out.strct.assign(nn, {});
   out.st_dims.assign(nn, 0);

@@ -206,13 +206,21 @@ void launch_zero_system(const DevProblem& P, hipStream_t st);       // every sma
 struct CholAux {
   hipStream_t aux = nullptr, mid = nullptr, head = nullptr;
   hipEvent_t ev_fill = nullptr;  // pose system cleared (head stream, beside the linearisation)
+  hipEvent_t ev_xb = nullptr;    // multifrontal look-ahead: second half of a level's extend-add done (bulk stream)
+  int* bwd_cnt = nullptr;        // ticket counters of k_bwd_front (65536, zero between launches)
+  double* bwd_scr = nullptr; size_t bwd_scr_elems = 0;   // its scratch (grown on demand by launch_nd_solve)
+  hipEvent_t ev_xa = nullptr;    // ... the chain's stream has enqueued the level below completely
   hipEvent_t ev_sb = nullptr, ev_cf = nullptr, ev_g = nullptr, ev_z = nullptr;  // speed-bias rows ready | chain factor done | Gramians done (mid) | chain sweeps done (aux)
   bool cf_pending = false;
   std::vector<hipEvent_t> ev, prof_ev, panel_ev;  // panel_ev: start of every big panel on the main stream (COVGPU_TRACE_PANELS=1)
   std::vector<double> prof_flops;
   // per big panel of the batched (arrow) factorisation: device list of the LIVE (batch, ti, tj) tiles of its bulk update,
   // interleaved so that list position p runs on XCD p % 8 and every XCD gets the same number of tiles (k_chol.hip)
-  struct TriCache { std::vector<int*> list; std::vector<int> count; int key = -1; void clear(); };
+  struct TriCache {
+    std::vector<int*> list; std::vector<int> count; int key = -1;
+    int *listA = nullptr, *listB = nullptr; int countA = 0, countB = 0;   // last panel's update split at DenseBatch::split_ta
+    void clear();
+  };
   TriCache tri0;                  // block-arrow batches of the pose-graph solve (k_pgo.hip)
   std::vector<TriCache> tri_lev;  // one per level of the multifrontal solve (k_front.hip), selected by DenseBatch::tri_slot
   void tri_clear();
@@ -250,6 +258,14 @@ struct DenseBatch {
   const long long* tab = nullptr;  // per-matrix (element offset, leading dimension): fronts of unequal order in one batch (GemmArgs::btab)
   int tri_slot = -1;               // which CholAux::tri_lev entry caches the live-tile lists of this batch's bulk updates
   BwdXfer xfer;                    // dense_backward_solve only
+  // Look-ahead ACROSS levels of the multifrontal solve (k_front.hip): split_ta > 0 splits the trailing update of the batch's last
+  // panel — border tile rows < split_ta (what the parents' FIRST panel receives) on the chain's stream, the rest on the bulk
+  // stream, which the caller continues with the second half of the extend-add while the parents' first panel is factored.
+  // pre_trsm: event the first panel's substitutions wait for (the caller's second-half extend-add of THIS batch's fronts).
+  int split_ta = 0;
+  hipEvent_t pre_trsm = nullptr;
+  int* bwd_cnt = nullptr;          // [n] zeroed ticket counters: whole-front backward substitution in one launch (k_panel.hip: k_bwd_front)
+  double* bwd_scr = nullptr;       // its scratch: [n][interior tiles <= 4][row chunks][128]
   int own_max = 0;                 // > 0: largest real interior order over the batch — columns beyond it are identity padding in EVERY
                                    // matrix (L = I, block inverses = I, y = 0 already in place), so the panel kernel factors only the
                                    // 16-column blocks that hold a real column and skips all-padding panels
@@ -263,6 +279,8 @@ void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* 
                         hipStream_t st, const long long* btab = nullptr, int nb = -1);  // nb: 16-column blocks to factor (-1: the whole panel)
 void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, double* x, int ncol, int nbt, size_t sM, size_t sR, hipStream_t st,
                       const long long* btab, const int* live, int tI, BwdXfer xf = BwdXfer());
+void launch_bwd_front(const double* S, int tI, int ntiles, int nchunk, double* y, const double* Linv, int nbt, size_t sL, size_t sR, hipStream_t st,
+                      const long long* btab, const int* live, BwdXfer xf, int* cnt, double* scr);
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
                      size_t sR, const int* live, int tI, hipStream_t st, bool chain = false, const long long* btab = nullptr, int nb = -1);
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,
@@ -301,7 +319,9 @@ struct NdLevel {
   std::vector<int> live_h;
   int own_max = 0;                        // largest real interior order of the batch (DenseBatch::own_max)
   int ext_first = 0, ext_count = 0;       // extend-add work list (NdDev::ext) for the SUBTREE children of this level's fronts
-  int ext2_first = 0, ext2_count = 0;     // ... for their TOP children (top levels of a sharded solve only)
+  int ext_countA = 0;                     // ... of which the first ext_countA tiles lie in the fronts' first 256 rows (first panel)
+  int split_ta = 0;                       // border tiles (128) of this level's fronts that reach their parents' first 256 columns (max)
+  int ext2_first = 0, ext2_count = 0, ext2_countA = 0;   // ... for their TOP children (top levels of a sharded solve only)
 };
 struct NdDev {
   bool active = false;

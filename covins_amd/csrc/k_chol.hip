@@ -286,9 +286,15 @@ void CholAux::init() {
   if (!ev_g) (void)hipEventCreateWithFlags(&ev_g, hipEventDisableTiming);
   if (!ev_z) (void)hipEventCreateWithFlags(&ev_z, hipEventDisableTiming);
   if (!ev_fill) (void)hipEventCreateWithFlags(&ev_fill, hipEventDisableTiming);
+  if (!ev_xb) (void)hipEventCreateWithFlags(&ev_xb, hipEventDisableTiming);
+  if (!ev_xa) (void)hipEventCreateWithFlags(&ev_xa, hipEventDisableTiming);
+  if (!bwd_cnt && hipMalloc((void**)&bwd_cnt, 65536 * sizeof(int)) == hipSuccess) (void)hipMemset(bwd_cnt, 0, 65536 * sizeof(int));
 }
 void CholAux::TriCache::clear() {
   for (int* p : list) if (p) (void)hipFree(p);
+  if (listA) (void)hipFree(listA);
+  if (listB) (void)hipFree(listB);
+  listA = listB = nullptr; countA = countB = 0;
   list.clear(); count.clear(); key = -1;
 }
 void CholAux::tri_clear() {
@@ -309,6 +315,10 @@ void CholAux::destroy() {
   if (ev_g) { (void)hipEventDestroy(ev_g); ev_g = nullptr; }
   if (ev_z) { (void)hipEventDestroy(ev_z); ev_z = nullptr; }
   if (ev_fill) { (void)hipEventDestroy(ev_fill); ev_fill = nullptr; }
+  if (ev_xb) { (void)hipEventDestroy(ev_xb); ev_xb = nullptr; }
+  if (ev_xa) { (void)hipEventDestroy(ev_xa); ev_xa = nullptr; }
+  if (bwd_cnt) { (void)hipFree(bwd_cnt); bwd_cnt = nullptr; }
+  if (bwd_scr) { (void)hipFree(bwd_scr); bwd_scr = nullptr; bwd_scr_elems = 0; }
   cf_pending = false;
   if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
 }
@@ -356,7 +366,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   // events per big panel: H rows-h done | B bulk done | C rows-r done | 1 potrf(t0) | 2 X(t0+1,t0) | 3 potrf(t0+1) | Rc next diagonal updated
   while ((int)ax.ev.size() < 8 * (NP + 1)) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ax.ev.push_back(e); }
   // (a solve may factorise several matrices — arrow blocks, then the border system: launches accumulate until collect())
-  if (ax.profile) while (ax.prof_ev.size() < 2 * (ax.prof_flops.size() + (size_t)NP)) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev.push_back(e); }
+  if (ax.profile) while (ax.prof_ev.size() < 2 * (ax.prof_flops.size() + (size_t)NP + 1)) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev.push_back(e); }
   hipEvent_t* eH = ax.ev.data();
   hipEvent_t* eB = eH + (NP + 1);
   hipEvent_t* eC = eB + (NP + 1);
@@ -396,44 +406,56 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   };
   if (bt.tri_slot >= (int)ax.tri_lev.size()) ax.tri_lev.resize(bt.tri_slot + 1);
   CholAux::TriCache& tc = bt.tri_slot >= 0 ? ax.tri_lev[bt.tri_slot] : ax.tri0;
-  if (bt.live_h != nullptr && tc.key != T * 4096 + nbt) {  // live-tile lists of every panel's bulk update (static per problem)
+  // live tiles (i, j), j <= i, of the triangle that starts at tile tb, for the fronts whose interior reaches panel column t0;
+  // part 0: all | 1: rows i < split_ta | 2: rows i >= split_ta. XCD-balanced, interleaved (position p runs on XCD p % 8).
+  auto build_list = [&](int t0, int tb, int part, int*& d_out, int& n_out) {
+    d_out = nullptr; n_out = 0;
+    std::vector<int> q[8];  // per-XCD queues; whole 8x8 supertiles of one batch go to the currently shortest queue
+    for (int a = 0; a < nbt; ++a) {
+      const int nI = bt.live_h[2 * a], nO = bt.live_h[2 * a + 1];
+      if (t0 >= nI) continue;
+      auto live = [&](int t) { return t < nI || (t >= bt.tI && t - bt.tI < nO); };
+      const int nt = T - tb, Ts = (nt + 7) / 8;
+      for (int si = 0; si < Ts; ++si)
+        for (int sj = 0; sj <= si; ++sj) {
+          std::vector<int> grp;
+          for (int i = 8 * si; i < std::min(nt, 8 * si + 8); ++i)
+            for (int j = 8 * sj; j < std::min(i + 1, 8 * sj + 8); ++j)
+              if (live(tb + i) && live(tb + j) && (part == 0 || (i < bt.split_ta) == (part == 1))) grp.push_back((a << 20) | (i << 10) | j);
+          if (grp.empty()) continue;
+          int best = 0;
+          for (int x = 1; x < 8; ++x) if (q[x].size() < q[best].size()) best = x;
+          q[best].insert(q[best].end(), grp.begin(), grp.end());
+        }
+    }
+    size_t longest = 0;
+    for (int x = 0; x < 8; ++x) longest = std::max(longest, q[x].size());
+    if (longest == 0) return true;
+    std::vector<int> lst(8 * longest, -1);
+    for (int x = 0; x < 8; ++x) for (size_t k = 0; k < q[x].size(); ++k) lst[8 * k + x] = q[x][k];
+    if (hipMalloc((void**)&d_out, lst.size() * sizeof(int)) != hipSuccess) { d_out = nullptr; return false; }
+    (void)hipMemcpy(d_out, lst.data(), lst.size() * sizeof(int), hipMemcpyHostToDevice);
+    n_out = (int)lst.size();
+    return true;
+  };
+  const int key = (T * 4096 + nbt) * 8 + bt.split_ta;
+  if (bt.live_h != nullptr && tc.key != key) {  // live-tile lists of every panel's bulk update (static per problem)
     tc.clear();
-    tc.key = T * 4096 + nbt;
+    tc.key = key;
     tc.list.assign(NP, nullptr); tc.count.assign(NP, 0);
     for (int P = 0; P < NP && P < Pstop; ++P) {
       // (the LAST panel of a partial factorisation applies its whole trailing update in one launch: triangle from t0 + 2)
-      const int t0 = 2 * P, tb = (Pstop < NP && P == Pstop - 1) ? t0 + 2 : t0 + 4;
+      const bool last = Pstop < NP && P == Pstop - 1;
+      const int t0 = 2 * P, tb = last ? t0 + 2 : t0 + 4;
       if (tb >= T) break;
-      std::vector<int> q[8];  // per-XCD queues; whole 8x8 supertiles of one batch go to the currently shortest queue
-      for (int a = 0; a < nbt; ++a) {
-        const int nI = bt.live_h[2 * a], nO = bt.live_h[2 * a + 1];
-        if (t0 >= nI) continue;
-        auto live = [&](int t) { return t < nI || (t >= bt.tI && t - bt.tI < nO); };
-        const int nt = T - tb, Ts = (nt + 7) / 8;
-        for (int si = 0; si < Ts; ++si)
-          for (int sj = 0; sj <= si; ++sj) {
-            std::vector<int> grp;
-            for (int i = 8 * si; i < std::min(nt, 8 * si + 8); ++i)
-              for (int j = 8 * sj; j < std::min(i + 1, 8 * sj + 8); ++j)
-                if (live(tb + i) && live(tb + j)) grp.push_back((a << 20) | (i << 10) | j);
-            if (grp.empty()) continue;
-            int best = 0;
-            for (int x = 1; x < 8; ++x) if (q[x].size() < q[best].size()) best = x;
-            q[best].insert(q[best].end(), grp.begin(), grp.end());
-          }
-      }
-      size_t longest = 0;
-      for (int x = 0; x < 8; ++x) longest = std::max(longest, q[x].size());
-      if (longest == 0) continue;
-      std::vector<int> lst(8 * longest, -1);
-      for (int x = 0; x < 8; ++x) for (size_t k = 0; k < q[x].size(); ++k) lst[8 * k + x] = q[x][k];
-      int* d = nullptr;
-      if (hipMalloc((void**)&d, lst.size() * sizeof(int)) != hipSuccess) { tc.clear(); break; }
-      (void)hipMemcpy(d, lst.data(), lst.size() * sizeof(int), hipMemcpyHostToDevice);
-      tc.list[P] = d; tc.count[P] = (int)lst.size();
+      bool ok = true;
+      if (last && bt.split_ta > 0) ok = build_list(t0, tb, 1, tc.listA, tc.countA) && build_list(t0, tb, 2, tc.listB, tc.countB);
+      else ok = build_list(t0, tb, 0, tc.list[P], tc.count[P]);
+      if (!ok) { tc.clear(); break; }
     }
   }
   int Plast = NP - 1;
+  bool split_last = false;  // the last panel's bulk update was left running on B for the caller (DenseBatch::split_ta)
   for (int P = 0; P < NP; ++P) {
     const int t0 = 2 * P, w = (T - t0 >= 2) ? 2 : 1;
     const int h0 = (t0 + 2 < T) ? t0 + 2 : T, h1 = (t0 + 4 < T) ? t0 + 4 : T;  // rows h = [h0, h1), rows r = [h1, T)
@@ -470,39 +492,57 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // triangle, three dependent launches on the chain's own stream.
       const int nbp = bt.own_max > 0 ? std::max(0, std::min(8 * w, (bt.own_max - t0 * kTile + 15) / 16)) : -1;
       launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp);
+      if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
       (void)hipEventRecord(e1[P], M);
+      bool split_done = false;
       if (T > h0) {
         if (P > 0) { if (h1 > h0) wait(M, eHp[P]); if (T > h1) wait(M, e2[P]); }
         launch_trsm_sub(S, ld, t0, w, h0, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp);
         if (P >= 1) wait(M, eB[P - 1]);  // bulk(P-1) was the previous writer of the trailing tiles
         const int tb = h0, nt = T - tb;
-        if (kd(P) > 0) {
-          const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
+        auto syrk = [&](hipStream_t s2, const int* list, int count, double pairs) {
           GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab};
-          const bool listed = bt.live_h != nullptr && P < (int)tc.list.size() && tc.list[P] != nullptr;
-          if (listed) g.tri = tc.list[P];
-          if (!listed || tc.count[P] > 0) {
-            double pairs = 0.0;
-            for (int a = 0; a < nbt; ++a) {
-              if (bt.live_h == nullptr) { pairs += (double)nt * (nt + 1) / 2; continue; }
-              const int nI = bt.live_h[2 * a], nO = bt.live_h[2 * a + 1];
-              if (t0 >= nI) continue;
-              int nl = 0;
-              for (int t = tb; t < T; ++t) nl += (t < nI || (t >= bt.tI && t - bt.tI < nO)) ? 1 : 0;
-              pairs += (double)nl * (nl + 1) / 2;
-            }
-            if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], M);
-            if (listed) hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(tc.count[P], 1), dim3(256), lds_gemm, M, g);
-            else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, M, g);
-            if (ax.profile) {
-              (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], M);
-              ax.prof_flops.push_back(pairs * 2.0 * kTile * kTile * kd(P));
-            }
+          g.tri = list;
+          if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], s2);
+          if (list != nullptr) hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(count, 1), dim3(256), lds_gemm, s2, g);
+          else {
+            const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
+            hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, s2, g);
+          }
+          if (ax.profile) {
+            (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], s2);
+            ax.prof_flops.push_back(pairs * 2.0 * kTile * kTile * kd(P));
+          }
+        };
+        if (kd(P) > 0) {
+          double pairs = 0.0, pairsA = 0.0;
+          for (int a = 0; a < nbt; ++a) {
+            if (bt.live_h == nullptr) { pairs += (double)nt * (nt + 1) / 2; continue; }
+            const int nI = bt.live_h[2 * a], nO = bt.live_h[2 * a + 1];
+            if (t0 >= nI) continue;
+            int nl = 0;
+            for (int t = tb; t < T; ++t) nl += (t < nI || (t >= bt.tI && t - bt.tI < nO)) ? 1 : 0;
+            pairs += (double)nl * (nl + 1) / 2;
+            const int na = std::min(nl, bt.split_ta);
+            pairsA += (double)na * (na + 1) / 2;
+          }
+          if (bt.split_ta > 0 && bt.live_h != nullptr && (tc.listA != nullptr || tc.listB != nullptr)) {
+            // look-ahead across levels: the tiles the parents' first panel receives on the chain's stream, the rest on the bulk stream
+            (void)hipEventRecord(eH[P], M);
+            if (tc.countA > 0) syrk(M, tc.listA, tc.countA, pairsA);
+            wait(B, eH[P]);
+            if (tc.countB > 0) syrk(B, tc.listB, tc.countB, pairs - pairsA);
+            (void)hipEventRecord(eB[P], B);
+            split_done = true;
+          } else {
+            const bool listed = bt.live_h != nullptr && P < (int)tc.list.size() && tc.list[P] != nullptr;
+            if (!listed || tc.count[P] > 0) syrk(M, listed ? tc.list[P] : nullptr, listed ? tc.count[P] : 0, pairs);
           }
         }
       }
-      (void)hipEventRecord(eH[P], M); (void)hipEventRecord(eC[P], M); (void)hipEventRecord(eB[P], M);
-      Plast = P;
+      (void)hipEventRecord(eH[P], M); (void)hipEventRecord(eC[P], M);
+      if (!split_done) (void)hipEventRecord(eB[P], M);
+      Plast = P; split_last = split_done;
       break;
     }
     {
@@ -510,6 +550,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // block substitution, rows r on theirs — three dependent launches per panel instead of six
       const int nbp = bt.own_max > 0 ? std::max(0, std::min(8 * w, (bt.own_max - t0 * kTile + 15) / 16)) : -1;
       launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp);
+      if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
       (void)hipEventRecord(e1[P], M);
       if (h1 > h0) {
         if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
@@ -565,7 +606,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     }
     (void)hipEventRecord(eB[P], B);
   }
-  wait(M, eB[Plast]);
+  if (!split_last) wait(M, eB[Plast]);
   if (Plast >= 1) wait(M, eB[Plast - 1]);
   wait(M, eC[Plast]);
   wait(M, eH[Plast]);
@@ -580,6 +621,16 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
 void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStream_t st, int tfact, int tend, DenseBatch bt) {
   const int nbt = bt.n > 0 ? bt.n : 1;
   const size_t ld = (size_t)npad;
+  {
+    // multifrontal front of few interior tiles: given rows and every interior tile in ONE launch (k_panel.hip: k_bwd_front)
+    const int nt_real = bt.own_max > 0 ? std::min(tfact, (bt.own_max + kTile - 1) / kTile) : tfact;
+    if (bt.bwd_cnt != nullptr && bt.bwd_scr != nullptr && bt.xfer.gidx != nullptr && bt.tab != nullptr && bt.live != nullptr && nt_real >= 1 && nt_real <= 4 &&
+        nbt <= 65536) {
+      const int nchunk = std::max(1, ((tend - tfact) * kTile + 255) / 256);
+      launch_bwd_front(S, tfact, nt_real, nchunk, b + npad, Linv, nbt, bt.sL, bt.sR, st, bt.tab, bt.live, bt.xfer, bt.bwd_cnt, bt.bwd_scr);
+      return;
+    }
+  }
   if (tend > tfact) {  // all given rows in one launch (k_panel.hip)
     launch_bwd_given(S, ld, tfact * kTile, tend * kTile, b + npad, b, tfact * kTile, nbt, bt.sM, bt.sR, st, bt.tab, bt.live, bt.tI, bt.xfer);
     tend = tfact;

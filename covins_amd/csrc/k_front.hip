@@ -139,9 +139,10 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& 
     }
   }
   // extend-add work lists: per level the 64x64 tiles of the parents' fronts that receive something from a child of either kind
-  auto worklist = [&](int l, const std::vector<int>& cptr, const std::vector<int>& cidx, int& first, int& count) {
+  auto worklist = [&](int l, const std::vector<int>& cptr, const std::vector<int>& cidx, int& first, int& count, int& countA) {
     NdLevel& L = dev.lev[l];
     first = (int)dev.h_ext.size() / 3;
+    std::vector<int> tiles;
     for (int k = 0; k < L.n; ++k) {
       const int i = L.first + k;
       const int T = (ld[i] + 63) / 64;
@@ -156,13 +157,29 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& 
         }
         for (int a : rows) for (int b : rows) if (b <= a) mark[(size_t)a * T + b] = 1;
       }
-      for (int a = 0; a < T; ++a) for (int b = 0; b <= a; ++b) if (mark[(size_t)a * T + b]) { dev.h_ext.push_back(i); dev.h_ext.push_back(a); dev.h_ext.push_back(b); }
+      for (int a = 0; a < T; ++a) for (int b = 0; b <= a; ++b) if (mark[(size_t)a * T + b]) { tiles.push_back(i); tiles.push_back(a); tiles.push_back(b); }
     }
+    // tiles of the fronts' first 256 rows (what the first panel's factorisation needs) first: NdLevel::ext_countA
+    countA = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (size_t q = 0; q < tiles.size(); q += 3)
+        if ((tiles[q + 1] < 4) == (pass == 0)) { dev.h_ext.insert(dev.h_ext.end(), tiles.begin() + q, tiles.begin() + q + 3); countA += pass == 0 ? 1 : 0; }
     count = (int)dev.h_ext.size() / 3 - first;
   };
   for (int l = 0; l < nlev; ++l) {
-    worklist(l, dev.h_cptr, dev.h_cidx, dev.lev[l].ext_first, dev.lev[l].ext_count);
-    worklist(l, dev.h_cptr2, dev.h_cidx2, dev.lev[l].ext2_first, dev.lev[l].ext2_count);
+    worklist(l, dev.h_cptr, dev.h_cidx, dev.lev[l].ext_first, dev.lev[l].ext_count, dev.lev[l].ext_countA);
+    worklist(l, dev.h_cptr2, dev.h_cidx2, dev.lev[l].ext2_first, dev.lev[l].ext2_count, dev.lev[l].ext2_countA);
+    // border tiles of this level's fronts that carry unknowns of the parents' first 256 columns (a front's border lists its
+    // parent's unknowns first, in the parent's own order)
+    NdLevel& L = dev.lev[l];
+    L.split_ta = 0;
+    for (int k = 0; k < L.n; ++k) {
+      const int n = order[L.first + k], p = hp.parent[n];
+      if (p < 0) continue;
+      int d = 0;
+      for (int v : hp.strct[n]) if (hp.vnode[v] == p && hp.voff[v] < 256) d += NdHostPlan::vdim(v);
+      L.split_ta = std::max(L.split_ta, (d + kTile - 1) / kTile);
+    }
   }
   dev.active = true;
 }
@@ -331,6 +348,18 @@ void launch_nd_zero(const DevProblem& P, const NdDev& nd, hipStream_t st) {
 
 void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hipStream_t st, CholAux& ax) {
   const int nlev = (int)nd.lev.size(), ltop = nd.top_lev0;
+  static const bool lookahead = getenv("COVGPU_ND_LOOKAHEAD") == nullptr || atoi(getenv("COVGPU_ND_LOOKAHEAD")) != 0;
+  ax.init();
+  {  // scratch of the one-launch backward substitution (k_bwd_front): [fronts][interior tiles <= 4][256-row chunks of the border][128]
+    size_t need = 0;
+    for (const NdLevel& L : nd.lev)
+      need = std::max(need, (size_t)L.n * std::min(4, (L.own_max + kTile - 1) / kTile) * std::max(1, (L.ntot - L.nI + 255) / 256) * kTile);
+    if (need > ax.bwd_scr_elems) {
+      if (ax.bwd_scr) (void)hipFree(ax.bwd_scr);
+      ax.bwd_scr = nullptr; ax.bwd_scr_elems = 0;
+      if (hipMalloc((void**)&ax.bwd_scr, need * sizeof(double)) == hipSuccess) ax.bwd_scr_elems = need;
+    }
+  }
   ax.mark(st, -1);
   hipMemsetAsync(P.nd_rhs, 0, nd.rhs_elems * sizeof(double), st);
   {
@@ -346,26 +375,56 @@ void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     bt.tab = P.nd_ntab + 2 * (size_t)L.first; bt.tri_slot = l; bt.own_max = L.own_max;
     return bt;
   };
-  auto extend = [&](int l, bool top_children) {
+  // part: 0 all tiles | 1 the tiles of the fronts' first 256 rows | 2 the others
+  auto extend = [&](int l, bool top_children, int part, hipStream_t s2) {
     const NdLevel& L = nd.lev[l];
-    const int first = top_children ? L.ext2_first : L.ext_first, count = top_children ? L.ext2_count : L.ext_count;
+    int first = top_children ? L.ext2_first : L.ext_first, count = top_children ? L.ext2_count : L.ext_count;
+    const int countA = top_children ? L.ext2_countA : L.ext_countA;
+    if (part == 1) count = countA;
+    if (part == 2) { first += countA; count -= countA; }
     if (count > 0)
-      hipLaunchKernelGGL(k_nd_extend, dim3(count), dim3(256), 0, st, P, lev_args(P, nd, l), (const int*)nd.rhs_node, (const int*)(nd.ext + 3 * (size_t)first),
+      hipLaunchKernelGGL(k_nd_extend, dim3(count), dim3(256), 0, s2, P, lev_args(P, nd, l), (const int*)nd.rhs_node, (const int*)(nd.ext + 3 * (size_t)first),
                          (const int*)(top_children ? nd.cptr2 : nd.cptr), (const int*)(top_children ? nd.cidx2 : nd.cidx), top_children ? 1 : 0);
   };
-  auto factor = [&](int l) {
+  // split: the trailing update of this level's last panel is split for the look-ahead into the next level (DenseBatch::split_ta)
+  auto factor = [&](int l, bool split, hipEvent_t pre_trsm) {
     const NdLevel& L = nd.lev[l];
     ax.mark(st, -3);
-    if (L.n > 0) dense_cholesky_solve_raw(P.nd_M, P.nd_rhs + L.rhs_off, P.nd_Linv + L.linv_off, P.flag, L.ntot, st, ax, L.nI / kTile, false, batch(l));
+    if (L.n > 0) {
+      DenseBatch bt = batch(l);
+      bt.split_ta = split ? L.split_ta : 0; bt.pre_trsm = pre_trsm;
+      dense_cholesky_solve_raw(P.nd_M, P.nd_rhs + L.rhs_off, P.nd_Linv + L.linv_off, P.flag, L.ntot, st, ax, L.nI / kTile, false, bt);
+    }
     ax.mark(st, -4);
   };
+  // Levels [l0, l1) one after the other, with a look-ahead across the level boundary: of level l's last trailing update only the
+  // tiles its parents' first panel receives run on the chain's stream, followed by that part of the extend-add and the parents'
+  // first panel; the rest of the update and of the extend-add run beside it on the bulk stream (ax.aux).
+  auto run_levels = [&](int l0, int l1, bool top_children) {
+    bool prev_split = false;
+    for (int l = l0; l < l1; ++l) {
+      hipEvent_t pre = nullptr;
+      if (prev_split) {
+        (void)hipEventRecord(ax.ev_xa, st);   // (the bulk stream already follows the level below through its own update; this
+        (void)hipStreamWaitEvent(ax.aux, ax.ev_xa, 0);   //  also covers a batch that declined the split)
+        extend(l, top_children, 1, st);
+        extend(l, top_children, 2, ax.aux);
+        (void)hipEventRecord(ax.ev_xb, ax.aux);
+        pre = ax.ev_xb;
+      } else extend(l, top_children, 0, st);
+      const NdLevel& L = nd.lev[l];
+      const bool split = lookahead && l + 1 < l1 && L.n > 0 && nd.lev[l + 1].n > 0 && L.split_ta > 0;
+      factor(l, split, pre);
+      prev_split = split;
+    }
+  };
   // ---- the subtrees of this rank (single GPU: the whole tree), level by level
-  for (int l = 0; l < ltop; ++l) { extend(l, false); factor(l); }
+  run_levels(0, ltop, false);
   if (ltop < nlev) {
     // ---- agent-sharded solve: the top fronts so far hold THIS rank's residuals and subtrees only. One
     //      all-reduce over [top fronts | their right-hand sides | grad, hdiag of the top unknowns] (contiguous), then the
     //      damping of the top unknowns; from here on every rank runs the top of the tree redundantly, with no further exchange.
-    for (int l = ltop; l < nlev; ++l) extend(l, false);
+    for (int l = ltop; l < nlev; ++l) extend(l, false, 0, st);
     double* gh = P.nd_rhs + nd.gh_off;
     if (nd.ntop > 0) hipLaunchKernelGGL(k_nd_gh, dim3((nd.ntop + 255) / 256), dim3(256), 0, st, P, (const int*)nd.top_g, nd.ntop, gh, 0);
     if (ax.reduce != nullptr) ax.reduce(ax.reduce_ctx, P.nd_M + nd.M_sub, (nd.M_elems - nd.M_sub) + nd.rhs_top + 2 * (size_t)nd.ntop, 0, st);
@@ -374,7 +433,7 @@ void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
       hipLaunchKernelGGL(k_nd_top_damp, dim3((nd.ntop + 255) / 256), dim3(256), 0, st, P, (const int*)nd.top_var, (const int*)nd.top_r, (const int*)nd.top_g, nd.ntop,
                          (const int*)nd.rhs_node, mu);
     }
-    for (int l = ltop; l < nlev; ++l) { extend(l, true); factor(l); }
+    run_levels(ltop, nlev, true);
   }
   for (int l = nlev - 1; l >= 0; --l) {
     // top-down: the ancestors' unknowns are read from `dst` by the first launch of the level, the fronts' own unknowns are
@@ -384,6 +443,8 @@ void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     DenseBatch bt = batch(l);
     bt.xfer.gidx = nd.gidx; bt.xfer.own_g = nd.own_g; bt.xfer.st_g = nd.st_g; bt.xfer.own_dims = nd.own_dims; bt.xfer.st_dims = nd.st_dims;
     bt.xfer.x = dst; bt.xfer.first = L.first;
+    static const bool fused_bwd = getenv("COVGPU_ND_BWD_FUSED") == nullptr || atoi(getenv("COVGPU_ND_BWD_FUSED")) != 0;
+    bt.bwd_cnt = fused_bwd ? ax.bwd_cnt : nullptr; bt.bwd_scr = ax.bwd_scr;
     dense_backward_solve(P.nd_M, P.nd_rhs + L.rhs_off, P.nd_Linv + L.linv_off, L.ntot, st, L.nI / kTile, L.ntot / kTile, bt);
     ax.mark(st, -5);
   }

@@ -607,6 +607,137 @@ __global__ __launch_bounds__(256) void k_bwd_given(const double* __restrict__ M,
   }
 }
 
+// Backward substitution of a whole multifrontal front in ONE launch (fronts of at most four interior tiles: every level below
+// the top of the tree). Workgroup (column tile ct, row chunk k) of a front forms the partial sums of
+//   y[c] -= sum_r L[r][c] x[r]   over ITS 256 given rows (the ancestors' unknowns, read straight from the solution vector)
+// for the 128 interior columns of tile ct and parks them in `scr`; the workgroup of the front that finishes LAST (ticket
+// counter; nobody waits for anybody: no co-residency assumption) adds them in chunk order and solves the interior tiles from
+// the last to the first: x_p = L_pp^-T y_p with the block inverses, y[cols left of the tile] -= L[tile rows, cols]^T x_p.
+// Replaces 1 + (interior tiles) dependent launches per level whose first streamed a whole border through one workgroup per
+// column tile (latency-bound: ~50 us for a 1.5k-row border).
+__global__ __launch_bounds__(256) void k_bwd_front(const double* __restrict__ M, int tI, int nchunk, double* __restrict__ y, const double* __restrict__ Dinv_all,
+                                                    size_t bsL, size_t bsR, const long long* __restrict__ btab, const int* __restrict__ live, BwdXfer xf,
+                                                    int* __restrict__ cnt, double* __restrict__ scr) {
+  const int batch = blockIdx.y, tid = threadIdx.x;
+  const int ct = blockIdx.x / nchunk, k = blockIdx.x % nchunk;
+  const int nIt = live[2 * batch];            // real interior tiles of this front
+  const int node = xf.first + batch;
+  const int nst = xf.st_dims[node];
+  const int nch = max(1, (nst + 255) / 256);  // row chunks of this front
+  if (ct >= nIt || k >= nch) return;
+  M += (size_t)btab[2 * batch];
+  const size_t ld = (size_t)btab[2 * batch + 1];
+  y += (size_t)batch * bsR;
+  const double* Dinv_f = Dinv_all + (size_t)batch * bsL;
+  double* scr_f = scr + (size_t)batch * gridDim.x * kTile;   // [tile][chunk][128]
+  __shared__ double2 part[4][64];
+  __shared__ int s_ticket;
+  __shared__ double sx[kTile], sv[kTile], sxg[256];
+  {
+    const int r0 = tI * kTile + 256 * k, nr = min(256, nst - 256 * k);   // this chunk's rows [r0, r0 + nr)
+    const int* gi = xf.gidx + xf.st_g[node] + 256 * k;
+    if (tid < nr) sxg[tid] = xf.x[gi[tid]];
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    const int col = ct * kTile + 2 * lane;
+    double2 acc = {0.0, 0.0};
+    const double* Lp = M + (size_t)r0 * ld + col;
+    int r = wv;
+    for (; r + 28 < nr; r += 32) {
+      double2 v[8]; double xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { v[u] = *reinterpret_cast<const double2*>(Lp + (size_t)(r + 4 * u) * ld); xv[u] = sxg[r + 4 * u]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += v[u].x * xv[u]; acc.y += v[u].y * xv[u]; }
+    }
+    for (; r < nr; r += 4) { const double2 v = *reinterpret_cast<const double2*>(Lp + (size_t)r * ld); const double xv = sxg[r]; acc.x += v.x * xv; acc.y += v.y * xv; }
+    part[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0) {
+      const double2 a = part[0][lane], b = part[1][lane], c = part[2][lane], d = part[3][lane];
+      double2 t; t.x = ((a.x + b.x) + c.x) + d.x; t.y = ((a.y + b.y) + c.y) + d.y;
+      double* dst = scr_f + ((size_t)ct * nchunk + k) * kTile + 2 * lane;
+      __hip_atomic_store(dst, t.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 1, t.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // ---- ticket: the last workgroup of the front goes on. The partial sums travel through device-scope accesses (they bypass the
+  //      per-XCD L2, which is not coherent across XCDs) and are complete (vmcnt) before the ticket is drawn; a device-scope FENCE
+  //      here would write back and INVALIDATE the XCD's whole L2 under every workgroup that still streams its rows of L (measured:
+  //      the sweep got slower than the separate launches).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a workgroup-scope release fence does not wait for the write-through stores)
+  __syncthreads();
+  if (tid == 0) s_ticket = __hip_atomic_fetch_add(&cnt[batch], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (s_ticket != nIt * nch - 1) return;
+  if (tid == 0) __hip_atomic_store(&cnt[batch], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (next launch: ordered by the stream)
+  for (int p = nIt - 1; p >= 0; --p) {
+    const int k0 = p * kTile;
+    const double* Dinv = Dinv_f + (size_t)p * kTile * kTile;
+    {
+      const int c = tid & 127, jbc = c >> 4, cl = c & 15;
+      const bool act = tid < kTile;
+      double v = act ? y[k0 + c] : 0.0;
+      if (act) for (int q = 0; q < nch; ++q) v -= __hip_atomic_load(scr_f + ((size_t)p * nchunk + q) * kTile + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      double dv[PB], Lc[7][PB];
+#pragma unroll
+      for (int r = 0; r < PB; ++r) dv[r] = act ? Dinv[jbc * 256 + r * PB + cl] : 0.0;
+#pragma unroll
+      for (int jb = 1; jb < 8; ++jb)
+#pragma unroll
+        for (int r = 0; r < PB; ++r) Lc[jb - 1][r] = (act && jbc < jb) ? M[(size_t)(k0 + PB * jb + r) * ld + k0 + c] : 0.0;
+#pragma unroll
+      for (int jb = 7; jb >= 0; --jb) {
+        if (act && jbc == jb) sv[c] = v;
+        __syncthreads();
+        if (act && jbc == jb) {
+          double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+          for (int r = 0; r < PB; r += 4) {
+            s0 += dv[r] * sv[PB * jb + r]; s1 += dv[r + 1] * sv[PB * jb + r + 1];
+            s2 += dv[r + 2] * sv[PB * jb + r + 2]; s3 += dv[r + 3] * sv[PB * jb + r + 3];
+          }
+          sx[c] = (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
+        if (jb > 0 && act && jbc < jb) {
+          double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+          for (int r = 0; r < PB; r += 4) {
+            s0 += Lc[jb > 0 ? jb - 1 : 0][r] * sx[PB * jb + r]; s1 += Lc[jb > 0 ? jb - 1 : 0][r + 1] * sx[PB * jb + r + 1];
+            s2 += Lc[jb > 0 ? jb - 1 : 0][r + 2] * sx[PB * jb + r + 2]; s3 += Lc[jb > 0 ? jb - 1 : 0][r + 3] * sx[PB * jb + r + 3];
+          }
+          v -= (s0 + s1) + (s2 + s3);
+        }
+      }
+    }
+    // own unknowns of this tile -> solution vector
+    {
+      const int n = xf.own_dims[node];
+      const int* gi = xf.gidx + xf.own_g[node];
+      if (tid < kTile && k0 + tid < n) xf.x[gi[k0 + tid]] = sx[tid];
+    }
+    // y[cols left of the tile] -= L[tile rows, cols]^T x_p: two groups of 64 rows per 128 columns, added in group order
+    if (p > 0) {
+      __shared__ double part2[2][kTile];
+      const int cl = tid & 127, rg = tid >> 7;
+      for (int c0 = 0; c0 < k0; c0 += kTile) {
+        const double* Lc2 = M + (size_t)(k0 + 64 * rg) * ld + c0 + cl;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
+        for (int r = 0; r < 64; r += 4) {
+          a0 += Lc2[(size_t)r * ld] * sx[64 * rg + r]; a1 += Lc2[(size_t)(r + 1) * ld] * sx[64 * rg + r + 1];
+          a2 += Lc2[(size_t)(r + 2) * ld] * sx[64 * rg + r + 2]; a3 += Lc2[(size_t)(r + 3) * ld] * sx[64 * rg + r + 3];
+        }
+        part2[rg][cl] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (rg == 0) y[c0 + cl] -= part2[0][cl] + part2[1][cl];
+        __syncthreads();
+      }
+    }
+  }
+}
+
 // ---- launch wrappers (k_chol.hip schedules them) ----------------------------------------------------------------------
 void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, double* x, int ncol, int nbt, size_t sM, size_t sR, hipStream_t st,
                       const long long* btab, const int* live, int tI, BwdXfer xf) {
@@ -639,6 +770,11 @@ void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const 
   else if (need <= 8) hipLaunchKernelGGL(k_trsm_sub<8>, grid, dim3(64), 0, st, g);
   else if (need <= 12) hipLaunchKernelGGL(k_trsm_sub<12>, grid, dim3(64), 0, st, g);
   else hipLaunchKernelGGL(k_trsm_sub<16>, grid, dim3(64), 0, st, g);
+}
+
+void launch_bwd_front(const double* S, int tI, int ntiles, int nchunk, double* y, const double* Linv, int nbt, size_t sL, size_t sR, hipStream_t st,
+                      const long long* btab, const int* live, BwdXfer xf, int* cnt, double* scr) {
+  hipLaunchKernelGGL(k_bwd_front, dim3(ntiles * nchunk, nbt), dim3(256), 0, st, S, tI, nchunk, y, Linv, sL, sR, btab, live, xf, cnt, scr);
 }
 
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,

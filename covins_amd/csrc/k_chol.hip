@@ -105,13 +105,13 @@ __device__ __forceinline__ bool tile_live(const GemmArgs& g, int batch, int t) {
 template <int MODE, int TSA, int TSB, int KC>
 COV_DEV void gemm_abt_body(const GemmArgs& g) {
   constexpr int LDT = KC + 1;
-  static_assert((TSA == kTile && TSB == kTile) || (MODE == MODE_SYRK_RECT && TSA == 64 && TSB == 64) ||
-                (MODE == MODE_TRSM && TSA == 32 && TSB == kTile), "quarter forms: RECT 64x64, TRSM 32x128");
+  static_assert((TSA == kTile && TSB == kTile) || (MODE != MODE_TRSM && TSA == 64 && TSB == 64) ||
+                (MODE == MODE_TRSM && TSA == 32 && TSB == kTile), "quarter forms: RECT / TRI 64x64, TRSM 32x128");
   constexpr int WGR = (TSA == 32) ? 1 : 2, WGC = 4 / WGR;  // wave grid
   constexpr int WTR = TSA / WGR, WTC = TSB / WGC;           // wave tile
   constexpr int NMR = WTR / 16, NMC = WTC / 16;             // MFMA tiles per wave
   constexpr int ZQ = (TSA == kTile && TSB == kTile) ? 1 : 4;  // quarter index and batch index share blockIdx.z
-  if (ZQ == 4) __builtin_amdgcn_s_setprio(3);  // quarter forms run on the serial chain only, beside bulk waves: issue priority over them
+  if (ZQ == 4 && MODE != MODE_SYRK_TRI) __builtin_amdgcn_s_setprio(3);  // RECT / TRSM quarter forms run on the serial chain only, beside bulk waves: issue priority over them
   int tri_entry = 0;
   if (MODE == MODE_SYRK_TRI && g.tri != nullptr) { tri_entry = g.tri[blockIdx.x]; if (tri_entry < 0) return; }
   const int zq = (int)blockIdx.z % ZQ,
@@ -122,6 +122,7 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
   int ti, tj;
   if (MODE == MODE_SYRK_TRI && g.tri != nullptr) {
     ti = (tri_entry >> 10) & 1023; tj = tri_entry & 1023;
+    if (ZQ == 4 && ti == tj && qc > qr) return;   // quadrant above the diagonal
   } else if (MODE == MODE_SYRK_TRI) {
     // XCD-aware decode: block b -> XCD (b & 7) (observed dispatch order; placement affects speed only).
     const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
@@ -350,6 +351,9 @@ void CholAux::collect() {
   prof_flops.clear();
 }
 
+// trailing updates given as explicit tile lists of at most this many entries (incl. the XCD padding) run as 64x64 quadrants
+static const int kQuarterMax = getenv("COVGPU_QUARTER_MAX") ? atoi(getenv("COVGPU_QUARTER_MAX")) : 1024;
+
 void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax, int tstop, bool solve,
                               DenseBatch bt) {
   const int nbt = bt.n > 0 ? bt.n : 1;
@@ -504,7 +508,11 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
           GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab};
           g.tri = list;
           if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], s2);
-          if (list != nullptr) hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(count, 1), dim3(256), lds_gemm, s2, g);
+          // a short list runs at the LATENCY of one workgroup's K loop (16 chunks of 64 MFMAs per wave): as 64x64 quadrants it is
+          // four times as many workgroups, each four times shorter
+          if (list != nullptr && count <= kQuarterMax)
+            hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_TRI, 64, 64>), dim3(count, 1, 4), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), s2, g);
+          else if (list != nullptr) hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(count, 1), dim3(256), lds_gemm, s2, g);
           else {
             const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
             hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, s2, g);
@@ -596,7 +604,9 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       }
       if (!listed || tc.count[P] > 0) {
         if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], B);
-        if (listed) hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(tc.count[P], 1), dim3(256), lds_gemm, B, g);
+        if (listed && tc.count[P] <= kQuarterMax)
+          hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_TRI, 64, 64>), dim3(tc.count[P], 1, 4), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), B, g);
+        else if (listed) hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(tc.count[P], 1), dim3(256), lds_gemm, B, g);
         else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, B, g);
         if (ax.profile) {
           (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], B);

@@ -266,6 +266,7 @@ void launch_zero_system(const DevProblem& P, hipStream_t st) {
   }
   add(P.grad, (size_t)P.N); add(P.hdiag, (size_t)P.N);
   add(P.part + (size_t)SC_COST * P.part_n, (size_t)P.part_n);
+  add(P.scal + SC_GMAX, 1);   // (k_dogleg_stats takes an atomic max into it)
   for (int i = m; i < 16; ++i) { z.p[i] = nullptr; z.n[i] = 0; }
   hipLaunchKernelGGL(k_zero_many, dim3(128, m), dim3(256), 0, st, z);
   hipMemsetAsync(P.flag, 0, sizeof(int), st);
@@ -277,8 +278,8 @@ void launch_part_finish(const DevProblem& P, int slot0, int nslots, hipStream_t 
   hipLaunchKernelGGL(k_part_finish, dim3(nslots), dim3(1024), 0, st, P, slot0);
 }
 void launch_dogleg_stats(const DevProblem& P, hipStream_t st) {
-  launch_part_clear(P, SC_GG, 3, st);                       // GG, GN2, GDOT are adjacent slots
-  hipMemsetAsync(P.scal + SC_GMAX, 0, sizeof(double), st);
+  // (no clearing of the partial sums: every wave of a reduction kernel STORES its slot, the same slots at every launch — the
+  //  fill launches were seven ~5 us links of the launch-bound tail of an iteration; SC_GMAX is cleared with the system)
   // (at most 256 workgroups: every wave ends with an atomic max on one address — 4500 of them took 45 us)
   hipLaunchKernelGGL(k_dogleg_stats, dim3(std::min(vec_grid(P.N), 256)), dim3(256), 0, st, P);
   launch_part_finish(P, SC_GG, 3, st);
@@ -287,12 +288,10 @@ void launch_cauchy_vec(const DevProblem& P, hipStream_t st) {
   hipLaunchKernelGGL(k_cauchy_vec, dim3(vec_grid(P.N)), dim3(256), 0, st, P);
 }
 void launch_combine_step(const DevProblem& P, double cg, double cn, hipStream_t st) {
-  launch_part_clear(P, SC_GS, 2, st);                       // GS, SN2 adjacent
   hipLaunchKernelGGL(k_combine_step, dim3(vec_grid(P.N)), dim3(256), 0, st, P, cg, cn, 0);
   launch_part_finish(P, SC_GS, 2, st);
 }
 void launch_combine_step_dev(const DevProblem& P, hipStream_t st) {
-  launch_part_clear(P, SC_GS, 2, st);
   hipLaunchKernelGGL(k_combine_step, dim3(vec_grid(P.N)), dim3(256), 0, st, P, 0.0, 0.0, 1);
   launch_part_finish(P, SC_GS, 2, st);
 }
@@ -316,7 +315,6 @@ void launch_accept(const DevProblem& P, hipStream_t st) {
   if (P.L) hipMemcpyAsync(P.lm, P.lm_c, (size_t)3 * P.L * sizeof(double), hipMemcpyDeviceToDevice, st);
 }
 void launch_xnorm(const DevProblem& P, hipStream_t st) {
-  launch_part_clear(P, SC_XN2, 1, st);
   const int n = P.K > 3 * P.L ? P.K : 3 * P.L;
   hipLaunchKernelGGL(k_xnorm, dim3(vec_grid(n)), dim3(256), 0, st, P);
   launch_part_finish(P, SC_XN2, 1, st);

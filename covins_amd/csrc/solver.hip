@@ -935,9 +935,11 @@ static void collect_profile(covgpu_context* c, bool built, bool solved) {
   if (solved) c->chol.collect();
 }
 
+// (no clearing of the partial sums before these: every wave of a reduction kernel stores its slot, the same slots at every launch.
+//  Measured and dropped: the inertial / loop-edge kernels on a side stream beside the observation kernel, and the whole Cauchy
+//  leg underneath the linear solve — both within the +-1 % run-to-run noise, the event hops cost what the overlap buys.)
 static void enqueue_jvp(covgpu_context* c, const double* v_all) {
   const DevProblem& P = c->P;
-  launch_part_clear(P, SC_JV2, 1, c->st);
   launch_obs_jvp(P, v_all, c->st);
   launch_imu_jvp(P, v_all, c->st);
   launch_edge_jvp(P, v_all, c->st);
@@ -946,7 +948,6 @@ static void enqueue_jvp(covgpu_context* c, const double* v_all) {
 
 static void enqueue_cost_candidate(covgpu_context* c) {
   const DevProblem& P = c->P;
-  launch_part_clear(P, SC_COST, 1, c->st);
   launch_obs_cost(P, P.pose_c, P.lm_c, c->st);
   launch_imu_cost(P, P.pose_c, P.sb_c, c->st);
   launch_edge_cost(P, P.pose_c, c->st);

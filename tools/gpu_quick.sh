@@ -8,5 +8,5 @@ cat gpurun_out/${tag}_tests.txt
 for f in gpurun_out/${tag}_bench_*.json; do python -c "
 import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', round(d['value'],2), d['phase_ms_per_iteration'], d['config']['layout']['nd_fronts'], d['ate_rmse_m']['final'])" 2>&1 | tail -1; done
 cat gpurun_out/${tag}_marks.txt
-COVGPU_ND_BWD_FUSED=0 timeout 300 python bench.py --steps 5 --warmup 2 --no-e2e --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('unfused backward', round(d['value'],2), d['phase_ms_per_iteration'])"
+timeout 300 python bench.py --strategy lm --steps 5 --warmup 2 --no-e2e --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lm', round(d['value'],2), d['phase_ms_per_iteration'])"

@@ -501,7 +501,12 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       bool split_done = false;
       if (T > h0) {
         if (P > 0) { if (h1 > h0) wait(M, eHp[P]); if (T > h1) wait(M, e2[P]); }
+        // (measured and dropped: solving only the rows the parents' first panel receives here and the others on the bulk stream —
+        //  the bulk stream's leg (rest rows, rest of the update, second half of the extend-add) is what the next level's
+        //  substitutions wait for, and it only got longer: 3.37 vs 3.33 ms)
+        const bool split = bt.split_ta > 0 && bt.live_h != nullptr && kd(P) > 0 && (tc.listA != nullptr || tc.listB != nullptr);
         launch_trsm_sub(S, ld, t0, w, h0, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp);
+        if (split) { (void)hipEventRecord(eH[P], M); wait(B, eH[P]); }
         if (P >= 1) wait(M, eB[P - 1]);  // bulk(P-1) was the previous writer of the trailing tiles
         const int tb = h0, nt = T - tb;
         auto syrk = [&](hipStream_t s2, const int* list, int count, double pairs) {
@@ -534,11 +539,9 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
             const int na = std::min(nl, bt.split_ta);
             pairsA += (double)na * (na + 1) / 2;
           }
-          if (bt.split_ta > 0 && bt.live_h != nullptr && (tc.listA != nullptr || tc.listB != nullptr)) {
+          if (split) {
             // look-ahead across levels: the tiles the parents' first panel receives on the chain's stream, the rest on the bulk stream
-            (void)hipEventRecord(eH[P], M);
             if (tc.countA > 0) syrk(M, tc.listA, tc.countA, pairsA);
-            wait(B, eH[P]);
             if (tc.countB > 0) syrk(B, tc.listB, tc.countB, pairs - pairsA);
             (void)hipEventRecord(eB[P], B);
             split_done = true;

@@ -272,14 +272,24 @@ __global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, co
       v[i][j] = (own_cols && rr[i] < nrow && cc[j] <= rr[i]) ? F[(size_t)rr[i] * ld + cc[j]] : 0.0;
       hit[i][j] = false;
     }
-  for (int k = cptr[node]; k < cptr[node + 1]; ++k) {
+  // children in child order (deterministic sums); the row maps of child k + 1 are fetched before the entries of child k are
+  // gathered, so a child costs one memory latency on this launch-bound kernel, not two dependent ones
+  const int kbeg = cptr[node], kend = cptr[node + 1];
+  int irn[4], icn[4];
+  auto load_maps = [&](int k) {
+    const int* inv = a.inv + a.inv_off[cidx[k]];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { irn[i] = rr[i] < nrow ? inv[rr[i]] : -1; icn[i] = cc[i] < nrow ? inv[cc[i]] : -1; }
+  };
+  if (kbeg < kend) load_maps(kbeg);
+  for (int k = kbeg; k < kend; ++k) {
     const int ch = cidx[k];
-    const int* inv = a.inv + a.inv_off[ch];
     const size_t ldc = (size_t)P.nd_ntab[2 * ch + 1];
     const double* C = P.nd_M + P.nd_ntab[2 * ch];
     int ir[4], ic[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ir[i] = rr[i] < nrow ? inv[rr[i]] : -1; ic[i] = cc[i] < nrow ? inv[cc[i]] : -1; }
+    for (int i = 0; i < 4; ++i) { ir[i] = irn[i]; ic[i] = icn[i]; }
+    if (k + 1 < kend) load_maps(k + 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (ir[i] < 0) continue;

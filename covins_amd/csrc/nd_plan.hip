@@ -48,12 +48,14 @@ struct Builder {
   void leaf(std::vector<int>& vars, int parent) {
     std::vector<int> P, V;
     for (int v : vars) ((v & 1) ? V : P).push_back(v);
-    if (V.empty() || (P.empty() && V.size() <= 28) || leaf_dims >= (1 << 29)) { new_node(vars, parent); return; }  // (COVGPU_GBA_DENSE: one front = the dense system)
-    // The speed-bias chain is cut into segments of at most 28 blocks (252 unknowns: ONE 256-column panel for the whole
-    // bottom level instead of up to three): a cut block joins the pose front — it is the separator of its two neighbours.
+    // The speed-bias chain is cut into segments of at most 14 blocks (126 unknowns: half a panel — the bottom level's panel
+    // factorisation, substitutions and rank update all scale with the widest front; 10 / 14 / 21 / 28 blocks measured, 14 best):
+    // a cut block joins the pose front — it is the separator of its two neighbours.
+    constexpr int vseg = 14;
+    if (V.empty() || (P.empty() && (int)V.size() <= vseg) || leaf_dims >= (1 << 29)) { new_node(vars, parent); return; }  // (COVGPU_GBA_DENSE: one front = the dense system)
     std::sort(V.begin(), V.end());
     const int nV = (int)V.size(), pd = 6 * (int)P.size();
-    int s = (nV + 1 + 28) / 29;
+    int s = (nV + 1 + vseg) / (vseg + 1);
     while (s > 1 && pd <= 256 && pd + 9 * (s - 1) > 256) --s;   // keep the pose front a single panel
     std::vector<std::vector<int>> seg(s);
     {

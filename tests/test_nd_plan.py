@@ -108,9 +108,9 @@ def test_replay_equals_dense_solve(small_map, leaf):
     if leaf >= 0x3fffffff:
         assert info[0] == 1 and info[1] == 1     # one front = the dense system (COVGPU_GBA_DENSE)
     elif leaf >= 100000:
-        # nothing is cut: the pose front (+ the cut blocks of the speed-bias chains) and, below it, chain segments of <= 28 blocks
+        # nothing is cut: the pose front (+ the cut blocks of the speed-bias chains) and, below it, chain segments of <= 14 blocks
         assert info[1] == 2 and all(p == 0 for p in parent[1:])
-        assert all(len(o) <= 28 and all(v & 1 for v in o) for o in own[1:])
+        assert all(len(o) <= 14 and all(v & 1 for v in o) for o in own[1:])
         assert sum(len(o) for o in own) == 2 * prob.K
     else:
         assert info[0] > 3 and info[1] >= 2

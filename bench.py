@@ -172,7 +172,7 @@ def main():
             import subprocess
             sha = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")))
-            if pj.get("workload") == args.workload and pj.get("kernels_sha256") == _kernels_digest() and "k_gemm_abt<0" in pj.get("kernel", ""):
+            if pj.get("workload") == args.workload and pj.get("kernels_sha256") == _kernels_digest() and "k_gemm_abt" in pj.get("kernel", ""):
                 traffic = pj["fetch_bytes_x2"] + pj["write_bytes"]; mfma_busy = pj.get("mfma_busy_frac"); traffic_src = pj.get("git_sha", sha)
         except Exception:
             pass
@@ -215,7 +215,8 @@ def main():
                            "final_sim3": synth.ate_rmse(sol.kf_pose[:, 4:], truth, with_scale=True)},  # evo_ape -va / -vas
             "phase_ms_per_iteration": {"linearise+schur": prof["build_ms"] / max(prof["n_build"], 1),
                                        "factor+solve": prof["factor_ms"] / max(prof["n_factor"], 1)},
-            "roofline": {"kernel": "k_gemm_abt<SYRK_TRI> (rank-256 trailing update of the batched front factorisation, v_mfma_f64_16x16x4_f64)",
+            "roofline": {"kernel": "k_gemm_abt<SYRK_TRI> / k_gemm_abt_q<SYRK_TRI,64,64> (rank-256 trailing update of the batched front factorisation, "
+                                   "v_mfma_f64_16x16x4_f64; 128x128 tiles, or 64x64 quadrants for tile lists of <= 1024 entries)",
                          "bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
                          "mfma_busy_frac_pmc": mfma_busy,

@@ -445,8 +445,8 @@ def config_named(name: str, seed: int = 0) -> SynthConfig:
         return SynthConfig(agents=(1, 2, 3, 4, 5), seed=seed)
     if name == "a12x500":         # configs[4] at reduced scale: 12 agents (5 MH paths + 7 re-posed copies), <= 500 keyframes each
         return SynthConfig(agents=tuple(range(1, 13)), max_kf_per_agent=500, seed=seed)
-    if name == "a12":             # configs[4] at its stated size: 12 agents x 1667 keyframes = 20k keyframes, ~2M landmarks, 500 obs / keyframe
-        return SynthConfig(agents=tuple(range(1, 13)), kf_per_agent=1667, kf_dt=0.08, new_lm_per_kf=130, max_obs_per_kf=500, seed=seed)
+    if name == "a12":             # configs[4] at its stated size: 12 agents x 1667 keyframes = 20k keyframes, ~2M landmarks, <= 530 obs / keyframe
+        return SynthConfig(agents=tuple(range(1, 13)), kf_per_agent=1667, kf_dt=0.08, new_lm_per_kf=150, max_obs_per_kf=530, seed=seed)
     if name == "a12x1000":        # 12 agents x 1000 keyframes
         return SynthConfig(agents=tuple(range(1, 13)), kf_per_agent=1000, kf_dt=0.1, new_lm_per_kf=110, max_obs_per_kf=500, seed=seed)
     if name == "tiny":            # CPU tests

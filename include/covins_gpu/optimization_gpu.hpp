@@ -20,10 +20,13 @@
 // spelling differs between the real COVINS classes and a stand-in (see INTEGRATION.md for the COVINS binding).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <map>
+#include <unordered_map>
 #include <memory>
 #include <set>
 #include <string>
@@ -63,6 +66,14 @@ struct Params {
 };
 
 namespace detail {
+
+// f(keyframe, feature index) for every observation of a landmark: through Types::visit_observations(landmark, f) when the binding
+// offers it (a walk under the landmark's lock, no copy), otherwise over the copy Landmark::GetObservations() returns — a
+// std::map of smart pointers: one allocation and one atomic reference-count round trip per observation, 60 % of the walk.
+template <class Types, class L, class F>
+inline auto visit_observations(const L& lm, F&& f, int) -> decltype(Types::visit_observations(lm, f), void()) { Types::visit_observations(lm, f); }
+template <class Types, class L, class F>
+inline void visit_observations(const L& lm, F&& f, long) { const auto obs = lm.GetObservations(); for (auto& m : obs) f(m.first, m.second); }
 
 inline void fatal(const char* msg) {  // the reference prints COUTFATAL and exit(-1) (e.g. optimization_be.cpp:113-114)
   std::fprintf(stderr, "[covins_gpu] FATAL: %s\n", msg);
@@ -208,14 +219,27 @@ class OptimizationT {
 
   static Params& params() { static Params p; return p; }
 
-  struct Index { std::vector<KeyframePtr> kfs; std::vector<LandmarkPtr> lms; std::vector<std::pair<KeyframePtr, size_t>> obs; std::vector<LandmarkPtr> obs_lm; };
+  // row k of the IR = kfs[k], landmark l = lms[l]; observation i of the IR (landmark-major, Flat::obs_ptr) = feature obs_feat[i] of
+  // keyframe kfs[Flat::obs_kf[i]]. (No smart-pointer copies per observation: 0.87 M observations x four atomic reference-count
+  // updates on the keyframes' control blocks, contended between the walking threads, were most of a 0.28 s walk.)
+  struct Index { std::vector<KeyframePtr> kfs; std::vector<LandmarkPtr> lms; std::vector<size_t> obs_feat; };
 
   // Map -> IR for one GBA round (optimization_be.cpp:74-254 round 1, :308-557 round 2)
   static void FlattenGBA(const MapPtr& map, bool visual_only, bool round2, detail::Flat& f, Index& ix) {
     const Params& prm = params();
+    const bool tim = std::getenv("COVGPU_FLATTEN_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+      if (!tim) return;
+      const auto t = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[covins_gpu] flatten %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+      t_last = t;
+    };
     auto keyframes = map->GetKeyframesVec();
     auto landmarks = map->GetLandmarksVec();
-    std::map<Keyframe*, int32_t> row;
+    lap("map vectors");
+    std::unordered_map<const Keyframe*, int32_t> row;
+    row.reserve(2 * keyframes.size() + 16);
     std::map<size_t, std::vector<int32_t>> cams_of_client;
     for (auto& kf : keyframes) {
       if (kf->IsInvalid()) continue;
@@ -254,6 +278,7 @@ class OptimizationT {
       }
       f.kf_cam.push_back(cam);
     }
+    lap("keyframes");
     // IMU factors (:117-144 / :367-420)
     f.imu_ptr.assign(1, 0);
     if (!visual_only)
@@ -286,55 +311,71 @@ class OptimizationT {
     // host threads, each filling its own Flat/Index slice; the slices are concatenated in landmark order, so the IR is
     // the same for any thread count. (The map is exclusively checked out for the call, backend.cpp:134; the accessors
     // take the per-object mutexes.)
+    lap("IMU factors");
     const size_t th_min_observations = 2;
     int nth = prm.flatten_threads > 0 ? prm.flatten_threads : (int)std::thread::hardware_concurrency();
     nth = std::max(1, std::min(nth, 16));
     if (landmarks.size() < 4096) nth = 1;
-    struct Slice { std::vector<double> lm, uv, sigma; std::vector<int32_t> obs_kf, nobs; std::vector<LandmarkPtr> lms, obs_lm; std::vector<std::pair<KeyframePtr, size_t>> obs; };
+    struct Slice { std::vector<double> lm, uv, sigma; std::vector<int32_t> obs_kf, nobs; std::vector<LandmarkPtr> lms; std::vector<size_t> feat; };
     std::vector<Slice> slices(nth);
     auto walk = [&](int t) {
-      Slice& sl = slices[t];
+      Slice sl;   // (thread-local while it grows: the vectors' end pointers of neighbouring slices[] entries share cache lines)
       const size_t l0 = landmarks.size() * (size_t)t / nth, l1 = landmarks.size() * (size_t)(t + 1) / nth;
+      sl.lm.reserve(3 * (l1 - l0)); sl.lms.reserve(l1 - l0); sl.nobs.reserve(l1 - l0);
+      sl.obs_kf.reserve(12 * (l1 - l0)); sl.uv.reserve(24 * (l1 - l0)); sl.sigma.reserve(12 * (l1 - l0)); sl.feat.reserve(12 * (l1 - l0));
       for (size_t li = l0; li < l1; ++li) {
         const LandmarkPtr& lm = landmarks[li];
         if (lm->IsInvalid()) continue;
-        const auto observations = lm->GetObservations();
-        if (observations.size() < th_min_observations) continue;
-        size_t num_edges = 0;
-        for (auto& mit : observations) { if (!mit.first || mit.first->IsInvalid()) continue; num_edges++; }
-        if (num_edges < th_min_observations) continue;
-        const Vector3Type pw = lm->GetWorldPos();
-        for (int i = 0; i < 3; ++i) sl.lm.push_back(pw[i]);
-        sl.lms.push_back(lm);
+        // (emitted straight into the slice and rolled back if fewer than two valid observations remain: :150-160, 428-440)
+        const size_t o_mark = sl.obs_kf.size();
         int32_t n = 0;
-        for (auto& mit : observations) {
-          const KeyframePtr& kfx = mit.first;
-          if (!kfx || kfx->IsInvalid()) continue;
-          const size_t feat = mit.second;
+        detail::visit_observations<Types>(*lm, [&](const KeyframePtr& kfx, size_t feat) {
+          if (!kfx || kfx->IsInvalid()) return;
           sl.obs_kf.push_back(row.at(kfx.get()));
           sl.uv.push_back((double)kfx->keypoints_distorted_[feat][0]);  // float -> double (utils_base.hpp:76-80)
           sl.uv.push_back((double)kfx->keypoints_distorted_[feat][1]);
           sl.sigma.push_back(((double)kfx->keypoints_aors_[feat][1] + 1) * 2.0);  // :184, 478
-          sl.obs.emplace_back(kfx, feat); sl.obs_lm.push_back(lm);
+          sl.feat.push_back(feat);
           ++n;
+        }, 0);
+        if ((size_t)n < th_min_observations) {
+          sl.obs_kf.resize(o_mark); sl.uv.resize(2 * o_mark); sl.sigma.resize(o_mark); sl.feat.resize(o_mark);
+          continue;
         }
+        const Vector3Type pw = lm->GetWorldPos();
+        for (int i = 0; i < 3; ++i) sl.lm.push_back(pw[i]);
+        sl.lms.push_back(lm);
         sl.nobs.push_back(n);
       }
+      slices[t] = std::move(sl);
     };
-    {
+    auto in_threads = [&](const std::function<void(int)>& fn) {
       std::vector<std::thread> th;
-      for (int t = 1; t < nth; ++t) th.emplace_back(walk, t);
-      walk(0);
+      for (int t = 1; t < nth; ++t) th.emplace_back(fn, t);
+      fn(0);
       for (auto& x : th) x.join();
-    }
-    f.obs_ptr.assign(1, 0);
-    for (Slice& sl : slices) {
-      f.lm.insert(f.lm.end(), sl.lm.begin(), sl.lm.end()); f.uv.insert(f.uv.end(), sl.uv.begin(), sl.uv.end());
-      f.sigma.insert(f.sigma.end(), sl.sigma.begin(), sl.sigma.end()); f.obs_kf.insert(f.obs_kf.end(), sl.obs_kf.begin(), sl.obs_kf.end());
-      for (int32_t n : sl.nobs) f.obs_ptr.push_back(f.obs_ptr.back() + n);
-      ix.lms.insert(ix.lms.end(), sl.lms.begin(), sl.lms.end()); ix.obs.insert(ix.obs.end(), sl.obs.begin(), sl.obs.end());
-      ix.obs_lm.insert(ix.obs_lm.end(), sl.obs_lm.begin(), sl.obs_lm.end());
-    }
+    };
+    in_threads(walk);
+    lap("landmark walk (threads)");
+    // slices -> IR at their offsets (prefix sums), again in the threads: 35 MB of copies
+    std::vector<size_t> lm0(nth + 1, 0), ob0(nth + 1, 0);
+    for (int t = 0; t < nth; ++t) { lm0[t + 1] = lm0[t] + slices[t].lms.size(); ob0[t + 1] = ob0[t] + slices[t].obs_kf.size(); }
+    f.lm.resize(3 * lm0[nth]); f.obs_ptr.resize(lm0[nth] + 1); ix.lms.resize(lm0[nth]);
+    f.uv.resize(2 * ob0[nth]); f.sigma.resize(ob0[nth]); f.obs_kf.resize(ob0[nth]); ix.obs_feat.resize(ob0[nth]);
+    f.obs_ptr[0] = 0;
+    in_threads([&](int t) {
+      Slice& sl = slices[t];
+      std::copy(sl.lm.begin(), sl.lm.end(), f.lm.begin() + 3 * lm0[t]);
+      std::copy(sl.uv.begin(), sl.uv.end(), f.uv.begin() + 2 * ob0[t]);
+      std::copy(sl.sigma.begin(), sl.sigma.end(), f.sigma.begin() + ob0[t]);
+      std::copy(sl.obs_kf.begin(), sl.obs_kf.end(), f.obs_kf.begin() + ob0[t]);
+      std::copy(sl.feat.begin(), sl.feat.end(), ix.obs_feat.begin() + ob0[t]);
+      std::move(sl.lms.begin(), sl.lms.end(), ix.lms.begin() + lm0[t]);
+      int32_t at = (int32_t)ob0[t];
+      for (size_t q = 0; q < sl.nobs.size(); ++q) { at += sl.nobs[q]; f.obs_ptr[lm0[t] + q + 1] = at; }
+      sl = Slice();
+    });
+    lap("slices -> IR");
     // loop edges (:238-254 / :534-557): sqrt_info = diag(100 I3, 1e4 I3); loss only in round 2
     if (!round2 || prm.gba_use_map_loop_constraints)
       for (auto& lc : map->GetLoopConstraints()) {
@@ -408,12 +449,14 @@ class OptimizationT {
       int64_t counts[2] = {0, 0};
       SolveGBA(ctx, o, p, r, &erase, &lm_left, counts);
       size_t num_bad = 0;
-      for (size_t i = 0; i < f.obs_kf.size(); ++i)
-        if (erase[i]) {  // :281-289
-          ix.obs[i].first->EraseLandmark(ix.obs[i].second);
-          ix.obs_lm[i]->EraseObservation(ix.obs[i].first);
-          ++num_bad;
-        }
+      for (size_t l = 0; l < ix.lms.size(); ++l)
+        for (int32_t i = f.obs_ptr[l]; i < f.obs_ptr[l + 1]; ++i)
+          if (erase[i]) {  // :281-289
+            const KeyframePtr& kf = ix.kfs[f.obs_kf[i]];
+            kf->EraseLandmark(ix.obs_feat[i]);
+            ix.lms[l]->EraseObservation(kf);
+            ++num_bad;
+          }
       std::printf("--> GBA removed %zu of %zu observations\n", num_bad, f.obs_kf.size() * 2);
     }
     {  // second round (:296-610)
@@ -458,6 +501,14 @@ class OptimizationT {
   // ---- optimization_be.cpp:833-1086
   static auto PoseGraphOptimization(MapPtr map, PoseMap corrected_poses) -> void {
     const Params& prm = params();
+    const bool tim = std::getenv("COVGPU_FLATTEN_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+      if (!tim) return;
+      const auto t = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[covins_gpu] flatten %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+      t_last = t;
+    };
     auto keyframes = map->GetKeyframesVec();
     auto landmarks = map->GetLandmarksVec();
     detail::Flat f;

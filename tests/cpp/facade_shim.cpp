@@ -7,6 +7,8 @@
 
 using namespace standin;
 using Opt = covins_gpu::OptimizationT<standin::Types>;
+using OptCopy = covins_gpu::OptimizationT<standin::TypesBase>;   // no observation visitor: the walk goes through Landmark::GetObservations()
+static int g_use_visitor = 1;
 
 struct Handle {
   std::shared_ptr<Map> map;
@@ -89,8 +91,9 @@ void shim_free(Handle* h) { delete h; }
 int shim_flatten_gba(Handle* h, int visual_only, int round2, int* sizes /* K L O I E S */, double* pose, unsigned char* fixed, double* lm,
                      int* obs_ptr, int* obs_kf, double* uv, double* sigma, int* imu_i, int* imu_j, int* ei, int* ej, double* loss, double* noise, int* kf_cam,
                      int* ncam) {
-  covins_gpu::detail::Flat f; Opt::Index ix;
-  Opt::FlattenGBA(h->map, visual_only != 0, round2 != 0, f, ix);
+  covins_gpu::detail::Flat f;
+  if (g_use_visitor) { Opt::Index ix; Opt::FlattenGBA(h->map, visual_only != 0, round2 != 0, f, ix); }
+  else { OptCopy::Index ix; OptCopy::FlattenGBA(h->map, visual_only != 0, round2 != 0, f, ix); }
   covgpu_problem p = f.view();
   sizes[0] = p.num_kf; sizes[1] = p.num_lm; sizes[2] = p.num_obs; sizes[3] = p.num_imu; sizes[4] = p.num_edge; sizes[5] = p.num_imu_samples;
   if (ncam) *ncam = p.num_cam;
@@ -105,6 +108,9 @@ int shim_flatten_gba(Handle* h, int visual_only, int round2, int* sizes /* K L O
   std::memcpy(ei, f.ei.data(), f.ei.size() * 4); std::memcpy(ej, f.ej.data(), f.ej.size() * 4); std::memcpy(loss, f.loss.data(), f.loss.size() * 8);
   return 0;
 }
+
+void shim_use_visitor(int on) { g_use_visitor = on; }
+void shim_set_flatten_threads(int n) { Opt::params().flatten_threads = n; OptCopy::params().flatten_threads = n; }
 
 void shim_gba(Handle* h, int iterations, int visual_only, int outlier_removal) {
   Opt::GlobalBundleAdjustment(h->map, iterations, -1.0, visual_only != 0, outlier_removal != 0, false);
@@ -121,7 +127,6 @@ void shim_set_params(int strategy, const char* placerec_type) {
   Opt::params().strategy = strategy;
   Opt::params().placerec_type = placerec_type;
 }
-void shim_set_flatten_threads(int n) { Opt::params().flatten_threads = n; }
 // n > 1: GlobalBundleAdjustment shards the map over n in-process ranks, all on HIP device `device` (virtual ranks: the one-GPU form)
 void shim_set_gpus(int n, int device) { Opt::params().n_gpus = n; Opt::params().devices.assign((size_t)(n > 1 ? n : 0), device); }
 void shim_set_invalid(Handle* h, int kf) { h->kfs[kf]->SetInvalid(); }

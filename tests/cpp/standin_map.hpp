@@ -5,6 +5,7 @@
 #pragma once
 #include <array>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <utility>
 #include <vector>
@@ -86,7 +87,9 @@ class Landmark {
   void SetInvalid() { invalid_ = true; }
   Vec3 GetWorldPos() const { return pos_w_; }
   void SetWorldPos(Vec3 p) { pos_w_ = p; }
-  KfObservations GetObservations() const { return observations_; }
+  KfObservations GetObservations() const { std::unique_lock<std::mutex> lock(mtx_obs_); return observations_; }  // landmark_base.cpp:84-87
+  // the three-line addition INTEGRATION.md proposes for LandmarkBase: walk the observations under the lock without copying the map
+  template <class F> void VisitObservations(F&& f) const { std::unique_lock<std::mutex> lock(mtx_obs_); for (auto& o : observations_) f(o.first, o.second); }
   void AddObservation(KeyframePtr kf, size_t idx) { observations_[kf] = idx; }
   void EraseObservation(KeyframePtr kf) { observations_.erase(kf); }
   int GetFeatureIndex(KeyframePtr kf) const { auto it = observations_.find(kf); return it == observations_.end() ? -1 : (int)it->second; }
@@ -98,6 +101,7 @@ class Landmark {
   bool invalid_ = false;
   Vec3 pos_w_;
   KfObservations observations_;
+  mutable std::mutex mtx_obs_;
   std::weak_ptr<Keyframe> ref_;
 };
 
@@ -123,7 +127,7 @@ class Map {
   }
 };
 
-struct Types {
+struct TypesBase {
   using Map = standin::Map;
   using Keyframe = standin::Keyframe;
   using Landmark = standin::Landmark;
@@ -144,6 +148,11 @@ struct Types {
     for (int k = 0; k < 3; ++k) { acc0[k] = kf.acc0_[k]; gyr0[k] = kf.gyr0_[k]; }
   }
   static void imu_calib(const Keyframe& kf, double out5[5]) { for (int k = 0; k < 5; ++k) out5[k] = kf.imu_calib_[k]; }
+};
+// with the optional observation visitor (optimization_gpu.hpp: detail::visit_observations); TypesBase exercises the fallback
+// through Landmark::GetObservations() — what an unmodified LandmarkBase offers
+struct Types : TypesBase {
+  template <class F> static void visit_observations(const Landmark& lm, F&& f) { lm.VisitObservations(f); }
 };
 
 }  // namespace standin

@@ -14,11 +14,15 @@ def _sorted_obs(ptr, kf, *cols):
     return (kf[order],) + tuple(c[order] for c in cols)
 
 
-@pytest.mark.parametrize("visual_only,round2", [(False, True), (False, False), (True, True)])
-def test_cpp_flatten_matches_python(tiny_map, visual_only, round2):
+@pytest.mark.parametrize("visual_only,round2,visitor", [(False, True, 1), (False, False, 1), (True, True, 1), (False, True, 0)])
+def test_cpp_flatten_matches_python(tiny_map, visual_only, round2, visitor):
+    # visitor 0: the walk over the copy Landmark::GetObservations() returns (an unmodified LandmarkBase); 1: Types::visit_observations
+    from tests.facade_util import lib
     sm = StandinMap(tiny_map)
     try:
+        lib().shim_use_visitor(visitor)
         f = sm.flatten_gba(visual_only, round2)
+        lib().shim_use_visitor(1)
         p, _ = mapdata.flatten_gba(tiny_map, visual_only, loop_loss=round2)
         assert f["sizes"][:5] == (p.K, p.L, p.O, p.I, p.E)
         assert np.allclose(f["pose"][:, 4:], p.kf_pose[:, 4:], atol=1e-15)

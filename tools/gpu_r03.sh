@@ -16,6 +16,7 @@ bash tools/pmc_pass.sh ${tag} > gpurun_out/${tag}_pmc.log 2>&1
 mkdir -p profiles; cp gpurun_out/pmc_traffic_current.json profiles/pmc_traffic_current.json
 COVGPU_TRACE_PANELS=1 python bench.py --steps 1 --warmup 1 --no-e2e --no-cpu-baseline 2>&1 >/dev/null | grep "covgpu marks" | tail -2 > gpurun_out/${tag}_marks_unprofiled.txt
 python bench.py --steps 10 --warmup 2 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+python tools/cpp_flatten_time.py mh12345 7 2>/dev/null | tail -1 > gpurun_out/${tag}_cpp_flatten.txt; cat gpurun_out/${tag}_cpp_flatten.txt
 tail -4 gpurun_out/${tag}_gpu_tests_tail.txt; tail -2 gpurun_out/${tag}_pmc.log
 for f in gpurun_out/${tag}_bench*.json; do python -c "
 import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', round(d['value'],2), d['phase_ms_per_iteration'], round(d['roofline']['achieved'],1), d['roofline']['traffic'], d['config']['layout']['device_mib'], d['config']['layout']['nd_fronts'], d['ate_rmse_m']['final'], d.get('cpu_baseline',{}).get('value'), d.get('max_pose_diff_gpu_cpu_m'), d.get('e2e_call',{}).get('t_call_s'))" 2>&1 | tail -1; done

@@ -27,13 +27,22 @@ for f in sorted(os.listdir(d)):
         h.update(open(os.path.join(d, f), "rb").read())
 out = {"workload": "mh12345", "kernels_sha256": h.hexdigest(),
        "git_sha": subprocess.run(["git", "rev-parse", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip() or "gpu-box snapshot (no .git)"}
+# the trailing update runs in two tile forms (full 128x128 tiles; 64x64 quadrants for short tile lists): per-launch figures over both
+def is_syrk(name): return "k_gemm_abt<0" in name or "k_gemm_abt_q<0" in name
+calls = fetch = write = 0.0
+names = []
 for row in csv.DictReader(open(os.path.join(root, "gpurun_out", "${tag}_pmc_hbm_traffic.csv"))):
-    if "k_gemm_abt<0" in row["Name"]:
-        out.update(kernel=row["Name"], calls=int(row["Calls"]), fetch_bytes_x2=float(row["FETCH_x2_MB_per_call"]) * 1048576.0,
-                   write_bytes=float(row["WRITE_MB_per_call"]) * 1048576.0)
+    if is_syrk(row["Name"]):
+        c = int(row["Calls"]); calls += c; names.append(row["Name"].split("(")[0].replace("void covgpu::", ""))
+        fetch += c * float(row["FETCH_x2_MB_per_call"]) * 1048576.0; write += c * float(row["WRITE_MB_per_call"]) * 1048576.0
+if calls:
+    out.update(kernel=" + ".join(sorted(set(names))), calls=int(calls), fetch_bytes_x2=fetch / calls, write_bytes=write / calls)
+busy = wsum = 0.0
 for row in csv.DictReader(open(os.path.join(root, "gpurun_out", "${tag}_pmc_mfma.csv"))):
-    if "k_gemm_abt<0" in row["Name"] and row.get("MfmaBusy_pct"):
-        out["mfma_busy_frac"] = float(row["MfmaBusy_pct"]) / 100.0
+    if is_syrk(row["Name"]) and row.get("MfmaBusy_pct"):
+        w = float(row.get("Calls") or 1); busy += w * float(row["MfmaBusy_pct"]) / 100.0; wsum += w
+if wsum:
+    out["mfma_busy_frac"] = busy / wsum   # (weighted by launches)
 json.dump(out, open(os.path.join(root, "gpurun_out", "pmc_traffic_current.json"), "w"), indent=1)
 print(json.dumps(out))
 PY

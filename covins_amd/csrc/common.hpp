@@ -170,7 +170,8 @@ enum { SC_COST = 0, SC_JV2 = 1, SC_GG = 2, SC_GN2 = 3, SC_GDOT = 4, SC_GMAX = 5,
 
 struct CholAux;
 // ---- launchers (each enqueues on `st`, no synchronisation)
-void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared = nullptr);  // reprojection -> Hll, g, S (Schur), bred, cost
+void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared = nullptr, hipStream_t side = nullptr,
+                     hipEvent_t ev_lin = nullptr, hipEvent_t ev_kf = nullptr);  // reprojection -> Hll, g, S (Schur), bred, cost
 void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st);
 void launch_obs_jvp(const DevProblem& P, const double* v_all, hipStream_t st);  // scal[SC_JV2] += sum |J v|^2
 void launch_obs_cost(const DevProblem& P, const double* pose, const double* lm, hipStream_t st);  // scal[SC_COST] +=
@@ -210,8 +211,7 @@ struct CholAux {
   int* bwd_cnt = nullptr;        // ticket counters of k_bwd_front (65536, zero between launches)
   double* bwd_scr = nullptr; size_t bwd_scr_elems = 0;   // its scratch (grown on demand by launch_nd_solve)
   hipEvent_t ev_xa = nullptr;    // ... the chain's stream has enqueued the level below completely
-  hipEvent_t ev_sb = nullptr, ev_cf = nullptr, ev_g = nullptr, ev_z = nullptr;  // speed-bias rows ready | chain factor done | Gramians done (mid) | chain sweeps done (aux)
-  bool cf_pending = false;
+  hipEvent_t ev_lin = nullptr, ev_kf = nullptr;  // landmark linearisation done (main stream) | per-keyframe reduction done (side stream): launch_lm_build
   std::vector<hipEvent_t> ev, prof_ev, panel_ev;  // panel_ev: start of every big panel on the main stream (COVGPU_TRACE_PANELS=1)
   std::vector<double> prof_flops;
   // per big panel of the batched (arrow) factorisation: device list of the LIVE (batch, ti, tj) tiles of its bulk update,

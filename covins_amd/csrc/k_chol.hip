@@ -282,10 +282,8 @@ void CholAux::init() {
   if (!head) (void)hipStreamCreateWithPriority(&head, hipStreamNonBlocking, hi);
   if (!mid) mid = make_side_stream(hi);
   if (!aux) aux = make_side_stream(lo);
-  if (!ev_sb) (void)hipEventCreateWithFlags(&ev_sb, hipEventDisableTiming);
-  if (!ev_cf) (void)hipEventCreateWithFlags(&ev_cf, hipEventDisableTiming);
-  if (!ev_g) (void)hipEventCreateWithFlags(&ev_g, hipEventDisableTiming);
-  if (!ev_z) (void)hipEventCreateWithFlags(&ev_z, hipEventDisableTiming);
+  if (!ev_lin) (void)hipEventCreateWithFlags(&ev_lin, hipEventDisableTiming);
+  if (!ev_kf) (void)hipEventCreateWithFlags(&ev_kf, hipEventDisableTiming);
   if (!ev_fill) (void)hipEventCreateWithFlags(&ev_fill, hipEventDisableTiming);
   if (!ev_xb) (void)hipEventCreateWithFlags(&ev_xb, hipEventDisableTiming);
   if (!ev_xa) (void)hipEventCreateWithFlags(&ev_xa, hipEventDisableTiming);
@@ -311,16 +309,13 @@ void CholAux::destroy() {
   for (auto e : panel_ev) (void)hipEventDestroy(e);
   panel_ev.clear();
   ev.clear(); prof_ev.clear();
-  if (ev_sb) { (void)hipEventDestroy(ev_sb); ev_sb = nullptr; }
-  if (ev_cf) { (void)hipEventDestroy(ev_cf); ev_cf = nullptr; }
-  if (ev_g) { (void)hipEventDestroy(ev_g); ev_g = nullptr; }
-  if (ev_z) { (void)hipEventDestroy(ev_z); ev_z = nullptr; }
+  if (ev_lin) { (void)hipEventDestroy(ev_lin); ev_lin = nullptr; }
+  if (ev_kf) { (void)hipEventDestroy(ev_kf); ev_kf = nullptr; }
   if (ev_fill) { (void)hipEventDestroy(ev_fill); ev_fill = nullptr; }
   if (ev_xb) { (void)hipEventDestroy(ev_xb); ev_xb = nullptr; }
   if (ev_xa) { (void)hipEventDestroy(ev_xa); ev_xa = nullptr; }
   if (bwd_cnt) { (void)hipFree(bwd_cnt); bwd_cnt = nullptr; }
   if (bwd_scr) { (void)hipFree(bwd_scr); bwd_scr = nullptr; bwd_scr_elems = 0; }
-  cf_pending = false;
   if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
 }
 void CholAux::mark(hipStream_t s, int tag) {

@@ -430,14 +430,21 @@ static inline int stream_grid(int n) {
 
 constexpr int kG = 16;
 
-void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared) {
+// side != nullptr: the per-keyframe reduction (diagonal blocks, gradient, right-hand side: compute-heavy re-linearisation) runs on the
+// side stream beside the pair pass (off-diagonal blocks: L2-bound record reads) — both follow the landmark pass only and write
+// disjoint entries; whatever comes next on `st` follows both.
+void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared, hipStream_t side, hipEvent_t ev_lin, hipEvent_t ev_kf) {
   if (P.L == 0) { if (pose_system_cleared) (void)hipStreamWaitEvent(st, pose_system_cleared, 0); return; }
   const int groups = kBuildThreads / kG, nblk = (P.L + groups - 1) / groups;
   hipLaunchKernelGGL(k_lm_lin<kG>, dim3(nblk), dim3(kBuildThreads), 0, st, P, mu);  // writes per-observation records only
-  hipLaunchKernelGGL(k_cost_finish, dim3(1), dim3(256), 0, st, P, nblk);
-  if (pose_system_cleared) (void)hipStreamWaitEvent(st, pose_system_cleared, 0);     // first writers of the pose system follow
-  hipLaunchKernelGGL(k_kf_reduce, dim3(P.K), dim3(64), 0, st, P);
+  const bool fork = side != nullptr && ev_lin != nullptr && ev_kf != nullptr && P.npairs > 0;
+  hipStream_t s2 = fork ? side : st;
+  if (fork) { (void)hipEventRecord(ev_lin, st); (void)hipStreamWaitEvent(s2, ev_lin, 0); }
+  hipLaunchKernelGGL(k_cost_finish, dim3(1), dim3(256), 0, s2, P, nblk);
+  if (pose_system_cleared) { (void)hipStreamWaitEvent(s2, pose_system_cleared, 0); if (fork) (void)hipStreamWaitEvent(st, pose_system_cleared, 0); }  // first writers of the pose system follow
+  hipLaunchKernelGGL(k_kf_reduce, dim3(P.K), dim3(64), 0, s2, P);
   if (P.npairs) hipLaunchKernelGGL(k_pair_blocks, dim3((P.npairs + kPairsPerWg - 1) / kPairsPerWg), dim3(kPairLanes * kPairsPerWg), 0, st, P);
+  if (fork) { (void)hipEventRecord(ev_kf, s2); (void)hipStreamWaitEvent(st, ev_kf, 0); }
 }
 void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st) {
   if (P.L == 0) return;

@@ -906,7 +906,7 @@ static void enqueue_build(covgpu_context* c, double mu) {
     launch_imu_gather(P, 1, c->st);
     launch_finalize_diag(P, mu, 1, c->st);
   }
-  launch_lm_build(P, mu, c->st, c->chol.ev_fill);
+  launch_lm_build(P, mu, c->st, c->chol.ev_fill, c->chol.mid, c->chol.ev_lin, c->chol.ev_kf);
   launch_imu_gather(P, 0, c->st);  // pose-dimension part: adds onto the blocks k_kf_reduce assigned (fixed order: visual, inertial, loop)
   launch_edge_build(P, c->st);
   launch_edge_gather(P, c->st);
@@ -1324,7 +1324,6 @@ static int schur_impl(covgpu_context* c, const covgpu_options* opt, const covgpu
   RC(upload_impl(c, opt, p, pgo, false)); RC(reset_state(c));  // dense form: the test reads C back as one matrix
   launch_preintegrate(c->P, c->st);
   enqueue_build(c, mu);
-  if (c->chol.cf_pending) { HIPCHK(hipStreamWaitEvent(c->st, c->chol.ev_cf, 0)); c->chol.cf_pending = false; }  // not used here
   RC(read_scalars(c));
   *cost = c->h_scal[SC_COST];
   // assemble the reduced system in IR layout (D rows per keyframe) from its structured parts

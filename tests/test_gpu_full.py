@@ -148,7 +148,10 @@ def test_multifrontal_solve_equals_one_front_solve(ctx):
     (sd, rd, ld), (sa, ra, la) = out["COVGPU_GBA_DENSE"], out[""]
     assert ld["nd_fronts"] == 1 and la["nd_fronts"] > 20 and la["nd_levels"] >= 4
     assert rd.iterations == ra.iterations and list(rd.accepted_trace[:6]) == list(ra.accepted_trace[:6])
-    assert np.allclose(np.array(ra.cost_trace[:6]), np.array(rd.cost_trace[:6]), rtol=1e-9)
+    # two elimination orders of one system: each linear solve is exact to ~1e-10 of its step (the GN system's condition number
+    # times 1e-16), and the differences compound over the six nonlinear iterations: observed 2e-11 after the first, 1e-9 after the fourth
+    assert np.allclose(np.array(ra.cost_trace[:1]), np.array(rd.cost_trace[:1]), rtol=1e-9)
+    assert np.allclose(np.array(ra.cost_trace[:6]), np.array(rd.cost_trace[:6]), rtol=1e-8)
     assert np.abs(sd.kf_pose - sa.kf_pose).max() < 1e-8 and np.abs(sd.kf_speed_bias - sa.kf_speed_bias).max() < 1e-8
     n_ill, d_good, d_white = landmark_parity(sa.lm_pos, sd)
     assert d_good < 1e-6 and d_white < 1e-4

@@ -211,6 +211,7 @@ struct CholAux {
   int* bwd_cnt = nullptr;        // ticket counters of k_bwd_front (65536, zero between launches)
   double* bwd_scr = nullptr; size_t bwd_scr_elems = 0;   // its scratch (grown on demand by launch_nd_solve)
   hipEvent_t ev_xa = nullptr;    // ... the chain's stream has enqueued the level below completely
+  hipEvent_t ev_zero = nullptr;  // per-iteration buffers cleared (main stream): the side stream's inertial kernels follow
   hipEvent_t ev_lin = nullptr, ev_kf = nullptr;  // landmark linearisation done (main stream) | per-keyframe reduction done (side stream): launch_lm_build
   std::vector<hipEvent_t> ev, prof_ev, panel_ev;  // panel_ev: start of every big panel on the main stream (COVGPU_TRACE_PANELS=1)
   std::vector<double> prof_flops;
@@ -266,6 +267,8 @@ struct DenseBatch {
   hipEvent_t pre_trsm = nullptr;
   int* bwd_cnt = nullptr;          // [n] zeroed ticket counters: whole-front backward substitution in one launch (k_panel.hip: k_bwd_front)
   double* bwd_scr = nullptr;       // its scratch: [n][interior tiles <= 4][row chunks][128]
+  const int* own_dims = nullptr;   // device, [n]: real interior order of every matrix of the batch — substitutions and rank updates stop at a
+                                   // front's OWN last real column (own_max is the batch's: levels mix fronts of 9 .. 250 unknowns)
   int own_max = 0;                 // > 0: largest real interior order over the batch — columns beyond it are identity padding in EVERY
                                    // matrix (L = I, block inverses = I, y = 0 already in place), so the panel kernel factors only the
                                    // 16-column blocks that hold a real column and skips all-padding panels
@@ -282,7 +285,7 @@ void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, dou
 void launch_bwd_front(const double* S, int tI, int ntiles, int nchunk, double* y, const double* Linv, int nbt, size_t sL, size_t sR, hipStream_t st,
                       const long long* btab, const int* live, BwdXfer xf, int* cnt, double* scr);
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
-                     size_t sR, const int* live, int tI, hipStream_t st, bool chain = false, const long long* btab = nullptr, int nb = -1);
+                     size_t sR, const int* live, int tI, hipStream_t st, bool chain = false, const long long* btab = nullptr, int nb = -1, const int* own = nullptr);
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,
                          size_t sL, size_t sR, hipStream_t st, const long long* btab = nullptr, const int* live = nullptr, int tI = 0,
                          BwdXfer xf = BwdXfer());  // xf.gidx != nullptr (pass it with p == 0 only): the front's own unknowns go to the solution vector

@@ -81,6 +81,8 @@ struct GemmArgs {
   // fronts of unequal order in one batch (k_front.hip): btab[2 batch] = element offset of the matrix, btab[2 batch + 1] = its
   // leading dimension; nullptr = the uniform bsM / ld above
   const long long* btab;
+  // [batch] real interior order of every matrix (nullptr: KD applies to all): the K range stops at a front's own last real column
+  const int* own;
 };
 __device__ __forceinline__ bool tile_live(const GemmArgs& g, int batch, int t) {
   if (g.live == nullptr) return true;
@@ -144,7 +146,13 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
     if (!tile_live(g, batch, g.ra0 / kTile + ti)) return;                    // A rows are padding
     if (MODE != MODE_TRSM && !tile_live(g, batch, g.rb0 / kTile + tj)) return;  // B rows are padding
   }
-  const int kbeg = 0, kend = g.KD;
+  const int kbeg = 0;
+  int kend = g.KD;
+  if (MODE != MODE_TRSM && g.own != nullptr) {
+    const int real = g.own[batch] - g.kcol0;
+    if (real <= 0) return;   // (wave-uniform) this front has no real column in the panel: A = B = 0
+    kend = min(kend, ((real + KC - 1) / KC) * KC);
+  }
   extern __shared__ __attribute__((aligned(16))) double smem[];  // [TSA][KC+1] + [TSB][KC+1] doubles
   double (*sA)[LDT] = reinterpret_cast<double (*)[LDT]>(smem);
   double (*sB)[LDT] = reinterpret_cast<double (*)[LDT]>(smem + TSA * LDT);
@@ -282,6 +290,7 @@ void CholAux::init() {
   if (!head) (void)hipStreamCreateWithPriority(&head, hipStreamNonBlocking, hi);
   if (!mid) mid = make_side_stream(hi);
   if (!aux) aux = make_side_stream(lo);
+  if (!ev_zero) (void)hipEventCreateWithFlags(&ev_zero, hipEventDisableTiming);
   if (!ev_lin) (void)hipEventCreateWithFlags(&ev_lin, hipEventDisableTiming);
   if (!ev_kf) (void)hipEventCreateWithFlags(&ev_kf, hipEventDisableTiming);
   if (!ev_fill) (void)hipEventCreateWithFlags(&ev_fill, hipEventDisableTiming);
@@ -309,6 +318,7 @@ void CholAux::destroy() {
   for (auto e : panel_ev) (void)hipEventDestroy(e);
   panel_ev.clear();
   ev.clear(); prof_ev.clear();
+  if (ev_zero) { (void)hipEventDestroy(ev_zero); ev_zero = nullptr; }
   if (ev_lin) { (void)hipEventDestroy(ev_lin); ev_lin = nullptr; }
   if (ev_kf) { (void)hipEventDestroy(ev_kf); ev_kf = nullptr; }
   if (ev_fill) { (void)hipEventDestroy(ev_fill); ev_fill = nullptr; }
@@ -378,7 +388,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   // C tiles (rows [r0, r1), tile columns [tc0, tc0+ntc)) -= A[rows, K] A[tc.., K]^T, K = tiles kt0.. (KD columns); lower part only
   auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2, bool quad) {
     if (r1 <= r0 || ntc <= 0 || KD <= 0) return;
-    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab};
+    GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab, bt.own_dims};
     if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4 * nbt), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0, nbt), dim3(256), lds_gemm, s2, g);
   };
@@ -500,12 +510,12 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         //  the bulk stream's leg (rest rows, rest of the update, second half of the extend-add) is what the next level's
         //  substitutions wait for, and it only got longer: 3.37 vs 3.33 ms)
         const bool split = bt.split_ta > 0 && bt.live_h != nullptr && kd(P) > 0 && (tc.listA != nullptr || tc.listB != nullptr);
-        launch_trsm_sub(S, ld, t0, w, h0, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp);
+        launch_trsm_sub(S, ld, t0, w, h0, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
         if (split) { (void)hipEventRecord(eH[P], M); wait(B, eH[P]); }
         if (P >= 1) wait(M, eB[P - 1]);  // bulk(P-1) was the previous writer of the trailing tiles
         const int tb = h0, nt = T - tb;
         auto syrk = [&](hipStream_t s2, const int* list, int count, double pairs) {
-          GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab};
+          GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab, bt.own_dims};
           g.tri = list;
           if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], s2);
           // a short list runs at the LATENCY of one workgroup's K loop (16 chunks of 64 MFMAs per wave): as 64x64 quadrants it is
@@ -560,12 +570,12 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       (void)hipEventRecord(e1[P], M);
       if (h1 > h0) {
         if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
-        launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp);
+        launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
       }
       (void)hipEventRecord(eH[P], M);
       if (T > h1) {
         wait(R, e1[P]);
-        launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab, nbp);
+        launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab, nbp, bt.own_dims);
       }
       (void)hipEventRecord(eC[P], R);
     }
@@ -585,7 +595,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     if (P + 1 < NP) wait(B, eRc[P + 1]);
     if (nt > 0 && kd(P) > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
-      GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab};
+      GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab, bt.own_dims};
       // arrow buffers: the live tiles of this panel's update as an explicit, XCD-balanced list (built once per problem).
       // The implicit triangle grid x batch launched ~2.6k workgroups of which ~400 did work, with every batch's first
       // supertile on XCD 0: 17 TFLOP/s.

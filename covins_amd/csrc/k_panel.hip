@@ -401,12 +401,13 @@ struct TrsmSubArgs {
   const int* live; int tI;           // see GemmArgs (k_chol.hip)
   int chain;                         // 1: launched on the serial chain — its waves raise their issue priority over the bulk update's
   const long long* btab;             // see GemmArgs (k_chol.hip)
+  const int* own;                    // [batch] real interior order of every front (nullptr: the launch-wide NB applies to all)
 };
 
 // X = A L^-T on a 16-row slab, L = the (16 NB)-order factor at (k0, k0). One wave, everything in registers.
 // acc[i][reg] at lane (n = lane & 15, fk = lane >> 4) holds Z[16 i + 4 fk + reg][n] = X[row0 + n][k0 + 16 i + 4 fk + reg].
 template <int NB>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trsm_sub(TrsmSubArgs g) {
+COV_DEV void trsm_sub_body(const TrsmSubArgs& g) {
   const int batch = blockIdx.y, lane = threadIdx.x, n = lane & 15, fk = lane >> 4;
   const int row0 = g.r0 + PB * (int)blockIdx.x;
   if (g.chain) __builtin_amdgcn_s_setprio(3);  // resident beside bulk-update waves that keep the matrix pipe busy: without it the slab runs 2.5x longer
@@ -471,6 +472,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     part += __shfl_xor(part, 32, 64);
     if (fk == 0) g.rhs[(size_t)batch * g.bsR + row0 + n] -= part;
   }
+}
+
+// The launch is sized for the widest front of the batch; a front with fewer real columns in this panel runs the shorter body
+// (its further columns are identity padding: X = A = 0 there), one without any returns at once.
+template <int NB>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trsm_sub(TrsmSubArgs g) {
+  if (g.own != nullptr) {
+    const int real = g.own[blockIdx.y] - g.k0;
+    if (real <= 0) return;
+    const int nbf = (real + PB - 1) / PB;
+    if (NB > 4 && nbf <= 4) { trsm_sub_body<4>(g); return; }
+    if (NB > 8 && nbf <= 8) { trsm_sub_body<8>(g); return; }
+    if (NB > 12 && nbf <= 12) { trsm_sub_body<12>(g); return; }
+  }
+  trsm_sub_body<NB>(g);
 }
 
 // Backward substitution step for tile p with the 16x16 block inverses (Dinv == nullptr: x_p is given):
@@ -760,9 +776,9 @@ void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* 
 }
 
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
-                     size_t sR, const int* live, int tI, hipStream_t st, bool chain, const long long* btab, int nb) {
+                     size_t sR, const int* live, int tI, hipStream_t st, bool chain, const long long* btab, int nb, const int* own) {
   if (r1 <= r0 || nb == 0) return;
-  TrsmSubArgs g{S, ld, t0 * kTile, r0 * kTile, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, live, tI, chain ? 1 : 0, btab};
+  TrsmSubArgs g{S, ld, t0 * kTile, r0 * kTile, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, live, tI, chain ? 1 : 0, btab, own};
   const dim3 grid((r1 - r0) * (kTile / PB), nbt);
   // nb: 16-column blocks of the panel that hold real columns (the rest is identity padding with zeros below: X = A there)
   const int need = nb > 0 ? std::min(nb, 8 * w) : 8 * w;

@@ -899,14 +899,19 @@ static void enqueue_build(covgpu_context* c, double mu) {
   else (void)hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), c->chol.head);
   (void)hipEventRecord(c->chol.ev_fill, c->chol.head);
   launch_zero_system(P, c->st);
-  // inertial factors first: the speed-bias blocks are then final, and the (serial, one wave per IMU chain) chain
-  // factorisation runs on the auxiliary stream underneath the landmark pass
-  launch_imu_build(P, c->st);
+  // inertial factors (one wave per factor: latency, not throughput) on the side stream beside the landmark pass; their speed-bias
+  // blocks are final before anything of the pose system is touched, the pose-dimension part is gathered after the visual blocks
+  hipStream_t side = c->chol.mid;
+  (void)hipEventRecord(c->chol.ev_zero, c->st);
+  (void)hipStreamWaitEvent(side, c->chol.ev_zero, 0);
+  launch_imu_build(P, side);
   if (P.vi) {
-    launch_imu_gather(P, 1, c->st);
-    launch_finalize_diag(P, mu, 1, c->st);
+    launch_imu_gather(P, 1, side);
+    launch_finalize_diag(P, mu, 1, side);
   }
-  launch_lm_build(P, mu, c->st, c->chol.ev_fill, c->chol.mid, c->chol.ev_lin, c->chol.ev_kf);
+  launch_lm_build(P, mu, c->st, c->chol.ev_fill, side, c->chol.ev_lin, c->chol.ev_kf);
+  (void)hipEventRecord(c->chol.ev_kf, side);
+  (void)hipStreamWaitEvent(c->st, c->chol.ev_kf, 0);
   launch_imu_gather(P, 0, c->st);  // pose-dimension part: adds onto the blocks k_kf_reduce assigned (fixed order: visual, inertial, loop)
   launch_edge_build(P, c->st);
   launch_edge_gather(P, c->st);

@@ -267,6 +267,7 @@ struct DenseBatch {
   hipEvent_t pre_trsm = nullptr;
   int* bwd_cnt = nullptr;          // [n] zeroed ticket counters: whole-front backward substitution in one launch (k_panel.hip: k_bwd_front)
   double* bwd_scr = nullptr;       // its scratch: [n][interior tiles <= 4][row chunks][128]
+  const int* own_dims_h = nullptr; // host copy of own_dims (flop accounting of the profiled run)
   const int* own_dims = nullptr;   // device, [n]: real interior order of every matrix of the batch — substitutions and rank updates stop at a
                                    // front's OWN last real column (own_max is the batch's: levels mix fronts of 9 .. 250 unknowns)
   int own_max = 0;                 // > 0: largest real interior order over the batch — columns beyond it are identity padding in EVERY

@@ -413,6 +413,12 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     if (bt.own_max <= 0) return full;
     return std::max(0, std::min(full, ((bt.own_max - 2 * Pp * kTile + 31) / 32) * 32));
   };
+  // K range front `a` really runs in panel Pp's rank update (GemmArgs::own): for the flop count of the profiled run
+  auto kd_front = [&](int Pp, int a, int chunk) {
+    if (bt.own_dims_h == nullptr) return kd(Pp);
+    const int real = bt.own_dims_h[a] - 2 * Pp * kTile;
+    return real <= 0 ? 0 : std::min(kd(Pp), ((real + chunk - 1) / chunk) * chunk);
+  };
   if (bt.tri_slot >= (int)ax.tri_lev.size()) ax.tri_lev.resize(bt.tri_slot + 1);
   CholAux::TriCache& tc = bt.tri_slot >= 0 ? ax.tri_lev[bt.tri_slot] : ax.tri0;
   // live tiles (i, j), j <= i, of the triangle that starts at tile tb, for the fronts whose interior reaches panel column t0;
@@ -514,7 +520,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         if (split) { (void)hipEventRecord(eH[P], M); wait(B, eH[P]); }
         if (P >= 1) wait(M, eB[P - 1]);  // bulk(P-1) was the previous writer of the trailing tiles
         const int tb = h0, nt = T - tb;
-        auto syrk = [&](hipStream_t s2, const int* list, int count, double pairs) {
+        auto syrk = [&](hipStream_t s2, const int* list, int count, double flops) {
           GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab, bt.own_dims};
           g.tri = list;
           if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], s2);
@@ -529,20 +535,22 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
           }
           if (ax.profile) {
             (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], s2);
-            ax.prof_flops.push_back(pairs * 2.0 * kTile * kTile * kd(P));
+            ax.prof_flops.push_back(flops);
           }
         };
         if (kd(P) > 0) {
-          double pairs = 0.0, pairsA = 0.0;
+          double pairs = 0.0, pairsA = 0.0;   // flops of the whole update | of its first split_ta tile rows
+          const double per_k = 2.0 * kTile * kTile;
           for (int a = 0; a < nbt; ++a) {
-            if (bt.live_h == nullptr) { pairs += (double)nt * (nt + 1) / 2; continue; }
+            if (bt.live_h == nullptr) { pairs += (double)nt * (nt + 1) / 2 * per_k * kd(P); continue; }
             const int nI = bt.live_h[2 * a], nO = bt.live_h[2 * a + 1];
             if (t0 >= nI) continue;
             int nl = 0;
             for (int t = tb; t < T; ++t) nl += (t < nI || (t >= bt.tI && t - bt.tI < nO)) ? 1 : 0;
-            pairs += (double)nl * (nl + 1) / 2;
+            const double kf = kd_front(P, a, KCQ);
+            pairs += (double)nl * (nl + 1) / 2 * per_k * kf;
             const int na = std::min(nl, bt.split_ta);
-            pairsA += (double)na * (na + 1) / 2;
+            pairsA += (double)na * (na + 1) / 2 * per_k * kf;
           }
           if (split) {
             // look-ahead across levels: the tiles the parents' first panel receives on the chain's stream, the rest on the bulk stream
@@ -601,14 +609,14 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // supertile on XCD 0: 17 TFLOP/s.
       const bool listed = bt.live_h != nullptr && P < (int)tc.list.size() && tc.list[P] != nullptr;
       if (listed) g.tri = tc.list[P];
-      double pairs = 0.0;  // tile pairs that do work
+      double flops = 0.0;  // of the tile pairs that do work, over the K range each front really runs
       for (int a = 0; a < nbt; ++a) {
-        if (bt.live_h == nullptr) { pairs += (double)nt * (nt + 1) / 2; continue; }
+        if (bt.live_h == nullptr) { flops += (double)nt * (nt + 1) / 2 * 2.0 * kTile * kTile * kd(P); continue; }
         const int nI = bt.live_h[2 * a], nO = bt.live_h[2 * a + 1];
         if (t0 >= nI) continue;
         int nl = 0;
         for (int t = tb; t < T; ++t) nl += (t < nI || (t >= bt.tI && t - bt.tI < nO)) ? 1 : 0;
-        pairs += (double)nl * (nl + 1) / 2;
+        flops += (double)nl * (nl + 1) / 2 * 2.0 * kTile * kTile * kd_front(P, a, KC);
       }
       if (!listed || tc.count[P] > 0) {
         if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], B);
@@ -618,7 +626,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, B, g);
         if (ax.profile) {
           (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], B);
-          ax.prof_flops.push_back(pairs * 2.0 * kTile * kTile * kd(P));
+          ax.prof_flops.push_back(flops);
         }
       }
     }

@@ -382,7 +382,7 @@ void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     DenseBatch bt;
     bt.n = L.n; bt.sM = 0; bt.sL = (size_t)L.nI * kTile; bt.sR = (size_t)2 * L.ntot;
     bt.live = L.live; bt.tI = L.nI / kTile; bt.live_h = L.live_h.data();
-    bt.tab = P.nd_ntab + 2 * (size_t)L.first; bt.tri_slot = l; bt.own_max = L.own_max; bt.own_dims = nd.own_dims + L.first;
+    bt.tab = P.nd_ntab + 2 * (size_t)L.first; bt.tri_slot = l; bt.own_max = L.own_max; bt.own_dims = nd.own_dims + L.first; bt.own_dims_h = nd.h_own_dims.data() + L.first;
     return bt;
   };
   // part: 0 all tiles | 1 the tiles of the fronts' first 256 rows | 2 the others

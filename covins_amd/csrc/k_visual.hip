@@ -316,16 +316,32 @@ __global__ __launch_bounds__(kPairLanes * kPairsPerWg) void k_pair_blocks(DevPro
   double acc[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-  for (int e = e0 + g; e < e1; e += kPairLanes) {
+  // two common landmarks per lane and trip: four 144-byte records in flight instead of two (the pass runs at the latency of these
+  // scattered reads); the second one of an odd tail reads the first again with weight zero
+  for (int e = e0 + g; e < e1; e += 2 * kPairLanes) {
+    const int e2 = e + kPairLanes;
+    const bool two = e2 < e1;
     const double2* y = reinterpret_cast<const double2*>(P.obsZ + 18 * (size_t)P.pair_oa[e]);
     const double2* w = reinterpret_cast<const double2*>(P.obsZ + 18 * (size_t)P.pair_ob[e]);
-    double yv[18], wv[18];
+    const double2* y2 = reinterpret_cast<const double2*>(P.obsZ + 18 * (size_t)P.pair_oa[two ? e2 : e]);
+    const double2* w2 = reinterpret_cast<const double2*>(P.obsZ + 18 * (size_t)P.pair_ob[two ? e2 : e]);
+    double yv[18], wv[18], yu[18], wu[18];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { const double2 a2 = y[k], b2 = w[k]; yv[2 * k] = a2.x; yv[2 * k + 1] = a2.y; wv[2 * k] = b2.x; wv[2 * k + 1] = b2.y; }
+    for (int k = 0; k < 9; ++k) {
+      const double2 a2 = y[k], b2 = w[k], c2 = y2[k], d2 = w2[k];
+      yv[2 * k] = a2.x; yv[2 * k + 1] = a2.y; wv[2 * k] = b2.x; wv[2 * k + 1] = b2.y;
+      yu[2 * k] = c2.x; yu[2 * k + 1] = c2.y; wu[2 * k] = d2.x; wu[2 * k + 1] = d2.y;
+    }
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
       for (int c = 0; c < 6; ++c) acc[6 * r + c] += yv[3 * r] * wv[3 * c] + yv[3 * r + 1] * wv[3 * c + 1] + yv[3 * r + 2] * wv[3 * c + 2];
+    if (two) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[6 * r + c] += yu[3 * r] * wu[3 * c] + yu[3 * r + 1] * wu[3 * c + 1] + yu[3 * r + 2] * wu[3 * c + 2];
+    }
   }
 #pragma unroll
   for (int k = 0; k < 36; ++k) sp[grp][k][g] = acc[k];

@@ -1,5 +1,5 @@
 # round-3 measurement pass (one MI355X): GPU tests, bench lines of every workload, kernel stats, iteration timeline, PMC passes
-tag=${1:-r03a}
+tag=${1:-r03b}
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -q -s --timeout 900 2>&1 | grep -E "passed|failed|error|world|a12x1000|difference|pgo " | tail -30 > gpurun_out/${tag}_gpu_tests_tail.txt
 for w in mh01 mh123; do python bench.py --workload $w --steps 3 --warmup 1 --no-e2e > gpurun_out/${tag}_bench_$w.json 2> gpurun_out/${tag}_bench_$w.err; done

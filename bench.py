@@ -203,7 +203,7 @@ def main():
                        "sharding": ("none (1 GPU)" if not sharded else
                                     f"ONE map sharded over {world} ranks: {plan.subtrees} subtrees of the elimination tree dealt to the ranks, "
                                     f"{lay['top_unknowns']} scalar unknowns in the replicated top ({int((plan.pose_rank < 0).sum())} shared keyframe poses); "
-                                    f"{'RCCL' if world > 1 else 'in-process one-rank group'} all-reduce (issued by libcovgpu on its own stream) of the top fronts + right-hand sides + gradient rows ({lay['allreduce_kib'] / 1024:.1f} MiB per linear solve) "
+                                    f"{'RCCL' if world > 1 or keep == ('rccl',) else 'in-process one-rank group'} all-reduce (issued by libcovgpu on its own stream) of the top fronts + right-hand sides + gradient rows ({lay['allreduce_kib'] / 1024:.1f} MiB per linear solve) "
                                     f"and 3 scalar exchanges per iteration: {shard_stats['collectives']} collectives, {shard_stats['bytes'] / 1e6:.1f} MB on rank 0 "
                                     f"in the timed steps + warm-up")},
             "kf_per_s": k_free * iters_all / dt,

@@ -140,11 +140,17 @@ def attach(ctx, plan: ShardPlan, rank: int, world: int, force_single: bool = Fal
     if group is not None:
         ctx.set_shard_group(plan, rank, group)
         return (group,)
+    from . import backend
     if world <= 1:
+        # one rank: the RCCL form (a one-rank communicator: collectives stream-ordered, no host synchronisation — what every rank of
+        # a real run executes); the in-process group (host barriers: the test vehicle of the virtual ranks) only without librccl
+        buf = (C.c_uint8 * 128)()
+        if backend.lib().covgpu_rccl_unique_id(buf) == 0:
+            ctx.set_shard_rccl(plan, 0, 1, bytes(buf))
+            return ("rccl",)
         g = Group(1)
         ctx.set_shard_group(plan, 0, g)
         return (g,)
-    from . import backend
     from torch.distributed import TCPStore
     import datetime
     store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")), world, rank == 0,

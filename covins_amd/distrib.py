@@ -151,19 +151,29 @@ def attach(ctx, plan: ShardPlan, rank: int, world: int, force_single: bool = Fal
         g = Group(1)
         ctx.set_shard_group(plan, 0, g)
         return (g,)
-    from torch.distributed import TCPStore
-    import datetime
-    store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")), world, rank == 0,
-                     timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+    store = open_store(rank, world)
     if rank == 0:
         buf = (C.c_uint8 * 128)()
         rc = backend.lib().covgpu_rccl_unique_id(buf)
         if rc != 0:
             raise backend.CovGpuError(backend.lib().covgpu_last_error().decode())
-        store.set("covgpu_rccl_id", bytes(buf))
-    uid = store.get("covgpu_rccl_id")
+        store.set("rccl_id", bytes(buf))
+    uid = store.get("rccl_id")
     ctx.set_shard_rccl(plan, rank, world, bytes(uid))
     return (store,)
+
+
+def open_store(rank: int, world: int):
+    """Key-value store on MASTER_ADDR:MASTER_PORT for the few bytes the ranks exchange outside the data path (the RCCL unique id,
+    the solved pieces at the end of a bench run). Under `python -m torch.distributed.run` the elastic agent already serves a
+    TCPStore on that port (TORCHELASTIC_USE_AGENT_STORE): every rank connects as a client, exactly as torch's own env://
+    rendezvous does; launched by hand, rank 0 hosts it."""
+    import datetime
+    from torch.distributed import PrefixStore, TCPStore
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")), world, rank == 0 and not agent,
+                     timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+    return PrefixStore(f"covgpu/{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}/", store)
 
 
 def barrier(ctx, sharded: bool) -> None:
@@ -189,5 +199,5 @@ def throughput(dt_max: float, iterations: float) -> float:
 def gather_solutions(sol: FlatProblem, rank: int, world: int, store) -> Sequence:
     """All ranks' (poses, speed-bias, landmarks) on every rank, through the TCPStore of `attach` (small: a few MB)."""
     import pickle
-    store.set(f"covgpu_sol_{rank}", pickle.dumps((sol.kf_pose, sol.kf_speed_bias, sol.lm_pos)))
-    return [pickle.loads(store.get(f"covgpu_sol_{r}")) for r in range(world)]
+    store.set(f"sol_{rank}", pickle.dumps((sol.kf_pose, sol.kf_speed_bias, sol.lm_pos)))
+    return [pickle.loads(store.get(f"sol_{r}")) for r in range(world)]

@@ -135,6 +135,23 @@ def test_two_rank_gloo_top_front_reduction():
     assert not S[np.ix_(o0, o1)].any()
 
 
+def test_store_rendezvous_under_torchrun(tmp_path):
+    """The few bytes the ranks exchange outside the data path (RCCL unique id, solved pieces) travel through a TCPStore on
+    MASTER_ADDR:MASTER_PORT. Under `python -m torch.distributed.run` — how the driver launches bench.py for N > 1 — the elastic agent
+    already listens on that port: the ranks must connect as clients (a rank-0 server there fails with 'address already in use')."""
+    import subprocess
+    import sys
+    port = 29500 + 2000 + (os.getpid() % 2000)
+    out = str(tmp_path / "store")
+    env = dict(os.environ, COVGPU_TEST_OUT=out)
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "store_worker.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), worker], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    h = [open(f"{out}.{k}").read() for k in range(2)]
+    assert h[0] == h[1] and len(h[0]) == 64
+
+
 def test_single_process_is_identity():
     assert distrib.aggregate(0.5, 7, None, False) == (0.5, 7.0)
     assert distrib.throughput(2.0, 10.0) == 5.0

@@ -274,11 +274,17 @@ void nd_shard_assign(NdHostPlan& hp, int world) {
     double tot = 0.0;
     for (int c : cand) tot += sub[c];
     // enough pieces and none much heavier than a rank's fair share: stop. Opening a node makes it a TOP node — its whole front
-    // joins the all-reduced range and its factorisation is replicated — so the top is also capped at 96 MiB of fronts.
+    // joins the all-reduced range and its factorisation is replicated on every rank. The solve is latency-bound (a rank runs
+    // two agents' subtrees in the same batched launches almost as fast as one), so what a larger top buys in balance it loses in
+    // the exchange: the top never grows beyond 48 MiB of fronts unless the roots alone are larger — rather fewer subtrees than
+    // ranks (ranks without a subtree still hold the top and take part in the exchange).
     if ((int)cand.size() >= world && sub[cand[0]] <= 1.25 * tot / world) break;
-    if ((int)cand.size() >= world && top_bytes > 96.0 * 1048576.0) break;
     int pick = -1;
-    for (size_t q = 0; q < cand.size() && pick < 0; ++q) if (!hp.child[cand[q]].empty()) pick = (int)q;  // heaviest that can still be opened
+    for (size_t q = 0; q < cand.size() && pick < 0; ++q) {   // heaviest that can still be opened within the cap
+      const int c = cand[q];
+      const double nb = 8.0 * (double)(hp.own_dims[c] + hp.st_dims[c]) * (double)(hp.own_dims[c] + hp.st_dims[c]);
+      if (!hp.child[c].empty() && top_bytes + nb <= 48.0 * 1048576.0) pick = (int)q;
+    }
     if (pick < 0) break;
     const int c = cand[pick];
     cand.erase(cand.begin() + pick);

@@ -40,8 +40,8 @@ bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs
 
 // Multi-GPU split of the tree: the top of the tree is replicated, the subtrees below it are dealt to the
 // ranks by longest-processing-time-first on their factorisation flops. Top = the roots, grown downwards (heaviest subtree
-// first) until there are at least `world` subtrees and none outweighs 1.25x a rank's fair share (or the top reaches 96 MiB of
-// fronts: every top front is all-reduced and factorised on every rank). Deterministic.
+// first) until there are at least `world` subtrees and none outweighs 1.25x a rank's fair share — but never beyond 48 MiB of top
+// fronts (every top front is all-reduced and factorised on every rank): rather fewer subtrees than ranks. Deterministic.
 void nd_shard_assign(NdHostPlan& hp, int world);
 // variable ids -> var_map[old id] (chain positions of one problem -> IR keyframes -> chain positions of a rank's sub-problem)
 void nd_plan_remap(NdHostPlan& hp, const std::vector<int>& var_map);

@@ -51,7 +51,9 @@ def test_sharded_gauss_newton_step_equals_unsharded(name, world):
     p = problem(name)
     o = backend.default_options()
     plan = distrib.shard_plan(p, o, world)
-    assert plan is not None and plan.subtrees >= world   # (a single agent splits too: the units are subtrees, not agents)
+    # (a single agent splits too: the units are subtrees, not agents; the top is capped — rather fewer subtrees than ranks: at world 8
+    #  two ranks of the 5-agent map hold the replicated top only and still take part in every exchange)
+    assert plan is not None and plan.subtrees >= min(world, 5)
     ctx = backend.Context(0)
     dx0, dl0, c0 = ctx.gn_step(p, o, 1e-8)
     ctx.close()
@@ -78,7 +80,7 @@ def test_sharded_gauss_newton_step_equals_unsharded(name, world):
     assert st["collectives"] == 1    # one exchange per linear solve (covgpu_gn_step reads no trust-region scalars)
 
 
-@pytest.mark.parametrize("name,world,strategy", [("mh123", 3, 0), ("mh12345", 5, 0), ("mh12345", 4, 1), ("mh01", 2, 0)])
+@pytest.mark.parametrize("name,world,strategy", [("mh123", 3, 0), ("mh12345", 5, 0), ("mh12345", 4, 1), ("mh01", 2, 0), ("mh12345", 8, 0)])
 def test_sharded_solve_equals_unsharded(name, world, strategy):
     p = problem(name)
     o = backend.default_options(max_iterations=10, strategy=strategy)

@@ -471,6 +471,8 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   }
   int Plast = NP - 1;
   bool split_last = false;  // the last panel's bulk update was left running on B for the caller (DenseBatch::split_ta)
+  bool tail_on_chain = false;  // the last panel ran whole on the chain's own stream: nothing of it to join (every event packet on
+                               // the chain's stream is a few microseconds between two dependent kernels)
   for (int P = 0; P < NP; ++P) {
     const int t0 = 2 * P, w = (T - t0 >= 2) ? 2 : 1;
     const int h0 = (t0 + 2 < T) ? t0 + 2 : T, h1 = (t0 + 4 < T) ? t0 + 4 : T;  // rows h = [h0, h1), rows r = [h1, T)
@@ -508,7 +510,6 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       const int nbp = bt.own_max > 0 ? std::max(0, std::min(8 * w, (bt.own_max - t0 * kTile + 15) / 16)) : -1;
       launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp);
       if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
-      (void)hipEventRecord(e1[P], M);
       bool split_done = false;
       if (T > h0) {
         if (P > 0) { if (h1 > h0) wait(M, eHp[P]); if (T > h1) wait(M, e2[P]); }
@@ -564,9 +565,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
           }
         }
       }
-      (void)hipEventRecord(eH[P], M); (void)hipEventRecord(eC[P], M);
-      if (!split_done) (void)hipEventRecord(eB[P], M);
-      Plast = P; split_last = split_done;
+      Plast = P; split_last = split_done; tail_on_chain = true;
       break;
     }
     {
@@ -575,14 +574,15 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       const int nbp = bt.own_max > 0 ? std::max(0, std::min(8 * w, (bt.own_max - t0 * kTile + 15) / 16)) : -1;
       launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp);
       if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
-      (void)hipEventRecord(e1[P], M);
+      // (no event of its own for "panel factored": every event packet here sits between two dependent kernels of the chain — the
+      //  rest rows, which only need the factored panel, start one kernel later, after eH)
       if (h1 > h0) {
         if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
         launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
       }
       (void)hipEventRecord(eH[P], M);
       if (T > h1) {
-        wait(R, e1[P]);
+        wait(R, eH[P]);
         launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab, nbp, bt.own_dims);
       }
       (void)hipEventRecord(eC[P], R);
@@ -590,7 +590,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     // ---- M: look-ahead part of SYRK(P) on the next panel's 2x2 diagonal tiles
     if (P + 1 < NP) {
       const int u0 = t0 + 2, uw = (T - u0 >= 2) ? 2 : 1;
-      wait(M, eH[P]);                          // L rows u0, u0+1
+      // (L rows u0, u0+1 were solved on this stream)
       if (P >= 1) wait(M, eB[P - 1]);          // bulk(P-1) was the previous writer of these tiles
       rect(u0, u0 + uw, u0, uw, t0, kd(P), M, true);
       (void)hipEventRecord(eRc[P + 1], M);
@@ -632,10 +632,9 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     }
     (void)hipEventRecord(eB[P], B);
   }
-  if (!split_last) wait(M, eB[Plast]);
+  if (!split_last && !tail_on_chain) wait(M, eB[Plast]);
   if (Plast >= 1) wait(M, eB[Plast - 1]);
-  wait(M, eC[Plast]);
-  wait(M, eH[Plast]);
+  if (!tail_on_chain) { wait(M, eC[Plast]); wait(M, eH[Plast]); }
   if (!solve) return;
   // y = L^-1 b was formed along the way (potrf: y_p = L_pp^-1 b_p; every TRSM: b[rows] -= L[rows, p] y_p) and lives
   // in b[npad .. 2 npad). Remaining: L^T x = y.

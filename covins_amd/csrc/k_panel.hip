@@ -405,6 +405,9 @@ struct TrsmSubArgs {
 };
 
 // X = A L^-T on a 16-row slab, L = the (16 NB)-order factor at (k0, k0). One wave, everything in registers.
+// (Measured and dropped: FOUR waves per slab for the 16 slabs of the next panel's rows on the serial chain — block columns dealt
+//  to the waves, Z_j handed on through LDS with one LDS-only barrier per step. Correct, but 260 VGPRs once unrolled — the
+//  workgroup then only starts on an empty CU — and 3.01 vs 2.95 ms for the whole solve.)
 // acc[i][reg] at lane (n = lane & 15, fk = lane >> 4) holds Z[16 i + 4 fk + reg][n] = X[row0 + n][k0 + 16 i + 4 fk + reg].
 template <int NB>
 COV_DEV void trsm_sub_body(const TrsmSubArgs& g) {

@@ -460,7 +460,7 @@ void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t 
   if (pose_system_cleared) { (void)hipStreamWaitEvent(s2, pose_system_cleared, 0); if (fork) (void)hipStreamWaitEvent(st, pose_system_cleared, 0); }  // first writers of the pose system follow
   hipLaunchKernelGGL(k_kf_reduce, dim3(P.K), dim3(64), 0, s2, P);
   if (P.npairs) hipLaunchKernelGGL(k_pair_blocks, dim3((P.npairs + kPairsPerWg - 1) / kPairsPerWg), dim3(kPairLanes * kPairsPerWg), 0, st, P);
-  if (fork) { (void)hipEventRecord(ev_kf, s2); (void)hipStreamWaitEvent(st, ev_kf, 0); }
+  // (fork: the caller joins the side stream back — it has more on it)
 }
 void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st) {
   if (P.L == 0) return;

@@ -574,31 +574,38 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       const int nbp = bt.own_max > 0 ? std::max(0, std::min(8 * w, (bt.own_max - t0 * kTile + 15) / 16)) : -1;
       launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp);
       if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
-      // (every event packet on this stream sits between two dependent kernels of the chain, a few microseconds each: ONE event per
-      //  panel, eH, recorded after the look-ahead update of the next diagonal block — the rest rows (which only need the factored
-      //  panel), the next panel's rows on stream H and the bulk update all start from it, two small kernels later than they could)
+      // Every event packet on this stream sits between two dependent kernels of the chain, a few microseconds each. While the bulk
+      // update is short (the period of the factorisation is the chain: small fronts, the tail of big ones) there is ONE event per
+      // panel, eH, recorded after the look-ahead update of the next diagonal block — the rest rows (which only need the factored
+      // panel), the next panel's rows on stream H and the bulk update all start from it, two small kernels later than they could.
+      // While the bulk update is long (the period is the bulk) they start as early as possible: an event after each kernel.
+      const double bulk_pairs = (T - (t0 + 4) > 0) ? 0.5 * (double)(T - (t0 + 4)) * (T - (t0 + 4) + 1) * nbt : 0.0;
+      const bool chain_bound = bulk_pairs <= 700.0;
+      if (!chain_bound) (void)hipEventRecord(e1[P], M);
       if (h1 > h0) {
         if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
         launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
       }
+      if (!chain_bound) (void)hipEventRecord(eH[P], M);
       // ---- M: look-ahead part of SYRK(P) on the next panel's 2x2 diagonal tiles
       if (P + 1 < NP) {
         const int u0 = t0 + 2, uw = (T - u0 >= 2) ? 2 : 1;
         if (P >= 1) wait(M, eB[P - 1]);          // bulk(P-1) was the previous writer of these tiles
         rect(u0, u0 + uw, u0, uw, t0, kd(P), M, true);
       }
-      (void)hipEventRecord(eH[P], M);
+      // (A bulk launched at the same instant as the next diagonal update takes every workgroup slot first and the chain waits
+      //  ~75 us for the first round of tiles to retire: the bulk starts after that small kernel in either regime.)
+      (void)hipEventRecord(chain_bound ? eH[P] : eRc[P], M);
       if (T > h1) {
-        wait(R, eH[P]);
+        wait(R, chain_bound ? eH[P] : e1[P]);
         launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab, nbp, bt.own_dims);
       }
       (void)hipEventRecord(eC[P], R);
+      if (!chain_bound) wait(B, eRc[P]);
     }
     // ---- B: bulk of SYRK(P), triangle starting two tile columns further (those belong to the look-ahead)
     const int tb = t0 + 4, nt = T - tb;
     wait(B, eC[P]);
-    // (A bulk launched at the same instant as the next diagonal update takes every workgroup slot first and the chain waits
-    //  ~75 us for the first round of tiles to retire: the bulk starts after that small kernel — eC follows eH, recorded after it.)
     if (nt > 0 && kd(P) > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
       GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab, bt.own_dims};

@@ -1,8 +1,8 @@
 // k_panel.hip — the serial chain of the dense FP64 Cholesky (k_chol.hip), 256 columns per step.
 //
 // Replaces, like k_chol.hip, the linear-algebra half of ceres::Solve(SPARSE_SCHUR) (optimization_be.cpp:560-567,
-// 1024-1031). After the block-arrow elimination the factorisation of the 5-agent map is 40 tile steps
-// of pure latency: per 256-column panel the chain was potrf(128) -> TRSM -> rank-128 update -> potrf(128) -> TRSM ->
+// 1024-1031). With the fronts of the elimination tree the factorisation of the 5-agent map is 15 serial
+// panels of pure latency. In round 2a a 256-column panel was potrf(128) -> TRSM -> rank-128 update -> potrf(128) -> TRSM ->
 // next-diagonal update, six dependent launches of 20-80 us each with a 128x128 explicit inverse in the middle. Here the
 // same panel is three launches and no large inverse:
 //   k_potrf_panel   ONE workgroup (8 waves) factors the whole 256x256 diagonal block. The trailing 16x16 tiles live in

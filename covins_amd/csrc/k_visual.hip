@@ -23,7 +23,8 @@
 //                  6x6 blocks with FP64 atomics: 11.1 ms and run-to-run rounding differences; these three passes take
 //                  0.66 ms on the 5-agent map.)
 //   obs_*          one thread per observation over the SoA stream (cost, J*v products, test dumps).
-// All writes to the pose system go through c_entry (common.hpp): dense matrix or block-arrow buffers.
+// All writes to the pose system go through c_entry (common.hpp): the fronts of the multifrontal solve (nd_entry), or the dense
+// matrix of the per-kernel test entry points.
 #include "common.hpp"
 #include "dev_math.hpp"
 #include "reduce.hpp"

@@ -321,8 +321,9 @@ extern "C" void covgpu_get_profile(covgpu_context* c, double* out) {
   out[7] = (double)(c->have ? c->P.npairs + c->P.nepairs : 0);  // off-diagonal 6x6 pose-pose blocks of the reduced system (nnzS - K)
 }
 
-// out[16] = { arrow form (0/1), blocks, border keyframes, largest interior (keyframes), arrow buffer order, border system
-//             order, dense order npad, covisible pairs, edge pairs, chains, device bytes allocated for the problem (MiB), 0... }
+// out[16] = { shard world, shard rank, scalar unknowns of the replicated top, top levels, KiB all-reduced per linear solve, 0,
+//             dense order npad, covisible pairs, edge pairs, IMU chains, device MiB allocated for the problem,
+//             fronts, levels, serial 256-column panels, order of the root level, MiB of fronts } (include/covgpu.h)
 extern "C" void covgpu_get_layout(covgpu_context* c, int64_t* out) {
   for (int i = 0; i < 16; ++i) out[i] = 0;
   if (!c->have) return;
@@ -889,9 +890,9 @@ static void enqueue_build(covgpu_context* c, double mu) {
   const DevProblem& P = c->P;
   c->cur_damp = mu;
   if (c->profiling) (void)hipEventRecord(c->ev[0], c->st);
-  // the big fill of the pose system (0.6 GB of arrow buffers on the 5-agent map) runs on its own stream beside the inertial
+  // the clearing of the fronts' live tiles (1.1 GB of fronts on the 5-agent map) runs on its own stream beside the inertial
   // kernels and the landmark linearisation, which only write per-factor / per-observation records; its first writers
-  // (k_kf_reduce ...) wait for it. Every reader of the previous system has finished: each linear solve ends with a host sync.
+  // (k_kf_reduce ...) wait for it. Every reader of the previous system has finished: each iteration ends with a host sync.
   c->chol.init();
   (void)hipEventRecord(c->chol.ev_fill, c->st);
   (void)hipStreamWaitEvent(c->chol.head, c->chol.ev_fill, 0);
@@ -1390,8 +1391,8 @@ extern "C" int covgpu_schur_pgo(covgpu_context* c, const covgpu_options* opt, co
   return schur_impl(c, opt, p, true, mu, S, b, cost);
 }
 
-// one damped Gauss-Newton step at the uploaded estimate through the PRODUCT solve path (structured speed-bias
-// elimination + block-arrow or dense pose solve + landmark back-substitution)
+// one damped Gauss-Newton step at the uploaded estimate through the PRODUCT solve path (landmark elimination, multifrontal
+// solve of the reduced camera system — sharded if a shard is set — and landmark back-substitution)
 extern "C" int covgpu_gn_step(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p, double mu, double* dx, double* dl, double* cost) {
   RC(upload_impl(c, opt, p, false)); RC(reset_state(c));
   launch_preintegrate(c->P, c->st);

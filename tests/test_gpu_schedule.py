@@ -1,0 +1,42 @@
+"""The multifrontal solve is one fixed arithmetic laid over several streams (look-ahead across tree levels, side streams, event
+schemes chosen by regime). Scheduling must not change a bit of the result: a solve with the look-ahead across levels switched off
+(every level strictly after the one below, on one stream) must reproduce the default solve EXACTLY — a missing dependency
+between streams shows up here as a difference, long before it shows up as a wrong answer. The two kernel-form switches change the
+summation order and are held to rounding level instead."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HELPER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "solve_once.py")
+
+
+def _solve(tmp_path, tag, name, **env):
+    out = str(tmp_path / f"{tag}.npz")
+    r = subprocess.run([sys.executable, HELPER, name, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("name", ["mh01", "mh123"])
+def test_look_ahead_across_levels_changes_no_bit(tmp_path, name):
+    a = _solve(tmp_path, "default", name)
+    b = _solve(tmp_path, "default_again", name)
+    c = _solve(tmp_path, "no_lookahead", name, COVGPU_ND_LOOKAHEAD="0")
+    for k in ("pose", "sb", "lm", "cost"):
+        assert np.array_equal(a[k], b[k]), f"two default solves differ in {k}: the solve is not deterministic"
+        assert np.array_equal(a[k], c[k]), f"look-ahead on / off differ in {k}: a dependency between streams is missing"
+    assert np.array_equal(a["acc"], c["acc"])
+
+
+def test_kernel_form_switches_stay_at_rounding_level(tmp_path):
+    a = _solve(tmp_path, "default", "mh01")
+    for tag, env in (("full_tiles", dict(COVGPU_QUARTER_MAX="0")), ("per_tile_backward", dict(COVGPU_ND_BWD_FUSED="0"))):
+        b = _solve(tmp_path, tag, "mh01", **env)
+        assert np.array_equal(a["acc"], b["acc"])
+        assert np.allclose(a["cost"], b["cost"], rtol=1e-8)
+        assert np.abs(a["pose"] - b["pose"]).max() < 1e-8 and np.abs(a["sb"] - b["sb"]).max() < 1e-8

@@ -43,6 +43,14 @@ struct covgpu_profile_t {
   long n_build = 0, n_factor = 0, n_syrk = 0;
 };
 
+// elimination tree of the last single-GPU GBA upload and what it was built for (upload_impl)
+struct PlanCache {
+  bool valid = false; int K = 0; bool vi = false; int leaf = 0;
+  std::vector<int> chain_ptr, pos_kf;
+  std::vector<uint64_t> keys;   // sorted (position i << 32 | position j) of every covisible / loop-edge pair
+  NdHostPlan hp;
+};
+
 struct covgpu_context {
   int device = 0;
   hipStream_t st = nullptr;
@@ -57,6 +65,7 @@ struct covgpu_context {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   CholAux chol;
   PgoPlan pgo_plan;  // block-arrow pose-graph solve (k_pgo.hip)
+  PlanCache plan_cache;  // elimination tree of the previous single-GPU GBA upload (reused when the new problem's couplings are a subset)
   NdDev nd;          // multifrontal GBA solve (k_front.hip)
   // agent-sharded solve: the global plan (variables as 2 * IR keyframe + kind, node -> rank), this rank's
   // identity and its collective
@@ -765,9 +774,28 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
         nd_plan_remap(nhp, to_pos);
       } else {
         const bool one_front = e_dense && e_dense[0] == '1';
-        if (!nd_plan_build(P.K, vi, P.nchains, chain_ptr.data(), (int)h_pair_i.size(), h_pair_i.data(), h_pair_j.data(), P.nepairs, ei.data(), ej.data(),
-                           one_front ? 0x3fffffff : nd_leaf_dims(0), nhp)) {
-          g_err = "nested-dissection plan: a coupling joins two branches"; return COVGPU_ERR_INVALID_ARG;
+        const int leaf = one_front ? 0x3fffffff : nd_leaf_dims(0);
+        // The plan of the previous upload serves again if this problem has the same keyframes in the same chain positions and its
+        // couplings are a SUBSET of the ones the plan was built for (a tree stays a valid elimination order when couplings
+        // disappear: the second round of a GlobalBundleAdjustment call is the first one minus the erased observations).
+        std::vector<uint64_t> keys(h_pair_i.size() + ei.size());
+        {
+          std::vector<uint64_t> ka(h_pair_i.size()), kb(ei.size());
+          for (size_t q = 0; q < ka.size(); ++q) ka[q] = ((uint64_t)(uint32_t)h_pair_i[q] << 32) | (uint32_t)h_pair_j[q];
+          for (size_t q = 0; q < kb.size(); ++q) kb[q] = ((uint64_t)(uint32_t)ei[q] << 32) | (uint32_t)ej[q];
+          if (!std::is_sorted(ka.begin(), ka.end())) std::sort(ka.begin(), ka.end());
+          std::merge(ka.begin(), ka.end(), kb.begin(), kb.end(), keys.begin());
+          keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        }
+        PlanCache& pc = c->plan_cache;
+        const bool hit = pc.valid && pc.K == P.K && pc.vi == vi && pc.leaf == leaf && pc.chain_ptr == chain_ptr && pc.pos_kf == pos_kf &&
+                         std::includes(pc.keys.begin(), pc.keys.end(), keys.begin(), keys.end());
+        if (hit) nhp = pc.hp;
+        else {
+          if (!nd_plan_build(P.K, vi, P.nchains, chain_ptr.data(), (int)h_pair_i.size(), h_pair_i.data(), h_pair_j.data(), P.nepairs, ei.data(), ej.data(), leaf, nhp)) {
+            g_err = "nested-dissection plan: a coupling joins two branches"; return COVGPU_ERR_INVALID_ARG;
+          }
+          pc.valid = true; pc.K = P.K; pc.vi = vi; pc.leaf = leaf; pc.chain_ptr = chain_ptr; pc.pos_kf = pos_kf; pc.keys.swap(keys); pc.hp = nhp;
         }
       }
       if (nhp.maxdepth > 64) { g_err = "nested-dissection plan: tree deeper than 64 levels"; return COVGPU_ERR_INVALID_ARG; }

@@ -437,10 +437,20 @@ class OptimizationT {
                                      bool outlier_removal = true, bool estimate_bias = false) -> void {
     (void)time_limit; (void)estimate_bias;  // never read by the reference either
     std::printf("+++ GBA: Start +++\n");
+    const bool tim = std::getenv("COVGPU_FLATTEN_TIMING") != nullptr;   // per-stage wall times of the call on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+      if (!tim) return;
+      const auto t = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[covins_gpu] GBA call %-34s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+      t_last = t;
+    };
     covgpu_context* ctx = Context();
+    lap("context");
     if (outlier_removal) {  // first round (:62-293)
       detail::Flat f; Index ix;
       FlattenGBA(map, visual_only, false, f, ix);
+      lap("round 1: Map -> IR");
       covgpu_problem p = f.view();
       covgpu_options o = Options(5, visual_only);  // max_num_iterations = 5 (:262)
       covgpu_result r;
@@ -448,6 +458,7 @@ class OptimizationT {
       std::vector<int32_t> lm_left(ix.lms.size() + 1);
       int64_t counts[2] = {0, 0};
       SolveGBA(ctx, o, p, r, &erase, &lm_left, counts);
+      lap("round 1: upload + solve + outlier pass");
       size_t num_bad = 0;
       for (size_t l = 0; l < ix.lms.size(); ++l)
         for (int32_t i = f.obs_ptr[l]; i < f.obs_ptr[l + 1]; ++i)
@@ -458,15 +469,19 @@ class OptimizationT {
             ++num_bad;
           }
       std::printf("--> GBA removed %zu of %zu observations\n", num_bad, f.obs_kf.size() * 2);
+      lap("round 1: erase observations");
     }
+    lap("round 1: release IR");
     {  // second round (:296-610)
       detail::Flat f; Index ix;
       FlattenGBA(map, visual_only, true, f, ix);
+      lap("round 2: Map -> IR");
       std::printf("--> KFs: %zu\n--> LMs: %zu\n", ix.kfs.size(), ix.lms.size());
       covgpu_problem p = f.view();
       covgpu_options o = Options(interations_limit, visual_only);
       covgpu_result r;
       SolveGBA(ctx, o, p, r, nullptr, nullptr, nullptr);
+      lap("round 2: upload + solve");
       if (r.termination == 4) std::fprintf(stderr, "[covins_gpu] GBA: linear solve failed, keeping the last accepted estimate (as ceres::Solve would)\n");
       if (r.reserved > 0) std::fprintf(stderr, "[covins_gpu] GBA: %d IMU factors without a positive definite covariance carry no weight\n", r.reserved);
       for (size_t k = 0; k < ix.kfs.size(); ++k) {  // :572-595
@@ -492,9 +507,12 @@ class OptimizationT {
         ix.lms[l]->SetOptimized();
         ix.lms[l]->is_gba_optimized_ = true;
       }
+      lap("round 2: write-back");
     }
+    lap("round 2: release IR");
     std::printf("--> Clean Map\n");
     map->Clean();  // :614
+    lap("Map::Clean");
     std::printf("--> done.\n+++ GBA: End +++\n");
   }
 

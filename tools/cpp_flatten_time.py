@@ -13,6 +13,9 @@ from covins_amd import mapdata, synth            # noqa: E402
 from tests.facade_util import StandinMap, lib   # noqa: E402
 
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "gba":   # (torch's HIP runtime must come up before libcovgpu loads /opt/rocm's: INTEGRATION.md §5)
+        import torch
+        torch.cuda.init()
     name = sys.argv[1] if len(sys.argv) > 1 else "mh12345"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
     m = synth.make_map(synth.config_named(name))
@@ -29,8 +32,17 @@ if __name__ == "__main__":
             ts.append(time.perf_counter() - t0)
         out[visitor] = ts
     lib().shim_use_visitor(1)
+    t_gba = None
+    if len(sys.argv) > 3 and sys.argv[3] == "gba":   # needs a GPU: the whole C++ GlobalBundleAdjustment call on the stand-in map, twice (first: warm-up)
+        t_gba = []
+        for _ in range(3):
+            sm2 = StandinMap(m)
+            t0 = time.perf_counter(); sm2.gba(10); t_gba.append(time.perf_counter() - t0)
+            sm2.close()
     sm.close()
     print(f"{name}: K={sizes[0]} L={sizes[1]} O={sizes[2]} I={sizes[3]} E={sizes[4]}; C++ FlattenGBA, {reps} reps, {os.cpu_count()} host threads available: "
           f"median {np.median(out[1]) * 1e3:.1f} ms (min {min(out[1]) * 1e3:.1f}) with Types::visit_observations, "
           f"{np.median(out[0]) * 1e3:.1f} ms (min {min(out[0]) * 1e3:.1f}) over Landmark::GetObservations() copies; "
-          f"numpy mirror flatten {t_py * 1e3:.1f} ms; building the stand-in object graph {t_build:.2f} s (not part of a call)")
+          f"numpy mirror flatten {t_py * 1e3:.1f} ms; building the stand-in object graph {t_build:.2f} s (not part of a call)"
+          + (f"; whole C++ covins_gpu::Optimization::GlobalBundleAdjustment(map, 10) on the stand-in map: {', '.join(f'{t * 1e3:.0f}' for t in t_gba)} ms "
+             f"(first call includes context creation and library warm-up)" if t_gba else ""))

@@ -167,13 +167,14 @@ def main():
         # HBM traffic of the dominant kernel cannot be read inside this process (PMC counters need rocprofv3):
         # tools/pmc_pass.sh runs the counter passes of THIS command and stamps the result with the git SHA and the kernel
         # name; a stale or foreign file is refused and `traffic` stays null.
-        traffic, mfma_busy, traffic_src = None, None, None
+        traffic, mfma_busy, traffic_src, build_traffic, build_parts = None, None, None, None, None
         try:
             import subprocess
             sha = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")))
             if pj.get("workload") == args.workload and pj.get("kernels_sha256") == _kernels_digest() and "k_gemm_abt" in pj.get("kernel", ""):
                 traffic = pj["fetch_bytes_x2"] + pj["write_bytes"]; mfma_busy = pj.get("mfma_busy_frac"); traffic_src = pj.get("git_sha", sha)
+                build_traffic = pj.get("build_bytes_per_iteration"); build_parts = pj.get("build_bytes_by_kernel")
         except Exception:
             pass
         truth = m.truth["kf_pose"][:, 4:]
@@ -228,6 +229,8 @@ def main():
             "roofline_build": {"kernel": "linearise + landmark Schur pass (k_lm_lin, k_kf_reduce, k_pair_blocks, k_imu_*, k_edge_*)", "bound": "hbm",
                                "achieved": b_build / (prof["build_ms"] / max(prof["n_build"], 1) * 1e-3) / 1e9 if prof["build_ms"] > 0 else 0.0,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "traffic": build_traffic, "traffic_mb_by_kernel": build_parts,
+                               "traffic_note": "HBM bytes per iteration of the pass's kernels (2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_pass.sh); null without a counter pass of these sources",
                                "nnzS_blocks": nnzS,
                                "note": "whole linearise+Schur pass (a dozen kernels; the clearing of the fronts' live tiles runs on a second stream "
                                        "underneath) against SURVEY.md 8(d)'s algorithmic bytes (inputs once, H/g blocks, S blocks once). The pass "

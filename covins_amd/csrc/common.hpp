@@ -47,10 +47,15 @@ struct DevProblem {
 
   // keyframe-major view of the observations and covisible-pair lists (static per problem, built at upload)
   int *kf_obs_ptr, *kf_obs_idx;             // [K+1], [O]
+  // keyframe-major copies (slot t of kf_obs_idx): what k_kf_reduce reads of an observation, coalesced instead of three scattered 8-byte
+  // gathers from the landmark-major stream; obs_zpos = inverse of kf_obs_idx: the slot of observation o — where its Z record lives
+  double* kobs;                             // [O][3] u, v, sigma
+  int *kobs_lm, *obs_zpos;                  // [O] landmark of slot t | slot of observation o
   int npairs;
   int *pair_ptr, *pair_i, *pair_j;          // [npairs+1], [npairs] chain-major positions, i > j
   int *pair_oa, *pair_ob;                   // [sum] observation of keyframe i / keyframe j of each common landmark
-  double *obsZ;                             // [O][18] per-observation Z = (Jp^T Jl) R with Hll^-1 = R R^T: the one record of the landmark elimination (k_visual.hip)
+  double *obsZ;                             // [O][18] per-observation Z = (Jp^T Jl) R with Hll^-1 = R R^T: the one record of the landmark elimination (k_visual.hip),
+                                            // KEYFRAME-major (slot obs_zpos[o]): the records a covisible pair reads lie in its two keyframes' 60-KB blocks (L2)
   double *lmRT;                             // [L][9] per landmark: lower factor R (6) | t = R^T g_l (3)
   double *cost_part;                        // per-block cost partials
 
@@ -170,6 +175,7 @@ enum { SC_COST = 0, SC_JV2 = 1, SC_GG = 2, SC_GN2 = 3, SC_GDOT = 4, SC_GMAX = 5,
 
 struct CholAux;
 // ---- launchers (each enqueues on `st`, no synchronisation)
+void launch_kobs_build(const DevProblem& P, int* pair_oa, int* pair_ob, size_t nent, hipStream_t st);  // upload: keyframe-major copies, Z slots, pair lists -> Z slots
 void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared = nullptr, hipStream_t side = nullptr,
                      hipEvent_t ev_lin = nullptr, hipEvent_t ev_kf = nullptr);  // reprojection -> Hll, g, S (Schur), bred, cost
 void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st);

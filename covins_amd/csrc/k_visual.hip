@@ -42,8 +42,8 @@ struct ObsLin {
 
 // R4 + R6 for one observation. `fixed` zeroes the pose Jacobian (constant parameter block, opt_be.cpp:329-341).
 template <bool JAC>
-COV_DEV void eval_obs(const DevProblem& P, const double* __restrict__ pose, const double* __restrict__ lm, int o, int kf, int l,
-                      ObsLin& out) {
+COV_DEV void eval_obs_uvs(const DevProblem& P, const double* __restrict__ pose, const double* __restrict__ lm, double mu_, double mv_, double sigma, int kf, int l,
+                          ObsLin& out) {
   const int cam = P.kf_cam[kf];
   const double* ps = pose + 7 * kf;
   const double* ex = P.cam_extr + 7 * cam;
@@ -64,8 +64,8 @@ COV_DEV void eval_obs(const DevProblem& P, const double* __restrict__ pose, cons
     }
     return;
   }
-  const double is = 1.0 / P.obs_sigma[o];
-  double r0 = (u - P.obs_u[o]) * is, r1 = (v - P.obs_v[o]) * is;
+  const double is = 1.0 / sigma;
+  double r0 = (u - mu_) * is, r1 = (v - mv_) * is;
   double c;
   const double sq = cauchy_scale(P.reproj_loss_a, r0 * r0 + r1 * r1, &c);
   out.r0 = r0 * sq; out.r1 = r1 * sq; out.cost = c;
@@ -83,6 +83,12 @@ COV_DEV void eval_obs(const DevProblem& P, const double* __restrict__ pose, cons
       out.jp[6 * row + 3] = fx ? 0.0 : -jlw.x; out.jp[6 * row + 4] = fx ? 0.0 : -jlw.y; out.jp[6 * row + 5] = fx ? 0.0 : -jlw.z;
     }
   }
+}
+
+// the same from the landmark-major observation stream
+template <bool JAC>
+COV_DEV void eval_obs(const DevProblem& P, const double* __restrict__ pose, const double* __restrict__ lm, int o, int kf, int l, ObsLin& out) {
+  eval_obs_uvs<JAC>(P, pose, lm, P.obs_u[o], P.obs_v[o], P.obs_sigma[o], kf, l, out);
 }
 
 COV_DEV void group_sync() {
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_lm_lin(DevProblem P, double m
     }
     double Z[18];
     z_of(e, R, Z);
-    double2* zo = reinterpret_cast<double2*>(P.obsZ + 18 * (size_t)(o0 + a));  // 144-byte record, 16-byte aligned
+    double2* zo = reinterpret_cast<double2*>(P.obsZ + 18 * (size_t)P.obs_zpos[o0 + a]);  // 144-byte record, 16-byte aligned, in its keyframe's block
 #pragma unroll
     for (int k = 0; k < 9; ++k) zo[k] = double2{Z[2 * k], Z[2 * k + 1]};
   }
@@ -253,9 +259,10 @@ __global__ __launch_bounds__(64) void k_kf_reduce(DevProblem P) {
 #pragma unroll
   for (int k = 0; k < kRec; ++k) part[k] = 0.0;
   for (int t = o0 + lane; t < o1; t += 64) {
-    const int o = P.kf_obs_idx[t], l = P.obs_lm[o];
+    const int l = P.kobs_lm[t];
+    const double* uvs = P.kobs + 3 * (size_t)t;
     ObsLin e;
-    eval_obs<true>(P, P.pose, P.lm, o, kf, l, e);
+    eval_obs_uvs<true>(P, P.pose, P.lm, uvs[0], uvs[1], uvs[2], kf, l, e);
     const double* rt = P.lmRT + 9 * (size_t)l;
     double R[6], Z[18];
 #pragma unroll
@@ -462,6 +469,25 @@ void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t 
   hipLaunchKernelGGL(k_kf_reduce, dim3(P.K), dim3(64), 0, s2, P);
   if (P.npairs) hipLaunchKernelGGL(k_pair_blocks, dim3((P.npairs + kPairsPerWg - 1) / kPairsPerWg), dim3(kPairLanes * kPairsPerWg), 0, st, P);
   // (fork: the caller joins the side stream back — it has more on it)
+}
+// upload: keyframe-major copies of the observation stream (DevProblem::kobs), the Z slot of every observation, and the covisible-pair
+// entries turned from observation indices into Z slots
+__global__ __launch_bounds__(256) void k_kobs_build(DevProblem P) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P.O) return;
+  const int o = P.kf_obs_idx[t];
+  P.kobs[3 * (size_t)t] = P.obs_u[o]; P.kobs[3 * (size_t)t + 1] = P.obs_v[o]; P.kobs[3 * (size_t)t + 2] = P.obs_sigma[o];
+  P.kobs_lm[t] = P.obs_lm[o];
+  P.obs_zpos[o] = t;
+}
+__global__ __launch_bounds__(256) void k_remap_idx(size_t n, int* __restrict__ a, int* __restrict__ b, const int* __restrict__ map) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (q < n) { a[q] = map[a[q]]; b[q] = map[b[q]]; }
+}
+void launch_kobs_build(const DevProblem& P, int* pair_oa, int* pair_ob, size_t nent, hipStream_t st) {
+  if (P.O == 0) return;
+  hipLaunchKernelGGL(k_kobs_build, dim3((P.O + 255) / 256), dim3(256), 0, st, P);
+  if (nent > 0) hipLaunchKernelGGL(k_remap_idx, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, st, nent, pair_oa, pair_ob, (const int*)P.obs_zpos);
 }
 void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st) {
   if (P.L == 0) return;

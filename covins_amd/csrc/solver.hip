@@ -667,6 +667,8 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
       HIPCHK(hipMemcpyAsync(pj.data(), P.pair_j, (size_t)P.npairs * sizeof(int), hipMemcpyDeviceToHost, c->st));
     }
     RC(dev_alloc(c, &P.obsZ, (size_t)18 * P.O)); RC(dev_alloc(c, &P.lmRT, (size_t)9 * P.L));
+    RC(dev_alloc(c, &P.kobs, (size_t)3 * P.O)); RC(dev_alloc(c, &P.kobs_lm, (size_t)P.O)); RC(dev_alloc(c, &P.obs_zpos, (size_t)P.O));
+    launch_kobs_build(P, P.pair_oa, P.pair_ob, pl.nent, c->st);
     RC(dev_alloc(c, &P.cost_part, (size_t)(P.L / 4 + 64)));
     HIPCHK(hipStreamSynchronize(c->st));
     h_pair_i.swap(pi); h_pair_j.swap(pj);

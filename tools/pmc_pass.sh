@@ -37,6 +37,19 @@ for row in csv.DictReader(open(os.path.join(root, "gpurun_out", "${tag}_pmc_hbm_
         fetch += c * float(row["FETCH_x2_MB_per_call"]) * 1048576.0; write += c * float(row["WRITE_MB_per_call"]) * 1048576.0
 if calls:
     out.update(kernel=" + ".join(sorted(set(names))), calls=int(calls), fetch_bytes_x2=fetch / calls, write_bytes=write / calls)
+# counter traffic of the whole linearise + landmark-Schur pass per trust-region iteration (bench.py: roofline_build.traffic)
+BUILD = ("k_lm_lin", "k_kf_reduce", "k_pair_blocks", "k_imu_build", "k_imu_gather", "k_edge_build", "k_edge_gather_kf", "k_edge_gather_pair",
+         "k_finalize_diag", "k_zero_many", "k_nd_zero", "k_cost_finish")
+its = 0; bbytes = 0.0; parts = {}
+for row in csv.DictReader(open(os.path.join(root, "gpurun_out", "${tag}_pmc_hbm_traffic.csv"))):
+    nm = row["Name"].split("(")[0].replace("void covgpu::", "").replace("covgpu::", "").split("<")[0]
+    if nm in BUILD:
+        c = int(row["Calls"]); b = c * (float(row["FETCH_x2_MB_per_call"]) + float(row["WRITE_MB_per_call"])) * 1048576.0
+        bbytes += b; parts[nm] = parts.get(nm, 0.0) + b
+        if nm == "k_lm_lin": its = c
+if its:
+    out["build_bytes_per_iteration"] = bbytes / its
+    out["build_bytes_by_kernel"] = {k: round(v / its / 1e6, 1) for k, v in sorted(parts.items(), key=lambda kv: -kv[1])}   # MB
 busy = wsum = 0.0
 for row in csv.DictReader(open(os.path.join(root, "gpurun_out", "${tag}_pmc_mfma.csv"))):
     if is_syrk(row["Name"]) and row.get("MfmaBusy_pct"):

@@ -141,3 +141,81 @@ def test_plan_is_deterministic_and_levels_are_heights(small_map):
         if parent[k] >= 0:
             h[parent[k]] = max(h[parent[k]], h[k] + 1)
     assert np.array_equal(h, level)
+
+
+def _replay_sparse(S, b, parent, level, own, st, D):
+    """_replay on a scipy CSR system: the same multifrontal elimination, fronts gathered by sparse slicing (full-size maps)."""
+    nn, n = len(parent), S.shape[0]
+    rows_own = [_scalars(own[k], D) for k in range(nn)]
+    rows_st = [_scalars(st[k], D) for k in range(nn)]
+    node_of = -np.ones(n, int)
+    for k in range(nn):
+        assert np.all(node_of[rows_own[k]] == -1)
+        node_of[rows_own[k]] = k
+    assert np.all(node_of >= 0)
+    depth = np.zeros(nn, int)
+    for k in range(nn):
+        if parent[k] >= 0:
+            assert parent[k] < k
+            depth[k] = depth[parent[k]] + 1
+    # every structural non-zero between two nodes lies in the front of the deeper one
+    C = S.tocoo()
+    na, nb = node_of[C.row], node_of[C.col]
+    deeper = np.where(depth[na] >= depth[nb], na, nb); other_row = np.where(depth[na] >= depth[nb], C.col, C.row)
+    cross = (na != nb) & (C.data != 0)   # (the block-CSR source stores whole 15x15 blocks: explicit zeros are no couplings)
+    mask = np.zeros(n, bool)
+    for k in np.unique(deeper[cross]):
+        mask[:] = False; mask[rows_st[k]] = True
+        sel = cross & (deeper == k)
+        assert mask[other_row[sel]].all(), "a non-zero of the system has no place in any front"
+    fronts = []
+    for k in range(nn):
+        idx = np.r_[rows_own[k], rows_st[k]]
+        m = len(rows_own[k])
+        F = np.zeros((len(idx), len(idx)))
+        F[:, :m] = S[idx][:, rows_own[k]].toarray()
+        F[:m, m:] = F[m:, :m].T
+        fronts.append([idx, m, F, np.r_[b[rows_own[k]], np.zeros(len(rows_st[k]))]])
+    x = np.zeros(n)
+    facs = {}
+    for k in np.argsort(level, kind="stable"):
+        idx, m, F, r = fronts[k]
+        L11 = np.linalg.cholesky(F[:m, :m])
+        L21 = np.linalg.solve(L11, F[:m, m:]).T
+        y1 = np.linalg.solve(L11, r[:m])
+        facs[k] = (L11, L21, y1)
+        p = parent[k]
+        if p >= 0:
+            where = -np.ones(n, int); where[fronts[p][0]] = np.arange(len(fronts[p][0]))
+            loc = where[idx[m:]]
+            assert (loc >= 0).all(), "fill outside the parent's front"
+            fronts[p][2][np.ix_(loc, loc)] += F[m:, m:] - L21 @ L21.T
+            fronts[p][3][loc] += r[m:] - L21 @ y1
+        else:
+            assert len(idx) == m
+        fronts[k][2] = None
+    for k in np.argsort(level, kind="stable")[::-1]:
+        idx, m = fronts[k][0], fronts[k][1]
+        L11, L21, y1 = facs[k]
+        x[idx[:m]] = np.linalg.solve(L11.T, y1 - L21.T @ x[idx[m:]])
+    return x
+
+
+def test_replay_at_three_agent_size():
+    """The plan the GPU solves with on the 3-agent BASELINE map — speed-bias chains cut into segments, excess unknowns of a level's
+    widest fronts moved into the parents (the panel balance pass moves 36 unknowns here), 201 fronts in 7 levels — replayed on the
+    oracle's sparse reduced camera system: the residual of the multifrontal solution is at rounding level."""
+    import scipy.sparse as sp
+    m = synth.make_map(synth.config_named("mh123"))
+    prob, _ = mapdata.flatten_gba(m, visual_only=False, loop_loss=True)
+    ptr, col, blocks, bvec, _ = covo.schur_sparse(prob, covo.default_options(), 1e-4)
+    S = sp.bsr_matrix((np.asarray(blocks), np.asarray(col), np.asarray(ptr)), shape=(15 * prob.K, 15 * prob.K)).tocsr()
+    info, parent, level, own, st = _plan(prob, backend.default_options(), 0)
+    od = np.array([sum(9 if v & 1 else 6 for v in o) for o in own])
+    assert info[0] > 150 and info[1] >= 6
+    assert max(od[level == 0]) <= 126                       # bottom level: speed-bias segments of <= 14 blocks
+    widest = [od[level == l].max() for l in range(info[1])]
+    assert sum(-(-w // 256) for w in widest) <= 11          # serial 256-column panels of the whole factorisation
+    x = _replay_sparse(S, np.asarray(bvec), parent, level, own, st, 15)
+    r = S @ x - bvec
+    assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(bvec)

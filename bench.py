@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-shard", action="store_true", help="run the agent-sharded path (plan, sub-problem, RCCL collectives) even on ONE GPU")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-call timing after the timed region (profiling runs)")
+    ap.add_argument("--sustain-s", type=float, default=8.0, help="after the timed region, repeat the same steps back to back for about this many seconds, "
+                    "un-timed in `value` and reported as `sustained`: long enough for an external GPU-utilisation sampler to see the device busy (0: off)")
     args = ap.parse_args()
 
     import torch
@@ -146,6 +148,19 @@ def main():
     dt = time.perf_counter() - t0
     dt, iters_all = distrib.aggregate(dt, iters, ctx, sharded)
     shard_stats = ctx.shard_stats()
+    # sustained leg (not `value`): the same step repeated for --sustain-s seconds, so that a sampler outside this process (rocm-smi every
+    # few seconds) sees the GPU busy — the timed region above is 20 steps x ~35 ms and falls between two samples
+    sustained = None
+    if args.sustain_s > 0 and dt > 0:
+        n_sus = max(1, int(args.sustain_s / (dt / max(args.steps, 1))))   # same count on every rank (dt is the max over ranks)
+        distrib.barrier(ctx, sharded)
+        ts = time.perf_counter(); it_s = 0
+        for _ in range(n_sus):
+            it_s += ctx.solve_resident(opt).iterations
+        distrib.barrier(ctx, sharded)
+        ts = time.perf_counter() - ts
+        sustained = {"steps": n_sus, "seconds": ts, "iterations_per_s": it_s / ts,
+                     "what": "the timed step repeated back to back after the timed region (not `value`): corroboration for an external GPU-busy sampler"}
     # one more step, NOT timed, with HIP events around the build pass, the factor+solve and every trailing-update launch
     ctx.set_profiling(True)
     ctx.solve_resident(opt)
@@ -167,7 +182,7 @@ def main():
         # HBM traffic of the dominant kernel cannot be read inside this process (PMC counters need rocprofv3):
         # tools/pmc_pass.sh runs the counter passes of THIS command and stamps the result with the git SHA and the kernel
         # name; a stale or foreign file is refused and `traffic` stays null.
-        traffic, mfma_busy, traffic_src, build_traffic, build_parts = None, None, None, None, None
+        traffic, mfma_busy, traffic_src, build_traffic, build_parts, potrf_traffic, potrf_busy = None, None, None, None, None, None, None
         try:
             import subprocess
             sha = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
@@ -175,6 +190,7 @@ def main():
             if pj.get("workload") == args.workload and pj.get("kernels_sha256") == _kernels_digest() and "k_gemm_abt" in pj.get("kernel", ""):
                 traffic = pj["fetch_bytes_x2"] + pj["write_bytes"]; mfma_busy = pj.get("mfma_busy_frac"); traffic_src = pj.get("git_sha", sha)
                 build_traffic = pj.get("build_bytes_per_iteration"); build_parts = pj.get("build_bytes_by_kernel")
+                potrf_traffic = pj.get("potrf_bytes_per_launch"); potrf_busy = pj.get("potrf_mfma_busy_frac")
         except Exception:
             pass
         truth = m.truth["kf_pose"][:, 4:]
@@ -185,6 +201,13 @@ def main():
         nnzS = prof["offdiag_blocks"] + prob.K  # covisible keyframe pairs incl. the diagonal
         b_build = (32.0 * prob.O + 128.0 * prob.K + 24.0 * prob.L + 2304.0 * prob.I + 8.0 * (135.0 * prob.K + 9.0 * prob.L)
                    + 288.0 * nnzS)  # inputs once, H/g blocks, S blocks written once (their read-back belongs to the solve)
+        # SURVEY.md 8(d) in full: algorithmic bytes of one trust-region iteration (linearise + Schur, candidate evaluation, state update)
+        b_iter = (2.0 * (32.0 * prob.O + 128.0 * prob.K + 24.0 * prob.L) + 2304.0 * prob.I + 8.0 * (135.0 * prob.K + 9.0 * prob.L)
+                  + 2.0 * 288.0 * nnzS + (128.0 * prob.K + 24.0 * prob.L))
+        t_iter_ms = dt / max(iters_all, 1) * 1e3
+        potrf_tflops = prof["potrf_flops"] / (prof["potrf_ms"] * 1e-3) / 1e12 if prof["potrf_ms"] > 0 else 0.0
+        n_lin = max(prof["n_factor"], 1)
+        t_ideal_ms = (b_iter / (HBM_PEAK_GBS * 1e9) + prof["plan_flops"] / (FP64_MATRIX_PEAK_TFLOPS * 1e12)) * 1e3
         out = {
             "metric": "GBA iterations/sec, 5-agent EuRoC merged map" if args.workload == "mh12345" else f"GBA iterations/sec, {args.workload}",
             "value": iters_all / dt, "unit": "iterations/s",
@@ -216,16 +239,33 @@ def main():
                            "final_sim3": synth.ate_rmse(sol.kf_pose[:, 4:], truth, with_scale=True)},  # evo_ape -va / -vas
             "phase_ms_per_iteration": {"linearise+schur": prof["build_ms"] / max(prof["n_build"], 1),
                                        "factor+solve": prof["factor_ms"] / max(prof["n_factor"], 1)},
-            "roofline": {"kernel": "k_gemm_abt<SYRK_TRI> / k_gemm_abt_q<SYRK_TRI,64,64> (rank-256 trailing update of the batched front factorisation, "
-                                   "v_mfma_f64_16x16x4_f64; 128x128 tiles, or 64x64 quadrants for tile lists of <= 1024 entries)",
-                         "bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": syrk_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
-                         "mfma_busy_frac_pmc": mfma_busy,
-                         "traffic_note": ("HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from tools/pmc_pass.sh at " + str(traffic_src)) if traffic is not None
-                                         else "null: no counter pass of these kernel sources (tools/pmc_pass.sh writes profiles/pmc_traffic_current.json)",
-                         "launches": prof["n_syrk"], "avg_launch_ms": prof["syrk_ms"] / max(prof["n_syrk"], 1),
-                         "note": "the one MFMA-bound kernel; the factor+solve phase as a whole is bound by the serial panel chain "
-                                 "(k_potrf_panel, one workgroup per front and panel: latency, no roofline), see DESIGN.md 4.6"},
+            # the kernel with the largest share of GPU time (first row of profiles/*_kernel_stats.csv): the serial panel chain
+            "roofline": {"kernel": "k_potrf_panel (ONE workgroup per front factors a 256x256 diagonal block of the batched front factorisation: "
+                                   "the serial panel chain; v_mfma_f64_16x16x4_f64 for the in-block updates, wave 0 carries the pivot chain)",
+                         "bound": "mfma", "achieved": potrf_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": potrf_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": potrf_traffic, "mfma_busy_frac_pmc": potrf_busy,
+                         "launches": prof["n_potrf"], "launches_per_linear_solve": prof["n_potrf"] / n_lin,
+                         "avg_launch_ms": prof["potrf_ms"] / max(prof["n_potrf"], 1),
+                         "flops_per_launch": prof["potrf_flops"] / max(prof["n_potrf"], 1),
+                         "chain_ms_per_iteration": prof["potrf_ms"] / n_lin,
+                         "note": "algorithmic flops per launch = sum over the fronts of the batch of n^3/3 + n^2 (n = the front's real columns in the "
+                                 "panel), over the HIP-event duration of the launch on its stream (un-timed profiling step). One workgroup per "
+                                 "front: a latency-bound pivot chain, far below the matrix peak by construction — its launches are serial, so "
+                                 "chain_ms_per_iteration is on the critical path of every linear solve (DESIGN.md 4.5-4.6)"},
+            "roofline_syrk": {"kernel": "k_gemm_abt<SYRK_TRI> / k_gemm_abt_q<SYRK_TRI,64,64> (rank-256 trailing update of the batched front factorisation, "
+                                        "v_mfma_f64_16x16x4_f64; 128x128 tiles, or 64x64 quadrants for tile lists of <= 1024 entries)",
+                              "bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": syrk_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+                              "mfma_busy_frac_pmc": mfma_busy,
+                              "traffic_note": ("HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from tools/pmc_pass.sh at " + str(traffic_src)) if traffic is not None
+                                              else "null: no counter pass of these kernel sources (tools/pmc_pass.sh writes profiles/pmc_traffic_current.json)",
+                              "launches": prof["n_syrk"], "avg_launch_ms": prof["syrk_ms"] / max(prof["n_syrk"], 1),
+                              "note": "the one throughput-bound MFMA kernel (side streams, mostly off the critical path)"},
+            "roofline_iteration": {"what": "one whole trust-region iteration against the two rooflines it could be bound by: SURVEY.md 8(d)'s B_iter at the "
+                                           "HBM peak plus the plan's factorisation flops at the FP64 matrix peak",
+                                   "algorithmic_bytes": b_iter, "factorisation_flops": prof["plan_flops"], "ideal_ms": t_ideal_ms,
+                                   "measured_ms": t_iter_ms, "frac": t_ideal_ms / t_iter_ms if t_iter_ms > 0 else 0.0,
+                                   "phase_flop_rate_tflops": prof["plan_flops"] / (prof["factor_ms"] / n_lin * 1e-3) / 1e12 if prof["factor_ms"] > 0 else 0.0},
             "roofline_build": {"kernel": "linearise + landmark Schur pass (k_lm_lin, k_kf_reduce, k_pair_blocks, k_imu_*, k_edge_*)", "bound": "hbm",
                                "achieved": b_build / (prof["build_ms"] / max(prof["n_build"], 1) * 1e-3) / 1e9 if prof["build_ms"] > 0 else 0.0,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -238,6 +278,8 @@ def main():
                                        "(DESIGN.md 4.1, 6)"},
         }
         out["roofline_build"]["frac"] = out["roofline_build"]["achieved"] / HBM_PEAK_GBS
+        if sustained is not None:
+            out["sustained"] = sustained
         # whole Optimization::GlobalBundleAdjustment call as backend.cpp:141-156 issues it (outlier round of 5 iterations +
         # main round, flatten + H2D + solves + D2H + write-back + Map::Clean) — PCIe- and host-inclusive, never `value`
         from covins_amd.optimization import Optimization, OptParams

@@ -47,6 +47,8 @@ def lib() -> C.CDLL:
         _LIB.covgpu_set_profiling.restype = None
         _LIB.covgpu_get_profile.argtypes = [C.c_void_p, capi._dp]
         _LIB.covgpu_get_profile.restype = None
+        _LIB.covgpu_get_profile2.argtypes = [C.c_void_p, capi._dp]
+        _LIB.covgpu_get_profile2.restype = None
         _LIB.covgpu_get_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         _LIB.covgpu_get_layout.restype = None
     return _LIB
@@ -183,10 +185,11 @@ class Context:
         lib().covgpu_set_profiling(self._h, int(on))
 
     def profile(self) -> dict:
-        out = np.zeros(8)
-        lib().covgpu_get_profile(self._h, dptr(out))
+        out = np.zeros(16)
+        lib().covgpu_get_profile2(self._h, dptr(out))
         return dict(build_ms=out[0], n_build=int(out[1]), factor_ms=out[2], n_factor=int(out[3]), syrk_ms=out[4],
-                    n_syrk=int(out[5]), syrk_flops=out[6], offdiag_blocks=int(out[7]))
+                    n_syrk=int(out[5]), syrk_flops=out[6], offdiag_blocks=int(out[7]),
+                    potrf_ms=out[8], n_potrf=int(out[9]), potrf_flops=out[10], plan_flops=out[11])
 
     def layout(self) -> dict:
         out = (C.c_int64 * 16)()

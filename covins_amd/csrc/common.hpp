@@ -221,6 +221,11 @@ struct CholAux {
   hipEvent_t ev_lin = nullptr, ev_kf = nullptr;  // landmark linearisation done (main stream) | per-keyframe reduction done (side stream): launch_lm_build
   std::vector<hipEvent_t> ev, prof_ev, panel_ev;  // panel_ev: start of every big panel on the main stream (COVGPU_TRACE_PANELS=1)
   std::vector<double> prof_flops;
+  // (profiling only) the same for every k_potrf_panel launch — the serial chain, the kernel with the largest share of GPU time
+  std::vector<hipEvent_t> prof_ev2;
+  std::vector<double> prof_flops2;
+  double potrf_ms = 0, potrf_flops = 0;
+  long n_potrf = 0;
   // per big panel of the batched (arrow) factorisation: device list of the LIVE (batch, ti, tj) tiles of its bulk update,
   // interleaved so that list position p runs on XCD p % 8 and every XCD gets the same number of tiles (k_chol.hip)
   struct TriCache {
@@ -355,11 +360,12 @@ struct NdDev {
       h_cidx2, h_inv_off, h_inv, h_rhs_node, h_ext, h_top_var, h_top_r, h_top_g;
   std::vector<long long> h_ntab;
   size_t M_elems = 0, rhs_elems = 0, linv_elems = 0;
+  double plan_flops = 0;                   // flops of one factorisation of the plan's fronts (NdHostPlan::flops: dense count on the real sizes)
 };
 void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& dev);  // host tables + level shapes from the plan
 void launch_nd_init(const DevProblem& P, const NdDev& nd, hipStream_t st);    // once per upload: identity block inverses for the padding columns
 void launch_nd_zero(const DevProblem& P, const NdDev& nd, hipStream_t st);    // per iteration: clear the live tiles, identity on interior padding
-void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hipStream_t st, CholAux& ax);  // damped system in the fronts + bred -> dst (IR layout)
+bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hipStream_t st, CholAux& ax);  // false: scratch allocation failed, nothing enqueued. damped system in the fronts + bred -> dst (IR layout)
 
 void launch_dogleg_stats(const DevProblem& P, hipStream_t st);  // GG, GN2, GDOT, GMAX from grad/hdiag/gn
 void launch_cauchy_vec(const DevProblem& P, hipStream_t st);    // vtmp = grad / d^2

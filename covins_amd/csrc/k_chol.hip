@@ -315,6 +315,8 @@ void CholAux::destroy() {
   if (head) { (void)hipStreamDestroy(head); head = nullptr; }
   for (auto e : ev) (void)hipEventDestroy(e);
   for (auto e : prof_ev) (void)hipEventDestroy(e);
+  for (auto e : prof_ev2) (void)hipEventDestroy(e);
+  prof_ev2.clear();
   for (auto e : panel_ev) (void)hipEventDestroy(e);
   panel_ev.clear();
   ev.clear(); prof_ev.clear();
@@ -354,6 +356,12 @@ void CholAux::collect() {
     syrk_ms += ms; syrk_flops += prof_flops[i]; n_syrk++;
   }
   prof_flops.clear();
+  for (size_t i = 0; i < prof_flops2.size(); ++i) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, prof_ev2[2 * i], prof_ev2[2 * i + 1]) != hipSuccess) continue;
+    potrf_ms += ms; potrf_flops += prof_flops2[i]; n_potrf++;
+  }
+  prof_flops2.clear();
 }
 
 // trailing updates given as explicit tile lists of at most this many entries (incl. the XCD padding) run as 64x64 quadrants
@@ -469,6 +477,25 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       if (!ok) { tc.clear(); break; }
     }
   }
+  // k_potrf_panel of big panel P, all fronts of the batch; profiling: an event pair around the launch and its algorithmic flops
+  // (per front n^3 / 3 for the factorisation + n^2 for the forward substitution riding along, n = the front's REAL columns in the panel)
+  auto potrf = [&](int t0, int w, int nbp) {
+    const bool prof = ax.profile && nbp != 0;
+    if (prof) {
+      while (ax.prof_ev2.size() < 2 * (ax.prof_flops2.size() + 1)) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev2.push_back(e); }
+      (void)hipEventRecord(ax.prof_ev2[2 * ax.prof_flops2.size()], M);
+    }
+    launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp);
+    if (prof) {
+      double fl = 0.0;
+      for (int a = 0; a < nbt; ++a) {
+        const double n = bt.own_dims_h != nullptr ? (double)std::max(0, std::min(w * kTile, bt.own_dims_h[a] - t0 * kTile)) : (double)(w * kTile);
+        fl += n * n * n / 3.0 + n * n;
+      }
+      (void)hipEventRecord(ax.prof_ev2[2 * ax.prof_flops2.size() + 1], M);
+      ax.prof_flops2.push_back(fl);
+    }
+  };
   int Plast = NP - 1;
   bool split_last = false;  // the last panel's bulk update was left running on B for the caller (DenseBatch::split_ta)
   bool tail_on_chain = false;  // the last panel ran whole on the chain's own stream: nothing of it to join (every event packet on
@@ -508,7 +535,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // streams, ~100 us of event hops per front level) buys nothing — factor, solve ALL rows below, update the WHOLE trailing
       // triangle, three dependent launches on the chain's own stream.
       const int nbp = bt.own_max > 0 ? std::max(0, std::min(8 * w, (bt.own_max - t0 * kTile + 15) / 16)) : -1;
-      launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp);
+      potrf(t0, w, nbp);
       if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
       bool split_done = false;
       if (T > h0) {
@@ -572,7 +599,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // 256-column chain (k_panel.hip): one workgroup factors the whole diagonal block, rows h follow on the same stream by
       // block substitution, rows r on theirs — three dependent launches per panel instead of six
       const int nbp = bt.own_max > 0 ? std::max(0, std::min(8 * w, (bt.own_max - t0 * kTile + 15) / 16)) : -1;
-      launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp);
+      potrf(t0, w, nbp);
       if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
       // Every event packet on this stream sits between two dependent kernels of the chain, a few microseconds each. While the bulk
       // update is short (the period of the factorisation is the chain: small fronts, the tail of big ones) there is ONE event per

@@ -42,7 +42,7 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& 
   std::vector<int> order, newid(nn, -1);
   for (int l = 0; l < nlev; ++l) for (int n : lnodes[l]) { newid[n] = (int)order.size(); order.push_back(n); }
   const int nl = (int)order.size();
-  dev.nnodes = nl; dev.top_lev0 = Hs;
+  dev.nnodes = nl; dev.top_lev0 = Hs; dev.plan_flops = hp.flops;
   dev.h_vnode.assign(2 * (size_t)K, -1); dev.h_voff.assign(2 * (size_t)K, 0); dev.h_vord.assign(2 * (size_t)K, 0); dev.h_vown.assign(2 * (size_t)K, 0);
   for (int v = 0; v < 2 * K; ++v)
     if (hp.vnode[v] >= 0) {
@@ -356,7 +356,7 @@ void launch_nd_zero(const DevProblem& P, const NdDev& nd, hipStream_t st) {
   }
 }
 
-void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hipStream_t st, CholAux& ax) {
+bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hipStream_t st, CholAux& ax) {
   const int nlev = (int)nd.lev.size(), ltop = nd.top_lev0;
   static const bool lookahead = getenv("COVGPU_ND_LOOKAHEAD") == nullptr || atoi(getenv("COVGPU_ND_LOOKAHEAD")) != 0;
   ax.init();
@@ -367,7 +367,8 @@ void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     if (need > ax.bwd_scr_elems) {
       if (ax.bwd_scr) (void)hipFree(ax.bwd_scr);
       ax.bwd_scr = nullptr; ax.bwd_scr_elems = 0;
-      if (hipMalloc((void**)&ax.bwd_scr, need * sizeof(double)) == hipSuccess) ax.bwd_scr_elems = need;
+      if (hipMalloc((void**)&ax.bwd_scr, need * sizeof(double)) != hipSuccess) { ax.bwd_scr = nullptr; return false; }   // (nothing enqueued yet)
+      ax.bwd_scr_elems = need;
     }
   }
   ax.mark(st, -1);
@@ -459,6 +460,7 @@ void launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     ax.mark(st, -5);
   }
   ax.mark(st, -6);
+  return true;
 }
 
 }  // namespace covgpu

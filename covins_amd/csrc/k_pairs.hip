@@ -5,10 +5,12 @@
 // Both are "for every landmark, every pair of its observing keyframes": sum n_l^2 entries (8.7 M on the 5-agent map). The
 // host version (counting pass, fill pass, per-row stable sorts on 16 threads) was the longest stage of an upload (28 of
 // 44 ms). Here: one thread per landmark counts and emits 64-bit keys (row keyframe << 32 | column keyframe) with the pair
-// of observation indices as value, ONE stable radix sort (rocPRIM through hipCUB — setup code, not a hot kernel),
+// of observation indices as value, ONE stable radix sort (rocPRIM's device primitives, called directly — setup code, not a hot kernel),
 // run-length encoding of the sorted keys = the unique pairs with their common-landmark counts. Stable sort + emission in
 // landmark order = the fixed summation order k_pair_blocks relies on (bit-reproducibility contract, k_visual.hip).
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "common.hpp"
 
@@ -78,9 +80,9 @@ bool build_pairs_device(int L, int K, const int* d_lm_obs_ptr, const int* d_obs_
   hipLaunchKernelGGL(k_pair_count, dim3((L + 255) / 256), dim3(256), 0, st, L, d_lm_obs_ptr, d_obs_kf, d_key_of_kf, d_cnt);
   {
     size_t b = 0;
-    PB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_cnt, d_off, L, st));
+    PB_HIP(rocprim::exclusive_scan(nullptr, b, d_cnt, d_off, 0ull, (size_t)L, rocprim::plus<unsigned long long>(), st));
     if (!need_tmp(b)) { ok = false; goto done; }
-    PB_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, b, d_cnt, d_off, L, st));
+    PB_HIP(rocprim::exclusive_scan(d_tmp, b, d_cnt, d_off, 0ull, (size_t)L, rocprim::plus<unsigned long long>(), st));
   }
   PB_HIP(hipMemcpyAsync(&last_cnt, d_cnt + (L - 1), 8, hipMemcpyDeviceToHost, st));
   PB_HIP(hipMemcpyAsync(&last_off, d_off + (L - 1), 8, hipMemcpyDeviceToHost, st));
@@ -93,18 +95,18 @@ bool build_pairs_device(int L, int K, const int* d_lm_obs_ptr, const int* d_obs_
   hipLaunchKernelGGL(k_pair_emit, dim3((L + 255) / 256), dim3(256), 0, st, L, d_lm_obs_ptr, d_obs_kf, d_key_of_kf, d_off, d_keys, d_vals);
   {
     size_t b = 0;
-    PB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, b, d_keys, d_keys2, d_vals, d_vals2, (int)total, 0, 32 + kbits, st));
+    PB_HIP(rocprim::radix_sort_pairs(nullptr, b, d_keys, d_keys2, d_vals, d_vals2, (size_t)total, 0u, (unsigned)(32 + kbits), st));
     if (!need_tmp(b)) { ok = false; goto done; }
-    PB_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, b, d_keys, d_keys2, d_vals, d_vals2, (int)total, 0, 32 + kbits, st));
+    PB_HIP(rocprim::radix_sort_pairs(d_tmp, b, d_keys, d_keys2, d_vals, d_vals2, (size_t)total, 0u, (unsigned)(32 + kbits), st));
   }
   // unique pairs + number of common landmarks of each (d_keys / d_vals are free again: reused as outputs)
   PB_HIP(hipMalloc((void**)&d_counts, total * 4)); PB_HIP(hipMalloc((void**)&d_nruns, 4));
   d_uniq = d_keys;
   {
     size_t b = 0;
-    PB_HIP(hipcub::DeviceRunLengthEncode::Encode(nullptr, b, d_keys2, d_uniq, d_counts, d_nruns, (int)total, st));
+    PB_HIP(rocprim::run_length_encode(nullptr, b, d_keys2, (unsigned)total, d_uniq, d_counts, d_nruns, st));
     if (!need_tmp(b)) { ok = false; goto done; }
-    PB_HIP(hipcub::DeviceRunLengthEncode::Encode(d_tmp, b, d_keys2, d_uniq, d_counts, d_nruns, (int)total, st));
+    PB_HIP(rocprim::run_length_encode(d_tmp, b, d_keys2, (unsigned)total, d_uniq, d_counts, d_nruns, st));
   }
   PB_HIP(hipMemcpyAsync(&nruns, d_nruns, 4, hipMemcpyDeviceToHost, st));
   PB_HIP(hipStreamSynchronize(st));
@@ -117,9 +119,9 @@ bool build_pairs_device(int L, int K, const int* d_lm_obs_ptr, const int* d_obs_
   hipLaunchKernelGGL(k_count_widen, dim3((nruns + 255) / 256), dim3(256), 0, st, nruns, d_counts, d_scan);
   {
     size_t b = 0;
-    PB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_scan, d_scan + nruns, nruns, st));
+    PB_HIP(rocprim::exclusive_scan(nullptr, b, d_scan, d_scan + nruns, 0ull, (size_t)nruns, rocprim::plus<unsigned long long>(), st));
     if (!need_tmp(b)) { ok = false; goto done; }
-    PB_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, b, d_scan, d_scan + nruns, nruns, st));
+    PB_HIP(rocprim::exclusive_scan(d_tmp, b, d_scan, d_scan + nruns, 0ull, (size_t)nruns, rocprim::plus<unsigned long long>(), st));
   }
   hipLaunchKernelGGL(k_pair_ptr, dim3((nruns + 255) / 256), dim3(256), 0, st, nruns, d_scan + nruns, d_counts, out.pair_ptr);
   if (want_obs) {

@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <memory>
@@ -51,6 +52,7 @@ struct PlanCache {
   NdHostPlan hp;
 };
 
+struct covgpu_group;
 struct covgpu_context {
   int device = 0;
   hipStream_t st = nullptr;
@@ -75,6 +77,13 @@ struct covgpu_context {
   struct Reducer* reducer = nullptr;
   double* d_red = nullptr;     // [SC_COUNT + 2 world] scratch of the scalar all-reduce
   double cur_damp = 0.0;       // damping of the system being built (the top unknowns get theirs after the all-reduce)
+  // a collective (or a scratch allocation of the linear solve) that failed while the iteration was being enqueued (broken / timed-out
+  // group barrier, scratch hipMalloc, non-zero ncclAllReduce): latched here, checked after the iteration's host synchronisation —
+  // the solve then returns an error instead of an estimate computed from un-reduced top fronts
+  bool coll_failed = false;
+  std::string coll_err;
+  covgpu_group* group = nullptr;   // the in-process group this context's reducer belongs to (aborted when this rank gives up)
+  std::atomic<int>* peer_fail = nullptr;   // covgpu_gba_solve_multi: raised by any rank of the call that gave up; polled while waiting
 };
 
 // ---------------------------------------------------------------------------------------------------- collectives
@@ -86,6 +95,8 @@ struct Reducer {
   size_t calls = 0, bytes = 0;
   virtual ~Reducer() {}
   virtual int allreduce(double* dev, size_t n, int op, hipStream_t st) = 0;
+  virtual void abort() {}                       // make every peer's pending and future collectives return
+  virtual std::string last_error() { return "all-reduce failed"; }
 };
 
 struct GroupPtrs { double* p[16]; };
@@ -113,6 +124,8 @@ struct GroupReducer : Reducer {
   covgpu_group* g = nullptr;
   double* scratch = nullptr; size_t scratch_n = 0;
   ~GroupReducer() override { if (scratch) (void)hipFree(scratch); }
+  void abort() override { std::lock_guard<std::mutex> lk(g->m); g->broken = true; g->cv.notify_all(); }
+  std::string last_error() override { return "in-process group all-reduce failed (a member gave up, timed out, or the scratch allocation failed)"; }
   int allreduce(double* dev, size_t n, int op, hipStream_t st) override {
     if (n == 0) return 0;
     if (scratch_n < n) { if (scratch) (void)hipFree(scratch); if (hipMalloc((void**)&scratch, n * sizeof(double)) != hipSuccess) return 1; scratch_n = n; }
@@ -135,6 +148,8 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, struct RcclId, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommAbort)(void*) = nullptr;
+  int (*CommGetAsyncError)(void*, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 struct RcclId { char internal[128]; };   // ncclUniqueId (rccl.h:40-43)
@@ -149,26 +164,49 @@ static RcclApi* rccl_api() {
     api.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(api.h, "ncclAllReduce");
     api.CommDestroy = (int (*)(void*))dlsym(api.h, "ncclCommDestroy");
     api.GetErrorString = (const char* (*)(int))dlsym(api.h, "ncclGetErrorString");
+    api.CommAbort = (int (*)(void*))dlsym(api.h, "ncclCommAbort");
+    api.CommGetAsyncError = (int (*)(void*, int*))dlsym(api.h, "ncclCommGetAsyncError");
     if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) { dlclose(api.h); api.h = nullptr; }
   });
   return api.h ? &api : nullptr;
 }
 struct RcclReducer : Reducer {
   void* comm = nullptr;
+  bool aborted = false;
+  int last_rc = 0;
   ~RcclReducer() override { if (comm && rccl_api()) rccl_api()->CommDestroy(comm); }
   int allreduce(double* dev, size_t n, int op, hipStream_t st) override {
     if (n == 0) return 0;
+    if (aborted) return 1;
     ++calls; bytes += n * sizeof(double);
-    return rccl_api()->AllReduce(dev, dev, n, /*ncclFloat64*/ 8, op == 0 ? /*ncclSum*/ 0 : /*ncclMax*/ 2, comm, st);
+    last_rc = rccl_api()->AllReduce(dev, dev, n, /*ncclFloat64*/ 8, op == 0 ? /*ncclSum*/ 0 : /*ncclMax*/ 2, comm, st);
+    return last_rc;
+  }
+  // asynchronous error of the communicator (a peer died, a link failed): polled by the host while it waits for the iteration
+  int async_error() {
+    int e = 0;
+    if (comm && rccl_api()->CommGetAsyncError && rccl_api()->CommGetAsyncError(comm, &e) == 0) return e;
+    return 0;
+  }
+  void abort() override {   // tears the communicator down at once: collective kernels in flight on any stream of this rank return
+    if (comm && rccl_api()->CommAbort) { rccl_api()->CommAbort(comm); comm = nullptr; }
+    aborted = true;
+  }
+  std::string last_error() override {
+    return std::string("RCCL all-reduce failed: ") + (rccl_api()->GetErrorString && last_rc ? rccl_api()->GetErrorString(last_rc) : "communicator aborted or asynchronous error");
   }
 };
 
+static void coll_latch(covgpu_context* c) {
+  if (!c->coll_failed) { c->coll_failed = true; c->coll_err = c->reducer ? c->reducer->last_error() : "all-reduce failed"; }
+}
 static void ctx_reduce(void* vc, double* dev, size_t n, int op, hipStream_t st) {
   covgpu_context* c = (covgpu_context*)vc;
-  if (c->reducer && n) (void)c->reducer->allreduce(dev, n, op, st);
+  if (c->reducer && n && c->reducer->allreduce(dev, n, op, st) != 0) coll_latch(c);
 }
 static void clear_shard(covgpu_context* c) {
   delete c->reducer; c->reducer = nullptr;
+  c->coll_failed = false; c->coll_err.clear(); c->group = nullptr;
   c->sharded = false; c->rank = 0; c->world = 1; c->shard_plan.reset();
   c->chol.reduce = nullptr; c->chol.reduce_ctx = nullptr;
 }
@@ -204,7 +242,9 @@ static int set_shard_common(covgpu_context* c, const covgpu_nd_plan* plan, int r
 extern "C" int covgpu_set_shard_group(covgpu_context* c, const covgpu_nd_plan* plan, int32_t rank, covgpu_group* g) {
   if (!g) { g_err = "covgpu_set_shard_group: NULL group"; return COVGPU_ERR_INVALID_ARG; }
   GroupReducer* r = new GroupReducer(); r->g = g;
-  return set_shard_common(c, plan, rank, g->world, r);
+  const int rc = set_shard_common(c, plan, rank, g->world, r);
+  if (rc == COVGPU_OK) c->group = g;
+  return rc;
 }
 extern "C" int covgpu_rccl_unique_id(uint8_t* out128) {
   RcclApi* api = rccl_api();
@@ -322,12 +362,21 @@ extern "C" void covgpu_destroy(covgpu_context* c) {
 extern "C" void covgpu_set_profiling(covgpu_context* c, int on) {
   c->profiling = on; c->prof = covgpu_profile_t();
   c->chol.profile = on != 0; c->chol.syrk_ms = 0; c->chol.syrk_flops = 0; c->chol.n_syrk = 0;
+  c->chol.potrf_ms = 0; c->chol.potrf_flops = 0; c->chol.n_potrf = 0;
 }
 // out[0..7] = build ms, n_build, factor ms, n_factor, syrk ms, n_syrk launches, syrk flops, tri-solve ms
 extern "C" void covgpu_get_profile(covgpu_context* c, double* out) {
   out[0] = c->prof.t_build_ms; out[1] = (double)c->prof.n_build; out[2] = c->prof.t_factor_ms; out[3] = (double)c->prof.n_factor;
   out[4] = c->chol.syrk_ms; out[5] = (double)c->chol.n_syrk; out[6] = c->chol.syrk_flops;
   out[7] = (double)(c->have ? c->P.npairs + c->P.nepairs : 0);  // off-diagonal 6x6 pose-pose blocks of the reduced system (nnzS - K)
+}
+// out[0..7] as covgpu_get_profile; out[8] = k_potrf_panel ms (sum over its launches), [9] = its launches, [10] = its algorithmic flops,
+// [11] = flops of ONE multifrontal factorisation of the resident problem's plan (Cholesky of every front incl. its border updates),
+// [12..15] = 0
+extern "C" void covgpu_get_profile2(covgpu_context* c, double* out) {
+  covgpu_get_profile(c, out);
+  out[8] = c->chol.potrf_ms; out[9] = (double)c->chol.n_potrf; out[10] = c->chol.potrf_flops; out[11] = c->have ? c->nd.plan_flops : 0.0;
+  out[12] = out[13] = out[14] = out[15] = 0.0;
 }
 
 // out[16] = { shard world, shard rank, scalar unknowns of the replicated top, top levels, KiB all-reduced per linear solve, 0,
@@ -956,7 +1005,9 @@ static void enqueue_solve(covgpu_context* c, double* dst_all) {
   // with profiling on, every bulk trailing-update (SYRK) launch gets its own event pair on its stream so that
   // bench.py can quote the dominant kernel's duration
   if (c->profiling) (void)hipEventRecord(c->ev[2], c->st);
-  if (P.nd) launch_nd_solve(P, c->nd, dst_all, c->cur_damp, c->st, c->chol);              // GBA: multifrontal solve of the whole system (k_front.hip)
+  if (P.nd) {   // GBA: multifrontal solve of the whole system (k_front.hip)
+    if (!launch_nd_solve(P, c->nd, dst_all, c->cur_damp, c->st, c->chol) && !c->coll_failed) { c->coll_failed = true; c->coll_err = "scratch allocation of the backward substitution failed"; }
+  }
   else launch_pose_graph_solve(P, dst_all, c->st, c->chol, c->pgo_plan.active ? &c->pgo_plan : nullptr);  // pose graph (k_pgo.hip)
   if (c->profiling) (void)hipEventRecord(c->ev[3], c->st);
   launch_lm_backsub(P, dst_all, dst_all, c->st);
@@ -1011,8 +1062,42 @@ __global__ void k_shard_scal_unpack(DevProblem P, const double* buf, int world) 
 static void reduce_scalars(covgpu_context* c) {
   if (!c->sharded || !c->reducer) return;
   hipLaunchKernelGGL(k_shard_scal_pack, dim3(1), dim3(64), 0, c->st, c->P, c->d_red, c->rank, c->world);
-  (void)c->reducer->allreduce(c->d_red, (size_t)SC_COUNT + 2 * (size_t)c->world, 0, c->st);
+  if (c->reducer->allreduce(c->d_red, (size_t)SC_COUNT + 2 * (size_t)c->world, 0, c->st) != 0) coll_latch(c);
   hipLaunchKernelGGL(k_shard_scal_unpack, dim3(1), dim3(64), 0, c->st, c->P, (const double*)c->d_red, c->world);
+}
+
+// Host wait for the iteration just enqueued. One GPU: hipStreamSynchronize. Sharded: polled, so that a collective that never
+// completes (a peer died, gave up before its first collective, or never arrived) ends in an ERROR after COVGPU_COLL_TIMEOUT_S
+// (default 300 s) instead of a hang; RCCL's asynchronous communicator errors and the give-up flag of an in-process multi-GPU call
+// are seen here too. On any of these the collective is aborted (ncclCommAbort / group abort: the peers return as well).
+static int wait_iteration(covgpu_context* c) {
+  if (c->sharded && c->reducer) {
+    static const double limit = getenv("COVGPU_COLL_TIMEOUT_S") ? std::max(1.0, atof(getenv("COVGPU_COLL_TIMEOUT_S"))) : 300.0;
+    RcclReducer* rr = dynamic_cast<RcclReducer*>(c->reducer);
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    for (;;) {
+      const hipError_t q = hipStreamQuery(c->st);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) { g_err = std::string("hipStreamQuery: ") + hipGetErrorString(q); return COVGPU_ERR_NO_DEVICE; }
+      if ((++spins & 1023) == 0) {
+        const char* why = nullptr;
+        if (c->peer_fail && c->peer_fail->load(std::memory_order_relaxed)) why = "another rank of the call gave up";
+        else if (rr && rr->async_error() != 0) why = "RCCL reported an asynchronous communicator error";
+        else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) why = "collective timed out (COVGPU_COLL_TIMEOUT_S)";
+        if (why) { if (!c->coll_failed) { c->coll_failed = true; c->coll_err = why; } c->reducer->abort(); break; }
+      } else if (spins > 4096) std::this_thread::yield();
+    }
+  }
+  HIPCHK(hipStreamSynchronize(c->st));
+  HIPCHK(hipGetLastError());  // a failed kernel launch anywhere in the batch just drained surfaces here
+  if (c->coll_failed) {
+    if (c->reducer) c->reducer->abort();
+    if (c->peer_fail) c->peer_fail->store(1);
+    g_err = (c->sharded ? "sharded solve, rank " + std::to_string(c->rank) + ": " : std::string("solve: ")) + c->coll_err;
+    return COVGPU_ERR_NO_DEVICE;
+  }
+  return COVGPU_OK;
 }
 
 // Trust-region loop with the step logic on the device (k_dense.hip: k_tr_*): ONE host read-back per iteration — what the
@@ -1026,6 +1111,7 @@ static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_r
   const covgpu_options& o = *opt;
   P.reproj_loss_a = o.reproj_loss_a;
   std::memset(res, 0, sizeof(*res));
+  c->coll_failed = false; c->coll_err.clear();   // (an aborted collective fails again at once and is latched again)
   const auto t_begin = std::chrono::steady_clock::now();
   RC(reset_state(c));
   HIPCHK(hipMemsetAsync(P.flag + 1, 0, sizeof(int), c->st));
@@ -1059,8 +1145,7 @@ static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_r
     reduce_scalars(c);
     launch_tr_decide(P, tc, c->st);
     HIPCHK(hipMemcpyAsync(h, P.tr, TR_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
-    HIPCHK(hipGetLastError());  // a failed kernel launch anywhere in the batch just drained surfaces here
+    RC(wait_iteration(c));
     collect_profile(c, !reuse, !reuse);
     if (!got_initial) { res->initial_cost = h[TR_INITCOST]; got_initial = true; }
     if (h[TR_RETRY] != 0.0) { reuse = false; continue; }  // factorisation failed: same iteration again with the raised damping
@@ -1179,12 +1264,14 @@ extern "C" int covgpu_gba_solve_multi(const covgpu_options* opt, covgpu_problem*
     covgpu_nd_plan* plan = nullptr;
     const int nsub = covgpu_shard_plan(opt, p, n_ranks, &plan, lm_rank.data(), imu_rank.data(), edge_rank.data());
     if (nsub <= 0) { g_err = "covgpu_gba_solve_multi: the problem does not split (" + g_err + ")"; return (int)COVGPU_ERR_INVALID_ARG; }
+    struct PlanGuard { covgpu_nd_plan* p; ~PlanGuard() { covgpu_nd_plan_destroy(p); } } plan_guard{plan};   // freed on every exit path
     bool shared_device = false;
     for (int a = 0; a < n_ranks; ++a) for (int b = 0; b < a; ++b) shared_device |= devices[a] == devices[b];
     covgpu_group* grp = nullptr;
     uint8_t uid[128];
     if (shared_device || n_ranks == 1) { RC(covgpu_group_create(n_ranks, &grp)); }
-    else { const int rc = covgpu_rccl_unique_id(uid); if (rc) { covgpu_nd_plan_destroy(plan); return rc; } }
+    else { RC(covgpu_rccl_unique_id(uid)); }
+    struct GroupGuard { covgpu_group* g; ~GroupGuard() { if (g) covgpu_group_destroy(g); } } grp_guard{grp};
     std::vector<SubProblem> sub(n_ranks);
     for (int r = 0; r < n_ranks; ++r) make_sub(*p, r, lm_rank.data(), imu_rank.data(), edge_rank.data(), sub[r]);
     std::vector<covgpu_result> res(n_ranks);
@@ -1193,17 +1280,41 @@ extern "C" int covgpu_gba_solve_multi(const covgpu_options* opt, covgpu_problem*
     std::vector<std::vector<uint8_t>> er(n_ranks);
     std::vector<std::vector<int32_t>> ll(n_ranks);
     std::vector<int64_t> cnt(2 * (size_t)n_ranks, 0);
+    // Failure protocol. A rank that fails raises `fail`; the stages that cannot block (context creation, validation + upload of the
+    // sub-problem) are separated from the next one by a host barrier after which EVERY rank checks the flag — so no rank enters
+    // ncclCommInitRank or its first all-reduce while a peer has already given up. Inside the solve the peers poll the flag while they
+    // wait for an iteration (wait_iteration) and abort their communicator; the in-process group is aborted directly.
+    std::atomic<int> fail{0};
+    struct HostBarrier {
+      std::mutex m; std::condition_variable cv; int count = 0, n = 0; long gen = 0;
+      void wait() { std::unique_lock<std::mutex> lk(m); const long g0 = gen; if (++count == n) { count = 0; ++gen; cv.notify_all(); } else cv.wait(lk, [&] { return gen != g0; }); }
+    } bar;
+    bar.n = n_ranks;
     auto work = [&](int r) {
       covgpu_context* c = nullptr;
       covgpu_options o = *opt; o.device = devices[r];
-      int rc = covgpu_create(&o, &c);
-      if (!rc) rc = grp ? covgpu_set_shard_group(c, plan, r, grp) : covgpu_set_shard_rccl(c, plan, r, n_ranks, uid);
-      if (!rc) rc = covgpu_gba_solve(c, &o, &sub[r].view, &res[r]);
-      if (!rc && obs_erase) {
-        er[r].assign(sub[r].obs_kf.size() + 1, 0); ll[r].assign(sub[r].lm_id.size() + 1, 0);
-        rc = covgpu_outlier_pass(c, outlier_threshold, er[r].data(), ll[r].data(), &cnt[2 * (size_t)r]);
+      int rc = COVGPU_OK;
+      auto give_up = [&](int code) { if (rc == COVGPU_OK && code != COVGPU_OK) { rc = code; errs[r] = covgpu_last_error(); fail.store(1); if (grp) covgpu_group_abort(grp); } };
+      give_up(covgpu_create(&o, &c));                                     // stage 1: a context on the rank's device
+      bar.wait();
+      if (!fail.load()) give_up(grp ? covgpu_set_shard_group(c, plan, r, grp) : covgpu_set_shard_rccl(c, plan, r, n_ranks, uid));   // stage 2: the collective (ncclCommInitRank: every rank is here)
+      if (c) c->peer_fail = &fail;
+      bar.wait();
+      const auto t_up0 = std::chrono::steady_clock::now();
+      if (!fail.load()) give_up(upload_impl(c, &o, &sub[r].view, false));  // stage 3: validation + H2D of the rank's share (OOM, malformed share)
+      const double t_up = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_up0).count();
+      bar.wait();
+      if (!fail.load()) give_up(solve_any(c, &o, &res[r]));               // stage 4: the solve (peers of a rank that fails in here: wait_iteration)
+      if (!fail.load() && rc == COVGPU_OK) {
+        const auto t_dn0 = std::chrono::steady_clock::now();
+        give_up(download_impl(c, &sub[r].view));
+        res[r].t_download_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dn0).count();
+        res[r].t_upload_s = t_up;
       }
-      if (rc) { errs[r] = covgpu_last_error(); if (grp) covgpu_group_abort(grp); }
+      if (!fail.load() && rc == COVGPU_OK && obs_erase) {
+        er[r].assign(sub[r].obs_kf.size() + 1, 0); ll[r].assign(sub[r].lm_id.size() + 1, 0);
+        give_up(covgpu_outlier_pass(c, outlier_threshold, er[r].data(), ll[r].data(), &cnt[2 * (size_t)r]));
+      }
       rcs[r] = rc;
       if (c) covgpu_destroy(c);
     };
@@ -1211,9 +1322,9 @@ extern "C" int covgpu_gba_solve_multi(const covgpu_options* opt, covgpu_problem*
     for (int r = 1; r < n_ranks; ++r) th.emplace_back(work, r);
     work(0);
     for (auto& t : th) t.join();
-    if (grp) covgpu_group_destroy(grp);
     int rc = COVGPU_OK;
     for (int r = 0; r < n_ranks; ++r) if (rcs[r]) { rc = rcs[r]; g_err = "rank " + std::to_string(r) + ": " + errs[r]; break; }
+    if (!rc && fail.load()) { rc = COVGPU_ERR_NO_DEVICE; g_err = "covgpu_gba_solve_multi: a rank gave up"; }
     if (!rc) {
       std::vector<int32_t> pr(p->num_kf), sr(p->num_kf);
       covgpu_nd_plan_owner(plan, pr.data(), sr.data());
@@ -1231,9 +1342,17 @@ extern "C" int covgpu_gba_solve_multi(const covgpu_options* opt, covgpu_problem*
         if (obs_erase) for (size_t i = 0; i < sub[r].obs_id.size(); ++i) obs_erase[sub[r].obs_id[i]] = er[r][i];
         if (counts) { counts[0] += cnt[2 * (size_t)r]; counts[1] += cnt[2 * (size_t)r + 1]; }
       }
-      if (out) *out = res[0];
+      if (out) {
+        // the trust-region trace, costs and counts are identical on every rank (all-reduced scalars): rank 0's. Per-rank fields
+        // are combined: IMU factors dropped for a non-PD covariance are counted where the factor lives (sum), timings are the slowest rank's
+        *out = res[0];
+        for (int r = 1; r < n_ranks; ++r) {
+          out->reserved += res[r].reserved;
+          out->t_upload_s = std::max(out->t_upload_s, res[r].t_upload_s); out->t_download_s = std::max(out->t_download_s, res[r].t_download_s);
+          out->t_solve_s = std::max(out->t_solve_s, res[r].t_solve_s);
+        }
+      }
     }
-    covgpu_nd_plan_destroy(plan);
     return rc;
   });
 }

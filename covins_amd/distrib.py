@@ -197,7 +197,17 @@ def throughput(dt_max: float, iterations: float) -> float:
 
 
 def gather_solutions(sol: FlatProblem, rank: int, world: int, store) -> Sequence:
-    """All ranks' (poses, speed-bias, landmarks) on every rank, through the TCPStore of `attach` (small: a few MB)."""
-    import pickle
-    store.set(f"sol_{rank}", pickle.dumps((sol.kf_pose, sol.kf_speed_bias, sol.lm_pos)))
-    return [pickle.loads(store.get(f"sol_{r}")) for r in range(world)]
+    """All ranks' (poses, speed-bias, landmarks) on every rank, through the TCPStore of `attach` (small: a few MB). Raw float64
+    buffers, never pickles: the store is an unauthenticated TCP service, and what comes out of it is only ever reinterpreted as
+    numbers (shapes follow from K, which every rank knows, and from the buffer length)."""
+    K = int(sol.kf_pose.shape[0])
+    parts = [np.ascontiguousarray(a, np.float64).reshape(-1) for a in (sol.kf_pose, sol.kf_speed_bias, sol.lm_pos)]
+    assert parts[0].size == 7 * K and parts[1].size == 9 * K and parts[2].size % 3 == 0
+    store.set(f"sol_{rank}", np.concatenate(parts).tobytes())
+    out = []
+    for r in range(world):
+        buf = np.frombuffer(bytes(store.get(f"sol_{r}")), np.float64)
+        if buf.size < 16 * K or (buf.size - 16 * K) % 3:
+            raise ValueError(f"rank {r}: solution buffer of {buf.size} doubles does not fit K={K}")
+        out.append((buf[:7 * K].reshape(K, 7).copy(), buf[7 * K:16 * K].reshape(K, 9).copy(), buf[16 * K:].reshape(-1, 3).copy()))
+    return out

@@ -348,6 +348,10 @@ void covgpu_set_profiling(covgpu_context* ctx, int on);
  * 256-column panels, order of the last level's fronts, MiB of fronts } */
 void covgpu_get_layout(covgpu_context* ctx, int64_t* out16);
 void covgpu_get_profile(covgpu_context* ctx, double* out8);
+/* out16: [0..7] as covgpu_get_profile; [8] k_potrf_panel (the serial panel chain of the front factorisation) milliseconds summed over
+ * its launches, [9] its launches, [10] its algorithmic flops (per front n^3/3 + n^2 on the front's real columns in the panel),
+ * [11] flops of one multifrontal factorisation of the resident problem (dense count on the fronts' real sizes), [12..15] 0 */
+void covgpu_get_profile2(covgpu_context* ctx, double* out16);
 
 #ifdef __cplusplus
 }

@@ -100,8 +100,8 @@ def test_twelve_agent_map_runs_on_one_gpu():
     properties instead of an oracle run (the CPU oracle does not finish at this size): monotone accepted steps, ATE drops."""
     import os
     name = "a12" if os.environ.get("COVGPU_TEST_A12") == "1" else "a12x1000"   # a12 = the stated 20k keyframes / 2M landmarks
-    m = synth.make_map(synth.config_named(name))
-    p = mapdata.flatten_gba(m, False, True)[0]
+    from tests.util import cached_problem
+    m, p = cached_problem(name)   # (shared with tests/test_gpu_full.py's oracle-parity checks at this size)
     assert p.K >= 12000 and p.L > 1_000_000
     ctx = backend.Context(0)
     o = backend.default_options(max_iterations=6)

@@ -3,7 +3,10 @@ for configs[1] (mh01), configs[2]'s GBA (mh123) and the metric's 5-agent map (mh
 (tests/golden/*.npz, made by tools/make_golden_full.py; oracle = block-sparse reduced system solved by scipy's SuperLU).
 Tolerances: poses 1e-6 m / 1e-7 rad, speed-bias 1e-6, cost trace 1e-6 relative, identical accept/reject sequence;
 landmarks by tests/util.landmark_parity. Plus one linearisation at full size: the device Gauss-Newton step must solve the
-ORACLE's reduced system (||S dx - b||), and the multifrontal solve must equal the one-front (dense) solve."""
+ORACLE's reduced system (||S dx - b||), and the multifrontal solve must equal the one-front (dense) solve.
+BASELINE configs[4] shape (12 agents): the same single-linearisation check at 12 x 1000 keyframes (and at the stated
+12 x 1667 = 20 004 keyframes with COVGPU_TEST_A12=1), and ONE trust-region iteration against the oracle's committed result
+(tests/golden/a12x1000_it1.npz, a12_it1.npz: tools/make_golden_full.py --one-iter)."""
 import hashlib
 import os
 
@@ -12,7 +15,7 @@ import pytest
 
 from covins_amd import backend, capi, mapdata, synth
 from oracle import covo
-from tests.util import landmark_parity, rot_angle
+from tests.util import cached_problem, landmark_parity, rot_angle
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -34,14 +37,8 @@ def ctx():
     c.close()
 
 
-_cache = {}
-
-
-def problem(name):
-    if name not in _cache:
-        m = synth.make_map(synth.config_named(name))
-        _cache[name] = (m, mapdata.flatten_gba(m, False, True)[0])
-    return _cache[name]
+problem = cached_problem
+A12 = ["a12x1000"] + (["a12"] if os.environ.get("COVGPU_TEST_A12") == "1" else [])   # configs[4] shape; a12 = its stated 20 004 keyframes
 
 
 @pytest.mark.parametrize("name", ["mh01", "mh123", "mh12345"])
@@ -103,11 +100,27 @@ def _spmv(ptr, col, blocks, x, D):
     return sp.bsr_matrix((blocks, col, ptr), shape=(n, n)) @ x
 
 
-@pytest.mark.parametrize("name", ["mh01", "mh12345"])
+def _lapack_multifrontal_solve(p, ptr, col, blocks, b):
+    """Reference solution of the oracle's block-CSR system at sizes SuperLU does not finish: oracle/covo_mf.py (LAPACK potrf /
+    trsm / syrk per front on the host; shares no arithmetic with the HIP kernels)."""
+    import ctypes as C
+    from oracle import covo_mf
+    n, K = len(b), len(ptr) - 1
+    covo_mf.set_problem(p, backend.default_options(), int(covo.lib().covo_num_threads()))
+    ptr = np.ascontiguousarray(ptr, np.int32); col = np.ascontiguousarray(col, np.int32)
+    vals = np.ascontiguousarray(blocks, np.float64).reshape(-1); rhs = np.ascontiguousarray(b, np.float64); x = np.zeros(n)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32)); dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rc = covo_mf.solve(n, 15, K, ip(ptr), ip(col), dp(vals), dp(rhs), dp(x))
+    assert rc == 0, rc
+    return x
+
+
+@pytest.mark.parametrize("name", ["mh01", "mh12345"] + A12)
 def test_single_linearisation_at_full_size(ctx, name):
     """The device Gauss-Newton step (multifrontal MFMA Cholesky of the reduced camera system + landmark
     back-substitution) must solve the reduced system the ORACLE assembles: ||S dx - b|| / ||b|| small, and dx equal to the
-    SuperLU solution of the same system."""
+    CPU solution of the same system (SuperLU; at the 12-agent sizes — 180k / 300k unknowns — LAPACK through the multifrontal
+    CPU port, which SuperLU cross-checks at the smaller sizes in tests/test_oracle.py)."""
     import scipy.sparse as sp
     import scipy.sparse.linalg as spla
     m, p = problem(name)
@@ -116,16 +129,41 @@ def test_single_linearisation_at_full_size(ctx, name):
     ptr, col, blocks, b, cost0 = covo.schur_sparse(p, covo.default_options(), mu)
     assert abs(cost - cost0) <= 1e-10 * cost0
     n = 15 * p.K
-    S = sp.bsr_matrix((blocks, col, ptr), shape=(n, n)).tocsc()
+    S = sp.bsr_matrix((blocks, col, ptr), shape=(n, n))
     r = S @ dx - b
     rel = np.linalg.norm(r) / np.linalg.norm(b)
-    x0 = spla.splu(S, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True)).solve(b)
+    if n > 60000:
+        x0, how = _lapack_multifrontal_solve(p, ptr, col, blocks, b), "lapack-multifrontal"
+    else:
+        x0, how = spla.splu(S.tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True)).solve(b), "superlu"
     rel0 = np.linalg.norm(S @ x0 - b) / np.linalg.norm(b)
     # compare in the metric of the system (the step along badly determined directions is large in absolute terms)
     d = np.sqrt(np.abs(S.diagonal()))
     err = np.abs((dx - x0) * d).max() / np.abs(x0 * d).max()
-    print(f"{name}: n={n} |S dx-b|/|b| gpu {rel:.2e} superlu {rel0:.2e}, scaled step difference {err:.2e}")
+    print(f"{name}: n={n} |S dx-b|/|b| gpu {rel:.2e} {how} {rel0:.2e}, scaled step difference {err:.2e}")
     assert rel < max(100 * rel0, 1e-9) and err < 1e-6
+
+
+@pytest.mark.parametrize("name", A12)
+def test_one_iteration_at_config4_shape_matches_oracle_golden(ctx, name):
+    """BASELINE configs[4] (synthetic 12-agent map): ONE trust-region iteration of the HIP path against the oracle's committed
+    result at the same size (optimization_be.cpp:560-567 with max_num_iterations = 1): initial cost 1e-9, candidate cost 1e-6,
+    the accept decision, every 4th pose within 1e-6 m / 1e-7 rad, speed-bias 1e-6."""
+    G = np.load(os.path.join(GOLD, f"{name}_it1.npz"))
+    m, p = problem(name)
+    assert digest(p) == str(G["in_digest"]), "regenerated inputs differ from the ones the golden was made on"
+    sol, res = ctx.gba_solve(p, backend.default_options(max_iterations=1))
+    assert res.iterations == int(G["iterations"]) == 1
+    assert list(res.accepted_trace[:1]) == list(G["acc"])
+    assert abs(res.initial_cost - G["cost"][0]) <= 1e-9 * G["cost"][0]
+    assert np.allclose(np.array(res.cost_trace[:1]), G["trace"], rtol=1e-6, atol=0)
+    st = int(G["kf_stride"])
+    dp = np.abs(sol.kf_pose[::st, 4:] - G["pose"][:, 4:]).max()
+    da = rot_angle(sol.kf_pose[::st, :4], G["pose"][:, :4]).max()
+    ds = np.abs(sol.kf_speed_bias[::st] - G["sb"]).max()
+    print(f"{name} one iteration: K={p.K} L={p.L} O={p.O} cost {res.initial_cost:.6e} -> {res.cost_trace[0]:.6e} (oracle {G['trace'][0]:.6e}) "
+          f"max|dp|={dp:.2e} m, max angle={da:.2e} rad, max|dsb|={ds:.2e}")
+    assert dp < 1e-6 and da < 1e-7 and ds < 1e-6
 
 
 def test_multifrontal_solve_equals_one_front_solve(ctx):

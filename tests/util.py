@@ -4,6 +4,19 @@ import numpy as np
 from covins_amd import mapdata
 
 
+_maps = {}
+
+
+def cached_problem(name):
+    """(map, flat GBA problem) of a named synthetic configuration, generated once per test session: the 12-agent maps take a
+    minute to generate and several test modules use them."""
+    from covins_amd import synth
+    if name not in _maps:
+        m = synth.make_map(synth.config_named(name))
+        _maps[name] = (m, mapdata.flatten_gba(m, False, True)[0])
+    return _maps[name]
+
+
 def truth_map(m):
     t = m.copy()
     t.kf_pose = m.truth["kf_pose"].copy()

@@ -10,10 +10,10 @@ mkdir -p $root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
-  rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_$ctr -o pmc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e > $root/gpurun_out/${tag}_pmc_$ctr.log 2>&1
+  rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_$ctr -o pmc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --sustain-s 0 > $root/gpurun_out/${tag}_pmc_$ctr.log 2>&1
 done
 rm -rf /tmp/pmc_mfma
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d /tmp/pmc_mfma -o pmc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e > $root/gpurun_out/${tag}_pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d /tmp/pmc_mfma -o pmc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --sustain-s 0 > $root/gpurun_out/${tag}_pmc_mfma.log 2>&1
 cd $root
 python tools/rocpd_pmc.py FETCH_SIZE=$(ls /tmp/pmc_FETCH_SIZE/*.db | head -1) WRITE_SIZE=$(ls /tmp/pmc_WRITE_SIZE/*.db | head -1) gpurun_out/${tag}_pmc_hbm_traffic.csv > /dev/null
 python tools/rocpd_counters.py $(ls /tmp/pmc_mfma/*.db | head -1) gpurun_out/${tag}_pmc_mfma.csv > /dev/null
@@ -37,6 +37,11 @@ for row in csv.DictReader(open(os.path.join(root, "gpurun_out", "${tag}_pmc_hbm_
         fetch += c * float(row["FETCH_x2_MB_per_call"]) * 1048576.0; write += c * float(row["WRITE_MB_per_call"]) * 1048576.0
 if calls:
     out.update(kernel=" + ".join(sorted(set(names))), calls=int(calls), fetch_bytes_x2=fetch / calls, write_bytes=write / calls)
+# the serial panel chain (bench.py: roofline = the kernel with the largest share of GPU time)
+for row in csv.DictReader(open(os.path.join(root, "gpurun_out", "${tag}_pmc_hbm_traffic.csv"))):
+    if "k_potrf_panel" in row["Name"]:
+        out["potrf_bytes_per_launch"] = (float(row["FETCH_x2_MB_per_call"]) + float(row["WRITE_MB_per_call"])) * 1048576.0
+        out["potrf_calls"] = int(row["Calls"])
 # counter traffic of the whole linearise + landmark-Schur pass per trust-region iteration (bench.py: roofline_build.traffic)
 BUILD = ("k_lm_lin", "k_kf_reduce", "k_pair_blocks", "k_imu_build", "k_imu_gather", "k_edge_build", "k_edge_gather_kf", "k_edge_gather_pair",
          "k_finalize_diag", "k_zero_many", "k_nd_zero", "k_cost_finish")
@@ -56,6 +61,9 @@ for row in csv.DictReader(open(os.path.join(root, "gpurun_out", "${tag}_pmc_mfma
         w = float(row.get("Calls") or 1); busy += w * float(row["MfmaBusy_pct"]) / 100.0; wsum += w
 if wsum:
     out["mfma_busy_frac"] = busy / wsum   # (weighted by launches)
+for row in csv.DictReader(open(os.path.join(root, "gpurun_out", "${tag}_pmc_mfma.csv"))):
+    if "k_potrf_panel" in row["Name"] and row.get("MfmaBusy_pct"):
+        out["potrf_mfma_busy_frac"] = float(row["MfmaBusy_pct"]) / 100.0
 json.dump(out, open(os.path.join(root, "gpurun_out", "pmc_traffic_current.json"), "w"), indent=1)
 print(json.dumps(out))
 PY

@@ -137,8 +137,11 @@ struct DevProblem {
 
 enum {
   TR_RADIUS = 0, TR_MU, TR_LMDF, TR_COST, TR_ALPHA, TR_GG, TR_GN2, TR_GDOT, TR_DNORM, TR_CG, TR_CN, TR_MODEL, TR_SN, TR_RHO, TR_COSTNEW,
-  TR_OK, TR_VALID, TR_ACC, TR_TERM, TR_FNCONV, TR_RETRY, TR_FIRST, TR_INITCOST, TR_REUSE, TR_COUNT = 32
+  TR_OK, TR_VALID, TR_ACC, TR_TERM, TR_FNCONV, TR_RETRY, TR_FIRST, TR_INITCOST, TR_REUSE,
+  TR_JA, TR_JB, TR_JC, TR_VV, TR_VG, TR_NN, TR_XN2,   // dot products of the fused tail (k_tail.hip): a rejected step re-derives its coefficients from them
+  TR_COUNT = 32
 };
+static_assert(TR_XN2 < TR_COUNT, "trust-region state slots");
 struct TrConsts {  // options the device-side step logic needs
   int strategy;
   double max_radius, min_relative_decrease, function_tolerance, parameter_tolerance, gradient_tolerance;
@@ -171,7 +174,9 @@ __device__ __forceinline__ double* c_entry(const DevProblem& P, int pi, int pj, 
 }
 
 // ---- scalar slots in DevProblem::scal
-enum { SC_COST = 0, SC_JV2 = 1, SC_GG = 2, SC_GN2 = 3, SC_GDOT = 4, SC_GMAX = 5, SC_GS = 6, SC_SN2 = 7, SC_XN2 = 8, SC_COUNT = 16 };
+enum { SC_COST = 0, SC_JV2 = 1, SC_GG = 2, SC_GN2 = 3, SC_GDOT = 4, SC_GMAX = 5, SC_GS = 6, SC_SN2 = 7, SC_XN2 = 8,
+       SC_VV = 9, SC_VG = 10, SC_NN = 11, SC_JA = 12, SC_JB = 13, SC_JC = 14,   // fused tail (k_tail.hip): |c|^2, c.n, |n|^2, |J c|^2, |J n|^2, (J c).(J n)
+       SC_COUNT = 16 };
 
 struct CholAux;
 // ---- launchers (each enqueues on `st`, no synchronisation)
@@ -367,6 +372,15 @@ void launch_nd_init(const DevProblem& P, const NdDev& nd, hipStream_t st);    //
 void launch_nd_zero(const DevProblem& P, const NdDev& nd, hipStream_t st);    // per iteration: clear the live tiles, identity on interior padding
 bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hipStream_t st, CholAux& ax);  // false: scratch allocation failed, nothing enqueued. damped system in the fronts + bred -> dst (IR layout)
 
+// fused trust-region tail (k_tail.hip): T1 stats, T2 J*v of (c, n) over all residual families, T3 / T6 finish (+ step logic in the
+// last workgroup), T4 candidate, T5 candidate cost
+void launch_tail_stats(const DevProblem& P, hipStream_t st);
+void launch_tail_jvp(const DevProblem& P, bool two, hipStream_t st);
+void launch_tail_cost(const DevProblem& P, hipStream_t st);
+void launch_tail_finish(const DevProblem& P, TrConsts tc, int stage, bool two, bool with_logic, int fresh, hipStream_t st);
+void launch_tail_logic(const DevProblem& P, TrConsts tc, int stage, int fresh, hipStream_t st);
+void launch_tail_apply(const DevProblem& P, hipStream_t st);
+
 void launch_dogleg_stats(const DevProblem& P, hipStream_t st);  // GG, GN2, GDOT, GMAX from grad/hdiag/gn
 void launch_cauchy_vec(const DevProblem& P, hipStream_t st);    // vtmp = grad / d^2
 void launch_combine_step(const DevProblem& P, double cg, double cn, hipStream_t st);  // step = cg*grad/d^2 + cn*gn ; GS, SN2
@@ -377,6 +391,7 @@ void launch_tr_after_model(const DevProblem& P, TrConsts tc, hipStream_t st);   
 void launch_tr_decide(const DevProblem& P, TrConsts tc, hipStream_t st);                    // rho test, radius / damping update, accept: x = candidate
 void launch_apply_step(const DevProblem& P, hipStream_t st);    // candidate = x (+) step
 void launch_accept(const DevProblem& P, hipStream_t st);        // x = candidate
+void launch_tr_accept(const DevProblem& P, hipStream_t st);     // x = candidate if TR_ACC (device-side decision)
 void launch_xnorm(const DevProblem& P, hipStream_t st);         // XN2
 void launch_relpose(int num, const int* ptr, const double* pB, const double* pA, const double* kpA, const double* kpB, const double* sigA,
                     const double* sigB, const double* camA, const int* distA, const double* camB, const int* distB, double th, int min_inliers,

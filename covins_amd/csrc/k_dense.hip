@@ -297,10 +297,13 @@ void launch_combine_step_dev(const DevProblem& P, hipStream_t st) {
 }
 void launch_tr_after_solve(const DevProblem& P, TrConsts tc, int fresh, hipStream_t st) { hipLaunchKernelGGL(k_tr_after_solve, dim3(1), dim3(64), 0, st, P, tc, fresh); }
 void launch_tr_after_model(const DevProblem& P, TrConsts tc, hipStream_t st) { hipLaunchKernelGGL(k_tr_after_model, dim3(1), dim3(64), 0, st, P, tc); }
-void launch_tr_decide(const DevProblem& P, TrConsts tc, hipStream_t st) {
-  hipLaunchKernelGGL(k_tr_decide, dim3(1), dim3(64), 0, st, P, tc);
+void launch_tr_accept(const DevProblem& P, hipStream_t st) {   // x = candidate if the step logic accepted it (TR_ACC)
   const size_t n = std::max((size_t)9 * P.K, (size_t)3 * P.L);
   hipLaunchKernelGGL(k_tr_accept, dim3(vec_grid((int)std::min<size_t>(n, 1u << 30))), dim3(256), 0, st, P);
+}
+void launch_tr_decide(const DevProblem& P, TrConsts tc, hipStream_t st) {
+  hipLaunchKernelGGL(k_tr_decide, dim3(1), dim3(64), 0, st, P, tc);
+  launch_tr_accept(P, st);
 }
 void launch_apply_step(const DevProblem& P, hipStream_t st) {
   const int n = P.K > 3 * P.L ? P.K : 3 * P.L;

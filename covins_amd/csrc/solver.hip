@@ -1124,7 +1124,28 @@ static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_r
   const TrConsts tc{o.strategy, o.max_radius, o.min_relative_decrease, o.function_tolerance, o.parameter_tolerance, o.gradient_tolerance};
   bool reuse = false, got_initial = false;
   int it = 0, accepted = 0, term = 0;
+  // COVGPU_TAIL=0: the round-3 tail (two J*v passes of three kernels, seven partial-sum finishers, four one-thread logic kernels:
+  // ~25 dependent launches); default: the fused tail of k_tail.hip (8 launches, one J*v pass for both dogleg directions)
+  static const bool fused_tail = getenv("COVGPU_TAIL") == nullptr || atoi(getenv("COVGPU_TAIL")) != 0;
+  const bool two = o.strategy == COVGPU_DOGLEG;
+  const bool coll = c->sharded && c->reducer != nullptr;   // scalar all-reduce between a finish and the step logic that reads it
   while (it < o.max_iterations) {
+    if (fused_tail) {
+      if (!reuse) {
+        const double damp = (o.strategy == COVGPU_LM) ? 1.0 / h[TR_RADIUS] : h[TR_MU];
+        enqueue_build(c, damp);
+        enqueue_solve(c, P.gn);
+        launch_tail_stats(P, c->st);
+        launch_tail_jvp(P, two, c->st);
+        launch_tail_finish(P, tc, 1, two, !coll, 1, c->st);
+        if (coll) { reduce_scalars(c); launch_tail_logic(P, tc, 1, 1, c->st); }
+      } else launch_tail_logic(P, tc, 1, 0, c->st);
+      launch_tail_apply(P, c->st);
+      launch_tail_cost(P, c->st);
+      launch_tail_finish(P, tc, 2, two, !coll, 0, c->st);
+      if (coll) { reduce_scalars(c); launch_tail_logic(P, tc, 2, 0, c->st); }
+      launch_tr_accept(P, c->st);
+    } else {
     if (!reuse) {
       const double damp = (o.strategy == COVGPU_LM) ? 1.0 / h[TR_RADIUS] : h[TR_MU];
       enqueue_build(c, damp);
@@ -1144,6 +1165,7 @@ static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_r
     enqueue_cost_candidate(c);
     reduce_scalars(c);
     launch_tr_decide(P, tc, c->st);
+    }
     HIPCHK(hipMemcpyAsync(h, P.tr, TR_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
     RC(wait_iteration(c));
     collect_profile(c, !reuse, !reuse);

@@ -2,7 +2,8 @@
 share of the SAME map (its subtrees of the elimination tree + the replicated top), driven in lockstep by host threads; the
 library's collectives run through its native in-process group (solver.hip GroupReducer: sums in rank order on the device).
 The sharded result must equal the unsharded one: one Gauss-Newton step to 1e-9 (relative) and the full 10-iteration solve
-to 1e-8 m with the identical accept sequence; four collectives per trust-region iteration."""
+to 1e-8 m with the identical accept sequence; three collectives per trust-region iteration (the top of the tree inside the
+linear solve, two scalar exchanges of the fused tail)."""
 import threading
 
 import numpy as np
@@ -98,7 +99,7 @@ def test_sharded_solve_equals_unsharded(name, world, strategy):
     print(f"{name} world {world}: pose {dp:.2e} speed-bias {ds:.2e} landmarks {dl:.2e}; {st['collectives']} collectives ({per_it:.1f} per iteration), "
           f"{st['bytes'] / 1e6:.1f} MB per solve, {lay['allreduce_kib'] / 1024:.1f} MiB per linear solve")
     assert dp < 1e-8 and ds < 1e-8 and dl < 1e-6
-    assert per_it <= 4.0
+    assert per_it <= 3.0   # top fronts once per linear solve + two scalar exchanges (k_tail.hip); a rejected step needs one less
 
 
 def test_one_rank_group_is_the_unsharded_solve():
@@ -136,6 +137,6 @@ def test_rccl_collective_in_a_one_rank_communicator():
     assert np.allclose(ctx.allreduce_host(np.array([1.5, -2.0]), 0), [1.5, -2.0])
     ctx.set_shard_none()
     ctx.close()
-    assert st["collectives"] == 4 * r1.iterations and st["world"] == 1
+    assert st["collectives"] == 3 * r1.iterations and st["world"] == 1   # (no rejected step in these four iterations)
     assert r0.iterations == r1.iterations and list(r0.accepted_trace[:4]) == list(r1.accepted_trace[:4])
     assert np.abs(s0.kf_pose - s1.kf_pose).max() < 1e-8 and np.abs(s0.lm_pos - s1.lm_pos).max() < 1e-6

@@ -54,6 +54,8 @@ struct DevProblem {
   int npairs;
   int *pair_ptr, *pair_i, *pair_j;          // [npairs+1], [npairs] chain-major positions, i > j
   int *pair_oa, *pair_ob;                   // [sum] observation of keyframe i / keyframe j of each common landmark
+  int *kp_ptr;                              // [K+1] by chain position: the pairs (i, j < i) of keyframe i are pair_ptr-indexed kp_ptr[pos] .. kp_ptr[pos + 1] (sorted by (i, j))
+  int max_obs_per_kf;                       // longest keyframe-major observation list (LDS budget of k_pair_blocks_kf)
   double *obsZ;                             // [O][18] per-observation Z = (Jp^T Jl) R with Hll^-1 = R R^T: the one record of the landmark elimination (k_visual.hip),
                                             // KEYFRAME-major (slot obs_zpos[o]): the records a covisible pair reads lie in its two keyframes' 60-KB blocks (L2)
   double *lmRT;                             // [L][9] per landmark: lower factor R (6) | t = R^T g_l (3)
@@ -217,7 +219,8 @@ void launch_zero_system(const DevProblem& P, hipStream_t st);       // every sma
 // (profiling only) one timed event pair around every bulk trailing-update launch
 struct CholAux {
   hipStream_t aux = nullptr, mid = nullptr, head = nullptr;
-  hipEvent_t ev_fill = nullptr;  // pose system cleared (head stream, beside the linearisation)
+  hipEvent_t ev_fill = nullptr;  // pose system cleared (head stream, beside the linearisation — or behind the previous linear solve)
+  hipEvent_t ev_done = nullptr;  // linear solve finished on the main stream: the fronts may be cleared for the next linearisation
   hipEvent_t ev_xb = nullptr;    // multifrontal look-ahead: second half of a level's extend-add done (bulk stream)
   int* bwd_cnt = nullptr;        // ticket counters of k_bwd_front (65536, zero between launches)
   double* bwd_scr = nullptr; size_t bwd_scr_elems = 0;   // its scratch (grown on demand by launch_nd_solve)

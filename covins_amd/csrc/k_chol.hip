@@ -294,6 +294,7 @@ void CholAux::init() {
   if (!ev_lin) (void)hipEventCreateWithFlags(&ev_lin, hipEventDisableTiming);
   if (!ev_kf) (void)hipEventCreateWithFlags(&ev_kf, hipEventDisableTiming);
   if (!ev_fill) (void)hipEventCreateWithFlags(&ev_fill, hipEventDisableTiming);
+  if (!ev_done) (void)hipEventCreateWithFlags(&ev_done, hipEventDisableTiming);
   if (!ev_xb) (void)hipEventCreateWithFlags(&ev_xb, hipEventDisableTiming);
   if (!ev_xa) (void)hipEventCreateWithFlags(&ev_xa, hipEventDisableTiming);
   if (!bwd_cnt && hipMalloc((void**)&bwd_cnt, 65536 * sizeof(int)) == hipSuccess) (void)hipMemset(bwd_cnt, 0, 65536 * sizeof(int));
@@ -324,6 +325,7 @@ void CholAux::destroy() {
   if (ev_lin) { (void)hipEventDestroy(ev_lin); ev_lin = nullptr; }
   if (ev_kf) { (void)hipEventDestroy(ev_kf); ev_kf = nullptr; }
   if (ev_fill) { (void)hipEventDestroy(ev_fill); ev_fill = nullptr; }
+  if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
   if (ev_xb) { (void)hipEventDestroy(ev_xb); ev_xb = nullptr; }
   if (ev_xa) { (void)hipEventDestroy(ev_xa); ev_xa = nullptr; }
   if (bwd_cnt) { (void)hipFree(bwd_cnt); bwd_cnt = nullptr; }

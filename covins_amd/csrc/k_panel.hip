@@ -32,6 +32,7 @@
 namespace covgpu {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 #ifdef COVGPU_PROBE
 __device__ long long g_pprobe[8];
@@ -395,6 +396,7 @@ struct TrsmSubArgs {
   double* M; size_t ld;
   int k0;                 // first column of the panel
   int r0;                 // first row (multiple of 16); workgroup x handles rows r0 + 16 x ..
+  int r1;                 // end of the row range (k_trsm_lds: a workgroup's last slabs may lie beyond it)
   const double* Dinv;     // block inverses of the panel's first tile (second tile 128*128 further)
   double* rhs; const double* yvec;   // forward substitution riding along: rhs[rows] -= X[rows, :] y[k0 ..)
   size_t bsM, bsL, bsR;
@@ -490,6 +492,135 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (NB > 12 && nbf <= 12) { trsm_sub_body<12>(g); return; }
   }
   trsm_sub_body<NB>(g);
+}
+
+// The same substitution, four slabs per workgroup with the factor streamed through LDS. k_trsm_sub's one-wave slab pulls the
+// whole 256x256 factor (136 tiles of 2 KB) through its own registers, a few tiles ahead: ~25 us of load latency around ~3 us of
+// matrix-core work — on the serial chain of EVERY panel (rows of the next panel in a multi-panel front, all rows below in a
+// single-panel one). Here the 256 threads of a workgroup fetch block column j + 2 (its Dinv block and the L tiles below it,
+// coalesced 16-byte loads, registers) while block column j + 1 moves from registers to the other LDS stage and the four waves
+// run step j out of LDS: a memory latency is spread over two to three steps, and the factor is read once per 64 rows instead
+// of once per 16. Same MFMA sequence per slab as k_trsm_sub: bit-identical results.
+constexpr int TL_WAVES = 4;                      // slabs per workgroup
+constexpr int TL_TILE = PB * PP;                 // one 16x16 tile at pitch PP (conflict-free 32-byte operand reads)
+struct TlCtx {
+  double* Mb; const double* Db; size_t ld; int k0, tid, pr, fk;
+};
+// cooperative fetch of block column J: tile 0 = Dinv_J, tiles 1 .. NB-1-J = L(J+1.., J); a thread takes 16-byte pieces, piece q ->
+// tile q >> 7, row (q >> 3) & 15, doubles 2 (q & 7) .. (the last piece index is clamped: unconditional loads, no divergent branch)
+template <int NB, int J, int NPF>
+COV_DEV void tl_fetch(const TlCtx& c, v2f64 (&pf)[NPF]) {
+  constexpr int np = (NB - J) * 128;
+#pragma unroll
+  for (int it = 0; it < NPF; ++it) {
+    if (256 * it < np) {
+      const int q = min(c.tid + 256 * it, np - 1);
+      const int t = q >> 7, rr = (q >> 3) & 15, c2 = (q & 7) * 2;
+      const double* src = (t == 0) ? c.Db + (size_t)(J >> 3) * kTile * kTile + (size_t)(J & 7) * 256 + rr * PB + c2
+                                   : c.Mb + (size_t)(c.k0 + PB * (J + t) + rr) * c.ld + c.k0 + PB * J + c2;
+      pf[it] = *reinterpret_cast<const v2f64*>(src);
+    }
+  }
+}
+template <int NB, int J, int NPF>
+COV_DEV void tl_stash(const TlCtx& c, const v2f64 (&pf)[NPF], double* st) {
+  constexpr int np = (NB - J) * 128;
+#pragma unroll
+  for (int it = 0; it < NPF; ++it) {
+    const int q = c.tid + 256 * it;
+    if (256 * it < np && q < np) {
+      const int t = q >> 7, rr = (q >> 3) & 15, c2 = (q & 7) * 2;
+      *reinterpret_cast<v2f64*>(st + t * TL_TILE + rr * PP + c2) = pf[it];
+    }
+  }
+}
+// steps J .. NB-1 of the block substitution (compile-time recursion: every register index is a constant). On entry block column J
+// is in flight to / in stage J & 1 and `pfx` holds block column J + 1 (pfy is free).
+template <int NB, int J, int NPF>
+COV_DEV void tl_steps(const TlCtx& c, v4f64 (&acc)[NB], v2f64 (&pfx)[NPF], v2f64 (&pfy)[NPF], double* stage) {
+  if constexpr (J < NB) {
+    double* cur = stage + (J & 1) * NB * TL_TILE;
+    double* oth = stage + ((J + 1) & 1) * NB * TL_TILE;
+    lds_barrier();                                // column J is in `cur`; everybody has finished reading `oth` (step J - 1)
+    if constexpr (J + 1 < NB) tl_stash<NB, J + 1, NPF>(c, pfx, oth);
+    if constexpr (J + 2 < NB) tl_fetch<NB, J + 2, NPF>(c, pfy);
+    const double* op = cur + c.pr * PP + 4 * c.fk;
+    const double2 dlo = *reinterpret_cast<const double2*>(op), dhi = *reinterpret_cast<const double2*>(op + 2);
+    const v4f64 d = v4f64{dlo.x, dlo.y, dhi.x, dhi.y};
+    v4f64 Z = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(d[s2], acc[J][s2], Z, 0, 0, 0);
+    acc[J] = Z;
+    const v4f64 Zn = -Z;
+#pragma unroll
+    for (int i = J + 1; i < NB; ++i) {
+      const double2 lo = *reinterpret_cast<const double2*>(op + (i - J) * TL_TILE), hi = *reinterpret_cast<const double2*>(op + (i - J) * TL_TILE + 2);
+      const v4f64 l = v4f64{lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(l[s2], Zn[s2], acc[i], 0, 0, 0);
+    }
+    tl_steps<NB, J + 1, NPF>(c, acc, pfy, pfx, stage);
+  }
+}
+template <int NB>
+COV_DEV void trsm_lds_body(const TrsmSubArgs& g, double* stage) {
+  const int batch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, fk = lane >> 4;
+  const int row0 = g.r0 + PB * (TL_WAVES * (int)blockIdx.x + wave);
+  const bool slab_on = row0 < g.r1;              // the last workgroup of a row range may hold fewer than four slabs (it still loads and syncs)
+  if (g.chain) __builtin_amdgcn_s_setprio(3);
+  TlCtx c;
+  c.Mb = g.M + (g.btab != nullptr ? (size_t)g.btab[2 * batch] : (size_t)batch * g.bsM);
+  c.ld = g.btab != nullptr ? (size_t)g.btab[2 * batch + 1] : g.ld;
+  c.Db = g.Dinv + (size_t)batch * g.bsL;
+  c.k0 = g.k0; c.tid = tid; c.fk = fk;
+  c.pr = 4 * (n & 3) + (n >> 2);  // logical row carried by A-operand lane n
+  double* Arow = c.Mb + (size_t)(row0 + n) * c.ld + g.k0 + 4 * fk;
+  constexpr int NPF = (NB * 128 + 255) / 256;     // 16-byte pieces per thread of block column 0 (the longest)
+  v2f64 pfa[NPF], pfb[NPF];
+  tl_fetch<NB, 0, NPF>(c, pfa);
+  if constexpr (NB > 1) tl_fetch<NB, 1, NPF>(c, pfb);
+  v4f64 acc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) acc[i] = slab_on ? *reinterpret_cast<const v4f64*>(Arow + PB * i) : v4f64{0.0, 0.0, 0.0, 0.0};
+  tl_stash<NB, 0, NPF>(c, pfa, stage);
+  tl_steps<NB, 0, NPF>(c, acc, pfb, pfa, stage);
+  if (!slab_on) return;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) *reinterpret_cast<v4f64*>(Arow + PB * i) = acc[i];
+  if (g.rhs != nullptr) {  // rhs[row0 + n] -= sum_k X[n][k] y[k]: lane partial, fixed butterfly over the four lanes sharing n
+    const double* yv = g.yvec + (size_t)batch * g.bsR + g.k0 + 4 * fk;
+    double part = 0.0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const v4f64 y4 = *reinterpret_cast<const v4f64*>(yv + PB * i);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) part += acc[i][s2] * y4[s2];
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (fk == 0) g.rhs[(size_t)batch * g.bsR + row0 + n] -= part;
+  }
+}
+template <int NB>
+__global__ __launch_bounds__(64 * TL_WAVES) void k_trsm_lds(TrsmSubArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double tl_stage[];   // [2][NB][16][PP]
+  const int batch = blockIdx.y;
+  if (g.live != nullptr) {  // (workgroup-uniform: a workgroup's 64 rows lie inside one 128-row tile)
+    const int nI = g.live[2 * batch], nO = g.live[2 * batch + 1];
+    const int tp = g.k0 / kTile, tr = (g.r0 + PB * TL_WAVES * (int)blockIdx.x) / kTile;
+    if (!(tp < nI || (tp >= g.tI && tp - g.tI < nO))) return;
+    if (!(tr < nI || (tr >= g.tI && tr - g.tI < nO))) return;
+  }
+  if (g.own != nullptr) {
+    const int real = g.own[batch] - g.k0;
+    if (real <= 0) return;
+    const int nbf = (real + PB - 1) / PB;
+    if (NB > 4 && nbf <= 4) { trsm_lds_body<4>(g, tl_stage); return; }
+    if (NB > 8 && nbf <= 8) { trsm_lds_body<8>(g, tl_stage); return; }
+    if (NB > 12 && nbf <= 12) { trsm_lds_body<12>(g, tl_stage); return; }
+  }
+  trsm_lds_body<NB>(g, tl_stage);
 }
 
 // Backward substitution step for tile p with the 16x16 block inverses (Dinv == nullptr: x_p is given):
@@ -781,10 +912,26 @@ void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* 
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
                      size_t sR, const int* live, int tI, hipStream_t st, bool chain, const long long* btab, int nb, const int* own) {
   if (r1 <= r0 || nb == 0) return;
-  TrsmSubArgs g{S, ld, t0 * kTile, r0 * kTile, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, live, tI, chain ? 1 : 0, btab, own};
+  TrsmSubArgs g{S, ld, t0 * kTile, r0 * kTile, r1 * kTile, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, live, tI, chain ? 1 : 0, btab, own};
   const dim3 grid((r1 - r0) * (kTile / PB), nbt);
   // nb: 16-column blocks of the panel that hold real columns (the rest is identity padding with zeros below: X = A there)
   const int need = nb > 0 ? std::min(nb, 8 * w) : 8 * w;
+  static const bool lds_form = getenv("COVGPU_TRSM_LDS") == nullptr || atoi(getenv("COVGPU_TRSM_LDS")) != 0;
+  if (lds_form) {   // four slabs per workgroup, the factor streamed through LDS (k_trsm_lds)
+    const dim3 g4((r1 - r0) * (kTile / PB) / TL_WAVES, nbt);
+    auto lds = [](int NBv) { return (size_t)2 * NBv * TL_TILE * sizeof(double); };
+    static bool once = [&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_lds<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(16));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_lds<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(12));
+      return true;
+    }();
+    (void)once;
+    if (need <= 4) hipLaunchKernelGGL(k_trsm_lds<4>, g4, dim3(64 * TL_WAVES), lds(4), st, g);
+    else if (need <= 8) hipLaunchKernelGGL(k_trsm_lds<8>, g4, dim3(64 * TL_WAVES), lds(8), st, g);
+    else if (need <= 12) hipLaunchKernelGGL(k_trsm_lds<12>, g4, dim3(64 * TL_WAVES), lds(12), st, g);
+    else hipLaunchKernelGGL(k_trsm_lds<16>, g4, dim3(64 * TL_WAVES), lds(16), st, g);
+    return;
+  }
   if (need <= 4) hipLaunchKernelGGL(k_trsm_sub<4>, grid, dim3(64), 0, st, g);
   else if (need <= 8) hipLaunchKernelGGL(k_trsm_sub<8>, grid, dim3(64), 0, st, g);
   else if (need <= 12) hipLaunchKernelGGL(k_trsm_sub<12>, grid, dim3(64), 0, st, g);

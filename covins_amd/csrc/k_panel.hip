@@ -32,7 +32,6 @@
 namespace covgpu {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 #ifdef COVGPU_PROBE
 __device__ long long g_pprobe[8];
@@ -55,6 +54,14 @@ constexpr int PROWS = 256;
 constexpr int NTW = 7;                 // tile-owning waves (waves 1..7; wave 0 carries the serial chain)
 constexpr int NSLOT = 18;              // 119 / 7 rounded up to even: tiles (i, k), 1 <= k <= i <= 15 except (1,1), column-major, dealt round-robin
 constexpr size_t kPanelLds = (size_t)(2 * PROWS * PP + 256 + 256 + 48 + 16 * PP + 16) * sizeof(double);
+
+// device-scope (cross-XCD coherent, L2-bypassing) accesses for data that another workgroup of a concurrently running launch picks up
+// behind a flag (the panel pipeline below; k_bwd_front uses the same idiom): no fences — a device-scope fence writes back and
+// invalidates the XCD's whole L2 under everybody else
+COV_DEV void st_dev(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+COV_DEV double ld_dev(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+COV_DEV v4f64 ld_dev4(const double* p) { return v4f64{ld_dev(p), ld_dev(p + 1), ld_dev(p + 2), ld_dev(p + 3)}; }
+COV_DEV void st_dev4(double* p, v4f64 v) { st_dev(p, v[0]); st_dev(p + 1, v[1]); st_dev(p + 2, v[2]); st_dev(p + 3, v[3]); }
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL store to be
 // acknowledged (s_waitcnt vmcnt(0): ~1 us per step here, where L / Dinv / y stream out while the factorisation goes on
@@ -117,9 +124,13 @@ COV_DEV void tile_update2(v4f64& c0, v4f64& c1, const double* pan, const double*
 // The rest of the panel is X_ij = T_ij Dinv_j^T, 4 MFMAs per tile. (Round 1 found the product with a 128x128 explicit inverse
 // too inaccurate for this system; a 16x16 block inverse formed by substitution is the standard blocked-TRSM building block
 // and tests/test_gpu_parity.py::test_mfma_cholesky_ill_conditioned_blocks and the full-size parity tests hold with it.)
+// PUB (the panel pipeline, k_panel_follow below): everything a follower needs of block column j — L below the diagonal block,
+// Dinv_j, y_j — leaves through device-scope stores, and pub[front] = pbase + j + 1 is raised once all of it has been acknowledged:
+// at the barrier of step j + 1, where the storing waves idle anyway while wave 0 factors the next diagonal block.
+template <bool PUB>
 __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
                                                       const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR,
-                                                      const long long* __restrict__ btab) {
+                                                      const long long* __restrict__ btab, int* __restrict__ pub, int pbase) {
   if (btab != nullptr) { M += (size_t)btab[2 * blockIdx.x]; ld = (size_t)btab[2 * blockIdx.x + 1]; }  // fronts of unequal order (GemmArgs::btab)
   else M += (size_t)blockIdx.x * bsM;
   Dinv_out += (size_t)blockIdx.x * bsL;
@@ -206,6 +217,7 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
     if (wave == 0) {
       // ---- (a): factor the diagonal block and form its inverse
       __builtin_amdgcn_s_setprio(3);
+      if (PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Dinv of the previous step (stored a whole step ago: no stall) is out before this step's barrier publishes it
       // lane id from the hardware (v_mbcnt): per-lane invariants of this block are recomputed every step rather than hoisted and
       // spilled — a reload from scratch at the head of every step costs the chain a memory latency
       const int ln = hw_lane_id();
@@ -270,12 +282,14 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
         asm volatile("" : "+v"(lv), "+v"(xv));  // selects, not a branch around the stores
         cur[(o + r) * PP + 4 * q + e] = lv;
         sDv[r * PB + 4 * q + e] = xv;
-        dst[e] = xv;
+        if (PUB) st_dev(dst + e, xv); else dst[e] = xv;
       }
       __builtin_amdgcn_s_setprio(0);
       PPROBE_ACC(5, tq0);
     }
+    if (PUB && wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // block column j - 1 (L, y) is out: these waves idle here for wave 0 anyway
     lds_barrier();  // ---- X(j): L_jj, Dinv_j in LDS; block column j complete in `cur`; trailing tiles carry panels < j
+    if (PUB && tid == 64 && j > 0) __hip_atomic_store(pub + blockIdx.x, pbase + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // block columns < j are complete in memory
     PPROBE_ACC(1, tq0);
     const long long tq1 = PPROBE_T0();
     if (wave == 0) {
@@ -368,7 +382,11 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
           const double2* src = reinterpret_cast<const double2*>(cur + row * PP + 8 * (u & 1));
           double2* dst = reinterpret_cast<double2*>(Mg + (size_t)row * ld + o + 8 * (u & 1));
           const double2 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-          dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+          if (PUB) {
+            double* d8 = reinterpret_cast<double*>(dst);
+            st_dev(d8, v0.x); st_dev(d8 + 1, v0.y); st_dev(d8 + 2, v1.x); st_dev(d8 + 3, v1.y);
+            st_dev(d8 + 4, v2.x); st_dev(d8 + 5, v2.y); st_dev(d8 + 6, v3.x); st_dev(d8 + 7, v3.y);
+          } else { dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3; }
         }
         if (u < 256) {
           const int rr = u >> 4, cc = u & 15;
@@ -383,11 +401,16 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
           }
           sRhs[col] -= (t0 + t1) + (t2 + t3);
         }
-        if (yout != nullptr && u >= 384 && u < 384 + PB) yout[k0 + o + u - 384] = sRhs[o + u - 384];
+        if (yout != nullptr && u >= 384 && u < 384 + PB) { if (PUB) st_dev(yout + k0 + o + u - 384, sRhs[o + u - 384]); else yout[k0 + o + u - 384] = sRhs[o + u - 384]; }
       }
       PPROBE_ACC(7, tq3);
     }
     PPROBE_ACC(3, tq2);
+  }
+  if (PUB) {   // the last block column
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid0 == 64) __hip_atomic_store(pub + blockIdx.x, pbase + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   PPROBE_FLUSH();
 }
@@ -396,7 +419,6 @@ struct TrsmSubArgs {
   double* M; size_t ld;
   int k0;                 // first column of the panel
   int r0;                 // first row (multiple of 16); workgroup x handles rows r0 + 16 x ..
-  int r1;                 // end of the row range (k_trsm_lds: a workgroup's last slabs may lie beyond it)
   const double* Dinv;     // block inverses of the panel's first tile (second tile 128*128 further)
   double* rhs; const double* yvec;   // forward substitution riding along: rhs[rows] -= X[rows, :] y[k0 ..)
   size_t bsM, bsL, bsR;
@@ -494,133 +516,174 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   trsm_sub_body<NB>(g);
 }
 
-// The same substitution, four slabs per workgroup with the factor streamed through LDS. k_trsm_sub's one-wave slab pulls the
-// whole 256x256 factor (136 tiles of 2 KB) through its own registers, a few tiles ahead: ~25 us of load latency around ~3 us of
-// matrix-core work — on the serial chain of EVERY panel (rows of the next panel in a multi-panel front, all rows below in a
-// single-panel one). Here the 256 threads of a workgroup fetch block column j + 2 (its Dinv block and the L tiles below it,
-// coalesced 16-byte loads, registers) while block column j + 1 moves from registers to the other LDS stage and the four waves
-// run step j out of LDS: a memory latency is spread over two to three steps, and the factor is read once per 64 rows instead
-// of once per 16. Same MFMA sequence per slab as k_trsm_sub: bit-identical results.
-constexpr int TL_WAVES = 4;                      // slabs per workgroup
-constexpr int TL_TILE = PB * PP;                 // one 16x16 tile at pitch PP (conflict-free 32-byte operand reads)
-struct TlCtx {
-  double* Mb; const double* Db; size_t ld; int k0, tid, pr, fk;
+// (Measured and dropped, round 4 — both bit-identical to this kernel: (i) four slabs per workgroup with the factor streamed through LDS
+//  by block columns, two block columns ahead: 36 us instead of 25 on the chain, a two-step prefetch distance does not cover a memory
+//  latency and every step then pays one; (ii) this kernel with a ring of TWENTY tiles and one wave per SIMD: no change at all — the slab
+//  is bound by its 544 dependent-issue MFMAs on one SIMD (16 Z chains of four dependent instructions each), not by the tile loads.)
+// ---------------------------------------------------------------------------------------------------------------------------
+// The panel pipeline of a multi-panel front (the root of the elimination tree: 8 of the 15 serial panels of the 5-agent map).
+// Per panel the chain was  potrf (88 us)  ->  substitution of the NEXT panel's 256 rows (25 us)  ->  rank-256 update of the next
+// diagonal block (15 us)  -> potrf ..., three dependent launches with their gaps: ~150 us. But block column j of the factor is final
+// after step j of the 16-step potrf, the substitution's step j needs nothing else, and the diagonal update is a sum over block
+// columns of X_j X_j^T: both can run in LOCK STEP behind the factorisation instead of after it. k_panel_follow is launched beside
+// k_potrf_panel<PUB> (another stream) and follows it through device-scope flags:
+//   workgroups 0..3   one wave per 16-row slab of the next panel's rows: step j waits for pub[front] > j (block column j of L,
+//                     Dinv_j and y_j are in memory), forms X_j = its block of the solved rows, stores it device-scope and raises
+//                     slab[front][s] = j + 1, then applies L(j+1.., j) to its remaining blocks (k_trsm_sub's arithmetic)
+//   workgroups 4..7   sixteen waves own the 136 lower 16x16 tiles of the next diagonal block in accumulator registers; step j waits
+//                     for all sixteen slabs and subtracts X_a,j X_b,j^T
+// Nobody the producer depends on ever waits for a consumer (potrf waits for nobody; the slabs wait for potrf only; the update waits
+// for the slabs only), so a late or descheduled consumer only delays itself; every spin is bounded (flag bit 2 -> the solve is
+// reported as failed, the wave leaves). Flags only grow: a launch uses the values pbase + 1 .. pbase + 16 of its epoch.
+// MEASURED, NOT ADOPTED (opt-in COVGPU_PIPE=1; tests/test_gpu_schedule.py holds it to the default's results): correct, but a root
+// panel takes ~250 us instead of 159. Two reasons. (i) A device-scope load or store acknowledgement costs ~4 us here, so a follower
+// step (one round of operand loads, one store) barely fits the 5.5 us the factorisation spends per block column: it cannot catch up.
+// (ii) It cannot START with the factorisation either: the rows it solves carry the look-ahead update of the panel before, which
+// trails that panel's rest-row substitution on another stream (~70 us). Following from the start would need the follower to carry
+// the rows of TWO panels ahead and both their updates (twice the registers and device-scope traffic) — left as a sketch.
+struct FollowArgs {
+  double* M; size_t ld;
+  int k0;                 // first column of the panel being factored
+  int r0;                 // first of the 256 rows that follow it (the next panel's rows)
+  int nb;                 // block columns the factorisation runs (steps)
+  const double* Dinv; double* rhs; const double* yvec;
+  size_t bsM, bsL, bsR; const long long* btab;
+  const int* live; int tI;
+  const int* pub; int* slab; int pbase; int* flag;
+  const int* bulk; int bulk_target;   // bulk[0] >= bulk_target: the previous panel's bulk update (another stream) has written the diagonal block this launch updates (0: nothing to wait for)
 };
-// cooperative fetch of block column J: tile 0 = Dinv_J, tiles 1 .. NB-1-J = L(J+1.., J); a thread takes 16-byte pieces, piece q ->
-// tile q >> 7, row (q >> 3) & 15, doubles 2 (q & 7) .. (the last piece index is clamped: unconditional loads, no divergent branch)
-template <int NB, int J, int NPF>
-COV_DEV void tl_fetch(const TlCtx& c, v2f64 (&pf)[NPF]) {
-  constexpr int np = (NB - J) * 128;
-#pragma unroll
-  for (int it = 0; it < NPF; ++it) {
-    if (256 * it < np) {
-      const int q = min(c.tid + 256 * it, np - 1);
-      const int t = q >> 7, rr = (q >> 3) & 15, c2 = (q & 7) * 2;
-      const double* src = (t == 0) ? c.Db + (size_t)(J >> 3) * kTile * kTile + (size_t)(J & 7) * 256 + rr * PB + c2
-                                   : c.Mb + (size_t)(c.k0 + PB * (J + t) + rr) * c.ld + c.k0 + PB * J + c2;
-      pf[it] = *reinterpret_cast<const v2f64*>(src);
-    }
-  }
-}
-template <int NB, int J, int NPF>
-COV_DEV void tl_stash(const TlCtx& c, const v2f64 (&pf)[NPF], double* st) {
-  constexpr int np = (NB - J) * 128;
-#pragma unroll
-  for (int it = 0; it < NPF; ++it) {
-    const int q = c.tid + 256 * it;
-    if (256 * it < np && q < np) {
-      const int t = q >> 7, rr = (q >> 3) & 15, c2 = (q & 7) * 2;
-      *reinterpret_cast<v2f64*>(st + t * TL_TILE + rr * PP + c2) = pf[it];
-    }
-  }
-}
-// steps J .. NB-1 of the block substitution (compile-time recursion: every register index is a constant). On entry block column J
-// is in flight to / in stage J & 1 and `pfx` holds block column J + 1 (pfy is free).
-template <int NB, int J, int NPF>
-COV_DEV void tl_steps(const TlCtx& c, v4f64 (&acc)[NB], v2f64 (&pfx)[NPF], v2f64 (&pfy)[NPF], double* stage) {
-  if constexpr (J < NB) {
-    double* cur = stage + (J & 1) * NB * TL_TILE;
-    double* oth = stage + ((J + 1) & 1) * NB * TL_TILE;
-    lds_barrier();                                // column J is in `cur`; everybody has finished reading `oth` (step J - 1)
-    if constexpr (J + 1 < NB) tl_stash<NB, J + 1, NPF>(c, pfx, oth);
-    if constexpr (J + 2 < NB) tl_fetch<NB, J + 2, NPF>(c, pfy);
-    const double* op = cur + c.pr * PP + 4 * c.fk;
-    const double2 dlo = *reinterpret_cast<const double2*>(op), dhi = *reinterpret_cast<const double2*>(op + 2);
-    const v4f64 d = v4f64{dlo.x, dlo.y, dhi.x, dhi.y};
-    v4f64 Z = v4f64{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(d[s2], acc[J][s2], Z, 0, 0, 0);
-    acc[J] = Z;
-    const v4f64 Zn = -Z;
-#pragma unroll
-    for (int i = J + 1; i < NB; ++i) {
-      const double2 lo = *reinterpret_cast<const double2*>(op + (i - J) * TL_TILE), hi = *reinterpret_cast<const double2*>(op + (i - J) * TL_TILE + 2);
-      const v4f64 l = v4f64{lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(l[s2], Zn[s2], acc[i], 0, 0, 0);
-    }
-    tl_steps<NB, J + 1, NPF>(c, acc, pfy, pfx, stage);
-  }
-}
 template <int NB>
-COV_DEV void trsm_lds_body(const TrsmSubArgs& g, double* stage) {
-  const int batch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, fk = lane >> 4;
-  const int row0 = g.r0 + PB * (TL_WAVES * (int)blockIdx.x + wave);
-  const bool slab_on = row0 < g.r1;              // the last workgroup of a row range may hold fewer than four slabs (it still loads and syncs)
-  if (g.chain) __builtin_amdgcn_s_setprio(3);
-  TlCtx c;
-  c.Mb = g.M + (g.btab != nullptr ? (size_t)g.btab[2 * batch] : (size_t)batch * g.bsM);
-  c.ld = g.btab != nullptr ? (size_t)g.btab[2 * batch + 1] : g.ld;
-  c.Db = g.Dinv + (size_t)batch * g.bsL;
-  c.k0 = g.k0; c.tid = tid; c.fk = fk;
-  c.pr = 4 * (n & 3) + (n >> 2);  // logical row carried by A-operand lane n
-  double* Arow = c.Mb + (size_t)(row0 + n) * c.ld + g.k0 + 4 * fk;
-  constexpr int NPF = (NB * 128 + 255) / 256;     // 16-byte pieces per thread of block column 0 (the longest)
-  v2f64 pfa[NPF], pfb[NPF];
-  tl_fetch<NB, 0, NPF>(c, pfa);
-  if constexpr (NB > 1) tl_fetch<NB, 1, NPF>(c, pfb);
+COV_DEV void follow_slab(const FollowArgs& g, int batch, int slab, double* Mb, size_t ld) {
+  const int lane = threadIdx.x & 63, n = lane & 15, fk = lane >> 4;
+  const int row0 = g.r0 + PB * slab;
+  const double* Db = g.Dinv + (size_t)batch * g.bsL;
+  const int pr = 4 * (n & 3) + (n >> 2);  // logical row carried by A-operand lane n
+  double* Arow = Mb + (size_t)(row0 + n) * ld + g.k0 + 4 * fk;
+  const double* Lrow = Mb + (size_t)(g.k0 + pr) * ld + g.k0 + 4 * fk;
+  const double* Drow = Db + pr * PB + 4 * fk;
   v4f64 acc[NB];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) acc[i] = slab_on ? *reinterpret_cast<const v4f64*>(Arow + PB * i) : v4f64{0.0, 0.0, 0.0, 0.0};
-  tl_stash<NB, 0, NPF>(c, pfa, stage);
-  tl_steps<NB, 0, NPF>(c, acc, pfb, pfa, stage);
-  if (!slab_on) return;
+  for (int i = 0; i < NB; ++i) acc[i] = *reinterpret_cast<const v4f64*>(Arow + PB * i);
+  __builtin_amdgcn_s_setprio(3);
+  // One memory latency per step while the follower keeps pace: the progress flag is re-read TOGETHER with the operands of a step
+  // (it decides whether the next step has to poll at all), and X_j is published one step late, behind the next step's loads (a
+  // device-scope store is acknowledged by then: no wait of its own on this chain).
+  int seen = __hip_atomic_load(g.pub + batch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-  for (int i = 0; i < NB; ++i) *reinterpret_cast<v4f64*>(Arow + PB * i) = acc[i];
-  if (g.rhs != nullptr) {  // rhs[row0 + n] -= sum_k X[n][k] y[k]: lane partial, fixed butterfly over the four lanes sharing n
+  for (int j = 0; j < NB; ++j) {
+    if (j < g.nb) {   // (wave-uniform)
+      for (int it = 0; seen < g.pbase + j + 1; ++it) {
+        __builtin_amdgcn_s_sleep(2);
+        seen = __hip_atomic_load(g.pub + batch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (it > (1 << 20)) { if (lane == 0) atomicOr(g.flag, 2); return; }   // (never observed; a bounded spin cannot hang the device)
+      }
+      const v4f64 d = ld_dev4(Drow + (size_t)(j >> 3) * kTile * kTile + (j & 7) * 256);
+      v4f64 lt[NB];
+#pragma unroll
+      for (int i = j + 1; i < NB; ++i) if (i < g.nb) lt[i] = ld_dev4(Lrow + (size_t)(PB * i) * ld + PB * j);
+      const int nxt = __hip_atomic_load(g.pub + batch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the operands are here, and the store of X_(j-1) (older than all of them) is acknowledged
+      if (j > 0 && lane == 0) __hip_atomic_store(g.slab + 16 * batch + slab, g.pbase + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      seen = nxt;
+      v4f64 Z = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(d[s2], acc[j][s2], Z, 0, 0, 0);
+      acc[j] = Z;
+      st_dev4(Arow + PB * j, Z);
+      const v4f64 Zn = -Z;
+#pragma unroll
+      for (int i = j + 1; i < NB; ++i)
+        if (i < g.nb) {
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[i][s2], Zn[s2], acc[i], 0, 0, 0);
+        }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(g.slab + 16 * batch + slab, g.pbase + g.nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (g.rhs != nullptr) {  // rhs[row0 + n] -= sum_k X[n][k] y[k] (y of the padding block columns is zero)
     const double* yv = g.yvec + (size_t)batch * g.bsR + g.k0 + 4 * fk;
     double part = 0.0;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const v4f64 y4 = *reinterpret_cast<const v4f64*>(yv + PB * i);
+    for (int i = 0; i < NB; ++i)
+      if (i < g.nb) {
+        const v4f64 y4 = ld_dev4(yv + PB * i);
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) part += acc[i][s2] * y4[s2];
-    }
+        for (int s2 = 0; s2 < 4; ++s2) part += acc[i][s2] * y4[s2];
+      }
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
     if (fk == 0) g.rhs[(size_t)batch * g.bsR + row0 + n] -= part;
   }
 }
+COV_DEV void follow_update(const FollowArgs& g, int batch, int wr, double* Mb, size_t ld) {
+  const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+  constexpr int NT = 9;   // 136 lower tiles of the 256x256 diagonal block over 16 waves
+  int ta[NT], tb[NT];
+  v4f64 acc[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const int t = wr + 16 * k;
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= t) ++a;
+    ta[k] = t < 136 ? a : -1; tb[k] = t - a * (a + 1) / 2;
+    acc[k] = v4f64{0.0, 0.0, 0.0, 0.0};   // (the block itself is read at the END: its previous writer may still be running)
+  }
+  auto slabs_done = [&]() {   // block columns of X every one of the sixteen slabs has published
+    int v = lane < 16 ? __hip_atomic_load(g.slab + 16 * batch + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return __builtin_amdgcn_readfirstlane(v) - g.pbase;
+  };
+  int ready = slabs_done();
+  for (int j = 0; j < g.nb; ++j) {
+    for (int it = 0; ready < j + 1; ++it) {
+      __builtin_amdgcn_s_sleep(2);
+      ready = slabs_done();
+      if (it > (1 << 20)) { if (lane == 0) atomicOr(g.flag, 2); return; }
+    }
+    const double* Xc = Mb + (size_t)(g.r0 + fr) * ld + g.k0 + PB * j + 4 * fk;
+    v4f64 xa[NT], xb[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+      if (ta[k] >= 0) { xa[k] = ld_dev4(Xc + (size_t)(PB * ta[k]) * ld); xb[k] = ld_dev4(Xc + (size_t)(PB * tb[k]) * ld); }   // (wave-uniform)
+    ready = slabs_done();   // (re-read with the operands: decides whether the next step polls)
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+      if (ta[k] >= 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[k][s2], xb[k][s2], acc[k], 0, 0, 0);
+      }
+  }
+  // the diagonal block += what was gathered, once its previous writer — the bulk update of the panel before, on its own stream — is done
+  for (int it = 0; g.bulk_target > 0 && __hip_atomic_load(g.bulk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.bulk_target; ++it) {
+    __builtin_amdgcn_s_sleep(4);
+    if (it > (1 << 20)) { if (lane == 0) atomicOr(g.flag, 2); return; }
+  }
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+    if (ta[k] >= 0) {
+      double* dst = Mb + (size_t)(g.r0 + PB * ta[k] + fk) * ld + g.r0 + PB * tb[k] + fr;
+      double v[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) v[rg] = ld_dev(dst + (size_t)(4 * rg) * ld);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) dst[(size_t)(4 * rg) * ld] = v[rg] + acc[k][rg];
+    }
+}
+__global__ void k_flag_set(int* p, int v) { if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+void launch_flag_set(int* p, int v, hipStream_t st) { hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, st, p, v); }
 template <int NB>
-__global__ __launch_bounds__(64 * TL_WAVES) void k_trsm_lds(TrsmSubArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double tl_stage[];   // [2][NB][16][PP]
-  const int batch = blockIdx.y;
-  if (g.live != nullptr) {  // (workgroup-uniform: a workgroup's 64 rows lie inside one 128-row tile)
-    const int nI = g.live[2 * batch], nO = g.live[2 * batch + 1];
-    const int tp = g.k0 / kTile, tr = (g.r0 + PB * TL_WAVES * (int)blockIdx.x) / kTile;
-    if (!(tp < nI || (tp >= g.tI && tp - g.tI < nO))) return;
-    if (!(tr < nI || (tr >= g.tI && tr - g.tI < nO))) return;
+__global__ __launch_bounds__(256) void k_panel_follow(FollowArgs g) {
+  const int batch = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (g.live != nullptr) {  // a front whose interior does not reach this panel / the next one: identity padding, nothing to follow
+    const int nI = g.live[2 * batch];
+    if (!(g.k0 / kTile < nI) || !(g.r0 / kTile < nI)) return;
   }
-  if (g.own != nullptr) {
-    const int real = g.own[batch] - g.k0;
-    if (real <= 0) return;
-    const int nbf = (real + PB - 1) / PB;
-    if (NB > 4 && nbf <= 4) { trsm_lds_body<4>(g, tl_stage); return; }
-    if (NB > 8 && nbf <= 8) { trsm_lds_body<8>(g, tl_stage); return; }
-    if (NB > 12 && nbf <= 12) { trsm_lds_body<12>(g, tl_stage); return; }
-  }
-  trsm_lds_body<NB>(g, tl_stage);
+  double* Mb = g.M + (g.btab != nullptr ? (size_t)g.btab[2 * batch] : (size_t)batch * g.bsM);
+  const size_t ld = g.btab != nullptr ? (size_t)g.btab[2 * batch + 1] : g.ld;
+  if (blockIdx.x < 4) follow_slab<NB>(g, batch, 4 * (int)blockIdx.x + wave, Mb, ld);
+  else follow_update(g, batch, 4 * ((int)blockIdx.x - 4) + wave, Mb, ld);
 }
 
 // Backward substitution step for tile p with the 16x16 block inverses (Dinv == nullptr: x_p is given):
@@ -897,41 +960,41 @@ void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, dou
 }
 
 void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
-                        hipStream_t st, const long long* btab, int nb) {
+                        hipStream_t st, const long long* btab, int nb, int* pub, int pbase) {
   if (nb < 0) nb = 8 * w;
   if (nb == 0) return;  // an all-padding panel of every front of the batch: L = I, Dinv = I, y = 0 are in place
   static bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds);
     return true;
   }();
   (void)once;
-  hipLaunchKernelGGL(k_potrf_panel, dim3(nbt), dim3(512), kPanelLds, st, S, ld, t0 * kTile, nb, Linv + (size_t)t0 * kTile * kTile, flag,
-                     (const double*)b, b ? b + npad : nullptr, sM, sL, sR, btab);
+  if (pub != nullptr)
+    hipLaunchKernelGGL(k_potrf_panel<true>, dim3(nbt), dim3(512), kPanelLds, st, S, ld, t0 * kTile, nb, Linv + (size_t)t0 * kTile * kTile, flag,
+                       (const double*)b, b ? b + npad : nullptr, sM, sL, sR, btab, pub, pbase);
+  else
+    hipLaunchKernelGGL(k_potrf_panel<false>, dim3(nbt), dim3(512), kPanelLds, st, S, ld, t0 * kTile, nb, Linv + (size_t)t0 * kTile * kTile, flag,
+                       (const double*)b, b ? b + npad : nullptr, sM, sL, sR, btab, (int*)nullptr, 0);
+}
+// the follower of a published panel factorisation (k_panel_follow): substitution of the 256 rows from tile row t0 + 2 and the rank
+// update of the diagonal block they meet, in lock step behind k_potrf_panel<PUB> running on another stream
+void launch_panel_follow(double* S, size_t ld, int t0, const double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
+                         hipStream_t st, const long long* btab, const int* live, int tI, int nb, const int* pub, int* slab, int pbase, const int* bulk, int bulk_target) {
+  FollowArgs g{S, ld, t0 * kTile, (t0 + 2) * kTile, nb, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, btab, live, tI, pub, slab, pbase, flag, bulk, bulk_target};
+  const dim3 grid(8, nbt);
+  if (nb <= 4) hipLaunchKernelGGL(k_panel_follow<4>, grid, dim3(256), 0, st, g);
+  else if (nb <= 8) hipLaunchKernelGGL(k_panel_follow<8>, grid, dim3(256), 0, st, g);
+  else if (nb <= 12) hipLaunchKernelGGL(k_panel_follow<12>, grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL(k_panel_follow<16>, grid, dim3(256), 0, st, g);
 }
 
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
                      size_t sR, const int* live, int tI, hipStream_t st, bool chain, const long long* btab, int nb, const int* own) {
   if (r1 <= r0 || nb == 0) return;
-  TrsmSubArgs g{S, ld, t0 * kTile, r0 * kTile, r1 * kTile, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, live, tI, chain ? 1 : 0, btab, own};
+  TrsmSubArgs g{S, ld, t0 * kTile, r0 * kTile, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, live, tI, chain ? 1 : 0, btab, own};
   const dim3 grid((r1 - r0) * (kTile / PB), nbt);
   // nb: 16-column blocks of the panel that hold real columns (the rest is identity padding with zeros below: X = A there)
   const int need = nb > 0 ? std::min(nb, 8 * w) : 8 * w;
-  static const bool lds_form = getenv("COVGPU_TRSM_LDS") == nullptr || atoi(getenv("COVGPU_TRSM_LDS")) != 0;
-  if (lds_form) {   // four slabs per workgroup, the factor streamed through LDS (k_trsm_lds)
-    const dim3 g4((r1 - r0) * (kTile / PB) / TL_WAVES, nbt);
-    auto lds = [](int NBv) { return (size_t)2 * NBv * TL_TILE * sizeof(double); };
-    static bool once = [&] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_lds<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(16));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_lds<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(12));
-      return true;
-    }();
-    (void)once;
-    if (need <= 4) hipLaunchKernelGGL(k_trsm_lds<4>, g4, dim3(64 * TL_WAVES), lds(4), st, g);
-    else if (need <= 8) hipLaunchKernelGGL(k_trsm_lds<8>, g4, dim3(64 * TL_WAVES), lds(8), st, g);
-    else if (need <= 12) hipLaunchKernelGGL(k_trsm_lds<12>, g4, dim3(64 * TL_WAVES), lds(12), st, g);
-    else hipLaunchKernelGGL(k_trsm_lds<16>, g4, dim3(64 * TL_WAVES), lds(16), st, g);
-    return;
-  }
   if (need <= 4) hipLaunchKernelGGL(k_trsm_sub<4>, grid, dim3(64), 0, st, g);
   else if (need <= 8) hipLaunchKernelGGL(k_trsm_sub<8>, grid, dim3(64), 0, st, g);
   else if (need <= 12) hipLaunchKernelGGL(k_trsm_sub<12>, grid, dim3(64), 0, st, g);

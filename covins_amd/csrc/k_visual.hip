@@ -306,82 +306,9 @@ __global__ __launch_bounds__(kPairLanes * kPairsPerWg) void k_pair_blocks(DevPro
   }
 }
 
-// The same blocks, one workgroup per KEYFRAME i (chain position pos): every pair (i, j < i) reads keyframe i's records, so the
-// workgroup stages them ONCE in LDS (<= 400 observations x 144 B = 57.6 KB on the EuRoC-shaped maps; records are keyframe-major:
-// one contiguous, coalesced read) and only the partner's records travel per common landmark: half the scattered 144-B reads of
-// k_pair_blocks (1.08 GB per iteration on the 5-agent map, none of them reused in the L2s by the counters). Pairs are sorted by
-// (i, j): kp_ptr[pos] .. kp_ptr[pos + 1] are keyframe i's. Same lanes-over-landmarks shape and the same fixed summation order per
-// block entry as k_pair_blocks (bit-identical results); the 36 partial sums go through LDS in two rounds of 18.
-__global__ __launch_bounds__(kPairLanes * kPairsPerWg) void k_pair_blocks_kf(DevProblem P, const int* __restrict__ kp_ptr) {
-  extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [kPairsPerWg][18][kPairLanes + 1] | records of keyframe i
-  double (*sp)[18][kPairLanes + 1] = reinterpret_cast<double (*)[18][kPairLanes + 1]>(s_dyn);
-  double* zi = s_dyn + kPairsPerWg * 18 * (kPairLanes + 1);
-  const int pos = blockIdx.x, p0 = kp_ptr[pos], p1 = kp_ptr[pos + 1];
-  if (p0 == p1) return;
-  const int kf = P.pos_kf[pos], slot0 = P.kf_obs_ptr[kf], nrec = P.kf_obs_ptr[kf + 1] - slot0;
-  {
-    const double2* src = reinterpret_cast<const double2*>(P.obsZ + 18 * (size_t)slot0);
-    double2* dst = reinterpret_cast<double2*>(zi);
-    for (int k = threadIdx.x; k < 9 * nrec; k += blockDim.x) dst[k] = src[k];
-  }
-  __syncthreads();
-  const int grp = threadIdx.x / kPairLanes, g = threadIdx.x % kPairLanes;
-  for (int pb = p0; pb < p1; pb += kPairsPerWg) {   // (uniform trip count: the barriers below are taken by every wave)
-    const int p = pb + grp;
-    const bool ok = p < p1;
-    const int e0 = ok ? P.pair_ptr[p] : 0, e1 = ok ? P.pair_ptr[p + 1] : 0;
-    double acc[36];
-#pragma unroll
-    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-    for (int e = e0 + g; e < e1; e += 2 * kPairLanes) {
-      const int e2 = e + kPairLanes;
-      const bool two = e2 < e1;
-      const double2* y = reinterpret_cast<const double2*>(zi + 18 * (P.pair_oa[e] - slot0));
-      const double2* w = reinterpret_cast<const double2*>(P.obsZ + 18 * (size_t)P.pair_ob[e]);
-      const double2* y2 = reinterpret_cast<const double2*>(zi + 18 * (P.pair_oa[two ? e2 : e] - slot0));
-      const double2* w2 = reinterpret_cast<const double2*>(P.obsZ + 18 * (size_t)P.pair_ob[two ? e2 : e]);
-      double yv[18], wv[18], yu[18], wu[18];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const double2 b2 = w[k], d2 = w2[k];
-        wv[2 * k] = b2.x; wv[2 * k + 1] = b2.y; wu[2 * k] = d2.x; wu[2 * k + 1] = d2.y;
-      }
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const double2 a2 = y[k], c2 = y2[k];
-        yv[2 * k] = a2.x; yv[2 * k + 1] = a2.y; yu[2 * k] = c2.x; yu[2 * k + 1] = c2.y;
-      }
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) acc[6 * r + c] += yv[3 * r] * wv[3 * c] + yv[3 * r + 1] * wv[3 * c + 1] + yv[3 * r + 2] * wv[3 * c + 2];
-      if (two) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-          for (int c = 0; c < 6; ++c) acc[6 * r + c] += yu[3 * r] * wu[3 * c] + yu[3 * r + 1] * wu[3 * c + 1] + yu[3 * r + 2] * wu[3 * c + 2];
-      }
-    }
-    const int pi = ok ? P.pair_i[p] : 0, pj = ok ? P.pair_j[p] : 0;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      __syncthreads();   // the previous round's sums have been read
-#pragma unroll
-      for (int k = 0; k < 18; ++k) sp[grp][k][g] = acc[18 * half + k];
-      __syncthreads();
-      if (ok) {
-        for (int k = g; k < 18; k += kPairLanes) {
-          double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-          for (int t = 0; t < kPairLanes; t += 2) { a0 += sp[grp][k][t]; a1 += sp[grp][k][t + 1]; }
-          const int kk = 18 * half + k;
-          *c_entry(P, pi, pj, kk / 6, kk % 6) = -(a0 + a1);
-        }
-      }
-    }
-  }
-}
-
+// (Measured and dropped, round 4: one workgroup per keyframe i with i's records staged once in LDS (57.6 KB) so that only the partner's
+//  records travel per common landmark — bit-identical, half the scattered reads, and SLOWER: 0.52 instead of 0.27 ms. One or two
+//  workgroups per CU (77 KB of LDS each) cannot keep enough partner reads in flight; eight waves per CU with every read in flight can.)
 // back-substitution: dl = Hinv (-g_l - sum_a W_a^T dp[kf_a]); written to out_all[n + 3l ..]
 template <int G>
 __global__ __launch_bounds__(kBuildThreads) void k_lm_backsub(DevProblem P, const double* __restrict__ dp, double* __restrict__ out_all) {
@@ -485,14 +412,7 @@ void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t 
   hipLaunchKernelGGL(k_cost_finish, dim3(1), dim3(256), 0, s2, P, nblk);
   if (pose_system_cleared) { (void)hipStreamWaitEvent(s2, pose_system_cleared, 0); if (fork) (void)hipStreamWaitEvent(st, pose_system_cleared, 0); }  // first writers of the pose system follow
   hipLaunchKernelGGL(k_kf_reduce, dim3(P.K), dim3(64), 0, s2, P);
-  static const bool exp_nopairs = getenv("COVGPU_EXP_NOPAIRS") != nullptr;   // timing experiment only (results are wrong)
-  static const bool staged = getenv("COVGPU_PAIR_STAGED") != nullptr && atoi(getenv("COVGPU_PAIR_STAGED")) != 0;   // opt-in: measured SLOWER (0.52 vs 0.27 ms: one or two workgroups per CU cannot hide the partner reads)
-  const size_t lds_kf = ((size_t)kPairsPerWg * 18 * (kPairLanes + 1) + (size_t)18 * P.max_obs_per_kf) * sizeof(double);
-  if (P.npairs && !exp_nopairs && staged && P.kp_ptr != nullptr && lds_kf <= 150 * 1024) {
-    static bool once = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_blocks_kf), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); return true; }();
-    (void)once;
-    hipLaunchKernelGGL(k_pair_blocks_kf, dim3(P.K), dim3(kPairLanes * kPairsPerWg), lds_kf, st, P, (const int*)P.kp_ptr);
-  } else if (P.npairs && !exp_nopairs) hipLaunchKernelGGL(k_pair_blocks, dim3((P.npairs + kPairsPerWg - 1) / kPairsPerWg), dim3(kPairLanes * kPairsPerWg), 0, st, P);
+  if (P.npairs) hipLaunchKernelGGL(k_pair_blocks, dim3((P.npairs + kPairsPerWg - 1) / kPairsPerWg), dim3(kPairLanes * kPairsPerWg), 0, st, P);
   // (fork: the caller joins the side stream back — it has more on it)
 }
 // upload: keyframe-major copies of the observation stream (DevProblem::kobs), the Z slot of every observation, and the covisible-pair

@@ -83,9 +83,6 @@ struct covgpu_context {
   bool coll_failed = false;
   std::string coll_err;
   covgpu_group* group = nullptr;   // the in-process group this context's reducer belongs to (aborted when this rank gives up)
-  // the fronts were cleared for the NEXT linearisation already (enqueue_solve: under the trust-region tail, where the chip idles);
-  // enqueue_build then skips its own clearing. Any upload resets it.
-  bool fronts_clean = false;
   std::atomic<int>* peer_fail = nullptr;   // covgpu_gba_solve_multi: raised by any rank of the call that gave up; polled while waiting
 };
 
@@ -346,7 +343,6 @@ static void free_problem(covgpu_context* c) {
   c->chol.tri_clear();
   c->have = false;
   c->pgo_plan.active = false;  // its device buffers were in `allocs`
-  c->fronts_clean = false;
   c->nd = NdDev();
 }
 
@@ -725,15 +721,6 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
     RC(dev_alloc(c, &P.cost_part, (size_t)(P.L / 4 + 64)));
     HIPCHK(hipStreamSynchronize(c->st));
     h_pair_i.swap(pi); h_pair_j.swap(pj);
-    {  // pairs by keyframe i (the list is sorted by (i, j)) for the keyframe-major pair pass (k_visual.hip: k_pair_blocks_kf)
-      std::vector<int> kpp(P.K + 1, 0);
-      bool sorted = true;
-      for (size_t q = 0; q < h_pair_i.size(); ++q) { kpp[h_pair_i[q] + 1]++; if (q && h_pair_i[q] < h_pair_i[q - 1]) sorted = false; }
-      for (int k = 0; k < P.K; ++k) kpp[k + 1] += kpp[k];
-      P.max_obs_per_kf = 0;
-      for (int k = 0; k < P.K; ++k) P.max_obs_per_kf = std::max(P.max_obs_per_kf, kptr[k + 1] - kptr[k]);
-      if (sorted) RC(dev_upload(c, &P.kp_ptr, kpp.data(), kpp.size()));
-    }
   }
   tm("covisible pair lists");
   // IMU
@@ -986,14 +973,13 @@ static void enqueue_build(covgpu_context* c, double mu) {
   // kernels and the landmark linearisation, which only write per-factor / per-observation records; its first writers
   // (k_kf_reduce ...) wait for it. Every reader of the previous system has finished: each iteration ends with a host sync.
   c->chol.init();
-  if (!(P.nd && c->fronts_clean)) {
-    (void)hipEventRecord(c->chol.ev_fill, c->st);
-    (void)hipStreamWaitEvent(c->chol.head, c->chol.ev_fill, 0);
-    if (P.nd) launch_nd_zero(P, c->nd, c->chol.head);
-    else (void)hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), c->chol.head);
-    (void)hipEventRecord(c->chol.ev_fill, c->chol.head);
-  }  // else: enqueue_solve cleared them behind the previous linear solve and recorded ev_fill on the head stream
-  c->fronts_clean = false;
+  // (measured, round 4: clearing them BEHIND the previous linear solve instead — on the head stream, under the trust-region tail — takes
+  //  0.11 ms off this pass and puts 0.12 ms onto the tail and the solve: the 0.65 GB of stores contend with the tail's re-linearisations)
+  (void)hipEventRecord(c->chol.ev_fill, c->st);
+  (void)hipStreamWaitEvent(c->chol.head, c->chol.ev_fill, 0);
+  if (P.nd) launch_nd_zero(P, c->nd, c->chol.head);
+  else (void)hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), c->chol.head);
+  (void)hipEventRecord(c->chol.ev_fill, c->chol.head);
   launch_zero_system(P, c->st);
   // inertial factors (one wave per factor: latency, not throughput) on the side stream beside the landmark pass; their speed-bias
   // blocks are final before anything of the pose system is touched, the pose-dimension part is gathered after the visual blocks
@@ -1026,17 +1012,6 @@ static void enqueue_solve(covgpu_context* c, double* dst_all) {
   }
   else launch_pose_graph_solve(P, dst_all, c->st, c->chol, c->pgo_plan.active ? &c->pgo_plan : nullptr);  // pose graph (k_pgo.hip)
   if (c->profiling) (void)hipEventRecord(c->ev[3], c->st);
-  // The factor is dead once the backward substitution has written the step: clear the fronts' live tiles for the NEXT linearisation
-  // now, on the head stream, under the trust-region tail (a dozen small latency-bound launches: the chip idles) instead of at the
-  // head of the next build, where it delayed the first writers of the system by ~0.1 ms (0.65 GB of stores on the 5-agent map).
-  static const bool early_zero = getenv("COVGPU_EARLY_ZERO") != nullptr && atoi(getenv("COVGPU_EARLY_ZERO")) != 0;   // opt-in: measured neutral (build -0.11 ms, tail +0.09, solve +0.03: the stores contend with the tail's re-linearisations)
-  if (P.nd && early_zero && !c->coll_failed) {
-    (void)hipEventRecord(c->chol.ev_done, c->st);
-    (void)hipStreamWaitEvent(c->chol.head, c->chol.ev_done, 0);
-    launch_nd_zero(P, c->nd, c->chol.head);
-    (void)hipEventRecord(c->chol.ev_fill, c->chol.head);
-    c->fronts_clean = true;
-  }
   launch_lm_backsub(P, dst_all, dst_all, c->st);
 }
 

@@ -297,6 +297,25 @@ def main():
                                "what": "covins_amd.optimization.Optimization.GlobalBundleAdjustment(map, 10, outlier_removal=True) "
                                        "on the same map, host flattening in numpy"}
         if not args.no_e2e:
+            # the same call through the C++ facade (include/covins_gpu/optimization_gpu.hpp — the maintainer-facing drop-in) on stand-in
+            # Map / Keyframe / Landmark objects of the same map (tests/cpp: the real COVINS classes need ROS / Eigen / OpenCV); the
+            # first call creates the thread's context and warms the library up, the second is timed
+            try:
+                from tests.facade_util import StandinMap
+                ts = []
+                for _ in range(2):
+                    smap = StandinMap(m)
+                    t_c = time.perf_counter(); smap.gba(args.iterations); ts.append(time.perf_counter() - t_c)
+                    stages_cpp = {k: round(v * 1e-3, 4) for k, v in StandinMap.last_stages().items()}
+                    smap.close()
+                out["e2e_call_cpp"] = {"t_call_s": ts[1], "t_first_call_s": ts[0], "kf_per_s_e2e": k_free / ts[1], "stages_s": stages_cpp,
+                                       "note": "Map::Clean is the reference's own method (map_be.cpp:448-454, 698-743: it copies every landmark's observation "
+                                               "map to read its size; the stand-in mirrors that) — not part of what this build replaces",
+                                       "what": "covins_gpu::Optimization::GlobalBundleAdjustment(map, 10) through the C++ facade on stand-in map "
+                                               "objects (one Map -> IR walk, one upload, both rounds on the device, erase, write-back, Map::Clean)"}
+            except Exception as e:   # (the shim needs g++ on the box; never fatal for the metric line)
+                out["e2e_call_cpp"] = {"t_call_s": None, "error": repr(e)[:200]}
+        if not args.no_e2e:
             # side figure: one PoseGraphOptimization solve of the same map (block-arrow solve); not `value`
             popt = backend.default_options(max_iterations=pgo_prm.pgo_iteration_limit, device=local_rank)
             ctx.pgo_solve(pgo_prob, popt)

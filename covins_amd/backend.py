@@ -47,6 +47,8 @@ def lib() -> C.CDLL:
         _LIB.covgpu_set_profiling.restype = None
         _LIB.covgpu_get_profile.argtypes = [C.c_void_p, capi._dp]
         _LIB.covgpu_get_profile.restype = None
+        _LIB.covgpu_gba_two_round.argtypes = [C.c_void_p, OP, PP, C.POINTER(capi.TwoRound), capi._bp, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                              C.POINTER(capi.Result), C.POINTER(capi.Result)]
         _LIB.covgpu_get_profile2.argtypes = [C.c_void_p, capi._dp]
         _LIB.covgpu_get_profile2.restype = None
         _LIB.covgpu_get_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
@@ -101,6 +103,23 @@ class Context:
         q = prob.copy(); s = q.as_struct(); r = Result()
         self._check(lib().covgpu_gba_solve(self._h, C.byref(opt), C.byref(s), C.byref(r)))
         return q, r
+
+    def gba_two_round(self, prob: FlatProblem, opt: Options, threshold: float, round1_iterations: int = 5, use_loops_round2: bool = True,
+                      loop_loss_round2: float = 1.0, kf_fixed_round2=None):
+        """Both rounds of GlobalBundleAdjustment behind one call (covgpu_gba_two_round): `prob` is the FIRST round's problem. Returns
+        (solution of round 2 in round-1 indexing, round-1 result, round-2 result, erase flags [O] bool, lm_left [L], (erased, short))."""
+        q = prob.copy(); s = q.as_struct(); r1 = Result(); r2 = Result()
+        erase = np.zeros(max(prob.O, 1), np.uint8); left = np.zeros(max(prob.L, 1), np.int32); cnt = (C.c_int64 * 2)()
+        tr = capi.TwoRound()
+        tr.outlier_threshold = float(threshold); tr.round1_iterations = int(round1_iterations); tr.use_loops_round2 = int(bool(use_loops_round2))
+        tr.loop_loss_round2 = float(loop_loss_round2)
+        fx = None
+        if kf_fixed_round2 is not None:
+            fx = np.ascontiguousarray(kf_fixed_round2, np.uint8)
+            tr.kf_fixed_round2 = fx.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._check(lib().covgpu_gba_two_round(self._h, C.byref(opt), C.byref(s), C.byref(tr), erase.ctypes.data_as(capi._bp), iptr(left), cnt,
+                                               C.byref(r1), C.byref(r2)))
+        return q, r1, r2, erase[:prob.O].astype(bool), left[:prob.L], (int(cnt[0]), int(cnt[1]))
 
     def pgo_solve(self, prob: FlatProblem, opt: Options) -> Tuple[FlatProblem, Result]:
         q = prob.copy(); s = q.as_struct(); r = Result()

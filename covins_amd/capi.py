@@ -62,6 +62,12 @@ class Result(C.Structure):
     ]
 
 
+class TwoRound(C.Structure):
+    """covgpu_two_round (include/covgpu.h): parameters of the second round of a GlobalBundleAdjustment call."""
+    _fields_ = [("outlier_threshold", C.c_double), ("round1_iterations", C.c_int32), ("use_loops_round2", C.c_int32),
+                ("loop_loss_round2", C.c_double), ("kf_fixed_round2", C.POINTER(C.c_uint8))]
+
+
 def _f64(a, shape):
     a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(shape))
     return a

@@ -335,6 +335,22 @@ struct PairLists {
   int *pair_oa = nullptr, *pair_ob = nullptr;                      // [nent] observation of keyframe i / of keyframe j of every common landmark, landmark order
 };
 bool build_pairs_device(int L, int K, const int* d_lm_obs_ptr, const int* d_obs_kf, const int* d_key_of_kf, bool want_obs, hipStream_t st, PairLists& out);
+// upload: observation stream unpacked and the keyframe-major lists built on the device (k_pairs.hip)
+void launch_obs_unpack(int L, int O, const int* lm_obs_ptr, const double* uv, int* obs_lm, double* u, double* v, int* iota, hipStream_t st);
+bool build_kf_lists_device(int O, int K, const int* d_obs_kf, const int* d_iota, int* kf_obs_ptr, int* kf_obs_idx, hipStream_t st);
+// second round of a GlobalBundleAdjustment call (optimization_be.cpp:296-557) from the resident first round: the compacted observation
+// stream (k_pairs.hip: round2_compact_device). lm_old[q] = first-round index of second-round landmark q.
+struct Round2Lists {
+  int L2 = 0, O2 = 0;
+  double *lm0 = nullptr, *obs_u = nullptr, *obs_v = nullptr, *obs_sigma = nullptr;
+  int *lm_obs_ptr = nullptr, *lm_old = nullptr, *obs_kf = nullptr, *obs_lm = nullptr, *kf_obs_ptr = nullptr, *kf_obs_idx = nullptr;
+  void free_all() {
+    for (void* q : {(void*)lm0, (void*)obs_u, (void*)obs_v, (void*)obs_sigma, (void*)lm_obs_ptr, (void*)lm_old, (void*)obs_kf, (void*)obs_lm, (void*)kf_obs_ptr, (void*)kf_obs_idx})
+      if (q) (void)hipFree(q);
+  }
+};
+bool round2_compact_device(int L, int O, int K, const unsigned char* d_erase, const int* d_left, const int* d_obs_kf, const int* d_obs_lm, const double* d_u,
+                           const double* d_v, const double* d_sigma, const double* d_lm0, hipStream_t st, Round2Lists& out);
 
 // ---- multifrontal solve of the whole reduced camera system (k_front.hip)
 struct NdHostPlan;

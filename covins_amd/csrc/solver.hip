@@ -83,6 +83,8 @@ struct covgpu_context {
   bool coll_failed = false;
   std::string coll_err;
   covgpu_group* group = nullptr;   // the in-process group this context's reducer belongs to (aborted when this rank gives up)
+  int* d_pairkey = nullptr;    // [K] key of every keyframe in the covisible-pair numbering (chain position, -1: constant pose), kept for the second round of a call
+  std::vector<int> h_perm;     // [K] keyframe -> chain position of the resident problem
   std::atomic<int>* peer_fail = nullptr;   // covgpu_gba_solve_multi: raised by any rank of the call that gave up; polled while waiting
 };
 
@@ -343,6 +345,7 @@ static void free_problem(covgpu_context* c) {
   c->chol.tri_clear();
   c->have = false;
   c->pgo_plan.active = false;  // its device buffers were in `allocs`
+  c->d_pairkey = nullptr;
   c->nd = NdDev();
 }
 
@@ -677,34 +680,37 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   RC(dev_upload(c, &P.cam_intr, p->cam_intr, (size_t)4 * P.A));
   RC(dev_upload(c, &P.cam_dist, p->cam_dist, (size_t)4 * P.A));
   RC(dev_upload(c, &P.cam_dist_type, (const int*)p->cam_dist_type, (size_t)P.A));
-  // observation stream: SoA
-  std::vector<int> obs_lm(P.O);
-  std::vector<double> u(P.O), v(P.O);
-  for (int l = 0; l < P.L; ++l)
-    for (int o = p->lm_obs_ptr[l]; o < p->lm_obs_ptr[l + 1]; ++o) obs_lm[o] = l;
-  for (int o = 0; o < P.O; ++o) { u[o] = p->obs_uv[2 * o]; v[o] = p->obs_uv[2 * o + 1]; }
+  // observation stream: SoA. The interleaved keypoints are split, the landmark index of every observation is filled and the
+  // keyframe-major lists are built ON THE DEVICE (k_pairs.hip) — three host loops over O and two more uploads before (12 of the 18 ms of an
+  // upload of the 5-agent map)
   std::vector<int> ptr0(1, 0);
   RC(dev_upload(c, &P.lm_obs_ptr, P.L ? (const int*)p->lm_obs_ptr : ptr0.data(), (size_t)P.L + 1));
   RC(dev_upload(c, &P.obs_kf, (const int*)p->obs_kf, (size_t)P.O));
-  RC(dev_upload(c, &P.obs_lm, obs_lm.data(), (size_t)P.O));
-  RC(dev_upload(c, &P.obs_u, u.data(), (size_t)P.O));
-  RC(dev_upload(c, &P.obs_v, v.data(), (size_t)P.O));
   RC(dev_upload(c, &P.obs_sigma, p->obs_sigma, (size_t)P.O));
+  RC(dev_alloc(c, &P.obs_lm, (size_t)P.O)); RC(dev_alloc(c, &P.obs_u, (size_t)P.O)); RC(dev_alloc(c, &P.obs_v, (size_t)P.O));
+  RC(dev_alloc(c, &P.kf_obs_ptr, (size_t)P.K + 1)); RC(dev_alloc(c, &P.kf_obs_idx, (size_t)P.O));
+  {
+    double* d_uv = nullptr; int* d_iota = nullptr;
+    HIPCHK(hipMalloc((void**)&d_uv, std::max<size_t>((size_t)2 * P.O, 2) * sizeof(double)));
+    if (hipMalloc((void**)&d_iota, std::max<size_t>((size_t)P.O, 1) * sizeof(int)) != hipSuccess) { (void)hipFree(d_uv); g_err = "hipMalloc: out of memory"; return COVGPU_ERR_OUT_OF_MEMORY; }
+    hipError_t e = P.O ? hipMemcpyAsync(d_uv, p->obs_uv, (size_t)2 * P.O * sizeof(double), hipMemcpyHostToDevice, c->st) : hipSuccess;
+    launch_obs_unpack(P.L, P.O, P.lm_obs_ptr, d_uv, P.obs_lm, P.obs_u, P.obs_v, d_iota, c->st);
+    const bool ok = e == hipSuccess && build_kf_lists_device(P.O, P.K, P.obs_kf, d_iota, P.kf_obs_ptr, P.kf_obs_idx, c->st);   // (ends with a stream synchronisation)
+    (void)hipStreamSynchronize(c->st);
+    (void)hipFree(d_uv); (void)hipFree(d_iota);
+    if (!ok) { g_err = "upload: device-side observation lists failed (allocation)"; return COVGPU_ERR_OUT_OF_MEMORY; }
+  }
   tm("validate, chains, states, observation stream");
   // keyframe-major observation lists + covisible pair lists (fixed keyframes carry no pose block -> excluded)
   std::vector<int> h_pair_i, h_pair_j;  // kept for the plan below
   {
-    std::vector<int> kptr(P.K + 1, 0), kidx(P.O);
-    for (int o = 0; o < P.O; ++o) kptr[p->obs_kf[o] + 1]++;
-    for (int k = 0; k < P.K; ++k) kptr[k + 1] += kptr[k];
-    { std::vector<int> cur(kptr.begin(), kptr.end() - 1); for (int o = 0; o < P.O; ++o) kidx[cur[p->obs_kf[o]]++] = o; }
-    RC(dev_upload(c, &P.kf_obs_ptr, kptr.data(), kptr.size())); RC(dev_upload(c, &P.kf_obs_idx, kidx.data(), kidx.size()));
     // covisible pairs (i > j in chain-major positions, free keyframes only) with, per pair, the observations of every common
     // landmark in landmark order: built on the device (k_pairs.hip: key emission + one stable radix sort + run-length encoding)
     std::vector<int> key(P.K);
     for (int k = 0; k < P.K; ++k) key[k] = p->kf_fixed[k] ? -1 : perm[k];
     int* d_key = nullptr;
     RC(dev_upload(c, &d_key, key.data(), key.size()));
+    c->d_pairkey = d_key; c->h_perm = perm;
     PairLists pl;
     if (!build_pairs_device(P.L, P.K, P.lm_obs_ptr, P.obs_kf, d_key, true, c->st, pl)) { g_err = "covisible pair lists: device allocation failed (or more than 2^31 entries)"; return COVGPU_ERR_OUT_OF_MEMORY; }
     for (int* q : {pl.pair_ptr, pl.pair_i, pl.pair_j, pl.pair_oa, pl.pair_ob}) if (q) c->allocs.push_back(q);
@@ -1226,6 +1232,103 @@ static int full_solve(covgpu_context* c, const covgpu_options* opt, covgpu_probl
 }
 extern "C" int covgpu_gba_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out) { return guarded([&] { return full_solve(c, opt, p, out, false); }); }
 extern "C" int covgpu_pgo_solve(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, covgpu_result* out) { return guarded([&] { return full_solve(c, opt, p, out, true); }); }
+
+// ------------------------------------------------------------------------------------------------ both rounds of a GlobalBundleAdjustment call
+// optimization_be.cpp:56-618 builds and solves TWO problems: the outlier round (5 iterations, loop edges without loss, :62-265), then —
+// after erasing the observations whose loss-corrected residual exceeds th_gba_outlier_global (:270-290) — the main round on the rebuilt
+// problem (:296-567), restarted from the SAME map state (the outlier round's estimate is discarded). The second problem is the first
+// minus the erased observations, minus the landmarks left with fewer than two (:428-440), with the loop edges' loss switched on (:555)
+// and optionally more constant poses (:338-341): nothing a second Map -> IR flatten and a second H2D upload would have to tell the
+// device. Here it is derived ON the device from the resident first round (k_pairs.hip: round2_compact_device; pair lists rebuilt by
+// the same device code as an upload; the elimination tree stays — couplings only disappear), and only the erase flags travel back for
+// the caller's map bookkeeping. p: the FIRST round's problem; on return its poses / speed-bias hold the second round's estimate and
+// lm_pos[l] the second round's for every landmark with lm_left[l] >= 2 (the others took no part, as in the reference).
+extern "C" int covgpu_gba_two_round(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, const covgpu_two_round* tr, uint8_t* obs_erase,
+                                    int32_t* lm_left, int64_t* counts, covgpu_result* round1, covgpu_result* round2) {
+  return guarded([&]() -> int {
+    if (!tr || !obs_erase || !lm_left) { g_err = "covgpu_gba_two_round: NULL argument"; return (int)COVGPU_ERR_INVALID_ARG; }
+    if (c->sharded) { g_err = "covgpu_gba_two_round runs on one GPU (sharded solve: covgpu_gba_solve_multi per round)"; return (int)COVGPU_ERR_INVALID_ARG; }
+    covgpu_options o1 = *opt;
+    o1.max_iterations = tr->round1_iterations > 0 ? tr->round1_iterations : 5;   // :262
+    auto t0 = std::chrono::steady_clock::now();
+    RC(upload_impl(c, &o1, p, false));
+    covgpu_result a, b;
+    const double t_up = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    RC(solve_any(c, &o1, &a));
+    a.t_upload_s = t_up;
+    DevProblem& P = c->P;
+    t0 = std::chrono::steady_clock::now();
+    // ---- outlier decisions at the resident estimate (:270-290); the flags stay on the device and a copy goes to the caller
+    unsigned char* de = nullptr; int* dl = nullptr; unsigned long long* dc = nullptr;
+    RC(dev_alloc(c, &de, (size_t)std::max(P.O, 1))); RC(dev_alloc(c, &dl, (size_t)std::max(P.L, 1))); RC(dev_alloc(c, &dc, (size_t)2));
+    HIPCHK(hipMemsetAsync(dc, 0, 2 * sizeof(unsigned long long), c->st));
+    launch_lm_outliers(P, tr->outlier_threshold, de, dl, dc, c->st);
+    unsigned long long hc[2] = {0, 0};
+    if (P.O) HIPCHK(hipMemcpyAsync(obs_erase, de, (size_t)P.O, hipMemcpyDeviceToHost, c->st));
+    if (P.L) HIPCHK(hipMemcpyAsync(lm_left, dl, sizeof(int) * (size_t)P.L, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(hc, dc, sizeof(hc), hipMemcpyDeviceToHost, c->st));
+    // ---- the second round's observation stream, compacted on the device
+    Round2Lists R;
+    if (!round2_compact_device(P.L, P.O, P.K, de, dl, P.obs_kf, P.obs_lm, P.obs_u, P.obs_v, P.obs_sigma, P.lm0, c->st, R)) {
+      g_err = "covgpu_gba_two_round: device allocation failed while compacting the observation stream"; return (int)COVGPU_ERR_OUT_OF_MEMORY;
+    }
+    for (void* q : {(void*)R.lm0, (void*)R.obs_u, (void*)R.obs_v, (void*)R.obs_sigma, (void*)R.lm_obs_ptr, (void*)R.lm_old, (void*)R.obs_kf, (void*)R.obs_lm, (void*)R.kf_obs_ptr,
+                    (void*)R.kf_obs_idx})
+      if (q) c->allocs.push_back(q);
+    if (counts) { counts[0] = (int64_t)hc[0]; counts[1] = (int64_t)hc[1]; }   // (round2_compact_device ends with a stream synchronisation)
+    const int L1 = P.L;
+    if (R.L2 > 0 && R.O2 > 0) {
+      P.L = R.L2; P.O = R.O2; P.N = P.n + 3 * P.L;
+      P.lm0 = R.lm0; P.lm_obs_ptr = R.lm_obs_ptr; P.obs_kf = R.obs_kf; P.obs_lm = R.obs_lm; P.obs_u = R.obs_u; P.obs_v = R.obs_v; P.obs_sigma = R.obs_sigma;
+      P.kf_obs_ptr = R.kf_obs_ptr; P.kf_obs_idx = R.kf_obs_idx;
+    } else { P.L = 0; P.O = 0; P.N = P.n; }
+    if (tr->kf_fixed_round2 != nullptr) {   // opt.gba_fix_poses_loaded_maps (:338-341): more constant poses in the second round
+      HIPCHK(hipMemcpyAsync(P.fixed, tr->kf_fixed_round2, (size_t)P.K, hipMemcpyHostToDevice, c->st));
+      std::vector<int> key(P.K);
+      for (int k = 0; k < P.K; ++k) key[k] = tr->kf_fixed_round2[k] ? -1 : c->h_perm[k];
+      HIPCHK(hipMemcpyAsync(c->d_pairkey, key.data(), sizeof(int) * (size_t)P.K, hipMemcpyHostToDevice, c->st));
+      HIPCHK(hipStreamSynchronize(c->st));
+    }
+    {  // covisible pairs of what is left (same device code as an upload); the elimination tree stays: couplings only disappear
+      PairLists pl;
+      if (!build_pairs_device(P.L, P.K, P.lm_obs_ptr, P.obs_kf, c->d_pairkey, true, c->st, pl)) { g_err = "covisible pair lists: device allocation failed"; return (int)COVGPU_ERR_OUT_OF_MEMORY; }
+      for (int* q : {pl.pair_ptr, pl.pair_i, pl.pair_j, pl.pair_oa, pl.pair_ob}) if (q) c->allocs.push_back(q);
+      P.npairs = pl.npairs; P.pair_ptr = pl.pair_ptr; P.pair_i = pl.pair_i; P.pair_j = pl.pair_j; P.pair_oa = pl.pair_oa; P.pair_ob = pl.pair_ob;
+      launch_kobs_build(P, P.pair_oa, P.pair_ob, pl.nent, c->st);
+    }
+    // (the reductions store one partial sum per wave into fixed slots and never clear them: fewer observations = fewer waves, and the
+    //  first round's partials beyond them would be summed again)
+    HIPCHK(hipMemsetAsync(P.part, 0, (size_t)SC_COUNT * P.part_n * sizeof(double), c->st));
+    if (!tr->use_loops_round2) { P.E = 0; P.nepairs = 0; }   // opt.gba_use_map_loop_constraints (:534)
+    else if (P.E > 0) {
+      std::vector<double> la((size_t)P.E, tr->loop_loss_round2);   // Cauchy on the loop edges in the second round (:555)
+      HIPCHK(hipMemcpyAsync(P.edge_loss_a, la.data(), sizeof(double) * (size_t)P.E, hipMemcpyHostToDevice, c->st));
+    }
+    HIPCHK(hipStreamSynchronize(c->st));
+    const double t_prep = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    RC(solve_any(c, opt, &b));
+    b.t_upload_s = t_prep;   // (what replaces the second upload: outlier pass, compaction, pair lists)
+    // ---- estimate of the second round -> caller's arrays; landmarks through the first-round index of every kept one
+    t0 = std::chrono::steady_clock::now();
+    HIPCHK(hipMemcpyAsync(p->kf_pose, P.pose, (size_t)7 * P.K * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    if (P.vi && p->kf_speed_bias) HIPCHK(hipMemcpyAsync(p->kf_speed_bias, P.sb, (size_t)9 * P.K * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    std::vector<double> lm2((size_t)3 * P.L);
+    std::vector<int> old((size_t)P.L);
+    if (P.L) {
+      HIPCHK(hipMemcpyAsync(lm2.data(), P.lm, lm2.size() * sizeof(double), hipMemcpyDeviceToHost, c->st));
+      HIPCHK(hipMemcpyAsync(old.data(), R.lm_old, old.size() * sizeof(int), hipMemcpyDeviceToHost, c->st));
+    }
+    HIPCHK(hipStreamSynchronize(c->st));
+    for (int q = 0; q < P.L; ++q) {
+      if (old[q] < 0 || old[q] >= L1) { g_err = "covgpu_gba_two_round: landmark map out of range"; return (int)COVGPU_ERR_INVALID_ARG; }
+      std::memcpy(p->lm_pos + 3 * (size_t)old[q], lm2.data() + 3 * (size_t)q, 3 * sizeof(double));
+    }
+    b.t_download_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (round1) *round1 = a;
+    if (round2) *round2 = b;
+    return (int)COVGPU_OK;
+  });
+}
 
 // ------------------------------------------------------------------------------------------------ in-process multi-GPU solve
 // What a covins_backend process (one process, several GPUs) calls: the whole sharded GlobalBundleAdjustment solve behind one

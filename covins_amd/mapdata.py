@@ -97,7 +97,8 @@ class SlamMap:
         keep = ~obs_mask
         counts = np.add.reduceat(keep.astype(np.int64), self.lm_obs_ptr[:-1]) if self.O else np.zeros(self.L, np.int64)
         counts[np.diff(self.lm_obs_ptr) == 0] = 0
-        self.obs_kf, self.obs_uv, self.obs_octave = self.obs_kf[keep], self.obs_uv[keep], self.obs_octave[keep]
+        rows = np.flatnonzero(keep)   # (one index list, three takes: a boolean mask is re-scanned by every indexing)
+        self.obs_kf, self.obs_uv, self.obs_octave = self.obs_kf.take(rows), self.obs_uv.take(rows, axis=0), self.obs_octave.take(rows)
         self.lm_obs_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
 
     def clean(self) -> int:
@@ -152,8 +153,7 @@ def flatten_gba(m: SlamMap, visual_only: bool, loop_loss: bool, use_loops: bool 
     obs_lm = np.repeat(np.arange(m.L), n_all)
     obs_keep = obs_valid & lm_in[obs_lm] if m.O else np.zeros(0, bool)
     obs_rows = np.nonzero(obs_keep)[0].astype(np.int32)
-    cnt = np.zeros(m.L, np.int64)
-    np.add.at(cnt, obs_lm[obs_rows], 1)
+    cnt = np.bincount(obs_lm[obs_rows], minlength=m.L) if len(obs_rows) else np.zeros(m.L, np.int64)
     lm_obs_ptr = np.concatenate([[0], np.cumsum(cnt[lm_rows])]).astype(np.int32)
 
     # IMU factors
@@ -182,6 +182,7 @@ def flatten_gba(m: SlamMap, visual_only: bool, loop_loss: bool, use_loops: bool 
                 continue  # "Loop KF missing -- skip loop" (:546-549)
             ei.append(a); ej.append(b); meas.append(lc.T_s1_s2)
     E = len(ei)
+    all_obs = len(obs_rows) == m.O
 
     prob = capi.FlatProblem(
         kf_pose=m.kf_pose[kf_rows],
@@ -189,9 +190,10 @@ def flatten_gba(m: SlamMap, visual_only: bool, loop_loss: bool, use_loops: bool 
         kf_fixed=fixed, kf_cam=m.kf_cam[kf_rows],
         cam_extr=m.cam_extr.copy(), cam_intr=m.cam_intr.copy(), cam_dist=m.cam_dist.copy(), cam_dist_type=m.cam_dist_type.copy(),  # (the IR owns its arrays)
         lm_pos=m.lm_pos[lm_rows], lm_obs_ptr=lm_obs_ptr,
-        obs_kf=remap[m.obs_kf[obs_rows]] if len(obs_rows) else np.zeros(0, np.int32),
-        obs_uv=m.obs_uv[obs_rows].astype(np.float64),                     # float -> double (opt_be.cpp:477)
-        obs_sigma=(m.obs_octave[obs_rows].astype(np.float64) + 1.0) * 2.0,  # (opt_be.cpp:478)
+        # (every observation kept — the usual case — : contiguous conversions instead of gathers through obs_rows)
+        obs_kf=(remap[m.obs_kf] if all_obs else remap[m.obs_kf[obs_rows]]) if len(obs_rows) else np.zeros(0, np.int32),
+        obs_uv=(m.obs_uv if all_obs else m.obs_uv[obs_rows]).astype(np.float64),                     # float -> double (opt_be.cpp:477)
+        obs_sigma=((m.obs_octave if all_obs else m.obs_octave[obs_rows]).astype(np.float64) + 1.0) * 2.0,  # (opt_be.cpp:478)
         imu_kf_i=np.array(imu_i, np.int32), imu_kf_j=np.array(imu_j, np.int32),
         imu_sample_ptr=np.array(ptr, np.int32), imu_samples=samples,
         imu_first=np.array(first).reshape(-1, 6) if first else np.zeros((0, 6)),

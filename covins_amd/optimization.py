@@ -35,8 +35,10 @@ class Optimization:
     @staticmethod
     def GlobalBundleAdjustment(map_: SlamMap, interations_limit: int, time_limit: float = -1.0, visual_only: bool = False,
                                outlier_removal: bool = True, estimate_bias: bool = False, *, params: Optional[OptParams] = None,
-                               ctx: Optional[backend.Context] = None) -> Dict[str, object]:
-        """`time_limit` and `estimate_bias` are accepted and ignored, exactly like the reference (never read)."""
+                               ctx: Optional[backend.Context] = None, device_second_round: bool = True) -> Dict[str, object]:
+        """`time_limit` and `estimate_bias` are accepted and ignored, exactly like the reference (never read).
+        device_second_round: the second round's problem is derived on the device from the resident first round (covgpu_gba_two_round:
+        one flatten and one upload per call); False: the reference's literal sequence — flatten, solve, erase, flatten again, solve."""
         import time
         prm = params or OptParams()
         own = ctx is None
@@ -55,6 +57,48 @@ class Optimization:
             st["download"] = st.get("download", 0.0) + res.t_download_s
             return sol, res
         try:
+            if outlier_removal and device_second_round:
+                # ONE flatten (the first round's problem, :80-254) and ONE upload; rounds, erase decisions and the rebuilt second-round
+                # problem (:296-557) on the device. The map is brought to the state the reference leaves: observations erased
+                # (:281-289), estimate of the second round written back (:572-609), Map::Clean (:614).
+                t0 = time.perf_counter()
+                prob, idx = mapdata.flatten_gba(map_, visual_only, loop_loss=False, use_loops=True)
+                fixed2 = None
+                if prm.gba_fix_poses_loaded_maps:
+                    fixed2 = prob.kf_fixed.copy(); fixed2[map_.kf_loaded[idx.kf_rows]] = 1
+                add("flatten", t0)
+                opt = backend.default_options(strategy=prm.strategy, max_iterations=int(interations_limit), visual_only=int(visual_only))
+                sol, res1, res2, bad, lm_left, (n_bad, n_short) = ctx.gba_two_round(
+                    prob, opt, prm.th_gba_outlier_global, 5, prm.gba_use_map_loop_constraints, 1.0, fixed2)
+                st["upload (host plan + H2D)"] = res1.t_upload_s
+                st["second round rebuilt on the device"] = res2.t_upload_s
+                st["solve"] = res1.t_solve_s + res2.t_solve_s
+                st["download"] = res2.t_download_s
+                t0 = time.perf_counter()
+                mask = np.zeros(map_.O, bool)
+                mask[idx.obs_rows[bad]] = True
+                map_.erase_observations(mask)
+                add("erase observations", t0)
+                info["outliers_removed"] = int(bad.sum()); info["round1"] = res1; info["round2"] = res2
+                info["landmarks_left_short"] = n_short
+                keep = lm_left >= 2   # landmarks of the second round (:428-440)
+                info["problem"] = (prob.K, int(keep.sum()), int(prob.O - bad.sum() - lm_left[~keep].sum()), prob.I, prob.E)
+                t0 = time.perf_counter()
+                q = sol.kf_pose[:, :4] / np.linalg.norm(sol.kf_pose[:, :4], axis=1, keepdims=True)
+                map_.kf_pose[idx.kf_rows, :4] = q
+                map_.kf_pose[idx.kf_rows, 4:] = sol.kf_pose[:, 4:]
+                if not visual_only:
+                    map_.kf_velocity[idx.kf_rows] = sol.kf_speed_bias[:, 0:3]
+                    map_.kf_bias_a[idx.kf_rows] = sol.kf_speed_bias[:, 3:6]
+                    map_.kf_bias_g[idx.kf_rows] = sol.kf_speed_bias[:, 6:9]
+                map_.kf_gba_optimized[idx.kf_rows] = True
+                map_.lm_pos[idx.lm_rows[keep]] = sol.lm_pos[keep]
+                map_.lm_gba_optimized[idx.lm_rows[keep]] = True
+                add("write-back", t0)
+                t0 = time.perf_counter()
+                info["cleaned"] = map_.clean()  # map->Clean() (opt_be.cpp:614)
+                add("Map::Clean", t0)
+                return info
             if outlier_removal:  # first round (opt_be.cpp:62-293): 5 iterations, loop edges without loss, then erase outliers
                 t0 = time.perf_counter()
                 prob, idx = mapdata.flatten_gba(map_, visual_only, loop_loss=False, use_loops=True)

@@ -190,6 +190,28 @@ int covgpu_reprojection_residual_norms(covgpu_context* ctx, const covgpu_options
 int covgpu_outlier_pass(covgpu_context* ctx, double threshold, uint8_t* obs_erase /* [O] */, int32_t* lm_left /* [L] */,
                         int64_t* counts /* [2] or NULL */);
 
+/* Both rounds of Optimization::GlobalBundleAdjustment (optimization_be.cpp:56-618) behind ONE call: the outlier round (:62-265,
+ * max_num_iterations = 5, loop edges without loss), the erase decisions (:270-290), and the main round (:296-567) on the problem the
+ * reference REBUILDS from the map after erasing — here derived on the device from the resident first round: the observation stream
+ * minus the erased observations, minus the landmarks left with fewer than two (:428-440), the loop edges' loss switched on (:555),
+ * optionally more constant poses (:338-341); restarted from the same initial estimate (the outlier round's is discarded, as in the
+ * reference). One Map -> IR flatten and one upload per call instead of two.
+ *   p            the FIRST round's problem (edge_loss_a as the first round wants it: 0). On return kf_pose / kf_speed_bias hold
+ *                the second round's estimate, lm_pos[l] the second round's for every landmark with lm_left[l] >= 2
+ *   opt          options of the second round (max_iterations = opt.gba_iteration_limit)
+ *   obs_erase, lm_left, counts   as covgpu_outlier_pass, for the caller's map bookkeeping (kf->EraseLandmark, lm->EraseObservation)
+ *   round1, round2 (may be NULL)  the two trust-region records; round2->t_upload_s = seconds of the device-side rebuild          */
+typedef struct covgpu_two_round {
+  double  outlier_threshold;         /* opt.th_gba_outlier_global (config_backend.yaml:121)                                  */
+  int32_t round1_iterations;         /* 5 (optimization_be.cpp:262); <= 0: 5                                                 */
+  int32_t use_loops_round2;          /* opt.gba_use_map_loop_constraints (:534)                                              */
+  double  loop_loss_round2;          /* Cauchy scale of the loop edges in the second round: 1.0 (:555)                       */
+  const uint8_t* kf_fixed_round2;    /* [num_kf] constant poses of the second round (opt.gba_fix_poses_loaded_maps, :338-341) or NULL: as round 1 */
+} covgpu_two_round;
+int covgpu_gba_two_round(covgpu_context* ctx, const covgpu_options* opt, covgpu_problem* p, const covgpu_two_round* tr,
+                         uint8_t* obs_erase /* [O] */, int32_t* lm_left /* [L] */, int64_t* counts /* [2] or NULL */,
+                         covgpu_result* round1, covgpu_result* round2);
+
 /* Covisibility recount on the resident problem (Keyframe::UpdateCovisibilityConnections, keyframe_be.cpp:559-608; run over all
  * keyframes after a GBA, backend.cpp:164-167): weight(i, j) = number of landmarks both keyframes observe.
  * Pairs with weight >= threshold (sys.covis_thres) are returned as kf_i > kf_j, sorted by (kf_i, kf_j); constant keyframes

@@ -61,6 +61,9 @@ struct Params {
   int n_gpus = 1;
   std::vector<int> devices;
   int flatten_threads = 0;  // host threads of the Map -> IR walk over landmarks; 0 = sys.threads_server-like default (hardware, <= 16)
+  // GlobalBundleAdjustment with outlier removal: derive the second round's problem on the device from the resident first round
+  // (covgpu_gba_two_round: ONE Map -> IR walk and ONE upload per call); 0: the reference's literal sequence — walk, solve, erase, walk, solve
+  int device_second_round = 1;
   // (IMU noise and gravity are NOT parameters: every IMU factor carries its keyframe's own VICalibration values,
   //  Types::imu_calib, as the reference's per-keyframe preintegrators do — keyframe_be.cpp:187-195.)
 };
@@ -415,6 +418,11 @@ class OptimizationT {
     }
     return h.ctx;
   }
+  // wall milliseconds of the stages of the calling thread's last GlobalBundleAdjustment call (measurement hook; no effect on the call)
+  static std::vector<std::pair<std::string, double>>& last_stages() {
+    static thread_local std::vector<std::pair<std::string, double>> v;
+    return v;
+  }
   // one GBA solve (+ optionally the outlier decisions at its estimate): one GPU through the thread's context, or sharded
   static void SolveGBA(covgpu_context* ctx, covgpu_options& o, covgpu_problem& p, covgpu_result& r, std::vector<uint8_t>* erase,
                        std::vector<int32_t>* lm_left, int64_t* counts) {
@@ -439,14 +447,87 @@ class OptimizationT {
     std::printf("+++ GBA: Start +++\n");
     const bool tim = std::getenv("COVGPU_FLATTEN_TIMING") != nullptr;   // per-stage wall times of the call on stderr
     auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) {
-      if (!tim) return;
+    last_stages().clear();
+    auto lap = [&](const char* what) {   // (two clock reads per stage: kept for last_stages(), printed on request)
       const auto t = std::chrono::steady_clock::now();
-      std::fprintf(stderr, "[covins_gpu] GBA call %-34s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+      const double ms = std::chrono::duration<double, std::milli>(t - t_last).count();
+      last_stages().emplace_back(what, ms);
+      if (tim) std::fprintf(stderr, "[covins_gpu] GBA call %-34s %7.2f ms\n", what, ms);
       t_last = t;
     };
     covgpu_context* ctx = Context();
     lap("context");
+    if (outlier_removal && params().device_second_round && params().n_gpus <= 1) {
+      // Both rounds behind one call. The first round's problem is walked once (:80-254); the outlier round, the erase decisions
+      // (:270-290) and the rebuilt second-round problem (:296-557) stay on the device; the map is brought to the state the reference
+      // leaves: observations erased (:281-289), the second round's estimate written back (:572-609), Map::Clean (:614).
+      const Params& prm = params();
+      detail::Flat f; Index ix;
+      FlattenGBA(map, visual_only, false, f, ix);
+      lap("Map -> IR (once)");
+      std::vector<uint8_t> fixed2;
+      if (prm.gba_fix_poses_loaded_maps) {   // :338-341
+        fixed2.assign(f.fixed.begin(), f.fixed.end());
+        for (size_t k = 0; k < ix.kfs.size(); ++k) if (ix.kfs[k]->is_loaded_) fixed2[k] = 1;
+      }
+      covgpu_two_round tr;
+      tr.outlier_threshold = prm.th_gba_outlier_global; tr.round1_iterations = 5; tr.use_loops_round2 = prm.gba_use_map_loop_constraints ? 1 : 0;
+      tr.loop_loss_round2 = 1.0; tr.kf_fixed_round2 = fixed2.empty() ? nullptr : fixed2.data();
+      covgpu_problem p = f.view();
+      covgpu_options o = Options(interations_limit, visual_only);
+      covgpu_result r1, r2;
+      std::vector<uint8_t> erase(f.obs_kf.size() + 1);
+      std::vector<int32_t> lm_left(ix.lms.size() + 1);
+      int64_t counts[2] = {0, 0};
+      if (covgpu_gba_two_round(ctx, &o, &p, &tr, erase.data(), lm_left.data(), counts, &r1, &r2) != COVGPU_OK) detail::fatal(covgpu_last_error());
+      lap("upload + both rounds on the device");
+      size_t num_bad = 0, lms2 = 0;
+      for (size_t l = 0; l < ix.lms.size(); ++l) {
+        for (int32_t i = f.obs_ptr[l]; i < f.obs_ptr[l + 1]; ++i)
+          if (erase[i]) {  // :281-289
+            const KeyframePtr& kf = ix.kfs[f.obs_kf[i]];
+            kf->EraseLandmark(ix.obs_feat[i]);
+            ix.lms[l]->EraseObservation(kf);
+            ++num_bad;
+          }
+        lms2 += lm_left[l] >= 2 ? 1 : 0;
+      }
+      std::printf("--> GBA removed %zu of %zu observations\n", num_bad, f.obs_kf.size() * 2);
+      std::printf("--> KFs: %zu\n--> LMs: %zu\n", ix.kfs.size(), lms2);
+      lap("erase observations");
+      if (r2.termination == 4) std::fprintf(stderr, "[covins_gpu] GBA: linear solve failed, keeping the last accepted estimate (as ceres::Solve would)\n");
+      if (r2.reserved > 0) std::fprintf(stderr, "[covins_gpu] GBA: %d IMU factors without a positive definite covariance carry no weight\n", r2.reserved);
+      for (size_t k = 0; k < ix.kfs.size(); ++k) {  // :572-595
+        KeyframePtr& kf = ix.kfs[k];
+        TransformType T;
+        detail::pose_to_transform(&f.pose[7 * k], T);
+        kf->SetPoseTws(T);
+        kf->SetPoseOptimized();
+        if (!visual_only) {
+          const double* s = &f.sb[9 * k];
+          Vector3Type vel, bA, bG;
+          for (int i = 0; i < 3; ++i) { vel[i] = s[i]; bA[i] = s[3 + i]; bG[i] = s[6 + i]; }
+          kf->SetStateBias(bA, bG);
+          kf->SetStateVelocity(vel);
+          kf->SetVelBiasOptimized();
+        }
+        kf->is_gba_optimized_ = true;
+      }
+      for (size_t l = 0; l < ix.lms.size(); ++l) {  // :598-609 — the landmarks of the SECOND round (:428-440: two observations left)
+        if (lm_left[l] < 2) continue;
+        Vector3Type pw;
+        for (int i = 0; i < 3; ++i) pw[i] = f.lm[3 * l + i];
+        ix.lms[l]->SetWorldPos(pw);
+        ix.lms[l]->SetOptimized();
+        ix.lms[l]->is_gba_optimized_ = true;
+      }
+      lap("write-back");
+      std::printf("--> Clean Map\n");
+      map->Clean();  // :614
+      lap("Map::Clean");
+      std::printf("--> done.\n+++ GBA: End +++\n");
+      return;
+    }
     if (outlier_removal) {  // first round (:62-293)
       detail::Flat f; Index ix;
       FlattenGBA(map, visual_only, false, f, ix);

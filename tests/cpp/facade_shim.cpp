@@ -129,6 +129,16 @@ void shim_set_params(int strategy, const char* placerec_type) {
 }
 // n > 1: GlobalBundleAdjustment shards the map over n in-process ranks, all on HIP device `device` (virtual ranks: the one-GPU form)
 void shim_set_gpus(int n, int device) { Opt::params().n_gpus = n; Opt::params().devices.assign((size_t)(n > 1 ? n : 0), device); }
+// stages of the last GlobalBundleAdjustment call of this thread: fills name (<= 63 chars each, 64-byte slots) / ms, returns the count
+int shim_last_stages(char* names, double* ms, int cap) {
+  int n = 0;
+  for (auto& st : Opt::last_stages()) {
+    if (n >= cap) break;
+    std::snprintf(names + 64 * n, 64, "%s", st.first.c_str()); ms[n] = st.second; ++n;
+  }
+  return n;
+}
+void shim_set_device_second_round(int on) { Opt::params().device_second_round = on; }
 void shim_set_invalid(Handle* h, int kf) { h->kfs[kf]->SetInvalid(); }
 
 // OptimizeRelativePose between two keyframes of the map: matches1[i] = the landmark of kf2 matched to feature i of kf1 (here:

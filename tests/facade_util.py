@@ -28,6 +28,7 @@ def lib():
         _LIB.shim_set_flatten_threads.argtypes = [C.c_int]
         _LIB.shim_set_gpus.argtypes = [C.c_int, C.c_int]
         _LIB.shim_set_invalid.argtypes = [C.c_void_p, C.c_int]
+        _LIB.shim_set_device_second_round.argtypes = [C.c_int]
     return _LIB
 
 
@@ -82,6 +83,18 @@ class StandinMap:
 
     def gba(self, iterations, visual_only=False, outlier_removal=True):
         lib().shim_gba(self.h, int(iterations), int(visual_only), int(outlier_removal))
+
+    @staticmethod
+    def last_stages():
+        """{stage: ms} of this thread's last GlobalBundleAdjustment call through the facade."""
+        names = C.create_string_buffer(64 * 16); ms = (C.c_double * 16)()
+        lib().shim_last_stages.restype = C.c_int
+        n = lib().shim_last_stages(names, ms, 16)
+        out = {}
+        for i in range(n):
+            k = names.raw[64 * i:64 * i + 64].split(b"\0")[0].decode()
+            out[k] = out.get(k, 0.0) + ms[i]
+        return out
 
     def pgo(self, corrected):
         idx = np.ascontiguousarray(list(corrected.keys()), dtype=np.int32)

@@ -93,6 +93,32 @@ def test_visual_only_gba_and_equidistant_camera():
     assert ate(me) < 0.01
 
 
+@pytest.mark.parametrize("fix_loaded", [False, True])
+def test_device_second_round_equals_the_literal_two_flatten_sequence(small_map, fix_loaded):
+    """covgpu_gba_two_round derives the second round's problem on the device from the resident first round (observation stream
+    compacted by the erase flags, landmarks left with fewer than two dropped, loop loss switched on, optionally more constant poses).
+    It must leave the map where the reference's literal sequence leaves it: flatten, solve 5, erase, flatten AGAIN, solve 10
+    (optimization_be.cpp:62-293 then :296-610)."""
+    from covins_amd.optimization import OptParams
+    prm = OptParams(gba_fix_poses_loaded_maps=fix_loaded)
+    a, b = small_map.copy(), small_map.copy()
+    if fix_loaded:
+        for m in (a, b):
+            m.kf_loaded[: m.K // 3] = True
+    ia = Optimization.GlobalBundleAdjustment(a, 10, -1.0, False, True, False, params=prm, device_second_round=True)
+    ib = Optimization.GlobalBundleAdjustment(b, 10, -1.0, False, True, False, params=prm, device_second_round=False)
+    assert ia["outliers_removed"] == ib["outliers_removed"] > 0
+    assert ia["problem"] == ib["problem"], (ia["problem"], ib["problem"])
+    assert ia["round2"].iterations == ib["round2"].iterations
+    assert list(ia["round2"].accepted_trace[:10]) == list(ib["round2"].accepted_trace[:10])
+    assert np.allclose(np.array(ia["round2"].cost_trace[:ia["round2"].iterations]), np.array(ib["round2"].cost_trace[:ib["round2"].iterations]), rtol=1e-12)
+    assert np.array_equal(a.lm_invalid, b.lm_invalid) and np.array_equal(a.lm_gba_optimized, b.lm_gba_optimized)
+    assert np.abs(a.kf_pose - b.kf_pose).max() < 1e-10 and np.abs(a.kf_velocity - b.kf_velocity).max() < 1e-10
+    assert np.abs(a.lm_pos - b.lm_pos).max() < 1e-9
+    print(f"device second round: {ia['outliers_removed']} observations erased, problem {ia['problem']}, "
+          f"stages {dict((k, round(v, 4)) for k, v in ia['stages_s'].items())} vs literal {dict((k, round(v, 4)) for k, v in ib['stages_s'].items())}")
+
+
 def test_twelve_agent_map_runs_on_one_gpu():
     """BASELINE configs[4] shape at 12 x 1000 keyframes (1.1M landmarks, 5.4M observations) on ONE GPU (VERDICT r01 item 6 /
     row J1): no K^2 allocation is left (the system lives in the fronts of the nested-dissection tree), so the footprint reported by the

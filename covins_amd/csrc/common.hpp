@@ -381,6 +381,11 @@ struct NdDev {
   int *ext = nullptr;                      // extend-add work lists: (node, tile row, tile column) of 64x64 tiles
   int *top_var = nullptr, *top_r = nullptr, *top_g = nullptr;  // per scalar unknown of the top nodes: variable | component | solution index
   int ntop = 0;
+  // sharded solve: what the ranks exchange of the top fronts = their LIVE LOWER-TRIANGULAR 128x128 tiles, packed (the fronts are stored
+  // as full squares: the upper triangle and the dead tiles are never read). top_tiles: (node, tile row, tile column) triples;
+  // top_pack: [n_top_tiles][128][128 tiles | top right-hand sides | grad, hdiag of the top unknowns] — one all-reduce
+  int* top_tiles = nullptr; int n_top_tiles = 0; double* top_pack = nullptr;
+  std::vector<int> h_top_tiles;
   // sharded solve: [top fronts | top right-hand sides | grad, hdiag of the top unknowns] is ONE contiguous range of the buffer
   size_t M_sub = 0, rhs_top = 0, gh_off = 0;   // elements of the subtree fronts | of the top levels' right-hand sides | offset of [grad | hdiag] in nd_rhs
   // host staging of the tables (filled by nd_tables, uploaded by solver.hip)

@@ -77,6 +77,12 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& 
       for (int v : hp.strct[n]) for (int r = 0; r < NdHostPlan::vdim(v); ++r) dev.h_gidx.push_back(gidx_of(v, r));
       L.live_h.push_back((hp.own_dims[n] + kTile - 1) / kTile);
       L.live_h.push_back(nO / kTile);
+      if (is_top(n)) {   // live lower-triangular tiles of a replicated front: what a sharded solve exchanges (same liveness as k_nd_zero)
+        const int nIt = L.nI / kTile, lo2 = 2 * ((hp.own_dims[n] + 2 * kTile - 1) / (2 * kTile)), lb = (hp.st_dims[n] + kTile - 1) / kTile;
+        auto live = [&](int t) { return t < lo2 || (t >= nIt && t - nIt < lb); };
+        const int Tn = ld[i] / kTile;
+        for (int tr = 0; tr < Tn; ++tr) for (int tc = 0; tc <= tr; ++tc) if (live(tr) && live(tc)) { dev.h_top_tiles.push_back(i); dev.h_top_tiles.push_back(tr); dev.h_top_tiles.push_back(tc); }
+      }
       if (is_top(n))
         for (int v : hp.own[n]) for (int r = 0; r < NdHostPlan::vdim(v); ++r) { dev.h_top_var.push_back(v); dev.h_top_r.push_back(r); dev.h_top_g.push_back(gidx_of(v, r)); }
       ++i;
@@ -324,6 +330,19 @@ __global__ __launch_bounds__(256) void k_nd_gh(DevProblem P, const int* __restri
   if (dir == 0) { buf[i] = P.grad[q]; buf[ntop + i] = P.hdiag[q]; }
   else { P.grad[q] = buf[i]; P.hdiag[q] = buf[ntop + i]; }
 }
+// sharded solve: the live lower tiles of the top fronts <-> the packed exchange buffer (dir 0: pack, 1: unpack). One workgroup per tile.
+__global__ __launch_bounds__(256) void k_nd_top_pack(DevProblem P, const int* __restrict__ tiles, double* __restrict__ pack, int dir) {
+  const int node = tiles[3 * blockIdx.x], tr = tiles[3 * blockIdx.x + 1], tc = tiles[3 * blockIdx.x + 2];
+  const size_t ld = (size_t)P.nd_ntab[2 * node + 1];
+  double* M = P.nd_M + P.nd_ntab[2 * node] + (size_t)tr * kTile * ld + (size_t)tc * kTile;
+  double* B = pack + (size_t)blockIdx.x * kTile * kTile;
+  for (int e = threadIdx.x; e < kTile * kTile / 2; e += 256) {
+    const int r = e / (kTile / 2), c2 = 2 * (e - r * (kTile / 2));
+    double2* m = reinterpret_cast<double2*>(M + (size_t)r * ld + c2);
+    double2* b = reinterpret_cast<double2*>(B + (size_t)r * kTile + c2);
+    if (dir == 0) *b = *m; else *m = *b;
+  }
+}
 // sharded solve: trust-region damping of the top unknowns, applied to the all-reduced top fronts with the all-reduced
 // diag(J^T J) (k_finalize_diag leaves them out: every rank holds only its part of their rows before the exchange)
 __global__ __launch_bounds__(256) void k_nd_top_damp(DevProblem P, const int* __restrict__ top_var, const int* __restrict__ top_r,
@@ -438,7 +457,18 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     for (int l = ltop; l < nlev; ++l) extend(l, false, 0, st);
     double* gh = P.nd_rhs + nd.gh_off;
     if (nd.ntop > 0) hipLaunchKernelGGL(k_nd_gh, dim3((nd.ntop + 255) / 256), dim3(256), 0, st, P, (const int*)nd.top_g, nd.ntop, gh, 0);
-    if (ax.reduce != nullptr) ax.reduce(ax.reduce_ctx, P.nd_M + nd.M_sub, (nd.M_elems - nd.M_sub) + nd.rhs_top + 2 * (size_t)nd.ntop, 0, st);
+    if (ax.reduce != nullptr) {
+      // ONE all-reduce of [live lower tiles of the top fronts, packed | top right-hand sides | grad, hdiag of the top unknowns]: the
+      // fronts are stored as full squares, of which the exchange needs half (33.6 -> 17.9 MB for the 5-agent map's root)
+      const size_t ntile = (size_t)nd.n_top_tiles * kTile * kTile, nvec = nd.rhs_top + 2 * (size_t)nd.ntop;
+      if (nd.top_pack != nullptr) {
+        if (nd.n_top_tiles > 0) hipLaunchKernelGGL(k_nd_top_pack, dim3(nd.n_top_tiles), dim3(256), 0, st, P, (const int*)nd.top_tiles, nd.top_pack, 0);
+        if (nvec > 0) (void)hipMemcpyAsync(nd.top_pack + ntile, P.nd_rhs, nvec * sizeof(double), hipMemcpyDeviceToDevice, st);
+        ax.reduce(ax.reduce_ctx, nd.top_pack, ntile + nvec, 0, st);
+        if (nd.n_top_tiles > 0) hipLaunchKernelGGL(k_nd_top_pack, dim3(nd.n_top_tiles), dim3(256), 0, st, P, (const int*)nd.top_tiles, nd.top_pack, 1);
+        if (nvec > 0) (void)hipMemcpyAsync(P.nd_rhs, nd.top_pack + ntile, nvec * sizeof(double), hipMemcpyDeviceToDevice, st);
+      } else ax.reduce(ax.reduce_ctx, P.nd_M + nd.M_sub, (nd.M_elems - nd.M_sub) + nd.rhs_top + 2 * (size_t)nd.ntop, 0, st);   // (whole squares: COVGPU_SHARD_PACK=0)
+    }
     if (nd.ntop > 0) {
       hipLaunchKernelGGL(k_nd_gh, dim3((nd.ntop + 255) / 256), dim3(256), 0, st, P, (const int*)nd.top_g, nd.ntop, gh, 1);
       hipLaunchKernelGGL(k_nd_top_damp, dim3((nd.ntop + 255) / 256), dim3(256), 0, st, P, (const int*)nd.top_var, (const int*)nd.top_r, (const int*)nd.top_g, nd.ntop,

@@ -391,7 +391,7 @@ extern "C" void covgpu_get_layout(covgpu_context* c, int64_t* out) {
   const DevProblem& P = c->P;
   out[0] = c->sharded ? c->world : 0; out[1] = c->sharded ? c->rank : 0; out[2] = c->nd.ntop;   // ranks | rank | scalar unknowns of the replicated top nodes
   out[3] = (int64_t)c->nd.lev.size() - c->nd.top_lev0;                                          // top levels
-  out[4] = (int64_t)(((c->nd.M_elems - c->nd.M_sub) + c->nd.rhs_top + 2 * (size_t)c->nd.ntop) * sizeof(double)) >> 10;  // KiB all-reduced per linear solve
+  out[4] = (int64_t)(((c->nd.top_pack != nullptr ? (size_t)c->nd.n_top_tiles * kTile * kTile : c->nd.M_elems - c->nd.M_sub) + c->nd.rhs_top + 2 * (size_t)c->nd.ntop) * sizeof(double)) >> 10;  // KiB all-reduced per linear solve
   out[6] = P.npad; out[7] = P.npairs; out[8] = P.nepairs; out[9] = P.nchains; out[10] = (int64_t)(c->alloc_bytes >> 20);
   if (P.nd) {  // multifrontal form: nodes, levels, serial 256-column panels (sum of the levels' interior orders / 256), root order, front bytes (MiB)
     out[11] = P.nd_nnodes; out[12] = P.nd_nlev;
@@ -901,6 +901,12 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
         }
         RC(dev_upload(c, &P.vw, vw.data(), vw.size()));
         RC(dev_alloc(c, &c->d_red, (size_t)SC_COUNT + 2 * (size_t)c->world));
+        static const bool pack_on = getenv("COVGPU_SHARD_PACK") == nullptr || atoi(getenv("COVGPU_SHARD_PACK")) != 0;
+        nd.n_top_tiles = (int)(nd.h_top_tiles.size() / 3);
+        if (pack_on) {
+          RC(dev_upload(c, &nd.top_tiles, nd.h_top_tiles.data(), nd.h_top_tiles.size()));
+          RC(dev_alloc(c, &nd.top_pack, (size_t)nd.n_top_tiles * kTile * kTile + nd.rhs_top + 2 * (size_t)nd.ntop));
+        }
         RC(dev_alloc(c, &P.scal_r, (size_t)SC_COUNT)); RC(dev_alloc(c, &P.flag_r, (size_t)4));
       }
       HIPCHK(hipStreamSynchronize(c->st));

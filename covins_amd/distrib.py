@@ -75,6 +75,29 @@ def shard_plan(prob: FlatProblem, opt: Options, world: int) -> Optional[ShardPla
     return ShardPlan(h, int(world), int(n), lr[:prob.L].copy(), ir[:prob.I].copy(), er[:prob.E].copy(), pr, sr, nr)
 
 
+def plan_digest(plan: ShardPlan) -> str:
+    """sha256 over everything that shapes the exchange: tree node -> rank, owner of every landmark / IMU factor / between factor, owner of
+    every keyframe's pose and speed-bias block."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(np.int64([plan.world, plan.subtrees]).tobytes())
+    for a in (plan.node_rank, plan.lm_rank, plan.imu_rank, plan.edge_rank, plan.pose_rank, plan.sb_rank):
+        a = np.ascontiguousarray(a, np.int32)
+        h.update(np.int64([a.size]).tobytes()); h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def check_plan_digest(store, rank: int, world: int, mine: str) -> None:
+    """Every rank publishes its digest and reads everybody's: ALL ranks raise on a mismatch (nobody is left waiting in a collective)."""
+    from . import backend
+    store.set(f"plan_digest_{rank}", mine.encode())
+    for r in range(world):
+        other = bytes(store.get(f"plan_digest_{r}")).decode()
+        if other != mine:
+            raise backend.CovGpuError(f"rank {rank}: shard plan digest {mine[:16]}.. differs from rank {r}'s {other[:16]}..: the ranks did not "
+                                      "compute the same plan (different problem or options) — aborting before any collective is issued")
+
+
 def shard_problem(prob: FlatProblem, plan: ShardPlan, rank: int) -> FlatProblem:
     """Rank `rank`'s share: every keyframe (states are replicated, 128 B each), its landmarks with their observations,
     its IMU factors, its between factors."""
@@ -152,6 +175,9 @@ def attach(ctx, plan: ShardPlan, rank: int, world: int, force_single: bool = Fal
         ctx.set_shard_group(plan, 0, g)
         return (g,)
     store = open_store(rank, world)
+    # every rank computed the plan ITSELF from its copy of the problem: a rank whose copy differs (another map revision, another
+    # option, a non-deterministic generator) would exchange fronts of another shape and hang or corrupt the solve. Digests first.
+    check_plan_digest(store, rank, world, plan_digest(plan))
     if rank == 0:
         buf = (C.c_uint8 * 128)()
         rc = backend.lib().covgpu_rccl_unique_id(buf)

@@ -25,6 +25,15 @@ if __name__ == "__main__":
     assert len(got) == world
     for r, (kp, ks, lp) in enumerate(got):
         assert (kp == r).all() and (ks == 10.0 + r).all() and (lp == 100.0 + r).all()
+    # the shard-plan digest exchange of distrib.attach: equal digests pass; with COVGPU_TEST_BAD_DIGEST=1 rank 1 publishes another one and
+    # EVERY rank must refuse
+    digest = "a" * 64 if not (os.environ.get("COVGPU_TEST_BAD_DIGEST") == "1" and rank == 1) else "b" * 64
+    refused = False
+    try:
+        distrib.check_plan_digest(store, rank, world, digest)
+    except Exception as e:
+        refused = "digest" in str(e)
+    assert refused == (os.environ.get("COVGPU_TEST_BAD_DIGEST") == "1"), "plan digest check"
     out = os.environ["COVGPU_TEST_OUT"]
     with open(f"{out}.{rank}", "w") as f:
         f.write(hashlib.sha256(uid).hexdigest())

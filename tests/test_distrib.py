@@ -171,6 +171,25 @@ def test_store_rendezvous_launched_by_hand(tmp_path):
     assert h[0] == h[1] and len(h[0]) == 64
 
 
+def test_ranks_with_different_shard_plans_refuse_before_any_collective(tmp_path):
+    """distrib.attach exchanges a digest of the shard plan every rank computed for itself: a rank whose plan differs (another map
+    revision, another option) makes EVERY rank raise before a communicator exists — instead of hanging in the first all-reduce."""
+    import subprocess
+    import sys
+    port = 29500 + 6000 + (os.getpid() % 2000)
+    out = str(tmp_path / "store")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "store_worker.py")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, COVGPU_TEST_OUT=out, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   COVGPU_TEST_BAD_DIGEST="1")
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        procs.append(subprocess.Popen([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for pr in procs:
+        _, err = pr.communicate(timeout=300)
+        assert pr.returncode == 0, err[-2000:]   # (the worker asserts that its rank refused)
+
+
 def test_single_process_is_identity():
     assert distrib.aggregate(0.5, 7, None, False) == (0.5, 7.0)
     assert distrib.throughput(2.0, 10.0) == 5.0

@@ -181,6 +181,7 @@ enum { SC_COST = 0, SC_JV2 = 1, SC_GG = 2, SC_GN2 = 3, SC_GDOT = 4, SC_GMAX = 5,
 struct CholAux;
 // ---- launchers (each enqueues on `st`, no synchronisation)
 void launch_kobs_build(const DevProblem& P, int* pair_oa, int* pair_ob, size_t nent, hipStream_t st);  // upload: keyframe-major copies, Z slots, pair lists -> Z slots
+void launch_lm_lin(const DevProblem& P, double mu, hipStream_t st);   // landmark-major linearisation: records, H_ll, g_l, cost partials
 void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared = nullptr, hipStream_t side = nullptr,
                      hipEvent_t ev_lin = nullptr, hipEvent_t ev_kf = nullptr);  // reprojection -> Hll, g, S (Schur), bred, cost
 void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st);

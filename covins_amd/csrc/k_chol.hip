@@ -711,7 +711,8 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       }
     }
     (void)hipEventRecord(eB[P], B);
-    if (ax.pipe_flags != nullptr) { bulk_done_tag = ++ax.bulk_tag; launch_flag_set(ax.pipe_flags + 17 * CholAux::kPipeFronts, bulk_done_tag, B); }   // bulk(P) is done: the next follower's last act may go ahead
+    static const bool pipe_flagged = getenv("COVGPU_PIPE") != nullptr && atoi(getenv("COVGPU_PIPE")) != 0;
+    if (pipe_flagged && ax.pipe_flags != nullptr) { bulk_done_tag = ++ax.bulk_tag; launch_flag_set(ax.pipe_flags + 17 * CholAux::kPipeFronts, bulk_done_tag, B); }   // bulk(P) is done: the next follower's last act may go ahead
   }
   if (!split_last && !tail_on_chain) wait(M, eB[Plast]);
   if (Plast >= 1) wait(M, eB[Plast - 1]);

@@ -201,16 +201,24 @@ struct NdLevArgs {
 // tile; dead tiles exit at once. Touched: the lower triangle over [interior tiles up to the last big panel that holds a real
 // column | real border tiles] (a half-padded 256-column panel is read whole by the panel kernels), and the 2x2 diagonal
 // tiles of the all-padding panels (k_potrf_panel factors every panel of every front of the batch).
-__global__ __launch_bounds__(256) void k_nd_zero(DevProblem P, NdLevArgs a) {
-  const int node = a.first + blockIdx.z, tr = blockIdx.y, tc = blockIdx.x;
+// (ONE launch over the tiles of all levels — a level per launch was seven dependent host enqueues at the head of every linearisation,
+//  with the chip idle behind them: blocks [blk0[l], blk0[l + 1]) belong to level l, tile (tr, tc) of its front number `fz`)
+struct NdZeroArgs { int nlev; int first[24], n[24], nI[24], T[24]; long long blk0[25]; const int *own_dims, *st_dims; };
+__global__ __launch_bounds__(256) void k_nd_zero(DevProblem P, NdZeroArgs z) {
+  int l = 0;
+  while (l + 1 < z.nlev && (long long)blockIdx.x >= z.blk0[l + 1]) ++l;
+  const int T = z.T[l];
+  const int q = (int)((long long)blockIdx.x - z.blk0[l]);
+  const int fz = q / (T * T), rem = q - fz * T * T, tr = rem / T, tc = rem - tr * T;
   if (tc > tr) return;
-  const int nIt = a.nI / kTile, lo2 = 2 * ((a.own_dims[node] + 2 * kTile - 1) / (2 * kTile)), lb = (a.st_dims[node] + kTile - 1) / kTile;
+  const int node = z.first[l] + fz;
+  const int nIt = z.nI[l] / kTile, lo2 = 2 * ((z.own_dims[node] + 2 * kTile - 1) / (2 * kTile)), lb = (z.st_dims[node] + kTile - 1) / kTile;
   auto live = [&](int t) { return t < lo2 || (t >= nIt && t - nIt < lb); };
   const bool pad_diag = tr >= lo2 && tr < nIt && tc >= (tr & ~1);
   if (!((live(tr) && live(tc)) || pad_diag)) return;
   const size_t ld = (size_t)P.nd_ntab[2 * node + 1];
   double* M = P.nd_M + P.nd_ntab[2 * node] + (size_t)tr * kTile * ld + (size_t)tc * kTile;
-  const int own = a.own_dims[node];
+  const int own = z.own_dims[node];
   for (int e = threadIdx.x; e < kTile * kTile / 2; e += 256) {
     const int r = e / (kTile / 2), c2 = 2 * (e - r * (kTile / 2));
     double2 v = {0.0, 0.0};
@@ -367,12 +375,23 @@ void launch_nd_init(const DevProblem& P, const NdDev& nd, hipStream_t st) {
 }
 
 void launch_nd_zero(const DevProblem& P, const NdDev& nd, hipStream_t st) {
+  NdZeroArgs z;
+  z.nlev = 0; z.blk0[0] = 0; z.own_dims = nd.own_dims; z.st_dims = nd.st_dims;
+  auto flush = [&] {
+    if (z.nlev > 0 && z.blk0[z.nlev] > 0) hipLaunchKernelGGL(k_nd_zero, dim3((unsigned)z.blk0[z.nlev]), dim3(256), 0, st, P, z);
+    z.nlev = 0; z.blk0[0] = 0;
+  };
   for (size_t l = 0; l < nd.lev.size(); ++l) {
     const NdLevel& L = nd.lev[l];
     if (L.n == 0) continue;
     const int T = L.ntot / kTile;
-    hipLaunchKernelGGL(k_nd_zero, dim3(T, T, L.n), dim3(256), 0, st, P, lev_args(P, nd, (int)l));
+    const long long nb = (long long)T * T * L.n;
+    if (z.nlev == 24 || z.blk0[z.nlev] + nb > 0x7fffff00ll) flush();   // (more than 24 levels / 2^31 blocks: another launch)
+    z.first[z.nlev] = L.first; z.n[z.nlev] = L.n; z.nI[z.nlev] = L.nI; z.T[z.nlev] = T;
+    z.blk0[z.nlev + 1] = z.blk0[z.nlev] + nb;
+    ++z.nlev;
   }
+  flush();
 }
 
 bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hipStream_t st, CholAux& ax) {

@@ -402,10 +402,17 @@ constexpr int kG = 16;
 // side != nullptr: the per-keyframe reduction (diagonal blocks, gradient, right-hand side: compute-heavy re-linearisation) runs on the
 // side stream beside the pair pass (off-diagonal blocks: L2-bound record reads) — both follow the landmark pass only and write
 // disjoint entries; whatever comes next on `st` follows both.
+// first pass alone (per-observation records, per-landmark blocks, cost partials: touches nothing of the pose system) — the caller
+// enqueues it ahead of the clearing of the fronts
+void launch_lm_lin(const DevProblem& P, double mu, hipStream_t st) {
+  if (P.L == 0) return;
+  const int groups = kBuildThreads / kG, nblk = (P.L + groups - 1) / groups;
+  hipLaunchKernelGGL(k_lm_lin<kG>, dim3(nblk), dim3(kBuildThreads), 0, st, P, mu);
+}
+// the two passes that write the pose system, behind launch_lm_lin on `st`
 void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared, hipStream_t side, hipEvent_t ev_lin, hipEvent_t ev_kf) {
   if (P.L == 0) { if (pose_system_cleared) (void)hipStreamWaitEvent(st, pose_system_cleared, 0); return; }
   const int groups = kBuildThreads / kG, nblk = (P.L + groups - 1) / groups;
-  hipLaunchKernelGGL(k_lm_lin<kG>, dim3(nblk), dim3(kBuildThreads), 0, st, P, mu);  // writes per-observation records only
   const bool fork = side != nullptr && ev_lin != nullptr && ev_kf != nullptr && P.npairs > 0;
   hipStream_t s2 = fork ? side : st;
   if (fork) { (void)hipEventRecord(ev_lin, st); (void)hipStreamWaitEvent(s2, ev_lin, 0); }

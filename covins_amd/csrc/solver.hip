@@ -985,18 +985,22 @@ static void enqueue_build(covgpu_context* c, double mu) {
   // kernels and the landmark linearisation, which only write per-factor / per-observation records; its first writers
   // (k_kf_reduce ...) wait for it. Every reader of the previous system has finished: each iteration ends with a host sync.
   c->chol.init();
-  // (measured, round 4: clearing them BEHIND the previous linear solve instead — on the head stream, under the trust-region tail — takes
-  //  0.11 ms off this pass and puts 0.12 ms onto the tail and the solve: the 0.65 GB of stores contend with the tail's re-linearisations)
-  (void)hipEventRecord(c->chol.ev_fill, c->st);
-  (void)hipStreamWaitEvent(c->chol.head, c->chol.ev_fill, 0);
+  // Enqueue order = host time: every iteration starts behind a host synchronisation with the chip empty, and a launch is ~6 us of host
+  // work. The main stream's own first kernels (the small clears, the landmark linearisation: 0.17 ms, on nobody's results) go out FIRST;
+  // the clearing of the fronts (head stream) and the inertial kernels (side stream) follow underneath them. (Before: seven clearing
+  // launches ahead of everything, the linearisation started ~0.1 ms into the iteration.)
+  // (measured, round 4: clearing the fronts BEHIND the previous linear solve instead — under the trust-region tail — takes 0.11 ms off
+  //  this pass and puts 0.12 ms onto the tail and the solve: the 0.65 GB of stores contend with the tail's re-linearisations)
+  launch_zero_system(P, c->st);
+  hipStream_t side = c->chol.mid;
+  (void)hipEventRecord(c->chol.ev_zero, c->st);
+  launch_lm_lin(P, mu, c->st);   // writes per-observation records, per-landmark blocks and cost partials only
+  // (the head stream waits for nobody: every reader of the previous system has finished — each iteration ends with a host sync)
   if (P.nd) launch_nd_zero(P, c->nd, c->chol.head);
   else (void)hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), c->chol.head);
   (void)hipEventRecord(c->chol.ev_fill, c->chol.head);
-  launch_zero_system(P, c->st);
   // inertial factors (one wave per factor: latency, not throughput) on the side stream beside the landmark pass; their speed-bias
   // blocks are final before anything of the pose system is touched, the pose-dimension part is gathered after the visual blocks
-  hipStream_t side = c->chol.mid;
-  (void)hipEventRecord(c->chol.ev_zero, c->st);
   (void)hipStreamWaitEvent(side, c->chol.ev_zero, 0);
   launch_imu_build(P, side);
   if (P.vi) {

@@ -1,4 +1,4 @@
-# round-4 measurement pass (one MI355X): usage  bash tools/gpu_r04.sh <tag> [tests|bench|prof|pmc|side|all]
+# round-4 measurement pass (one MI355X): usage  bash tools/gpu_r04.sh <tag> [tests|bench|side|a12|prof|pmc|all]
 tag=${1:-r04f}; what=${2:-all}
 mkdir -p gpurun_out
 if [[ $what == tests || $what == all ]]; then
@@ -18,6 +18,11 @@ if [[ $what == side || $what == all ]]; then
   for i in 1 2; do python bench.py --force-shard --steps 8 --warmup 2 --no-e2e --no-cpu-baseline --sustain-s 0 2>/dev/null > gpurun_out/${tag}_bench_forced_shard_rccl_1rank_$i.json; python bench.py --steps 8 --warmup 2 --no-e2e --no-cpu-baseline --sustain-s 0 2>/dev/null > gpurun_out/${tag}_bench_plain_beside_$i.json; done
   COVGPU_FLATTEN_TIMING=1 python tools/cpp_flatten_time.py mh12345 5 gba 2>&1 | grep -E "GBA call|C\+\+" | tail -12 > gpurun_out/${tag}_cpp_call.txt
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 > gpurun_out/${tag}_smoke.txt; cat gpurun_out/${tag}_smoke.txt
+fi
+if [[ $what == a12 || $what == all ]]; then
+  COVGPU_TEST_A12=1 timeout 2400 python -m pytest tests/test_gpu_full.py -m gpu -q -s -k "a12" --timeout 2400 2>&1 | grep -E "passed|failed|error|Error|a12" | tail -12 > gpurun_out/${tag}_gpu_tests_a12.txt
+  tail -4 gpurun_out/${tag}_gpu_tests_a12.txt
+  COVGPU_TRACE_PANELS=1 timeout 600 python bench.py --workload a12 --steps 1 --warmup 1 --no-e2e --no-cpu-baseline --sustain-s 0 2>&1 >/dev/null | grep "covgpu marks" | tail -1 > gpurun_out/${tag}_marks_a12.txt
 fi
 if [[ $what == prof || $what == all ]]; then
   root=$(pwd); cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/ks

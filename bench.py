@@ -92,6 +92,46 @@ def _kernels_digest():
     return h.hexdigest()
 
 
+def run_a12_leg(args, rank, local_rank, world, strategy, store):
+    """BASELINE configs[4] (synthetic 12-agent map at its stated 20 004 keyframes / 2.02 M landmarks) on the ranks of this run: the ONE map
+    sharded by subtree exactly like the metric's (world 1: unsharded), one warm-up and two timed steps of 10 iterations, barrier +
+    max-over-ranks timing. Every rank generates the map itself (seeded generator) and computes the same plan."""
+    from covins_amd import backend, distrib, mapdata, synth
+    t_gen = time.perf_counter()
+    m = synth.make_map(synth.config_named("a12"))
+    full, _ = mapdata.flatten_gba(m, visual_only=False, loop_loss=True)
+    t_gen = time.perf_counter() - t_gen
+    opt = backend.default_options(strategy=strategy, max_iterations=args.iterations, device=local_rank)
+    ctx = backend.Context(local_rank)
+    try:
+        sharded = world > 1
+        prob, keep = full, None
+        if sharded:
+            plan = distrib.shard_plan(full, opt, world)
+            if plan is None:
+                return {"value": None, "error": "the map does not split"}
+            prob = distrib.shard_problem(full, plan, rank)
+            keep = distrib.attach(ctx, plan, rank, world, store=store, tag="a12")
+        t_up = time.perf_counter()
+        ctx.upload(prob, opt)
+        t_up = time.perf_counter() - t_up
+        ctx.solve_resident(opt)
+        distrib.barrier(ctx, sharded)
+        t0 = time.perf_counter(); iters = 0; steps = 2
+        for _ in range(steps):
+            res = ctx.solve_resident(opt); iters += res.iterations
+        distrib.barrier(ctx, sharded)
+        dt, iters_all = distrib.aggregate(time.perf_counter() - t0, iters, ctx, sharded)
+        lay = ctx.layout(); st = ctx.shard_stats()
+        return {"workload": f"a12: 12-agent synthetic map, K={full.K} L={full.L} O={full.O}", "value": iters_all / dt, "unit": "iterations/s", "n_gpus": world,
+                "steps": steps, "warmup": 1, "ms_per_step": dt / steps * 1e3, "scaling": "strong", "final_cost": res.final_cost, "initial_cost": res.initial_cost,
+                "layout": lay, "allreduce_mib_per_linear_solve": lay["allreduce_kib"] / 1024.0, "collectives_rank0": st["collectives"],
+                "map_generation_s": t_gen, "upload_s": t_up}
+    finally:
+        del keep
+        ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,10 +143,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-shard", action="store_true", help="run the agent-sharded path (plan, sub-problem, RCCL collectives) even on ONE GPU")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-call timing after the timed region (profiling runs)")
+    ap.add_argument("--a12-leg", type=int, default=-1, help="after the metric's workload, also time BASELINE configs[4] at its stated size (12 x 1667 keyframes, 2M landmarks) "
+                    "on the same ranks and report it as `a12_leg` (1 / 0; default: on for --gpus > 1 — the scaling curve of the configuration the north star "
+                    "names for 8 GPUs —, off for the one-GPU default run, whose a12 figure is `python bench.py --workload a12`)")
     ap.add_argument("--sustain-s", type=float, default=8.0, help="after the timed region, repeat the same steps back to back for about this many seconds, "
                     "un-timed in `value` and reported as `sustained`: long enough for an external GPU-utilisation sampler to see the device busy (0: off)")
     args = ap.parse_args()
 
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("COVGPU_COLL_TIMEOUT_S", "120")   # a collective that never completes ends the run with an error after two minutes, not a hang
     import torch
     torch.cuda.init()  # torch's bundled HIP runtime must come up BEFORE libcovgpu loads /opt/rocm's (else "No HIP GPUs"); torch is used for nothing else here
     from covins_amd import backend, capi, distrib, mapdata, synth
@@ -303,27 +348,6 @@ def main():
                                        "on the same map (median of three calls; stages of that call), host flattening in numpy; ONE flatten and ONE upload per call: the second round's "
                                        "problem is derived on the device (covgpu_gba_two_round)"}
         if not args.no_e2e:
-            # the same call through the C++ facade (include/covins_gpu/optimization_gpu.hpp — the maintainer-facing drop-in) on stand-in
-            # Map / Keyframe / Landmark objects of the same map (tests/cpp: the real COVINS classes need ROS / Eigen / OpenCV); the
-            # first call creates the thread's context and warms the library up, the second is timed
-            try:
-                from tests.facade_util import StandinMap
-                ts, stg = [], []
-                for _ in range(4):
-                    smap = StandinMap(m)
-                    t_c = time.perf_counter(); smap.gba(args.iterations); ts.append(time.perf_counter() - t_c)
-                    stg.append({k: round(v * 1e-3, 4) for k, v in StandinMap.last_stages().items()})
-                    smap.close()
-                mid = sorted(range(1, 4), key=lambda i: ts[i])[1]   # median of the three calls after the warm-up call
-                stages_cpp = stg[mid]
-                out["e2e_call_cpp"] = {"t_call_s": ts[mid], "t_calls_s": [round(t, 4) for t in ts[1:]], "t_first_call_s": ts[0], "kf_per_s_e2e": k_free / ts[mid], "stages_s": stages_cpp,
-                                       "note": "Map::Clean is the reference's own method (map_be.cpp:448-454, 698-743: it copies every landmark's observation "
-                                               "map to read its size; the stand-in mirrors that) — not part of what this build replaces",
-                                       "what": "covins_gpu::Optimization::GlobalBundleAdjustment(map, 10) through the C++ facade on stand-in map "
-                                               "objects (one Map -> IR walk, one upload, both rounds on the device, erase, write-back, Map::Clean)"}
-            except Exception as e:   # (the shim needs g++ on the box; never fatal for the metric line)
-                out["e2e_call_cpp"] = {"t_call_s": None, "error": repr(e)[:200]}
-        if not args.no_e2e:
             # side figure: one PoseGraphOptimization solve of the same map (block-arrow solve); not `value`
             popt = backend.default_options(max_iterations=pgo_prm.pgo_iteration_limit, device=local_rank)
             ctx.pgo_solve(pgo_prob, popt)
@@ -347,14 +371,47 @@ def main():
             out["delta_ate_gpu_cpu_m"] = abs(out["ate_rmse_m"]["final"] - out["cpu_baseline"]["ate_rmse_m_final"])
             out["max_pose_diff_gpu_cpu_m"] = float(np.abs(sol.kf_pose[:, 4:] - qc.kf_pose[:, 4:]).max())
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    distrib.barrier(ctx, sharded)
+    ctx.close()
+    if rank == 0 and not args.no_e2e:
+        # the same call through the C++ facade (include/covins_gpu/optimization_gpu.hpp — the maintainer-facing drop-in) on stand-in
+        # Map / Keyframe / Landmark objects of the same map (tests/cpp: the real COVINS classes need ROS / Eigen / OpenCV); the
+        # first call creates the thread's context and warms the library up. Behind ctx.close(): with the bench's own context alive the
+        # facade's streams share the runtime's four hardware queues with it (0.19 instead of 0.17 s)
+        try:
+            from tests.facade_util import StandinMap
+            ts, stg = [], []
+            for _ in range(4):
+                smap = StandinMap(m)
+                t_c = time.perf_counter(); smap.gba(args.iterations); ts.append(time.perf_counter() - t_c)
+                stg.append({k: round(v * 1e-3, 4) for k, v in StandinMap.last_stages().items()})
+                smap.close()
+            mid = sorted(range(1, 4), key=lambda i: ts[i])[1]   # median of the three calls after the warm-up call
+            stages_cpp = stg[mid]
+            out["e2e_call_cpp"] = {"t_call_s": ts[mid], "t_calls_s": [round(t, 4) for t in ts[1:]], "t_first_call_s": ts[0], "kf_per_s_e2e": int(full.K - full.kf_fixed.sum()) / ts[mid], "stages_s": stages_cpp,
+                                   "note": "Map::Clean is the reference's own method (map_be.cpp:448-454, 698-743: it copies every landmark's observation "
+                                           "map to read its size; the stand-in mirrors that) — not part of what this build replaces",
+                                   "what": "covins_gpu::Optimization::GlobalBundleAdjustment(map, 10) through the C++ facade on stand-in map "
+                                           "objects (one Map -> IR walk, one upload, both rounds on the device, erase, write-back, Map::Clean)"}
+        except Exception as e:   # (the shim needs g++ on the box; never fatal for the metric line)
+            out["e2e_call_cpp"] = {"t_call_s": None, "error": repr(e)[:200]}
+    # ---- configs[4] leg (all ranks, behind everything else and with the metric's context closed: eight live streams share the runtime's
+    #      four hardware queues and the chain and bulk streams of the second context then serialise — measured: 32.8 instead of 43.7 it/s)
+    want_leg = args.a12_leg == 1 or (args.a12_leg < 0 and world > 1 and args.workload == "mh12345")
+    if want_leg:
+        try:
+            a12_leg = run_a12_leg(args, rank, local_rank, world, strategy, keep[0] if (world > 1 and keep) else None)
+        except Exception as e:   # (never fatal for the metric line; a hang is bounded by COVGPU_COLL_TIMEOUT_S)
+            a12_leg = {"value": None, "error": repr(e)[:300]}
+        if rank == 0:
+            out["a12_leg"] = a12_leg
+    if rank == 0:
         # RCCL prints its version banner through C stdio, which would otherwise be flushed AFTER this line at exit: flush it
         # first so that the JSON line is the last thing on stdout
         import ctypes
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
-    distrib.barrier(ctx, sharded)
-    ctx.close()
 
 
 if __name__ == "__main__":

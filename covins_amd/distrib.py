@@ -155,11 +155,12 @@ class Group:
             self.handle = None
 
 
-def attach(ctx, plan: ShardPlan, rank: int, world: int, force_single: bool = False, group: Optional[Group] = None):
+def attach(ctx, plan: ShardPlan, rank: int, world: int, force_single: bool = False, group: Optional[Group] = None, store=None, tag: str = ""):
     """Gives `ctx` its collective. Real ranks (world > 1, one process per GPU): RCCL inside libcovgpu; rank 0 creates the
     unique id and passes it to the others through a torch.distributed TCPStore on MASTER_ADDR:MASTER_PORT (key exchange
     only — no torch process group, no tensor ever touches it). A one-rank run with force_single exercises the whole sharded
-    path through an in-process group of one. Returns the objects that must stay alive with the context."""
+    path through an in-process group of one. `store` / `tag`: a second context of the same process (another workload of the same bench run)
+    reuses the first one's store under its own key names. Returns the objects that must stay alive with the context."""
     if group is not None:
         ctx.set_shard_group(plan, rank, group)
         return (group,)
@@ -174,7 +175,11 @@ def attach(ctx, plan: ShardPlan, rank: int, world: int, force_single: bool = Fal
         g = Group(1)
         ctx.set_shard_group(plan, 0, g)
         return (g,)
-    store = open_store(rank, world)
+    if store is None:
+        store = open_store(rank, world)
+    else:
+        from torch.distributed import PrefixStore
+        store = PrefixStore(f"{tag}/", store)
     # every rank computed the plan ITSELF from its copy of the problem: a rank whose copy differs (another map revision, another
     # option, a non-deterministic generator) would exchange fronts of another shape and hang or corrupt the solve. Digests first.
     check_plan_digest(store, rank, world, plan_digest(plan))

@@ -114,3 +114,42 @@ def test_single_keyframe_and_two_keyframe_problems(ctx, tiny_map):
     from scipy.spatial.transform import Rotation as R
     Ra = R.from_quat(sol.kf_pose[0, :4])
     assert np.allclose(Ra.inv().apply(sol.kf_pose[1, 4:] - sol.kf_pose[0, 4:]), [0.3, -0.2, 0.1], atol=1e-9)
+
+
+def test_two_round_call_degenerate_cases(small_map):
+    """covgpu_gba_two_round at its corners: (i) a threshold nothing exceeds — the second round's problem is the first's with the loop
+    loss switched on: equal to solving that problem directly; (ii) second round without the loop edges (opt.gba_use_map_loop_constraints
+    = 0); (iii) visual-only; (iv) a threshold everything exceeds — every landmark is dropped, the second round is the inertial / loop
+    problem alone and the landmark array comes back untouched."""
+    import numpy as np
+    from covins_amd import backend, mapdata
+    ctx = backend.Context(0)
+    try:
+        p1, _ = mapdata.flatten_gba(small_map, False, loop_loss=False, use_loops=True)
+        o = backend.default_options(max_iterations=6)
+        # (i)
+        sol, r1, r2, bad, left, (nb, ns) = ctx.gba_two_round(p1, o, 1e9)
+        assert nb == 0 and not bad.any() and (left == np.diff(p1.lm_obs_ptr)).all()
+        p2, _ = mapdata.flatten_gba(small_map, False, loop_loss=True, use_loops=True)
+        ref, rr = ctx.gba_solve(p2, o)
+        assert r1.iterations == 5 and r2.iterations == rr.iterations and list(r2.accepted_trace[:6]) == list(rr.accepted_trace[:6])
+        assert np.allclose(np.array(r2.cost_trace[:r2.iterations]), np.array(rr.cost_trace[:rr.iterations]), rtol=1e-12)
+        assert np.abs(sol.kf_pose - ref.kf_pose).max() < 1e-10 and np.abs(sol.lm_pos - ref.lm_pos).max() < 1e-9
+        # (ii)
+        sol, r1, r2, bad, left, _ = ctx.gba_two_round(p1, o, 1e9, use_loops_round2=False)
+        p3, _ = mapdata.flatten_gba(small_map, False, loop_loss=True, use_loops=False)
+        ref, rr = ctx.gba_solve(p3, o)
+        assert p3.E == 0 and p1.E > 0
+        assert np.allclose(np.array(r2.cost_trace[:r2.iterations]), np.array(rr.cost_trace[:rr.iterations]), rtol=1e-12)
+        assert np.abs(sol.kf_pose - ref.kf_pose).max() < 1e-10
+        # (iii)
+        pv, _ = mapdata.flatten_gba(small_map, True, loop_loss=False, use_loops=True)
+        ov = backend.default_options(max_iterations=6, visual_only=1)
+        sol, r1, r2, bad, left, (nb, ns) = ctx.gba_two_round(pv, ov, 0.92)
+        assert nb > 0 and r2.final_cost < r2.initial_cost and np.array_equal(sol.kf_speed_bias, pv.kf_speed_bias)
+        # (iv)
+        sol, r1, r2, bad, left, (nb, ns) = ctx.gba_two_round(p1, o, 0.0)
+        assert bad.all() and (left == 0).all() and ns == p1.L
+        assert np.array_equal(sol.lm_pos, p1.lm_pos) and r2.final_cost <= r2.initial_cost and np.isfinite(sol.kf_pose).all()
+    finally:
+        ctx.close()

@@ -269,6 +269,49 @@ def test_gba_solve_matches_oracle(ctx, tiny_vi, strategy, visual_only):
     assert np.array_equal(sol.kf_pose[fx], tiny_vi.kf_pose[fx])
 
 
+@pytest.mark.parametrize("r0", [0.1, 10.0])
+def test_radius_limited_dogleg_steps_follow_the_oracle(ctx, tiny_vi, small_vi, r0):
+    """The committed full-size results only ever take the Gauss-Newton step (the reference's initial radius of 1e4 never binds). With a
+    small initial radius the first 7-10 steps are radius-limited: scaled Cauchy steps, then dogleg interpolations, the radius tripling
+    after every good step — every coefficient pair (cg, cn) of k_tail.hip's one-pass model (|J step|^2 = cg^2 JA + 2 cg cn JC + cn^2 JB,
+    g.step, |step|^2 from the same pass) against the oracle, which evaluates J step for the step it actually takes."""
+    for prob in (tiny_vi, small_vi):
+        g, o = opts(max_iterations=14)
+        g.initial_radius = r0; o.initial_radius = r0
+        sol, res = ctx.gba_solve(prob, g)
+        ref, rres = covo.gba_solve(prob, o)
+        n = rres.iterations
+        assert res.iterations == n and list(res.accepted_trace[:n]) == list(rres.accepted_trace[:n])
+        assert rres.radius_trace[0] == 3.0 * r0   # (the first step hit the radius and was good: tripled)
+        assert np.allclose(np.array(res.cost_trace[:n]), np.array(rres.cost_trace[:n]), rtol=1e-6)
+        assert np.allclose(np.array(res.radius_trace[:n]), np.array(rres.radius_trace[:n]), rtol=1e-6)
+        assert np.abs(sol.kf_pose[:, 4:] - ref.kf_pose[:, 4:]).max() < 1e-6 and rot_angle(sol.kf_pose[:, :4], ref.kf_pose[:, :4]).max() < 1e-7
+
+
+def test_rejected_lm_steps_follow_the_oracle(ctx, tiny_vi):
+    """From a badly perturbed estimate (rotations of ~35 degrees, translations of ~1.2 m) Levenberg-Marquardt REJECTS its first two steps
+    (radius divided by 2, then by 4, system rebuilt with the larger damping) before it gets going: the device-side step logic must take
+    the oracle's decisions. Compared over the first six iterations: further on this input amplifies rounding differences (an
+    ill-conditioned start) and two correct solvers part ways."""
+    from scipy.spatial.transform import Rotation as R
+    rng = np.random.default_rng(5)
+    q = tiny_vi.copy()
+    for k in range(q.K):
+        if q.kf_fixed[k]:
+            continue
+        q.kf_pose[k, :4] = (R.from_quat(q.kf_pose[k, :4]) * R.from_rotvec(rng.normal(0, 0.6, 3))).as_quat()
+        q.kf_pose[k, 4:] += rng.normal(0, 1.2, 3)
+    g, o = opts(strategy=capi.COVGPU_LM, max_iterations=6)
+    sol, res = ctx.gba_solve(q, g)
+    ref, rres = covo.gba_solve(q, o)
+    n = rres.iterations
+    acc = list(rres.accepted_trace[:n])
+    assert acc[:3] == [0, 0, 1], acc   # (the point of this input)
+    assert res.iterations == n and list(res.accepted_trace[:n]) == acc
+    assert np.allclose(np.array(res.cost_trace[:n]), np.array(rres.cost_trace[:n]), rtol=1e-5)
+    assert np.allclose(np.array(res.radius_trace[:n]), np.array(rres.radius_trace[:n]), rtol=1e-5)
+
+
 def test_gba_solve_small_map(ctx, small_vi, small_map):
     g, o = opts()
     sol, res = ctx.gba_solve(small_vi, g)

@@ -76,6 +76,50 @@ COV_DEV int hw_lane_id() {
   return l;
 }
 
+// DPP row_newbcast (gfx90a+, the one DPP control 64-bit operations take): lane C of every 16-lane row to the whole row.
+// Written as inline assembly because the compiler does not fold v_mov_b64_dpp into the multiply-add (a dependent pair per element, twice
+// the instructions on the chain) — and therefore WITHOUT the compiler's hazard handling: a DPP source written by a VALU instruction needs
+// two wait states (five after an EXEC write). diag_sweep keeps that distance by construction: the broadcast of the pivot carries its own
+// s_nop, every multiply-add reads the register its predecessor of the PREVIOUS pivot wrote (>= 4 instructions earlier, asm volatile
+// statements keep their order), and dpp_fence() separates the sweep from whatever wrote the registers before it.
+template <int C> COV_DEV double dpp_bcast(double v) {
+  double d;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v), "n"(C));
+  return d;
+}
+// acc += (acc of lane C of this row) * m
+template <int C> COV_DEV void dpp_fmac(double& acc, double m) {
+  asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(C));
+}
+COV_DEV void dpp_fence(double (&a)[16], double (&w)[4]) {
+  asm volatile("s_nop 4" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]),
+               "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+}
+
+// Pivots C .. 15 of the diagonal-block sweep of k_potrf_panel's wave 0 (see there), unrolled by recursion: the DPP control is an immediate
+template <int C> COV_DEV void diag_sweep(double (&a)[16], double (&w)[4], int r, bool& bad, double& rsr) {
+  if constexpr (C < 16) {
+    int rr = r;
+    asm volatile("" : "+v"(rr));  // (lane masks recomputed per pivot instead of sixteen hoisted SGPR pairs)
+    const double d = dpp_bcast<C>(a[C]);
+    bad = bad || !(d > 0.0);  // (a non-positive pivot poisons the block with inf/NaN: flagged, the caller discards the solve)
+    // 1/d: hardware estimate + two Newton steps arranged as r1 = r + r e, r2 = r1 + r1 e^2 (e = 1 - d r): three dependent
+    // operations after the estimate instead of four
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double e0 = fma(-d, r0, 1.0);
+    const double r1 = fma(r0, e0, r0), e1 = e0 * e0;
+    const double rinv = fma(r1, e1, r1);
+    const double nt = -(a[C] * rinv);
+#pragma unroll
+    for (int cc = C + 1; cc < 16; ++cc) dpp_fmac<C>(a[cc], nt);
+    const double ntw = (rr > C) ? nt : 0.0;  // rows <= C of W are final rows of the inverse
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dpp_fmac<C>(w[e], ntw);
+    rsr = (rr == C) ? d : rsr;   // the lane's own pivot
+    diag_sweep<C + 1>(a, w, r, bad, rsr);
+  }
+}
+
 // acc (tile (i,k), accumulator layout: row = (lane>>4) + 4 reg, col = lane & 15) -= P_i P_k^T for the 16-column panel `pan`
 COV_DEV v4f64 tile_update(v4f64 acc, const double* pan, int i, int k, int fr, int fk) {
   const double* pa = pan + (PB * i + fr) * PP + 4 * fk;
@@ -135,13 +179,11 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
   else M += (size_t)blockIdx.x * bsM;
   Dinv_out += (size_t)blockIdx.x * bsL;
   if (rhs != nullptr) { rhs += (size_t)blockIdx.x * bsR; yout += (size_t)blockIdx.x * bsR; }
-  extern __shared__ __attribute__((aligned(16))) double sP[];  // panel[2][256][PP] | sDv[16][16] | sRhs[256] | colA[16] rowW[16] sdd[16] | sDg[16][PP]
+  extern __shared__ __attribute__((aligned(16))) double sP[];  // panel[2][256][PP] | sDv[16][16] | sRhs[256] | sdd[2][16] + 16 spare | sDg[16][PP]
   double* sDv = sP + 2 * PROWS * PP;
   double* sRhs = sDv + 256;
-  double* colA = sRhs + 256;   // wave 0 only: LDS operations of one wave execute in order, no barrier needed
-  double* rowW = colA + 16;
-  double* sdd = rowW + 16;      // the block's 16 pivots
-  double* sDg = sdd + 16;       // [16][PP] the diagonal tile wave 0 takes over next (panels before the current one applied)
+  double* sdd = sRhs + 256;     // [2][16] 1/sqrt of the block's 16 pivots (+ 16 spare)
+  double* sDg = sdd + 48;       // [16][PP] the diagonal tile wave 0 takes over next (panels before the current one applied)
   double* sZero = sDg + 16 * PP;  // [16] zeros (A operand of tiles that take no update, tile_update2)
   const int tid0 = threadIdx.x, lane = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int fr0 = lane & 15, fk0 = lane >> 4;
@@ -172,11 +214,13 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
   for (int s = 0; s < NSLOT; ++s) {
     const bool on = (tik[s] >> 8) != 99;
     const int ii = on ? (tik[s] & 255) : 1, kk = on ? (tik[s] >> 8) : 1;
-    const double* src = Mg + (size_t)(PB * ii + fk0) * ld + PB * kk + fr0;
+    // (diagonal tiles are kept SYMMETRIC — the sweep of wave 0 wants whole rows —: an entry above the diagonal is read from its mirror image)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      const double v = src[(size_t)(4 * rg) * ld];
-      acc[s][rg] = (!on || (ii == kk && fr0 > fk0 + 4 * rg)) ? 0.0 : v;
+      const int rw = fk0 + 4 * rg;
+      const bool up = ii == kk && fr0 > rw;
+      const double v = Mg[(size_t)(PB * ii + (up ? fr0 : rw)) * ld + PB * kk + (up ? rw : fr0)];
+      acc[s][rg] = on ? v : 0.0;
     }
   }
   {
@@ -184,7 +228,7 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
     if (row < n) {
       double v[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) { const int col = 8 * half + c; v[c] = (row >= PB || col <= row) ? Mg[(size_t)row * ld + col] : 0.0; }
+      for (int c = 0; c < 8; ++c) { const int col = 8 * half + c; const bool up = row < PB && col > row; v[c] = Mg[(size_t)(up ? col : row) * ld + (up ? row : col)]; }
 #pragma unroll
       for (int c = 0; c < 8; ++c) sP[row * PP + 8 * half + c] = v[c];
     }
@@ -192,7 +236,7 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
     if (tid0 < 16) sZero[tid0] = 0.0;
     if (tid0 < 256 && nb > 1) {  // diagonal tile (1,1): wave 0 takes it over at step 0 (see below)
       const int rr = tid0 >> 4, cc = tid0 & 15;
-      sDg[rr * PP + cc] = (cc <= rr) ? Mg[(size_t)(PB + rr) * ld + PB + cc] : 0.0;
+      sDg[rr * PP + cc] = Mg[(size_t)(PB + (cc <= rr ? rr : cc)) * ld + PB + (cc <= rr ? cc : rr)];
     }
   }
   __syncthreads();
@@ -221,67 +265,42 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
       // lane id from the hardware (v_mbcnt): per-lane invariants of this block are recomputed every step rather than hoisted and
       // spilled — a reload from scratch at the head of every step costs the chain a memory latency
       const int ln = hw_lane_id();
-      const int r = ln >> 2, q = ln & 3;
-      double a[4], w[4], lfin[4] = {0.0, 0.0, 0.0, 0.0};
+      const int r = ln & 15, g = ln >> 4;
+      // The sweep lives in REGISTERS, one matrix row per lane, and what a pivot needs of another row arrives by DPP row_newbcast (lane c
+      // of every 16-lane row to the whole row) — no LDS round trip on the chain. Lane (r, g): a[0..15] = row r of the SYMMETRIC block (the
+      // four 16-lane rows carry identical copies), w[0..3] = W[r][4g..4g+3]. Pivot c: d = a_c[c], t_r = a_r[c] / d (the lane's own
+      // register), a_r[cc] -= t_r a_c[cc] for cc > c (both triangles: row c' must still be whole when its turn comes; rows <= c turn into
+      // garbage nobody reads), W_r: -= t_r W_c: for r > c. Column c is final after its pivot: scaled by 1/sqrt(d) in place.
+      double a[PB], w[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { a[e] = cur[(o + r) * PP + 4 * q + e]; w[e] = (4 * q + e == r) ? 1.0 : 0.0; }
+      for (int e = 0; e < PB; e += 2) { const double2 v = *reinterpret_cast<const double2*>(cur + (o + r) * PP + e); a[e] = v.x; a[e + 1] = v.y; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (4 * g + e == r) ? 1.0 : 0.0;
       bool bad = false;
-#pragma unroll
-      for (int c = 0; c < PB; ++c) {
-        const int qc = c >> 2, ec = c & 3;
-        int rr = r, qq = q;
-        asm volatile("" : "+v"(rr), "+v"(qq));  // lane masks recomputed per pivot (hoisted they become ~100 spilled SGPR pairs)
-        // column c is final now: the lanes that own it publish it and keep their entry aside (lfin) — after that the
-        // register may be overwritten, so the trailing update below needs no per-column mask at all: entries of finished
-        // columns and of the strict upper triangle turn into garbage that is only ever read back into such entries
-        if (qq == qc) { colA[r] = a[ec]; lfin[ec] = a[ec]; }
-        if (rr == c) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) rowW[4 * q + e] = w[e];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const double d = colA[c];
-        const double mr = colA[r];
-        double cv[4], xr[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { cv[e] = colA[4 * q + e]; xr[e] = rowW[4 * q + e]; }
-        __builtin_amdgcn_wave_barrier();
-        bad = bad || !(d > 0.0);  // (a non-positive pivot poisons the block with inf/NaN: flagged, the caller discards the solve)
-        if (ln == 0) sdd[c] = d;
-        // 1/d: hardware estimate + two Newton steps arranged as r1 = r + r e, r2 = r1 + r1 e^2 (e = 1 - d r): three dependent
-        // operations after the estimate instead of four — this reciprocal is the only arithmetic between two LDS round trips
-        const double r0 = __builtin_amdgcn_rcp(d);
-        const double e0 = fma(-d, r0, 1.0);
-        const double r1 = fma(r0, e0, r0), e1 = e0 * e0;
-        const double rinv = fma(r1, e1, r1);
-        const double t = mr * rinv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] -= t * cv[e];
-        const double tw = (rr > c) ? t : 0.0;  // rows <= c of W are final rows of the inverse
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] -= tw * xr[e];
-      }
+      double rsr = 1.0;
+      dpp_fence(a, w);
+      diag_sweep<0>(a, w, r, bad, rsr);
       if (bad && ln == 0) atomicOr(flag, 1);
-      // scale factors 1/sqrt(d) from the saved pivots, once: L = A diag(d)^-1/2 (by column), X = diag(d)^-1/2 W (by row)
-      __builtin_amdgcn_wave_barrier();
-      double rsc[4], rsr;
-#pragma unroll
-      for (int e = 0; e < 5; ++e) {
-        double dv = sdd[e < 4 ? 4 * q + e : r];
-        dv = (dv > 0.0) ? dv : 1.0;
+      // 1/sqrt(d_r), once per lane: X = diag(d)^-1/2 W (by row) here; L = A diag(d)^-1/2 (by column) is applied by the threads that store
+      // L_jj (nobody reads it from LDS before): the raw columns and the sixteen factors go to LDS
+      {
+        const double dv = (rsr > 0.0) ? rsr : 1.0;
         double rs = __builtin_amdgcn_rsq(dv);
         rs = rs * (1.5 - 0.5 * dv * rs * rs);
         rs = rs * (1.5 - 0.5 * dv * rs * rs);
-        if (e < 4) rsc[e] = rs; else rsr = rs;
+        rsr = rs;
       }
-      double* dst = Dinv_out + (size_t)(j >> 3) * kTile * kTile + (size_t)(j & 7) * 256 + r * PB + 4 * q;
+      if (ln < PB) {
+        sdd[PB * (j & 1) + r] = rsr;   // (two buffers: the storing threads of step j run beside the sweep of step j + 1)
+#pragma unroll
+        for (int e = 0; e < PB; e += 2) *reinterpret_cast<double2*>(cur + (o + r) * PP + e) = double2{a[e], a[e + 1]};   // (above the diagonal: leftovers nobody reads)
+      }
+      double* dst = Dinv_out + (size_t)(j >> 3) * kTile * kTile + (size_t)(j & 7) * 256 + r * PB + 4 * g;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const bool low = 4 * q + e <= r;
-        double lv = low ? lfin[e] * rsc[e] : 0.0, xv = low ? w[e] * rsr : 0.0;
-        asm volatile("" : "+v"(lv), "+v"(xv));  // selects, not a branch around the stores
-        cur[(o + r) * PP + 4 * q + e] = lv;
-        sDv[r * PB + 4 * q + e] = xv;
+        double xv = (4 * g + e <= r) ? w[e] * rsr : 0.0;
+        asm volatile("" : "+v"(xv));  // selects, not a branch around the stores
+        sDv[r * PB + 4 * g + e] = xv;
         if (PUB) st_dev(dst + e, xv); else dst[e] = xv;
       }
       __builtin_amdgcn_s_setprio(0);
@@ -390,7 +409,7 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
         }
         if (u < 256) {
           const int rr = u >> 4, cc = u & 15;
-          if (cc <= rr) Mg[(size_t)(o + rr) * ld + o + cc] = cur[(o + rr) * PP + cc];
+          if (cc <= rr) Mg[(size_t)(o + rr) * ld + o + cc] = cur[(o + rr) * PP + cc] * sdd[PB * (j & 1) + cc];
         }
         for (int col = o + PB + u; col < n; col += 448) {
           double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;

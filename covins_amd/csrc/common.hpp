@@ -221,10 +221,6 @@ struct CholAux {
   hipEvent_t ev_fill = nullptr;  // pose system cleared (head stream, beside the linearisation)
   hipEvent_t ev_xb = nullptr;    // multifrontal look-ahead: second half of a level's extend-add done (bulk stream)
   int* bwd_cnt = nullptr;        // ticket counters of k_bwd_front (65536, zero between launches)
-  // panel pipeline (k_panel.hip: k_potrf_panel<PUB> + k_panel_follow): progress flags [kPipeFronts] published block columns per front |
-  // [kPipeFronts][16] per slab; they only grow — every fused launch takes the next epoch of 32 values
-  int* pipe_flags = nullptr; int pipe_epoch = 0; int bulk_tag = 0;   // (+ one flag behind them: bulk updates finished, counted by bulk_tag)
-  static constexpr int kPipeFronts = 1024;
   double* bwd_scr = nullptr; size_t bwd_scr_elems = 0;   // its scratch (grown on demand by launch_nd_solve)
   hipEvent_t ev_xa = nullptr;    // ... the chain's stream has enqueued the level below completely
   hipEvent_t ev_zero = nullptr;  // per-iteration buffers cleared (main stream): the side stream's inertial kernels follow
@@ -301,10 +297,7 @@ void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStrea
 // 256-column panel chain (k_panel.hip): with it the Linv buffer holds, per tile, the eight 16x16 diagonal-block inverses
 // instead of the 128x128 inverse. COVGPU_PANEL=0 selects the round-2a chain (two 128-column potrf + inverse per panel).
 void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
-                        hipStream_t st, const long long* btab = nullptr, int nb = -1, int* pub = nullptr, int pbase = 0);
-void launch_panel_follow(double* S, size_t ld, int t0, const double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
-                         hipStream_t st, const long long* btab, const int* live, int tI, int nb, const int* pub, int* slab, int pbase, const int* bulk, int bulk_target);
-void launch_flag_set(int* p, int v, hipStream_t st);   // one device-scope store of v (stream-ordered progress flag)  // nb: 16-column blocks to factor (-1: the whole panel)
+                        hipStream_t st, const long long* btab = nullptr, int nb = -1);   // nb: 16-column blocks to factor (-1: the whole panel)
 void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, double* x, int ncol, int nbt, size_t sM, size_t sR, hipStream_t st,
                       const long long* btab, const int* live, int tI, BwdXfer xf = BwdXfer());
 void launch_bwd_front(const double* S, int tI, int ntiles, int nchunk, double* y, const double* Linv, int nbt, size_t sL, size_t sR, hipStream_t st,

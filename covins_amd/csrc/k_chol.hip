@@ -297,7 +297,6 @@ void CholAux::init() {
   if (!ev_xb) (void)hipEventCreateWithFlags(&ev_xb, hipEventDisableTiming);
   if (!ev_xa) (void)hipEventCreateWithFlags(&ev_xa, hipEventDisableTiming);
   if (!bwd_cnt && hipMalloc((void**)&bwd_cnt, 65536 * sizeof(int)) == hipSuccess) (void)hipMemset(bwd_cnt, 0, 65536 * sizeof(int));
-  if (!pipe_flags && hipMalloc((void**)&pipe_flags, (17 * kPipeFronts + 16) * sizeof(int)) == hipSuccess) { (void)hipMemset(pipe_flags, 0, (17 * kPipeFronts + 16) * sizeof(int)); pipe_epoch = 0; bulk_tag = 0; }
 }
 void CholAux::TriCache::clear() {
   for (int* p : list) if (p) (void)hipFree(p);
@@ -328,7 +327,6 @@ void CholAux::destroy() {
   if (ev_xb) { (void)hipEventDestroy(ev_xb); ev_xb = nullptr; }
   if (ev_xa) { (void)hipEventDestroy(ev_xa); ev_xa = nullptr; }
   if (bwd_cnt) { (void)hipFree(bwd_cnt); bwd_cnt = nullptr; }
-  if (pipe_flags) { (void)hipFree(pipe_flags); pipe_flags = nullptr; }
   if (bwd_scr) { (void)hipFree(bwd_scr); bwd_scr = nullptr; bwd_scr_elems = 0; }
   if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
 }
@@ -499,7 +497,6 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     }
   };
   int Plast = NP - 1;
-  int bulk_done_tag = 0;    // value the bulk stream stores into the bulk flag behind the latest bulk update
   bool split_last = false;  // the last panel's bulk update was left running on B for the caller (DenseBatch::split_ta)
   bool tail_on_chain = false;  // the last panel ran whole on the chain's own stream: nothing of it to join (every event packet on
                                // the chain's stream is a few microseconds between two dependent kernels)
@@ -604,50 +601,6 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       const int nbp = bt.own_max > 0 ? std::max(0, std::min(8 * w, (bt.own_max - t0 * kTile + 15) / 16)) : -1;
       const double bulk_pairs = (T - (t0 + 4) > 0) ? 0.5 * (double)(T - (t0 + 4)) * (T - (t0 + 4) + 1) * nbt : 0.0;
       const bool chain_bound = bulk_pairs <= 700.0;
-      // The panel pipeline (k_panel.hip): while the chain is the period of the factorisation, the substitution of the next panel's rows
-      // and the update of the next diagonal block FOLLOW the factorisation through device flags (stream H, beside it) instead of
-      // trailing it as two more dependent launches. COVGPU_PIPE=1 selects it; the default is the three-launch chain.
-      static const bool pipe_on = getenv("COVGPU_PIPE") != nullptr && atoi(getenv("COVGPU_PIPE")) != 0;   // opt-in: correct (tests), measured SLOWER — see the note at k_panel_follow
-      const int nsteps = nbp < 0 ? 8 * w : nbp;
-      const bool fused = pipe_on && chain_bound && w == 2 && h1 - h0 == 2 && P + 1 < NP && P + 1 != Pstop && nsteps > 0 && ax.pipe_flags != nullptr &&
-                         nbt <= CholAux::kPipeFronts && kd(P) == nsteps * 16;
-      if (fused) {
-        ax.pipe_epoch += 32;
-        if (ax.pipe_epoch > 0x7fff0000) { (void)hipMemsetAsync(ax.pipe_flags, 0, 17 * CholAux::kPipeFronts * sizeof(int), M); ax.pipe_epoch = 32; }   // (flags only grow; the bulk tag has its own count)
-        int* pub = ax.pipe_flags; int* slab = ax.pipe_flags + CholAux::kPipeFronts;
-        // (the follower's stream must not run ahead of what M carries BEFORE this factorisation — the caller's extend-add into these
-        //  fronts, the level below; from the second panel on it follows M through its own look-ahead update above)
-        if (P == 0) { (void)hipEventRecord(e1[P], M); wait(H, e1[P]); }
-        // M: the factorisation, publishing its block columns
-        if (ax.profile) {
-          while (ax.prof_ev2.size() < 2 * (ax.prof_flops2.size() + 1)) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev2.push_back(e); }
-          (void)hipEventRecord(ax.prof_ev2[2 * ax.prof_flops2.size()], M);
-        }
-        launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp, pub, ax.pipe_epoch);
-        if (ax.profile) {
-          double fl = 0.0;
-          for (int a = 0; a < nbt; ++a) {
-            const double n = bt.own_dims_h != nullptr ? (double)std::max(0, std::min(w * kTile, bt.own_dims_h[a] - t0 * kTile)) : (double)(w * kTile);
-            fl += n * n * n / 3.0 + n * n;
-          }
-          (void)hipEventRecord(ax.prof_ev2[2 * ax.prof_flops2.size() + 1], M);
-          ax.prof_flops2.push_back(fl);
-        }
-        // H: its follower. Rows h carry the look-ahead update of panel P - 1 (enqueued on H above, stream order); the next diagonal
-        // block was last written by bulk(P - 1); the first panel's rows wait for the second half of the caller's extend-add
-        // (the follower does NOT wait for bulk(P - 1) on the host side: it starts with the factorisation and only its last act, adding
-        //  what it gathered onto the diagonal block, polls the device flag the bulk stream raises behind bulk(P - 1))
-        if (P == 0 && bt.pre_trsm != nullptr) { wait(H, bt.pre_trsm); wait(M, bt.pre_trsm); }
-        launch_panel_follow(S, ld, t0, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, H, bt.tab, bt.live, bt.tI, nsteps, pub, slab, ax.pipe_epoch,
-                            ax.pipe_flags + 17 * CholAux::kPipeFronts, P >= 1 ? bulk_done_tag : 0);
-        (void)hipEventRecord(eH[P], H);
-        wait(M, eH[P]);            // the next factorisation follows the follower
-        if (T > h1) {
-          wait(R, eH[P]);
-          launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab, nbp, bt.own_dims);
-        }
-        (void)hipEventRecord(eC[P], R);
-      } else {
       potrf(t0, w, nbp);
       if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
       // Every event packet on this stream sits between two dependent kernels of the chain, a few microseconds each. While the bulk
@@ -676,7 +629,6 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       }
       (void)hipEventRecord(eC[P], R);
       if (!chain_bound) wait(B, eRc[P]);
-      }
     }
     // ---- B: bulk of SYRK(P), triangle starting two tile columns further (those belong to the look-ahead)
     const int tb = t0 + 4, nt = T - tb;
@@ -711,8 +663,6 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       }
     }
     (void)hipEventRecord(eB[P], B);
-    static const bool pipe_flagged = getenv("COVGPU_PIPE") != nullptr && atoi(getenv("COVGPU_PIPE")) != 0;
-    if (pipe_flagged && ax.pipe_flags != nullptr) { bulk_done_tag = ++ax.bulk_tag; launch_flag_set(ax.pipe_flags + 17 * CholAux::kPipeFronts, bulk_done_tag, B); }   // bulk(P) is done: the next follower's last act may go ahead
   }
   if (!split_last && !tail_on_chain) wait(M, eB[Plast]);
   if (Plast >= 1) wait(M, eB[Plast - 1]);

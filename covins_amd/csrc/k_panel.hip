@@ -35,33 +35,35 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 #ifdef COVGPU_PROBE
 __device__ long long g_pprobe[8];
+__device__ long long g_pstep[4][16];   // per step: wave 0 sweep done, wave 0 past X, wave 0 past Y, probed tile wave's updates done (relative to kernel start)
+#define PSTEP(k, j, t0) do { if ((threadIdx.x & 63) == 0) g_pstep[k][j] = clock64() - (t0); } while (0)
+__device__ long long g_parr[16][16];   // arrival of every wave at barrier X(j)
+#define PARR(j, t0) do { if ((threadIdx.x & 63) == 0) g_parr[threadIdx.x >> 6][j] = clock64() - (t0); } while (0)
+#ifndef PPROBE_WAVE
+#define PPROBE_WAVE 1
+#endif
 // (accumulated in registers and written once: a global read-modify-write per phase costs more than the phases themselves)
 #define PPROBE_DECL() long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define PPROBE_ACC(i, t0) do { pacc[i] += clock64() - (t0); } while (0)
 #define PPROBE_T0() clock64()
-#define PPROBE_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 6; ++i_) g_pprobe[i_] = pacc[i_]; if (threadIdx.x == 64) { g_pprobe[6] = pacc[6]; g_pprobe[7] = pacc[7]; } } while (0)
+#define PPROBE_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 6; ++i_) g_pprobe[i_] = pacc[i_]; if (threadIdx.x == 64 * PPROBE_WAVE) { g_pprobe[6] = pacc[6]; g_pprobe[7] = pacc[7]; } } while (0)
 #else
 #define PPROBE_DECL() do {} while (0)
 #define PPROBE_ACC(i, t0) do {} while (0)
 #define PPROBE_T0() 0
 #define PPROBE_FLUSH() do {} while (0)
+#define PSTEP(k, j, t0) do {} while (0)
+#define PARR(j, t0) do {} while (0)
+#define PPROBE_WAVE 1
 #endif
 
 constexpr int PB = 16;                 // block edge
 constexpr int PP = 18;                 // LDS pitch of a panel row (16 doubles + 2): rows 16-byte aligned, and the 16 lanes of a quarter wave
                                        // reading 32 bytes of 16 consecutive rows hit all 64 banks once (ds_read_b128, conflict-free)
 constexpr int PROWS = 256;
-constexpr int NTW = 7;                 // tile-owning waves (waves 1..7; wave 0 carries the serial chain)
-constexpr int NSLOT = 18;              // 119 / 7 rounded up to even: tiles (i, k), 1 <= k <= i <= 15 except (1,1), column-major, dealt round-robin
-constexpr size_t kPanelLds = (size_t)(2 * PROWS * PP + 256 + 256 + 48 + 16 * PP + 16) * sizeof(double);
-
-// device-scope (cross-XCD coherent, L2-bypassing) accesses for data that another workgroup of a concurrently running launch picks up
-// behind a flag (the panel pipeline below; k_bwd_front uses the same idiom): no fences — a device-scope fence writes back and
-// invalidates the XCD's whole L2 under everybody else
-COV_DEV void st_dev(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-COV_DEV double ld_dev(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-COV_DEV v4f64 ld_dev4(const double* p) { return v4f64{ld_dev(p), ld_dev(p + 1), ld_dev(p + 2), ld_dev(p + 3)}; }
-COV_DEV void st_dev4(double* p, v4f64 v) { st_dev(p, v[0]); st_dev(p + 1, v[1]); st_dev(p + 2, v[2]); st_dev(p + 3, v[3]); }
+constexpr int NW = 16;                 // waves of the panel workgroup: wave 0 carries the serial chain, waves 1..15 own the trailing tiles
+constexpr int NSLOT = 10;              // tile slots per wave: 119 tiles (i, k), 1 <= k <= i <= 15 except (1,1), ~30 per SIMD, SIMD 0 with three tile waves
+constexpr size_t kPanelLds = (size_t)(2 * PROWS * PP + 256 + 256 + 32 + 16 * PP) * sizeof(double);
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL store to be
 // acknowledged (s_waitcnt vmcnt(0): ~1 us per step here, where L / Dinv / y stream out while the factorisation goes on
@@ -133,144 +135,107 @@ COV_DEV v4f64 tile_update(v4f64 acc, const double* pan, int i, int k, int fr, in
   return acc;
 }
 
-// Two tiles at once: their (dependent) 4-MFMA chains interleaved, so the matrix pipe sees independent instructions back to
-// back (34 cycles each) instead of one chain at the dependent rate (66). A tile that takes no update this step reads its A
-// operand from a row of zeros (`zrow`): its accumulator is unchanged, and the code has ONE path per pair — the loop body of
-// this kernel has to stay well inside the 64 KiB instruction cache (a version with separate paths for full and partial
-// groups was 100 KiB of code and ran at instruction-fetch speed: 200 us instead of 120; one with 40 tiles per wave on four
-// waves had its accumulators shuttled between VGPRs and AGPRs around every MFMA).
-COV_DEV void tile_update2(v4f64& c0, v4f64& c1, const double* pan, const double* zrow, int pk0, int pk1, bool u0, bool u1, int fr, int fk) {
-  const double* base = pan + fr * PP + 4 * fk;
-  const double* pa0 = u0 ? base + PB * PP * (pk0 & 255) : zrow; const double* pb0 = base + PB * PP * (u0 ? (pk0 >> 8) : 0);
-  const double* pa1 = u1 ? base + PB * PP * (pk1 & 255) : zrow; const double* pb1 = base + PB * PP * (u1 ? (pk1 >> 8) : 0);
-  const double2 a0 = *reinterpret_cast<const double2*>(pa0), a0h = *reinterpret_cast<const double2*>(pa0 + 2);
-  const double2 b0 = *reinterpret_cast<const double2*>(pb0), b0h = *reinterpret_cast<const double2*>(pb0 + 2);
-  const double2 a1 = *reinterpret_cast<const double2*>(pa1), a1h = *reinterpret_cast<const double2*>(pa1 + 2);
-  const double2 b1 = *reinterpret_cast<const double2*>(pb1), b1h = *reinterpret_cast<const double2*>(pb1 + 2);
-  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0.x, b0.x, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1.x, b1.x, c1, 0, 0, 0);
-  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0.y, b0.y, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1.y, b1.y, c1, 0, 0, 0);
-  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0h.x, b0h.x, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1h.x, b1h.x, c1, 0, 0, 0);
-  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0h.y, b0h.y, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1h.y, b1h.y, c1, 0, 0, 0);
+// Panel j (LDS, complete: block column j of the factor from row o = 16 j on, raw diagonal block + its column factors `rs`) leaves for
+// memory, and the right-hand side below it takes y_j (in sRhs[o ..)): thread u of NT, half rows of 64 bytes.
+template <int NT>
+COV_DEV void panel_out(const double* pan, double* sRhs, const double* rs, double* Mg, size_t ld, int o, int n, int u, double* yo) {
+  for (int row = o + PB + (u >> 1); row < n; row += NT / 2) {
+    const double2* src = reinterpret_cast<const double2*>(pan + row * PP + 8 * (u & 1));
+    double2* dst = reinterpret_cast<double2*>(Mg + (size_t)row * ld + o + 8 * (u & 1));
+    const double2 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+    dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+  }
+  for (int e = NT - 1 - u; e < 256; e += NT) {  // the block's own rows: lower part, scaled by column (from the other end of the threads than the half rows)
+    const int rr = e >> 4, cc = e & 15;
+    if (cc <= rr) Mg[(size_t)(o + rr) * ld + o + cc] = pan[(o + rr) * PP + cc] * rs[cc];
+  }
+  for (int row = o + PB + (NT - 1 - u); row < n; row += NT) {
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+    for (int c = 0; c < PB; c += 4) {
+      t0 += sRhs[o + c] * pan[row * PP + c]; t1 += sRhs[o + c + 1] * pan[row * PP + c + 1];
+      t2 += sRhs[o + c + 2] * pan[row * PP + c + 2]; t3 += sRhs[o + c + 3] * pan[row * PP + c + 3];
+    }
+    sRhs[row] -= (t0 + t1) + (t2 + t3);
+  }
+  if (yo != nullptr && u < PB) yo[o + u] = sRhs[o + u];
 }
 
-// Factor the (16 nb)-order diagonal block at (k0, k0), nb = 16 (a 256-column panel) or 8 (a last single tile).
+// Factor the (16 nb)-order diagonal block at (k0, k0), nb = 16 (a 256-column panel) or fewer (the last panel of a front).
 // Dinv_out: block j at Dinv_out + (j >> 3) * 128*128 + (j & 7) * 256, [16][16] row-major (zeros above the diagonal).
 //
-// The diagonal-block sweep of wave 0 ((a) in the loop below): lane (r = lane>>2, q = lane&3) owns A[r][4q..4q+3] and
-// W[r][4q..4q+3] (W starts as I). Per pivot c the raw column c of A and row c of W are published in LDS (one round trip);
-// with t_r = a_rc / d_c every lane does a[r][cc] -= t_r a[cc][c] and, for r > c, W[r][:] -= t_r W[c][:] — the forward
-// substitution L X = I in outer-product form with the same multipliers (L_rc X_c: = a_rc W_c: / d_c). L = A diag(d)^-1/2 and
-// X = diag(d)^-1/2 W are scaled once at the end: between two LDS round trips sits one reciprocal, no square root.
-// The rest of the panel is X_ij = T_ij Dinv_j^T, 4 MFMAs per tile. (Round 1 found the product with a 128x128 explicit inverse
-// too inaccurate for this system; a 16x16 block inverse formed by substitution is the standard blocked-TRSM building block
-// and tests/test_gpu_parity.py::test_mfma_cholesky_ill_conditioned_blocks and the full-size parity tests hold with it.)
-// PUB (the panel pipeline, k_panel_follow below): everything a follower needs of block column j — L below the diagonal block,
-// Dinv_j, y_j — leaves through device-scope stores, and pub[front] = pbase + j + 1 is raised once all of it has been acknowledged:
-// at the barrier of step j + 1, where the storing waves idle anyway while wave 0 factors the next diagonal block.
-template <bool PUB>
-__global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
-                                                      const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR,
-                                                      const long long* __restrict__ btab, int* __restrict__ pub, int pbase) {
+// Sixteen waves, two roles, each a loop of its own (a wave's registers are then either the sweep's or the tiles'), two
+// workgroup barriers per block column j:
+//   wave 0 (the chain)    (a) diagonal block j  ->  X(j+1,j) = T(j+1,j) Dinv_j^T  ->  T(j+1,j+1) -= X X^T  ->  (a) diagonal block j+1 ...
+//   waves on SIMDs 1-3    (twelve; wave w runs on SIMD w & 3) own the 119 trailing 16x16 tiles in REGISTERS in the MFMA accumulator
+//                         layout, dealt round-robin in column-major order: between barriers X(j) and Y(j) they solve the remaining tiles of
+//                         panel j (i >= j+2) against Dinv_j; between Y(j) and X(j+1) — while wave 0 already factors block j+1 — they apply
+//                         panel j to block column j+1 (handed on through LDS), to the diagonal tile (j+2,j+2) (handed to wave 0 through sDg
+//                         one step ahead) and to the rest of their tiles. The matrix pipe runs one v_mfma_f64_16x16x4 in 64 cycles,
+//                         dependent or not (tools/valu_probe.hip): 680 tile updates of 4 are 24 us of three matrix pipes, and the first
+//                         eight steps are bound by them, the last eight by wave 0's chain.
+//                         L and y leave ONE STEP BEHIND (panel_out), in the solve phase.
+//   waves 4, 8, 12        (SIMD 0, beside the chain wave, which takes every issue slot there during its sweep) help to fill LDS and exit.
+// The diagonal-block sweep of wave 0 is described at its place in the loop; the rest of the panel is X_ij = T_ij Dinv_j^T, 4 MFMAs per
+// tile. (Round 1 found the product with a 128x128 explicit inverse too inaccurate for this system; a 16x16 block inverse formed by
+// substitution is the standard blocked-TRSM building block and tests/test_gpu_parity.py::test_mfma_cholesky_ill_conditioned_blocks and
+// the full-size parity tests hold with it.)
+__global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
+                                                         const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR,
+                                                         const long long* __restrict__ btab) {
   if (btab != nullptr) { M += (size_t)btab[2 * blockIdx.x]; ld = (size_t)btab[2 * blockIdx.x + 1]; }  // fronts of unequal order (GemmArgs::btab)
   else M += (size_t)blockIdx.x * bsM;
   Dinv_out += (size_t)blockIdx.x * bsL;
   if (rhs != nullptr) { rhs += (size_t)blockIdx.x * bsR; yout += (size_t)blockIdx.x * bsR; }
-  extern __shared__ __attribute__((aligned(16))) double sP[];  // panel[2][256][PP] | sDv[16][16] | sRhs[256] | sdd[2][16] + 16 spare | sDg[16][PP]
+  extern __shared__ __attribute__((aligned(16))) double sP[];  // panel[2][256][PP] | sDv[16][16] | sRhs[256] | sdd[2][16] | sDg[16][PP]
   double* sDv = sP + 2 * PROWS * PP;
   double* sRhs = sDv + 256;
-  double* sdd = sRhs + 256;     // [2][16] 1/sqrt of the block's 16 pivots (+ 16 spare)
-  double* sDg = sdd + 48;       // [16][PP] the diagonal tile wave 0 takes over next (panels before the current one applied)
-  double* sZero = sDg + 16 * PP;  // [16] zeros (A operand of tiles that take no update, tile_update2)
-  const int tid0 = threadIdx.x, lane = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-  const int fr0 = lane & 15, fk0 = lane >> 4;
+  double* sdd = sRhs + 256;     // [2][16] 1/sqrt of the block's 16 pivots
+  double* sDg = sdd + 32;       // [16][PP] the diagonal tile wave 0 takes over next (panels before the current one applied)
+  const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int n = PB * nb;
   double* Mg = M + (size_t)k0 * ld + k0;
-  PPROBE_DECL();
   const long long tp0 = PPROBE_T0();
 
-  // ---- tile slots of this wave (wave-uniform, packed i | k << 8; k = 99: none)
-  int tik[NSLOT];
-#pragma unroll
-  for (int s = 0; s < NSLOT; ++s) {
-    // Wave 4 shares SIMD 0 with the chain wave: it gets the first eleven tiles only (block column 1: one update each, 2 % of
-    // the work), the other six waves deal the remaining 108 round-robin — the chain wave's sweep runs 15 % faster for it.
-    int t, k = 1;
-    bool ok;
-    if (wave == 4) { t = s + 1; ok = s < 11; }
-    else { const int h = wave < 4 ? wave - 1 : wave - 2; t = 11 + s * 6 + h + 1; ok = wave >= 1 && t < 120; }
-    if (ok) { while (t >= 16 - k) { t -= 16 - k; ++k; } }
-    const int i = k + t;
-    ok = ok && i < nb;
-    tik[s] = ok ? (i | (k << 8)) : (99 << 8);
-  }
-  // ---- load: trailing tiles into registers, block column 0 and the right-hand side into LDS
-  // (unconditional loads from a clamped address: a branch per slot would serialise 18 memory latencies)
-  v4f64 acc[NSLOT];
-#pragma unroll
-  for (int s = 0; s < NSLOT; ++s) {
-    const bool on = (tik[s] >> 8) != 99;
-    const int ii = on ? (tik[s] & 255) : 1, kk = on ? (tik[s] >> 8) : 1;
-    // (diagonal tiles are kept SYMMETRIC — the sweep of wave 0 wants whole rows —: an entry above the diagonal is read from its mirror image)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int rw = fk0 + 4 * rg;
-      const bool up = ii == kk && fr0 > rw;
-      const double v = Mg[(size_t)(PB * ii + (up ? fr0 : rw)) * ld + PB * kk + (up ? rw : fr0)];
-      acc[s][rg] = on ? v : 0.0;
-    }
-  }
+  // ---- block column 0 (its diagonal tile SYMMETRIC: an entry above the diagonal is read from its mirror image — the sweep of wave 0
+  // wants whole rows), the diagonal tile (1,1) and the right-hand side into LDS
   {
-    const int row = tid0 >> 1, half = tid0 & 1;
+    const int row = tid0 >> 2, qt = tid0 & 3;
     if (row < n) {
-      double v[8];
+      double v[4];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) { const int col = 8 * half + c; const bool up = row < PB && col > row; v[c] = Mg[(size_t)(up ? col : row) * ld + (up ? row : col)]; }
+      for (int c = 0; c < 4; ++c) { const int col = 4 * qt + c; const bool up = row < PB && col > row; v[c] = Mg[(size_t)(up ? col : row) * ld + (up ? row : col)]; }
 #pragma unroll
-      for (int c = 0; c < 8; ++c) sP[row * PP + 8 * half + c] = v[c];
+      for (int c = 0; c < 4; ++c) sP[row * PP + 4 * qt + c] = v[c];
     }
-    if (tid0 < PROWS) sRhs[tid0] = (rhs != nullptr && tid0 < n) ? rhs[k0 + tid0] : 0.0;
-    if (tid0 < 16) sZero[tid0] = 0.0;
-    if (tid0 < 256 && nb > 1) {  // diagonal tile (1,1): wave 0 takes it over at step 0 (see below)
-      const int rr = tid0 >> 4, cc = tid0 & 15;
+    if (tid0 >= 512 && tid0 < 512 + PROWS) { const int t = tid0 - 512; sRhs[t] = (rhs != nullptr && t < n) ? rhs[k0 + t] : 0.0; }
+    if (tid0 >= 768 && nb > 1) {  // diagonal tile (1,1): wave 0 takes it over at step 0 (see below)
+      const int rr = (tid0 - 768) >> 4, cc = tid0 & 15;
       sDg[rr * PP + cc] = Mg[(size_t)(PB + (cc <= rr ? rr : cc)) * ld + PB + (cc <= rr ? cc : rr)];
     }
   }
-  __syncthreads();
-  PPROBE_ACC(4, tp0);
 
-  // Software pipeline, two barriers per block column. Wave 0 carries the serial chain alone:
-  //     (a) diagonal block j  ->  X(j+1,j) = T(j+1,j) Dinv_j^T  ->  T(j+1,j+1) -= X X^T  ->  (a) diagonal block j+1 ...
-  // and the tile waves work around it: between barriers X(j) and Y(j) the remaining tiles of panel j (i >= j+2) are solved
-  // against Dinv_j; between Y(j) and X(j+1) — while wave 0 already factors block j+1 — they apply panel j to block column
-  // j+1 (handed on through LDS), to the diagonal tile (j+2,j+2) (handed to wave 0 through sDg one step ahead) and to the
-  // rest of the trailing tiles, and stream L, y out. (With three phases in lock step — factor | solve | update — every step
-  // cost the sum of the three, 6.4 us; now it costs wave 0's chain, ~4.)
-  for (int j = 0; j < nb; ++j) {
-    double* cur = sP + (j & 1) * PROWS * PP;          // block column j, rows 16 j .. n
-    double* oth = sP + ((j + 1) & 1) * PROWS * PP;    // block column j+1 (being assembled)
-    const int o = PB * j;
-    // every per-lane constant of the step is rebuilt from the hardware lane id here: kept across the loop they are spilled
-    // (the accumulator tiles take the registers) and every reload is a memory latency, several of them on wave 0's chain
-    const int lq = hw_lane_id();
-    const int fr = lq & 15, fk = lq >> 4, tid = 64 * wave + lq;
-    const long long tq0 = PPROBE_T0();
-    if (wave == 0) {
-      // ---- (a): factor the diagonal block and form its inverse
-      __builtin_amdgcn_s_setprio(3);
-      if (PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Dinv of the previous step (stored a whole step ago: no stall) is out before this step's barrier publishes it
-      // lane id from the hardware (v_mbcnt): per-lane invariants of this block are recomputed every step rather than hoisted and
-      // spilled — a reload from scratch at the head of every step costs the chain a memory latency
-      const int ln = hw_lane_id();
-      const int r = ln & 15, g = ln >> 4;
+  if (wave == 0) {
+    // ================================================================ the chain
+    PPROBE_DECL();
+    __syncthreads();
+    PPROBE_ACC(4, tp0);
+    __builtin_amdgcn_s_setprio(3);
+    for (int j = 0; j < nb; ++j) {
+      double* cur = sP + (j & 1) * PROWS * PP;          // block column j, rows 16 j .. n
+      double* oth = sP + ((j + 1) & 1) * PROWS * PP;    // block column j+1 (being assembled)
+      double* dv = sDv;
+      const int o = PB * j;
+      const long long tq0 = PPROBE_T0();
+      // ---- (a): factor the diagonal block and form its inverse.
       // The sweep lives in REGISTERS, one matrix row per lane, and what a pivot needs of another row arrives by DPP row_newbcast (lane c
       // of every 16-lane row to the whole row) — no LDS round trip on the chain. Lane (r, g): a[0..15] = row r of the SYMMETRIC block (the
-      // four 16-lane rows carry identical copies), w[0..3] = W[r][4g..4g+3]. Pivot c: d = a_c[c], t_r = a_r[c] / d (the lane's own
-      // register), a_r[cc] -= t_r a_c[cc] for cc > c (both triangles: row c' must still be whole when its turn comes; rows <= c turn into
-      // garbage nobody reads), W_r: -= t_r W_c: for r > c. Column c is final after its pivot: scaled by 1/sqrt(d) in place.
+      // four 16-lane rows carry identical copies), w[0..3] = W[r][4g..4g+3] (W starts as I). Pivot c: d = a_c[c], t_r = a_r[c] / d (the
+      // lane's own register), a_r[cc] -= t_r a_c[cc] for cc > c (both triangles: row c' must still be whole when its turn comes; rows <= c
+      // turn into leftovers nobody reads), W_r: -= t_r W_c: for r > c — the forward substitution L X = I in outer-product form with the
+      // same multipliers. L = A diag(d)^-1/2 and X = diag(d)^-1/2 W are scaled once at the end.
+      const int ln = hw_lane_id();
+      const int r = ln & 15, g = ln >> 4;
       double a[PB], w[4];
 #pragma unroll
       for (int e = 0; e < PB; e += 2) { const double2 v = *reinterpret_cast<const double2*>(cur + (o + r) * PP + e); a[e] = v.x; a[e + 1] = v.y; }
@@ -284,10 +249,10 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
       // 1/sqrt(d_r), once per lane: X = diag(d)^-1/2 W (by row) here; L = A diag(d)^-1/2 (by column) is applied by the threads that store
       // L_jj (nobody reads it from LDS before): the raw columns and the sixteen factors go to LDS
       {
-        const double dv = (rsr > 0.0) ? rsr : 1.0;
-        double rs = __builtin_amdgcn_rsq(dv);
-        rs = rs * (1.5 - 0.5 * dv * rs * rs);
-        rs = rs * (1.5 - 0.5 * dv * rs * rs);
+        const double dvv = (rsr > 0.0) ? rsr : 1.0;
+        double rs = __builtin_amdgcn_rsq(dvv);
+        rs = rs * (1.5 - 0.5 * dvv * rs * rs);
+        rs = rs * (1.5 - 0.5 * dvv * rs * rs);
         rsr = rs;
       }
       if (ln < PB) {
@@ -296,23 +261,59 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
         for (int e = 0; e < PB; e += 2) *reinterpret_cast<double2*>(cur + (o + r) * PP + e) = double2{a[e], a[e + 1]};   // (above the diagonal: leftovers nobody reads)
       }
       double* dst = Dinv_out + (size_t)(j >> 3) * kTile * kTile + (size_t)(j & 7) * 256 + r * PB + 4 * g;
+      double xv[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        double xv = (4 * g + e <= r) ? w[e] * rsr : 0.0;
-        asm volatile("" : "+v"(xv));  // selects, not a branch around the stores
-        sDv[r * PB + 4 * g + e] = xv;
-        if (PUB) st_dev(dst + e, xv); else dst[e] = xv;
+        xv[e] = (4 * g + e <= r) ? w[e] * rsr : 0.0;
+        asm volatile("" : "+v"(xv[e]));  // selects, not a branch around the stores
+        dv[r * PB + 4 * g + e] = xv[e];
+        dst[e] = xv[e];
       }
-      __builtin_amdgcn_s_setprio(0);
       PPROBE_ACC(5, tq0);
+      PSTEP(0, j, tp0);
+      lds_barrier();  // ---- X(j): L_jj, Dinv_j in LDS; block column j complete in `cur`; trailing tiles carry panels < j
+      PPROBE_ACC(1, tq0);
+      PSTEP(1, j, tp0);
+      const long long tq1 = PPROBE_T0();
+      if (j + 1 < nb) {
+        // X(j+1,j) = T(j+1,j) Dinv_j^T (in place in `cur`; the B operand — Dinv_j[r][4g..4g+3] — is what this lane holds), then the next
+        // diagonal tile T(j+1,j+1) (in sDg, panels < j applied) -= X X^T, into `oth` where (a) of the next step reads it
+        double* tp = cur + (o + PB + r) * PP + 4 * g;
+        const double2 ta = *reinterpret_cast<const double2*>(tp), tc = *reinterpret_cast<const double2*>(tp + 2);
+        v4f64 x = v4f64{0.0, 0.0, 0.0, 0.0};
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(ta.x, xv[0], x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(ta.y, xv[1], x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(tc.x, xv[2], x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(tc.y, xv[3], x, 0, 0, 0);
+        v4f64 dg;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) { cur[(o + PB + g + 4 * rg) * PP + r] = x[rg]; dg[rg] = sDg[(g + 4 * rg) * PP + r]; }
+        __builtin_amdgcn_wave_barrier();
+        dg = tile_update(dg, cur, j + 1, j + 1, r, g);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) oth[(o + PB + g + 4 * rg) * PP + r] = dg[rg];
+      }
+      lds_barrier();  // ---- Y(j): panel j complete in `cur`, the next diagonal tile in `oth`
+      PPROBE_ACC(2, tq1);
+      PSTEP(2, j, tp0);
     }
-    if (PUB && wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // block column j - 1 (L, y) is out: these waves idle here for wave 0 anyway
-    lds_barrier();  // ---- X(j): L_jj, Dinv_j in LDS; block column j complete in `cur`; trailing tiles carry panels < j
-    if (PUB && tid == 64 && j > 0) __hip_atomic_store(pub + blockIdx.x, pbase + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // block columns < j are complete in memory
-    PPROBE_ACC(1, tq0);
-    const long long tq1 = PPROBE_T0();
-    if (wave == 0) {
-      if (lq < PB) {  // y_j = Dinv_j b_j
+    __builtin_amdgcn_s_setprio(0);
+    PPROBE_FLUSH();
+    return;
+  }
+
+  const int jsplit = nb > 8 ? nb - 8 : 0;   // steps before it are bound by the matrix pipes (the chain wave waits), the last eight by the chain
+  if ((wave & 3) == 0) {
+    // ================================================================ SIMD 0's other waves: y_j, and the way out of panel j while the steps
+    // are bound by the matrix pipes (the chain wave, which takes every issue slot of this SIMD during its sweep, then waits for the tiles)
+    __syncthreads();
+    const int lq = tid0 & 63;
+    for (int j = 0; j < nb; ++j) {
+      const double* cur = sP + (j & 1) * PROWS * PP;
+      const int o = PB * j;
+      PARR(j, tp0);
+      lds_barrier();  // ---- X(j)
+      if (wave == 4 && lq < PB) {  // y_j = Dinv_j b_j
         double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
 #pragma unroll
         for (int k = 0; k < PB; k += 4) {
@@ -321,115 +322,93 @@ __global__ __launch_bounds__(512) void k_potrf_panel(double* __restrict__ M, siz
         }
         sRhs[o + lq] = (y0 + y1) + (y2 + y3);
       }
-      if (j + 1 < nb) {
-        // X(j+1,j) = T(j+1,j) Dinv_j^T (in place in `cur`), then the next diagonal tile T(j+1,j+1) (in sDg, panels < j
-        // applied) -= X X^T, into `oth` where (a) of the next step reads it
-        double* tp = cur + (o + PB + fr) * PP + 4 * fk;
-        const double* dp = sDv + fr * PB + 4 * fk;
-        const double2 ta = *reinterpret_cast<const double2*>(tp), tc = *reinterpret_cast<const double2*>(tp + 2);
-        const double2 tb = *reinterpret_cast<const double2*>(dp), td = *reinterpret_cast<const double2*>(dp + 2);
-        const double a0 = ta.x, a1 = ta.y, a2 = tc.x, a3 = tc.y, b0 = tb.x, b1 = tb.y, b2 = td.x, b3 = td.y;
-        v4f64 x = v4f64{0.0, 0.0, 0.0, 0.0};
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, x, 0, 0, 0);
-        v4f64 dg;
+      lds_barrier();  // ---- Y(j)
+      if (j < jsplit) panel_out<192>(cur, sRhs, sdd + PB * (j & 1), Mg, ld, o, n, 64 * ((wave >> 2) - 1) + lq, yout != nullptr ? yout + k0 : nullptr);
+      if (wave == PPROBE_WAVE) PSTEP(3, j, tp0);
+    }
+    return;
+  }
+
+
+  // ================================================================ the tile waves
+  PPROBE_DECL();
+  const int lane0 = tid0 & 63, fr0 = lane0 & 15, fk0 = lane0 >> 4;
+  const int tw = 3 * (wave >> 2) + (wave & 3) - 1;   // 0 .. 11
+  // ---- tile slots of this wave (wave-uniform, packed i | k << 8; k = 99: none): the 119 tiles (i, k), 1 <= k <= i <= 15 except (1,1), in
+  // column-major order, round-robin: every SIMD carries the same number of tiles at every step
+  int tik[NSLOT];
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) { cur[(o + PB + fk + 4 * rg) * PP + fr] = x[rg]; dg[rg] = sDg[(fk + 4 * rg) * PP + fr]; }
-        __builtin_amdgcn_wave_barrier();
-        dg = tile_update(dg, cur, j + 1, j + 1, fr, fk);
+  for (int s = 0; s < NSLOT; ++s) {
+    const int u = 12 * s + tw;
+    int t = u + 1, k = 1;
+    bool ok = u < 119;
+    if (ok) { while (t >= 16 - k) { t -= 16 - k; ++k; } }
+    const int i = k + t;
+    ok = ok && i < nb;
+    tik[s] = ok ? (i | (k << 8)) : (99 << 8);
+  }
+  // ---- the wave's trailing tiles into registers (unconditional loads from a clamped address: a branch per slot would serialise the
+  // memory latencies); diagonal tiles symmetric
+  v4f64 acc[NSLOT];
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) oth[(o + PB + fk + 4 * rg) * PP + fr] = dg[rg];
-      }
-    } else {
-      for (int i = j + 1 + wave; i < nb; i += NTW) {  // X(i,j) for i >= j+2
-        double* tp = cur + (PB * i + fr) * PP + 4 * fk;
-        const double* dp = sDv + fr * PB + 4 * fk;
-        const double2 ta = *reinterpret_cast<const double2*>(tp), tc = *reinterpret_cast<const double2*>(tp + 2);
-        const double2 tb = *reinterpret_cast<const double2*>(dp), td = *reinterpret_cast<const double2*>(dp + 2);
-        const double a0 = ta.x, a1 = ta.y, a2 = tc.x, a3 = tc.y, b0 = tb.x, b1 = tb.y, b2 = td.x, b3 = td.y;
-        v4f64 x = v4f64{0.0, 0.0, 0.0, 0.0};
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, x, 0, 0, 0);
+  for (int s = 0; s < NSLOT; ++s) {
+    const bool on = (tik[s] >> 8) != 99;
+    const int ii = on ? (tik[s] & 255) : 1, kk = on ? (tik[s] >> 8) : 1;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) cur[(PB * i + fk + 4 * rg) * PP + fr] = x[rg];
-      }
+    for (int rg = 0; rg < 4; ++rg) {
+      const int rw = fk0 + 4 * rg;
+      const bool up = ii == kk && fr0 > rw;
+      const double v = Mg[(size_t)(PB * ii + (up ? fr0 : rw)) * ld + PB * kk + (up ? rw : fr0)];
+      acc[s][rg] = on ? v : 0.0;
+    }
+  }
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    double* cur = sP + (j & 1) * PROWS * PP;
+    double* oth = sP + ((j + 1) & 1) * PROWS * PP;
+    const double* dv = sDv;
+    // every per-lane constant of the step is rebuilt from the hardware lane id here: kept across the loop they are spilled
+    // (the accumulator tiles take the registers) and every reload is a memory latency
+    const int lq = hw_lane_id();
+    const int fr = lq & 15, fk = lq >> 4;
+    PARR(j, tp0);
+    lds_barrier();  // ---- X(j)
+    for (int i = j + 2 + tw; i < nb; i += 12) {  // X(i,j) for i >= j+2
+      double* tp = cur + (PB * i + fr) * PP + 4 * fk;
+      const double* dp = dv + fr * PB + 4 * fk;
+      const double2 ta = *reinterpret_cast<const double2*>(tp), tc = *reinterpret_cast<const double2*>(tp + 2);
+      const double2 tb = *reinterpret_cast<const double2*>(dp), td = *reinterpret_cast<const double2*>(dp + 2);
+      v4f64 x = v4f64{0.0, 0.0, 0.0, 0.0};
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(ta.x, tb.x, x, 0, 0, 0);
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(ta.y, tb.y, x, 0, 0, 0);
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(tc.x, td.x, x, 0, 0, 0);
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(tc.y, td.y, x, 0, 0, 0);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) cur[(PB * i + fk + 4 * rg) * PP + fr] = x[rg];
     }
     lds_barrier();  // ---- Y(j): panel j complete in `cur`, the next diagonal tile in `oth`
-    PPROBE_ACC(2, tq1);
     const long long tq2 = PPROBE_T0();
-    if (wave != 0) {
-      // panel j onto every trailing tile of this wave (one pass, four slots at a time); block column j+1 goes on to `oth`
-      // and the diagonal tile (j+2,j+2) to sDg on the way. Tile (j+1,j+1) is wave 0's already.
+    // panel j onto every trailing tile of this wave; block column j+1 goes on to `oth` and the diagonal tile (j+2,j+2) to sDg on the way.
+    // Tile (j+1,j+1) is wave 0's already.
 #pragma unroll
-      for (int s = 0; s < NSLOT; s += 2) {
-        int pk[2]; bool u[2];
+    for (int s = 0; s < NSLOT; ++s) {
+      int pk = tik[s];
+      asm volatile("" : "+s"(pk));  // keeps the LDS row addresses of all slots from being hoisted out of the j loop (spills)
+      const int i = pk & 255, k = pk >> 8;
+      if (k >= j + 1 && k != 99 && !(k == j + 1 && i == k)) {
+        acc[s] = tile_update(acc[s], cur, i, k, fr, fk);
+        if (k == j + 1 || (k == j + 2 && i == k)) {
+          double* dstp = (i == k) ? sDg + fk * PP + fr : oth + (PB * i + fk) * PP + fr;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          pk[e] = tik[s + e];
-          asm volatile("" : "+s"(pk[e]));  // keeps the LDS row addresses of all slots from being hoisted out of the j loop (spills)
-          const int i = pk[e] & 255, k = pk[e] >> 8;
-          u[e] = k >= j + 1 && k != 99 && !(k == j + 1 && i == k);
-        }
-#ifdef PANEL_W4_IDLE
-        if (wave == 4) { u[0] = false; u[1] = false; }
-#endif
-        if (u[0] || u[1]) {
-          tile_update2(acc[s], acc[s + 1], cur, sZero + 4 * fk, pk[0], pk[1], u[0], u[1], fr, fk);
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int i = pk[e] & 255, k = pk[e] >> 8;
-            if (u[e] && (k == j + 1 || (k == j + 2 && i == k))) {
-              const int l2 = hw_lane_id();  // (not a spilled copy of the lane id)
-              const int fr2 = l2 & 15, fk2 = l2 >> 4;
-              double* dstp = (i == k) ? sDg + fk2 * PP + fr2 : oth + (PB * i + fk2) * PP + fr2;
-#pragma unroll
-              for (int rg = 0; rg < 4; ++rg) dstp[4 * rg * PP] = acc[s + e][rg];
-            }
-          }
+          for (int rg = 0; rg < 4; ++rg) dstp[4 * rg * PP] = acc[s][rg];
         }
       }
-      PPROBE_ACC(6, tq2);
-      const long long tq3 = PPROBE_T0();
-      {  // L panel, y, right-hand side update (waves 1..7: 448 threads)
-        const int u = tid - 64;
-        // rows below the diagonal block: 64 bytes per thread, branch-free; the block's own rows (lower part) by 256 threads
-        for (int row = o + PB + (u >> 1); row < n; row += 224) {
-          const double2* src = reinterpret_cast<const double2*>(cur + row * PP + 8 * (u & 1));
-          double2* dst = reinterpret_cast<double2*>(Mg + (size_t)row * ld + o + 8 * (u & 1));
-          const double2 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-          if (PUB) {
-            double* d8 = reinterpret_cast<double*>(dst);
-            st_dev(d8, v0.x); st_dev(d8 + 1, v0.y); st_dev(d8 + 2, v1.x); st_dev(d8 + 3, v1.y);
-            st_dev(d8 + 4, v2.x); st_dev(d8 + 5, v2.y); st_dev(d8 + 6, v3.x); st_dev(d8 + 7, v3.y);
-          } else { dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3; }
-        }
-        if (u < 256) {
-          const int rr = u >> 4, cc = u & 15;
-          if (cc <= rr) Mg[(size_t)(o + rr) * ld + o + cc] = cur[(o + rr) * PP + cc] * sdd[PB * (j & 1) + cc];
-        }
-        for (int col = o + PB + u; col < n; col += 448) {
-          double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-#pragma unroll
-          for (int c = 0; c < PB; c += 4) {
-            t0 += sRhs[o + c] * cur[col * PP + c]; t1 += sRhs[o + c + 1] * cur[col * PP + c + 1];
-            t2 += sRhs[o + c + 2] * cur[col * PP + c + 2]; t3 += sRhs[o + c + 3] * cur[col * PP + c + 3];
-          }
-          sRhs[col] -= (t0 + t1) + (t2 + t3);
-        }
-        if (yout != nullptr && u >= 384 && u < 384 + PB) { if (PUB) st_dev(yout + k0 + o + u - 384, sRhs[o + u - 384]); else yout[k0 + o + u - 384] = sRhs[o + u - 384]; }
-      }
-      PPROBE_ACC(7, tq3);
     }
-    PPROBE_ACC(3, tq2);
-  }
-  if (PUB) {   // the last block column
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid0 == 64) __hip_atomic_store(pub + blockIdx.x, pbase + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PPROBE_ACC(6, tq2);
+    if (wave == PPROBE_WAVE) PSTEP(3, j, tp0);
+    const long long tq3 = PPROBE_T0();
+    if (j >= jsplit) panel_out<768>(cur, sRhs, sdd + PB * (j & 1), Mg, ld, PB * j, n, 64 * tw + lq, yout != nullptr ? yout + k0 : nullptr);   // (the tile waves have the time now)
+    PPROBE_ACC(7, tq3);
   }
   PPROBE_FLUSH();
 }
@@ -539,171 +518,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 //  by block columns, two block columns ahead: 36 us instead of 25 on the chain, a two-step prefetch distance does not cover a memory
 //  latency and every step then pays one; (ii) this kernel with a ring of TWENTY tiles and one wave per SIMD: no change at all — the slab
 //  is bound by its 544 dependent-issue MFMAs on one SIMD (16 Z chains of four dependent instructions each), not by the tile loads.)
-// ---------------------------------------------------------------------------------------------------------------------------
-// The panel pipeline of a multi-panel front (the root of the elimination tree: 8 of the 15 serial panels of the 5-agent map).
-// Per panel the chain was  potrf (88 us)  ->  substitution of the NEXT panel's 256 rows (25 us)  ->  rank-256 update of the next
-// diagonal block (15 us)  -> potrf ..., three dependent launches with their gaps: ~150 us. But block column j of the factor is final
-// after step j of the 16-step potrf, the substitution's step j needs nothing else, and the diagonal update is a sum over block
-// columns of X_j X_j^T: both can run in LOCK STEP behind the factorisation instead of after it. k_panel_follow is launched beside
-// k_potrf_panel<PUB> (another stream) and follows it through device-scope flags:
-//   workgroups 0..3   one wave per 16-row slab of the next panel's rows: step j waits for pub[front] > j (block column j of L,
-//                     Dinv_j and y_j are in memory), forms X_j = its block of the solved rows, stores it device-scope and raises
-//                     slab[front][s] = j + 1, then applies L(j+1.., j) to its remaining blocks (k_trsm_sub's arithmetic)
-//   workgroups 4..7   sixteen waves own the 136 lower 16x16 tiles of the next diagonal block in accumulator registers; step j waits
-//                     for all sixteen slabs and subtracts X_a,j X_b,j^T
-// Nobody the producer depends on ever waits for a consumer (potrf waits for nobody; the slabs wait for potrf only; the update waits
-// for the slabs only), so a late or descheduled consumer only delays itself; every spin is bounded (flag bit 2 -> the solve is
-// reported as failed, the wave leaves). Flags only grow: a launch uses the values pbase + 1 .. pbase + 16 of its epoch.
-// MEASURED, NOT ADOPTED (opt-in COVGPU_PIPE=1; tests/test_gpu_schedule.py holds it to the default's results): correct, but a root
-// panel takes ~250 us instead of 159. Two reasons. (i) A device-scope load or store acknowledgement costs ~4 us here, so a follower
-// step (one round of operand loads, one store) barely fits the 5.5 us the factorisation spends per block column: it cannot catch up.
-// (ii) It cannot START with the factorisation either: the rows it solves carry the look-ahead update of the panel before, which
-// trails that panel's rest-row substitution on another stream (~70 us). Following from the start would need the follower to carry
-// the rows of TWO panels ahead and both their updates (twice the registers and device-scope traffic) — left as a sketch.
-struct FollowArgs {
-  double* M; size_t ld;
-  int k0;                 // first column of the panel being factored
-  int r0;                 // first of the 256 rows that follow it (the next panel's rows)
-  int nb;                 // block columns the factorisation runs (steps)
-  const double* Dinv; double* rhs; const double* yvec;
-  size_t bsM, bsL, bsR; const long long* btab;
-  const int* live; int tI;
-  const int* pub; int* slab; int pbase; int* flag;
-  const int* bulk; int bulk_target;   // bulk[0] >= bulk_target: the previous panel's bulk update (another stream) has written the diagonal block this launch updates (0: nothing to wait for)
-};
-template <int NB>
-COV_DEV void follow_slab(const FollowArgs& g, int batch, int slab, double* Mb, size_t ld) {
-  const int lane = threadIdx.x & 63, n = lane & 15, fk = lane >> 4;
-  const int row0 = g.r0 + PB * slab;
-  const double* Db = g.Dinv + (size_t)batch * g.bsL;
-  const int pr = 4 * (n & 3) + (n >> 2);  // logical row carried by A-operand lane n
-  double* Arow = Mb + (size_t)(row0 + n) * ld + g.k0 + 4 * fk;
-  const double* Lrow = Mb + (size_t)(g.k0 + pr) * ld + g.k0 + 4 * fk;
-  const double* Drow = Db + pr * PB + 4 * fk;
-  v4f64 acc[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) acc[i] = *reinterpret_cast<const v4f64*>(Arow + PB * i);
-  __builtin_amdgcn_s_setprio(3);
-  // One memory latency per step while the follower keeps pace: the progress flag is re-read TOGETHER with the operands of a step
-  // (it decides whether the next step has to poll at all), and X_j is published one step late, behind the next step's loads (a
-  // device-scope store is acknowledged by then: no wait of its own on this chain).
-  int seen = __hip_atomic_load(g.pub + batch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    if (j < g.nb) {   // (wave-uniform)
-      for (int it = 0; seen < g.pbase + j + 1; ++it) {
-        __builtin_amdgcn_s_sleep(2);
-        seen = __hip_atomic_load(g.pub + batch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (it > (1 << 20)) { if (lane == 0) atomicOr(g.flag, 2); return; }   // (never observed; a bounded spin cannot hang the device)
-      }
-      const v4f64 d = ld_dev4(Drow + (size_t)(j >> 3) * kTile * kTile + (j & 7) * 256);
-      v4f64 lt[NB];
-#pragma unroll
-      for (int i = j + 1; i < NB; ++i) if (i < g.nb) lt[i] = ld_dev4(Lrow + (size_t)(PB * i) * ld + PB * j);
-      const int nxt = __hip_atomic_load(g.pub + batch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the operands are here, and the store of X_(j-1) (older than all of them) is acknowledged
-      if (j > 0 && lane == 0) __hip_atomic_store(g.slab + 16 * batch + slab, g.pbase + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      seen = nxt;
-      v4f64 Z = v4f64{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(d[s2], acc[j][s2], Z, 0, 0, 0);
-      acc[j] = Z;
-      st_dev4(Arow + PB * j, Z);
-      const v4f64 Zn = -Z;
-#pragma unroll
-      for (int i = j + 1; i < NB; ++i)
-        if (i < g.nb) {
-#pragma unroll
-          for (int s2 = 0; s2 < 4; ++s2) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[i][s2], Zn[s2], acc[i], 0, 0, 0);
-        }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) __hip_atomic_store(g.slab + 16 * batch + slab, g.pbase + g.nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (g.rhs != nullptr) {  // rhs[row0 + n] -= sum_k X[n][k] y[k] (y of the padding block columns is zero)
-    const double* yv = g.yvec + (size_t)batch * g.bsR + g.k0 + 4 * fk;
-    double part = 0.0;
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      if (i < g.nb) {
-        const v4f64 y4 = ld_dev4(yv + PB * i);
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) part += acc[i][s2] * y4[s2];
-      }
-    part += __shfl_xor(part, 16, 64);
-    part += __shfl_xor(part, 32, 64);
-    if (fk == 0) g.rhs[(size_t)batch * g.bsR + row0 + n] -= part;
-  }
-}
-COV_DEV void follow_update(const FollowArgs& g, int batch, int wr, double* Mb, size_t ld) {
-  const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
-  constexpr int NT = 9;   // 136 lower tiles of the 256x256 diagonal block over 16 waves
-  int ta[NT], tb[NT];
-  v4f64 acc[NT];
-#pragma unroll
-  for (int k = 0; k < NT; ++k) {
-    const int t = wr + 16 * k;
-    int a = 0;
-    while ((a + 1) * (a + 2) / 2 <= t) ++a;
-    ta[k] = t < 136 ? a : -1; tb[k] = t - a * (a + 1) / 2;
-    acc[k] = v4f64{0.0, 0.0, 0.0, 0.0};   // (the block itself is read at the END: its previous writer may still be running)
-  }
-  auto slabs_done = [&]() {   // block columns of X every one of the sixteen slabs has published
-    int v = lane < 16 ? __hip_atomic_load(g.slab + 16 * batch + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-    return __builtin_amdgcn_readfirstlane(v) - g.pbase;
-  };
-  int ready = slabs_done();
-  for (int j = 0; j < g.nb; ++j) {
-    for (int it = 0; ready < j + 1; ++it) {
-      __builtin_amdgcn_s_sleep(2);
-      ready = slabs_done();
-      if (it > (1 << 20)) { if (lane == 0) atomicOr(g.flag, 2); return; }
-    }
-    const double* Xc = Mb + (size_t)(g.r0 + fr) * ld + g.k0 + PB * j + 4 * fk;
-    v4f64 xa[NT], xb[NT];
-#pragma unroll
-    for (int k = 0; k < NT; ++k)
-      if (ta[k] >= 0) { xa[k] = ld_dev4(Xc + (size_t)(PB * ta[k]) * ld); xb[k] = ld_dev4(Xc + (size_t)(PB * tb[k]) * ld); }   // (wave-uniform)
-    ready = slabs_done();   // (re-read with the operands: decides whether the next step polls)
-#pragma unroll
-    for (int k = 0; k < NT; ++k)
-      if (ta[k] >= 0) {
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[k][s2], xb[k][s2], acc[k], 0, 0, 0);
-      }
-  }
-  // the diagonal block += what was gathered, once its previous writer — the bulk update of the panel before, on its own stream — is done
-  for (int it = 0; g.bulk_target > 0 && __hip_atomic_load(g.bulk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.bulk_target; ++it) {
-    __builtin_amdgcn_s_sleep(4);
-    if (it > (1 << 20)) { if (lane == 0) atomicOr(g.flag, 2); return; }
-  }
-#pragma unroll
-  for (int k = 0; k < NT; ++k)
-    if (ta[k] >= 0) {
-      double* dst = Mb + (size_t)(g.r0 + PB * ta[k] + fk) * ld + g.r0 + PB * tb[k] + fr;
-      double v[4];
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) v[rg] = ld_dev(dst + (size_t)(4 * rg) * ld);
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) dst[(size_t)(4 * rg) * ld] = v[rg] + acc[k][rg];
-    }
-}
-__global__ void k_flag_set(int* p, int v) { if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-void launch_flag_set(int* p, int v, hipStream_t st) { hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, st, p, v); }
-template <int NB>
-__global__ __launch_bounds__(256) void k_panel_follow(FollowArgs g) {
-  const int batch = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (g.live != nullptr) {  // a front whose interior does not reach this panel / the next one: identity padding, nothing to follow
-    const int nI = g.live[2 * batch];
-    if (!(g.k0 / kTile < nI) || !(g.r0 / kTile < nI)) return;
-  }
-  double* Mb = g.M + (g.btab != nullptr ? (size_t)g.btab[2 * batch] : (size_t)batch * g.bsM);
-  const size_t ld = g.btab != nullptr ? (size_t)g.btab[2 * batch + 1] : g.ld;
-  if (blockIdx.x < 4) follow_slab<NB>(g, batch, 4 * (int)blockIdx.x + wave, Mb, ld);
-  else follow_update(g, batch, 4 * ((int)blockIdx.x - 4) + wave, Mb, ld);
-}
+// (Measured and dropped, round 4: a panel PIPELINE for multi-panel fronts — the factorisation publishing its block columns through
+//  device-scope flags, a second launch on another stream following it in lock step with the substitution of the next panel's rows and
+//  the update of the next diagonal block. Correct, but a root panel took ~250 us instead of 159: a device-scope load / store
+//  acknowledgement costs ~4 us here, as long as a whole factorisation step. profiles/r04_ab_experiments.txt; the code is in the history
+//  of this file, commit 5ecf8c0.)
 
 // Backward substitution step for tile p with the 16x16 block inverses (Dinv == nullptr: x_p is given):
 //   x_p = L_pp^-T y_p ; y[cols left of the tile] -= L[tile rows, cols]^T x_p.
@@ -979,32 +798,16 @@ void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, dou
 }
 
 void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
-                        hipStream_t st, const long long* btab, int nb, int* pub, int pbase) {
+                        hipStream_t st, const long long* btab, int nb) {
   if (nb < 0) nb = 8 * w;
   if (nb == 0) return;  // an all-padding panel of every front of the batch: L = I, Dinv = I, y = 0 are in place
   static bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds);
     return true;
   }();
   (void)once;
-  if (pub != nullptr)
-    hipLaunchKernelGGL(k_potrf_panel<true>, dim3(nbt), dim3(512), kPanelLds, st, S, ld, t0 * kTile, nb, Linv + (size_t)t0 * kTile * kTile, flag,
-                       (const double*)b, b ? b + npad : nullptr, sM, sL, sR, btab, pub, pbase);
-  else
-    hipLaunchKernelGGL(k_potrf_panel<false>, dim3(nbt), dim3(512), kPanelLds, st, S, ld, t0 * kTile, nb, Linv + (size_t)t0 * kTile * kTile, flag,
-                       (const double*)b, b ? b + npad : nullptr, sM, sL, sR, btab, (int*)nullptr, 0);
-}
-// the follower of a published panel factorisation (k_panel_follow): substitution of the 256 rows from tile row t0 + 2 and the rank
-// update of the diagonal block they meet, in lock step behind k_potrf_panel<PUB> running on another stream
-void launch_panel_follow(double* S, size_t ld, int t0, const double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
-                         hipStream_t st, const long long* btab, const int* live, int tI, int nb, const int* pub, int* slab, int pbase, const int* bulk, int bulk_target) {
-  FollowArgs g{S, ld, t0 * kTile, (t0 + 2) * kTile, nb, Linv + (size_t)t0 * kTile * kTile, b, b ? b + npad : nullptr, sM, sL, sR, btab, live, tI, pub, slab, pbase, flag, bulk, bulk_target};
-  const dim3 grid(8, nbt);
-  if (nb <= 4) hipLaunchKernelGGL(k_panel_follow<4>, grid, dim3(256), 0, st, g);
-  else if (nb <= 8) hipLaunchKernelGGL(k_panel_follow<8>, grid, dim3(256), 0, st, g);
-  else if (nb <= 12) hipLaunchKernelGGL(k_panel_follow<12>, grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL(k_panel_follow<16>, grid, dim3(256), 0, st, g);
+  hipLaunchKernelGGL(k_potrf_panel, dim3(nbt), dim3(64 * NW), kPanelLds, st, S, ld, t0 * kTile, nb, Linv + (size_t)t0 * kTile * kTile, flag,
+                     (const double*)b, b ? b + npad : nullptr, sM, sL, sR, btab);
 }
 
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,

@@ -84,6 +84,16 @@ int main() {
     hipDeviceSynchronize();
     printf("k_potrf_panel nb=%d (x%d batched): best %.1f us; phases (sum over %d steps) A %.1f (wave 0's diagonal block alone %.1f)  B %.1f  C %.1f us; prologue %.1f us; wave 1: tile updates %.1f  L store + rhs %.1f us\n",
            nb, NBT, best * 1e3, nb, ph[1], ph[5], ph[2], ph[3], ph[4], ph[6], ph[7]);
+    if (nb == 16) {
+      long long ps[4][16]; hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_pstep), sizeof(ps));
+      printf("  step: sweep done | past X | past Y | wave %d updates done  [us from kernel start]\n", PPROBE_WAVE);
+      for (int j = 0; j < 16; ++j) printf("   %2d: %6.2f %6.2f %6.2f %6.2f\n", j, ps[0][j] / 2400.0, ps[1][j] / 2400.0, ps[2][j] / 2400.0, ps[3][j] / 2400.0);
+    }
+    if (nb == 16) {
+      long long pa[16][16]; hipMemcpyFromSymbol(pa, HIP_SYMBOL(g_parr), sizeof(pa));
+      printf("  arrival at X(j) [us], waves 1..15:\n");
+      for (int j = 1; j < 16; ++j) { printf("   %2d:", j); for (int w = 1; w < 16; ++w) printf(" %6.2f", pa[w][j] / 2400.0); printf("\n"); }
+    }
     // rows below by block substitution
     float bestT = 1e9;
     std::vector<double> Apost(A.size());

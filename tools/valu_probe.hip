@@ -82,6 +82,33 @@ __global__ __launch_bounds__(64) void k(double* out, const double* in) {
   out[32 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + i1 + i2 + i3 + s0 + s1 + s2 + s3 + lds[(threadIdx.x + 1) & 63];
 }
 
+// sixteen waves (four per SIMD), each a dependent chain of 1024 v_mfma_f64_16x16x4: cycles per instruction as seen by one SIMD
+__global__ __launch_bounds__(1024) void k16(double* out, const double* in, int lds_reads) {
+  typedef double v4 __attribute__((ext_vector_type(4)));
+  __shared__ double lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += 1024) lds[i] = in[i & 63];
+  double m = in[threadIdx.x & 63];
+  v4 acc = {m, m, m, m};
+  __syncthreads();
+  const long long t0 = clock64();
+  for (int it = 0; it < 256; ++it) {
+    double a0 = m, a1 = m, a2 = m, a3 = m;
+    if (lds_reads) {  // the operand pattern of a tile update: 4 x 16 bytes per lane
+      const double2* p = reinterpret_cast<const double2*>(lds + (((threadIdx.x & 15) * 18 + 4 * ((threadIdx.x >> 4) & 3) + 16 * it) & 4095 & ~1));
+      const double2 x = p[0], y = p[1];
+      a0 = x.x; a1 = x.y; a2 = y.x; a3 = y.y;
+    }
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, m, acc, 0, 0, 0);
+  }
+  __syncthreads();
+  const long long t1 = clock64();
+  if (threadIdx.x == 0) out[0] = (double)(t1 - t0) / (4.0 * 1024.0);
+  out[64 + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+}
+
 int main() {
   double *out, *in;
   hipMalloc(&out, 4096); hipMalloc(&in, 4096);
@@ -92,5 +119,10 @@ int main() {
                         "2 readlane + fmac(sgpr) [per group of 3, /16 counts 4 groups as 16]", "v_rcp_f64 dependent", "ds_bpermute_b32 independent", "ds_bpermute_b32 dependent", "ds_write_b64+ds_read_b64 round trip",
                         "v_mov_b64_dpp -> v_fmac_f64 pair", "s_nop 1 + v_fmac_f64_dpp dependent", "v_mfma_f64_16x16x4 dependent", "v_mfma_f64_4x4x4 dependent", "ds_read_b32 dependent address", "v_mfma_f64_16x16x4 two chains interleaved"};
   for (int i = 0; i < 17; ++i) printf("%-70s %8.1f cycles\n", nm[i], h[i]);
+  for (int lr = 0; lr < 2; ++lr) {
+    for (int r = 0; r < 3; ++r) { hipLaunchKernelGGL(k16, dim3(1), dim3(1024), 0, 0, out, in, lr); hipDeviceSynchronize(); }
+    hipMemcpy(h, out, 8, hipMemcpyDeviceToHost);
+    printf("16 waves x 1024 dependent v_mfma_f64_16x16x4%s: %.1f cycles per instruction and SIMD\n", lr ? " + LDS operand reads" : "", h[0]);
+  }
   return 0;
 }

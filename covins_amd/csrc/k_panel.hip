@@ -46,7 +46,7 @@ __device__ long long g_parr[16][16];   // arrival of every wave at barrier X(j)
 #define PPROBE_DECL() long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define PPROBE_ACC(i, t0) do { pacc[i] += clock64() - (t0); } while (0)
 #define PPROBE_T0() clock64()
-#define PPROBE_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 6; ++i_) g_pprobe[i_] = pacc[i_]; if (threadIdx.x == 64 * PPROBE_WAVE) { g_pprobe[6] = pacc[6]; g_pprobe[7] = pacc[7]; } } while (0)
+#define PPROBE_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 1; i_ < 6; ++i_) g_pprobe[i_] = pacc[i_]; if (threadIdx.x == 64 * PPROBE_WAVE) { g_pprobe[6] = pacc[6]; g_pprobe[7] = pacc[7]; } } while (0)
 #else
 #define PPROBE_DECL() do {} while (0)
 #define PPROBE_ACC(i, t0) do {} while (0)
@@ -135,6 +135,17 @@ COV_DEV v4f64 tile_update(v4f64 acc, const double* pan, int i, int k, int fr, in
   return acc;
 }
 
+// the 119 trailing tiles (i, k), 1 <= k <= i <= 15 except (1,1), in column-major order, packed i | k << 8
+struct PanelTileTab { int v[119]; };
+constexpr PanelTileTab make_panel_tiles() {
+  PanelTileTab t{};
+  int u = 0;
+  for (int k = 1; k < 16; ++k)
+    for (int i = k; i < 16; ++i) { if (i == 1 && k == 1) continue; t.v[u++] = i | (k << 8); }
+  return t;
+}
+__constant__ PanelTileTab kPanelTile = make_panel_tiles();
+
 // Panel j (LDS, complete: block column j of the factor from row o = 16 j on, raw diagonal block + its column factors `rs`) leaves for
 // memory, and the right-hand side below it takes y_j (in sRhs[o ..)): thread u of NT, half rows of 64 bytes.
 template <int NT>
@@ -198,27 +209,42 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M,
   const long long tp0 = PPROBE_T0();
 
   // ---- block column 0 (its diagonal tile SYMMETRIC: an entry above the diagonal is read from its mirror image — the sweep of wave 0
-  // wants whole rows), the diagonal tile (1,1) and the right-hand side into LDS
-  {
-    const int row = tid0 >> 2, qt = tid0 & 3;
-    if (row < n) {
-      double v[4];
+  // wants whole rows), the diagonal tile (1,1) and the right-hand side go to LDS: by the four waves of SIMD 0 (a row per thread), which
+  // own no tiles. The tile waves only ISSUE the loads of their tiles before the barrier behind the prologue (first needed at the end of
+  // step 0) and go on to barrier X(0): the chain wave starts its sweep one memory round trip after the launch, beside them.
+  auto fill_lds = [&]() {
+    const int fid = 64 * (wave >> 2) + (tid0 & 63);   // 0 .. 255
+    double fv[PB], frhs = 0.0, fdg = 0.0;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { const int col = 4 * qt + c; const bool up = row < PB && col > row; v[c] = Mg[(size_t)(up ? col : row) * ld + (up ? row : col)]; }
+    for (int c = 0; c < PB; ++c) fv[c] = 0.0;
+    if (fid < n) {
+      if (fid >= PB) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) sP[row * PP + 4 * qt + c] = v[c];
+        for (int c = 0; c < PB; c += 2) { const double2 v = *reinterpret_cast<const double2*>(Mg + (size_t)fid * ld + c); fv[c] = v.x; fv[c + 1] = v.y; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < PB; ++c) fv[c] = Mg[(size_t)(c > fid ? c : fid) * ld + (c > fid ? fid : c)];
+      }
+      if (rhs != nullptr) frhs = rhs[k0 + fid];
     }
-    if (tid0 >= 512 && tid0 < 512 + PROWS) { const int t = tid0 - 512; sRhs[t] = (rhs != nullptr && t < n) ? rhs[k0 + t] : 0.0; }
-    if (tid0 >= 768 && nb > 1) {  // diagonal tile (1,1): wave 0 takes it over at step 0 (see below)
-      const int rr = (tid0 - 768) >> 4, cc = tid0 & 15;
-      sDg[rr * PP + cc] = Mg[(size_t)(PB + (cc <= rr ? rr : cc)) * ld + PB + (cc <= rr ? cc : rr)];
+    if (nb > 1) {  // diagonal tile (1,1): wave 0 takes it over at step 0 (see below)
+      const int rr = fid >> 4, cc = fid & 15;
+      fdg = Mg[(size_t)(PB + (cc <= rr ? rr : cc)) * ld + PB + (cc <= rr ? cc : rr)];
     }
-  }
+    if (fid < n) {
+#pragma unroll
+      for (int c = 0; c < PB; c += 2) *reinterpret_cast<double2*>(sP + fid * PP + c) = double2{fv[c], fv[c + 1]};
+    }
+    sRhs[fid] = frhs;
+    if (nb > 1) sDg[(fid >> 4) * PP + (fid & 15)] = fdg;
+    // (no barrier of its own: the first one everybody meets is X(0); before it the chain wave only reads rows 0..15 of block column 0,
+    //  which its own lanes have just written)
+  };
 
   if (wave == 0) {
     // ================================================================ the chain
     PPROBE_DECL();
-    __syncthreads();
+    fill_lds();
     PPROBE_ACC(4, tp0);
     __builtin_amdgcn_s_setprio(3);
     for (int j = 0; j < nb; ++j) {
@@ -306,7 +332,7 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M,
   if ((wave & 3) == 0) {
     // ================================================================ SIMD 0's other waves: y_j, and the way out of panel j while the steps
     // are bound by the matrix pipes (the chain wave, which takes every issue slot of this SIMD during its sweep, then waits for the tiles)
-    __syncthreads();
+    fill_lds();
     const int lq = tid0 & 63;
     for (int j = 0; j < nb; ++j) {
       const double* cur = sP + (j & 1) * PROWS * PP;
@@ -340,29 +366,30 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M,
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
     const int u = 12 * s + tw;
-    int t = u + 1, k = 1;
-    bool ok = u < 119;
-    if (ok) { while (t >= 16 - k) { t -= 16 - k; ++k; } }
-    const int i = k + t;
-    ok = ok && i < nb;
-    tik[s] = ok ? (i | (k << 8)) : (99 << 8);
+    const int pk = kPanelTile.v[u < 119 ? u : 0];   // (a table: the search for the column was ~1 us of scalar loops per wave)
+    tik[s] = (u < 119 && (pk & 255) < nb) ? pk : (99 << 8);
   }
-  // ---- the wave's trailing tiles into registers (unconditional loads from a clamped address: a branch per slot would serialise the
-  // memory latencies); diagonal tiles symmetric
+  // ---- the wave's trailing tiles into registers: the loads are only ISSUED here (see above): addresses from four per-lane offsets (and
+  // four mirrored ones for the diagonal tiles, kept symmetric) and a wave-uniform base per tile; a slot without a tile loads tile (1,1)
+  // and never looks at it again (a select would wait for the load)
+  unsigned offn[4], offm[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const int rw = fk0 + 4 * rg;
+    offn[rg] = (unsigned)rw * (unsigned)ld + (unsigned)fr0;
+    offm[rg] = fr0 > rw ? (unsigned)fr0 * (unsigned)ld + (unsigned)rw : offn[rg];
+  }
   v4f64 acc[NSLOT];
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
     const bool on = (tik[s] >> 8) != 99;
     const int ii = on ? (tik[s] & 255) : 1, kk = on ? (tik[s] >> 8) : 1;
+    const double* base = Mg + (size_t)(PB * ii) * ld + PB * kk;
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int rw = fk0 + 4 * rg;
-      const bool up = ii == kk && fr0 > rw;
-      const double v = Mg[(size_t)(PB * ii + (up ? fr0 : rw)) * ld + PB * kk + (up ? rw : fr0)];
-      acc[s][rg] = on ? v : 0.0;
-    }
+    for (int rg = 0; rg < 4; ++rg) acc[s][rg] = base[ii == kk ? offm[rg] : offn[rg]];
   }
-  __syncthreads();
+  // (480 eight-byte loads per workgroup are ~3 us of the CU's address path, the prologue is as long as they take to issue. Measured and
+  //  dropped: half of them behind barrier X(0) — the conditional load inside the step loop costs 38 spilled registers.)
   for (int j = 0; j < nb; ++j) {
     double* cur = sP + (j & 1) * PROWS * PP;
     double* oth = sP + ((j + 1) & 1) * PROWS * PP;

@@ -65,7 +65,7 @@ int main() {
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
       long long pr[8]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_pprobe), sizeof(pr));
-      for (int k = 1; k <= 7; ++k) ph[k] = std::min(ph[k], pr[k] / 2400.0);  // shader cycles at 2.4 GHz
+      for (int k = 0; k <= 7; ++k) ph[k] = std::min(ph[k], pr[k] / 2400.0);  // shader cycles at 2.4 GHz
     }
     for (int nbt : {1, 2, 5}) {  // is the batch concurrent? (needs NBT >= nbt matrices: reuse the first)
       float bq = 1e9;
@@ -92,7 +92,7 @@ int main() {
     if (nb == 16) {
       long long pa[16][16]; hipMemcpyFromSymbol(pa, HIP_SYMBOL(g_parr), sizeof(pa));
       printf("  arrival at X(j) [us], waves 1..15:\n");
-      for (int j = 1; j < 16; ++j) { printf("   %2d:", j); for (int w = 1; w < 16; ++w) printf(" %6.2f", pa[w][j] / 2400.0); printf("\n"); }
+      for (int j = 0; j < 16; ++j) { printf("   %2d:", j); for (int w = 1; w < 16; ++w) printf(" %6.2f", pa[w][j] / 2400.0); printf("\n"); }
     }
     // rows below by block substitution
     float bestT = 1e9;

@@ -541,6 +541,132 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   trsm_sub_body<NB>(g);
 }
 
+// The same substitution with FOUR waves per slab, one per SIMD: the single wave above is bound by ITS matrix pipe (544 v_mfma_f64_16x16x4 of
+// 64 cycles, dependent or not: 14.5 us before any load latency), and on the serial chain sixteen slabs are all there is to run. Wave w owns
+// the blocks i = w, w + 4, ... of Z. Nobody waits at a barrier: block j of Z goes through LDS (all sixteen kept) behind a counter the
+// other waves poll, and the wave that owns block j + 1 applies L(j+1, j) to it FIRST, publishes Z_{j+1} = Dinv_{j+1} acc_{j+1} and only
+// then catches up on its other blocks — the chain is (read Z_j, 4 MFMAs, 4 MFMAs, write Z_{j+1}) per step, everything else fills in behind.
+// The L tiles of a wave stream through a ring of registers in a FIXED order (step-major; its slot of the next owner's block row is fetched
+// and dropped when it lies on or above the diagonal: ring positions stay compile-time constants).
+#ifdef COVGPU_PROBE
+__device__ long long g_tprobe[4][24];
+#define TPROBE(k) do { if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_tprobe[wave][k] = clock64() - tstart; } while (0)
+#else
+#define TPROBE(k) do {} while (0)
+#endif
+template <int NB>
+COV_DEV void trsm_sub4_body(const TrsmSubArgs& g, v4f64 (*zall)[64], int* zcount, double (*spart)[16]) {
+  constexpr int MB = NB / 4;
+  const int batch = blockIdx.y, lane = threadIdx.x & 63, n = lane & 15, fk = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row0 = g.r0 + PB * (int)blockIdx.x;
+#ifdef COVGPU_PROBE
+  const long long tstart = clock64();
+#endif
+  if (g.chain) __builtin_amdgcn_s_setprio(3);
+  double* Mb = g.M + (g.btab != nullptr ? (size_t)g.btab[2 * batch] : (size_t)batch * g.bsM);
+  const size_t ld = g.btab != nullptr ? (size_t)g.btab[2 * batch + 1] : g.ld;
+  const double* Db = g.Dinv + (size_t)batch * g.bsL;
+  const int pr = 4 * (n & 3) + (n >> 2);  // logical row carried by A-operand lane n
+  double* Arow = Mb + (size_t)(row0 + n) * ld + g.k0 + 4 * fk;
+  const double* Lrow = Mb + (size_t)(g.k0 + pr) * ld + g.k0 + 4 * fk;
+  const double* Drow = Db + pr * PB + 4 * fk;
+  auto Ltile = [&](int i, int j) { return *reinterpret_cast<const v4f64*>(Lrow + (size_t)(PB * i) * ld + PB * j); };
+  auto Dblk = [&](int j) { return *reinterpret_cast<const v4f64*>(Drow + (size_t)(j >> 3) * kTile * kTile + (j & 7) * 256); };
+  v4f64 acc[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) acc[m] = *reinterpret_cast<const v4f64*>(Arow + PB * (4 * m + wave));
+  v4f64 dmine[MB];   // the block inverses of this wave's blocks
+#pragma unroll
+  for (int m = 0; m < MB; ++m) dmine[m] = Dblk(4 * m + wave);
+  constexpr int RING = 8;
+  v4f64 ring[RING];
+  // fetch cursor over the fixed sequence: for j = 0 .. NB-2, for m = (j + 1) / 4 .. MB-1 -> tile (4 m + wave, j)
+  int pj = 0, pm = 0, pt = 0;
+  auto fetch = [&]() {
+    if (pj < NB - 1) {
+      ring[pt % RING] = Ltile(4 * pm + wave, pj); ++pt;
+      if (++pm >= MB) { ++pj; pm = (pj + 1) >> 2; }
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < RING - 1; ++k) fetch();
+  auto publish = [&](int j, int m) {   // Z_j = Dinv_j acc_j: final block of X, and -Z_j for everybody
+    v4f64 Z = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(dmine[m][s], acc[m][s], Z, 0, 0, 0);
+    acc[m] = Z;
+    zall[j][lane] = -Z;
+    if (lane == 0) __hip_atomic_store(zcount, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS operations of a wave execute in order)
+  };
+  if (wave == 0) publish(0, 0);
+  int t = 0;
+#pragma unroll
+  for (int j = 0; j + 1 < NB; ++j) {
+    const int o1 = (j + 1) & 3, m1 = (j + 1) >> 2;
+    if (wave != (j & 3)) {   // (the publisher itself need not look)
+      int spins = 0;
+      while (__hip_atomic_load(zcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < j + 1 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+    }
+    const v4f64 Zn = zall[j][lane];
+    if (NB == 16) TPROBE(j);
+#pragma unroll
+    for (int m = m1; m < MB; ++m) {
+      fetch();
+      if (m > m1 || wave >= o1) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[t % RING][s], Zn[s], acc[m], 0, 0, 0);
+      }
+      ++t;
+      if (m == m1 && wave == o1) publish(j + 1, m1);
+    }
+  }
+  if (NB == 16) TPROBE(16);
+#pragma unroll
+  for (int m = 0; m < MB; ++m) *reinterpret_cast<v4f64*>(Arow + PB * (4 * m + wave)) = acc[m];
+  if (g.rhs != nullptr) {  // rhs[row0 + n] -= sum_k X[n][k] y[k]: lane partial, fixed butterfly over the four lanes sharing n, waves in order
+    const double* yv = g.yvec + (size_t)batch * g.bsR + g.k0 + 4 * fk;
+    double part = 0.0;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const v4f64 y4 = *reinterpret_cast<const v4f64*>(yv + PB * (4 * m + wave));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) part += acc[m][s] * y4[s];
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (fk == 0) spart[wave][n] = part;
+    lds_barrier();
+    if (wave == 0 && fk == 0) g.rhs[(size_t)batch * g.bsR + row0 + n] -= ((spart[0][n] + spart[1][n]) + spart[2][n]) + spart[3][n];
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_trsm_sub4(TrsmSubArgs g) {
+  __shared__ v4f64 zall[16][64];
+  __shared__ double spart[4][16];
+  __shared__ int zcount;
+  if (g.live != nullptr) {
+    const int batch = blockIdx.y, row0 = g.r0 + PB * (int)blockIdx.x;
+    const int nI = g.live[2 * batch], nO = g.live[2 * batch + 1];
+    const int tp = g.k0 / kTile, tr = row0 / kTile;
+    if (!(tp < nI || (tp >= g.tI && tp - g.tI < nO))) return;
+    if (!(tr < nI || (tr >= g.tI && tr - g.tI < nO))) return;
+  }
+  int nbf = NB;
+  if (g.own != nullptr) {
+    const int real = g.own[blockIdx.y] - g.k0;
+    if (real <= 0) return;
+    nbf = (real + PB - 1) / PB;
+  }
+  if (threadIdx.x == 0) zcount = 0;
+  __syncthreads();
+  if (NB > 4 && nbf <= 4) { trsm_sub4_body<4>(g, zall, &zcount, spart); return; }
+  if (NB > 8 && nbf <= 8) { trsm_sub4_body<8>(g, zall, &zcount, spart); return; }
+  if (NB > 12 && nbf <= 12) { trsm_sub4_body<12>(g, zall, &zcount, spart); return; }
+  trsm_sub4_body<NB>(g, zall, &zcount, spart);
+}
+
 // (Measured and dropped, round 4 — both bit-identical to this kernel: (i) four slabs per workgroup with the factor streamed through LDS
 //  by block columns, two block columns ahead: 36 us instead of 25 on the chain, a two-step prefetch distance does not cover a memory
 //  latency and every step then pays one; (ii) this kernel with a ring of TWENTY tiles and one wave per SIMD: no change at all — the slab
@@ -844,6 +970,14 @@ void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const 
   const dim3 grid((r1 - r0) * (kTile / PB), nbt);
   // nb: 16-column blocks of the panel that hold real columns (the rest is identity padding with zeros below: X = A there)
   const int need = nb > 0 ? std::min(nb, 8 * w) : 8 * w;
+  static const int four = getenv("COVGPU_TRSM4") == nullptr ? 1 : atoi(getenv("COVGPU_TRSM4"));   // 0: one wave per slab everywhere; 2: four waves on the serial chain only
+  if (four == 1 || (four == 2 && chain)) {
+    if (need <= 4) hipLaunchKernelGGL(k_trsm_sub4<4>, grid, dim3(256), 0, st, g);
+    else if (need <= 8) hipLaunchKernelGGL(k_trsm_sub4<8>, grid, dim3(256), 0, st, g);
+    else if (need <= 12) hipLaunchKernelGGL(k_trsm_sub4<12>, grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(k_trsm_sub4<16>, grid, dim3(256), 0, st, g);
+    return;
+  }
   if (need <= 4) hipLaunchKernelGGL(k_trsm_sub<4>, grid, dim3(64), 0, st, g);
   else if (need <= 8) hipLaunchKernelGGL(k_trsm_sub<8>, grid, dim3(64), 0, st, g);
   else if (need <= 12) hipLaunchKernelGGL(k_trsm_sub<12>, grid, dim3(64), 0, st, g);

@@ -55,6 +55,13 @@ constexpr int KC = 16;        // K chunk staged through LDS (full-tile kernels)
 constexpr int KCQ = 32;       // quarter forms: they run at memory LATENCY (one dependent global->LDS step per chunk while the
                               // chip is loaded: ~3 us each), so fewer, larger chunks
 constexpr int LDT = KC + 1;   // LDS pitch (doubles): odd pitch -> conflict-free fragment reads
+#ifndef COVGPU_PFF
+#define COVGPU_PFF 1
+#endif
+#ifndef COVGPU_PFQ
+#define COVGPU_PFQ 4
+#endif
+constexpr int PFF = COVGPU_PFF, PFQ = COVGPU_PFQ;   // chunks in flight in registers: full tiles, quarter forms
 
 enum { MODE_SYRK_TRI = 0, MODE_SYRK_RECT = 1, MODE_TRSM = 2 };
 
@@ -104,7 +111,10 @@ __device__ __forceinline__ bool tile_live(const GemmArgs& g, int batch, int t) {
 // tiles, 48 -> 96 for the quarter forms; spills stay outside the K loop) makes them fit — and changes nothing
 // end to end (27.85 vs 27.65 ms, bulk 41.0 vs 42.5 TFLOP/s): under load the quarter kernels are bound by their
 // 4-16 dependent global -> LDS steps at loaded memory latency, not by the dispatch.
-template <int MODE, int TSA, int TSB, int KC>
+// workgroup barrier that orders LDS traffic only (no s_waitcnt vmcnt(0): global loads stay in flight across it)
+COV_DEV void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int MODE, int TSA, int TSB, int KC, int PF>
 COV_DEV void gemm_abt_body(const GemmArgs& g) {
   constexpr int LDT = KC + 1;
   static_assert((TSA == kTile && TSB == kTile) || (MODE != MODE_TRSM && TSA == 64 && TSB == 64) ||
@@ -169,16 +179,20 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
   constexpr int LPR = KC / 2, RPP = 256 / LPR, NPA = TSA / RPP, NPB = TSB / RPP;
   const int c2 = (tid % LPR) * 2, rbase = tid / LPR;
   const unsigned offa = (unsigned)rbase * ldab + (unsigned)c2 * 8u, offb = (unsigned)rbase * ldbb + (unsigned)c2 * 8u;
-  double2 pa[NPA], pb[NPB];
-  auto gload = [&](int kc) {
+  // PF chunks are in flight in registers (stage = chunk index mod PF: the K loop is unrolled by PF). With one chunk ahead the quarter
+  // forms ran at memory latency — a chunk is 0.85 us of matrix work, a load under load 2-3 us, and a launch of ~300 workgroups leaves one
+  // or two per CU: nothing else to run meanwhile.
+  double2 pa[PF][NPA], pb[PF][NPB];
+  auto gload = [&](int kc, int st) {
     const char* Ak = Ag + (size_t)kc * sizeof(double);  // uniform
     const char* Bk = Bg + (size_t)kc * sizeof(double);
 #pragma unroll
-    for (int it = 0; it < NPA; ++it) pa[it] = *reinterpret_cast<const double2*>(Ak + (size_t)(RPP * it) * ldab + offa);
+    for (int it = 0; it < NPA; ++it) pa[st][it] = *reinterpret_cast<const double2*>(Ak + (size_t)(RPP * it) * ldab + offa);
 #pragma unroll
-    for (int it = 0; it < NPB; ++it) pb[it] = *reinterpret_cast<const double2*>(Bk + (size_t)(RPP * it) * ldbb + offb);
+    for (int it = 0; it < NPB; ++it) pb[st][it] = *reinterpret_cast<const double2*>(Bk + (size_t)(RPP * it) * ldbb + offb);
   };
-  gload(kbeg);
+#pragma unroll
+  for (int u = 0; u < PF; ++u) if (kbeg + u * KC < kend) gload(kbeg + u * KC, u);
   const int fr = lane & 15, fk = lane >> 4;
   // f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
   const unsigned offc = (unsigned)(wr * WTR + fk) * ldab + (unsigned)(wc * WTC + fr) * 8u;  // per lane; the rest is uniform
@@ -195,25 +209,30 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
       }
     }
   const double sgn = (MODE == MODE_TRSM) ? 1.0 : -1.0;  // SYRK: acc = C - A B^T through a negated A fragment
-  for (int kc = kbeg; kc < kend; kc += KC) {
-    __syncthreads();  // previous chunk fully consumed
+  for (int kc0 = kbeg; kc0 < kend; kc0 += PF * KC) {
 #pragma unroll
-    for (int it = 0; it < NPA; ++it) { sA[rbase + RPP * it][c2] = sgn * pa[it].x; sA[rbase + RPP * it][c2 + 1] = sgn * pa[it].y; }
+    for (int u = 0; u < PF; ++u) {
+      const int kc = kc0 + u * KC;
+      if (kc >= kend) break;
+      lds_only_barrier();  // previous chunk fully consumed (LDS traffic only: __syncthreads() would also wait for the chunks in flight)
 #pragma unroll
-    for (int it = 0; it < NPB; ++it) { sB[rbase + RPP * it][c2] = pb[it].x; sB[rbase + RPP * it][c2 + 1] = pb[it].y; }
-    __syncthreads();
-    if (kc + KC < kend) gload(kc + KC);  // prefetch the next chunk while the matrix cores work
+      for (int it = 0; it < NPA; ++it) { sA[rbase + RPP * it][c2] = sgn * pa[u][it].x; sA[rbase + RPP * it][c2 + 1] = sgn * pa[u][it].y; }
 #pragma unroll
-    for (int kk = 0; kk < KC; kk += 4) {
-      double a[NMR], b[NMC];
+      for (int it = 0; it < NPB; ++it) { sB[rbase + RPP * it][c2] = pb[u][it].x; sB[rbase + RPP * it][c2 + 1] = pb[u][it].y; }
+      lds_only_barrier();
+      if (kc + PF * KC < kend) gload(kc + PF * KC, u);  // refill this stage while the matrix cores work
 #pragma unroll
-      for (int t = 0; t < NMR; ++t) a[t] = sA[wr * WTR + t * 16 + fr][kk + fk];
+      for (int kk = 0; kk < KC; kk += 4) {
+        double a[NMR], b[NMC];
 #pragma unroll
-      for (int t = 0; t < NMC; ++t) b[t] = sB[wc * WTC + t * 16 + fr][kk + fk];
+        for (int t = 0; t < NMR; ++t) a[t] = sA[wr * WTR + t * 16 + fr][kk + fk];
 #pragma unroll
-      for (int tm = 0; tm < NMR; ++tm)
+        for (int t = 0; t < NMC; ++t) b[t] = sB[wc * WTC + t * 16 + fr][kk + fk];
 #pragma unroll
-        for (int tn = 0; tn < NMC; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        for (int tm = 0; tm < NMR; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < NMC; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      }
     }
   }
   // (TRSM in place: every A element of this workgroup's rows was staged before the last barrier above)
@@ -254,9 +273,9 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) { gemm_abt_body<MODE, kTile, kTile, KC>(g); }
+__global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) { gemm_abt_body<MODE, kTile, kTile, KC, PFF>(g); }
 template <int MODE, int TSA, int TSB>
-__global__ __launch_bounds__(256, 2) void k_gemm_abt_q(GemmArgs g) { gemm_abt_body<MODE, TSA, TSB, KCQ>(g); }
+__global__ __launch_bounds__(256, 2) void k_gemm_abt_q(GemmArgs g) { gemm_abt_body<MODE, TSA, TSB, KCQ, PFQ>(g); }
 
 // The single-workgroup potrf (133 KB LDS + 174 VGPRs x 256 threads: needs an EMPTY CU) starves for the whole duration
 // of a bulk trailing update when every CU holds two bulk workgroups: 400-800 us instead of ~100 us (profiles/r01q,

@@ -519,6 +519,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   bool split_last = false;  // the last panel's bulk update was left running on B for the caller (DenseBatch::split_ta)
   bool tail_on_chain = false;  // the last panel ran whole on the chain's own stream: nothing of it to join (every event packet on
                                // the chain's stream is a few microseconds between two dependent kernels)
+  static const bool trace2 = getenv("COVGPU_TRACE_PANELS") != nullptr && atoi(getenv("COVGPU_TRACE_PANELS")) >= 2;   // dev aid: per-kernel marks, tag 100 (P + 1) + k
   for (int P = 0; P < NP; ++P) {
     const int t0 = 2 * P, w = (T - t0 >= 2) ? 2 : 1;
     const int h0 = (t0 + 2 < T) ? t0 + 2 : T, h1 = (t0 + 4 < T) ? t0 + 4 : T;  // rows h = [h0, h1), rows r = [h1, T)
@@ -530,12 +531,14 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         wait(H, eH[P - 1]);                    // B operand: L rows t0, t0+1 — their last TRSM ran on the chain's stream
         if (P >= 2) wait(H, eB[P - 2]);        // bulk(P-2) was the previous writer of these tiles
         rect(h0, h1, t0, w, t0 - 2, kd(P - 1), H, true);
+        if (trace2) ax.mark(H, 100 * (P + 1) + 6);   // rows h carry panel P-1
         (void)hipEventRecord(eHp[P], H);
       }
       if (T > h1) {
         wait(R, eH[P - 1]);                    // B operand: L rows t0, t0+1 (rows h of panel P-1)
         if (P >= 2) wait(R, eB[P - 2]);
         rect(h1, T, t0, w, t0 - 2, kd(P - 1), R, false);
+        if (trace2) ax.mark(R, 100 * (P + 1) + 7);   // rows r carry panel P-1
         (void)hipEventRecord(e2[P], R);  // rows r carry panel P-1's update
       }
     }
@@ -555,6 +558,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // triangle, three dependent launches on the chain's own stream.
       const int nbp = bt.own_max > 0 ? std::max(0, std::min(8 * w, (bt.own_max - t0 * kTile + 15) / 16)) : -1;
       potrf(t0, w, nbp);
+      if (trace2) ax.mark(M, 100 * (P + 1) + 1);   // potrf done
       if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
       bool split_done = false;
       if (T > h0) {
@@ -619,7 +623,12 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // block substitution, rows r on theirs — three dependent launches per panel instead of six
       const int nbp = bt.own_max > 0 ? std::max(0, std::min(8 * w, (bt.own_max - t0 * kTile + 15) / 16)) : -1;
       const double bulk_pairs = (T - (t0 + 4) > 0) ? 0.5 * (double)(T - (t0 + 4)) * (T - (t0 + 4) + 1) * nbt : 0.0;
-      const bool chain_bound = bulk_pairs <= 700.0;
+      // (round 4: the threshold was 700 tile pairs — every panel of the 5-agent map's fronts. With the panel factorisation at 60 us the
+      //  period of a multi-panel front was no longer the chain but the cycle  look-ahead(P) -> rest rows(P) -> bulk(P) -> look-ahead(P+1),
+      //  all of it behind the ONE event of the chain-bound form: 140-160 us per panel. Events after every kernel: 284 -> 298 it/s, and
+      //  no loss on the one-panel fronts. COVGPU_CHAIN_PAIRS restores a threshold.)
+      static const double chain_pairs = getenv("COVGPU_CHAIN_PAIRS") ? atof(getenv("COVGPU_CHAIN_PAIRS")) : 0.0;
+      const bool chain_bound = bulk_pairs <= chain_pairs;
       potrf(t0, w, nbp);
       if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
       // Every event packet on this stream sits between two dependent kernels of the chain, a few microseconds each. While the bulk
@@ -631,6 +640,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       if (h1 > h0) {
         if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
         launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
+        if (trace2) ax.mark(M, 100 * (P + 1) + 2);   // rows h solved
       }
       if (!chain_bound) (void)hipEventRecord(eH[P], M);
       // ---- M: look-ahead part of SYRK(P) on the next panel's 2x2 diagonal tiles
@@ -638,6 +648,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         const int u0 = t0 + 2, uw = (T - u0 >= 2) ? 2 : 1;
         if (P >= 1) wait(M, eB[P - 1]);          // bulk(P-1) was the previous writer of these tiles
         rect(u0, u0 + uw, u0, uw, t0, kd(P), M, true);
+        if (trace2) ax.mark(M, 100 * (P + 1) + 3);   // next diagonal block updated
       }
       // (A bulk launched at the same instant as the next diagonal update takes every workgroup slot first and the chain waits
       //  ~75 us for the first round of tiles to retire: the bulk starts after that small kernel in either regime.)
@@ -645,6 +656,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       if (T > h1) {
         wait(R, chain_bound ? eH[P] : e1[P]);
         launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab, nbp, bt.own_dims);
+        if (trace2) ax.mark(R, 100 * (P + 1) + 4);   // rest rows solved
       }
       (void)hipEventRecord(eC[P], R);
       if (!chain_bound) wait(B, eRc[P]);
@@ -681,6 +693,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         }
       }
     }
+    if (trace2) ax.mark(B, 100 * (P + 1) + 5);   // bulk update done
     (void)hipEventRecord(eB[P], B);
   }
   if (!split_last && !tail_on_chain) wait(M, eB[Plast]);

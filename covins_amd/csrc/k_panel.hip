@@ -5,19 +5,21 @@
 // panels of pure latency. In round 2a a 256-column panel was potrf(128) -> TRSM -> rank-128 update -> potrf(128) -> TRSM ->
 // next-diagonal update, six dependent launches of 20-80 us each with a 128x128 explicit inverse in the middle. Here the
 // same panel is three launches and no large inverse:
-//   k_potrf_panel   ONE workgroup (8 waves) factors the whole 256x256 diagonal block. The trailing 16x16 tiles live in
-//                   REGISTERS in the MFMA accumulator layout for the whole kernel (119 tiles over 7 waves); only the
-//                   current 16-column panel travels through LDS (double-buffered). A software pipeline, two barriers per
-//                   block column: wave 0 carries the serial chain alone (diagonal block + its inverse in one sweep ->
-//                   the tile below it -> the next diagonal tile), the other waves solve the rest of the panel against the
-//                   block inverse on the matrix core, apply the panel to every trailing tile and stream L / y out. The
-//                   right-hand side rides along as one more row. Leaves L in place, y = L^-1 b, and the INVERSES OF THE
-//                   SIXTEEN 16x16 DIAGONAL BLOCKS.
-//   k_trsm_sub      X = A L^-T for 16-row slabs below the panel, one wave per slab, no LDS, no barrier: block forward
+//   k_potrf_panel   ONE workgroup (16 waves) factors the whole 256x256 diagonal block. The trailing 16x16 tiles live in
+//                   REGISTERS in the MFMA accumulator layout for the whole kernel (119 tiles over the twelve waves of SIMDs
+//                   1-3); only the current 16-column panel travels through LDS (double-buffered). Two barriers per block
+//                   column: wave 0 carries the serial chain alone (diagonal block + its inverse in one sweep IN REGISTERS,
+//                   rows exchanged by DPP row broadcasts -> the tile below it -> the next diagonal tile), the tile waves solve
+//                   the rest of the panel against the block inverse on the matrix core and apply the panel to every trailing
+//                   tile; L / y leave by whoever has the time. The right-hand side rides along as one more row. Leaves L in
+//                   place, y = L^-1 b, and the INVERSES OF THE SIXTEEN 16x16 DIAGONAL BLOCKS. (Round 3: 8 waves, the sweep
+//                   through LDS round trips, 87 us per launch; round 4: 60 us. tools/panel_probe.hip, tools/valu_probe.hip.)
+//   k_trsm_sub4     X = A L^-T for 16-row slabs below the panel, FOUR waves per slab (one per SIMD): block forward
 //                   substitution on Z = X^T kept in accumulator layout — a finished 16x16 block Z_j IS the B operand of the
 //                   trailing updates acc_i -= L_ij Z_j (the C/D layout of v_mfma_f64_16x16x4 equals its B layout), and
 //                   Z_j = Dinv_j acc_j needs only the small block inverses. Exact substitution between blocks: better
-//                   conditioned than the product with a 128x128 explicit inverse it replaces.
+//                   conditioned than the product with a 128x128 explicit inverse it replaces. (k_trsm_sub: the same with one
+//                   wave per slab, bound by one SIMD's matrix pipe; COVGPU_TRSM4=0.)
 //   k_bwd_step_sub  backward substitution per 128-tile with the same block inverses.
 // A logical row permutation makes every MFMA operand a contiguous 32-byte load: hardware k-slot (lane>>4, step s) carries
 // logical index 4*(lane>>4)+s instead of (lane>>4)+4*s — consistently for A and B, so products are unchanged.

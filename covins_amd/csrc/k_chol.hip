@@ -659,7 +659,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         if (trace2) ax.mark(R, 100 * (P + 1) + 4);   // rest rows solved
       }
       (void)hipEventRecord(eC[P], R);
-      if (!chain_bound) wait(B, eRc[P]);
+      if (!chain_bound) wait(B, eRc[P]);   // (measured again in round 4 with the 60 us panel: without this wait 298.6 -> 292.7 it/s)
     }
     // ---- B: bulk of SYRK(P), triangle starting two tile columns further (those belong to the look-ahead)
     const int tb = t0 + 4, nt = T - tb;

@@ -287,6 +287,10 @@ struct DenseBatch {
   const int* own_dims_h = nullptr; // host copy of own_dims (flop accounting of the profiled run)
   const int* own_dims = nullptr;   // device, [n]: real interior order of every matrix of the batch — substitutions and rank updates stop at a
                                    // front's OWN last real column (own_max is the batch's: levels mix fronts of 9 .. 250 unknowns)
+  // border x border 128-tiles of a front that NO child contributes to are not cleared per iteration; the first panel's trailing update
+  // then starts them from zero instead of reading them (GemmArgs::beta0). beta0_off[front of the batch] -> first entry of its lower-triangular
+  // tile map in beta0 (1: some child adds into the tile — it is cleared and read as before)
+  const int* beta0_off = nullptr; const int* beta0 = nullptr;
   int own_max = 0;                 // > 0: largest real interior order over the batch — columns beyond it are identity padding in EVERY
                                    // matrix (L = I, block inverses = I, y = 0 already in place), so the panel kernel factors only the
                                    // 16-column blocks that hold a real column and skips all-padding panels
@@ -373,6 +377,7 @@ struct NdDev {
   int *inv_off = nullptr, *inv = nullptr;  // [nodes] offset of the node's map parent front row -> own front row (-1: none)
   int *rhs_node = nullptr;                 // [nodes] element offset of the node's right-hand side in nd_rhs
   int *ext = nullptr;                      // extend-add work lists: (node, tile row, tile column) of 64x64 tiles
+  int *bb_off = nullptr, *bb = nullptr;    // per node: offset of its lower-triangular map over BORDER 128-tiles in bb (1: a child contributes to the tile; see DenseBatch::beta0)
   int *top_var = nullptr, *top_r = nullptr, *top_g = nullptr;  // per scalar unknown of the top nodes: variable | component | solution index
   int ntop = 0;
   // sharded solve: what the ranks exchange of the top fronts = their LIVE LOWER-TRIANGULAR 128x128 tiles, packed (the fronts are stored
@@ -384,7 +389,7 @@ struct NdDev {
   size_t M_sub = 0, rhs_top = 0, gh_off = 0;   // elements of the subtree fronts | of the top levels' right-hand sides | offset of [grad | hdiag] in nd_rhs
   // host staging of the tables (filled by nd_tables, uploaded by solver.hip)
   std::vector<int> h_vnode, h_voff, h_vord, h_vown, h_ndepth, h_nI, h_abase, h_fidx, h_own_dims, h_st_dims, h_own_g, h_st_g, h_gidx, h_cptr, h_cidx, h_cptr2,
-      h_cidx2, h_inv_off, h_inv, h_rhs_node, h_ext, h_top_var, h_top_r, h_top_g;
+      h_cidx2, h_inv_off, h_inv, h_rhs_node, h_ext, h_top_var, h_top_r, h_top_g, h_bb_off, h_bb;
   std::vector<long long> h_ntab;
   size_t M_elems = 0, rhs_elems = 0, linv_elems = 0;
   double plan_flops = 0;                   // flops of one factorisation of the plan's fronts (NdHostPlan::flops: dense count on the real sizes)

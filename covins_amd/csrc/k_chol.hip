@@ -90,6 +90,9 @@ struct GemmArgs {
   const long long* btab;
   // [batch] real interior order of every matrix (nullptr: KD applies to all): the K range stops at a front's own last real column
   const int* own;
+  // SYRK_TRI, first panel (kcol0 == 0) of multifrontal fronts: a border x border tile whose map entry is 0 was NOT cleared (no child
+  // adds into it, DenseBatch::beta0): the accumulator starts from zero instead of from memory
+  const int* beta0_off; const int* beta0;
 };
 __device__ __forceinline__ bool tile_live(const GemmArgs& g, int batch, int t) {
   if (g.live == nullptr) return true;
@@ -196,6 +199,11 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
   const int fr = lane & 15, fk = lane >> 4;
   // f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
   const unsigned offc = (unsigned)(wr * WTR + fk) * ldab + (unsigned)(wc * WTC + fr) * 8u;  // per lane; the rest is uniform
+  bool fresh = false;   // (wave-uniform) the tile was not cleared: start from zero
+  if (MODE == MODE_SYRK_TRI && g.beta0 != nullptr && g.kcol0 == 0) {
+    const int a = g.ra0 / kTile + ti - g.tI, b = g.cc0 / kTile + tj - g.tI;
+    fresh = b >= 0 && a >= b && g.beta0[g.beta0_off[batch] + a * (a + 1) / 2 + b] == 0;
+  }
   v4f64 acc[NMR][NMC];
 #pragma unroll
   for (int tm = 0; tm < NMR; ++tm)
@@ -204,7 +212,7 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
       const unsigned rowoff = offc + (unsigned)(tm * 16 + 4 * rg) * ldab;  // one VGPR per row; tn goes into the immediate
 #pragma unroll
       for (int tn = 0; tn < NMC; ++tn) {
-        if (MODE == MODE_TRSM) acc[tm][tn][rg] = 0.0;
+        if (MODE == MODE_TRSM || fresh) acc[tm][tn][rg] = 0.0;
         else acc[tm][tn][rg] = *reinterpret_cast<const double*>(Cg + rowoff + tn * 128);
       }
     }
@@ -573,7 +581,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         const int tb = h0, nt = T - tb;
         auto syrk = [&](hipStream_t s2, const int* list, int count, double flops) {
           GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab, bt.own_dims};
-          g.tri = list;
+          g.tri = list; g.beta0_off = bt.beta0_off; g.beta0 = bt.beta0;
           if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], s2);
           // a short list runs at the LATENCY of one workgroup's K loop (16 chunks of 64 MFMAs per wave): as 64x64 quadrants it is
           // four times as many workgroups, each four times shorter
@@ -672,6 +680,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // supertile on XCD 0: 17 TFLOP/s.
       const bool listed = bt.live_h != nullptr && P < (int)tc.list.size() && tc.list[P] != nullptr;
       if (listed) g.tri = tc.list[P];
+      g.beta0_off = bt.beta0_off; g.beta0 = bt.beta0;
       double flops = 0.0;  // of the tile pairs that do work, over the K range each front really runs
       for (int a = 0; a < nbt; ++a) {
         if (bt.live_h == nullptr) { flops += (double)nt * (nt + 1) / 2 * 2.0 * kTile * kTile * kd(P); continue; }

@@ -187,6 +187,30 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& 
       L.split_ta = std::max(L.split_ta, (d + kTile - 1) / kTile);
     }
   }
+  // border x border 128-tiles that receive something from a child (NdDev::bb): only those are cleared per iteration and read by the first
+  // panel's trailing update. A top front of a sharded solve is summed over the ranks as it stands: all its tiles count as contributed to.
+  dev.h_bb_off.assign(nl, 0); dev.h_bb.clear();
+  for (int i = 0; i < nl; ++i) {
+    const int nI = dev.h_nI[i], lb = (ld[i] - nI + kTile - 1) / kTile;
+    dev.h_bb_off[i] = (int)dev.h_bb.size();
+    dev.h_bb.resize(dev.h_bb.size() + (size_t)lb * (lb + 1) / 2, is_top(order[i]) ? 1 : 0);
+    if (is_top(order[i]) || lb == 0) continue;
+    int* bb = dev.h_bb.data() + dev.h_bb_off[i];
+    auto children = [&](const std::vector<int>& cptr, const std::vector<int>& cidx) {
+      for (int q = cptr[i]; q < cptr[i + 1]; ++q) {
+        const int* inv = dev.h_inv.data() + dev.h_inv_off[cidx[q]];
+        std::vector<int> rows;
+        for (int t = 0; t < lb; ++t) {
+          bool any = false;
+          for (int r = nI + kTile * t; r < std::min(ld[i], nI + kTile * t + kTile) && !any; ++r) any = inv[r] >= 0;
+          if (any) rows.push_back(t);
+        }
+        for (int a : rows) for (int b : rows) if (b <= a) bb[a * (a + 1) / 2 + b] = 1;
+      }
+    };
+    children(dev.h_cptr, dev.h_cidx);
+    children(dev.h_cptr2, dev.h_cidx2);
+  }
   dev.active = true;
 }
 
@@ -203,7 +227,7 @@ struct NdLevArgs {
 // tiles of the all-padding panels (k_potrf_panel factors every panel of every front of the batch).
 // (ONE launch over the tiles of all levels — a level per launch was seven dependent host enqueues at the head of every linearisation,
 //  with the chip idle behind them: blocks [blk0[l], blk0[l + 1]) belong to level l, tile (tr, tc) of its front number `fz`)
-struct NdZeroArgs { int nlev; int first[24], n[24], nI[24], T[24]; long long blk0[25]; const int *own_dims, *st_dims; };
+struct NdZeroArgs { int nlev; int first[24], n[24], nI[24], T[24]; long long blk0[25]; const int *own_dims, *st_dims, *bb_off, *bb; };
 __global__ __launch_bounds__(256) void k_nd_zero(DevProblem P, NdZeroArgs z) {
   int l = 0;
   while (l + 1 < z.nlev && (long long)blockIdx.x >= z.blk0[l + 1]) ++l;
@@ -216,6 +240,8 @@ __global__ __launch_bounds__(256) void k_nd_zero(DevProblem P, NdZeroArgs z) {
   auto live = [&](int t) { return t < lo2 || (t >= nIt && t - nIt < lb); };
   const bool pad_diag = tr >= lo2 && tr < nIt && tc >= (tr & ~1);
   if (!((live(tr) && live(tc)) || pad_diag)) return;
+  // a border x border tile no child adds into: the first panel's trailing update starts it from zero itself (GemmArgs::beta0)
+  if (z.bb != nullptr && tc >= nIt && !z.bb[z.bb_off[node] + (tr - nIt) * (tr - nIt + 1) / 2 + (tc - nIt)]) return;
   const size_t ld = (size_t)P.nd_ntab[2 * node + 1];
   double* M = P.nd_M + P.nd_ntab[2 * node] + (size_t)tr * kTile * ld + (size_t)tc * kTile;
   const int own = z.own_dims[node];
@@ -376,7 +402,8 @@ void launch_nd_init(const DevProblem& P, const NdDev& nd, hipStream_t st) {
 
 void launch_nd_zero(const DevProblem& P, const NdDev& nd, hipStream_t st) {
   NdZeroArgs z;
-  z.nlev = 0; z.blk0[0] = 0; z.own_dims = nd.own_dims; z.st_dims = nd.st_dims;
+  static const bool beta0 = getenv("COVGPU_BETA0") == nullptr || atoi(getenv("COVGPU_BETA0")) != 0;   // (A/B switch; k_front.hip's batch() reads the same)
+  z.nlev = 0; z.blk0[0] = 0; z.own_dims = nd.own_dims; z.st_dims = nd.st_dims; z.bb_off = nd.bb_off; z.bb = beta0 ? nd.bb : nullptr;
   auto flush = [&] {
     if (z.nlev > 0 && z.blk0[z.nlev] > 0) hipLaunchKernelGGL(k_nd_zero, dim3((unsigned)z.blk0[z.nlev]), dim3(256), 0, st, P, z);
     z.nlev = 0; z.blk0[0] = 0;
@@ -410,7 +437,7 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     }
   }
   ax.mark(st, -1);
-  hipMemsetAsync(P.nd_rhs, 0, nd.rhs_elems * sizeof(double), st);
+  // (the right-hand sides were cleared on the head stream of the build, beside the fronts: solver.hip enqueue_build)
   {
     const int cnt = std::max(P.vi ? 324 * P.K : 0, P.n);
     hipLaunchKernelGGL(k_nd_assemble, dim3((cnt + 255) / 256), dim3(256), 0, st, P, (const int*)nd.rhs_node);
@@ -421,6 +448,8 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     DenseBatch bt;
     bt.n = L.n; bt.sM = 0; bt.sL = (size_t)L.nI * kTile; bt.sR = (size_t)2 * L.ntot;
     bt.live = L.live; bt.tI = L.nI / kTile; bt.live_h = L.live_h.data();
+    static const bool beta0 = getenv("COVGPU_BETA0") == nullptr || atoi(getenv("COVGPU_BETA0")) != 0;
+    if (beta0 && nd.bb != nullptr) { bt.beta0_off = nd.bb_off + L.first; bt.beta0 = nd.bb; }
     bt.tab = P.nd_ntab + 2 * (size_t)L.first; bt.tri_slot = l; bt.own_max = L.own_max; bt.own_dims = nd.own_dims + L.first; bt.own_dims_h = nd.h_own_dims.data() + L.first;
     return bt;
   };

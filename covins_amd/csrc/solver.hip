@@ -876,6 +876,8 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
       RC(dev_upload(c, &nd.inv_off, nd.h_inv_off.data(), nd.h_inv_off.size())); RC(dev_upload(c, &nd.inv, nd.h_inv.data(), nd.h_inv.size()));
       RC(dev_upload(c, &nd.rhs_node, nd.h_rhs_node.data(), nd.h_rhs_node.size()));
       RC(dev_upload(c, &nd.ext, nd.h_ext.data(), nd.h_ext.size()));
+      RC(dev_upload(c, &nd.bb_off, nd.h_bb_off.data(), nd.h_bb_off.size()));
+      RC(dev_upload(c, &nd.bb, nd.h_bb.data(), std::max<size_t>(nd.h_bb.size(), 1)));
       RC(dev_upload(c, &nd.top_var, nd.h_top_var.data(), nd.h_top_var.size())); RC(dev_upload(c, &nd.top_r, nd.h_top_r.data(), nd.h_top_r.size()));
       RC(dev_upload(c, &nd.top_g, nd.h_top_g.data(), nd.h_top_g.size()));
       for (NdLevel& L : nd.lev) RC(dev_upload(c, &L.live, L.live_h.data(), L.live_h.size()));
@@ -996,7 +998,7 @@ static void enqueue_build(covgpu_context* c, double mu) {
   (void)hipEventRecord(c->chol.ev_zero, c->st);
   launch_lm_lin(P, mu, c->st);   // writes per-observation records, per-landmark blocks and cost partials only
   // (the head stream waits for nobody: every reader of the previous system has finished — each iteration ends with a host sync)
-  if (P.nd) launch_nd_zero(P, c->nd, c->chol.head);
+  if (P.nd) { launch_nd_zero(P, c->nd, c->chol.head); (void)hipMemsetAsync(P.nd_rhs, 0, c->nd.rhs_elems * sizeof(double), c->chol.head); }   // (the fronts' right-hand sides: was a fill on the chain, in front of the assembly)
   else (void)hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), c->chol.head);
   (void)hipEventRecord(c->chol.ev_fill, c->chol.head);
   // inertial factors (one wave per factor: latency, not throughput) on the side stream beside the landmark pass; their speed-bias
@@ -1007,14 +1009,19 @@ static void enqueue_build(covgpu_context* c, double mu) {
     launch_imu_gather(P, 1, side);
     launch_finalize_diag(P, mu, 1, side);
   }
+  // Between the pair pass and the first factorisation every launch is a link of the chain (~6 us each): the loop edges are linearised
+  // on the side stream beside the landmark pass (they depend on the estimate only), and the cost partials are summed there too — behind
+  // the last kernel that writes one (the landmark pass's own finisher runs on the side stream when the pass forks).
+  launch_edge_build(P, side);
   launch_lm_build(P, mu, c->st, c->chol.ev_fill, side, c->chol.ev_lin, c->chol.ev_kf);
+  const bool forked = P.L > 0 && P.npairs > 0;   // (launch_lm_build's condition: its finisher of the visual cost ran on `side`)
+  if (forked) launch_part_finish(P, SC_COST, 1, side);
   (void)hipEventRecord(c->chol.ev_kf, side);
   (void)hipStreamWaitEvent(c->st, c->chol.ev_kf, 0);
   launch_imu_gather(P, 0, c->st);  // pose-dimension part: adds onto the blocks k_kf_reduce assigned (fixed order: visual, inertial, loop)
-  launch_edge_build(P, c->st);
   launch_edge_gather(P, c->st);
   launch_finalize_diag(P, mu, P.vi ? 0 : 2, c->st);
-  launch_part_finish(P, SC_COST, 1, c->st);
+  if (!forked) launch_part_finish(P, SC_COST, 1, c->st);
   if (c->profiling) (void)hipEventRecord(c->ev[1], c->st);
 }
 

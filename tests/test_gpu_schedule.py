@@ -31,6 +31,11 @@ def test_look_ahead_across_levels_changes_no_bit(tmp_path, name):
         assert np.array_equal(a[k], b[k]), f"two default solves differ in {k}: the solve is not deterministic"
         assert np.array_equal(a[k], c[k]), f"look-ahead on / off differ in {k}: a dependency between streams is missing"
     assert np.array_equal(a["acc"], c["acc"])
+    # round 4: the event scheme of a multi-panel front (an event behind every kernel | round 3's single event per panel) and the border
+    # tiles the first trailing update starts from zero instead of having them cleared — both leave the arithmetic alone
+    d = _solve(tmp_path, "single_event_cleared", name, COVGPU_CHAIN_PAIRS="700", COVGPU_BETA0="0")
+    for k in ("pose", "sb", "lm", "cost"):
+        assert np.array_equal(a[k], d[k]), f"event scheme / un-cleared border tiles differ in {k}"
 
 
 def test_kernel_form_switches_stay_at_rounding_level(tmp_path):

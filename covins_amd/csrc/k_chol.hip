@@ -52,14 +52,14 @@ __device__ long long g_probe[8];
 #endif
 
 constexpr int KC = 16;        // K chunk staged through LDS (full-tile kernels)
-constexpr int KCQ = 64;       // quarter forms: they run at memory LATENCY (one dependent global->LDS step per chunk while the
+constexpr int KCQ = 32;       // quarter forms: they run at memory LATENCY (one dependent global->LDS step per chunk while the
                               // chip is loaded: ~3 us each), so fewer, larger chunks
 constexpr int LDT = KC + 1;   // LDS pitch (doubles): odd pitch -> conflict-free fragment reads
 #ifndef COVGPU_PFF
 #define COVGPU_PFF 1
 #endif
 #ifndef COVGPU_PFQ
-#define COVGPU_PFQ 2
+#define COVGPU_PFQ 4
 #endif
 constexpr int PFF = COVGPU_PFF, PFQ = COVGPU_PFQ;   // chunks in flight in registers: full tiles, quarter forms
 

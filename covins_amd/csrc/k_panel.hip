@@ -304,20 +304,25 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M,
       PSTEP(1, j, tp0);
       const long long tq1 = PPROBE_T0();
       if (j + 1 < nb) {
-        // X(j+1,j) = T(j+1,j) Dinv_j^T (in place in `cur`; the B operand — Dinv_j[r][4g..4g+3] — is what this lane holds), then the next
-        // diagonal tile T(j+1,j+1) (in sDg, panels < j applied) -= X X^T, into `oth` where (a) of the next step reads it
+        // X(j+1,j) = T(j+1,j) Dinv_j^T, formed TRANSPOSED — X^T = Dinv_j T^T, the operands of the same four instructions swapped (Dinv_j[r][4g..4g+3]
+        // is what this lane holds) —: lane (r, g) then holds X[r][g], X[r][g+4], X[r][g+8], X[r][g+12], which IS an operand of the next diagonal
+        // tile's update T(j+1,j+1) -= X X^T under the k-slot assignment (g, s) <-> column g + 4 s (any assignment does, taken for both
+        // operands): no LDS round trip between the two products. The tile waves get X in row layout through `cur`, the next sweep the
+        // updated tile through `oth`.
         double* tp = cur + (o + PB + r) * PP + 4 * g;
         const double2 ta = *reinterpret_cast<const double2*>(tp), tc = *reinterpret_cast<const double2*>(tp + 2);
-        v4f64 x = v4f64{0.0, 0.0, 0.0, 0.0};
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(ta.x, xv[0], x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(ta.y, xv[1], x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(tc.x, xv[2], x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(tc.y, xv[3], x, 0, 0, 0);
         v4f64 dg;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) { cur[(o + PB + g + 4 * rg) * PP + r] = x[rg]; dg[rg] = sDg[(g + 4 * rg) * PP + r]; }
-        __builtin_amdgcn_wave_barrier();
-        dg = tile_update(dg, cur, j + 1, j + 1, r, g);
+        for (int rg = 0; rg < 4; ++rg) dg[rg] = sDg[(g + 4 * rg) * PP + r];
+        v4f64 xt = v4f64{0.0, 0.0, 0.0, 0.0};
+        xt = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[0], ta.x, xt, 0, 0, 0);
+        xt = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[1], ta.y, xt, 0, 0, 0);
+        xt = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[2], tc.x, xt, 0, 0, 0);
+        xt = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[3], tc.y, xt, 0, 0, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-xt[s2], xt[s2], dg, 0, 0, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) cur[(o + PB + r) * PP + g + 4 * s2] = xt[s2];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) oth[(o + PB + g + 4 * rg) * PP + r] = dg[rg];
       }
@@ -390,8 +395,9 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M,
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) acc[s][rg] = base[ii == kk ? offm[rg] : offn[rg]];
   }
-  // (480 eight-byte loads per workgroup are ~3 us of the CU's address path, the prologue is as long as they take to issue. Measured and
-  //  dropped: half of them behind barrier X(0) — the conditional load inside the step loop costs 38 spilled registers.)
+  // (The first step is as long as the tile loads take to issue, ~5 us: 244 KB into ONE CU at ~50 GB/s. Measured and dropped: half of them
+  //  behind barrier X(0) — the conditional load inside the step loop costs 38 spilled registers —; 16-byte loads by lane pairs with a DPP
+  //  swap behind X(0): half the instructions, the same time.)
   for (int j = 0; j < nb; ++j) {
     double* cur = sP + (j & 1) * PROWS * PP;
     double* oth = sP + ((j + 1) & 1) * PROWS * PP;

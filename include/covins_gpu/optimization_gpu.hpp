@@ -407,8 +407,18 @@ class OptimizationT {
     covgpu_context* ctx = nullptr; int device = -1;
     ~ContextHolder() { if (ctx) covgpu_destroy(ctx); }
   };
-  static covgpu_context* Context() {
+  static ContextHolder& Holder() {
     static thread_local ContextHolder h;
+    return h;
+  }
+  // Explicit release of the calling thread's cached context (streams, pinned buffers, the last problem's device buffers): for callers
+  // that do not want to rely on the thread_local destructor at thread / process teardown, or want the HBM back between calls.
+  static void Shutdown() {
+    ContextHolder& h = Holder();
+    if (h.ctx != nullptr) { covgpu_destroy(h.ctx); h.ctx = nullptr; h.device = -1; }
+  }
+  static covgpu_context* Context() {
+    ContextHolder& h = Holder();
     const int dev = params().device;
     if (h.ctx != nullptr && h.device != dev) { covgpu_destroy(h.ctx); h.ctx = nullptr; }
     if (h.ctx == nullptr) {
@@ -455,7 +465,7 @@ class OptimizationT {
       if (tim) std::fprintf(stderr, "[covins_gpu] GBA call %-34s %7.2f ms\n", what, ms);
       t_last = t;
     };
-    covgpu_context* ctx = Context();
+    covgpu_context* ctx = params().n_gpus > 1 ? nullptr : Context();   // (the sharded solve creates its own contexts, one per device)
     lap("context");
     if (outlier_removal && params().device_second_round && params().n_gpus <= 1) {
       // Both rounds behind one call. The first round's problem is walked once (:80-254); the outlier round, the erase decisions

@@ -51,6 +51,17 @@ def test_cpp_gba_matches_python_facade():
         st = sm.state()
     finally:
         sm.close()
+    # the explicit release of the thread's cached context (Optimization::Shutdown): the next call builds a new one and gives the same result
+    from tests.facade_util import lib
+    lib().shim_shutdown()
+    sm2 = StandinMap(m)
+    try:
+        sm2.gba(10, visual_only=False, outlier_removal=True)
+        st2 = sm2.state()
+    finally:
+        sm2.close()
+    lib().shim_shutdown()
+    assert np.abs(st["pose"] - st2["pose"]).max() < 1e-9 and np.array_equal(st["lm_nobs"], st2["lm_nobs"])
     mp = m.copy()
     info = Optimization.GlobalBundleAdjustment(mp, 10, -1.0, False, True, False)
     assert info["outliers_removed"] > 0

@@ -123,8 +123,37 @@ def run_a12_leg(args, rank, local_rank, world, strategy, store):
         distrib.barrier(ctx, sharded)
         dt, iters_all = distrib.aggregate(time.perf_counter() - t0, iters, ctx, sharded)
         lay = ctx.layout(); st = ctx.shard_stats()
-        return {"workload": f"a12: 12-agent synthetic map, K={full.K} L={full.L} O={full.O}", "value": iters_all / dt, "unit": "iterations/s", "n_gpus": world,
+        # one more, un-timed step with HIP events on: phase times and the per-launch figures of this leg's own roofline objects
+        ctx.set_profiling(True)
+        ctx.solve_resident(opt)
+        prof = ctx.profile()
+        ctx.set_profiling(False)
+        n_lin = max(prof["n_factor"], 1)
+        nnzS = prof["offdiag_blocks"] + full.K
+        b_build = 32.0 * full.O + 128.0 * full.K + 24.0 * full.L + 2304.0 * full.I + 8.0 * (135.0 * full.K + 9.0 * full.L) + 288.0 * nnzS
+        b_iter = (2.0 * (32.0 * full.O + 128.0 * full.K + 24.0 * full.L) + 2304.0 * full.I + 8.0 * (135.0 * full.K + 9.0 * full.L)
+                  + 2.0 * 288.0 * nnzS + (128.0 * full.K + 24.0 * full.L))
+        t_iter_ms = dt / max(iters_all, 1) * 1e3
+        t_ideal_ms = (b_iter / (HBM_PEAK_GBS * 1e9) + prof["plan_flops"] / (FP64_MATRIX_PEAK_TFLOPS * 1e12)) * 1e3
+        syrk_tf = prof["syrk_flops"] / (prof["syrk_ms"] * 1e-3) / 1e12 if prof["syrk_ms"] > 0 else 0.0
+        potrf_tf = prof["potrf_flops"] / (prof["potrf_ms"] * 1e-3) / 1e12 if prof["potrf_ms"] > 0 else 0.0
+        build_ms = prof["build_ms"] / max(prof["n_build"], 1)
+        return {"workload": f"a12: 12-agent synthetic map (BASELINE configs[4] at its stated size), K={full.K} L={full.L} O={full.O} I={full.I} E={full.E}",
+                "value": iters_all / dt, "unit": "iterations/s", "n_gpus": world,
                 "steps": steps, "warmup": 1, "ms_per_step": dt / steps * 1e3, "scaling": "strong", "final_cost": res.final_cost, "initial_cost": res.initial_cost,
+                "kf_per_s": int(full.K - full.kf_fixed.sum()) * iters_all / dt,
+                "phase_ms_per_iteration": {"linearise+schur": build_ms, "factor+solve": prof["factor_ms"] / n_lin},
+                "roofline_iteration": {"algorithmic_bytes": b_iter, "factorisation_flops": prof["plan_flops"], "ideal_ms": t_ideal_ms, "measured_ms": t_iter_ms,
+                                       "frac": t_ideal_ms / t_iter_ms if t_iter_ms > 0 else 0.0,
+                                       "phase_flop_rate_tflops": prof["plan_flops"] / (prof["factor_ms"] / n_lin * 1e-3) / 1e12 if prof["factor_ms"] > 0 else 0.0},
+                "roofline_syrk": {"kernel": "k_gemm_abt<SYRK_TRI> (rank-256 trailing update, full 128x128 tiles)", "bound": "mfma", "achieved": syrk_tf,
+                                  "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": syrk_tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                                  "launches": prof["n_syrk"], "avg_launch_ms": prof["syrk_ms"] / max(prof["n_syrk"], 1)},
+                "roofline_potrf": {"kernel": "k_potrf_panel", "bound": "mfma", "achieved": potrf_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": potrf_tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": None, "launches_per_linear_solve": prof["n_potrf"] / n_lin,
+                                   "avg_launch_ms": prof["potrf_ms"] / max(prof["n_potrf"], 1), "chain_ms_per_iteration": prof["potrf_ms"] / n_lin},
+                "roofline_build": {"bound": "hbm", "achieved": b_build / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": (b_build / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if build_ms > 0 else 0.0, "traffic": None, "algorithmic_bytes": b_build},
                 "layout": lay, "allreduce_mib_per_linear_solve": lay["allreduce_kib"] / 1024.0, "collectives_rank0": st["collectives"],
                 "map_generation_s": t_gen, "upload_s": t_up}
     finally:
@@ -144,12 +173,19 @@ def main():
     ap.add_argument("--force-shard", action="store_true", help="run the agent-sharded path (plan, sub-problem, RCCL collectives) even on ONE GPU")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-call timing after the timed region (profiling runs)")
     ap.add_argument("--a12-leg", type=int, default=-1, help="after the metric's workload, also time BASELINE configs[4] at its stated size (12 x 1667 keyframes, 2M landmarks) "
-                    "on the same ranks and report it as `a12_leg` (1 / 0; default: on for --gpus > 1 — the scaling curve of the configuration the north star "
-                    "names for 8 GPUs —, off for the one-GPU default run, whose a12 figure is `python bench.py --workload a12`)")
+                    "on the same ranks and report it as `a12_leg` with rooflines of its own (1 / 0; default: on for the metric's workload at any --gpus — the "
+                    "configuration the north star names for the scaling curve; ~70 s of map generation + upload, 3 + 1 steps)")
     ap.add_argument("--sustain-s", type=float, default=8.0, help="after the timed region, repeat the same steps back to back for about this many seconds, "
                     "un-timed in `value` and reported as `sustained`: long enough for an external GPU-utilisation sampler to see the device busy (0: off)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the ranks ourselves, exactly as the driver does (one process per GPU over RCCL)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         os.environ.setdefault("COVGPU_COLL_TIMEOUT_S", "120")   # a collective that never completes ends the run with an error after two minutes, not a hang
     import torch
@@ -257,7 +293,11 @@ def main():
             "metric": "GBA iterations/sec, 5-agent EuRoC merged map" if args.workload == "mh12345" else f"GBA iterations/sec, {args.workload}",
             "value": iters_all / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": ("synthetic map on the EuRoC ground-truth trajectories MH01-05 (orb_slam3/evaluation/Ground_truth/EuRoC_left_cam), EuRoC calibration; "
+                     "IMU of agents 3-5: the RECORDED 200 Hz samples (EuRoC_IMU/MH03-05.txt), agents 1-2: synthesised from the trajectory (no recording in the "
+                     "tree); landmarks, pixel measurements (1 px noise), drift of the initial estimate and loop constraints synthetic") if args.workload == "mh12345"
+                    else "synthetic (covins_amd/synth.py; recorded EuRoC IMU where an agent runs MH03-05 at its own keyframe times)",
             "timed_region": "profiling events off; phase / kernel figures below come from one extra un-timed step",
             "config": {"workload": f"{args.workload}: {len(cfg.agents)}-agent EuRoC MH-shaped merged map, visual-inertial GBA "
                                    f"(K={prob.K} keyframes, L={prob.L} landmarks, O={prob.O} observations, I={prob.I} IMU factors, "
@@ -397,7 +437,7 @@ def main():
             out["e2e_call_cpp"] = {"t_call_s": None, "error": repr(e)[:200]}
     # ---- configs[4] leg (all ranks, behind everything else and with the metric's context closed: eight live streams share the runtime's
     #      four hardware queues and the chain and bulk streams of the second context then serialise — measured: 32.8 instead of 43.7 it/s)
-    want_leg = args.a12_leg == 1 or (args.a12_leg < 0 and world > 1 and args.workload == "mh12345")
+    want_leg = args.a12_leg == 1 or (args.a12_leg < 0 and args.workload == "mh12345" and not args.force_shard)
     if want_leg:
         try:
             a12_leg = run_a12_leg(args, rank, local_rank, world, strategy, keep[0] if (world > 1 and keep) else None)

@@ -3,6 +3,7 @@
 #include "nd_plan.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <queue>
 #include <tuple>
 
@@ -20,6 +21,7 @@ struct Builder {
   std::vector<int> side;
   std::vector<char> inS;
   int regid = 0;
+  int top_mode = 0;   // several agents in a region: 0 ONE cover of all cross-agent couplings | 1 two groups of agents, recursively
 
   Builder(int K_, bool vi_, int leaf, const std::vector<std::vector<int>>& adj_, const std::vector<int>& chain_of_, NdHostPlan& o)
       : K(K_), vi(vi_), leaf_dims(leaf), adj(adj_), chain_of(chain_of_), out(o), reg(2 * (size_t)K_, -1), deg(2 * (size_t)K_, 0),
@@ -83,7 +85,33 @@ struct Builder {
     std::sort(chains.begin(), chains.end());
     chains.erase(std::unique(chains.begin(), chains.end()), chains.end());
     int nparts = 2;
-    if (chains.size() >= 2) {
+    if (chains.size() >= 3 && top_mode == 1) {
+      // Two GROUPS of agents (round 5): the cover of the couplings that cross between the groups; each group is cut again below it.
+      // One cover of ALL cross-agent couplings (top_mode 0) puts every loop-closure zone of the map into ONE front — on the 5-agent
+      // map with the ground-truth orientations read correctly 621 keyframes = 15 serial panels and 60 % of the flops.
+      const int nc = (int)chains.size();
+      std::vector<int> cidx(out.K, 0);
+      std::vector<long long> W((size_t)nc * nc, 0), size(nc, 0);
+      ++regid;
+      for (int v : vars) { reg[v] = regid; side[v] = (int)(std::lower_bound(chains.begin(), chains.end(), chain_of[v >> 1]) - chains.begin()); size[side[v]] += 1; }
+      for (int v : vars) for (int w : adj[v]) if (reg[w] == regid && side[w] != side[v]) W[(size_t)side[v] * nc + side[w]] += 1;
+      long long total = 0;
+      for (int c = 0; c < nc; ++c) total += size[c];
+      // all bipartitions with agent 0 on side 0 (nc <= 20): lightest crossing weight among those with at least a third of the unknowns on
+      // the lighter side (a quarter, a tenth, ... if none qualifies)
+      unsigned best = 0; long long best_w = -1;
+      for (int frac = 3; frac <= 48 && best_w < 0; frac *= 2)
+        for (unsigned m = 1; m < (1u << (nc - 1)); ++m) {
+          const unsigned g = m << 1;   // bit c set: agent c on side 1
+          long long s1 = 0, w = 0;
+          for (int c = 0; c < nc; ++c) if (g >> c & 1) s1 += size[c];
+          if (std::min(s1, total - s1) * frac < total) continue;
+          for (int a = 0; a < nc; ++a) for (int b = 0; b < nc; ++b) if ((g >> a & 1) != (g >> b & 1)) w += W[(size_t)a * nc + b];
+          if (best_w < 0 || w < best_w) { best_w = w; best = g; }
+        }
+      if (best_w < 0) best = 2;
+      for (int v : vars) side[v] = (int)(best >> side[v] & 1);
+    } else if (chains.size() >= 2) {
       nparts = (int)chains.size();
       for (int v : vars) side[v] = (int)(std::lower_bound(chains.begin(), chains.end(), chain_of[v >> 1]) - chains.begin());
     } else {
@@ -161,6 +189,7 @@ bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs
   std::vector<int> all;
   for (int q = 0; q < K; ++q) { all.push_back(2 * q); if (vi) all.push_back(2 * q + 1); }
   Builder bld(K, vi, leaf_dims, adj, chain_of, out);
+  if (const char* e = getenv("COVGPU_ND_TOP")) bld.top_mode = atoi(e);
   bld.build(all, -1);
   const int nn = out.nnodes;
   auto is_proper_ancestor = [&](int a, int n) {  // a above n?

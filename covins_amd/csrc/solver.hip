@@ -1445,19 +1445,21 @@ extern "C" int covgpu_gba_solve_multi(const covgpu_options* opt, covgpu_problem*
       if (c) c->peer_fail = &fail;
       bar.wait();
       const auto t_up0 = std::chrono::steady_clock::now();
-      if (!fail.load()) give_up(upload_impl(c, &o, &sub[r].view, false));  // stage 3: validation + H2D of the rank's share (OOM, malformed share)
+      if (!fail.load()) give_up(guarded([&] { return upload_impl(c, &o, &sub[r].view, false); }));  // (guarded: a host exception in a rank's thread would otherwise terminate the process with the peers parked at the barrier) stage 3: validation + H2D of the rank's share (OOM, malformed share)
       const double t_up = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_up0).count();
       bar.wait();
-      if (!fail.load()) give_up(solve_any(c, &o, &res[r]));               // stage 4: the solve (peers of a rank that fails in here: wait_iteration)
+      if (!fail.load()) give_up(guarded([&] { return solve_any(c, &o, &res[r]); }));               // stage 4: the solve (peers of a rank that fails in here: wait_iteration)
       if (!fail.load() && rc == COVGPU_OK) {
         const auto t_dn0 = std::chrono::steady_clock::now();
-        give_up(download_impl(c, &sub[r].view));
+        give_up(guarded([&] { return download_impl(c, &sub[r].view); }));
         res[r].t_download_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dn0).count();
         res[r].t_upload_s = t_up;
       }
       if (!fail.load() && rc == COVGPU_OK && obs_erase) {
-        er[r].assign(sub[r].obs_kf.size() + 1, 0); ll[r].assign(sub[r].lm_id.size() + 1, 0);
-        give_up(covgpu_outlier_pass(c, outlier_threshold, er[r].data(), ll[r].data(), &cnt[2 * (size_t)r]));
+        give_up(guarded([&] {
+          er[r].assign(sub[r].obs_kf.size() + 1, 0); ll[r].assign(sub[r].lm_id.size() + 1, 0);
+          return covgpu_outlier_pass(c, outlier_threshold, er[r].data(), ll[r].data(), &cnt[2 * (size_t)r]);
+        }));
       }
       rcs[r] = rc;
       if (c) covgpu_destroy(c);

@@ -3,8 +3,10 @@
 No EuRoC images or saved COVINS maps exist offline, so the BASELINE.json configurations are synthesised:
 true trajectories are the EuRoC Machine-Hall ground-truth paths shipped in the reference (fixture
 covins_amd/data/euroc_mh_4hz.npz, derived by tools/make_euroc_fixture.py), calibration is the EuRoC
-camera/IMU (orb_slam3/Examples/Monocular-Inertial/EuRoC.yaml:9-17,30-37,40-44), IMU samples are
-differentiated from a C2 spline through the keyframe poses (+ white noise and bias random walk), landmarks
+camera/IMU (orb_slam3/Examples/Monocular-Inertial/EuRoC.yaml:9-17,30-37,40-44), the IMU samples of agents
+on MH03-05 are the RECORDED 200 Hz samples of orb_slam3/Examples/Monocular-Inertial/EuRoC_IMU/MH0{3,4,5}.txt aligned by
+their absolute time stamps, those of MH01/02 (no recording in the tree) and of every resampled or re-posed
+path are differentiated from a C2 spline through the keyframe poses (+ white noise and bias random walk), landmarks
 are spawned on the hall surfaces and tracked over a window of neighbouring keyframes (SLAM-like track
 lengths); landmark fusion happens where the reference does it — around loop closures: landmarks of the
 keyframes near one loop keyframe are re-observed by the keyframes near the other (PlaceRecognition::ConnectLoop
@@ -71,6 +73,7 @@ class SynthConfig:
     loop_noise_deg: float = 0.2
     outlier_frac: float = 0.0             # gross outliers among observations (for the outlier round)
     imu_noise: bool = True
+    recorded_imu: bool = True             # MH03-05 at their own keyframe times: the recorded 200 Hz samples (needs imu_noise: a noise-free map is all-synthetic)
     seed: int = 0
 
 
@@ -112,12 +115,36 @@ def _agent_trajectory(seq: int, agent: int, cfg: SynthConfig):
     s0 = cfg.kf_start
     s1 = len(t) if cfg.max_kf_per_agent is None else min(len(t), s0 + cfg.max_kf_per_agent)
     t, p_wc, q_wc = t[s0:s1] - t[s0], p_wc[s0:s1], q_wc[s0:s1]
-    # body pose T_w_s = T_w_c * T_s_c^-1
-    R_wc = R.from_quat(q_wc)
-    R_sc = R.from_matrix(TBC[:3, :3])
-    R_ws = R_wc * R_sc.inv()
-    p_ws = p_wc - R_ws.apply(TBC[:3, 3])
-    return t, p_ws, R_ws
+    p_ws, R_ws = _body_from_camera(p_wc, q_wc)
+    rec = None
+    if cfg.recorded_imu and cfg.imu_noise and seq <= 5 and not cfg.kf_per_agent and f"imu_{base}" in d:
+        rec = _recorded_imu(d, base, s0, s1)
+    return t, p_ws, R_ws, rec
+
+
+def _body_from_camera(p_wc, q_wc):
+    """body pose T_w_s = T_w_c * T_s_c^-1 (q_wc: camera -> world, tools/make_euroc_fixture.py)"""
+    R_ws = R.from_quat(q_wc) * R.from_matrix(TBC[:3, :3]).inv()
+    return p_wc - R_ws.apply(TBC[:3, 3]), R_ws
+
+
+def _recorded_imu(d, base: int, s0: int, s1: int):
+    """The recorded samples between keyframes s0 .. s1-1 of sequence `base`, and what stands in for the unknown truth of the
+    states only an IMU observes: velocity = derivative of a spline through the 20 Hz ground truth; biases = the sequence's mean of
+    (recorded - predicted from that spline), one constant per sequence (EuRoC's own estimate for the machine hall is
+    b_g ~ (-0.002, 0.021, 0.077) rad/s, b_a ~ (-0.02, 0.13, 0.06) m/s^2; this reproduces it)."""
+    n_sub = int(round(IMU_RATE * 0.25))
+    imu = d[f"imu_{base}"]
+    t20 = d[f"t20_{base}"]
+    p20, R20 = _body_from_camera(d[f"p20_{base}"], d[f"q20_{base}"])
+    cs, rs = CubicSpline(t20, p20), RotationSpline(t20, R20)
+    ti = np.arange(len(imu)) / IMU_RATE
+    inner = (ti >= 1.0) & (ti <= ti[-1] - 1.0)
+    bg = (imu[inner, 0:3] - rs(ti[inner], 1)).mean(0)
+    ba = (imu[inner, 3:6] - rs(ti[inner]).inv().apply(cs(ti[inner], 2) + np.array([0.0, 0.0, GRAVITY]))).mean(0)
+    tk = np.arange(s0, s1) * 0.25
+    rows = (np.arange(s0, s1 - 1)[:, None] * n_sub + np.arange(0, n_sub + 1)[None, :])  # [n-1, n_sub+1]; column 0 = at keyframe i
+    return dict(gyr=imu[rows, 0:3], acc=imu[rows, 3:6], vel=cs(tk, 1), ba=ba, bg=bg)
 
 
 def make_map(cfg: SynthConfig) -> SlamMap:
@@ -129,8 +156,12 @@ def make_map(cfg: SynthConfig) -> SlamMap:
 
     per_agent = []
     for a, seq in enumerate(cfg.agents):
-        t, p_ws, R_ws = _agent_trajectory(seq, a, cfg)
+        t, p_ws, R_ws, rec = _agent_trajectory(seq, a, cfg)
         n = len(t)
+        if rec is not None and n >= 2:
+            per_agent.append(dict(t=t, p=p_ws, R=R_ws, v=rec["vel"], n=n, n_sub=rec["acc"].shape[1] - 1, acc=rec["acc"], gyr=rec["gyr"],
+                                  ba=np.tile(rec["ba"], (n, 1)), bg=np.tile(rec["bg"], (n, 1)), recorded=True))
+            continue
         cs = CubicSpline(t, p_ws, bc_type="natural")
         rs = RotationSpline(t, R_ws)
         vel = cs(t, 1)

@@ -203,7 +203,7 @@ def _replay_sparse(S, b, parent, level, own, st, D):
 
 def test_replay_at_three_agent_size():
     """The plan the GPU solves with on the 3-agent BASELINE map — speed-bias chains cut into segments, excess unknowns of a level's
-    widest fronts moved into the parents (the panel balance pass moves 36 unknowns here), 201 fronts in 7 levels — replayed on the
+    widest fronts moved into the parents, ~200 fronts in 7 levels (round 5, ground-truth orientations read correctly: root of 1 050 unknowns, 13 serial panels) — replayed on the
     oracle's sparse reduced camera system: the residual of the multifrontal solution is at rounding level."""
     import scipy.sparse as sp
     m = synth.make_map(synth.config_named("mh123"))
@@ -215,7 +215,7 @@ def test_replay_at_three_agent_size():
     assert info[0] > 150 and info[1] >= 6
     assert max(od[level == 0]) <= 126                       # bottom level: speed-bias segments of <= 14 blocks
     widest = [od[level == l].max() for l in range(info[1])]
-    assert sum(-(-w // 256) for w in widest) <= 11          # serial 256-column panels of the whole factorisation
+    assert sum(-(-w // 256) for w in widest) <= 13          # serial 256-column panels of the whole factorisation
     x = _replay_sparse(S, np.asarray(bvec), parent, level, own, st, 15)
     r = S @ x - bvec
     assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(bvec)

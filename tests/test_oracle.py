@@ -248,8 +248,13 @@ def test_dense_vs_schur_step(tiny_map):
         for mu in (1e-8, 1e-3):
             dp_d, dl_d = covo.step(p, o, mu, dense=True)
             dp_s, dl_s = covo.step(p, o, mu, dense=False)
-            assert rel_err(dp_s, dp_d) < 1e-7
-            assert rel_err(dl_s, dl_d) < 1e-7
+            # two elimination orders of one system agree to rounding x condition: the visual-only system of this 28-keyframe map at
+            # mu = 1e-8 has cond(S) ~ 3e11 (weakly damped scale / gauge directions), the others stay below the 1e-7 floor
+            S, _, _ = covo.schur(p, o, mu)
+            live = np.nonzero(np.diag(S) != 0)[0]
+            tol = max(1e-7, 1e-16 * np.linalg.cond(S[np.ix_(live, live)]))
+            assert rel_err(dp_s, dp_d) < tol
+            assert rel_err(dl_s, dl_d) < tol
     # the gauge keyframe's pose does not move, its speed-bias block does
     g = np.nonzero(p.kf_fixed)[0][0]
     assert not dp_s[15 * g:15 * g + 6].any() and dp_s[15 * g + 6:15 * g + 15].any()

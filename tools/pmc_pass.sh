@@ -10,10 +10,10 @@ mkdir -p $root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
-  rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_$ctr -o pmc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --sustain-s 0 > $root/gpurun_out/${tag}_pmc_$ctr.log 2>&1
+  rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_$ctr -o pmc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --sustain-s 0 --a12-leg 0 > $root/gpurun_out/${tag}_pmc_$ctr.log 2>&1
 done
 rm -rf /tmp/pmc_mfma
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d /tmp/pmc_mfma -o pmc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --sustain-s 0 > $root/gpurun_out/${tag}_pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d /tmp/pmc_mfma -o pmc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --sustain-s 0 --a12-leg 0 > $root/gpurun_out/${tag}_pmc_mfma.log 2>&1
 cd $root
 python tools/rocpd_pmc.py FETCH_SIZE=$(ls /tmp/pmc_FETCH_SIZE/*.db | head -1) WRITE_SIZE=$(ls /tmp/pmc_WRITE_SIZE/*.db | head -1) gpurun_out/${tag}_pmc_hbm_traffic.csv > /dev/null
 python tools/rocpd_counters.py $(ls /tmp/pmc_mfma/*.db | head -1) gpurun_out/${tag}_pmc_mfma.csv > /dev/null

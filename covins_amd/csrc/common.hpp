@@ -236,6 +236,7 @@ struct CholAux {
   // interleaved so that list position p runs on XCD p % 8 and every XCD gets the same number of tiles (k_chol.hip)
   struct TriCache {
     std::vector<int*> list; std::vector<int> count; int key = -1;
+    std::vector<int*> listC; std::vector<int> countC;   // the bulk update's tiles in the next-but-one panel's two tile columns (launched first, k_chol.hip: eA)
     int *listA = nullptr, *listB = nullptr; int countA = 0, countB = 0;   // last panel's update split at DenseBatch::split_ta
     void clear();
   };

@@ -327,6 +327,8 @@ void CholAux::init() {
 }
 void CholAux::TriCache::clear() {
   for (int* p : list) if (p) (void)hipFree(p);
+  for (int* p : listC) if (p) (void)hipFree(p);
+  listC.clear(); countC.clear();
   if (listA) (void)hipFree(listA);
   if (listB) (void)hipFree(listB);
   listA = listB = nullptr; countA = countB = 0;
@@ -408,7 +410,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   ax.init();
   const int NP = (T + 1) / 2;  // big panels of two tile columns
   // events per big panel: H rows-h done | B bulk done | C rows-r done | 1 potrf(t0) | 2 X(t0+1,t0) | 3 potrf(t0+1) | Rc next diagonal updated
-  while ((int)ax.ev.size() < 8 * (NP + 1)) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ax.ev.push_back(e); }
+  while ((int)ax.ev.size() < 9 * (NP + 1)) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ax.ev.push_back(e); }
   // (a solve may factorise several matrices — arrow blocks, then the border system: launches accumulate until collect())
   if (ax.profile) while (ax.prof_ev.size() < 2 * (ax.prof_flops.size() + (size_t)NP + 1)) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev.push_back(e); }
   hipEvent_t* eH = ax.ev.data();
@@ -419,6 +421,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   hipEvent_t* e3 = e2 + (NP + 1);
   hipEvent_t* eRc = e3 + (NP + 1);
   hipEvent_t* eHp = eRc + (NP + 1);  // rows h updated with column t0 (their last TRSM then runs on the chain's own stream)
+  hipEvent_t* eA = eHp + (NP + 1);   // bulk(P) has updated the NEXT-BUT-ONE panel's two tile columns (the first of its two launches; == eB where the bulk is one launch)
 
   // C tiles (rows [r0, r1), tile columns [tc0, tc0+ntc)) -= A[rows, K] A[tc.., K]^T, K = tiles kt0.. (KD columns); lower part only
   auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2, bool quad) {
@@ -457,7 +460,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   if (bt.tri_slot >= (int)ax.tri_lev.size()) ax.tri_lev.resize(bt.tri_slot + 1);
   CholAux::TriCache& tc = bt.tri_slot >= 0 ? ax.tri_lev[bt.tri_slot] : ax.tri0;
   // live tiles (i, j), j <= i, of the triangle that starts at tile tb, for the fronts whose interior reaches panel column t0;
-  // part 0: all | 1: rows i < split_ta | 2: rows i >= split_ta. XCD-balanced, interleaved (position p runs on XCD p % 8).
+  // part 0: all | 1: rows i < split_ta | 2: rows i >= split_ta | 3: tile columns j < 2 | 4: tile columns j >= 2. XCD-balanced, interleaved (position p runs on XCD p % 8).
   auto build_list = [&](int t0, int tb, int part, int*& d_out, int& n_out) {
     d_out = nullptr; n_out = 0;
     std::vector<int> q[8];  // per-XCD queues; whole 8x8 supertiles of one batch go to the currently shortest queue
@@ -471,7 +474,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
           std::vector<int> grp;
           for (int i = 8 * si; i < std::min(nt, 8 * si + 8); ++i)
             for (int j = 8 * sj; j < std::min(i + 1, 8 * sj + 8); ++j)
-              if (live(tb + i) && live(tb + j) && (part == 0 || (i < bt.split_ta) == (part == 1))) grp.push_back((a << 20) | (i << 10) | j);
+              if (live(tb + i) && live(tb + j) && (part == 0 || (part <= 2 && (i < bt.split_ta) == (part == 1)) || (part >= 3 && (j < 2) == (part == 3)))) grp.push_back((a << 20) | (i << 10) | j);
           if (grp.empty()) continue;
           int best = 0;
           for (int x = 1; x < 8; ++x) if (q[x].size() < q[best].size()) best = x;
@@ -488,11 +491,16 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     n_out = (int)lst.size();
     return true;
   };
-  const int key = (T * 4096 + nbt) * 8 + bt.split_ta;
+  // Two launches per bulk update (round 5): first the tiles of the next-but-one panel's two tile columns, then the rest. Everything on or beside the
+  // chain that follows a bulk update — the next diagonal look-ahead, the look-ahead of the next panel's rows — writes those two tile columns only and
+  // waits for the FIRST launch (eA). With one launch the chain of a big front waited for the whole previous bulk update every panel: on the 5-agent
+  // map's root (3 726 unknowns, 15 panels, bulk 100 us) the period was bulk -> diagonal look-ahead -> bulk = 165 us instead of the chain's 128.
+  static const bool col_split = getenv("COVGPU_BULK_SPLIT") == nullptr || atoi(getenv("COVGPU_BULK_SPLIT")) != 0;
+  const int key = ((T * 4096 + nbt) * 8 + bt.split_ta) * 2 + (col_split ? 1 : 0);
   if (bt.live_h != nullptr && tc.key != key) {  // live-tile lists of every panel's bulk update (static per problem)
     tc.clear();
     tc.key = key;
-    tc.list.assign(NP, nullptr); tc.count.assign(NP, 0);
+    tc.list.assign(NP, nullptr); tc.count.assign(NP, 0); tc.listC.assign(NP, nullptr); tc.countC.assign(NP, 0);
     for (int P = 0; P < NP && P < Pstop; ++P) {
       // (the LAST panel of a partial factorisation applies its whole trailing update in one launch: triangle from t0 + 2)
       const bool last = Pstop < NP && P == Pstop - 1;
@@ -500,6 +508,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       if (tb >= T) break;
       bool ok = true;
       if (last && bt.split_ta > 0) ok = build_list(t0, tb, 1, tc.listA, tc.countA) && build_list(t0, tb, 2, tc.listB, tc.countB);
+      else if (col_split) ok = build_list(t0, tb, 3, tc.listC[P], tc.countC[P]) && build_list(t0, tb, 4, tc.list[P], tc.count[P]);
       else ok = build_list(t0, tb, 0, tc.list[P], tc.count[P]);
       if (!ok) { tc.clear(); break; }
     }
@@ -537,14 +546,14 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       if (h1 > h0) {
         wait(H, eC[P - 1]);                    // L rows h0.. were rest rows of panel P-1
         wait(H, eH[P - 1]);                    // B operand: L rows t0, t0+1 — their last TRSM ran on the chain's stream
-        if (P >= 2) wait(H, eB[P - 2]);        // bulk(P-2) was the previous writer of these tiles
+        if (P >= 2) wait(H, eA[P - 2]);        // bulk(P-2) was the previous writer of these tiles (its first launch: these two tile columns)
         rect(h0, h1, t0, w, t0 - 2, kd(P - 1), H, true);
         if (trace2) ax.mark(H, 100 * (P + 1) + 6);   // rows h carry panel P-1
         (void)hipEventRecord(eHp[P], H);
       }
       if (T > h1) {
         wait(R, eH[P - 1]);                    // B operand: L rows t0, t0+1 (rows h of panel P-1)
-        if (P >= 2) wait(R, eB[P - 2]);
+        if (P >= 2) wait(R, eA[P - 2]);
         rect(h1, T, t0, w, t0 - 2, kd(P - 1), R, false);
         if (trace2) ax.mark(R, 100 * (P + 1) + 7);   // rows r carry panel P-1
         (void)hipEventRecord(e2[P], R);  // rows r carry panel P-1's update
@@ -554,6 +563,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       (void)hipEventRecord(eH[P], H);
       (void)hipEventRecord(eC[P], R);
       (void)hipEventRecord(eB[P], B);
+      (void)hipEventRecord(eA[P], B);
       Plast = P;
       break;
     }
@@ -654,7 +664,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // ---- M: look-ahead part of SYRK(P) on the next panel's 2x2 diagonal tiles
       if (P + 1 < NP) {
         const int u0 = t0 + 2, uw = (T - u0 >= 2) ? 2 : 1;
-        if (P >= 1) wait(M, eB[P - 1]);          // bulk(P-1) was the previous writer of these tiles
+        if (P >= 1) wait(M, eA[P - 1]);          // bulk(P-1) was the previous writer of these tiles (its first launch)
         rect(u0, u0 + uw, u0, uw, t0, kd(P), M, true);
         if (trace2) ax.mark(M, 100 * (P + 1) + 3);   // next diagonal block updated
       }
@@ -671,6 +681,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     }
     // ---- B: bulk of SYRK(P), triangle starting two tile columns further (those belong to the look-ahead)
     const int tb = t0 + 4, nt = T - tb;
+    bool recA = false;
     wait(B, eC[P]);
     if (nt > 0 && kd(P) > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
@@ -690,11 +701,20 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         for (int t = tb; t < T; ++t) nl += (t < nI || (t >= bt.tI && t - bt.tI < nO)) ? 1 : 0;
         flops += (double)nl * (nl + 1) / 2 * 2.0 * kTile * kTile * kd_front(P, a, KC);
       }
-      if (!listed || tc.count[P] > 0) {
+      const int cntC = (listed && P < (int)tc.listC.size() && tc.listC[P] != nullptr) ? tc.countC[P] : 0;
+      if (!listed || tc.count[P] > 0 || cntC > 0) {
         if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], B);
-        if (listed && tc.count[P] <= kQuarterMax)
-          hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_TRI, 64, 64>), dim3(tc.count[P], 1, 4), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), B, g);
-        else if (listed) hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(tc.count[P], 1), dim3(256), lds_gemm, B, g);
+        auto tri = [&](const int* list, int count) {
+          g.tri = list;
+          if (count <= kQuarterMax) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_TRI, 64, 64>), dim3(count, 1, 4), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), B, g);
+          else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(count, 1), dim3(256), lds_gemm, B, g);
+        };
+        if (cntC > 0) {   // the next-but-one panel's two tile columns first: what the chain waits for
+          tri(tc.listC[P], cntC);
+          (void)hipEventRecord(eA[P], B); recA = true;
+          if (trace2) ax.mark(B, 100 * (P + 1) + 8);   // first bulk launch done
+        }
+        if (listed) { if (tc.count[P] > 0) tri(tc.list[P], tc.count[P]); }
         else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(nblk, nbt), dim3(256), lds_gemm, B, g);
         if (ax.profile) {
           (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size() + 1], B);
@@ -704,6 +724,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     }
     if (trace2) ax.mark(B, 100 * (P + 1) + 5);   // bulk update done
     (void)hipEventRecord(eB[P], B);
+    if (!recA) (void)hipEventRecord(eA[P], B);
   }
   if (!split_last && !tail_on_chain) wait(M, eB[Plast]);
   if (Plast >= 1) wait(M, eB[Plast - 1]);

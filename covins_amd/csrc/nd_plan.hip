@@ -162,8 +162,8 @@ struct Builder {
 
 }  // namespace
 
-bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
-                   const int* epair_i, const int* epair_j, int leaf_dims, NdHostPlan& out) {
+static bool nd_plan_build_mode(int top_mode, int K, bool vi, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
+                               const int* epair_i, const int* epair_j, int leaf_dims, NdHostPlan& out) {
   out = NdHostPlan();
   out.K = K; out.vi = vi ? 1 : 0; out.nvar = 2 * K;
   out.vnode.assign(2 * (size_t)K, -1); out.voff.assign(2 * (size_t)K, 0); out.vord.assign(2 * (size_t)K, -1);
@@ -189,7 +189,7 @@ bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs
   std::vector<int> all;
   for (int q = 0; q < K; ++q) { all.push_back(2 * q); if (vi) all.push_back(2 * q + 1); }
   Builder bld(K, vi, leaf_dims, adj, chain_of, out);
-  if (const char* e = getenv("COVGPU_ND_TOP")) bld.top_mode = atoi(e);
+  bld.top_mode = top_mode;
   bld.build(all, -1);
   const int nn = out.nnodes;
   auto is_proper_ancestor = [&](int a, int n) {  // a above n?
@@ -283,6 +283,32 @@ bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs
     out.flops += m * m * m / 3.0 + m * m * b + m * b * b;
   }
   return true;
+}
+
+// What one factorisation of the plan costs on the device, roughly (round 5 figures of one MI355X): the levels run one after the other, a level
+// costs one serial chain of ~140 us per 256 columns of its widest front plus ~40 us of transition, and the flops run at ~30 TFLOP/s beside them.
+static double nd_plan_cost(const NdHostPlan& hp) {
+  double t = hp.flops / 30e12;
+  for (int l = 0; l < hp.nlev; ++l) t += (hp.lev_nI[l] / 256) * 140e-6 + 40e-6;
+  return t;
+}
+
+bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
+                   const int* epair_i, const int* epair_j, int leaf_dims, NdHostPlan& out) {
+  // Three or more agents: ONE cover of all cross-agent couplings at the top (mode 0) or two groups of agents, recursively (mode 1) — both
+  // plans are built (milliseconds) and the cheaper one by nd_plan_cost is kept. 5-agent map: 2.84e10 flops / 23 serial panels / 7 levels
+  // against 2.42e10 / 22 / 9; 12-agent map: a 17 652-order root and 2.13e12 flops against a 7 206-order root and 1.30e12.
+  // COVGPU_ND_TOP=0 / 1 forces a mode. Deterministic: every rank of a sharded solve and covgpu_shard_plan pick the same plan.
+  int forced = -1;
+  if (const char* e = getenv("COVGPU_ND_TOP")) forced = atoi(e) != 0 ? 1 : 0;
+  if (nchains < 3 || forced == 0 || leaf_dims >= (1 << 29))
+    return nd_plan_build_mode(0, K, vi, nchains, chain_ptr, npairs, pair_i, pair_j, nepairs, epair_i, epair_j, leaf_dims, out);
+  if (forced == 1) return nd_plan_build_mode(1, K, vi, nchains, chain_ptr, npairs, pair_i, pair_j, nepairs, epair_i, epair_j, leaf_dims, out);
+  NdHostPlan alt;
+  const bool ok0 = nd_plan_build_mode(0, K, vi, nchains, chain_ptr, npairs, pair_i, pair_j, nepairs, epair_i, epair_j, leaf_dims, out);
+  const bool ok1 = nd_plan_build_mode(1, K, vi, nchains, chain_ptr, npairs, pair_i, pair_j, nepairs, epair_i, epair_j, leaf_dims, alt);
+  if (ok1 && (!ok0 || nd_plan_cost(alt) < nd_plan_cost(out))) out = std::move(alt);
+  return ok0 || ok1;
 }
 
 void nd_shard_assign(NdHostPlan& hp, int world) {

@@ -98,7 +98,11 @@ def test_sharded_solve_equals_unsharded(name, world, strategy):
     per_it = st["collectives"] / max(r0.iterations, 1)
     print(f"{name} world {world}: pose {dp:.2e} speed-bias {ds:.2e} landmarks {dl:.2e}; {st['collectives']} collectives ({per_it:.1f} per iteration), "
           f"{st['bytes'] / 1e6:.1f} MB per solve, {lay['allreduce_kib'] / 1024:.1f} MiB per linear solve")
-    assert dp < 1e-8 and ds < 1e-8 and dl < 1e-6
+    # landmarks by the criterion of every parity test (tests/util.landmark_parity): well-conditioned ones within 1e-6 m, the near-degenerate
+    # ones within 1e-4 whitened units (a landmark almost on one ray moves micrometres along it between two summation orders)
+    from tests.util import landmark_parity
+    n_ill, d_good, d_white = landmark_parity(sol.lm_pos, s0)
+    assert dp < 1e-8 and ds < 1e-8 and d_good < 1e-6 and d_white < 1e-4 and n_ill <= p.L // 12
     assert per_it <= 3.0   # top fronts once per linear solve + two scalar exchanges (k_tail.hip); a rejected step needs one less
 
 

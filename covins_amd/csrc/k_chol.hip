@@ -508,7 +508,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       if (tb >= T) break;
       bool ok = true;
       if (last && bt.split_ta > 0) ok = build_list(t0, tb, 1, tc.listA, tc.countA) && build_list(t0, tb, 2, tc.listB, tc.countB);
-      else if (col_split) ok = build_list(t0, tb, 3, tc.listC[P], tc.countC[P]) && build_list(t0, tb, 4, tc.list[P], tc.count[P]);
+      else if (col_split && !last) ok = build_list(t0, tb, 3, tc.listC[P], tc.countC[P]) && build_list(t0, tb, 4, tc.list[P], tc.count[P]);   // (the last panel's update is ONE launch on the chain's stream)
       else ok = build_list(t0, tb, 0, tc.list[P], tc.count[P]);
       if (!ok) { tc.clear(); break; }
     }

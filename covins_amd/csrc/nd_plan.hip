@@ -294,12 +294,15 @@ static double nd_plan_cost(const NdHostPlan& hp) {
 }
 
 bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
-                   const int* epair_i, const int* epair_j, int leaf_dims, NdHostPlan& out) {
+                   const int* epair_i, const int* epair_j, int leaf_dims, NdHostPlan& out, int top_mode) {
   // Three or more agents: ONE cover of all cross-agent couplings at the top (mode 0) or two groups of agents, recursively (mode 1) — both
   // plans are built (milliseconds) and the cheaper one by nd_plan_cost is kept. 5-agent map: 2.84e10 flops / 23 serial panels / 7 levels
   // against 2.42e10 / 22 / 9; 12-agent map: a 17 652-order root and 2.13e12 flops against a 7 206-order root and 1.30e12.
   // COVGPU_ND_TOP=0 / 1 forces a mode. Deterministic: every rank of a sharded solve and covgpu_shard_plan pick the same plan.
-  int forced = -1;
+  // top_mode 0: the plan of a SHARDED solve — one separator of all agents at the top, whose children (one region per agent) are the
+  // subtrees dealt to the ranks; with two groups of agents there are two subtrees, and opening them puts fronts of (separator + root)^2
+  // into the replicated, all-reduced top.
+  int forced = top_mode;
   if (const char* e = getenv("COVGPU_ND_TOP")) forced = atoi(e) != 0 ? 1 : 0;
   if (nchains < 3 || forced == 0 || leaf_dims >= (1 << 29))
     return nd_plan_build_mode(0, K, vi, nchains, chain_ptr, npairs, pair_i, pair_j, nepairs, epair_i, epair_j, leaf_dims, out);

@@ -36,7 +36,9 @@ struct NdHostPlan {
 // positions are chain-major (solver.hip build_chains); pair / epair lists are keyframe pairs by position (i > j).
 // leaf_dims: a region of at most this many scalar unknowns is not cut further. Returns false on an inconsistent input.
 bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
-                   const int* epair_i, const int* epair_j, int leaf_dims, NdHostPlan& out);
+                   const int* epair_i, const int* epair_j, int leaf_dims, NdHostPlan& out, int top_mode = -1);
+// top_mode: how a region of three or more agents is cut — 0: ONE cover of all cross-agent couplings (its children: one region per agent;
+// the plan of a sharded solve) | 1: two groups of agents, recursively | -1: both are built and the cheaper one is kept (nd_plan.hip).
 
 // Multi-GPU split of the tree: the top of the tree is replicated, the subtrees below it are dealt to the
 // ranks by longest-processing-time-first on their factorisation flops. Top = the roots, grown downwards (heaviest subtree

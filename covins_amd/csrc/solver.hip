@@ -520,7 +520,9 @@ static int nd_leaf_dims(int requested) {
   const int v = e ? atoi(e) : 0;
   return v > 0 ? v : 600;
 }
-extern "C" int covgpu_nd_plan_create(const covgpu_options* opt, const covgpu_problem* p, int32_t leaf_dims, covgpu_nd_plan** out) {
+static int nd_plan_create_mode(const covgpu_options* opt, const covgpu_problem* p, int32_t leaf_dims, covgpu_nd_plan** out, int top_mode);
+extern "C" int covgpu_nd_plan_create(const covgpu_options* opt, const covgpu_problem* p, int32_t leaf_dims, covgpu_nd_plan** out) { return nd_plan_create_mode(opt, p, leaf_dims, out, -1); }
+static int nd_plan_create_mode(const covgpu_options* opt, const covgpu_problem* p, int32_t leaf_dims, covgpu_nd_plan** out, int top_mode) {
   return guarded([&] {
     const bool vi = !opt->visual_only;
     *out = nullptr;
@@ -533,7 +535,7 @@ extern "C" int covgpu_nd_plan_create(const covgpu_options* opt, const covgpu_pro
     const auto t_pl = std::chrono::steady_clock::now();
     struct PT { std::chrono::steady_clock::time_point t0; ~PT() { if (getenv("COVGPU_PLAN_TIMING")) std::fprintf(stderr, "[covgpu] nd_plan_build %.1f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3); } } pt{t_pl};
     if (!nd_plan_build(p->num_kf, vi, (int)chain_ptr.size() - 1, chain_ptr.data(), (int)pi.size(), pi.data(), pj.data(), (int)ei.size(), ei.data(), ej.data(),
-                       nd_leaf_dims(leaf_dims), pl->hp)) {
+                       nd_leaf_dims(leaf_dims), pl->hp, top_mode)) {
       delete pl; g_err = "nested-dissection plan: a coupling joins two branches"; return (int)COVGPU_ERR_INVALID_ARG;
     }
     *out = pl;
@@ -579,7 +581,7 @@ extern "C" int32_t covgpu_shard_plan(const covgpu_options* opt, const covgpu_pro
   *plan_out = nullptr;
   if (world < 1) return 0;
   covgpu_nd_plan* pl = nullptr;
-  if (covgpu_nd_plan_create(opt, p, 0, &pl) != COVGPU_OK) return 0;
+  if (nd_plan_create_mode(opt, p, 0, &pl, 0) != COVGPU_OK) return 0;   // (one separator of all agents at the top: its children are the subtrees)
   NdHostPlan& hp = pl->hp;
   nd_shard_assign(hp, world);
   if (hp.nsub == 0) { delete pl; return 0; }
@@ -1154,7 +1156,9 @@ static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_r
   static const bool fused_tail = getenv("COVGPU_TAIL") == nullptr || atoi(getenv("COVGPU_TAIL")) != 0;
   const bool two = o.strategy == COVGPU_DOGLEG;
   const bool coll = c->sharded && c->reducer != nullptr;   // scalar all-reduce between a finish and the step logic that reads it
+  static const bool host_timing = getenv("COVGPU_HOST_TIMING") != nullptr;   // dev aid: host enqueue time | host wait per iteration
   while (it < o.max_iterations) {
+    const auto t_enq0 = std::chrono::steady_clock::now();
     if (fused_tail) {
       if (!reuse) {
         const double damp = (o.strategy == COVGPU_LM) ? 1.0 / h[TR_RADIUS] : h[TR_MU];
@@ -1192,7 +1196,11 @@ static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_r
     launch_tr_decide(P, tc, c->st);
     }
     HIPCHK(hipMemcpyAsync(h, P.tr, TR_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    const auto t_enq1 = std::chrono::steady_clock::now();
     RC(wait_iteration(c));
+    if (host_timing)
+      std::fprintf(stderr, "[covgpu] iteration %d: host enqueue %.0f us, host wait %.0f us\n", it, std::chrono::duration<double>(t_enq1 - t_enq0).count() * 1e6,
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enq1).count() * 1e6);
     collect_profile(c, !reuse, !reuse);
     if (!got_initial) { res->initial_cost = h[TR_INITCOST]; got_initial = true; }
     if (h[TR_RETRY] != 0.0) { reuse = false; continue; }  // factorisation failed: same iteration again with the raised damping

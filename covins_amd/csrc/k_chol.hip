@@ -395,6 +395,8 @@ void CholAux::collect() {
 
 // trailing updates given as explicit tile lists of at most this many entries (incl. the XCD padding) run as 64x64 quadrants
 static const int kQuarterMax = getenv("COVGPU_QUARTER_MAX") ? atoi(getenv("COVGPU_QUARTER_MAX")) : 1024;
+// look-ahead update of the rows below the next panel (stream R): tiles up to which it runs as quarter tiles
+static const int kRectQuarterMax = getenv("COVGPU_RECTR_QUARTER_MAX") ? atoi(getenv("COVGPU_RECTR_QUARTER_MAX")) : 512;
 
 void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax, int tstop, bool solve,
                               DenseBatch bt) {
@@ -554,7 +556,9 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       if (T > h1) {
         wait(R, eH[P - 1]);                    // B operand: L rows t0, t0+1 (rows h of panel P-1)
         if (P >= 2) wait(R, eA[P - 2]);
-        rect(h1, T, t0, w, t0 - 2, kd(P - 1), R, false);
+        // (round 5: as quarter tiles while the launch is small — a full tile is one workgroup's 16-chunk K loop, 50-57 us of latency that the
+        //  rest rows' substitution and, behind it, the bulk update and the last panel's substitution wait for)
+        rect(h1, T, t0, w, t0 - 2, kd(P - 1), R, (T - h1) * w * nbt <= kRectQuarterMax);
         if (trace2) ax.mark(R, 100 * (P + 1) + 7);   // rows r carry panel P-1
         (void)hipEventRecord(e2[P], R);  // rows r carry panel P-1's update
       }
@@ -587,7 +591,10 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         const bool split = bt.split_ta > 0 && bt.live_h != nullptr && kd(P) > 0 && (tc.listA != nullptr || tc.listB != nullptr);
         launch_trsm_sub(S, ld, t0, w, h0, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
         if (split) { (void)hipEventRecord(eH[P], M); wait(B, eH[P]); }
-        if (P >= 1) wait(M, eB[P - 1]);  // bulk(P-1) was the previous writer of the trailing tiles
+        // bulk(P-1) was the previous writer of the trailing tiles. The part of this update that stays on the chain's stream (rows < split_ta <= 2:
+        // tile columns 0, 1 of the triangle) only meets the FIRST launch of that bulk update — on the 5-agent map's upper levels (borders of
+        // 2 000 unknowns) the whole of it is 160 us, and the next level's first panel waited for it; the rest follows it on the bulk stream anyway
+        if (P >= 1) wait(M, (split && bt.split_ta <= 2) ? eA[P - 1] : eB[P - 1]);
         const int tb = h0, nt = T - tb;
         auto syrk = [&](hipStream_t s2, const int* list, int count, double flops) {
           GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab, bt.own_dims};
@@ -735,6 +742,13 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   dense_backward_solve(S, b, Linv, npad, st, T, T, bt);
 }
 
+// Fronts of at most this many interior tiles run their whole backward substitution in ONE launch (k_bwd_front: the last workgroup solves the
+// interior tiles one after the other, ~3 us per tile + 0.7 us per tile pair, against 8.6 us per tile and launch). Round 4: 4 (every front of
+// the 5-agent map but the root then had <= 4); round 5: the maps' upper levels hold fronts of 5-6 tiles.
+int bwd_front_max_tiles() {
+  static const int v = getenv("COVGPU_BWD_FRONT_TILES") ? std::max(1, atoi(getenv("COVGPU_BWD_FRONT_TILES"))) : 8;
+  return v;
+}
 // L^T x = y for the factored tile columns [0, tfact) of an npad-order matrix; for tile rows p in [tfact, tend) x_p is
 // GIVEN (already in b[p*128 ..]) and only its contribution L[rows p, cols < tfact*128]^T x_p is taken out of y.
 void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStream_t st, int tfact, int tend, DenseBatch bt) {
@@ -743,7 +757,7 @@ void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStrea
   {
     // multifrontal front of few interior tiles: given rows and every interior tile in ONE launch (k_panel.hip: k_bwd_front)
     const int nt_real = bt.own_max > 0 ? std::min(tfact, (bt.own_max + kTile - 1) / kTile) : tfact;
-    if (bt.bwd_cnt != nullptr && bt.bwd_scr != nullptr && bt.xfer.gidx != nullptr && bt.tab != nullptr && bt.live != nullptr && nt_real >= 1 && nt_real <= 4 &&
+    if (bt.bwd_cnt != nullptr && bt.bwd_scr != nullptr && bt.xfer.gidx != nullptr && bt.tab != nullptr && bt.live != nullptr && nt_real >= 1 && nt_real <= bwd_front_max_tiles() &&
         nbt <= 65536) {
       const int nchunk = std::max(1, ((tend - tfact) * kTile + 255) / 256);
       launch_bwd_front(S, tfact, nt_real, nchunk, b + npad, Linv, nbt, bt.sL, bt.sR, st, bt.tab, bt.live, bt.xfer, bt.bwd_cnt, bt.bwd_scr);

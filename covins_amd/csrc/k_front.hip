@@ -428,7 +428,7 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
   {  // scratch of the one-launch backward substitution (k_bwd_front): [fronts][interior tiles <= 4][256-row chunks of the border][128]
     size_t need = 0;
     for (const NdLevel& L : nd.lev)
-      need = std::max(need, (size_t)L.n * std::min(4, (L.own_max + kTile - 1) / kTile) * std::max(1, (L.ntot - L.nI + 255) / 256) * kTile);
+      need = std::max(need, (size_t)L.n * std::min(bwd_front_max_tiles(), (L.own_max + kTile - 1) / kTile) * std::max(1, (L.ntot - L.nI + 255) / 256) * kTile);
     if (need > ax.bwd_scr_elems) {
       if (ax.bwd_scr) (void)hipFree(ax.bwd_scr);
       ax.bwd_scr = nullptr; ax.bwd_scr_elems = 0;

@@ -890,7 +890,17 @@ __global__ __launch_bounds__(256) void k_bwd_front(const double* __restrict__ M,
       const int c = tid & 127, jbc = c >> 4, cl = c & 15;
       const bool act = tid < kTile;
       double v = act ? y[k0 + c] : 0.0;
-      if (act) for (int q = 0; q < nch; ++q) v -= __hip_atomic_load(scr_f + ((size_t)p * nchunk + q) * kTile + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (eight partial sums in flight, subtracted in chunk order: one at a time each load was a dependent ~1.5 us round trip past the L2 —
+      //  10 chunks x 4 tiles = 60 us of a 69 us launch on the 5-agent map's upper levels)
+      if (act)
+        for (int q0 = 0; q0 < nch; q0 += 8) {
+          double t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            t[u] = q0 + u < nch ? __hip_atomic_load(scr_f + ((size_t)p * nchunk + q0 + u) * kTile + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v -= t[u];
+        }
       double dv[PB], Lc[7][PB];
 #pragma unroll
       for (int r = 0; r < PB; ++r) dv[r] = act ? Dinv[jbc * 256 + r * PB + cl] : 0.0;

@@ -4,6 +4,7 @@ library's collectives run through its native in-process group (solver.hip GroupR
 The sharded result must equal the unsharded one: one Gauss-Newton step to 1e-9 (relative) and the full 10-iteration solve
 to 1e-8 m with the identical accept sequence; three collectives per trust-region iteration (the top of the tree inside the
 linear solve, two scalar exchanges of the fused tail)."""
+import os
 import threading
 
 import numpy as np
@@ -55,9 +56,16 @@ def test_sharded_gauss_newton_step_equals_unsharded(name, world):
     # (a single agent splits too: the units are subtrees, not agents; the top is capped — rather fewer subtrees than ranks: at world 8
     #  two ranks of the 5-agent map hold the replicated top only and still take part in every exchange)
     assert plan is not None and plan.subtrees >= min(world, 5)
-    ctx = backend.Context(0)
-    dx0, dl0, c0 = ctx.gn_step(p, o, 1e-8)
-    ctx.close()
+    # the unsharded reference on the SAME elimination tree as the sharded plan (one separator of all agents at the top: what
+    # covgpu_shard_plan builds; the one-GPU default on this map is the two-groups tree, whose step differs by rounding x condition, 3e-9
+    # at mu = 1e-8): the 1e-9 below then measures the sharding alone
+    os.environ["COVGPU_ND_TOP"] = "0"
+    try:
+        ctx = backend.Context(0)
+        dx0, dl0, c0 = ctx.gn_step(p, o, 1e-8)
+        ctx.close()
+    finally:
+        del os.environ["COVGPU_ND_TOP"]
     parts, (st, lay) = run_virtual_ranks(p, plan, lambda ctx, sub, r: ctx.gn_step(sub, o, 1e-8))
     po, so = np.where(plan.pose_rank < 0, 0, plan.pose_rank), np.where(plan.sb_rank < 0, 0, plan.sb_rank)
     dx = np.zeros_like(dx0); dl = np.zeros_like(dl0)

@@ -462,7 +462,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   if (bt.tri_slot >= (int)ax.tri_lev.size()) ax.tri_lev.resize(bt.tri_slot + 1);
   CholAux::TriCache& tc = bt.tri_slot >= 0 ? ax.tri_lev[bt.tri_slot] : ax.tri0;
   // live tiles (i, j), j <= i, of the triangle that starts at tile tb, for the fronts whose interior reaches panel column t0;
-  // part 0: all | 1: rows i < split_ta | 2: rows i >= split_ta | 3: tile columns j < 2 | 4: tile columns j >= 2. XCD-balanced, interleaved (position p runs on XCD p % 8).
+  // part 0: all | 1: rows i < split_ta | 2: rows i >= split_ta | 3: tile columns j < 2 and rows i < split_ta | 4: the others. XCD-balanced, interleaved (position p runs on XCD p % 8).
   auto build_list = [&](int t0, int tb, int part, int*& d_out, int& n_out) {
     d_out = nullptr; n_out = 0;
     std::vector<int> q[8];  // per-XCD queues; whole 8x8 supertiles of one batch go to the currently shortest queue
@@ -476,7 +476,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
           std::vector<int> grp;
           for (int i = 8 * si; i < std::min(nt, 8 * si + 8); ++i)
             for (int j = 8 * sj; j < std::min(i + 1, 8 * sj + 8); ++j)
-              if (live(tb + i) && live(tb + j) && (part == 0 || (part <= 2 && (i < bt.split_ta) == (part == 1)) || (part >= 3 && (j < 2) == (part == 3)))) grp.push_back((a << 20) | (i << 10) | j);
+              if (live(tb + i) && live(tb + j) && (part == 0 || (part <= 2 && (i < bt.split_ta) == (part == 1)) || (part >= 3 && (j < 2 || i < bt.split_ta) == (part == 3)))) grp.push_back((a << 20) | (i << 10) | j);
           if (grp.empty()) continue;
           int best = 0;
           for (int x = 1; x < 8; ++x) if (q[x].size() < q[best].size()) best = x;
@@ -591,10 +591,10 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         const bool split = bt.split_ta > 0 && bt.live_h != nullptr && kd(P) > 0 && (tc.listA != nullptr || tc.listB != nullptr);
         launch_trsm_sub(S, ld, t0, w, h0, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
         if (split) { (void)hipEventRecord(eH[P], M); wait(B, eH[P]); }
-        // bulk(P-1) was the previous writer of the trailing tiles. The part of this update that stays on the chain's stream (rows < split_ta <= 2:
-        // tile columns 0, 1 of the triangle) only meets the FIRST launch of that bulk update — on the 5-agent map's upper levels (borders of
+        // bulk(P-1) was the previous writer of the trailing tiles. The part of this update that stays on the chain's stream (rows < split_ta: what
+        // build_list puts into the first launch beside tile columns 0, 1) only meets the FIRST launch of that bulk update — on the 5-agent map's upper levels (borders of
         // 2 000 unknowns) the whole of it is 160 us, and the next level's first panel waited for it; the rest follows it on the bulk stream anyway
-        if (P >= 1) wait(M, (split && bt.split_ta <= 2) ? eA[P - 1] : eB[P - 1]);
+        if (P >= 1) wait(M, split ? eA[P - 1] : eB[P - 1]);
         const int tb = h0, nt = T - tb;
         auto syrk = [&](hipStream_t s2, const int* list, int count, double flops) {
           GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab, bt.own_dims};
@@ -743,10 +743,10 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
 }
 
 // Fronts of at most this many interior tiles run their whole backward substitution in ONE launch (k_bwd_front: the last workgroup solves the
-// interior tiles one after the other, ~3 us per tile + 0.7 us per tile pair, against 8.6 us per tile and launch). Round 4: 4 (every front of
-// the 5-agent map but the root then had <= 4); round 5: the maps' upper levels hold fronts of 5-6 tiles.
+// interior tiles one after the other). Measured in round 5 on the corrected 5-agent map, whose upper levels hold fronts of 5-6 tiles: the
+// serial part costs ~15 us per tile (dependent loads of one workgroup), a launch per tile 8.6 — 4: 212.8 it/s, 8: 211.8, 16: 200.0.
 int bwd_front_max_tiles() {
-  static const int v = getenv("COVGPU_BWD_FRONT_TILES") ? std::max(1, atoi(getenv("COVGPU_BWD_FRONT_TILES"))) : 8;
+  static const int v = getenv("COVGPU_BWD_FRONT_TILES") ? std::max(1, atoi(getenv("COVGPU_BWD_FRONT_TILES"))) : 4;
   return v;
 }
 // L^T x = y for the factored tile columns [0, tfact) of an npad-order matrix; for tile rows p in [tfact, tend) x_p is

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void k_tail_stats(DevProblem P) {
 // ---- T2: JA = |J va|^2, JB = |J vb|^2, JC = (J va).(J vb) over all residual blocks, at the current estimate. TWO == false: vb only (LM).
 //          Segments by blockIdx: [0, nb_obs) reprojection (grid-stride over the SoA stream) | [nb_obs, nb_obs + nb_imu) one wave per
 //          IMU factor | the rest: one thread per between factor.
+static_assert(kImuWaves == 4, "k_tail_jvp / k_tail_cost index their IMU and edge segments as 4 waves / 256 threads per workgroup");
 template <bool TWO>
 __global__ __launch_bounds__(64 * kImuWaves) void k_tail_jvp(DevProblem P, const double* __restrict__ va, const double* __restrict__ vb, int nb_obs, int nb_imu) {
   __shared__ double sm[kImuWaves][kImuLds];
@@ -276,7 +277,9 @@ __global__ __launch_bounds__(1024) void k_tail_finish(DevProblem P, SlotList sl,
   if (threadIdx.x == 0) {
     __hip_atomic_store(&P.scal[slot], sc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sum is out before the ticket is drawn (k_bwd_front uses the same idiom)
-    s_ticket = __hip_atomic_fetch_add(&P.flag[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (release on the ticket, acquire for the winner — inside the HIP memory model, not only what gfx9 happens to do; this kernel
+    //  runs alone on the chip, so the cache maintenance the release / acquire imply costs nothing measurable)
+    s_ticket = __hip_atomic_fetch_add(&P.flag[2], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   if (s_ticket != (int)gridDim.x - 1 || threadIdx.x != 0) return;

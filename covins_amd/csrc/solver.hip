@@ -1107,13 +1107,13 @@ static int wait_iteration(covgpu_context* c) {
       const hipError_t q = hipStreamQuery(c->st);
       if (q == hipSuccess) break;
       if (q != hipErrorNotReady) { g_err = std::string("hipStreamQuery: ") + hipGetErrorString(q); return COVGPU_ERR_NO_DEVICE; }
-      if ((++spins & 1023) == 0) {
+      if ((++spins & (spins > 256 ? 63 : 1023)) == 0) {   // (fail checks: every 1024 busy polls at first, then every 64 sleeping polls = ~4 ms)
         const char* why = nullptr;
         if (c->peer_fail && c->peer_fail->load(std::memory_order_relaxed)) why = "another rank of the call gave up";
         else if (rr && rr->async_error() != 0) why = "RCCL reported an asynchronous communicator error";
         else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) why = "collective timed out (COVGPU_COLL_TIMEOUT_S)";
         if (why) { if (!c->coll_failed) { c->coll_failed = true; c->coll_err = why; } c->reducer->abort(); break; }
-      } else if (spins > 4096) std::this_thread::yield();
+      } else if (spins > 256) std::this_thread::sleep_for(std::chrono::microseconds(50));   // (a rank's host thread sleeps between polls instead of burning a core for the whole iteration)
     }
   }
   HIPCHK(hipStreamSynchronize(c->st));
@@ -1268,8 +1268,21 @@ extern "C" int covgpu_pgo_solve(covgpu_context* c, const covgpu_options* opt, co
 // the same device code as an upload; the elimination tree stays — couplings only disappear), and only the erase flags travel back for
 // the caller's map bookkeeping. p: the FIRST round's problem; on return its poses / speed-bias hold the second round's estimate and
 // lm_pos[l] the second round's for every landmark with lm_left[l] >= 2 (the others took no part, as in the reference).
+// State of the context afterwards: the resident problem is the SECOND round's (compacted landmark / observation indexing), which the
+// caller's covgpu_problem does not describe — so the context is marked as holding no problem when the call returns, successfully or not:
+// covgpu_download / covgpu_outlier_pass / covgpu_solve_resident after it fail with "no problem uploaded" instead of scattering into the
+// first round's slots, and an error half-way cannot leave a half-switched problem behind. (Everything the caller needs came back through
+// p, obs_erase, lm_left and the two results.)
+static int gba_two_round_impl(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, const covgpu_two_round* tr, uint8_t* obs_erase,
+                              int32_t* lm_left, int64_t* counts, covgpu_result* round1, covgpu_result* round2);
 extern "C" int covgpu_gba_two_round(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, const covgpu_two_round* tr, uint8_t* obs_erase,
                                     int32_t* lm_left, int64_t* counts, covgpu_result* round1, covgpu_result* round2) {
+  const int rc = gba_two_round_impl(c, opt, p, tr, obs_erase, lm_left, counts, round1, round2);
+  if (c) { c->have = false; }
+  return rc;
+}
+static int gba_two_round_impl(covgpu_context* c, const covgpu_options* opt, covgpu_problem* p, const covgpu_two_round* tr, uint8_t* obs_erase,
+                              int32_t* lm_left, int64_t* counts, covgpu_result* round1, covgpu_result* round2) {
   return guarded([&]() -> int {
     if (!tr || !obs_erase || !lm_left) { g_err = "covgpu_gba_two_round: NULL argument"; return (int)COVGPU_ERR_INVALID_ARG; }
     if (c->sharded) { g_err = "covgpu_gba_two_round runs on one GPU (sharded solve: covgpu_gba_solve_multi per round)"; return (int)COVGPU_ERR_INVALID_ARG; }

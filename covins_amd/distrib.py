@@ -87,15 +87,31 @@ def plan_digest(plan: ShardPlan) -> str:
     return h.hexdigest()
 
 
+_attach_seq = {}   # per store: how many attaches this process has run on it — the ranks attach in the same order, so the count names the attach
+
+
 def check_plan_digest(store, rank: int, world: int, mine: str) -> None:
-    """Every rank publishes its digest and reads everybody's: ALL ranks raise on a mismatch (nobody is left waiting in a collective)."""
+    """Every rank publishes its digest and reads everybody's: ALL ranks raise on a mismatch (nobody is left waiting in a collective).
+    The keys carry the attach's sequence number (a second attach on the same store must not read the first one's digests), and
+    a second round of keys — every rank's verdict — follows the comparison, so that no rank goes on to ncclCommInitRank while another
+    has already refused."""
     from . import backend
-    store.set(f"plan_digest_{rank}", mine.encode())
+    seq = _attach_seq.get(id(store), 0)
+    _attach_seq[id(store)] = seq + 1
+    store.set(f"plan_digest_{seq}_{rank}", mine.encode())
+    bad = None
     for r in range(world):
-        other = bytes(store.get(f"plan_digest_{r}")).decode()
-        if other != mine:
-            raise backend.CovGpuError(f"rank {rank}: shard plan digest {mine[:16]}.. differs from rank {r}'s {other[:16]}..: the ranks did not "
-                                      "compute the same plan (different problem or options) — aborting before any collective is issued")
+        other = bytes(store.get(f"plan_digest_{seq}_{r}")).decode()
+        if other != mine and bad is None:
+            bad = (r, other)
+    store.set(f"plan_digest_ok_{seq}_{rank}", b"0" if bad else b"1")
+    refused = [r for r in range(world) if bytes(store.get(f"plan_digest_ok_{seq}_{r}")) != b"1"]
+    if bad:
+        raise backend.CovGpuError(f"rank {rank}: shard plan digest {mine[:16]}.. differs from rank {bad[0]}'s {bad[1][:16]}..: the ranks did not "
+                                  "compute the same plan (different problem or options) — aborting before any collective is issued")
+    if refused:
+        raise backend.CovGpuError(f"rank {rank}: rank(s) {refused} refused the shard plan (their digest differs from another rank's) — aborting "
+                                  "before any collective is issued")
 
 
 def shard_problem(prob: FlatProblem, plan: ShardPlan, rank: int) -> FlatProblem:

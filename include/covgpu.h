@@ -200,7 +200,9 @@ int covgpu_outlier_pass(covgpu_context* ctx, double threshold, uint8_t* obs_eras
  *                the second round's estimate, lm_pos[l] the second round's for every landmark with lm_left[l] >= 2
  *   opt          options of the second round (max_iterations = opt.gba_iteration_limit)
  *   obs_erase, lm_left, counts   as covgpu_outlier_pass, for the caller's map bookkeeping (kf->EraseLandmark, lm->EraseObservation)
- *   round1, round2 (may be NULL)  the two trust-region records; round2->t_upload_s = seconds of the device-side rebuild          */
+ *   round1, round2 (may be NULL)  the two trust-region records; round2->t_upload_s = seconds of the device-side rebuild
+ * Afterwards the context holds NO resident problem (what is resident is the second round's compacted problem, which `p` does not
+ * describe): covgpu_solve_resident / covgpu_download / covgpu_outlier_pass need a new covgpu_upload first.                        */
 typedef struct covgpu_two_round {
   double  outlier_threshold;         /* opt.th_gba_outlier_global (config_backend.yaml:121)                                  */
   int32_t round1_iterations;         /* 5 (optimization_be.cpp:262); <= 0: 5                                                 */

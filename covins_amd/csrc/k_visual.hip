@@ -257,11 +257,17 @@ __global__ __launch_bounds__(64) void k_kf_reduce(DevProblem P) {
 // (The first version had lane = block entry, 36 of 64 lanes busy, every lane walking all common landmarks in sequence:
 // 0.78 ms on the 5-agent map, the longest kernel of the linearisation.)
 constexpr int kPairLanes = 16, kPairsPerWg = 8;
-__global__ __launch_bounds__(kPairLanes * kPairsPerWg) void k_pair_blocks(DevProblem P) {
+__global__ __launch_bounds__(kPairLanes * kPairsPerWg) void k_pair_blocks(DevProblem P, int pair_xcd_order) {
   __shared__ double sp[kPairsPerWg][36][kPairLanes + 1];
   const int grp = threadIdx.x / kPairLanes, g = threadIdx.x % kPairLanes;
-  const int p = blockIdx.x * kPairsPerWg + grp;
-  const bool ok = p < P.npairs;
+  // XCD-aware order (round 5): workgroup b runs on XCD b % 8 (observed dispatch order; placement affects speed only). The pair list is sorted by
+  // (row keyframe, column keyframe) in chain order, and the two keyframes' record blocks (60 KB each) are what a pair reads: with consecutive
+  // pair groups dealt round-robin every XCD's L2 fetched every keyframe's block — eight copies of the 125 MB record array per pass. Each XCD
+  // now takes one CONTIGUOUS eighth of the list: its L2 holds the ~40 keyframe blocks around the row keyframe it is working on.
+  const int nblk = (P.npairs + kPairsPerWg - 1) / kPairsPerWg, nbx = (nblk + 7) / 8;
+  const int lb = pair_xcd_order ? ((int)blockIdx.x & 7) * nbx + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int p = lb * kPairsPerWg + grp;
+  const bool ok = lb < nblk && p < P.npairs;
   const int e0 = ok ? P.pair_ptr[p] : 0, e1 = ok ? P.pair_ptr[p + 1] : 0;
   double acc[36];
 #pragma unroll
@@ -419,7 +425,11 @@ void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t 
   hipLaunchKernelGGL(k_cost_finish, dim3(1), dim3(256), 0, s2, P, nblk);
   if (pose_system_cleared) { (void)hipStreamWaitEvent(s2, pose_system_cleared, 0); if (fork) (void)hipStreamWaitEvent(st, pose_system_cleared, 0); }  // first writers of the pose system follow
   hipLaunchKernelGGL(k_kf_reduce, dim3(P.K), dim3(64), 0, s2, P);
-  if (P.npairs) hipLaunchKernelGGL(k_pair_blocks, dim3((P.npairs + kPairsPerWg - 1) / kPairsPerWg), dim3(kPairLanes * kPairsPerWg), 0, st, P);
+  if (P.npairs) {
+    static const int xcd_order = getenv("COVGPU_PAIR_XCD") == nullptr || atoi(getenv("COVGPU_PAIR_XCD")) != 0;
+    const int nblk = (P.npairs + kPairsPerWg - 1) / kPairsPerWg;
+    hipLaunchKernelGGL(k_pair_blocks, dim3(xcd_order ? 8 * ((nblk + 7) / 8) : nblk), dim3(kPairLanes * kPairsPerWg), 0, st, P, xcd_order);
+  }
   // (fork: the caller joins the side stream back — it has more on it)
 }
 // upload: keyframe-major copies of the observation stream (DevProblem::kobs), the Z slot of every observation, and the covisible-pair

@@ -433,6 +433,22 @@ def main():
                                            "map to read its size; the stand-in mirrors that) — not part of what this build replaces",
                                    "what": "covins_gpu::Optimization::GlobalBundleAdjustment(map, 10) through the C++ facade on stand-in map "
                                            "objects (one Map -> IR walk, one upload, both rounds on the device, erase, write-back, Map::Clean)"}
+            # the same with Params::device_clean (opt-in): the call's end from its own counts instead of map->Clean()
+            from tests.facade_util import lib as _shim
+            _shim().shim_set_device_clean(1)
+            try:
+                ts2, stg2 = [], []
+                for _ in range(3):
+                    smap = StandinMap(m)
+                    t_c = time.perf_counter(); smap.gba(args.iterations); ts2.append(time.perf_counter() - t_c)
+                    stg2.append({k: round(v * 1e-3, 4) for k, v in StandinMap.last_stages().items()})
+                    smap.close()
+                mid2 = sorted(range(3), key=lambda i: ts2[i])[1]
+                out["e2e_call_cpp"]["device_clean"] = {"t_call_s": ts2[mid2], "t_calls_s": [round(t, 4) for t in ts2], "stages_s": stg2[mid2],
+                                                       "what": "Params::device_clean = 1 (opt-in): landmarks left with < 2 observations erased from the counts of the call "
+                                                               "(map_be.cpp:698-717) instead of map->Clean()'s second copy of every observation map"}
+            finally:
+                _shim().shim_set_device_clean(0)
         except Exception as e:   # (the shim needs g++ on the box; never fatal for the metric line)
             out["e2e_call_cpp"] = {"t_call_s": None, "error": repr(e)[:200]}
     # ---- configs[4] leg (all ranks, behind everything else and with the metric's context closed: eight live streams share the runtime's

@@ -54,7 +54,10 @@ __device__ long long g_probe[8];
 constexpr int KC = 16;        // K chunk staged through LDS (full-tile kernels)
 constexpr int KCQ = 32;       // quarter forms: they run at memory LATENCY (one dependent global->LDS step per chunk while the
                               // chip is loaded: ~3 us each), so fewer, larger chunks
-constexpr int LDT = KC + 1;   // LDS pitch (doubles): odd pitch -> conflict-free fragment reads
+constexpr int kLdsPad = 2;   // LDS pitch = K chunk + 2 doubles: the fragment reads (lane -> row fr, column kk + fk) of a half-wave then hit 32 distinct bank pairs.
+                            // Rounds 1-4 used + 1 ("odd pitch" — odd in DOUBLES, i.e. 34 / 66 dwords): two-way conflicts, SQ_LDS_BANK_CONFLICT = 25 % of
+                            // the LDS cycles of the quarter-tile kernel (profiles/r05*_pmc_gemm_*.csv)
+constexpr int LDT = KC + kLdsPad;   // LDS pitch (doubles) of the full-tile kernels
 #ifndef COVGPU_PFF
 #define COVGPU_PFF 1
 #endif
@@ -119,7 +122,7 @@ COV_DEV void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrie
 
 template <int MODE, int TSA, int TSB, int KC, int PF>
 COV_DEV void gemm_abt_body(const GemmArgs& g) {
-  constexpr int LDT = KC + 1;
+  constexpr int LDT = KC + kLdsPad;
   static_assert((TSA == kTile && TSB == kTile) || (MODE != MODE_TRSM && TSA == 64 && TSB == 64) ||
                 (MODE == MODE_TRSM && TSA == 32 && TSB == kTile), "quarter forms: RECT / TRI 64x64, TRSM 32x128");
   constexpr int WGR = (TSA == 32) ? 1 : 2, WGC = 4 / WGR;  // wave grid
@@ -429,7 +432,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   auto rect = [&](int r0, int r1, int tc0, int ntc, int kt0, int KD, hipStream_t s2, bool quad) {
     if (r1 <= r0 || ntc <= 0 || KD <= 0) return;
     GemmArgs g{S, ld, kt0 * kTile, KD, r0 * kTile, tc0 * kTile, tc0 * kTile, r1 - r0, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab, bt.own_dims};
-    if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4 * nbt), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), s2, g);
+    if (quad) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_RECT, 64, 64>), dim3(ntc, r1 - r0, 4 * nbt), dim3(256), (size_t)(64 + 64) * (KCQ + kLdsPad) * sizeof(double), s2, g);
     else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_RECT>, dim3(ntc, r1 - r0, nbt), dim3(256), lds_gemm, s2, g);
   };
 
@@ -603,7 +606,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
           // a short list runs at the LATENCY of one workgroup's K loop (16 chunks of 64 MFMAs per wave): as 64x64 quadrants it is
           // four times as many workgroups, each four times shorter
           if (list != nullptr && count <= kQuarterMax)
-            hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_TRI, 64, 64>), dim3(count, 1, 4), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), s2, g);
+            hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_TRI, 64, 64>), dim3(count, 1, 4), dim3(256), (size_t)(64 + 64) * (KCQ + kLdsPad) * sizeof(double), s2, g);
           else if (list != nullptr) hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(count, 1), dim3(256), lds_gemm, s2, g);
           else {
             const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
@@ -713,7 +716,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], B);
         auto tri = [&](const int* list, int count) {
           g.tri = list;
-          if (count <= kQuarterMax) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_TRI, 64, 64>), dim3(count, 1, 4), dim3(256), (size_t)(64 + 64) * (KCQ + 1) * sizeof(double), B, g);
+          if (count <= kQuarterMax) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_TRI, 64, 64>), dim3(count, 1, 4), dim3(256), (size_t)(64 + 64) * (KCQ + kLdsPad) * sizeof(double), B, g);
           else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(count, 1), dim3(256), lds_gemm, B, g);
         };
         if (cntC > 0) {   // the next-but-one panel's two tile columns first: what the chain waits for

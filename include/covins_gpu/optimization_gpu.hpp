@@ -64,6 +64,13 @@ struct Params {
   // GlobalBundleAdjustment with outlier removal: derive the second round's problem on the device from the resident first round
   // (covgpu_gba_two_round: ONE Map -> IR walk and ONE upload per call); 0: the reference's literal sequence — walk, solve, erase, walk, solve
   int device_second_round = 1;
+  // Opt-in (0: the call ends with the reference's own map->Clean(), optimization_be.cpp:614). 1: the end of the two-round call reproduces what
+  // Map::Clean's map check does (map_be.cpp:698-717: every landmark of the map whose observation map holds fewer than two entries is erased)
+  // from counts the call already has — the Map -> IR walk visited every landmark's observations once, the device returned how many of them
+  // each landmark kept — instead of copying every landmark's observation map AGAIN to read its size (50 ms of a 180 ms call on the 5-agent
+  // map). NOT reproduced: Clean's second loop over every keyframe's landmark vector (:719-729), which only finds landmarks that a keyframe
+  // references but the map does not list — none in a consistent map. tests/test_facade.py compares the two ends.
+  int device_clean = 0;
   // (IMU noise and gravity are NOT parameters: every IMU factor carries its keyframe's own VICalibration values,
   //  Types::imu_calib, as the reference's per-keyframe preintegrators do — keyframe_be.cpp:187-195.)
 };
@@ -225,7 +232,12 @@ class OptimizationT {
   // row k of the IR = kfs[k], landmark l = lms[l]; observation i of the IR (landmark-major, Flat::obs_ptr) = feature obs_feat[i] of
   // keyframe kfs[Flat::obs_kf[i]]. (No smart-pointer copies per observation: 0.87 M observations x four atomic reference-count
   // updates on the keyframes' control blocks, contended between the walking threads, were most of a 0.28 s walk.)
-  struct Index { std::vector<KeyframePtr> kfs; std::vector<LandmarkPtr> lms; std::vector<size_t> obs_feat; };
+  struct Index {
+    std::vector<KeyframePtr> kfs; std::vector<LandmarkPtr> lms; std::vector<size_t> obs_feat;
+    // for Params::device_clean: per IR landmark the entries of its observation map that are NOT in the IR (invalid / null keyframes), and the
+    // valid landmarks the gating left out whose observation map holds fewer than two entries (what Map::Clean erases whatever the solve does)
+    std::vector<int32_t> lm_extra; std::vector<LandmarkPtr> short_lms;
+  };
 
   // Map -> IR for one GBA round (optimization_be.cpp:74-254 round 1, :308-557 round 2)
   static void FlattenGBA(const MapPtr& map, bool visual_only, bool round2, detail::Flat& f, Index& ix) {
@@ -319,7 +331,7 @@ class OptimizationT {
     int nth = prm.flatten_threads > 0 ? prm.flatten_threads : (int)std::thread::hardware_concurrency();
     nth = std::max(1, std::min(nth, 16));
     if (landmarks.size() < 4096) nth = 1;
-    struct Slice { std::vector<double> lm, uv, sigma; std::vector<int32_t> obs_kf, nobs; std::vector<LandmarkPtr> lms; std::vector<size_t> feat; };
+    struct Slice { std::vector<double> lm, uv, sigma; std::vector<int32_t> obs_kf, nobs, extra; std::vector<LandmarkPtr> lms, shorts; std::vector<size_t> feat; };
     std::vector<Slice> slices(nth);
     auto walk = [&](int t) {
       Slice sl;   // (thread-local while it grows: the vectors' end pointers of neighbouring slices[] entries share cache lines)
@@ -331,8 +343,9 @@ class OptimizationT {
         if (lm->IsInvalid()) continue;
         // (emitted straight into the slice and rolled back if fewer than two valid observations remain: :150-160, 428-440)
         const size_t o_mark = sl.obs_kf.size();
-        int32_t n = 0;
+        int32_t n = 0, total = 0;
         detail::visit_observations<Types>(*lm, [&](const KeyframePtr& kfx, size_t feat) {
+          ++total;
           if (!kfx || kfx->IsInvalid()) return;
           sl.obs_kf.push_back(row.at(kfx.get()));
           sl.uv.push_back((double)kfx->keypoints_distorted_[feat][0]);  // float -> double (utils_base.hpp:76-80)
@@ -343,12 +356,14 @@ class OptimizationT {
         }, 0);
         if ((size_t)n < th_min_observations) {
           sl.obs_kf.resize(o_mark); sl.uv.resize(2 * o_mark); sl.sigma.resize(o_mark); sl.feat.resize(o_mark);
+          if (total < 2) sl.shorts.push_back(lm);
           continue;
         }
         const Vector3Type pw = lm->GetWorldPos();
         for (int i = 0; i < 3; ++i) sl.lm.push_back(pw[i]);
         sl.lms.push_back(lm);
         sl.nobs.push_back(n);
+        sl.extra.push_back(total - n);
       }
       slices[t] = std::move(sl);
     };
@@ -363,7 +378,8 @@ class OptimizationT {
     // slices -> IR at their offsets (prefix sums), again in the threads: 35 MB of copies
     std::vector<size_t> lm0(nth + 1, 0), ob0(nth + 1, 0);
     for (int t = 0; t < nth; ++t) { lm0[t + 1] = lm0[t] + slices[t].lms.size(); ob0[t + 1] = ob0[t] + slices[t].obs_kf.size(); }
-    f.lm.resize(3 * lm0[nth]); f.obs_ptr.resize(lm0[nth] + 1); ix.lms.resize(lm0[nth]);
+    f.lm.resize(3 * lm0[nth]); f.obs_ptr.resize(lm0[nth] + 1); ix.lms.resize(lm0[nth]); ix.lm_extra.resize(lm0[nth]);
+    for (int t = 0; t < nth; ++t) ix.short_lms.insert(ix.short_lms.end(), slices[t].shorts.begin(), slices[t].shorts.end());
     f.uv.resize(2 * ob0[nth]); f.sigma.resize(ob0[nth]); f.obs_kf.resize(ob0[nth]); ix.obs_feat.resize(ob0[nth]);
     f.obs_ptr[0] = 0;
     in_threads([&](int t) {
@@ -374,6 +390,7 @@ class OptimizationT {
       std::copy(sl.obs_kf.begin(), sl.obs_kf.end(), f.obs_kf.begin() + ob0[t]);
       std::copy(sl.feat.begin(), sl.feat.end(), ix.obs_feat.begin() + ob0[t]);
       std::move(sl.lms.begin(), sl.lms.end(), ix.lms.begin() + lm0[t]);
+      std::copy(sl.extra.begin(), sl.extra.end(), ix.lm_extra.begin() + lm0[t]);
       int32_t at = (int32_t)ob0[t];
       for (size_t q = 0; q < sl.nobs.size(); ++q) { at += sl.nobs[q]; f.obs_ptr[lm0[t] + q + 1] = at; }
       sl = Slice();
@@ -533,8 +550,17 @@ class OptimizationT {
       }
       lap("write-back");
       std::printf("--> Clean Map\n");
-      map->Clean();  // :614
-      lap("Map::Clean");
+      if (prm.device_clean) {
+        // Map::Clean's map check (map_be.cpp:698-717) from the counts at hand: entries left = kept by the device + entries outside the IR
+        size_t removed = 0;
+        for (size_t l = 0; l < ix.lms.size(); ++l) if (lm_left[l] + ix.lm_extra[l] < 2) { map->EraseLandmark(ix.lms[l]); ++removed; }
+        for (auto& lm : ix.short_lms) { map->EraseLandmark(lm); ++removed; }
+        std::printf("----> Done: Removed %zu Landmarks (counts of the call; Params::device_clean)\n", removed);
+        lap("Map::Clean (from the call's counts)");
+      } else {
+        map->Clean();  // :614
+        lap("Map::Clean");
+      }
       std::printf("--> done.\n+++ GBA: End +++\n");
       return;
     }

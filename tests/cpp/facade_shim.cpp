@@ -139,6 +139,7 @@ int shim_last_stages(char* names, double* ms, int cap) {
   return n;
 }
 void shim_set_device_second_round(int on) { Opt::params().device_second_round = on; }
+void shim_set_device_clean(int on) { Opt::params().device_clean = on; }   // Params::device_clean: the call's own counts instead of map->Clean()
 void shim_shutdown() { Opt::Shutdown(); }   // releases the calling thread's cached context; the next call creates a new one
 void shim_set_invalid(Handle* h, int kf) { h->kfs[kf]->SetInvalid(); }
 

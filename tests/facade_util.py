@@ -29,6 +29,7 @@ def lib():
         _LIB.shim_set_gpus.argtypes = [C.c_int, C.c_int]
         _LIB.shim_set_invalid.argtypes = [C.c_void_p, C.c_int]
         _LIB.shim_set_device_second_round.argtypes = [C.c_int]
+        _LIB.shim_set_device_clean.argtypes = [C.c_int]
         _LIB.shim_shutdown.argtypes = []
     return _LIB
 

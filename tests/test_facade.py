@@ -76,6 +76,33 @@ def test_cpp_gba_matches_python_facade():
 
 
 @pytest.mark.gpu
+def test_cpp_device_clean_leaves_the_map_where_map_clean_leaves_it():
+    """Params::device_clean (opt-in): the end of the two-round call erases the landmarks Map::Clean's map check would erase
+    (map_be.cpp:698-717: fewer than two entries in the observation map), from the counts of the call instead of a second copy of every
+    observation map. Same map state as the call that ends with map->Clean(): a map with gross outliers (landmarks drop below two
+    observations) and an invalid keyframe (observation-map entries outside the IR)."""
+    from tests.facade_util import lib as shim_lib
+    cfg = synth.config_named("small"); cfg.outlier_frac = 0.08; cfg.track_window = 2; cfg.min_parallax_cos = 1.0
+    m = synth.make_map(cfg)
+    states = []
+    for on in (0, 1):
+        shim_lib().shim_set_device_clean(on)
+        sm = StandinMap(m)
+        try:
+            shim_lib().shim_set_invalid(sm.h, 7)
+            sm.gba(10, visual_only=False, outlier_removal=True)
+            states.append((sm.state(), dict(StandinMap.last_stages())))
+        finally:
+            sm.close()
+            shim_lib().shim_set_device_clean(0)
+    (a, sa), (b, sb) = states
+    assert "Map::Clean" in sa and "Map::Clean (from the call's counts)" in sb
+    assert np.array_equal(a["lm_invalid"], b["lm_invalid"]) and np.array_equal(a["lm_nobs"], b["lm_nobs"])
+    assert a["lm_invalid"].sum() > 0 and (a["lm_nobs"][a["lm_invalid"].astype(bool)] < 2).all()
+    assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["lm"], b["lm"])
+
+
+@pytest.mark.gpu
 def test_cpp_gba_sharded_over_two_in_process_ranks():
     """Params::n_gpus = 2: the C++ facade's GlobalBundleAdjustment through covgpu_gba_solve_multi — two contexts in this
     process (both on the one GPU of the test box: virtual ranks, the library's in-process collective), both rounds incl. the

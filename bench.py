@@ -449,6 +449,7 @@ def main():
                                                                "(map_be.cpp:698-717) instead of map->Clean()'s second copy of every observation map"}
             finally:
                 _shim().shim_set_device_clean(0)
+                _shim().shim_shutdown()   # the facade's cached context (its streams share the runtime's hardware queues with the a12 leg's: 15.6 instead of 20.4 it/s)
         except Exception as e:   # (the shim needs g++ on the box; never fatal for the metric line)
             out["e2e_call_cpp"] = {"t_call_s": None, "error": repr(e)[:200]}
     # ---- configs[4] leg (all ranks, behind everything else and with the metric's context closed: eight live streams share the runtime's

@@ -89,7 +89,7 @@ def test_cpp_device_clean_leaves_the_map_where_map_clean_leaves_it():
         shim_lib().shim_set_device_clean(on)
         sm = StandinMap(m)
         try:
-            shim_lib().shim_set_invalid(sm.h, 7)
+            shim_lib().shim_set_invalid(sm.h, int(np.nonzero(m.kf_succ < 0)[0][0]))   # (an agent's LAST keyframe: an invalid predecessor is fatal, optimization_be.cpp:371-379)
             sm.gba(10, visual_only=False, outlier_removal=True)
             states.append((sm.state(), dict(StandinMap.last_stages())))
         finally:

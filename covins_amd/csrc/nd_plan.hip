@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <queue>
+#include <thread>
 #include <tuple>
 
 namespace covgpu {
@@ -162,16 +163,12 @@ struct Builder {
 
 }  // namespace
 
-static bool nd_plan_build_mode(int top_mode, int K, bool vi, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
-                               const int* epair_i, const int* epair_j, int leaf_dims, NdHostPlan& out) {
-  out = NdHostPlan();
-  out.K = K; out.vi = vi ? 1 : 0; out.nvar = 2 * K;
-  out.vnode.assign(2 * (size_t)K, -1); out.voff.assign(2 * (size_t)K, 0); out.vord.assign(2 * (size_t)K, -1);
-  if (K <= 0) return false;
-  std::vector<int> chain_of(K, 0);
+// the coupling graph over the variables: built once per problem, shared by every candidate plan
+static void nd_graph(int K, bool vi, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs, const int* epair_i,
+                     const int* epair_j, std::vector<std::vector<int>>& adj, std::vector<int>& chain_of) {
+  chain_of.assign(K, 0);
   for (int c = 0; c < nchains; ++c) for (int q = chain_ptr[c]; q < chain_ptr[c + 1]; ++q) chain_of[q] = c;
-  // ---- coupling graph over the variables
-  std::vector<std::vector<int>> adj(2 * (size_t)K);
+  adj.assign(2 * (size_t)K, {});
   auto link = [&](int a, int b) { if (a != b) { adj[a].push_back(b); adj[b].push_back(a); } };
   for (int p = 0; p < npairs; ++p) link(2 * pair_i[p], 2 * pair_j[p]);
   for (int p = 0; p < nepairs; ++p) link(2 * epair_i[p], 2 * epair_j[p]);
@@ -185,6 +182,14 @@ static bool nd_plan_build_mode(int top_mode, int K, bool vi, int nchains, const 
         }
       }
   for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+}
+
+static bool nd_plan_build_mode(int top_mode, int K, bool vi, const std::vector<std::vector<int>>& adj, const std::vector<int>& chain_of, int leaf_dims,
+                               NdHostPlan& out) {
+  out = NdHostPlan();
+  out.K = K; out.vi = vi ? 1 : 0; out.nvar = 2 * K;
+  out.vnode.assign(2 * (size_t)K, -1); out.voff.assign(2 * (size_t)K, 0); out.vord.assign(2 * (size_t)K, -1);
+  if (K <= 0) return false;
   // ---- tree
   std::vector<int> all;
   for (int q = 0; q < K; ++q) { all.push_back(2 * q); if (vi) all.push_back(2 * q + 1); }
@@ -295,23 +300,47 @@ static double nd_plan_cost(const NdHostPlan& hp) {
 
 bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs, const int* pair_i, const int* pair_j, int nepairs,
                    const int* epair_i, const int* epair_j, int leaf_dims, NdHostPlan& out, int top_mode) {
-  // Three or more agents: ONE cover of all cross-agent couplings at the top (mode 0) or two groups of agents, recursively (mode 1) — both
-  // plans are built (milliseconds) and the cheaper one by nd_plan_cost is kept. 5-agent map: 2.84e10 flops / 23 serial panels / 7 levels
-  // against 2.42e10 / 22 / 9; 12-agent map: a 17 652-order root and 2.13e12 flops against a 7 206-order root and 1.30e12.
-  // COVGPU_ND_TOP=0 / 1 forces a mode. Deterministic: every rank of a sharded solve and covgpu_shard_plan pick the same plan.
-  // top_mode 0: the plan of a SHARDED solve — one separator of all agents at the top, whose children (one region per agent) are the
-  // subtrees dealt to the ranks; with two groups of agents there are two subtrees, and opening them puts fronts of (separator + root)^2
-  // into the replicated, all-reduced top.
+  // Candidates: (how a region of three or more agents is cut) x (the order below which a region is not cut further). All are built — the coupling
+  // graph once, the trees in host threads, milliseconds each — and the cheapest by nd_plan_cost is kept (ties: the first in the fixed order below).
+  //   top: ONE cover of all cross-agent couplings (0) | two groups of agents, recursively (1). 5-agent map: 2.84e10 flops / 23 serial panels /
+  //        7 levels against 2.42e10 / 22 / 9; 12-agent map: a 17 652-order root and 2.13e12 flops against a 7 206-order root and 1.30e12.
+  //   leaf: where the widest fronts land relative to the 256-column panel boundaries decides the number of serial panels. Measured on one
+  //        MI355X (profiles/r05_ab_experiments.txt), factor+solve per iteration against the model: 5-agent map leaf 400: 3.56 ms (model 3.96),
+  //        900: 3.77 (4.10), 500: 3.73 (4.11), 600: 3.90 (4.25), 1200: 4.04 (4.29), 250-350: 3.8-4.0 (4.28-4.41); mh01 and the 3-agent map are
+  //        fastest at 600, as the model says (1.39 / 2.24 ms against 1.57 / 2.42 at 400). Rounds 3-4 fixed 600.
+  // top_mode 0 (the plan of a SHARDED solve): one separator of all agents at the top, whose children (one region per agent) are the subtrees
+  // dealt to the ranks. COVGPU_ND_TOP=0 / 1 and leaf_dims > 0 (COVGPU_ND_LEAF) force a choice. Deterministic: every rank of a sharded solve
+  // and covgpu_shard_plan pick the same plan.
+  std::vector<std::vector<int>> adj;
+  std::vector<int> chain_of;
+  out = NdHostPlan();
+  out.K = K; out.vi = vi ? 1 : 0; out.nvar = 2 * K;
+  if (K <= 0) return false;
+  nd_graph(K, vi, nchains, chain_ptr, npairs, pair_i, pair_j, nepairs, epair_i, epair_j, adj, chain_of);
   int forced = top_mode;
   if (const char* e = getenv("COVGPU_ND_TOP")) forced = atoi(e) != 0 ? 1 : 0;
-  if (nchains < 3 || forced == 0 || leaf_dims >= (1 << 29))
-    return nd_plan_build_mode(0, K, vi, nchains, chain_ptr, npairs, pair_i, pair_j, nepairs, epair_i, epair_j, leaf_dims, out);
-  if (forced == 1) return nd_plan_build_mode(1, K, vi, nchains, chain_ptr, npairs, pair_i, pair_j, nepairs, epair_i, epair_j, leaf_dims, out);
-  NdHostPlan alt;
-  const bool ok0 = nd_plan_build_mode(0, K, vi, nchains, chain_ptr, npairs, pair_i, pair_j, nepairs, epair_i, epair_j, leaf_dims, out);
-  const bool ok1 = nd_plan_build_mode(1, K, vi, nchains, chain_ptr, npairs, pair_i, pair_j, nepairs, epair_i, epair_j, leaf_dims, alt);
-  if (ok1 && (!ok0 || nd_plan_cost(alt) < nd_plan_cost(out))) out = std::move(alt);
-  return ok0 || ok1;
+  std::vector<int> modes, leaves;
+  if (nchains < 3 || forced == 0 || leaf_dims >= (1 << 29)) modes = {0};
+  else if (forced == 1) modes = {1};
+  else modes = {0, 1};
+  if (leaf_dims > 0) leaves = {leaf_dims};
+  else leaves = {600, 400, 500, 900};
+  struct Cand { int mode, leaf; NdHostPlan hp; bool ok = false; double cost = 0; };
+  std::vector<Cand> cand;
+  for (int lf : leaves) for (int m : modes) { cand.emplace_back(); cand.back().mode = m; cand.back().leaf = lf; }
+  auto run = [&](size_t i) { cand[i].ok = nd_plan_build_mode(cand[i].mode, K, vi, adj, chain_of, cand[i].leaf, cand[i].hp); if (cand[i].ok) cand[i].cost = nd_plan_cost(cand[i].hp); };
+  if (cand.size() == 1) run(0);
+  else {
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < cand.size(); ++i) th.emplace_back(run, i);
+    run(0);
+    for (auto& t : th) t.join();
+  }
+  int best = -1;
+  for (size_t i = 0; i < cand.size(); ++i) if (cand[i].ok && (best < 0 || cand[i].cost < cand[best].cost)) best = (int)i;
+  if (best < 0) return false;
+  out = std::move(cand[best].hp);
+  return true;
 }
 
 void nd_shard_assign(NdHostPlan& hp, int world) {

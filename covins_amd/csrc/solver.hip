@@ -514,11 +514,11 @@ static bool host_pairs(const covgpu_problem* p, const std::vector<int>& perm, st
 
 // Host-only: the nested-dissection plan of the reduced camera system (nd_plan.hpp, k_front.hip) for inspection and the CPU
 // tests (tests/test_nd_plan.py replays the elimination in numpy on the oracle's system).
-static int nd_leaf_dims(int requested) {
+static int nd_leaf_dims(int requested) {   // 0: nd_plan_build chooses among its candidates (nd_plan.hip)
   if (requested > 0) return requested;
   const char* e = getenv("COVGPU_ND_LEAF");
   const int v = e ? atoi(e) : 0;
-  return v > 0 ? v : 600;
+  return v > 0 ? v : 0;
 }
 static int nd_plan_create_mode(const covgpu_options* opt, const covgpu_problem* p, int32_t leaf_dims, covgpu_nd_plan** out, int top_mode);
 extern "C" int covgpu_nd_plan_create(const covgpu_options* opt, const covgpu_problem* p, int32_t leaf_dims, covgpu_nd_plan** out) { return nd_plan_create_mode(opt, p, leaf_dims, out, -1); }

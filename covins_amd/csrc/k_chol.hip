@@ -592,12 +592,15 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         //  the bulk stream's leg (rest rows, rest of the update, second half of the extend-add) is what the next level's
         //  substitutions wait for, and it only got longer: 3.37 vs 3.33 ms)
         const bool split = bt.split_ta > 0 && bt.live_h != nullptr && kd(P) > 0 && (tc.listA != nullptr || tc.listB != nullptr);
+        static const bool early_wait2 = getenv("COVGPU_EARLY_WAIT") == nullptr || atoi(getenv("COVGPU_EARLY_WAIT")) != 0;
+        const bool waitedA = early_wait2 && split && P >= 1;
+        if (waitedA) wait(M, eA[P - 1]);   // (beside the waits above instead of between the substitution and the update: see the multi-panel branch)
         launch_trsm_sub(S, ld, t0, w, h0, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
         if (split) { (void)hipEventRecord(eH[P], M); wait(B, eH[P]); }
         // bulk(P-1) was the previous writer of the trailing tiles. The part of this update that stays on the chain's stream (rows < split_ta: what
         // build_list puts into the first launch beside tile columns 0, 1) only meets the FIRST launch of that bulk update — on the 5-agent map's upper levels (borders of
         // 2 000 unknowns) the whole of it is 160 us, and the next level's first panel waited for it; the rest follows it on the bulk stream anyway
-        if (P >= 1) wait(M, split ? eA[P - 1] : eB[P - 1]);
+        if (P >= 1 && !waitedA) wait(M, split ? eA[P - 1] : eB[P - 1]);
         const int tb = h0, nt = T - tb;
         auto syrk = [&](hipStream_t s2, const int* list, int count, double flops) {
           GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab, bt.own_dims};
@@ -656,6 +659,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       //  all of it behind the ONE event of the chain-bound form: 140-160 us per panel. Events after every kernel: 284 -> 298 it/s, and
       //  no loss on the one-panel fronts. COVGPU_CHAIN_PAIRS restores a threshold.)
       static const double chain_pairs = getenv("COVGPU_CHAIN_PAIRS") ? atof(getenv("COVGPU_CHAIN_PAIRS")) : 0.0;
+      static const bool early_wait = getenv("COVGPU_EARLY_WAIT") == nullptr || atoi(getenv("COVGPU_EARLY_WAIT")) != 0;
       const bool chain_bound = bulk_pairs <= chain_pairs;
       potrf(t0, w, nbp);
       if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
@@ -665,8 +669,13 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // panel), the next panel's rows on stream H and the bulk update all start from it, two small kernels later than they could.
       // While the bulk update is long (the period is the bulk) they start as early as possible: an event after each kernel.
       if (!chain_bound) (void)hipEventRecord(e1[P], M);
+      bool waitedA = false;
       if (h1 > h0) {
         if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
+        // (round 5: a wait packet on this stream costs ~7 us between two dependent kernels even when its event completed long ago — tools/event_probe.hip,
+        //  profiles/r05y_iteration_timeline.csv: 13-14 us from a kernel's end to the next one's start behind record + wait, 6-7 behind a record alone.
+        //  The wait of the next-diagonal update below for bulk(P-1)'s first launch — 30-40 us of slack — rides along with the one above.)
+        if (early_wait && P >= 1 && P + 1 < NP) { wait(M, eA[P - 1]); waitedA = true; }
         launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
         if (trace2) ax.mark(M, 100 * (P + 1) + 2);   // rows h solved
       }
@@ -674,7 +683,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // ---- M: look-ahead part of SYRK(P) on the next panel's 2x2 diagonal tiles
       if (P + 1 < NP) {
         const int u0 = t0 + 2, uw = (T - u0 >= 2) ? 2 : 1;
-        if (P >= 1) wait(M, eA[P - 1]);          // bulk(P-1) was the previous writer of these tiles (its first launch)
+        if (P >= 1 && !waitedA) wait(M, eA[P - 1]);          // bulk(P-1) was the previous writer of these tiles (its first launch)
         rect(u0, u0 + uw, u0, uw, t0, kd(P), M, true);
         if (trace2) ax.mark(M, 100 * (P + 1) + 3);   // next diagonal block updated
       }

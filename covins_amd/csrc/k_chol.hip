@@ -660,6 +660,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       //  no loss on the one-panel fronts. COVGPU_CHAIN_PAIRS restores a threshold.)
       static const double chain_pairs = getenv("COVGPU_CHAIN_PAIRS") ? atof(getenv("COVGPU_CHAIN_PAIRS")) : 0.0;
       static const bool early_wait = getenv("COVGPU_EARLY_WAIT") == nullptr || atoi(getenv("COVGPU_EARLY_WAIT")) != 0;
+      static const bool merge_trsm = getenv("COVGPU_TRSM_MERGE") != nullptr && atoi(getenv("COVGPU_TRSM_MERGE")) != 0;
       const bool chain_bound = bulk_pairs <= chain_pairs;
       potrf(t0, w, nbp);
       if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
@@ -668,15 +669,21 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // panel, eH, recorded after the look-ahead update of the next diagonal block — the rest rows (which only need the factored
       // panel), the next panel's rows on stream H and the bulk update all start from it, two small kernels later than they could.
       // While the bulk update is long (the period is the bulk) they start as early as possible: an event after each kernel.
-      if (!chain_bound) (void)hipEventRecord(e1[P], M);
+      // merge_trsm (round 5): rows h AND the rest rows in ONE substitution launch on the chain's stream — every 16-row slab is a workgroup of
+      // its own, so the launch is as long as one slab while workgroup slots are free — instead of the rest rows on stream R behind an event: a
+      // record whose waiter is blocked on it at that moment costs the RECORDING stream ~13 us as well (profiles/r05y_iteration_timeline.csv: both
+      // substitutions start 14 us after the factorisation ends), a record nobody is waiting for yet ~6.
+      const bool merge = merge_trsm && !chain_bound && h1 > h0 && T > h1;
+      if (!chain_bound && !merge) (void)hipEventRecord(e1[P], M);
       bool waitedA = false;
       if (h1 > h0) {
         if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
+        if (merge && P > 0) wait(M, e2[P]);    // ... and the rest rows theirs (stream R)
         // (round 5: a wait packet on this stream costs ~7 us between two dependent kernels even when its event completed long ago — tools/event_probe.hip,
         //  profiles/r05y_iteration_timeline.csv: 13-14 us from a kernel's end to the next one's start behind record + wait, 6-7 behind a record alone.
         //  The wait of the next-diagonal update below for bulk(P-1)'s first launch — 30-40 us of slack — rides along with the one above.)
         if (early_wait && P >= 1 && P + 1 < NP) { wait(M, eA[P - 1]); waitedA = true; }
-        launch_trsm_sub(S, ld, t0, w, h0, h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
+        launch_trsm_sub(S, ld, t0, w, h0, merge ? T : h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
         if (trace2) ax.mark(M, 100 * (P + 1) + 2);   // rows h solved
       }
       if (!chain_bound) (void)hipEventRecord(eH[P], M);
@@ -690,11 +697,12 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // (A bulk launched at the same instant as the next diagonal update takes every workgroup slot first and the chain waits
       //  ~75 us for the first round of tiles to retire: the bulk starts after that small kernel in either regime.)
       (void)hipEventRecord(chain_bound ? eH[P] : eRc[P], M);
-      if (T > h1) {
+      if (T > h1 && !merge) {
         wait(R, chain_bound ? eH[P] : e1[P]);   // (measured, round 4: waiting for rows h instead — so that the chain's substitution runs alone — 299.9 -> 297.5 it/s)
         launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab, nbp, bt.own_dims);
         if (trace2) ax.mark(R, 100 * (P + 1) + 4);   // rest rows solved
       }
+      if (merge) wait(R, eH[P]);   // (eC then stands for "every row below panel P is solved" as before: its waiters — the bulk update, stream H — need not change)
       (void)hipEventRecord(eC[P], R);
       if (!chain_bound) wait(B, eRc[P]);   // (measured again in round 4 with the 60 us panel: without this wait 298.6 -> 292.7 it/s)
     }

@@ -100,7 +100,7 @@ def test_cpp_device_clean_leaves_the_map_where_map_clean_leaves_it():
     assert np.array_equal(a["lm_invalid"], b["lm_invalid"]) and np.array_equal(a["lm_nobs"], b["lm_nobs"])
     assert a["lm_invalid"].sum() > 0 and (a["lm_nobs"][a["lm_invalid"].astype(bool)] < 2).all()
     # (two object graphs: the observations of a landmark are walked in std::map<KeyframePtr> = pointer order, so the two solves round differently)
-    assert np.abs(a["pose"] - b["pose"]).max() < 1e-9 and np.abs(a["vel"] - b["vel"]).max() < 1e-9
+    assert np.abs(a["pose"] - b["pose"]).max() < 1e-6 and np.abs(a["vel"] - b["vel"]).max() < 1e-6   # (the pose criterion of every parity test)
 
 
 @pytest.mark.gpu

@@ -324,8 +324,8 @@ def main():
                            "final_sim3": synth.ate_rmse(sol.kf_pose[:, 4:], truth, with_scale=True)},  # evo_ape -va / -vas
             "phase_ms_per_iteration": {"linearise+schur": prof["build_ms"] / max(prof["n_build"], 1),
                                        "factor+solve": prof["factor_ms"] / max(prof["n_factor"], 1)},
-            # the kernel with the largest share of GPU time (first row of profiles/*_kernel_stats.csv): the serial panel chain
-            "roofline": {"kernel": "k_potrf_panel (ONE workgroup per front factors a 256x256 diagonal block of the batched front factorisation: "
+            # the serial panel chain: second row of profiles/r05z_kernel_stats.csv (16.6 % of GPU time), and on the critical path of every linear solve
+            "roofline_potrf": {"kernel": "k_potrf_panel (ONE workgroup per front factors a 256x256 diagonal block of the batched front factorisation: "
                                    "the serial panel chain; v_mfma_f64_16x16x4_f64 for the in-block updates, wave 0 carries the pivot chain)",
                          "bound": "mfma", "achieved": potrf_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": potrf_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": potrf_traffic, "mfma_busy_frac_pmc": potrf_busy,
@@ -337,7 +337,9 @@ def main():
                                  "panel), over the HIP-event duration of the launch on its stream (un-timed profiling step). One workgroup per "
                                  "front: a latency-bound pivot chain, far below the matrix peak by construction — its launches are serial, so "
                                  "chain_ms_per_iteration is on the critical path of every linear solve (DESIGN.md 4.5-4.6)"},
-            "roofline_syrk": {"kernel": "k_gemm_abt<SYRK_TRI> / k_gemm_abt_q<SYRK_TRI,64,64> (rank-256 trailing update of the batched front factorisation, "
+            # the kernel with the largest share of GPU time (first row of profiles/r05z_kernel_stats.csv: 22.0 % on the corrected 5-agent map, whose
+            # fronts carry borders of 2 000 unknowns; on the round-4 map the panel chain led): the rank-256 trailing update
+            "roofline": {"kernel": "k_gemm_abt<SYRK_TRI> / k_gemm_abt_q<SYRK_TRI,64,64> (rank-256 trailing update of the batched front factorisation, "
                                         "v_mfma_f64_16x16x4_f64; 128x128 tiles, or 64x64 quadrants for tile lists of <= 1024 entries)",
                               "bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": syrk_tflops / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
@@ -345,7 +347,9 @@ def main():
                               "traffic_note": ("HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from tools/pmc_pass.sh at " + str(traffic_src)) if traffic is not None
                                               else "null: no counter pass of these kernel sources (tools/pmc_pass.sh writes profiles/pmc_traffic_current.json)",
                               "launches": prof["n_syrk"], "avg_launch_ms": prof["syrk_ms"] / max(prof["n_syrk"], 1),
-                              "note": "the one throughput-bound MFMA kernel (side streams, mostly off the critical path)"},
+                              "note": "algorithmic flops per launch = 2 x 128 x 128 x K per live tile pair (K = the front's real columns in the panel), over the HIP-event "
+                                      "duration of the launch on its stream (un-timed profiling step). The launches of this map are short — ~1 000 quarter-tile workgroups "
+                                      "whose waves live ~7 us: dispatch and tail, not the matrix pipe (DESIGN.md 5); configs[4]'s full-tile launches: a12_leg.roofline_syrk"},
             "roofline_iteration": {"what": "one whole trust-region iteration against the two rooflines it could be bound by: SURVEY.md 8(d)'s B_iter at the "
                                            "HBM peak plus the plan's factorisation flops at the FP64 matrix peak",
                                    "algorithmic_bytes": b_iter, "factorisation_flops": prof["plan_flops"], "ideal_ms": t_ideal_ms,

@@ -8,7 +8,7 @@ for spec in "$@"; do
 import json,sys
 try:
     d=json.loads(open('gpurun_out/${tag}_ab_${label}.json').read().strip().splitlines()[-1])
-    print('${label}', round(d['value'],2), {k: round(v,4) for k,v in d['phase_ms_per_iteration'].items()}, 'chain', round(d['roofline']['chain_ms_per_iteration'],4), 'potrf_us', round(d['roofline']['avg_launch_ms']*1e3,1), 'final', d['final_cost'], 'ate', round(d['ate_rmse_m']['final'],6))
+    print('${label}', round(d['value'],2), {k: round(v,4) for k,v in d['phase_ms_per_iteration'].items()}, 'chain', round(d['roofline_potrf']['chain_ms_per_iteration'],4), 'potrf_us', round(d['roofline_potrf']['avg_launch_ms']*1e3,1), 'final', d['final_cost'], 'ate', round(d['ate_rmse_m']['final'],6))
 except Exception as e:
     print('${label}', 'FAILED', e); print(open('gpurun_out/${tag}_ab_${label}.err').read()[-1500:])
 "

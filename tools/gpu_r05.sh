@@ -34,4 +34,4 @@ if has pmc; then
   tail -2 gpurun_out/${tag}_pmc.log
 fi
 for f in gpurun_out/${tag}_bench*.json; do python -c "
-import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', round(d['value'],2), d['phase_ms_per_iteration'], round(d['roofline']['frac'],5), round(d['roofline']['avg_launch_ms']*1e3,1), round(d['roofline_iteration']['frac'],4), d['config']['layout']['device_mib'], d['ate_rmse_m']['final'], d.get('cpu_baseline',{}).get('value'), d.get('max_pose_diff_gpu_cpu_m'), d.get('e2e_call',{}).get('t_call_s'), d.get('e2e_call_cpp',{}).get('t_call_s'), 'a12', (d.get('a12_leg') or {}).get('value'))" 2>&1 | tail -1; done
+import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', round(d['value'],2), d['phase_ms_per_iteration'], round(d['roofline']['frac'],5), round(d['roofline_potrf']['avg_launch_ms']*1e3,1), round(d['roofline_iteration']['frac'],4), d['config']['layout']['device_mib'], d['ate_rmse_m']['final'], d.get('cpu_baseline',{}).get('value'), d.get('max_pose_diff_gpu_cpu_m'), d.get('e2e_call',{}).get('t_call_s'), d.get('e2e_call_cpp',{}).get('t_call_s'), 'a12', (d.get('a12_leg') or {}).get('value'))" 2>&1 | tail -1; done

@@ -53,6 +53,9 @@ def cpu_baseline(prob, strategy: int, iterations: int, truth_xyz, reps: int = 3)
         t0 = time.perf_counter()
         q, res = covo.gba_solve(prob, o)
         times.append(time.perf_counter() - t0); solver_s.append(covo_mf.stats["seconds"])
+        if len(times) == 2 and sum(times) > 20.0:   # a bounded sample: ~30 s of CPU work on the corrected 5-agent map (14.5 s per solve)
+            break
+    reps = len(times)
     covo.use_sparse_solver(min_n=3000)   # back to SuperLU (parity legs)
     dt = float(np.median(times))
     return q, {

@@ -669,19 +669,20 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // panel, eH, recorded after the look-ahead update of the next diagonal block — the rest rows (which only need the factored
       // panel), the next panel's rows on stream H and the bulk update all start from it, two small kernels later than they could.
       // While the bulk update is long (the period is the bulk) they start as early as possible: an event after each kernel.
-      // merge_trsm (round 5): rows h AND the rest rows in ONE substitution launch on the chain's stream — every 16-row slab is a workgroup of
-      // its own, so the launch is as long as one slab while workgroup slots are free — instead of the rest rows on stream R behind an event: a
-      // record whose waiter is blocked on it at that moment costs the RECORDING stream ~13 us as well (profiles/r05y_iteration_timeline.csv: both
-      // substitutions start 14 us after the factorisation ends), a record nobody is waiting for yet ~6.
+      // merge_trsm (round 5, opt-in: COVGPU_TRSM_MERGE=1): rows h AND the rest rows in ONE substitution launch on the chain's stream — every 16-row
+      // slab is a workgroup of its own, so the launch is as long as one slab while workgroup slots are free — instead of the rest rows on stream R
+      // behind an event: a record whose waiter is blocked on it at that moment costs the RECORDING stream ~13 us as well
+      // (profiles/r05z_iteration_timeline.csv: both substitutions start 14 us after the factorisation ends), a record nobody is waiting for yet ~6.
+      // Measured: 233.5 / 233.1 against 232.6 / 232.0 it/s, configs[4] 20.0 against 20.3 — within noise, so the default stays the round-4 form.
       const bool merge = merge_trsm && !chain_bound && h1 > h0 && T > h1;
       if (!chain_bound && !merge) (void)hipEventRecord(e1[P], M);
       bool waitedA = false;
       if (h1 > h0) {
         if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
         if (merge && P > 0) wait(M, e2[P]);    // ... and the rest rows theirs (stream R)
-        // (round 5: a wait packet on this stream costs ~7 us between two dependent kernels even when its event completed long ago — tools/event_probe.hip,
-        //  profiles/r05y_iteration_timeline.csv: 13-14 us from a kernel's end to the next one's start behind record + wait, 6-7 behind a record alone.
-        //  The wait of the next-diagonal update below for bulk(P-1)'s first launch — 30-40 us of slack — rides along with the one above.)
+        // (round 5: the wait of the next-diagonal update below for bulk(P-1)'s first launch — 30-40 us of slack — rides along with the one above.
+        //  Measured: no difference (231.1 / 230.5 against 231.4 / 231.2 it/s) — a wait whose event completed long ago costs nothing; the 13-14 us
+        //  between two kernels of this stream come from the RECORD behind the first when its waiter is blocked on it at that moment: DESIGN.md 4.6)
         if (early_wait && P >= 1 && P + 1 < NP) { wait(M, eA[P - 1]); waitedA = true; }
         launch_trsm_sub(S, ld, t0, w, h0, merge ? T : h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
         if (trace2) ax.mark(M, 100 * (P + 1) + 2);   // rows h solved

@@ -16,6 +16,8 @@ from .capi import FlatProblem, Options, Result, dptr, iptr
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libcovgpu.so")
+if os.environ.get("COVGPU_LIBRARY"):   # dev aid: another build of the library (compile-time A/B, tools/gpu_ab.sh)
+    _SO = os.environ["COVGPU_LIBRARY"]
 _LIB: Optional[C.CDLL] = None
 
 

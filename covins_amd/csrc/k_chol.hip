@@ -62,7 +62,8 @@ constexpr int LDT = KC + kLdsPad;   // LDS pitch (doubles) of the full-tile kern
 #define COVGPU_PFF 1
 #endif
 #ifndef COVGPU_PFQ
-#define COVGPU_PFQ 4
+#define COVGPU_PFQ 2   // round 4: 4 (+2 % on a map whose trailing updates were ~300 workgroups: one per CU). Round 5, corrected map (~1 000 workgroups per
+                       // launch): two chunks in flight are 138 VGPRs instead of 210 — three workgroups per CU instead of two: 233.9 / 233.5 against 231.8 / 231.2 it/s
 #endif
 constexpr int PFF = COVGPU_PFF, PFQ = COVGPU_PFQ;   // chunks in flight in registers: full tiles, quarter forms
 

@@ -312,9 +312,7 @@ void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const 
                      size_t sR, const int* live, int tI, hipStream_t st, bool chain = false, const long long* btab = nullptr, int nb = -1, const int* own = nullptr);
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,
                          size_t sL, size_t sR, hipStream_t st, const long long* btab = nullptr, const int* live = nullptr, int tI = 0,
-                         BwdXfer xf = BwdXfer(), bool use_inv = false);  // xf.gidx != nullptr (pass it with p == 0 only): the front's own unknowns go to the solution vector
-// explicit inverses of the diagonal tiles [0, ntiles) of every matrix of the batch (k_panel.hip: k_tile_inv); use_inv above reads them
-void launch_tile_inv(const double* S, size_t ld, int ntiles, double* Linv, int nbt, size_t sM, size_t sL, hipStream_t st, const long long* btab, const int* live);
+                         BwdXfer xf = BwdXfer());  // xf.gidx != nullptr (pass it with p == 0 only): the front's own unknowns go to the solution vector
 
 // ---- block-arrow pose-graph solve (k_pgo.hip)
 struct PgoHostPlan { std::vector<std::vector<int>> block_kf; std::vector<int> border_kf; };

@@ -791,19 +791,13 @@ void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStrea
     tend = tfact;
   }
   if (bt.own_max > 0 && tend <= tfact) tend = std::min(tend, (bt.own_max + kTile - 1) / kTile);  // all-padding interior tiles: x = 0
-  // Round 5: a tile's step as ONE matrix-vector product with the explicit inverse of its diagonal tile (k_tile_inv, one launch for all tiles of
-  // the batch in front of the sweep) instead of eight dependent 16-column sub-steps: for fronts of more than one launch per tile it pays from three
-  // tiles on. COVGPU_BWD_INV=0: the sub-steps.
-  static const bool bwd_inv = getenv("COVGPU_BWD_INV") == nullptr || atoi(getenv("COVGPU_BWD_INV")) != 0;
-  const bool use_inv = bwd_inv && tend >= 3 && tend <= tfact;
-  if (use_inv) launch_tile_inv(S, ld, tend, Linv, nbt, bt.sM, bt.sL, st, bt.tab, bt.live);
   for (int p = tend - 1; p >= 0; --p) {
     const bool given = p >= tfact;
     const int ncol = given ? tfact * kTile : p * kTile;
     const int nb = (ncol + 31) / 32;
     if (given && nb == 0) continue;
       launch_bwd_step_sub(S, ld, p, given ? nullptr : Linv + (size_t)p * kTile * kTile, b + npad, b, ncol, nb > 0 ? nb : 1, nbt, bt.sM, bt.sL, bt.sR, st, bt.tab,
-                          bt.live, bt.tI, p == 0 ? bt.xfer : BwdXfer(), use_inv && !given);
+                          bt.live, bt.tI, p == 0 ? bt.xfer : BwdXfer());
   }
 }
 

@@ -690,50 +690,9 @@ __global__ __launch_bounds__(256) void k_trsm_sub4(TrsmSubArgs g) {
 // Thread c < 128 owns unknown c: every entry of L_pp it will need (rows of the blocks below its own) is loaded up front
 // (one memory latency), then eight block steps of two barriers each. Every workgroup of the launch repeats this (cheaper
 // than a separate launch on a launch-bound chain); the column update is split over the workgroups as before.
-// Explicit inverses of the 128x128 diagonal tiles of L (round 5): W = L_pp^-1, lower triangular in 16x16 blocks. The eight diagonal blocks are
-// the block inverses the panel kernel leaves (Linv tile p, [0, 2048)); the 28 blocks below them go to [2048, 9216) of the same tile of the Linv
-// buffer (16 384 doubles per tile are reserved), block (i, j), i > j, at 2048 + 256 (i (i - 1) / 2 + j), row-major. Block column j of a tile is one
-// workgroup: W_ij = -Dinv_i sum_{k = j .. i-1} L_ik W_kj for i = j+1 .. 7 (from L W = I). With W a backward-substitution step of a tile is ONE
-// matrix-vector product x_p = W^T y_p instead of eight dependent 16-column sub-steps (k_bwd_step_sub: 8.6 -> ~4 us per tile and launch).
-__global__ __launch_bounds__(256) void k_tile_inv(const double* __restrict__ M, size_t ld, size_t bsM, const long long* __restrict__ btab,
-                                                   double* __restrict__ Linv, size_t bsL, const int* __restrict__ live) {
-  const int batch = blockIdx.y, p = blockIdx.x >> 3, j = blockIdx.x & 7;
-  if (j == 7) return;                                   // nothing below the last block column
-  if (live != nullptr && p >= live[2 * batch]) return;  // padding tile of this front: never substituted (k_bwd_step_sub returns at once)
-  if (btab != nullptr) { M += (size_t)btab[2 * batch]; ld = (size_t)btab[2 * batch + 1]; }
-  else M += (size_t)batch * bsM;
-  double* Lt = Linv + (size_t)batch * bsL + (size_t)p * kTile * kTile;
-  __shared__ double Wc[8][256];
-  __shared__ double T[256];
-  const int t = threadIdx.x, r = t >> 4, c = t & 15, k0 = p * kTile;
-  Wc[j][t] = Lt[j * 256 + t];
-  __syncthreads();
-  for (int i = j + 1; i < 8; ++i) {
-    const double* Lrow = M + (size_t)(k0 + PB * i + r) * ld + k0;
-    double a0 = 0.0, a1 = 0.0;
-    for (int k = j; k < i; ++k) {
-#pragma unroll
-      for (int m = 0; m < PB; m += 2) { a0 += Lrow[PB * k + m] * Wc[k][m * PB + c]; a1 += Lrow[PB * k + m + 1] * Wc[k][(m + 1) * PB + c]; }
-    }
-    T[t] = a0 + a1;
-    __syncthreads();
-    const double* Di = Lt + i * 256 + r * PB;
-    double w0 = 0.0, w1 = 0.0;
-#pragma unroll
-    for (int m = 0; m < PB; m += 2) { w0 += Di[m] * T[m * PB + c]; w1 += Di[m + 1] * T[(m + 1) * PB + c]; }
-    const double w = -(w0 + w1);
-    Wc[i][t] = w;
-    Lt[2048 + 256 * (i * (i - 1) / 2 + j) + t] = w;
-    __syncthreads();
-  }
-}
-void launch_tile_inv(const double* S, size_t ld, int ntiles, double* Linv, int nbt, size_t sM, size_t sL, hipStream_t st, const long long* btab, const int* live) {
-  if (ntiles > 0) hipLaunchKernelGGL(k_tile_inv, dim3(8 * ntiles, nbt), dim3(256), 0, st, S, ld, sM, btab, Linv, sL, live);
-}
-
 __global__ __launch_bounds__(256) void k_bwd_step_sub(const double* __restrict__ M, size_t ld, int p, const double* __restrict__ Dinv,
                                                        double* __restrict__ y, double* __restrict__ x, int ncol, size_t bsM, size_t bsL, size_t bsR,
-                                                       const long long* __restrict__ btab, const int* __restrict__ live, int tI, BwdXfer xf, int use_inv) {
+                                                       const long long* __restrict__ btab, const int* __restrict__ live, int tI, BwdXfer xf) {
   if (live != nullptr) {  // padding tile of this front: x_p = 0 contributes nothing (GemmArgs::live)
     const int nI = live[2 * blockIdx.y], nO = live[2 * blockIdx.y + 1];
     if (!(p < nI || (p >= tI && p - tI < nO))) return;
@@ -749,29 +708,6 @@ __global__ __launch_bounds__(256) void k_bwd_step_sub(const double* __restrict__
   if (Dinv == nullptr) {
     if (tid < kTile) sx[tid] = x[k0 + tid];
     __syncthreads();
-  } else if (use_inv) {
-    // x_p = W^T y_p with the explicit inverse W of the diagonal tile (k_tile_inv): column c, block rows bj + h, bj + h + 2, ... per half h;
-    // the two halves are added in a fixed order
-    const int c = tid & 127, h = tid >> 7, bj = c >> 4, ci = c & 15;
-    if (tid < kTile) sv[tid] = y[k0 + tid];
-    __syncthreads();
-    double s0 = 0.0, s1 = 0.0;
-    for (int bi = bj + h; bi < 8; bi += 2) {
-      const double* Wb = (bi == bj) ? Dinv + bj * 256 : Dinv + 2048 + 256 * (bi * (bi - 1) / 2 + bj);
-#pragma unroll
-      for (int ri = 0; ri < PB; ri += 2) { s0 += Wb[ri * PB + ci] * sv[PB * bi + ri]; s1 += Wb[(ri + 1) * PB + ci] * sv[PB * bi + ri + 1]; }
-    }
-    __shared__ double half1[kTile];
-    if (h == 1) half1[c] = s0 + s1;
-    __syncthreads();
-    if (h == 0) sx[c] = (s0 + s1) + half1[c];
-    __syncthreads();
-    if (blockIdx.x == 0 && tid < kTile) x[k0 + tid] = sx[tid];
-    if (xf.gidx != nullptr && blockIdx.x == 0) {  // last step of a multifrontal front: its own unknowns -> solution vector
-      const int node = xf.first + blockIdx.y, n = xf.own_dims[node];
-      const int* gi = xf.gidx + xf.own_g[node];
-      for (int i = tid; i < n; i += 256) xf.x[gi[i]] = (i < kTile) ? sx[i] : x[i];   // (tile 0 from LDS: p == 0 here)
-    }
   } else {
     const int c = tid & 127, jbc = c >> 4, cl = c & 15;
     const bool act = tid < kTile;
@@ -1072,8 +1008,8 @@ void launch_bwd_front(const double* S, int tI, int ntiles, int nchunk, double* y
 }
 
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,
-                         size_t sL, size_t sR, hipStream_t st, const long long* btab, const int* live, int tI, BwdXfer xf, bool use_inv) {
-  hipLaunchKernelGGL(k_bwd_step_sub, dim3(nblocks, nbt), dim3(256), 0, st, S, ld, p, Linv_p, y, x, ncol, sM, sL, sR, btab, live, tI, xf, use_inv ? 1 : 0);
+                         size_t sL, size_t sR, hipStream_t st, const long long* btab, const int* live, int tI, BwdXfer xf) {
+  hipLaunchKernelGGL(k_bwd_step_sub, dim3(nblocks, nbt), dim3(256), 0, st, S, ld, p, Linv_p, y, x, ncol, sM, sL, sR, btab, live, tI, xf);
 }
 
 }  // namespace covgpu

@@ -1,6 +1,7 @@
 """The two probes the round-4 work on the serial panel chain leans on (tools/panel_probe.hip: k_potrf_panel / k_trsm_sub4 / k_bwd_step_sub
 against a host Cholesky with their per-step timelines; tools/valu_probe.hip: issue rates and latencies of the chain's instructions) include
-the product's kernel source: they must keep compiling for gfx950 (hipcc cross-compiles without a GPU)."""
+the product's kernel source: they must keep compiling for gfx950 (hipcc cross-compiles without a GPU). Round 5: tools/event_probe.hip (what an
+event packet between two dependent kernels costs: DESIGN.md 4.6)."""
 import os
 import shutil
 import subprocess
@@ -10,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("src,defs", [("tools/panel_probe.hip", ["-DCOVGPU_PROBE"]), ("tools/valu_probe.hip", [])])
+@pytest.mark.parametrize("src,defs", [("tools/panel_probe.hip", ["-DCOVGPU_PROBE"]), ("tools/valu_probe.hip", []), ("tools/event_probe.hip", [])])
 def test_probe_compiles_for_gfx950(tmp_path, src, defs):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):

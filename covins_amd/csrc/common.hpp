@@ -379,6 +379,12 @@ struct NdDev {
   int *inv_off = nullptr, *inv = nullptr;  // [nodes] offset of the node's map parent front row -> own front row (-1: none)
   int *rhs_node = nullptr;                 // [nodes] element offset of the node's right-hand side in nd_rhs
   int *ext = nullptr;                      // extend-add work lists: (node, tile row, tile column) of 64x64 tiles
+  // the same lists FLATTENED for the kernel (round 5): per tile 8 ints {front offset lo, hi | leading dimension | right-hand side offset | tile row |
+  // tile column | first, last+1 child entry}, per child entry 6 ints {front offset lo, hi | leading dimension | right-hand side offset | offset of its
+  // row map | 0} — a workgroup reaches a child's entries through three dependent loads (tile, child, row map) instead of six (tile, cptr, cidx,
+  // inv_off / ntab, row map)
+  int *extw = nullptr, *extc = nullptr, *extc2 = nullptr;
+  std::vector<int> h_extw, h_extc, h_extc2, h_ext_kind;
   int *bb_off = nullptr, *bb = nullptr;    // per node: offset of its lower-triangular map over BORDER 128-tiles in bb (1: a child contributes to the tile; see DenseBatch::beta0)
   int *top_var = nullptr, *top_r = nullptr, *top_g = nullptr;  // per scalar unknown of the top nodes: variable | component | solution index
   int ntop = 0;

@@ -169,7 +169,10 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& 
     countA = 0;
     for (int pass = 0; pass < 2; ++pass)
       for (size_t q = 0; q < tiles.size(); q += 3)
-        if ((tiles[q + 1] < 4) == (pass == 0)) { dev.h_ext.insert(dev.h_ext.end(), tiles.begin() + q, tiles.begin() + q + 3); countA += pass == 0 ? 1 : 0; }
+        if ((tiles[q + 1] < 4) == (pass == 0)) {
+          dev.h_ext.insert(dev.h_ext.end(), tiles.begin() + q, tiles.begin() + q + 3); countA += pass == 0 ? 1 : 0;
+          dev.h_ext_kind.push_back(&cptr == &dev.h_cptr2 ? 1 : 0);
+        }
     count = (int)dev.h_ext.size() / 3 - first;
   };
   for (int l = 0; l < nlev; ++l) {
@@ -185,6 +188,27 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& 
       int d = 0;
       for (int v : hp.strct[n]) if (hp.vnode[v] == p && hp.voff[v] < 256) d += NdHostPlan::vdim(v);
       L.split_ta = std::max(L.split_ta, (d + kTile - 1) / kTile);
+    }
+  }
+  // flattened work / child lists of the extend-add kernel (NdDev::extw / extc / extc2)
+  {
+    auto flat = [&](const std::vector<int>& cidx, std::vector<int>& out) {
+      for (int ch : cidx) {
+        const unsigned long long mo = (unsigned long long)dev.h_ntab[2 * (size_t)ch];
+        out.push_back((int)(unsigned)(mo & 0xffffffffull)); out.push_back((int)(unsigned)(mo >> 32));
+        out.push_back((int)dev.h_ntab[2 * (size_t)ch + 1]); out.push_back(dev.h_rhs_node[ch]); out.push_back(dev.h_inv_off[ch]); out.push_back(0);
+      }
+    };
+    flat(dev.h_cidx, dev.h_extc); flat(dev.h_cidx2, dev.h_extc2);
+    const size_t nt = dev.h_ext.size() / 3;
+    dev.h_extw.resize(8 * nt);
+    for (size_t q = 0; q < nt; ++q) {
+      const int node = dev.h_ext[3 * q];
+      const std::vector<int>& cp = dev.h_ext_kind[q] ? dev.h_cptr2 : dev.h_cptr;
+      const unsigned long long fo = (unsigned long long)dev.h_ntab[2 * (size_t)node];
+      int* w = dev.h_extw.data() + 8 * q;
+      w[0] = (int)(unsigned)(fo & 0xffffffffull); w[1] = (int)(unsigned)(fo >> 32); w[2] = (int)dev.h_ntab[2 * (size_t)node + 1]; w[3] = dev.h_rhs_node[node];
+      w[4] = dev.h_ext[3 * q + 1]; w[5] = dev.h_ext[3 * q + 2]; w[6] = cp[node]; w[7] = cp[node + 1];
     }
   }
   // border x border 128-tiles that receive something from a child (NdDev::bb): only those are cleared per iteration and read by the first
@@ -289,16 +313,29 @@ __global__ __launch_bounds__(256) void k_nd_assemble(DevProblem P, const int* __
 
 // parent front += children's Schur complements, parent right-hand side += children's reduced right-hand sides, in child order.
 // One workgroup per 64x64 tile of a host-built list (only tiles some child contributes to); a thread owns a 4x4 sub-grid.
-__global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, const int* __restrict__ rhs_off, const int* __restrict__ work,
-                                                    const int* __restrict__ cptr, const int* __restrict__ cidx, int second_pass) {
-  const int node = work[3 * blockIdx.x], tr = work[3 * blockIdx.x + 1], tc = work[3 * blockIdx.x + 2];
+// Round 5: tile and child descriptors flattened on the host (NdDev::extw / extc): tile -> child entry -> row map -> value, with the child entry two
+// and the row maps one child ahead of the gather — the kernel is a chain of dependent loads on the critical path of every level transition.
+__global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, const int* __restrict__ work, const int* __restrict__ child, int second_pass) {
+  const int4 w0 = reinterpret_cast<const int4*>(work)[2 * (size_t)blockIdx.x], w1 = reinterpret_cast<const int4*>(work)[2 * (size_t)blockIdx.x + 1];
+  const size_t foff = (size_t)(unsigned)w0.x | ((size_t)(unsigned)w0.y << 32);
+  const size_t ld = (size_t)w0.z;
+  const int rhs_p = w0.w, tr = w1.x, tc = w1.y, kbeg = w1.z, kend = w1.w;
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  const size_t ld = (size_t)P.nd_ntab[2 * node + 1];
-  double* F = P.nd_M + P.nd_ntab[2 * node];
+  double* F = P.nd_M + foff;
   const int nrow = (int)ld;
   int rr[4], cc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { rr[i] = 64 * tr + ty + 16 * i; cc[i] = 64 * tc + tx + 16 * i; }
+  struct Ch { size_t moff; int ldc, rhs, inv; };
+  auto load_ch = [&](int k) {
+    const int2* q = reinterpret_cast<const int2*>(child) + 3 * (size_t)k;
+    const int2 a0 = q[0], a1 = q[1], a2 = q[2];
+    Ch c; c.moff = (size_t)(unsigned)a0.x | ((size_t)(unsigned)a0.y << 32); c.ldc = a1.x; c.rhs = a1.y; c.inv = a2.x;
+    return c;
+  };
+  Ch c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};   // entries of child k + 1 | k + 2
+  if (kbeg < kend) c1 = load_ch(kbeg);
+  if (kbeg + 1 < kend) c2 = load_ch(kbeg + 1);
   // what the front holds already: only columns of the front's OWN unknowns carry original entries (a border x border entry
   // belongs to an ancestor's front) — those are read up front, beside the index loads, the rest starts from zero
   double v[4][4], rv[4] = {0.0, 0.0, 0.0, 0.0};
@@ -312,28 +349,28 @@ __global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, co
       v[i][j] = (own_cols && rr[i] < nrow && cc[j] <= rr[i]) ? F[(size_t)rr[i] * ld + cc[j]] : 0.0;
       hit[i][j] = false;
     }
-  // children in child order (deterministic sums); the row maps of child k + 1 are fetched before the entries of child k are
-  // gathered, so a child costs one memory latency on this launch-bound kernel, not two dependent ones
-  const int kbeg = cptr[node], kend = cptr[node + 1];
+  // children in child order (deterministic sums); the row maps of child k + 1 are fetched before the entries of child k are gathered
   int irn[4], icn[4];
-  auto load_maps = [&](int k) {
-    const int* inv = a.inv + a.inv_off[cidx[k]];
+  auto load_maps = [&](const Ch& c) {
+    const int* inv = a.inv + c.inv;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { irn[i] = rr[i] < nrow ? inv[rr[i]] : -1; icn[i] = cc[i] < nrow ? inv[cc[i]] : -1; }
   };
-  if (kbeg < kend) load_maps(kbeg);
+  if (kbeg < kend) load_maps(c1);
   for (int k = kbeg; k < kend; ++k) {
-    const int ch = cidx[k];
-    const size_t ldc = (size_t)P.nd_ntab[2 * ch + 1];
-    const double* C = P.nd_M + P.nd_ntab[2 * ch];
+    const Ch c = c1;
+    c1 = c2;
+    if (k + 2 < kend) c2 = load_ch(k + 2);
+    const double* C = P.nd_M + c.moff;
+    const size_t ldc = (size_t)c.ldc;
     int ir[4], ic[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ir[i] = irn[i]; ic[i] = icn[i]; }
-    if (k + 1 < kend) load_maps(k + 1);
+    if (k + 1 < kend) load_maps(c1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (ir[i] < 0) continue;
-      if (tr == tc && tx == 0) rv[i] += P.nd_rhs[rhs_off[ch] + ir[i]];  // (diagonal tiles: lane tx == 0 of a row folds the right-hand side)
+      if (tr == tc && tx == 0) rv[i] += P.nd_rhs[c.rhs + ir[i]];  // (diagonal tiles: lane tx == 0 of a row folds the right-hand side)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (ic[j] < 0 || cc[j] > rr[i]) continue;
@@ -346,7 +383,7 @@ __global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, co
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) if (hit[i][j]) F[(size_t)rr[i] * ld + cc[j]] = v[i][j];
-    if (rv[i] != 0.0) P.nd_rhs[rhs_off[node] + rr[i]] += rv[i];
+    if (rv[i] != 0.0) P.nd_rhs[rhs_p + rr[i]] += rv[i];
   }
 }
 
@@ -461,8 +498,8 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     if (part == 1) count = countA;
     if (part == 2) { first += countA; count -= countA; }
     if (count > 0)
-      hipLaunchKernelGGL(k_nd_extend, dim3(count), dim3(256), 0, s2, P, lev_args(P, nd, l), (const int*)nd.rhs_node, (const int*)(nd.ext + 3 * (size_t)first),
-                         (const int*)(top_children ? nd.cptr2 : nd.cptr), (const int*)(top_children ? nd.cidx2 : nd.cidx), top_children ? 1 : 0);
+      hipLaunchKernelGGL(k_nd_extend, dim3(count), dim3(256), 0, s2, P, lev_args(P, nd, l), (const int*)(nd.extw + 8 * (size_t)first),
+                         (const int*)(top_children ? nd.extc2 : nd.extc), top_children ? 1 : 0);
   };
   // split: the trailing update of this level's last panel is split for the look-ahead into the next level (DenseBatch::split_ta)
   auto factor = [&](int l, bool split, hipEvent_t pre_trsm) {

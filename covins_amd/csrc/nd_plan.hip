@@ -340,10 +340,27 @@ bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs
   for (size_t i = 0; i < cand.size(); ++i) if (cand[i].ok && (best < 0 || cand[i].cost < cand[best].cost)) best = (int)i;
   if (best < 0) return false;
   out = std::move(cand[best].hp);
+  out.top_mode = cand[best].mode; out.leaf = cand[best].leaf;
   return true;
 }
 
-void nd_shard_assign(NdHostPlan& hp, int world) {
+double nd_shard_cost(const NdHostPlan& hp, int world) {
+  const int nn = hp.nnodes;
+  double top_fl = 0.0, exch = 0.0;
+  std::vector<double> rank_fl(std::max(world, 1), 0.0);
+  for (int n = 0; n < nn; ++n) {
+    const double m = hp.own_dims[n], b = hp.st_dims[n], fl = m * m * m / 3.0 + m * m * b + m * b * b;
+    if (hp.node_rank.empty() || hp.node_rank[n] < 0) { top_fl += fl; exch += 0.5 * (m + b) * (m + b) * 8.0; }
+    else rank_fl[hp.node_rank[n]] += fl;
+  }
+  double busiest = 0.0;
+  for (double f : rank_fl) busiest = std::max(busiest, f);
+  double chain = 0.0;
+  for (int l = 0; l < hp.nlev; ++l) chain += (hp.lev_nI[l] / 256) * 140e-6 + 40e-6;
+  return (top_fl + busiest) / 30e12 + chain + (world > 1 ? 2.0 * (world - 1) / world * exch / 150e9 : 0.0);
+}
+
+void nd_shard_assign(NdHostPlan& hp, int world, double top_cap_bytes) {
   const int nn = hp.nnodes;
   hp.node_rank.assign(nn, -1);
   hp.nsub = 0;
@@ -370,7 +387,7 @@ void nd_shard_assign(NdHostPlan& hp, int world) {
     for (size_t q = 0; q < cand.size() && pick < 0; ++q) {   // heaviest that can still be opened within the cap
       const int c = cand[q];
       const double nb = 8.0 * (double)(hp.own_dims[c] + hp.st_dims[c]) * (double)(hp.own_dims[c] + hp.st_dims[c]);
-      if (!hp.child[c].empty() && top_bytes + nb <= 48.0 * 1048576.0) pick = (int)q;
+      if (!hp.child[c].empty() && top_bytes + nb <= top_cap_bytes) pick = (int)q;
     }
     if (pick < 0) break;
     const int c = cand[pick];

@@ -28,6 +28,7 @@ struct NdHostPlan {
   // every rank holds its front, the ranks' contributions are all-reduced once per linear solve). Empty: single GPU.
   std::vector<int> node_rank;
   int nsub = 0;                                      // subtrees hanging below the top nodes (the units dealt to the ranks)
+  int top_mode = 0, leaf = 0;                        // which candidate nd_plan_build kept: cut of a region of >= 3 agents (0 one cover | 1 two groups) | leaf size
   double flops = 0;                                  // partial factorisations, dense count on the real (unpadded) sizes
   size_t front_elems = 0;                            // sum over levels of batch x ntot^2
   static int vdim(int v) { return (v & 1) ? 9 : 6; }
@@ -44,7 +45,10 @@ bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs
 // ranks by longest-processing-time-first on their factorisation flops. Top = the roots, grown downwards (heaviest subtree
 // first) until there are at least `world` subtrees and none outweighs 1.25x a rank's fair share — but never beyond 48 MiB of top
 // fronts (every top front is all-reduced and factorised on every rank): rather fewer subtrees than ranks. Deterministic.
-void nd_shard_assign(NdHostPlan& hp, int world);
+void nd_shard_assign(NdHostPlan& hp, int world, double top_cap_bytes = 48.0 * 1048576.0);
+// what one factorisation costs a rank of a sharded solve, roughly: (replicated top + the busiest rank's subtrees) at 30 TFLOP/s, the serial panel chains of
+// every level, and the ring all-reduce of the top fronts' lower halves at 150 GB/s per link. Compares candidate shard plans (covgpu_shard_plan).
+double nd_shard_cost(const NdHostPlan& hp, int world);
 // variable ids -> var_map[old id] (chain positions of one problem -> IR keyframes -> chain positions of a rank's sub-problem)
 void nd_plan_remap(NdHostPlan& hp, const std::vector<int>& var_map);
 

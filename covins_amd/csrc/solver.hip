@@ -555,6 +555,7 @@ extern "C" void covgpu_nd_plan_info(const covgpu_nd_plan* pl, int64_t* out) {
     if (h.parent[n] < 0) out[9] = std::max<int64_t>(out[9], h.own_dims[n]);
   }
   out[5] = (int64_t)h.front_elems; out[6] = (int64_t)h.flops;
+  out[10] = h.top_mode; out[11] = h.leaf;   // which candidate tree (nd_plan_build): COVGPU_ND_TOP / COVGPU_ND_LEAF reproduce it
 }
 // per node: parent, level, own_ptr / st_ptr [nodes + 1]; variables as 2 * IR keyframe + (0 pose | 1 speed-bias)
 extern "C" void covgpu_nd_plan_arrays(const covgpu_nd_plan* pl, int32_t* parent, int32_t* level, int32_t* own_ptr, int32_t* own_var, int32_t* st_ptr,
@@ -580,11 +581,36 @@ extern "C" int32_t covgpu_shard_plan(const covgpu_options* opt, const covgpu_pro
                                      int32_t* imu_rank, int32_t* edge_rank) {
   *plan_out = nullptr;
   if (world < 1) return 0;
+  // Candidates (round 5): the tree with ONE separator of all agents at the top (its children, one region per agent, are the subtrees) and the tree with two
+  // groups of agents at the top, each with the replicated top capped at 48 MiB (round 4's cap) and at 512 MiB of fronts; the cheapest by nd_shard_cost —
+  // (replicated top + busiest rank's subtrees) at 30 TFLOP/s + the panel chains + the ring all-reduce of the top — is kept. On the corrected 5-agent map the
+  // one-separator top is 3 726 unknowns = 61 % of the flops on every rank; the two-groups tree gives two ranks a 1 968-order top (10 %) and, with its two
+  // second-level separators opened, four ranks a top of 45 %. COVGPU_SHARD_TREE = 0 / 1 forces the tree, COVGPU_SHARD_CAP_MIB the cap. Deterministic.
   covgpu_nd_plan* pl = nullptr;
-  if (nd_plan_create_mode(opt, p, 0, &pl, 0) != COVGPU_OK) return 0;   // (one separator of all agents at the top: its children are the subtrees)
+  {
+    const char* e_tree = getenv("COVGPU_SHARD_TREE");
+    const char* e_cap = getenv("COVGPU_SHARD_CAP_MIB");
+    std::vector<int> modes = e_tree ? std::vector<int>{atoi(e_tree) != 0 ? 1 : 0} : std::vector<int>{0, 1};
+    std::vector<double> caps = e_cap ? std::vector<double>{atof(e_cap)} : std::vector<double>{48.0, 512.0};
+    double best_cost = 0.0;
+    for (int mode : modes) {
+      covgpu_nd_plan* cand = nullptr;
+      if (nd_plan_create_mode(opt, p, 0, &cand, mode) != COVGPU_OK) continue;
+      for (double cap : caps) {
+        NdHostPlan trial = cand->hp;
+        nd_shard_assign(trial, world, cap * 1048576.0);
+        if (trial.nsub == 0) continue;
+        const double cost = nd_shard_cost(trial, world);
+        if (pl == nullptr || cost < best_cost) {
+          if (pl == nullptr) { pl = new covgpu_nd_plan(); pl->pos_kf = cand->pos_kf; }
+          pl->hp = std::move(trial); best_cost = cost;
+        }
+      }
+      delete cand;
+    }
+    if (pl == nullptr) return 0;
+  }
   NdHostPlan& hp = pl->hp;
-  nd_shard_assign(hp, world);
-  if (hp.nsub == 0) { delete pl; return 0; }
   const bool vi = !opt->visual_only;
   std::vector<int> perm(p->num_kf);
   for (int q = 0; q < p->num_kf; ++q) perm[pl->pos_kf[q]] = q;

@@ -55,17 +55,19 @@ def test_sharded_gauss_newton_step_equals_unsharded(name, world):
     plan = distrib.shard_plan(p, o, world)
     # (a single agent splits too: the units are subtrees, not agents; the top is capped — rather fewer subtrees than ranks: at world 8
     #  two ranks of the 5-agent map hold the replicated top only and still take part in every exchange)
-    assert plan is not None and plan.subtrees >= min(world, 5)
-    # the unsharded reference on the SAME elimination tree as the sharded plan (one separator of all agents at the top: what
-    # covgpu_shard_plan builds; the one-GPU default on this map is the two-groups tree, whose step differs by rounding x condition, 3e-9
-    # at mu = 1e-8): the 1e-9 below then measures the sharding alone
-    os.environ["COVGPU_ND_TOP"] = "0"
+    # (round 5: the shard plan is the cheapest of {one separator of all agents | two groups of agents} x {48 | 512 MiB of replicated top} by
+    #  nd_shard_cost — on the corrected 5-agent map two subtrees below a 1 968-order top at every world size)
+    assert plan is not None and plan.subtrees >= 2
+    # the unsharded reference on the SAME elimination tree as the sharded plan (covgpu_shard_plan chooses among candidate trees by its own cost
+    # model, the one-GPU solve by another; two trees' steps differ by rounding x condition, 3e-9 at mu = 1e-8): the 1e-9 below then measures the
+    # sharding alone
+    os.environ["COVGPU_ND_TOP"] = str(plan.top_mode); os.environ["COVGPU_ND_LEAF"] = str(plan.leaf)
     try:
         ctx = backend.Context(0)
         dx0, dl0, c0 = ctx.gn_step(p, o, 1e-8)
         ctx.close()
     finally:
-        del os.environ["COVGPU_ND_TOP"]
+        del os.environ["COVGPU_ND_TOP"]; del os.environ["COVGPU_ND_LEAF"]
     parts, (st, lay) = run_virtual_ranks(p, plan, lambda ctx, sub, r: ctx.gn_step(sub, o, 1e-8))
     po, so = np.where(plan.pose_rank < 0, 0, plan.pose_rank), np.where(plan.sb_rank < 0, 0, plan.sb_rank)
     dx = np.zeros_like(dx0); dl = np.zeros_like(dl0)

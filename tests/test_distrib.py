@@ -10,7 +10,7 @@ import os
 import numpy as np
 import torch.multiprocessing as mp
 
-from covins_amd import backend, distrib, mapdata, synth
+from covins_amd import backend, capi, distrib, mapdata, synth
 from oracle import covo
 
 
@@ -193,3 +193,44 @@ def test_ranks_with_different_shard_plans_refuse_before_any_collective(tmp_path)
 def test_single_process_is_identity():
     assert distrib.aggregate(0.5, 7, None, False) == (0.5, 7.0)
     assert distrib.throughput(2.0, 10.0) == 5.0
+
+
+def test_shard_plan_keeps_the_replicated_top_small_on_the_five_agent_map():
+    """Round 5: with the ground truth read correctly ONE separator of all agents is 621 keyframes on the 5-agent map — 61 % of the factorisation flops on
+    every rank, slower than one GPU. covgpu_shard_plan chooses among candidate trees by nd_shard_cost; what it keeps must replicate a small share and
+    give at least two ranks real work, and round 4's policy (one separator of all agents, 48 MiB cap) must still be reachable through its switches."""
+    import ctypes as C
+    p = _problem("mh12345")
+    o = backend.default_options()
+
+    def shares(pl):
+        lib = backend.lib()
+        info = (C.c_int64 * 16)()
+        lib.covgpu_nd_plan_info(pl.handle, info)
+        nn = int(info[0])
+        parent = np.zeros(nn, np.int32); level = np.zeros(nn, np.int32); optr = np.zeros(nn + 1, np.int32); sptr = np.zeros(nn + 1, np.int32)
+        ov = np.zeros(max(int(info[3]), 1), np.int32); sv = np.zeros(max(int(info[4]), 1), np.int32)
+        lib.covgpu_nd_plan_arrays(pl.handle, capi.iptr(parent), capi.iptr(level), capi.iptr(optr), capi.iptr(ov), capi.iptr(sptr), capi.iptr(sv))
+        dim = lambda v: np.where(v & 1, 9, 6)
+        own = np.array([dim(ov[optr[n]:optr[n + 1]]).sum() for n in range(nn)], float)
+        st = np.array([dim(sv[sptr[n]:sptr[n + 1]]).sum() for n in range(nn)], float)
+        fl = own ** 3 / 3.0 + own ** 2 * st + own * st ** 2
+        top = pl.node_rank < 0
+        per_rank = np.array([fl[pl.node_rank == r].sum() for r in range(pl.world)])
+        return fl[top].sum() / fl.sum(), per_rank / fl.sum(), int(own[top].sum())
+
+    for world in (2, 4):
+        pl = distrib.shard_plan(p, o, world)
+        top_share, rank_share, top_dims = shares(pl)
+        assert top_share < 0.2 and top_dims < 2500, (top_share, top_dims)
+        assert np.sort(rank_share)[-2] > 0.3            # two ranks carry real work
+        assert top_share + rank_share.max() < 0.65      # what the busiest rank factorises: well below the whole
+        pl.close()
+    os.environ["COVGPU_SHARD_TREE"] = "0"; os.environ["COVGPU_SHARD_CAP_MIB"] = "48"
+    try:
+        pl = distrib.shard_plan(p, o, 4)
+        top_share, rank_share, top_dims = shares(pl)
+        assert pl.subtrees == 5 and top_dims > 3000 and top_share > 0.5
+        pl.close()
+    finally:
+        del os.environ["COVGPU_SHARD_TREE"]; del os.environ["COVGPU_SHARD_CAP_MIB"]

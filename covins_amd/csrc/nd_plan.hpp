@@ -28,7 +28,7 @@ struct NdHostPlan {
   // every rank holds its front, the ranks' contributions are all-reduced once per linear solve). Empty: single GPU.
   std::vector<int> node_rank;
   int nsub = 0;                                      // subtrees hanging below the top nodes (the units dealt to the ranks)
-  int top_mode = 0, leaf = 0;                        // which candidate nd_plan_build kept: cut of a region of >= 3 agents (0 one cover | 1 two groups) | leaf size
+  int top_mode = 0, leaf = 0, group_frac100 = 300;   // which candidate nd_plan_build kept: cut of a region of >= 3 agents (0 one cover | 1 two groups) | leaf size | 100 x the two groups' balance bound
   double flops = 0;                                  // partial factorisations, dense count on the real (unpadded) sizes
   size_t front_elems = 0;                            // sum over levels of batch x ntot^2
   static int vdim(int v) { return (v & 1) ? 9 : 6; }

@@ -555,7 +555,7 @@ extern "C" void covgpu_nd_plan_info(const covgpu_nd_plan* pl, int64_t* out) {
     if (h.parent[n] < 0) out[9] = std::max<int64_t>(out[9], h.own_dims[n]);
   }
   out[5] = (int64_t)h.front_elems; out[6] = (int64_t)h.flops;
-  out[10] = h.top_mode; out[11] = h.leaf;   // which candidate tree (nd_plan_build): COVGPU_ND_TOP / COVGPU_ND_LEAF reproduce it
+  out[10] = h.top_mode; out[11] = h.leaf; out[12] = h.group_frac100;   // which candidate tree (nd_plan_build): COVGPU_ND_TOP / COVGPU_ND_LEAF / COVGPU_ND_GROUP_FRAC (= out[12] / 100) reproduce it
 }
 // per node: parent, level, own_ptr / st_ptr [nodes + 1]; variables as 2 * IR keyframe + (0 pose | 1 speed-bias)
 extern "C" void covgpu_nd_plan_arrays(const covgpu_nd_plan* pl, int32_t* parent, int32_t* level, int32_t* own_ptr, int32_t* own_var, int32_t* st_ptr,

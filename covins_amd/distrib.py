@@ -73,7 +73,7 @@ def shard_plan(prob: FlatProblem, opt: Options, world: int) -> Optional[ShardPla
     nr = np.zeros(int(info[0]), np.int32)
     lib.covgpu_nd_plan_ranks(h, capi.iptr(nr))
     plan = ShardPlan(h, int(world), int(n), lr[:prob.L].copy(), ir[:prob.I].copy(), er[:prob.E].copy(), pr, sr, nr)
-    plan.top_mode, plan.leaf = int(info[10]), int(info[11])   # which candidate tree was kept (COVGPU_ND_TOP / COVGPU_ND_LEAF reproduce it on one GPU)
+    plan.top_mode, plan.leaf, plan.group_frac = int(info[10]), int(info[11]), int(info[12]) / 100.0   # which candidate tree was kept (COVGPU_ND_TOP / COVGPU_ND_LEAF / COVGPU_ND_GROUP_FRAC reproduce it on one GPU)
     return plan
 
 

@@ -61,13 +61,13 @@ def test_sharded_gauss_newton_step_equals_unsharded(name, world):
     # the unsharded reference on the SAME elimination tree as the sharded plan (covgpu_shard_plan chooses among candidate trees by its own cost
     # model, the one-GPU solve by another; two trees' steps differ by rounding x condition, 3e-9 at mu = 1e-8): the 1e-9 below then measures the
     # sharding alone
-    os.environ["COVGPU_ND_TOP"] = str(plan.top_mode); os.environ["COVGPU_ND_LEAF"] = str(plan.leaf)
+    os.environ["COVGPU_ND_TOP"] = str(plan.top_mode); os.environ["COVGPU_ND_LEAF"] = str(plan.leaf); os.environ["COVGPU_ND_GROUP_FRAC"] = str(plan.group_frac)
     try:
         ctx = backend.Context(0)
         dx0, dl0, c0 = ctx.gn_step(p, o, 1e-8)
         ctx.close()
     finally:
-        del os.environ["COVGPU_ND_TOP"]; del os.environ["COVGPU_ND_LEAF"]
+        del os.environ["COVGPU_ND_TOP"]; del os.environ["COVGPU_ND_LEAF"]; del os.environ["COVGPU_ND_GROUP_FRAC"]
     parts, (st, lay) = run_virtual_ranks(p, plan, lambda ctx, sub, r: ctx.gn_step(sub, o, 1e-8))
     po, so = np.where(plan.pose_rank < 0, 0, plan.pose_rank), np.where(plan.sb_rank < 0, 0, plan.sb_rank)
     dx = np.zeros_like(dx0); dl = np.zeros_like(dl0)

@@ -3,6 +3,7 @@
 #include "nd_plan.hpp"
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <queue>
 #include <thread>
@@ -92,27 +93,86 @@ struct Builder {
       // One cover of ALL cross-agent couplings (top_mode 0) puts every loop-closure zone of the map into ONE front — on the 5-agent
       // map with the ground-truth orientations read correctly 621 keyframes = 15 serial panels and 60 % of the flops.
       const int nc = (int)chains.size();
-      std::vector<int> cidx(out.K, 0);
+      constexpr int kBruteChains = 14;   // 2^13 bipartitions x nc per step: a millisecond
+      std::vector<char> side_best;
       std::vector<long long> W((size_t)nc * nc, 0), size(nc, 0);
       ++regid;
       for (int v : vars) { reg[v] = regid; side[v] = (int)(std::lower_bound(chains.begin(), chains.end(), chain_of[v >> 1]) - chains.begin()); size[side[v]] += 1; }
       for (int v : vars) for (int w : adj[v]) if (reg[w] == regid && side[w] != side[v]) W[(size_t)side[v] * nc + side[w]] += 1;
       long long total = 0;
       for (int c = 0; c < nc; ++c) total += size[c];
-      // all bipartitions with agent 0 on side 0 (nc <= 20): lightest crossing weight among those with at least 1 / group_frac of the unknowns on
-      // the lighter side (half of that, a quarter, ... if none qualifies)
-      unsigned best = 0; long long best_w = -1;
-      for (double frac = group_frac; frac <= 48.0 && best_w < 0; frac *= 2.0)
-        for (unsigned m = 1; m < (1u << (nc - 1)); ++m) {
-          const unsigned g = m << 1;   // bit c set: agent c on side 1
-          long long s1 = 0, w = 0;
-          for (int c = 0; c < nc; ++c) if (g >> c & 1) s1 += size[c];
-          if ((double)std::min(s1, total - s1) * frac < (double)total) continue;
-          for (int a = 0; a < nc; ++a) for (int b = 0; b < nc; ++b) if ((g >> a & 1) != (g >> b & 1)) w += W[(size_t)a * nc + b];
-          if (best_w < 0 || w < best_w) { best_w = w; best = g; }
+      // Symmetric pair weights once: the crossing weight of a bipartition is then updated per moved chain (O(nc)) instead of recomputed (O(nc^2)).
+      std::vector<long long> Ws((size_t)nc * nc, 0);
+      for (int a = 0; a < nc; ++a) for (int b = 0; b < nc; ++b) Ws[(size_t)a * nc + b] = W[(size_t)a * nc + b] + W[(size_t)b * nc + a];
+      auto balanced = [&](long long s1, double frac) { return (double)std::min(s1, total - s1) * frac >= (double)total; };
+      uint64_t best = 0; long long best_w = -1;
+      if (nc <= kBruteChains) {
+        // all bipartitions with chain 0 on side 0, walked in Gray-code order (one chain changes side per step): lightest crossing weight among
+        // those with at least 1 / group_frac of the unknowns on the lighter side (half of that, a quarter, ... if none qualifies). Ties: the
+        // numerically smallest mask, as the plain enumeration of round 5 chose.
+        for (double frac = group_frac; frac <= 48.0 && best_w < 0; frac *= 2.0) {
+          uint64_t g = 0; long long s1 = 0, w = 0;
+          const uint64_t nm = (uint64_t)1 << (nc - 1);
+          for (uint64_t m = 1; m < nm; ++m) {
+            const int c = 1 + __builtin_ctzll(m);   // the chain that changes side at this step (chain 0 never does)
+            const bool to1 = !(g >> c & 1);
+            long long d = 0;   // change of the crossing weight: links to the side it leaves start to cross, links to the side it joins stop
+            for (int b = 0; b < nc; ++b) if (b != c) d += ((g >> b & 1) == (uint64_t)to1 ? -1 : 1) * Ws[(size_t)c * nc + b];
+            w += d; g ^= (uint64_t)1 << c; s1 += to1 ? size[c] : -size[c];
+            if (!balanced(s1, frac)) continue;
+            if (best_w < 0 || w < best_w || (w == best_w && g < best)) { best_w = w; best = g; }
+          }
         }
-      if (best_w < 0) best = 2;
-      for (int v : vars) side[v] = (int)(best >> side[v] & 1);
+      } else {
+        // Many chains (every keyframe without an IMU predecessor starts one: a map of short tracking sessions has dozens): 2^(nc-1) bipartitions are
+        // out of reach (26 chains took 49 s) — a deterministic Fiduccia-Mattheyses-style local search instead: from a few fixed starts
+        // (chains dealt by size to the lighter side; contiguous halves of the chain order) move the single chain with the best gain that keeps the
+        // balance bound, until no move gains. O(nc^2) per pass.
+        for (double frac = group_frac; frac <= 48.0 && best_w < 0; frac *= 2.0)
+          for (int start = 0; start < 3; ++start) {
+            std::vector<char> sd(nc, 0);
+            if (start == 0) {
+              std::vector<int> ord(nc);
+              for (int c = 0; c < nc; ++c) ord[c] = c;
+              std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return size[a] > size[b]; });
+              long long l0 = 0, l1 = 0;
+              for (int c : ord) { if (l1 < l0) { sd[c] = 1; l1 += size[c]; } else l0 += size[c]; }
+            } else {
+              long long acc = 0;
+              for (int c = 0; c < nc; ++c) { const int cc = start == 1 ? c : nc - 1 - c; sd[cc] = acc * 2 >= total ? 1 : 0; acc += size[cc]; }
+            }
+            long long s1 = 0, w = 0;
+            for (int c = 0; c < nc; ++c) if (sd[c]) s1 += size[c];
+            for (int a = 0; a < nc; ++a) for (int b = a + 1; b < nc; ++b) if (sd[a] != sd[b]) w += Ws[(size_t)a * nc + b];
+            for (int pass = 0; pass < 4 * nc; ++pass) {
+              int pick = -1; long long pick_d = 0;
+              for (int c = 0; c < nc; ++c) {
+                const long long ns1 = s1 + (sd[c] ? -size[c] : size[c]);
+                if (!balanced(ns1, frac) && balanced(s1, frac)) continue;   // (an unbalanced start may move towards balance)
+                long long d = 0;
+                for (int b = 0; b < nc; ++b) if (b != c) d += (sd[b] == sd[c] ? 1 : -1) * Ws[(size_t)c * nc + b];
+                if (!balanced(s1, frac)) { if (std::min(ns1, total - ns1) <= std::min(s1, total - s1)) continue; d = -1 - std::min(ns1, total - ns1); }   // repair first
+                if (d < pick_d) { pick_d = d; pick = c; }
+              }
+              if (pick < 0) break;
+              if (balanced(s1, frac)) w += pick_d;
+              else { long long d = 0; for (int b = 0; b < nc; ++b) if (b != pick) d += (sd[b] == sd[pick] ? 1 : -1) * Ws[(size_t)pick * nc + b]; w += d; }
+              s1 += sd[pick] ? -size[pick] : size[pick]; sd[pick] ^= 1;
+            }
+            if (!balanced(s1, frac) || s1 == 0 || s1 == total) continue;
+            if (best_w < 0 || w < best_w) { best_w = w; side_best.assign(sd.begin(), sd.end()); }
+          }
+      }
+      if (nc <= kBruteChains) {
+        if (best_w < 0) best = 2;
+        side_best.assign(nc, 0);
+        for (int c = 0; c < nc; ++c) side_best[c] = (char)(best >> c & 1);
+      } else if (best_w < 0) {   // nothing balanced was found: the largest chain against the rest
+        side_best.assign(nc, 0);
+        side_best[(int)(std::max_element(size.begin(), size.end()) - size.begin())] = 1;
+      }
+      if (side_best[0]) for (auto& b : side_best) b ^= 1;   // chain 0 on side 0, as the enumeration has it
+      for (int v : vars) side[v] = (int)side_best[side[v]];
     } else if (chains.size() >= 2) {
       nparts = (int)chains.size();
       for (int v : vars) side[v] = (int)(std::lower_bound(chains.begin(), chains.end(), chain_of[v >> 1]) - chains.begin());
@@ -336,16 +396,24 @@ bool nd_plan_build(int K, bool vi, int nchains, const int* chain_ptr, int npairs
   for (int lf : leaves)
     for (int m : modes)
       for (double fr : (m == 1 ? fracs : std::vector<double>{3.0})) { cand.emplace_back(); cand.back().mode = m; cand.back().leaf = lf; cand.back().frac = fr; }
+  // (a worker that throws — std::bad_alloc on a huge map — marks its candidate failed instead of reaching std::terminate; threads that cannot be
+  //  created leave their candidates to the calling thread)
   auto run = [&](size_t i) {
-    cand[i].ok = nd_plan_build_mode(cand[i].mode, cand[i].frac, K, vi, adj, chain_of, cand[i].leaf, cand[i].hp);
-    if (cand[i].ok) cand[i].cost = nd_plan_cost(cand[i].hp);
+    try {
+      cand[i].ok = nd_plan_build_mode(cand[i].mode, cand[i].frac, K, vi, adj, chain_of, cand[i].leaf, cand[i].hp);
+      if (cand[i].ok) cand[i].cost = nd_plan_cost(cand[i].hp);
+    } catch (...) { cand[i].ok = false; }
   };
   if (cand.size() == 1) run(0);
   else {
     std::vector<std::thread> th;
-    for (size_t i = 1; i < cand.size(); ++i) th.emplace_back(run, i);
+    std::vector<char> started(cand.size(), 0);
+    for (size_t i = 1; i < cand.size(); ++i) {
+      try { th.emplace_back(run, i); started[i] = 1; } catch (...) { break; }
+    }
     run(0);
     for (auto& t : th) t.join();
+    for (size_t i = 1; i < cand.size(); ++i) if (!started[i]) run(i);
   }
   int best = -1;
   for (size_t i = 0; i < cand.size(); ++i) if (cand[i].ok && (best < 0 || cand[i].cost < cand[best].cost)) best = (int)i;

@@ -1135,7 +1135,9 @@ static int wait_iteration(covgpu_context* c) {
       const hipError_t q = hipStreamQuery(c->st);
       if (q == hipSuccess) break;
       if (q != hipErrorNotReady) { g_err = std::string("hipStreamQuery: ") + hipGetErrorString(q); return COVGPU_ERR_NO_DEVICE; }
-      if ((++spins & (spins > 256 ? 63 : 1023)) == 0) {   // (fail checks: every 1024 busy polls at first, then every 64 sleeping polls = ~4 ms)
+      ++spins;
+      // fail checks: after the first 256 busy polls, then every 64 sleeping polls (~4 ms)
+      if (spins == 256 || (spins > 256 && (spins & 63) == 0)) {
         const char* why = nullptr;
         if (c->peer_fail && c->peer_fail->load(std::memory_order_relaxed)) why = "another rank of the call gave up";
         else if (rr && rr->async_error() != 0) why = "RCCL reported an asynchronous communicator error";

@@ -89,7 +89,6 @@ def plan_digest(plan: ShardPlan) -> str:
     return h.hexdigest()
 
 
-_attach_seq = {}   # per store: how many attaches this process has run on it — the ranks attach in the same order, so the count names the attach
 
 
 def check_plan_digest(store, rank: int, world: int, mine: str) -> None:
@@ -98,8 +97,9 @@ def check_plan_digest(store, rank: int, world: int, mine: str) -> None:
     a second round of keys — every rank's verdict — follows the comparison, so that no rank goes on to ncclCommInitRank while another
     has already refused."""
     from . import backend
-    seq = _attach_seq.get(id(store), 0)
-    _attach_seq[id(store)] = seq + 1
+    # the attach number comes from the STORE (ADVICE r05: a counter keyed by id(store) can be inherited by a fresh store that reuses the id in one
+    # process and not in another — the ranks would then wait for differently numbered keys): every rank counts its own attaches under its own key
+    seq = int(store.add(f"plan_digest_seq_{rank}", 1)) - 1
     store.set(f"plan_digest_{seq}_{rank}", mine.encode())
     bad = None
     for r in range(world):

@@ -219,3 +219,33 @@ def test_replay_at_three_agent_size():
     x = _replay_sparse(S, np.asarray(bvec), parent, level, own, st, 15)
     r = S @ x - bvec
     assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(bvec)
+
+
+@pytest.mark.parametrize("keep_every", [4, 6])
+def test_many_short_imu_chains_plan_in_milliseconds(small_map, keep_every):
+    """every keyframe without an IMU predecessor starts a chain, and the two-groups cut enumerated 2^(chains-1) bipartitions — 26 chains
+    took 49 s, 33 were undefined behaviour. A map of short tracking sessions (here: every `keep_every`-th IMU factor of the small map dropped, 30+
+    chains) must plan in well under a second through the local-search bipartition, and the plan must still replay to the dense solve."""
+    import time
+    prob, _ = mapdata.flatten_gba(small_map, visual_only=False, loop_loss=True)
+    q = prob.copy()
+    keep = np.ones(q.I, bool); keep[::keep_every] = False
+    ptr = q.imu_sample_ptr
+    sel = np.concatenate([np.arange(ptr[i], ptr[i + 1]) for i in np.nonzero(keep)[0]]) if keep.any() else np.zeros(0, int)
+    q.imu_samples = q.imu_samples[sel]
+    q.imu_sample_ptr = np.r_[0, np.cumsum((ptr[1:] - ptr[:-1])[keep])].astype(np.int32)
+    q.imu_kf_i, q.imu_kf_j, q.imu_first = q.imu_kf_i[keep], q.imu_kf_j[keep], q.imu_first[keep]
+    if q.imu_noise is not None:
+        q.imu_noise = q.imu_noise[keep]
+    nchains = q.K - q.I     # a chain per keyframe without a predecessor
+    assert nchains >= 30
+    t0 = time.perf_counter()
+    info, parent, level, own, st = _plan(q, backend.default_options(), 0)      # leaf 0: the default candidates, two-groups cut included
+    dt = time.perf_counter() - t0
+    assert dt < 2.0, f"planning {nchains} chains took {dt:.2f} s"
+    info2, parent2, _, own2, _ = _plan(q, backend.default_options(), 0)
+    assert info == info2 and np.array_equal(parent, parent2) and all(np.array_equal(a, b) for a, b in zip(own, own2))   # deterministic
+    S, bvec, _ = covo.schur(q, covo.default_options(), 1e-4)
+    x = _replay(S, bvec, parent, level, own, st, 15)
+    xd = np.linalg.solve(S, bvec)
+    assert np.abs(x - xd).max() <= 1e-9 * np.abs(xd).max()

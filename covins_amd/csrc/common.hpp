@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/covgpu.h"
@@ -183,7 +184,7 @@ struct CholAux;
 void launch_kobs_build(const DevProblem& P, int* pair_oa, int* pair_ob, size_t nent, hipStream_t st);  // upload: keyframe-major copies, Z slots, pair lists -> Z slots
 void launch_lm_lin(const DevProblem& P, double mu, hipStream_t st);   // landmark-major linearisation: records, H_ll, g_l, cost partials
 void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared = nullptr, hipStream_t side = nullptr,
-                     hipEvent_t ev_lin = nullptr, hipEvent_t ev_kf = nullptr);  // reprojection -> Hll, g, S (Schur), bred, cost
+                     hipEvent_t ev_lin = nullptr, hipEvent_t ev_kf = nullptr, CholAux* ax = nullptr);  // reprojection -> Hll, g, S (Schur), bred, cost
 void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st);
 void launch_obs_jvp(const DevProblem& P, const double* v_all, hipStream_t st);  // scal[SC_JV2] += sum |J v|^2
 void launch_obs_cost(const DevProblem& P, const double* pose, const double* lm, hipStream_t st);  // scal[SC_COST] +=
@@ -259,6 +260,29 @@ struct CholAux {
   void init();
   void destroy();
   void collect();
+  // ---- ordering between this context's streams through DEVICE FLAGS instead of HIP events (round 6; tools/gate_probe.hip:
+  // a cross-stream dependency through an event costs ~14 us and holds the recording stream's next kernel, through a flag ~5 us and 1.3):
+  //   record(e, s)  a one-thread kernel on s publishes a fresh sequence number in e's slot (the producer's data was released by its own end of kernel)
+  //   wait(s, e..)  a one-wave kernel on s polls the slots for the numbers their LAST record carried (HIP's semantics: the wait captures the record
+  //                 that precedes it in host order); the consumer kernel behind it starts at an ordinary dependent boundary and acquires at its start
+  // A gate is always enqueued after its signal: the earliest unfinished packet in host order never waits for a later one — no deadlock whatever
+  // the streams' mapping onto hardware queues. A gate that nevertheless waits longer than gate_timeout_s (a tool that serialises kernels out of
+  // order, a lost dispatch) raises gate_dead: every later gate returns at once, the solve reports an error and solver.hip repeats it with
+  // events. gates_on == false (COVGPU_GATES=0, or after such a failure): plain hipEventRecord / hipStreamWaitEvent.
+  static constexpr int kGateSlots = 16384;
+  bool gates_on = false, gates_broken = false;
+  long long* gate_flags = nullptr;       // [kGateSlots] device
+  int* gate_dead = nullptr;              // device: a gate gave up
+  int* gate_dead_h = nullptr;            // pinned host mirror of it (written by the gate itself; read after the host synchronisation)
+  std::unordered_map<hipEvent_t, int> gate_slot;
+  std::vector<long long> gate_seq;       // per slot: sequence number of the last record (0: never recorded)
+  long long gate_counter = 0;
+  double gate_timeout_s = 3.0;
+  long gate_signals = 0, gate_waits = 0; // launches issued (statistics)
+  void record(hipEvent_t e, hipStream_t s);
+  void wait(hipStream_t s, hipEvent_t e0, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
+  bool gate_failed() const { return gate_dead_h != nullptr && *(volatile int*)gate_dead_h != 0; }
+  void gates_disable();                  // after a failure: back to events for the life of the context (the flags are reset)
 };
 // dense SPD solve of Sred x = bred in place (lower Cholesky on the FP64 MFMA path); flag[0] != 0 on failure
 // batched form: n independent systems of identical shape; sM / sL / sR = elements between consecutive matrices, Linv

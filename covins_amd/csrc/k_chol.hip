@@ -328,6 +328,75 @@ void CholAux::init() {
   if (!ev_xb) (void)hipEventCreateWithFlags(&ev_xb, hipEventDisableTiming);
   if (!ev_xa) (void)hipEventCreateWithFlags(&ev_xa, hipEventDisableTiming);
   if (!bwd_cnt && hipMalloc((void**)&bwd_cnt, 65536 * sizeof(int)) == hipSuccess) (void)hipMemset(bwd_cnt, 0, 65536 * sizeof(int));
+  if (!gate_flags && !gates_broken) {
+    static const bool want = getenv("COVGPU_GATES") == nullptr || atoi(getenv("COVGPU_GATES")) != 0;
+    if (want && hipMalloc((void**)&gate_flags, kGateSlots * sizeof(long long)) == hipSuccess && hipMalloc((void**)&gate_dead, sizeof(int)) == hipSuccess &&
+        hipHostMalloc((void**)&gate_dead_h, sizeof(int), hipHostMallocDefault) == hipSuccess) {
+      (void)hipMemset(gate_flags, 0, kGateSlots * sizeof(long long)); (void)hipMemset(gate_dead, 0, sizeof(int)); *gate_dead_h = 0;
+      (void)hipDeviceSynchronize();   // (once per context: the fills are complete before the first gate polls)
+      if (const char* e = getenv("COVGPU_GATE_TIMEOUT_S")) gate_timeout_s = std::max(getenv("COVGPU_GATE_TIMEOUT_MIN") ? atof(getenv("COVGPU_GATE_TIMEOUT_MIN")) : 0.01, atof(e));   // (the test of the fallback sets it below a kernel's duration)
+      gates_on = true;
+    } else gates_broken = true;   // (events)
+  }
+}
+// ---- device-flag ordering between the streams of a context (common.hpp: CholAux::record / wait)
+__global__ void k_signal(long long* flag, long long seq) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_max(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct GateArgs { const long long* f[4]; long long s[4]; int n; int* dead; int* dead_h; long long limit; };
+__global__ void k_gate(GateArgs g) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = wall_clock64();   // 100 MHz
+  for (int i = 0; i < g.n; ++i) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(g.f[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.s[i]) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 127u) == 0) {
+        if (__hip_atomic_load(g.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        if (wall_clock64() - t0 > g.limit) {
+          __hip_atomic_store(g.dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(g.dead_h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          return;
+        }
+      }
+    }
+  }
+}
+void CholAux::record(hipEvent_t e, hipStream_t s) {
+  if (!gates_on) { (void)hipEventRecord(e, s); return; }
+  int slot;
+  auto it = gate_slot.find(e);
+  if (it == gate_slot.end()) {
+    slot = (int)gate_slot.size();
+    if (slot >= kGateSlots) { (void)hipEventRecord(e, s); return; }   // (never on the shipped maps: 9 events per panel of the widest level)
+    gate_slot.emplace(e, slot);
+    if ((int)gate_seq.size() <= slot) gate_seq.resize(slot + 1, 0);
+  } else slot = it->second;
+  gate_seq[slot] = ++gate_counter;
+  hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, gate_flags + slot, gate_seq[slot]);
+  ++gate_signals;
+}
+void CholAux::wait(hipStream_t s, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3) {
+  hipEvent_t es[4] = {e0, e1, e2, e3};
+  if (!gates_on) { for (hipEvent_t e : es) if (e != nullptr) (void)hipStreamWaitEvent(s, e, 0); return; }
+  GateArgs g; g.n = 0; g.dead = gate_dead; g.dead_h = gate_dead_h; g.limit = (long long)(gate_timeout_s * 1e8);
+  for (hipEvent_t e : es) {
+    if (e == nullptr) continue;
+    auto it = gate_slot.find(e);
+    if (it == gate_slot.end()) { (void)hipStreamWaitEvent(s, e, 0); continue; }   // never recorded through a flag: whatever HIP knows of it
+    if (gate_seq[it->second] == 0) continue;
+    g.f[g.n] = gate_flags + it->second; g.s[g.n] = gate_seq[it->second]; ++g.n;
+  }
+  if (g.n == 0) return;
+  for (int i = g.n; i < 4; ++i) { g.f[i] = nullptr; g.s[i] = 0; }
+  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, g);
+  ++gate_waits;
+}
+void CholAux::gates_disable() {
+  gates_on = false; gates_broken = true;
+  gate_slot.clear(); gate_seq.clear();
+  if (gate_dead) (void)hipMemset(gate_dead, 0, sizeof(int));
+  if (gate_dead_h) *gate_dead_h = 0;
 }
 void CholAux::TriCache::clear() {
   for (int* p : list) if (p) (void)hipFree(p);
@@ -360,6 +429,10 @@ void CholAux::destroy() {
   if (ev_xb) { (void)hipEventDestroy(ev_xb); ev_xb = nullptr; }
   if (ev_xa) { (void)hipEventDestroy(ev_xa); ev_xa = nullptr; }
   if (bwd_cnt) { (void)hipFree(bwd_cnt); bwd_cnt = nullptr; }
+  if (gate_flags) { (void)hipFree(gate_flags); gate_flags = nullptr; }
+  if (gate_dead) { (void)hipFree(gate_dead); gate_dead = nullptr; }
+  if (gate_dead_h) { (void)hipHostFree(gate_dead_h); gate_dead_h = nullptr; }
+  gates_on = false; gate_slot.clear(); gate_seq.clear();
   if (bwd_scr) { (void)hipFree(bwd_scr); bwd_scr = nullptr; bwd_scr_elems = 0; }
   if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
 }
@@ -445,7 +518,10 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   //   R  rows r = everything below (t0+4 ..): full-tile kernels, needed one panel later;
   //   B  the bulk rank-256 trailing update (triangle from tile t0+4).
   hipStream_t M = st, H = ax.head, R = ax.mid, B = ax.aux;
-  auto wait = [](hipStream_t s2, hipEvent_t e) { (void)hipStreamWaitEvent(s2, e, 0); };
+  // ordering between the four streams: device flags (CholAux::record / wait) or, with COVGPU_GATES=0, HIP events. Waits of one stream that stand
+  // side by side are ONE gate launch.
+  auto wait = [&ax](hipStream_t s2, hipEvent_t e0, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr) { ax.wait(s2, e0, e1, e2, e3); };
+  auto record = [&ax](hipEvent_t e, hipStream_t s2) { ax.record(e, s2); };
   // Partial factorisation (tstop >= 0, even): eliminate tile columns [0, tstop) only; the trailing block then holds
   // its Schur complement (and, with the forward substitution riding along, b's trailing part the reduced right-hand
   // side). Used by the block-arrow pose-graph solve (k_pgo.hip).
@@ -542,6 +618,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   bool split_last = false;  // the last panel's bulk update was left running on B for the caller (DenseBatch::split_ta)
   bool tail_on_chain = false;  // the last panel ran whole on the chain's own stream: nothing of it to join (every event packet on
                                // the chain's stream is a few microseconds between two dependent kernels)
+  static const bool early_wait2_env = getenv("COVGPU_EARLY_WAIT") == nullptr || atoi(getenv("COVGPU_EARLY_WAIT")) != 0;
   static const bool trace2 = getenv("COVGPU_TRACE_PANELS") != nullptr && atoi(getenv("COVGPU_TRACE_PANELS")) >= 2;   // dev aid: per-kernel marks, tag 100 (P + 1) + k
   for (int P = 0; P < NP; ++P) {
     const int t0 = 2 * P, w = (T - t0 >= 2) ? 2 : 1;
@@ -550,28 +627,27 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     //      2x2 diagonal part was enqueued on M at the end of the previous iteration
     if (P > 0) {
       if (h1 > h0) {
-        wait(H, eC[P - 1]);                    // L rows h0.. were rest rows of panel P-1
-        wait(H, eH[P - 1]);                    // B operand: L rows t0, t0+1 — their last TRSM ran on the chain's stream
-        if (P >= 2) wait(H, eA[P - 2]);        // bulk(P-2) was the previous writer of these tiles (its first launch: these two tile columns)
+        // L rows h0.. were rest rows of panel P-1 (eC) | B operand: L rows t0, t0+1 — their last TRSM ran on the chain's stream (eH) |
+        // bulk(P-2) was the previous writer of these tiles (its first launch: these two tile columns, eA)
+        wait(H, eC[P - 1], eH[P - 1], P >= 2 ? eA[P - 2] : nullptr);
         rect(h0, h1, t0, w, t0 - 2, kd(P - 1), H, true);
         if (trace2) ax.mark(H, 100 * (P + 1) + 6);   // rows h carry panel P-1
-        (void)hipEventRecord(eHp[P], H);
+        record(eHp[P], H);
       }
       if (T > h1) {
-        wait(R, eH[P - 1]);                    // B operand: L rows t0, t0+1 (rows h of panel P-1)
-        if (P >= 2) wait(R, eA[P - 2]);
+        wait(R, eH[P - 1], P >= 2 ? eA[P - 2] : nullptr);   // B operand: L rows t0, t0+1 (rows h of panel P-1) | previous writer
         // (round 5: as quarter tiles while the launch is small — a full tile is one workgroup's 16-chunk K loop, 50-57 us of latency that the
         //  rest rows' substitution and, behind it, the bulk update and the last panel's substitution wait for)
         rect(h1, T, t0, w, t0 - 2, kd(P - 1), R, (T - h1) * w * nbt <= kRectQuarterMax);
         if (trace2) ax.mark(R, 100 * (P + 1) + 7);   // rows r carry panel P-1
-        (void)hipEventRecord(e2[P], R);  // rows r carry panel P-1's update
+        record(e2[P], R);  // rows r carry panel P-1's update
       }
     }
     if (P == Pstop) {  // only the look-ahead updates of the last eliminated panel; nothing of this panel is factored
-      (void)hipEventRecord(eH[P], H);
-      (void)hipEventRecord(eC[P], R);
-      (void)hipEventRecord(eB[P], B);
-      (void)hipEventRecord(eA[P], B);
+      record(eH[P], H);
+      record(eC[P], R);
+      record(eB[P], B);
+      record(eA[P], B);
       Plast = P;
       break;
     }
@@ -588,16 +664,16 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
       bool split_done = false;
       if (T > h0) {
-        if (P > 0) { if (h1 > h0) wait(M, eHp[P]); if (T > h1) wait(M, e2[P]); }
+        const bool early_wait2 = early_wait2_env;
+        const bool split = bt.split_ta > 0 && bt.live_h != nullptr && kd(P) > 0 && (tc.listA != nullptr || tc.listB != nullptr);
+        const bool waitedA = early_wait2 && split && P >= 1;
+        // rows h / rest rows carry panel P-1 | (beside them instead of between the substitution and the update: see the multi-panel branch) bulk(P-1)'s first launch
+        if (P > 0) wait(M, h1 > h0 ? eHp[P] : nullptr, T > h1 ? e2[P] : nullptr, waitedA ? eA[P - 1] : nullptr);
         // (measured and dropped: solving only the rows the parents' first panel receives here and the others on the bulk stream —
         //  the bulk stream's leg (rest rows, rest of the update, second half of the extend-add) is what the next level's
         //  substitutions wait for, and it only got longer: 3.37 vs 3.33 ms)
-        const bool split = bt.split_ta > 0 && bt.live_h != nullptr && kd(P) > 0 && (tc.listA != nullptr || tc.listB != nullptr);
-        static const bool early_wait2 = getenv("COVGPU_EARLY_WAIT") == nullptr || atoi(getenv("COVGPU_EARLY_WAIT")) != 0;
-        const bool waitedA = early_wait2 && split && P >= 1;
-        if (waitedA) wait(M, eA[P - 1]);   // (beside the waits above instead of between the substitution and the update: see the multi-panel branch)
         launch_trsm_sub(S, ld, t0, w, h0, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
-        if (split) { (void)hipEventRecord(eH[P], M); wait(B, eH[P]); }
+        if (split) { record(eH[P], M); wait(B, eH[P]); }
         // bulk(P-1) was the previous writer of the trailing tiles. The part of this update that stays on the chain's stream (rows < split_ta: what
         // build_list puts into the first launch beside tile columns 0, 1) only meets the FIRST launch of that bulk update — on the 5-agent map's upper levels (borders of
         // 2 000 unknowns) the whole of it is 160 us, and the next level's first panel waited for it; the rest follows it on the bulk stream anyway
@@ -639,7 +715,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
             // look-ahead across levels: the tiles the parents' first panel receives on the chain's stream, the rest on the bulk stream
             if (tc.countA > 0) syrk(M, tc.listA, tc.countA, pairsA);
             if (tc.countB > 0) syrk(B, tc.listB, tc.countB, pairs - pairsA);
-            (void)hipEventRecord(eB[P], B);
+            record(eB[P], B);
             split_done = true;
           } else {
             const bool listed = bt.live_h != nullptr && P < (int)tc.list.size() && tc.list[P] != nullptr;
@@ -650,6 +726,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       Plast = P; split_last = split_done; tail_on_chain = true;
       break;
     }
+    bool bulk_wait_rc = false;
     {
       // 256-column chain (k_panel.hip): one workgroup factors the whole diagonal block, rows h follow on the same stream by
       // block substitution, rows r on theirs — three dependent launches per panel instead of six
@@ -676,19 +753,19 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // (profiles/r05z_iteration_timeline.csv: both substitutions start 14 us after the factorisation ends), a record nobody is waiting for yet ~6.
       // Measured: 233.5 / 233.1 against 232.6 / 232.0 it/s, configs[4] 20.0 against 20.3 — within noise, so the default stays the round-4 form.
       const bool merge = merge_trsm && !chain_bound && h1 > h0 && T > h1;
-      if (!chain_bound && !merge) (void)hipEventRecord(e1[P], M);
+      if (!chain_bound && !merge) record(e1[P], M);
       bool waitedA = false;
       if (h1 > h0) {
-        if (P > 0) wait(M, eHp[P]);            // rows h carry the look-ahead update of panel P-1 (stream H, above)
-        if (merge && P > 0) wait(M, e2[P]);    // ... and the rest rows theirs (stream R)
+        // rows h carry the look-ahead update of panel P-1 (stream H, above) | ... and, merged, the rest rows theirs (stream R) | bulk(P-1)'s first launch
+        waitedA = early_wait && P >= 1 && P + 1 < NP;
+        wait(M, P > 0 ? eHp[P] : nullptr, merge && P > 0 ? e2[P] : nullptr, waitedA ? eA[P - 1] : nullptr);
         // (round 5: the wait of the next-diagonal update below for bulk(P-1)'s first launch — 30-40 us of slack — rides along with the one above.
         //  Measured: no difference (231.1 / 230.5 against 231.4 / 231.2 it/s) — a wait whose event completed long ago costs nothing; the 13-14 us
         //  between two kernels of this stream come from the RECORD behind the first when its waiter is blocked on it at that moment: DESIGN.md 4.6)
-        if (early_wait && P >= 1 && P + 1 < NP) { wait(M, eA[P - 1]); waitedA = true; }
         launch_trsm_sub(S, ld, t0, w, h0, merge ? T : h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
         if (trace2) ax.mark(M, 100 * (P + 1) + 2);   // rows h solved
       }
-      if (!chain_bound) (void)hipEventRecord(eH[P], M);
+      if (!chain_bound) record(eH[P], M);
       // ---- M: look-ahead part of SYRK(P) on the next panel's 2x2 diagonal tiles
       if (P + 1 < NP) {
         const int u0 = t0 + 2, uw = (T - u0 >= 2) ? 2 : 1;
@@ -698,20 +775,20 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       }
       // (A bulk launched at the same instant as the next diagonal update takes every workgroup slot first and the chain waits
       //  ~75 us for the first round of tiles to retire: the bulk starts after that small kernel in either regime.)
-      (void)hipEventRecord(chain_bound ? eH[P] : eRc[P], M);
+      record(chain_bound ? eH[P] : eRc[P], M);
       if (T > h1 && !merge) {
         wait(R, chain_bound ? eH[P] : e1[P]);   // (measured, round 4: waiting for rows h instead — so that the chain's substitution runs alone — 299.9 -> 297.5 it/s)
         launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab, nbp, bt.own_dims);
         if (trace2) ax.mark(R, 100 * (P + 1) + 4);   // rest rows solved
       }
       if (merge) wait(R, eH[P]);   // (eC then stands for "every row below panel P is solved" as before: its waiters — the bulk update, stream H — need not change)
-      (void)hipEventRecord(eC[P], R);
-      if (!chain_bound) wait(B, eRc[P]);   // (measured again in round 4 with the 60 us panel: without this wait 298.6 -> 292.7 it/s)
+      record(eC[P], R);
+      bulk_wait_rc = !chain_bound;   // (measured again in round 4 with the 60 us panel: without this wait 298.6 -> 292.7 it/s)
     }
     // ---- B: bulk of SYRK(P), triangle starting two tile columns further (those belong to the look-ahead)
     const int tb = t0 + 4, nt = T - tb;
     bool recA = false;
-    wait(B, eC[P]);
+    wait(B, eC[P], bulk_wait_rc ? eRc[P] : nullptr);
     if (nt > 0 && kd(P) > 0) {
       const int Ts = (nt + 7) / 8, ns = Ts * (Ts + 1) / 2, nblk = ((ns + 7) / 8) * 8 * 64;
       GemmArgs g{S, ld, t0 * kTile, kd(P), tb * kTile, tb * kTile, tb * kTile, nt, nullptr, nullptr, nullptr, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, nullptr, bt.tab, bt.own_dims};
@@ -740,7 +817,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         };
         if (cntC > 0) {   // the next-but-one panel's two tile columns first: what the chain waits for
           tri(tc.listC[P], cntC);
-          (void)hipEventRecord(eA[P], B); recA = true;
+          record(eA[P], B); recA = true;
           if (trace2) ax.mark(B, 100 * (P + 1) + 8);   // first bulk launch done
         }
         if (listed) { if (tc.count[P] > 0) tri(tc.list[P], tc.count[P]); }
@@ -752,12 +829,10 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       }
     }
     if (trace2) ax.mark(B, 100 * (P + 1) + 5);   // bulk update done
-    (void)hipEventRecord(eB[P], B);
-    if (!recA) (void)hipEventRecord(eA[P], B);
+    record(eB[P], B);
+    if (!recA) record(eA[P], B);
   }
-  if (!split_last && !tail_on_chain) wait(M, eB[Plast]);
-  if (Plast >= 1) wait(M, eB[Plast - 1]);
-  if (!tail_on_chain) { wait(M, eC[Plast]); wait(M, eH[Plast]); }
+  wait(M, !split_last && !tail_on_chain ? eB[Plast] : nullptr, Plast >= 1 ? eB[Plast - 1] : nullptr, !tail_on_chain ? eC[Plast] : nullptr, !tail_on_chain ? eH[Plast] : nullptr);
   if (!solve) return;
   // y = L^-1 b was formed along the way (potrf: y_p = L_pp^-1 b_p; every TRSM: b[rows] -= L[rows, p] y_p) and lives
   // in b[npad .. 2 npad). Remaining: L^T x = y.

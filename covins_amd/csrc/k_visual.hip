@@ -421,14 +421,19 @@ void launch_lm_lin(const DevProblem& P, double mu, hipStream_t st) {
   hipLaunchKernelGGL(k_lm_lin<kG>, dim3(nblk), dim3(kBuildThreads), 0, st, P, mu);
 }
 // the two passes that write the pose system, behind launch_lm_lin on `st`
-void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared, hipStream_t side, hipEvent_t ev_lin, hipEvent_t ev_kf) {
-  if (P.L == 0) { if (pose_system_cleared) (void)hipStreamWaitEvent(st, pose_system_cleared, 0); return; }
+void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared, hipStream_t side, hipEvent_t ev_lin, hipEvent_t ev_kf, CholAux* ax) {
+  // (ordering through the context's device flags when the caller passes its CholAux, through HIP events otherwise: common.hpp)
+  auto record = [&](hipEvent_t e, hipStream_t s) { if (ax) ax->record(e, s); else (void)hipEventRecord(e, s); };
+  auto wait = [&](hipStream_t s, hipEvent_t e0, hipEvent_t e1 = nullptr) { if (ax) ax->wait(s, e0, e1); else { if (e0) (void)hipStreamWaitEvent(s, e0, 0); if (e1) (void)hipStreamWaitEvent(s, e1, 0); } };
+  if (P.L == 0) { if (pose_system_cleared) wait(st, pose_system_cleared); return; }
   const int groups = kBuildThreads / kG, nblk = (P.L + groups - 1) / groups;
   const bool fork = side != nullptr && ev_lin != nullptr && ev_kf != nullptr && P.npairs > 0;
   hipStream_t s2 = fork ? side : st;
-  if (fork) { (void)hipEventRecord(ev_lin, st); (void)hipStreamWaitEvent(s2, ev_lin, 0); }
+  // the side stream follows the landmark linearisation; the first writers of the pose system (both streams) follow the clearing of the fronts
+  // (one gate for both on the side stream: the clearing ends long before the landmark pass)
+  if (fork) { record(ev_lin, st); wait(s2, ev_lin, pose_system_cleared); if (pose_system_cleared) wait(st, pose_system_cleared); }
+  else if (pose_system_cleared) wait(s2, pose_system_cleared);
   hipLaunchKernelGGL(k_cost_finish, dim3(1), dim3(256), 0, s2, P, nblk);
-  if (pose_system_cleared) { (void)hipStreamWaitEvent(s2, pose_system_cleared, 0); if (fork) (void)hipStreamWaitEvent(st, pose_system_cleared, 0); }  // first writers of the pose system follow
   hipLaunchKernelGGL(k_kf_reduce, dim3(P.K), dim3(64), 0, s2, P);
   if (P.npairs) {
     static const int xcd_order = getenv("COVGPU_PAIR_XCD") == nullptr || atoi(getenv("COVGPU_PAIR_XCD")) != 0;

@@ -52,6 +52,7 @@ struct PlanCache {
   NdHostPlan hp;
 };
 
+constexpr int COVGPU_ERR_GATE_TIMEOUT = -1000;   // internal (solve_any): never returned through the C ABI
 struct covgpu_group;
 struct covgpu_context {
   int device = 0;
@@ -1025,15 +1026,15 @@ static void enqueue_build(covgpu_context* c, double mu) {
   //  this pass and puts 0.12 ms onto the tail and the solve: the 0.65 GB of stores contend with the tail's re-linearisations)
   launch_zero_system(P, c->st);
   hipStream_t side = c->chol.mid;
-  (void)hipEventRecord(c->chol.ev_zero, c->st);
+  c->chol.record(c->chol.ev_zero, c->st);
   launch_lm_lin(P, mu, c->st);   // writes per-observation records, per-landmark blocks and cost partials only
   // (the head stream waits for nobody: every reader of the previous system has finished — each iteration ends with a host sync)
   if (P.nd) { launch_nd_zero(P, c->nd, c->chol.head); (void)hipMemsetAsync(P.nd_rhs, 0, c->nd.rhs_elems * sizeof(double), c->chol.head); }   // (the fronts' right-hand sides: was a fill on the chain, in front of the assembly)
   else (void)hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), c->chol.head);
-  (void)hipEventRecord(c->chol.ev_fill, c->chol.head);
+  c->chol.record(c->chol.ev_fill, c->chol.head);
   // inertial factors (one wave per factor: latency, not throughput) on the side stream beside the landmark pass; their speed-bias
   // blocks are final before anything of the pose system is touched, the pose-dimension part is gathered after the visual blocks
-  (void)hipStreamWaitEvent(side, c->chol.ev_zero, 0);
+  c->chol.wait(side, c->chol.ev_zero);
   launch_imu_build(P, side);
   if (P.vi) {
     launch_imu_gather(P, 1, side);
@@ -1043,11 +1044,11 @@ static void enqueue_build(covgpu_context* c, double mu) {
   // on the side stream beside the landmark pass (they depend on the estimate only), and the cost partials are summed there too — behind
   // the last kernel that writes one (the landmark pass's own finisher runs on the side stream when the pass forks).
   launch_edge_build(P, side);
-  launch_lm_build(P, mu, c->st, c->chol.ev_fill, side, c->chol.ev_lin, c->chol.ev_kf);
+  launch_lm_build(P, mu, c->st, c->chol.ev_fill, side, c->chol.ev_lin, c->chol.ev_kf, &c->chol);
   const bool forked = P.L > 0 && P.npairs > 0;   // (launch_lm_build's condition: its finisher of the visual cost ran on `side`)
   if (forked) launch_part_finish(P, SC_COST, 1, side);
-  (void)hipEventRecord(c->chol.ev_kf, side);
-  (void)hipStreamWaitEvent(c->st, c->chol.ev_kf, 0);
+  c->chol.record(c->chol.ev_kf, side);
+  c->chol.wait(c->st, c->chol.ev_kf);
   launch_imu_gather(P, 0, c->st);  // pose-dimension part: adds onto the blocks k_kf_reduce assigned (fixed order: visual, inertial, loop)
   launch_edge_gather(P, c->st);
   launch_finalize_diag(P, mu, P.vi ? 0 : 2, c->st);
@@ -1148,6 +1149,10 @@ static int wait_iteration(covgpu_context* c) {
   }
   HIPCHK(hipStreamSynchronize(c->st));
   HIPCHK(hipGetLastError());  // a failed kernel launch anywhere in the batch just drained surfaces here
+  if (c->chol.gate_failed()) {   // a device-flag gate between two streams gave up (CholAux::wait): what this iteration computed is not ordered
+    g_err = "solve: a device-flag gate between the context's streams timed out (COVGPU_GATE_TIMEOUT_S; COVGPU_GATES=0 selects HIP events)";
+    return COVGPU_ERR_GATE_TIMEOUT;
+  }
   if (c->coll_failed) {
     if (c->reducer) c->reducer->abort();
     if (c->peer_fail) c->peer_fail->store(1);
@@ -1170,6 +1175,8 @@ static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_r
   std::memset(res, 0, sizeof(*res));
   c->coll_failed = false; c->coll_err.clear();   // (an aborted collective fails again at once and is latched again)
   const auto t_begin = std::chrono::steady_clock::now();
+  c->chol.init();
+  if (c->sharded) c->chol.gate_timeout_s = std::max(c->chol.gate_timeout_s, 120.0);   // (a gate may stand behind a collective that waits for a slower rank)
   RC(reset_state(c));
   HIPCHK(hipMemsetAsync(P.flag + 1, 0, sizeof(int), c->st));
   launch_preintegrate(P, c->st);  // R2: repropagate at the initial bias estimate (opt_be.cpp:396)
@@ -1268,7 +1275,20 @@ static int download_impl(covgpu_context* c, covgpu_problem* p) {
 
 extern "C" int covgpu_upload(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return guarded([&] { return upload_impl(c, opt, p, false); }); }
 extern "C" int covgpu_upload_pgo(covgpu_context* c, const covgpu_options* opt, const covgpu_problem* p) { return guarded([&] { return upload_impl(c, opt, p, true); }); }
-static int solve_any(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) { return solve_impl_dev(c, opt, out); }
+// A solve whose stream ordering through device flags failed (CholAux::wait timed out: a tool that serialises kernels out of submission order, a
+// lost dispatch) is repeated ONCE with HIP events — every solve restarts from the uploaded state (reset_state) — and the context keeps events from then on.
+static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_result* res);
+static int solve_any(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) {
+  int rc = solve_impl_dev(c, opt, out);
+  if (rc == COVGPU_ERR_GATE_TIMEOUT) {
+    std::fprintf(stderr, "[covgpu] warning: device-flag stream ordering timed out; repeating the solve with HIP events (this context keeps them)\n");
+    (void)hipDeviceSynchronize();
+    c->chol.gates_disable();
+    rc = solve_impl_dev(c, opt, out);
+    if (rc == COVGPU_ERR_GATE_TIMEOUT) { g_err = "solve: stream ordering failed"; rc = COVGPU_ERR_NO_DEVICE; }
+  }
+  return rc;
+}
 extern "C" int covgpu_solve_resident(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) { return guarded([&] { return solve_any(c, opt, out); }); }
 extern "C" int covgpu_download(covgpu_context* c, covgpu_problem* p) { return guarded([&] { return download_impl(c, p); }); }
 

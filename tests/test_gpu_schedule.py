@@ -38,6 +38,26 @@ def test_look_ahead_across_levels_changes_no_bit(tmp_path, name):
         assert np.array_equal(a[k], d[k]), f"event scheme / un-cleared border tiles differ in {k}"
 
 
+@pytest.mark.parametrize("name", ["mh01", "mh12345"])
+def test_device_flag_ordering_equals_event_ordering(tmp_path, name):
+    """Round 6: the streams of a context are ordered through device flags (a signal kernel behind the producer, a polling gate in front of the
+    consumer: CholAux::record / wait) instead of HIP events. The arithmetic is untouched: both orderings give the same bits; a dependency the
+    flags miss shows up here."""
+    a = _solve(tmp_path, "gates", name)
+    b = _solve(tmp_path, "events", name, COVGPU_GATES="0")
+    for k in ("pose", "sb", "lm", "cost", "acc"):
+        assert np.array_equal(a[k], b[k]), f"device-flag ordering and event ordering differ in {k}"
+
+
+def test_gate_timeout_falls_back_to_events(tmp_path):
+    """A gate that cannot be satisfied in time raises the context's give-up flag; the solve is repeated with HIP events and the result is the
+    event ordering's (here the timeout is set below a kernel's duration: 1e-7 s)."""
+    a = _solve(tmp_path, "events", "mh01", COVGPU_GATES="0")
+    b = _solve(tmp_path, "gates_timing_out", "mh01", COVGPU_GATE_TIMEOUT_S="0.0000001", COVGPU_GATE_TIMEOUT_MIN="0")
+    for k in ("pose", "sb", "lm", "cost", "acc"):
+        assert np.array_equal(a[k], b[k])
+
+
 def test_kernel_form_switches_stay_at_rounding_level(tmp_path):
     a = _solve(tmp_path, "default", "mh01")
     # (round_3_tail: the trust-region tail as ~25 launches with the second J*v pass on the combined step, instead of k_tail.hip's

@@ -279,8 +279,13 @@ struct CholAux {
   long long gate_counter = 0;
   double gate_timeout_s = 3.0;
   long gate_signals = 0, gate_waits = 0; // launches issued (statistics)
-  void record(hipEvent_t e, hipStream_t s);
+  void record(hipEvent_t e, hipStream_t s, int tag = 0);
   void wait(hipStream_t s, hipEvent_t e0, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
+  // dev aid (COVGPU_GATE_LOG=1): every signal / gate stamps wall_clock64 (100 MHz) into a device log — an un-profiled timeline of the streams'
+  // hand-overs, printed by collect(): "S<tag>@t" a signal of record(.., tag), "G<tag of the first awaited record>@t_start+wait" a gate
+  long long* gate_log = nullptr; int gate_log_n = 0;
+  std::vector<int> gate_log_tag; std::vector<char> gate_log_kind; std::vector<int> gate_tag_of_slot;
+  static constexpr int kGateLogMax = 16384;
   bool gate_failed() const { return gate_dead_h != nullptr && *(volatile int*)gate_dead_h != 0; }
   void gates_disable();                  // after a failure: back to events for the life of the context (the flags are reset)
 };

@@ -336,17 +336,28 @@ void CholAux::init() {
       (void)hipDeviceSynchronize();   // (once per context: the fills are complete before the first gate polls)
       if (const char* e = getenv("COVGPU_GATE_TIMEOUT_S")) gate_timeout_s = std::max(getenv("COVGPU_GATE_TIMEOUT_MIN") ? atof(getenv("COVGPU_GATE_TIMEOUT_MIN")) : 0.01, atof(e));   // (the test of the fallback sets it below a kernel's duration)
       gates_on = true;
+      if (getenv("COVGPU_GATE_LOG") && hipMalloc((void**)&gate_log, 2 * (size_t)kGateLogMax * sizeof(long long)) != hipSuccess) gate_log = nullptr;
     } else gates_broken = true;   // (events)
   }
 }
 // ---- device-flag ordering between the streams of a context (common.hpp: CholAux::record / wait)
-__global__ void k_signal(long long* flag, long long seq) {
-  if (threadIdx.x == 0) __hip_atomic_fetch_max(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef COVGPU_SIGNAL_RMW
+#define COVGPU_SIGNAL_RMW 0
+#endif
+__global__ void k_signal(long long* flag, long long seq, long long* log) {
+  // (a plain agent-scope store: an event is recorded on ONE stream, so the numbers of a slot arrive in order; a returning read-modify-write here
+  //  made the boundary behind the signal 4-5 us instead of ~1: covgpu gate log, round 6)
+  if (threadIdx.x == 0) {
+    if (COVGPU_SIGNAL_RMW) __hip_atomic_fetch_max(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (log) log[0] = wall_clock64();
+  }
 }
-struct GateArgs { const long long* f[4]; long long s[4]; int n; int* dead; int* dead_h; long long limit; };
+struct GateArgs { const long long* f[4]; long long s[4]; int n; int* dead; int* dead_h; long long limit; long long* log; };
 __global__ void k_gate(GateArgs g) {
   if (threadIdx.x != 0) return;
   const long long t0 = wall_clock64();   // 100 MHz
+  struct Stamp { long long* log; long long t0; __device__ ~Stamp() { if (log) { log[0] = t0; log[1] = wall_clock64(); } } } stamp{g.log, t0};
   for (int i = 0; i < g.n; ++i) {
     unsigned spins = 0;
     while (__hip_atomic_load(g.f[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.s[i]) {
@@ -362,7 +373,7 @@ __global__ void k_gate(GateArgs g) {
     }
   }
 }
-void CholAux::record(hipEvent_t e, hipStream_t s) {
+void CholAux::record(hipEvent_t e, hipStream_t s, int tag) {
   if (!gates_on) { (void)hipEventRecord(e, s); return; }
   int slot;
   auto it = gate_slot.find(e);
@@ -373,21 +384,30 @@ void CholAux::record(hipEvent_t e, hipStream_t s) {
     if ((int)gate_seq.size() <= slot) gate_seq.resize(slot + 1, 0);
   } else slot = it->second;
   gate_seq[slot] = ++gate_counter;
-  hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, gate_flags + slot, gate_seq[slot]);
+  long long* lg = nullptr;
+  if (gate_log != nullptr && gate_log_n < kGateLogMax) {
+    lg = gate_log + 2 * (size_t)gate_log_n++; gate_log_tag.push_back(tag); gate_log_kind.push_back('S');
+    if ((int)gate_tag_of_slot.size() <= slot) gate_tag_of_slot.resize(slot + 1, 0);
+    gate_tag_of_slot[slot] = tag;
+  }
+  hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, gate_flags + slot, gate_seq[slot], lg);
   ++gate_signals;
 }
 void CholAux::wait(hipStream_t s, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3) {
   hipEvent_t es[4] = {e0, e1, e2, e3};
   if (!gates_on) { for (hipEvent_t e : es) if (e != nullptr) (void)hipStreamWaitEvent(s, e, 0); return; }
-  GateArgs g; g.n = 0; g.dead = gate_dead; g.dead_h = gate_dead_h; g.limit = (long long)(gate_timeout_s * 1e8);
+  GateArgs g; g.n = 0; g.dead = gate_dead; g.dead_h = gate_dead_h; g.limit = (long long)(gate_timeout_s * 1e8); g.log = nullptr;
+  int first_tag = 0;
   for (hipEvent_t e : es) {
     if (e == nullptr) continue;
     auto it = gate_slot.find(e);
     if (it == gate_slot.end()) { (void)hipStreamWaitEvent(s, e, 0); continue; }   // never recorded through a flag: whatever HIP knows of it
     if (gate_seq[it->second] == 0) continue;
+    if (g.n == 0 && it->second < (int)gate_tag_of_slot.size()) first_tag = gate_tag_of_slot[it->second];
     g.f[g.n] = gate_flags + it->second; g.s[g.n] = gate_seq[it->second]; ++g.n;
   }
   if (g.n == 0) return;
+  if (gate_log != nullptr && gate_log_n < kGateLogMax) { g.log = gate_log + 2 * (size_t)gate_log_n++; gate_log_tag.push_back(first_tag); gate_log_kind.push_back('G'); }
   for (int i = g.n; i < 4; ++i) { g.f[i] = nullptr; g.s[i] = 0; }
   hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, g);
   ++gate_waits;
@@ -431,6 +451,7 @@ void CholAux::destroy() {
   if (bwd_cnt) { (void)hipFree(bwd_cnt); bwd_cnt = nullptr; }
   if (gate_flags) { (void)hipFree(gate_flags); gate_flags = nullptr; }
   if (gate_dead) { (void)hipFree(gate_dead); gate_dead = nullptr; }
+  if (gate_log) { (void)hipFree(gate_log); gate_log = nullptr; }
   if (gate_dead_h) { (void)hipHostFree(gate_dead_h); gate_dead_h = nullptr; }
   gates_on = false; gate_slot.clear(); gate_seq.clear();
   if (bwd_scr) { (void)hipFree(bwd_scr); bwd_scr = nullptr; bwd_scr_elems = 0; }
@@ -455,6 +476,19 @@ void CholAux::collect() {
     fprintf(stderr, "\n");
   }
   panel_n = 0;
+  if (gate_log != nullptr && gate_log_n > 0) {   // (the caller has synchronised)
+    std::vector<long long> h(2 * (size_t)gate_log_n);
+    (void)hipMemcpy(h.data(), gate_log, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    long long t0 = h[0];
+    for (int i = 0; i < gate_log_n; ++i) t0 = std::min(t0, h[2 * i]);
+    fprintf(stderr, "covgpu gate log [us]:");
+    for (int i = 0; i < gate_log_n; ++i) {
+      if (gate_log_kind[i] == 'S') fprintf(stderr, " S%d@%.1f", gate_log_tag[i], (h[2 * i] - t0) * 0.01);
+      else fprintf(stderr, " G%d@%.1f+%.1f", gate_log_tag[i], (h[2 * i] - t0) * 0.01, (h[2 * i + 1] - h[2 * i]) * 0.01);
+    }
+    fprintf(stderr, "\n");
+    gate_log_n = 0; gate_log_tag.clear(); gate_log_kind.clear();
+  }
   if (!profile) return;
   for (size_t i = 0; i < prof_flops.size(); ++i) {
     float ms = 0;
@@ -521,7 +555,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   // ordering between the four streams: device flags (CholAux::record / wait) or, with COVGPU_GATES=0, HIP events. Waits of one stream that stand
   // side by side are ONE gate launch.
   auto wait = [&ax](hipStream_t s2, hipEvent_t e0, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr) { ax.wait(s2, e0, e1, e2, e3); };
-  auto record = [&ax](hipEvent_t e, hipStream_t s2) { ax.record(e, s2); };
+  auto record = [&ax](hipEvent_t e, hipStream_t s2, int tag = 0) { ax.record(e, s2, tag); };
   // Partial factorisation (tstop >= 0, even): eliminate tile columns [0, tstop) only; the trailing block then holds
   // its Schur complement (and, with the forward substitution riding along, b's trailing part the reduced right-hand
   // side). Used by the block-arrow pose-graph solve (k_pgo.hip).
@@ -632,7 +666,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         wait(H, eC[P - 1], eH[P - 1], P >= 2 ? eA[P - 2] : nullptr);
         rect(h0, h1, t0, w, t0 - 2, kd(P - 1), H, true);
         if (trace2) ax.mark(H, 100 * (P + 1) + 6);   // rows h carry panel P-1
-        record(eHp[P], H);
+        record(eHp[P], H, 100 * (P + 1) + 17);
       }
       if (T > h1) {
         wait(R, eH[P - 1], P >= 2 ? eA[P - 2] : nullptr);   // B operand: L rows t0, t0+1 (rows h of panel P-1) | previous writer
@@ -640,14 +674,14 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         //  rest rows' substitution and, behind it, the bulk update and the last panel's substitution wait for)
         rect(h1, T, t0, w, t0 - 2, kd(P - 1), R, (T - h1) * w * nbt <= kRectQuarterMax);
         if (trace2) ax.mark(R, 100 * (P + 1) + 7);   // rows r carry panel P-1
-        record(e2[P], R);  // rows r carry panel P-1's update
+        record(e2[P], R, 100 * (P + 1) + 14);  // rows r carry panel P-1's update
       }
     }
     if (P == Pstop) {  // only the look-ahead updates of the last eliminated panel; nothing of this panel is factored
-      record(eH[P], H);
-      record(eC[P], R);
-      record(eB[P], B);
-      record(eA[P], B);
+      record(eH[P], H, 100 * (P + 1) + 10);
+      record(eC[P], R, 100 * (P + 1) + 12);
+      record(eB[P], B, 100 * (P + 1) + 11);
+      record(eA[P], B, 100 * (P + 1) + 18);
       Plast = P;
       break;
     }
@@ -673,7 +707,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         //  the bulk stream's leg (rest rows, rest of the update, second half of the extend-add) is what the next level's
         //  substitutions wait for, and it only got longer: 3.37 vs 3.33 ms)
         launch_trsm_sub(S, ld, t0, w, h0, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
-        if (split) { record(eH[P], M); wait(B, eH[P]); }
+        if (split) { record(eH[P], M, 100 * (P + 1) + 10); wait(B, eH[P]); }
         // bulk(P-1) was the previous writer of the trailing tiles. The part of this update that stays on the chain's stream (rows < split_ta: what
         // build_list puts into the first launch beside tile columns 0, 1) only meets the FIRST launch of that bulk update — on the 5-agent map's upper levels (borders of
         // 2 000 unknowns) the whole of it is 160 us, and the next level's first panel waited for it; the rest follows it on the bulk stream anyway
@@ -715,7 +749,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
             // look-ahead across levels: the tiles the parents' first panel receives on the chain's stream, the rest on the bulk stream
             if (tc.countA > 0) syrk(M, tc.listA, tc.countA, pairsA);
             if (tc.countB > 0) syrk(B, tc.listB, tc.countB, pairs - pairsA);
-            record(eB[P], B);
+            record(eB[P], B, 100 * (P + 1) + 11);
             split_done = true;
           } else {
             const bool listed = bt.live_h != nullptr && P < (int)tc.list.size() && tc.list[P] != nullptr;
@@ -753,7 +787,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // (profiles/r05z_iteration_timeline.csv: both substitutions start 14 us after the factorisation ends), a record nobody is waiting for yet ~6.
       // Measured: 233.5 / 233.1 against 232.6 / 232.0 it/s, configs[4] 20.0 against 20.3 — within noise, so the default stays the round-4 form.
       const bool merge = merge_trsm && !chain_bound && h1 > h0 && T > h1;
-      if (!chain_bound && !merge) record(e1[P], M);
+      if (!chain_bound && !merge) record(e1[P], M, 100 * (P + 1) + 13);
       bool waitedA = false;
       if (h1 > h0) {
         // rows h carry the look-ahead update of panel P-1 (stream H, above) | ... and, merged, the rest rows theirs (stream R) | bulk(P-1)'s first launch
@@ -765,7 +799,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         launch_trsm_sub(S, ld, t0, w, h0, merge ? T : h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
         if (trace2) ax.mark(M, 100 * (P + 1) + 2);   // rows h solved
       }
-      if (!chain_bound) record(eH[P], M);
+      if (!chain_bound) record(eH[P], M, 100 * (P + 1) + 10);
       // ---- M: look-ahead part of SYRK(P) on the next panel's 2x2 diagonal tiles
       if (P + 1 < NP) {
         const int u0 = t0 + 2, uw = (T - u0 >= 2) ? 2 : 1;
@@ -775,14 +809,14 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       }
       // (A bulk launched at the same instant as the next diagonal update takes every workgroup slot first and the chain waits
       //  ~75 us for the first round of tiles to retire: the bulk starts after that small kernel in either regime.)
-      record(chain_bound ? eH[P] : eRc[P], M);
+      record(chain_bound ? eH[P] : eRc[P], M, 100 * (P + 1) + (chain_bound ? 10 : 16));
       if (T > h1 && !merge) {
         wait(R, chain_bound ? eH[P] : e1[P]);   // (measured, round 4: waiting for rows h instead — so that the chain's substitution runs alone — 299.9 -> 297.5 it/s)
         launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab, nbp, bt.own_dims);
         if (trace2) ax.mark(R, 100 * (P + 1) + 4);   // rest rows solved
       }
       if (merge) wait(R, eH[P]);   // (eC then stands for "every row below panel P is solved" as before: its waiters — the bulk update, stream H — need not change)
-      record(eC[P], R);
+      record(eC[P], R, 100 * (P + 1) + 12);
       bulk_wait_rc = !chain_bound;   // (measured again in round 4 with the 60 us panel: without this wait 298.6 -> 292.7 it/s)
     }
     // ---- B: bulk of SYRK(P), triangle starting two tile columns further (those belong to the look-ahead)
@@ -817,7 +851,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
         };
         if (cntC > 0) {   // the next-but-one panel's two tile columns first: what the chain waits for
           tri(tc.listC[P], cntC);
-          record(eA[P], B); recA = true;
+          record(eA[P], B, 100 * (P + 1) + 18); recA = true;
           if (trace2) ax.mark(B, 100 * (P + 1) + 8);   // first bulk launch done
         }
         if (listed) { if (tc.count[P] > 0) tri(tc.list[P], tc.count[P]); }
@@ -829,8 +863,8 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       }
     }
     if (trace2) ax.mark(B, 100 * (P + 1) + 5);   // bulk update done
-    record(eB[P], B);
-    if (!recA) record(eA[P], B);
+    record(eB[P], B, 100 * (P + 1) + 11);
+    if (!recA) record(eA[P], B, 100 * (P + 1) + 18);
   }
   wait(M, !split_last && !tail_on_chain ? eB[Plast] : nullptr, Plast >= 1 ? eB[Plast - 1] : nullptr, !tail_on_chain ? eC[Plast] : nullptr, !tail_on_chain ? eH[Plast] : nullptr);
   if (!solve) return;

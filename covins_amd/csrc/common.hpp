@@ -321,6 +321,7 @@ struct DenseBatch {
   // then starts them from zero instead of reading them (GemmArgs::beta0). beta0_off[front of the batch] -> first entry of its lower-triangular
   // tile map in beta0 (1: some child adds into the tile — it is cleared and read as before)
   const int* beta0_off = nullptr; const int* beta0 = nullptr;
+  const int* plist = nullptr; const int* pbig_h = nullptr; const int* psmall_h = nullptr;   // NdLevel::plist / pbig / psmall
   int own_max = 0;                 // > 0: largest real interior order over the batch — columns beyond it are identity padding in EVERY
                                    // matrix (L = I, block inverses = I, y = 0 already in place), so the panel kernel factors only the
                                    // 16-column blocks that hold a real column and skips all-padding panels
@@ -332,7 +333,8 @@ void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStrea
 // 256-column panel chain (k_panel.hip): with it the Linv buffer holds, per tile, the eight 16x16 diagonal-block inverses
 // instead of the 128x128 inverse. COVGPU_PANEL=0 selects the round-2a chain (two 128-column potrf + inverse per panel).
 void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
-                        hipStream_t st, const long long* btab = nullptr, int nb = -1);   // nb: 16-column blocks to factor (-1: the whole panel)
+                        hipStream_t st, const long long* btab = nullptr, int nb = -1, const int* own = nullptr, const int* list = nullptr, int n_big = 0,
+                        int n_small = 0);   // nb: 16-column blocks to factor (-1: the whole panel); own / list / n_big / n_small: k_panel.hip (round 6)
 void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, double* x, int ncol, int nbt, size_t sM, size_t sR, hipStream_t st,
                       const long long* btab, const int* live, int tI, BwdXfer xf = BwdXfer());
 void launch_bwd_front(const double* S, int tI, int ntiles, int nchunk, double* y, const double* Linv, int nbt, size_t sL, size_t sR, hipStream_t st,
@@ -390,6 +392,9 @@ struct NdLevel {
   int* live = nullptr;                    // [n][2] device: real interior tiles | real border tiles (GemmArgs::live)
   std::vector<int> live_h;
   int own_max = 0;                        // largest real interior order of the batch (DenseBatch::own_max)
+  // k_potrf_panel's front lists (round 6): the level's fronts (index in the batch) by DEcreasing interior order; per 256-column panel P the first
+  // pbig[P] of them have more than 128 real columns in that panel (sixteen-wave form), the next psmall[P] have 1 .. 128 (four-wave form), the rest none
+  int* plist = nullptr; std::vector<int> plist_h, pbig, psmall;
   int ext_first = 0, ext_count = 0;       // extend-add work list (NdDev::ext) for the SUBTREE children of this level's fronts
   int ext_countA = 0;                     // ... of which the first ext_countA tiles lie in the fronts' first 256 rows (first panel)
   int split_ta = 0;                       // border tiles (128) of this level's fronts that reach their parents' first 256 columns (max)

@@ -637,7 +637,8 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       while (ax.prof_ev2.size() < 2 * (ax.prof_flops2.size() + 1)) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev2.push_back(e); }
       (void)hipEventRecord(ax.prof_ev2[2 * ax.prof_flops2.size()], M);
     }
-    launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp);
+    if (bt.plist != nullptr) launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp, bt.own_dims, bt.plist, bt.pbig_h[t0 / 2], bt.psmall_h[t0 / 2]);
+    else launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp);
     if (prof) {
       double fl = 0.0;
       for (int a = 0; a < nbt; ++a) {

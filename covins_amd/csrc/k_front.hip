@@ -88,6 +88,18 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& 
       ++i;
     }
     L.linv_off = loff; loff += (size_t)L.n * L.nI * kTile;
+    {  // front lists of the panel factorisation (NdLevel::plist)
+      L.plist_h.resize(L.n);
+      for (int k = 0; k < L.n; ++k) L.plist_h[k] = k;
+      std::stable_sort(L.plist_h.begin(), L.plist_h.end(), [&](int a, int b) { return dev.h_own_dims[L.first + a] > dev.h_own_dims[L.first + b]; });
+      const int np = L.nI / 256;
+      L.pbig.assign(np, 0); L.psmall.assign(np, 0);
+      for (int k = 0; k < L.n; ++k)
+        for (int P = 0; P < np; ++P) {
+          const int real = dev.h_own_dims[L.first + k] - 256 * P;
+          if (real > 128) ++L.pbig[P]; else if (real > 0) ++L.psmall[P];
+        }
+    }
   }
   if (Hs >= nlev) dev.M_sub = moff;
   dev.M_elems = moff; dev.linv_elems = loff;
@@ -162,6 +174,18 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& 
           if (any) rows.push_back(t);
         }
         for (int a : rows) for (int b : rows) if (b <= a) mark[(size_t)a * T + b] = 1;
+      }
+      // Round 6: the border x border part of a front is never cleared (k_nd_zero) — the extend-add STORES every entry of the 64-tiles it visits there
+      // (children's sum, or zero), so it must visit every lower 64-tile of each 128-tile some child reaches (NdDev::bb marks those for the first
+      // trailing update, which reads them; the others it starts from zero itself)
+      if (&cptr == &dev.h_cptr && !is_top(order[i])) {
+        const int t0 = dev.h_nI[i] / 64;
+        for (int A = t0; A < T; A += 2)
+          for (int B = t0; B <= A; B += 2) {
+            bool any = false;
+            for (int a = A; a < std::min(T, A + 2); ++a) for (int b = B; b < std::min(T, B + 2); ++b) if (b <= a && mark[(size_t)a * T + b]) any = true;
+            if (any) for (int a = A; a < std::min(T, A + 2); ++a) for (int b = B; b < std::min(T, B + 2); ++b) if (b <= a) mark[(size_t)a * T + b] = 1;
+          }
       }
       for (int a = 0; a < T; ++a) for (int b = 0; b <= a; ++b) if (mark[(size_t)a * T + b]) { tiles.push_back(i); tiles.push_back(a); tiles.push_back(b); }
     }
@@ -251,7 +275,12 @@ struct NdLevArgs {
 // tiles of the all-padding panels (k_potrf_panel factors every panel of every front of the batch).
 // (ONE launch over the tiles of all levels — a level per launch was seven dependent host enqueues at the head of every linearisation,
 //  with the chip idle behind them: blocks [blk0[l], blk0[l + 1]) belong to level l, tile (tr, tc) of its front number `fz`)
-struct NdZeroArgs { int nlev; int first[24], n[24], nI[24], T[24]; long long blk0[25]; const int *own_dims, *st_dims, *bb_off, *bb; };
+struct NdZeroArgs { int nlev; int first[24], n[24], nI[24], T[24]; long long blk0[25]; const int *own_dims, *st_dims, *bb_off, *bb; int first_top; };
+// the extend-add stores the border x border tiles whole instead of k_nd_zero clearing them (COVGPU_STORE_BORDER=0: round 5's clearing; needs COVGPU_BETA0 on)
+static bool nd_store_border() {
+  static const bool v = (getenv("COVGPU_STORE_BORDER") == nullptr || atoi(getenv("COVGPU_STORE_BORDER")) != 0) && (getenv("COVGPU_BETA0") == nullptr || atoi(getenv("COVGPU_BETA0")) != 0);
+  return v;
+}
 __global__ __launch_bounds__(256) void k_nd_zero(DevProblem P, NdZeroArgs z) {
   int l = 0;
   while (l + 1 < z.nlev && (long long)blockIdx.x >= z.blk0[l + 1]) ++l;
@@ -260,12 +289,17 @@ __global__ __launch_bounds__(256) void k_nd_zero(DevProblem P, NdZeroArgs z) {
   const int fz = q / (T * T), rem = q - fz * T * T, tr = rem / T, tc = rem - tr * T;
   if (tc > tr) return;
   const int node = z.first[l] + fz;
-  const int nIt = z.nI[l] / kTile, lo2 = 2 * ((z.own_dims[node] + 2 * kTile - 1) / (2 * kTile)), lb = (z.st_dims[node] + kTile - 1) / kTile;
+  // (a front of at most 128 unknowns: nothing reads its second tile column below the panel's own 2x2 tiles — the panel factorisation, the
+  //  substitutions and the rank updates all stop at the front's own last real 16-column block)
+  const int own_n = z.own_dims[node];
+  const int nIt = z.nI[l] / kTile, lo2 = own_n <= kTile ? 1 : 2 * ((own_n + 2 * kTile - 1) / (2 * kTile)), lb = (z.st_dims[node] + kTile - 1) / kTile;
   auto live = [&](int t) { return t < lo2 || (t >= nIt && t - nIt < lb); };
   const bool pad_diag = tr >= lo2 && tr < nIt && tc >= (tr & ~1);
   if (!((live(tr) && live(tc)) || pad_diag)) return;
-  // a border x border tile no child adds into: the first panel's trailing update starts it from zero itself (GemmArgs::beta0)
-  if (z.bb != nullptr && tc >= nIt && !z.bb[z.bb_off[node] + (tr - nIt) * (tr - nIt + 1) / 2 + (tc - nIt)]) return;
+  // a border x border tile no child adds into: the first panel's trailing update starts it from zero itself (GemmArgs::beta0); one that a child
+  // does add into is written whole by the extend-add (round 6: store_border) — except in the replicated top fronts of a sharded solve, which are
+  // summed over the ranks as they stand
+  if (z.bb != nullptr && tc >= nIt && (node < z.first_top || !z.bb[z.bb_off[node] + (tr - nIt) * (tr - nIt + 1) / 2 + (tc - nIt)])) return;
   const size_t ld = (size_t)P.nd_ntab[2 * node + 1];
   double* M = P.nd_M + P.nd_ntab[2 * node] + (size_t)tr * kTile * ld + (size_t)tc * kTile;
   const int own = z.own_dims[node];
@@ -315,7 +349,7 @@ __global__ __launch_bounds__(256) void k_nd_assemble(DevProblem P, const int* __
 // One workgroup per 64x64 tile of a host-built list (only tiles some child contributes to); a thread owns a 4x4 sub-grid.
 // Round 5: tile and child descriptors flattened on the host (NdDev::extw / extc): tile -> child entry -> row map -> value, with the child entry two
 // and the row maps one child ahead of the gather — the kernel is a chain of dependent loads on the critical path of every level transition.
-__global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, const int* __restrict__ work, const int* __restrict__ child, int second_pass) {
+__global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, const int* __restrict__ work, const int* __restrict__ child, int second_pass, int store_border) {
   const int4 w0 = reinterpret_cast<const int4*>(work)[2 * (size_t)blockIdx.x], w1 = reinterpret_cast<const int4*>(work)[2 * (size_t)blockIdx.x + 1];
   const size_t foff = (size_t)(unsigned)w0.x | ((size_t)(unsigned)w0.y << 32);
   const size_t ld = (size_t)w0.z;
@@ -379,10 +413,12 @@ __global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, co
       }
     }
   }
+  // border x border tiles (no original entries, never cleared: k_nd_zero): EVERY entry of the lower part is stored — what no child reaches is zero
+  const bool store_all = !own_cols && store_border != 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (hit[i][j]) F[(size_t)rr[i] * ld + cc[j]] = v[i][j];
+    for (int j = 0; j < 4; ++j) if (hit[i][j] || (store_all && rr[i] < nrow && cc[j] <= rr[i])) F[(size_t)rr[i] * ld + cc[j]] = v[i][j];
     if (rv[i] != 0.0) P.nd_rhs[rhs_p + rr[i]] += rv[i];
   }
 }
@@ -441,6 +477,8 @@ void launch_nd_zero(const DevProblem& P, const NdDev& nd, hipStream_t st) {
   NdZeroArgs z;
   static const bool beta0 = getenv("COVGPU_BETA0") == nullptr || atoi(getenv("COVGPU_BETA0")) != 0;   // (A/B switch; k_front.hip's batch() reads the same)
   z.nlev = 0; z.blk0[0] = 0; z.own_dims = nd.own_dims; z.st_dims = nd.st_dims; z.bb_off = nd.bb_off; z.bb = beta0 ? nd.bb : nullptr;
+  // nodes are numbered in level order: the first node of the first top level (sharded solve) — below it the extend-add stores the border tiles
+  z.first_top = !nd_store_border() ? 0 : (nd.top_lev0 < (int)nd.lev.size() ? nd.lev[nd.top_lev0].first : nd.nnodes);
   auto flush = [&] {
     if (z.nlev > 0 && z.blk0[z.nlev] > 0) hipLaunchKernelGGL(k_nd_zero, dim3((unsigned)z.blk0[z.nlev]), dim3(256), 0, st, P, z);
     z.nlev = 0; z.blk0[0] = 0;
@@ -487,6 +525,8 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     bt.live = L.live; bt.tI = L.nI / kTile; bt.live_h = L.live_h.data();
     static const bool beta0 = getenv("COVGPU_BETA0") == nullptr || atoi(getenv("COVGPU_BETA0")) != 0;
     if (beta0 && nd.bb != nullptr) { bt.beta0_off = nd.bb_off + L.first; bt.beta0 = nd.bb; }
+    static const bool plists = getenv("COVGPU_POTRF_LISTS") == nullptr || atoi(getenv("COVGPU_POTRF_LISTS")) != 0;
+    if (plists && L.plist != nullptr) { bt.plist = L.plist; bt.pbig_h = L.pbig.data(); bt.psmall_h = L.psmall.data(); }
     bt.tab = P.nd_ntab + 2 * (size_t)L.first; bt.tri_slot = l; bt.own_max = L.own_max; bt.own_dims = nd.own_dims + L.first; bt.own_dims_h = nd.h_own_dims.data() + L.first;
     return bt;
   };
@@ -499,7 +539,7 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     if (part == 2) { first += countA; count -= countA; }
     if (count > 0)
       hipLaunchKernelGGL(k_nd_extend, dim3(count), dim3(256), 0, s2, P, lev_args(P, nd, l), (const int*)(nd.extw + 8 * (size_t)first),
-                         (const int*)(top_children ? nd.extc2 : nd.extc), top_children ? 1 : 0);
+                         (const int*)(top_children ? nd.extc2 : nd.extc), top_children ? 1 : 0, (!top_children && l < ltop && nd_store_border()) ? 1 : 0);
   };
   // split: the trailing update of this level's last panel is split for the look-ahead into the next level (DenseBatch::split_ta)
   auto factor = [&](int l, bool split, hipEvent_t pre_trsm) {

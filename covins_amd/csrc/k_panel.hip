@@ -66,6 +66,9 @@ constexpr int PROWS = 256;
 constexpr int NW = 16;                 // waves of the panel workgroup: wave 0 carries the serial chain, waves 1..15 own the trailing tiles
 constexpr int NSLOT = 10;              // tile slots per wave: 119 tiles (i, k), 1 <= k <= i <= 15 except (1,1), ~30 per SIMD, SIMD 0 with three tile waves
 constexpr size_t kPanelLds = (size_t)(2 * PROWS * PP + 256 + 256 + 32 + 16 * PP) * sizeof(double);
+// the four-wave form for fronts of at most 128 real columns in the panel (round 6): one chain wave + three tile waves, 128 panel rows
+constexpr int PROWS4 = 128;
+constexpr size_t kPanelLds4 = (size_t)(2 * PROWS4 * PP + 256 + PROWS4 + 32 + 16 * PP) * sizeof(double);
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL store to be
 // acknowledged (s_waitcnt vmcnt(0): ~1 us per step here, where L / Dinv / y stream out while the factorisation goes on
@@ -147,6 +150,16 @@ constexpr PanelTileTab make_panel_tiles() {
   return t;
 }
 __constant__ PanelTileTab kPanelTile = make_panel_tiles();
+// the 27 trailing tiles of an 8-block panel (i, k), 1 <= k <= i <= 7 except (1,1), column-major (the four-wave form)
+struct PanelTileTab8 { int v[27]; };
+constexpr PanelTileTab8 make_panel_tiles8() {
+  PanelTileTab8 t{};
+  int u = 0;
+  for (int k = 1; k < 8; ++k)
+    for (int i = k; i < 8; ++i) { if (i == 1 && k == 1) continue; t.v[u++] = i | (k << 8); }
+  return t;
+}
+__constant__ PanelTileTab8 kPanelTile8 = make_panel_tiles8();
 
 // Panel j (LDS, complete: block column j of the factor from row o = 16 j on, raw diagonal block + its column factors `rs`) leaves for
 // memory, and the right-hand side below it takes y_j (in sRhs[o ..)): thread u of NT, half rows of 64 bytes.
@@ -193,17 +206,33 @@ COV_DEV void panel_out(const double* pan, double* sRhs, const double* rs, double
 // tile. (Round 1 found the product with a 128x128 explicit inverse too inaccurate for this system; a 16x16 block inverse formed by
 // substitution is the standard blocked-TRSM building block and tests/test_gpu_parity.py::test_mfma_cholesky_ill_conditioned_blocks and
 // the full-size parity tests hold with it.)
-__global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
-                                                         const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR,
-                                                         const long long* __restrict__ btab) {
-  if (btab != nullptr) { M += (size_t)btab[2 * blockIdx.x]; ld = (size_t)btab[2 * blockIdx.x + 1]; }  // fronts of unequal order (GemmArgs::btab)
-  else M += (size_t)blockIdx.x * bsM;
-  Dinv_out += (size_t)blockIdx.x * bsL;
-  if (rhs != nullptr) { rhs += (size_t)blockIdx.x * bsR; yout += (size_t)blockIdx.x * bsR; }
-  extern __shared__ __attribute__((aligned(16))) double sP[];  // panel[2][256][PP] | sDv[16][16] | sRhs[256] | sdd[2][16] | sDg[16][PP]
+// Round 6: (i) every front factors only ITS OWN real 16-column blocks of the panel (`own`: the launch-wide nb is the widest front's; a front's
+// further blocks are identity padding — L = I, block inverses = I, y = 0 are in place and stay), and a launch lists only the fronts that have
+// a real column in this panel (`list`): on the 12-agent map a level mixes 1 000-2 000 fronts of 9 .. 700 unknowns, and every one of them ran all
+// the steps of the widest in every panel of the level — 16 of that map's 38 ms per iteration. (ii) NWV = 4: the same kernel with ONE chain wave and
+// THREE tile waves (27 trailing tiles of an 8-block panel, 128 panel rows, 42 KB of LDS) for fronts of at most 128 real columns in the panel — the
+// speed-bias segments and the small pose fronts, thousands per level: three workgroups per CU instead of one. The arithmetic of a front is the
+// same in both forms (same tile updates in the same order).
+template <int NWV>
+COV_DEV void potrf_panel_body(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
+                              const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR,
+                              const long long* __restrict__ btab, const int* __restrict__ own, const int* __restrict__ list) {
+  constexpr int PROWS = (NWV == 16) ? 256 : PROWS4;   // (shadows the 16-wave constant)
+  constexpr int NTW = (NWV == 16) ? 12 : 3;           // tile waves
+  const int front = list != nullptr ? list[blockIdx.x] : (int)blockIdx.x;
+  if (own != nullptr) {
+    const int real = __builtin_amdgcn_readfirstlane(own[front]) - k0;
+    nb = min(nb, (real + PB - 1) / PB);
+    if (nb <= 0) return;   // (workgroup-uniform) no real column of this front in the panel
+  }
+  if (btab != nullptr) { M += (size_t)btab[2 * front]; ld = (size_t)btab[2 * front + 1]; }  // fronts of unequal order (GemmArgs::btab)
+  else M += (size_t)front * bsM;
+  Dinv_out += (size_t)front * bsL;
+  if (rhs != nullptr) { rhs += (size_t)front * bsR; yout += (size_t)front * bsR; }
+  extern __shared__ __attribute__((aligned(16))) double sP[];  // panel[2][PROWS][PP] | sDv[16][16] | sRhs[PROWS] | sdd[2][16] | sDg[16][PP]
   double* sDv = sP + 2 * PROWS * PP;
   double* sRhs = sDv + 256;
-  double* sdd = sRhs + 256;     // [2][16] 1/sqrt of the block's 16 pivots
+  double* sdd = sRhs + PROWS;   // [2][16] 1/sqrt of the block's 16 pivots
   double* sDg = sdd + 32;       // [16][PP] the diagonal tile wave 0 takes over next (panels before the current one applied)
   const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int n = PB * nb;
@@ -215,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M,
   // own no tiles. The tile waves only ISSUE the loads of their tiles before the barrier behind the prologue (first needed at the end of
   // step 0) and go on to barrier X(0): the chain wave starts its sweep one memory round trip after the launch, beside them.
   auto fill_lds = [&]() {
-    const int fid = 64 * (wave >> 2) + (tid0 & 63);   // 0 .. 255
+    const int fid = (NWV == 16) ? 64 * (wave >> 2) + (tid0 & 63) : tid0;   // 0 .. 255 (four-wave form: every wave fills, then the tile waves load their tiles)
     double fv[PB], frhs = 0.0, fdg = 0.0;
 #pragma unroll
     for (int c = 0; c < PB; ++c) fv[c] = 0.0;
@@ -237,7 +266,7 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M,
 #pragma unroll
       for (int c = 0; c < PB; c += 2) *reinterpret_cast<double2*>(sP + fid * PP + c) = double2{fv[c], fv[c + 1]};
     }
-    sRhs[fid] = frhs;
+    if (fid < PROWS) sRhs[fid] = frhs;
     if (nb > 1) sDg[(fid >> 4) * PP + (fid & 15)] = fdg;
     // (no barrier of its own: the first one everybody meets is X(0); before it the chain wave only reads rows 0..15 of block column 0,
     //  which its own lanes have just written)
@@ -335,8 +364,8 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M,
     return;
   }
 
-  const int jsplit = nb > 8 ? nb - 8 : 0;   // steps before it are bound by the matrix pipes (the chain wave waits), the last eight by the chain
-  if ((wave & 3) == 0) {
+  const int jsplit = (NWV == 16 && nb > 8) ? nb - 8 : 0;   // steps before it are bound by the matrix pipes (the chain wave waits), the last eight by the chain
+  if (NWV == 16 && (wave & 3) == 0) {
     // ================================================================ SIMD 0's other waves: y_j, and the way out of panel j while the steps
     // are bound by the matrix pipes (the chain wave, which takes every issue slot of this SIMD during its sweep, then waits for the tiles)
     fill_lds();
@@ -366,15 +395,17 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M,
   // ================================================================ the tile waves
   PPROBE_DECL();
   const int lane0 = tid0 & 63, fr0 = lane0 & 15, fk0 = lane0 >> 4;
-  const int tw = 3 * (wave >> 2) + (wave & 3) - 1;   // 0 .. 11
+  const int tw = (NWV == 16) ? 3 * (wave >> 2) + (wave & 3) - 1 : wave - 1;   // 0 .. NTW-1
+  if (NWV != 16) fill_lds();
   // ---- tile slots of this wave (wave-uniform, packed i | k << 8; k = 99: none): the 119 tiles (i, k), 1 <= k <= i <= 15 except (1,1), in
   // column-major order, round-robin: every SIMD carries the same number of tiles at every step
   int tik[NSLOT];
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
-    const int u = 12 * s + tw;
-    const int pk = kPanelTile.v[u < 119 ? u : 0];   // (a table: the search for the column was ~1 us of scalar loops per wave)
-    tik[s] = (u < 119 && (pk & 255) < nb) ? pk : (99 << 8);
+    const int u = NTW * s + tw;
+    constexpr int NTILE = (NWV == 16) ? 119 : 27;
+    const int pk = (NWV == 16) ? kPanelTile.v[u < NTILE ? u : 0] : kPanelTile8.v[u < NTILE ? u : 0];   // (a table: the search for the column was ~1 us of scalar loops per wave)
+    tik[s] = (u < NTILE && (pk & 255) < nb) ? pk : (99 << 8);
   }
   // ---- the wave's trailing tiles into registers: the loads are only ISSUED here (see above): addresses from four per-lane offsets (and
   // four mirrored ones for the diagonal tiles, kept symmetric) and a wave-uniform base per tile; a slot without a tile loads tile (1,1)
@@ -408,7 +439,17 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M,
     const int fr = lq & 15, fk = lq >> 4;
     PARR(j, tp0);
     lds_barrier();  // ---- X(j)
-    for (int i = j + 2 + tw; i < nb; i += 12) {  // X(i,j) for i >= j+2
+    if (NWV != 16 && tw == 0 && lq < PB) {  // y_j = Dinv_j b_j (the 16-wave form: wave 4)
+      const int o = PB * j;
+      double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+#pragma unroll
+      for (int k = 0; k < PB; k += 4) {
+        y0 += sDv[lq * PB + k] * sRhs[o + k]; y1 += sDv[lq * PB + k + 1] * sRhs[o + k + 1];
+        y2 += sDv[lq * PB + k + 2] * sRhs[o + k + 2]; y3 += sDv[lq * PB + k + 3] * sRhs[o + k + 3];
+      }
+      sRhs[o + lq] = (y0 + y1) + (y2 + y3);
+    }
+    for (int i = j + 2 + tw; i < nb; i += NTW) {  // X(i,j) for i >= j+2
       double* tp = cur + (PB * i + fr) * PP + 4 * fk;
       const double* dp = dv + fr * PB + 4 * fk;
       const double2 ta = *reinterpret_cast<const double2*>(tp), tc = *reinterpret_cast<const double2*>(tp + 2);
@@ -442,10 +483,22 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M,
     PPROBE_ACC(6, tq2);
     if (wave == PPROBE_WAVE) PSTEP(3, j, tp0);
     const long long tq3 = PPROBE_T0();
-    if (j >= jsplit) panel_out<768>(cur, sRhs, sdd + PB * (j & 1), Mg, ld, PB * j, n, 64 * tw + lq, yout != nullptr ? yout + k0 : nullptr);   // (the tile waves have the time now)
+    if (j >= jsplit) panel_out<64 * NTW>(cur, sRhs, sdd + PB * (j & 1), Mg, ld, PB * j, n, 64 * tw + lq, yout != nullptr ? yout + k0 : nullptr);   // (the tile waves have the time now)
     PPROBE_ACC(7, tq3);
   }
   PPROBE_FLUSH();
+}
+
+__global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
+                                                         const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR,
+                                                         const long long* __restrict__ btab, const int* __restrict__ own, const int* __restrict__ list) {
+  potrf_panel_body<16>(M, ld, k0, nb, Dinv_out, flag, rhs, yout, bsM, bsL, bsR, btab, own, list);
+}
+// (three workgroups per CU: 42 KB of LDS each; at most 168 registers per wave)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_potrf_panel4(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
+                                                         const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR,
+                                                         const long long* __restrict__ btab, const int* __restrict__ own, const int* __restrict__ list) {
+  potrf_panel_body<4>(M, ld, k0, nb, Dinv_out, flag, rhs, yout, bsM, bsL, bsR, btab, own, list);
 }
 
 struct TrsmSubArgs {
@@ -969,16 +1022,30 @@ void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, dou
 }
 
 void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
-                        hipStream_t st, const long long* btab, int nb) {
+                        hipStream_t st, const long long* btab, int nb, const int* own, const int* list, int n_big, int n_small) {
   if (nb < 0) nb = 8 * w;
   if (nb == 0) return;  // an all-padding panel of every front of the batch: L = I, Dinv = I, y = 0 are in place
   static bool once = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds4);
     return true;
   }();
   (void)once;
-  hipLaunchKernelGGL(k_potrf_panel, dim3(nbt), dim3(64 * NW), kPanelLds, st, S, ld, t0 * kTile, nb, Linv + (size_t)t0 * kTile * kTile, flag,
-                     (const double*)b, b ? b + npad : nullptr, sM, sL, sR, btab);
+  double* Lp = Linv + (size_t)t0 * kTile * kTile;
+  const double* yb = b ? b + npad : nullptr;
+  if (list == nullptr) {   // every front of the batch in the sixteen-wave form (arrow blocks of the pose graph, the dense solve)
+    hipLaunchKernelGGL(k_potrf_panel, dim3(nbt), dim3(64 * NW), kPanelLds, st, S, ld, t0 * kTile, nb, Lp, flag, (const double*)b, (double*)yb, sM, sL, sR, btab, own, list);
+    return;
+  }
+  // list[0 .. n_big): fronts with more than 128 real columns in this panel | list[n_big .. n_big + n_small): the others that have any (four waves)
+  // The four-wave form runs three fronts per CU on the same three matrix pipes: per front it is slower (one tile wave per SIMD instead of four), so it
+  // only pays when the small fronts outnumber the CUs — 5-agent map, 182 speed-bias segments: 245 it/s with it against 250 without.
+  static const int small_min = getenv("COVGPU_POTRF4_MIN") ? atoi(getenv("COVGPU_POTRF4_MIN")) : 384;
+  if (n_small <= small_min) { n_big += n_small; n_small = 0; }
+  if (n_big > 0) hipLaunchKernelGGL(k_potrf_panel, dim3(n_big), dim3(64 * NW), kPanelLds, st, S, ld, t0 * kTile, nb, Lp, flag, (const double*)b, (double*)yb, sM, sL, sR, btab, own, list);
+  if (n_small > 0)
+    hipLaunchKernelGGL(k_potrf_panel4, dim3(n_small), dim3(256), kPanelLds4, st, S, ld, t0 * kTile, std::min(nb, 8), Lp, flag, (const double*)b, (double*)yb, sM, sL, sR, btab, own,
+                       list + n_big);
 }
 
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,

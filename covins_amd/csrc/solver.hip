@@ -488,6 +488,43 @@ static int build_chains(const covgpu_problem* p, bool vi, std::vector<int>& perm
   return COVGPU_OK;
 }
 
+// Pose graph (round 6: the multifrontal solve of k_front.hip serves PoseGraphOptimization too): there are no IMU factors to read an agent's
+// time axis from, and the map hands keyframes over agent-interleaved (typedefs_base.hpp:178) — index distance says nothing. The edge list does:
+// an edge whose endpoints share no neighbour is a bridge between otherwise unrelated parts of the graph, a loop closure
+// (optimization_be.cpp:912-944); the odometry edges of one agent (every keyframe tied to its five predecessors, :947-1021) always share
+// neighbours. "Chains" = connected components of the graph without its bridges, each laid out in breadth-first order from a pseudo-peripheral
+// keyframe — along an odometry chain that IS the time axis up to a few places, and nd_plan's halving of a chain then cuts ~5 keyframes.
+static void build_chains_pgo(const covgpu_problem* p, std::vector<int>& perm, std::vector<int>& pos_kf, std::vector<int>& chain_ptr) {
+  const int K = p->num_kf, E = p->num_edge;
+  perm.assign(K, 0); pos_kf.assign(K, 0); chain_ptr.assign(1, 0);
+  std::vector<std::vector<int>> adj(K);
+  for (int e = 0; e < E; ++e) if (p->edge_i[e] != p->edge_j[e]) { adj[p->edge_i[e]].push_back(p->edge_j[e]); adj[p->edge_j[e]].push_back(p->edge_i[e]); }
+  for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+  auto bridge = [&](int u, int v) {
+    const std::vector<int>&A = adj[u], &B = adj[v];
+    for (size_t x = 0, y = 0; x < A.size() && y < B.size();) { if (A[x] == B[y]) return false; if (A[x] < B[y]) ++x; else ++y; }
+    return A.size() > 1 || B.size() > 1;
+  };
+  std::vector<std::vector<int>> nb(K);   // neighbours over non-bridge edges
+  for (int u = 0; u < K; ++u) for (int v : adj[u]) if (!bridge(u, v)) nb[u].push_back(v);
+  std::vector<int> level(K, -1), queue;
+  std::vector<char> placed(K, 0);
+  auto bfs = [&](int start) {
+    queue.assign(1, start); level[start] = 0;
+    for (size_t h = 0; h < queue.size(); ++h) { const int u = queue[h]; for (int v : nb[u]) if (level[v] < 0) { level[v] = level[u] + 1; queue.push_back(v); } }
+    return queue.back();
+  };
+  int pos = 0;
+  for (int k = 0; k < K; ++k) {
+    if (placed[k]) continue;
+    const int far = bfs(k);
+    for (int v : queue) level[v] = -1;
+    bfs(far);   // second sweep from a pseudo-peripheral keyframe: its breadth-first order is the layout
+    for (int v : queue) { level[v] = -1; placed[v] = 1; perm[v] = pos; pos_kf[pos] = v; ++pos; }
+    chain_ptr.push_back(pos);
+  }
+}
+
 // unique covisible pairs (free keyframes only) and edge pairs, as chain-major positions i > j (host-only plan functions;
 // upload_impl builds the same pair list with the per-pair observation lists the device needs)
 static bool host_pairs(const covgpu_problem* p, const std::vector<int>& perm, std::vector<int>& pi, std::vector<int>& pj, std::vector<int>& ei,
@@ -683,7 +720,12 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   P.N = P.n + 3 * P.L;
   // IMU chains -> chain-major keyframe order
   std::vector<int> perm, pos_kf, chain_ptr;
-  RC(build_chains(p, vi, perm, pos_kf, chain_ptr));
+  // pose graph on the elimination tree (round 6; COVGPU_PGO_ND=0: round 2's block-arrow scheme of k_pgo.hip on a dense matrix)
+  static const bool pgo_nd_on = getenv("COVGPU_PGO_ND") == nullptr || atoi(getenv("COVGPU_PGO_ND")) != 0;
+  const char* e_pgo_dense = getenv("COVGPU_PGO_DENSE");
+  const bool pgo_nd = pgo && pgo_nd_on && allow_arrow && p->num_edge > 0 && !(e_pgo_dense && e_pgo_dense[0] == '1') && !c->sharded;
+  if (pgo_nd) build_chains_pgo(p, perm, pos_kf, chain_ptr);
+  else RC(build_chains(p, vi, perm, pos_kf, chain_ptr));
   std::vector<int> chain_end(P.K);
   P.nchains = (int)chain_ptr.size() - 1;
   P.max_chain_len = 1;
@@ -695,7 +737,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   //      COVGPU_GBA_DENSE=1: the same code with ONE front = the dense system (equality tests). The dense row-major matrix
   //      Sred remains for the pose graph (k_pgo.hip builds its own block plan on it) and for covgpu_schur (reads it back).
   const char* e_dense = getenv("COVGPU_GBA_DENSE");
-  const bool use_nd = !pgo && allow_arrow;
+  const bool use_nd = (!pgo && allow_arrow) || pgo_nd;
   if (c->sharded && !use_nd) { g_err = "the agent-sharded solve is for GBA problems (covgpu_upload)"; return COVGPU_ERR_INVALID_ARG; }
   const size_t K = P.K;
   RC(dev_upload(c, &P.pose0, p->kf_pose, 7 * K));
@@ -911,7 +953,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
       RC(dev_upload(c, &nd.bb, nd.h_bb.data(), std::max<size_t>(nd.h_bb.size(), 1)));
       RC(dev_upload(c, &nd.top_var, nd.h_top_var.data(), nd.h_top_var.size())); RC(dev_upload(c, &nd.top_r, nd.h_top_r.data(), nd.h_top_r.size()));
       RC(dev_upload(c, &nd.top_g, nd.h_top_g.data(), nd.h_top_g.size()));
-      for (NdLevel& L : nd.lev) RC(dev_upload(c, &L.live, L.live_h.data(), L.live_h.size()));
+      for (NdLevel& L : nd.lev) { RC(dev_upload(c, &L.live, L.live_h.data(), L.live_h.size())); RC(dev_upload(c, &L.plist, L.plist_h.data(), L.plist_h.size())); }
       // one allocation: [subtree fronts | top fronts][top right-hand sides | grad, hdiag of the top unknowns | subtree right-hand
       // sides] — what a sharded solve all-reduces is one contiguous range of it
       RC(dev_alloc(c, &P.nd_M, nd.M_elems + nd.rhs_elems));
@@ -954,7 +996,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
       RC(dev_alloc(c, &P.Linv, (size_t)(P.npad / kTile) * kTile * kTile));
     }
   }
-  if (pgo && P.E) {  // block-arrow plan for the pose-graph solve (k_pgo.hip); COVGPU_PGO_DENSE=1 keeps the plain dense solve
+  if (pgo && P.E && !pgo_nd) {  // block-arrow plan for the pose-graph solve (k_pgo.hip); COVGPU_PGO_DENSE=1 keeps the plain dense solve
     PgoHostPlan hp;
     const char* dense = getenv("COVGPU_PGO_DENSE");
     if (!(dense && dense[0] == '1') && pgo_plan_analyse(P.K, P.E, p->edge_i, p->edge_j, hp)) {

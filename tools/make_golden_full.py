@@ -15,7 +15,8 @@ BASELINE configs[4] shape (`--one-iter a12x1000 a12`: 12 000 / 20 004 keyframes)
 trust-region iteration of the oracle (optimization_be.cpp:560-567 with max_num_iterations = 1) — initial / final cost, the
 accept flag, radius, and every KF_STRIDE-th pose and speed-bias. At this size the reduced system (15 K = 180k / 300k
 unknowns) goes through the threaded CPU port of the multifrontal solve (oracle/covo_mf.py: LAPACK per front), SuperLU does
-not finish; about 3 / 8 minutes on 8 cores.
+not finish; about 3 / 8 minutes on 8 cores. `--iters N a12x1000` (round 6): N iterations the same way -> tests/golden/<name>_itN.npz (cost trace,
+accept sequence, radii, strided poses and speed-bias after the N-th iteration; the seconds it took and the thread count are stored).
 """
 import hashlib
 import os
@@ -42,7 +43,7 @@ def digest(p: capi.FlatProblem) -> str:
     return h.hexdigest()
 
 
-def one_iteration(names):
+def one_iteration(names, iters=1):
     from covins_amd import backend
     from oracle import covo_mf
     threads = int(covo.lib().covo_num_threads())
@@ -52,15 +53,16 @@ def one_iteration(names):
         covo_mf.set_problem(p, backend.default_options(), threads)
         covo.use_sparse_solver(min_n=3000, kind="multifrontal")
         t0 = time.perf_counter()
-        q, res = covo.gba_solve(p, covo.default_options(max_iterations=1))
+        q, res = covo.gba_solve(p, covo.default_options(max_iterations=iters))
         dt = time.perf_counter() - t0
         out = {"in_digest": np.array(digest(p)), "sizes": np.array([p.K, p.L, p.O, p.I, p.E]), "kf_stride": np.array(KF_STRIDE),
                "pose": q.kf_pose[::KF_STRIDE], "sb": q.kf_speed_bias[::KF_STRIDE], "cost": np.array([res.initial_cost, res.final_cost]),
                "trace": np.array(res.cost_trace[:res.iterations]), "acc": np.array(res.accepted_trace[:res.iterations]),
                "radius": np.array(res.radius_trace[:res.iterations]), "iterations": np.array(res.iterations),
                "solver": np.array("oracle/covo_mf.py (multifrontal, LAPACK per front)")}
-        print(f"{name} one iteration: K={p.K} L={p.L} O={p.O} {dt:.1f} s cost {res.initial_cost:.9e} -> {res.final_cost:.9e} acc {list(res.accepted_trace[:1])}", flush=True)
-        dst = os.path.join(ROOT, "tests", "golden", f"{name}_it1.npz")
+        out["seconds"] = np.array(dt); out["threads"] = np.array(threads)
+        print(f"{name} {iters} iteration(s): K={p.K} L={p.L} O={p.O} {dt:.1f} s on {threads} threads cost {res.initial_cost:.9e} -> {res.final_cost:.9e} acc {list(res.accepted_trace[:res.iterations])}", flush=True)
+        dst = os.path.join(ROOT, "tests", "golden", f"{name}_it{iters}.npz")
         np.savez_compressed(dst, **out)
         print("wrote", dst, os.path.getsize(dst), "bytes", flush=True)
     covo.use_sparse_solver(min_n=3000)
@@ -69,6 +71,8 @@ def one_iteration(names):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--one-iter":
         return one_iteration(sys.argv[2:] or ["a12x1000"])
+    if len(sys.argv) > 2 and sys.argv[1] == "--iters":   # round 6: several trust-region iterations at configs[4]'s shape -> tests/golden/<name>_it<N>.npz
+        return one_iteration(sys.argv[3:] or ["a12x1000"], int(sys.argv[2]))
     names = sys.argv[1:] or ["mh01", "mh123", "mh12345"]
     covo.use_sparse_solver(min_n=3000)
     for name in names:

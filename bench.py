@@ -97,7 +97,7 @@ def _kernels_digest():
 
 def run_a12_leg(args, rank, local_rank, world, strategy, store):
     """BASELINE configs[4] (synthetic 12-agent map at its stated 20 004 keyframes / 2.02 M landmarks) on the ranks of this run: the ONE map
-    sharded by subtree exactly like the metric's (world 1: unsharded), one warm-up and two timed steps of 10 iterations, barrier +
+    sharded by subtree exactly like the metric's (world 1: unsharded), one warm-up and --a12-steps (5) timed steps of 10 iterations, barrier +
     max-over-ranks timing. Every rank generates the map itself (seeded generator) and computes the same plan."""
     from covins_amd import backend, distrib, mapdata, synth
     t_gen = time.perf_counter()
@@ -120,12 +120,34 @@ def run_a12_leg(args, rank, local_rank, world, strategy, store):
         t_up = time.perf_counter() - t_up
         ctx.solve_resident(opt)
         distrib.barrier(ctx, sharded)
-        t0 = time.perf_counter(); iters = 0; steps = 2
+        t0 = time.perf_counter(); iters = 0; steps = max(2, int(args.a12_steps))
         for _ in range(steps):
             res = ctx.solve_resident(opt); iters += res.iterations
         distrib.barrier(ctx, sharded)
         dt, iters_all = distrib.aggregate(time.perf_counter() - t0, iters, ctx, sharded)
         lay = ctx.layout(); st = ctx.shard_stats()
+        # ---- CPU baseline of this leg: ONE trust-region iteration of the oracle at the stated size on the box's host threads — a bounded
+        # sample (ten iterations would be minutes) — and the HIP path's distance from it after that iteration. Rank 0 of a one-GPU run only.
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline and not args.no_a12_cpu:
+            from oracle import covo, covo_mf
+            threads = int(covo.lib().covo_num_threads())
+            covo_mf.set_problem(full, backend.default_options(), threads)
+            covo.use_sparse_solver(min_n=3000, kind="multifrontal")
+            covo_mf.stats.update(calls=0, seconds=0.0)
+            tc = time.perf_counter()
+            q1, r1 = covo.gba_solve(full, covo.default_options(max_iterations=1, strategy=strategy))
+            tc = time.perf_counter() - tc
+            covo.use_sparse_solver(min_n=3000)
+            o1 = backend.default_options(strategy=strategy, max_iterations=1, device=local_rank)
+            g1 = ctx.solve_resident(o1)
+            s1 = ctx.download()
+            cpu = {"value": r1.iterations / tc, "unit": "GBA iterations/s", "cores": threads, "kind": "port",
+                   "sample": f"ONE trust-region iteration of the oracle on this map at its stated size (K={full.K} L={full.L} O={full.O}, 15K={15 * full.K}): "
+                             f"{tc:.1f} s, of which {covo_mf.stats['seconds']:.1f} s in the reduced-system solve (oracle/covo_mf.py, LAPACK per front)",
+                   "cost_after_one_iteration": {"cpu": r1.cost_trace[0], "gpu": g1.cost_trace[0]}, "accepted": {"cpu": int(r1.accepted_trace[0]), "gpu": int(g1.accepted_trace[0])},
+                   "max_pose_diff_gpu_cpu_m": float(np.abs(s1.kf_pose[:, 4:] - q1.kf_pose[:, 4:]).max()),
+                   "max_speed_bias_diff_gpu_cpu": float(np.abs(s1.kf_speed_bias - q1.kf_speed_bias).max())}
         # one more, un-timed step with HIP events on: phase times and the per-launch figures of this leg's own roofline objects
         ctx.set_profiling(True)
         ctx.solve_resident(opt)
@@ -158,7 +180,7 @@ def run_a12_leg(args, rank, local_rank, world, strategy, store):
                 "roofline_build": {"bound": "hbm", "achieved": b_build / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": (b_build / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if build_ms > 0 else 0.0, "traffic": None, "algorithmic_bytes": b_build},
                 "layout": lay, "allreduce_mib_per_linear_solve": lay["allreduce_kib"] / 1024.0, "collectives_rank0": st["collectives"],
-                "map_generation_s": t_gen, "upload_s": t_up}
+                "map_generation_s": t_gen, "upload_s": t_up, "cpu_baseline": cpu}
     finally:
         del keep
         ctx.close()
@@ -175,6 +197,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-shard", action="store_true", help="run the agent-sharded path (plan, sub-problem, RCCL collectives) even on ONE GPU")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-call timing after the timed region (profiling runs)")
+    ap.add_argument("--a12-steps", type=int, default=5, help="timed steps of the a12 leg (after one warm-up)")
+    ap.add_argument("--no-a12-cpu", action="store_true", help="skip the a12 leg's one-iteration CPU baseline (about a minute of host time)")
     ap.add_argument("--a12-leg", type=int, default=-1, help="after the metric's workload, also time BASELINE configs[4] at its stated size (12 x 1667 keyframes, 2M landmarks) "
                     "on the same ranks and report it as `a12_leg` with rooflines of its own (1 / 0; default: on for the metric's workload at any --gpus — the "
                     "configuration the north star names for the scaling curve; ~70 s of map generation + upload, 3 + 1 steps)")
@@ -395,7 +419,7 @@ def main():
                                        "on the same map (median of three calls; stages of that call), host flattening in numpy; ONE flatten and ONE upload per call: the second round's "
                                        "problem is derived on the device (covgpu_gba_two_round)"}
         if not args.no_e2e:
-            # side figure: one PoseGraphOptimization solve of the same map (block-arrow solve); not `value`
+            # side figure: one PoseGraphOptimization solve of the same map (multifrontal solve on the pose graph's own elimination tree); not `value`
             popt = backend.default_options(max_iterations=pgo_prm.pgo_iteration_limit, device=local_rank)
             ctx.pgo_solve(pgo_prob, popt)
             t_p = time.perf_counter()
@@ -404,7 +428,7 @@ def main():
                                "initial_cost": pres.initial_cost, "final_cost": pres.final_cost,
                                "phase_s": {"upload (plan + H2D)": pres.t_upload_s, "solve": pres.t_solve_s,
                                            "download": pres.t_download_s},
-                               "critical_path": "k_potrf_panel chain of the block-arrow pose-graph solve (k_pgo.hip): latency-bound, no roofline",
+                               "critical_path": "one panel chain per level of the pose graph's elimination tree (6-dof blocks, chains read from the edge graph; k_front.hip): latency-bound, no roofline",
                                "what": "covgpu_pgo_solve: whole PoseGraphOptimization solve (optimization_be.cpp:1024-1031) incl. plan, H2D, D2H"}
             if not args.no_cpu_baseline:
                 pq, pr, out["pgo_call"]["cpu_baseline"] = cpu_baseline_pgo(pgo_prob, pgo_prm.pgo_iteration_limit)

@@ -281,6 +281,11 @@ struct CholAux {
   long gate_signals = 0, gate_waits = 0; // launches issued (statistics)
   void record(hipEvent_t e, hipStream_t s, int tag = 0);
   void wait(hipStream_t s, hipEvent_t e0, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
+  // records and waits that stand side by side on one stream as ONE launch (every launch on the panel chain's stream is ~3.5 us under load): the
+  // kernel publishes r0 / r1 first, then polls w0 .. w3 — the same order as record(r0); record(r1); wait(w0 ..)
+  void sync(hipStream_t s, hipEvent_t r0, int tag0, hipEvent_t r1, int tag1, hipEvent_t w0 = nullptr, hipEvent_t w1 = nullptr, hipEvent_t w2 = nullptr,
+            hipEvent_t w3 = nullptr);
+  int gate_slot_of(hipEvent_t e, bool create);
   // dev aid (COVGPU_GATE_LOG=1): every signal / gate stamps wall_clock64 (100 MHz) into a device log — an un-profiled timeline of the streams'
   // hand-overs, printed by collect(): "S<tag>@t" a signal of record(.., tag), "G<tag of the first awaited record>@t_start+wait" a gate
   long long* gate_log = nullptr; int gate_log_n = 0;

@@ -353,9 +353,10 @@ __global__ void k_signal(long long* flag, long long seq, long long* log) {
     if (log) log[0] = wall_clock64();
   }
 }
-struct GateArgs { const long long* f[4]; long long s[4]; int n; int* dead; int* dead_h; long long limit; long long* log; };
+struct GateArgs { const long long* f[4]; long long s[4]; int n; int* dead; int* dead_h; long long limit; long long* log; long long* pf[2]; long long ps[2]; int np; };
 __global__ void k_gate(GateArgs g) {
   if (threadIdx.x != 0) return;
+  for (int i = 0; i < g.np; ++i) __hip_atomic_store(g.pf[i], g.ps[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // CholAux::sync: records first
   const long long t0 = wall_clock64();   // 100 MHz
   struct Stamp { long long* log; long long t0; __device__ ~Stamp() { if (log) { log[0] = t0; log[1] = wall_clock64(); } } } stamp{g.log, t0};
   for (int i = 0; i < g.n; ++i) {
@@ -373,16 +374,20 @@ __global__ void k_gate(GateArgs g) {
     }
   }
 }
+int CholAux::gate_slot_of(hipEvent_t e, bool create) {
+  auto it = gate_slot.find(e);
+  if (it != gate_slot.end()) return it->second;
+  if (!create) return -1;
+  const int slot = (int)gate_slot.size();
+  if (slot >= kGateSlots) return -1;   // (never on the shipped maps: 9 events per panel of the widest level)
+  gate_slot.emplace(e, slot);
+  if ((int)gate_seq.size() <= slot) gate_seq.resize(slot + 1, 0);
+  return slot;
+}
 void CholAux::record(hipEvent_t e, hipStream_t s, int tag) {
   if (!gates_on) { (void)hipEventRecord(e, s); return; }
-  int slot;
-  auto it = gate_slot.find(e);
-  if (it == gate_slot.end()) {
-    slot = (int)gate_slot.size();
-    if (slot >= kGateSlots) { (void)hipEventRecord(e, s); return; }   // (never on the shipped maps: 9 events per panel of the widest level)
-    gate_slot.emplace(e, slot);
-    if ((int)gate_seq.size() <= slot) gate_seq.resize(slot + 1, 0);
-  } else slot = it->second;
+  const int slot = gate_slot_of(e, true);
+  if (slot < 0) { (void)hipEventRecord(e, s); return; }
   gate_seq[slot] = ++gate_counter;
   long long* lg = nullptr;
   if (gate_log != nullptr && gate_log_n < kGateLogMax) {
@@ -393,20 +398,40 @@ void CholAux::record(hipEvent_t e, hipStream_t s, int tag) {
   hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, gate_flags + slot, gate_seq[slot], lg);
   ++gate_signals;
 }
-void CholAux::wait(hipStream_t s, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3) {
+void CholAux::wait(hipStream_t s, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3) { sync(s, nullptr, 0, nullptr, 0, e0, e1, e2, e3); }
+void CholAux::sync(hipStream_t s, hipEvent_t r0, int tag0, hipEvent_t r1, int tag1, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3) {
   hipEvent_t es[4] = {e0, e1, e2, e3};
-  if (!gates_on) { for (hipEvent_t e : es) if (e != nullptr) (void)hipStreamWaitEvent(s, e, 0); return; }
-  GateArgs g; g.n = 0; g.dead = gate_dead; g.dead_h = gate_dead_h; g.limit = (long long)(gate_timeout_s * 1e8); g.log = nullptr;
-  int first_tag = 0;
+  static const bool merged = getenv("COVGPU_GATE_MERGE") == nullptr || atoi(getenv("COVGPU_GATE_MERGE")) != 0;
+  if (!gates_on || !merged) {
+    if (r0 != nullptr) record(r0, s, tag0);
+    if (r1 != nullptr) record(r1, s, tag1);
+    if (!gates_on) { for (hipEvent_t e : es) if (e != nullptr) (void)hipStreamWaitEvent(s, e, 0); return; }
+    r0 = r1 = nullptr;
+  }
+  GateArgs g; g.n = 0; g.dead = gate_dead; g.dead_h = gate_dead_h; g.limit = (long long)(gate_timeout_s * 1e8); g.log = nullptr; g.np = 0;
+  g.pf[0] = g.pf[1] = nullptr; g.ps[0] = g.ps[1] = 0;
+  {
+    hipEvent_t rs[2] = {r0, r1}; const int tags[2] = {tag0, tag1};
+    for (int i = 0; i < 2; ++i) {
+      if (rs[i] == nullptr) continue;
+      const int slot = gate_slot_of(rs[i], true);
+      if (slot < 0) { (void)hipEventRecord(rs[i], s); continue; }
+      gate_seq[slot] = ++gate_counter;
+      if ((int)gate_tag_of_slot.size() <= slot) gate_tag_of_slot.resize(slot + 1, 0);
+      gate_tag_of_slot[slot] = tags[i];
+      g.pf[g.np] = gate_flags + slot; g.ps[g.np] = gate_seq[slot]; ++g.np; ++gate_signals;
+    }
+  }
+  int first_tag = g.np > 0 ? -(r0 != nullptr ? tag0 : tag1) : 0;   // (gate log: a negative tag marks a launch that also publishes)
   for (hipEvent_t e : es) {
     if (e == nullptr) continue;
     auto it = gate_slot.find(e);
     if (it == gate_slot.end()) { (void)hipStreamWaitEvent(s, e, 0); continue; }   // never recorded through a flag: whatever HIP knows of it
     if (gate_seq[it->second] == 0) continue;
-    if (g.n == 0 && it->second < (int)gate_tag_of_slot.size()) first_tag = gate_tag_of_slot[it->second];
+    if (g.n == 0 && g.np == 0 && it->second < (int)gate_tag_of_slot.size()) first_tag = gate_tag_of_slot[it->second];
     g.f[g.n] = gate_flags + it->second; g.s[g.n] = gate_seq[it->second]; ++g.n;
   }
-  if (g.n == 0) return;
+  if (g.n == 0 && g.np == 0) return;
   if (gate_log != nullptr && gate_log_n < kGateLogMax) { g.log = gate_log + 2 * (size_t)gate_log_n++; gate_log_tag.push_back(first_tag); gate_log_kind.push_back('G'); }
   for (int i = g.n; i < 4; ++i) { g.f[i] = nullptr; g.s[i] = 0; }
   hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, g);
@@ -776,7 +801,9 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       static const bool merge_trsm = getenv("COVGPU_TRSM_MERGE") != nullptr && atoi(getenv("COVGPU_TRSM_MERGE")) != 0;
       const bool chain_bound = bulk_pairs <= chain_pairs;
       potrf(t0, w, nbp);
-      if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);   // rows below the first panel: second half of the caller's extend-add
+      // rows below the first panel: second half of the caller's extend-add. IN FRONT of the record below — the rest rows' substitution on stream R
+      // starts from that record and inherits this wait
+      if (P == 0 && bt.pre_trsm != nullptr) wait(M, bt.pre_trsm);
       // Every event packet on this stream sits between two dependent kernels of the chain, a few microseconds each. While the bulk
       // update is short (the period of the factorisation is the chain: small fronts, the tail of big ones) there is ONE event per
       // panel, eH, recorded after the look-ahead update of the next diagonal block — the rest rows (which only need the factored
@@ -788,19 +815,26 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // (profiles/r05z_iteration_timeline.csv: both substitutions start 14 us after the factorisation ends), a record nobody is waiting for yet ~6.
       // Measured: 233.5 / 233.1 against 232.6 / 232.0 it/s, configs[4] 20.0 against 20.3 — within noise, so the default stays the round-4 form.
       const bool merge = merge_trsm && !chain_bound && h1 > h0 && T > h1;
-      if (!chain_bound && !merge) record(e1[P], M, 100 * (P + 1) + 13);
       bool waitedA = false;
+      hipEvent_t rec1 = (!chain_bound && !merge) ? e1[P] : nullptr;   // "panel P factored": the rest rows' substitution (stream R) starts from it
       if (h1 > h0) {
-        // rows h carry the look-ahead update of panel P-1 (stream H, above) | ... and, merged, the rest rows theirs (stream R) | bulk(P-1)'s first launch
+        // rows h carry the look-ahead update of panel P-1 (stream H, above) | ... and, merged, the rest rows theirs (stream R) | bulk(P-1)'s first launch.
+        // (round 6: the record behind the factorisation and these waits are ONE launch — CholAux::sync)
         waitedA = early_wait && P >= 1 && P + 1 < NP;
-        wait(M, P > 0 ? eHp[P] : nullptr, merge && P > 0 ? e2[P] : nullptr, waitedA ? eA[P - 1] : nullptr);
+        ax.sync(M, rec1, 100 * (P + 1) + 13, nullptr, 0, P > 0 ? eHp[P] : nullptr, merge && P > 0 ? e2[P] : nullptr, waitedA ? eA[P - 1] : nullptr);
+        rec1 = nullptr;
         // (round 5: the wait of the next-diagonal update below for bulk(P-1)'s first launch — 30-40 us of slack — rides along with the one above.
         //  Measured: no difference (231.1 / 230.5 against 231.4 / 231.2 it/s) — a wait whose event completed long ago costs nothing; the 13-14 us
         //  between two kernels of this stream come from the RECORD behind the first when its waiter is blocked on it at that moment: DESIGN.md 4.6)
         launch_trsm_sub(S, ld, t0, w, h0, merge ? T : h1, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, M, true, bt.tab, nbp, bt.own_dims);
         if (trace2) ax.mark(M, 100 * (P + 1) + 2);   // rows h solved
       }
-      if (!chain_bound) record(eH[P], M, 100 * (P + 1) + 10);
+      if (rec1 != nullptr) record(rec1, M, 100 * (P + 1) + 13);
+      // (round 6: "rows h solved" is published together with "next diagonal block updated", one launch behind that small update instead of one
+      //  launch in front of it and one behind: its waiters — the next panel's look-ahead on stream H — have ~50 us of slack)
+      static const bool late_eh = getenv("COVGPU_LATE_EH") == nullptr || atoi(getenv("COVGPU_LATE_EH")) != 0;
+      const bool eh_now = !chain_bound && !(late_eh && P + 1 < NP);
+      if (eh_now) record(eH[P], M, 100 * (P + 1) + 10);
       // ---- M: look-ahead part of SYRK(P) on the next panel's 2x2 diagonal tiles
       if (P + 1 < NP) {
         const int u0 = t0 + 2, uw = (T - u0 >= 2) ? 2 : 1;
@@ -810,7 +844,8 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       }
       // (A bulk launched at the same instant as the next diagonal update takes every workgroup slot first and the chain waits
       //  ~75 us for the first round of tiles to retire: the bulk starts after that small kernel in either regime.)
-      record(chain_bound ? eH[P] : eRc[P], M, 100 * (P + 1) + (chain_bound ? 10 : 16));
+      if (chain_bound || eh_now) record(chain_bound ? eH[P] : eRc[P], M, 100 * (P + 1) + (chain_bound ? 10 : 16));
+      else ax.sync(M, eH[P], 100 * (P + 1) + 10, eRc[P], 100 * (P + 1) + 16);
       if (T > h1 && !merge) {
         wait(R, chain_bound ? eH[P] : e1[P]);   // (measured, round 4: waiting for rows h instead — so that the chain's substitution runs alone — 299.9 -> 297.5 it/s)
         launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab, nbp, bt.own_dims);

@@ -721,7 +721,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   // IMU chains -> chain-major keyframe order
   std::vector<int> perm, pos_kf, chain_ptr;
   // pose graph on the elimination tree (round 6; COVGPU_PGO_ND=0: round 2's block-arrow scheme of k_pgo.hip on a dense matrix)
-  static const bool pgo_nd_on = getenv("COVGPU_PGO_ND") == nullptr || atoi(getenv("COVGPU_PGO_ND")) != 0;
+  const bool pgo_nd_on = getenv("COVGPU_PGO_ND") == nullptr || atoi(getenv("COVGPU_PGO_ND")) != 0;   // (read per upload: the parity test switches it)
   const char* e_pgo_dense = getenv("COVGPU_PGO_DENSE");
   const bool pgo_nd = pgo && pgo_nd_on && allow_arrow && p->num_edge > 0 && !(e_pgo_dense && e_pgo_dense[0] == '1') && !c->sharded;
   if (pgo_nd) build_chains_pgo(p, perm, pos_kf, chain_ptr);

@@ -288,7 +288,7 @@ int covgpu_schur_pgo(covgpu_context* ctx, const covgpu_options* opt, const covgp
                      double* S, double* b, double* cost);
 
 /* R8 building block: ONE damped Gauss-Newton step at the estimate in `p`, through the product solve path (speed-bias
- * chains -> block-arrow or dense MFMA Cholesky of the pose system -> landmark back-substitution):
+ * multifrontal MFMA Cholesky of the reduced camera system over its elimination tree -> landmark back-substitution):
  * dx[n] (IR layout, dim_per_kf per keyframe) and dl[3L]. Tests check S dx = b against the oracle's system at full size. */
 int covgpu_gn_step(covgpu_context* ctx, const covgpu_options* opt, const covgpu_problem* p, double mu,
                    double* dx /* [n] */, double* dl /* [L][3] */, double* cost);
@@ -300,8 +300,9 @@ int covgpu_solve_reduced(covgpu_context* ctx, int32_t n, const double* S, const 
 
 int32_t covgpu_reduced_dim(const covgpu_options* opt, const covgpu_problem* p);
 
-/* Host-only: the block partition the pose-graph solve uses (PoseGraphOptimization's linear solver,
- * optimization_be.cpp:1024-1031 -> block-arrow elimination). block_of_kf[k] = block index (>= 0) of
+/* Host-only: the block partition of round 2's block-arrow pose-graph solve (PoseGraphOptimization's linear solver,
+ * optimization_be.cpp:1024-1031; since round 6 the default is the multifrontal solve on the pose graph's own elimination
+ * tree — DESIGN.md 4.8 — and this scheme runs with COVGPU_PGO_ND=0). block_of_kf[k] = block index (>= 0) of
  * keyframe k, or -1 if it belongs to the border (loop-closure keyframes and separators). Returns the number of
  * blocks, or 0 if the graph is solved densely (too small, no split, or a border that is a large part of the
  * system; block_of_kf is then all -1). No edge joins two different blocks. Needs no device. */

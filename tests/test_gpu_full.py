@@ -166,6 +166,33 @@ def test_one_iteration_at_config4_shape_matches_oracle_golden(ctx, name):
     assert dp < 1e-6 and da < 1e-7 and ds < 1e-6
 
 
+def test_five_iterations_at_config4_shape_match_oracle_golden(ctx):
+    """the parity at BASELINE configs[4]'s shape was one iteration deep. Five trust-region iterations of the HIP path on the
+    12 x 1000-keyframe map (K = 12 000, 1.12 M landmarks, 5.4 M observations, 180 000 unknowns in the reduced system) against the oracle's
+    committed result (tools/make_golden_full.py --iters 5 a12x1000: 319 s on the build container's 8 cores, the reduced system through the
+    LAPACK multifrontal port oracle/covo_mf.py): the same accept sequence, cost trace 1e-6, radii, every 4th pose within 1e-6 m / 1e-7 rad,
+    speed-bias 1e-6 — the criteria of test_full_size_solve_matches_oracle_golden."""
+    name = "a12x1000"
+    G = np.load(os.path.join(GOLD, f"{name}_it5.npz"))
+    m, p = problem(name)
+    assert digest(p) == str(G["in_digest"]), "regenerated inputs differ from the ones the golden was made on"
+    n = int(G["iterations"])
+    assert n == 5
+    sol, res = ctx.gba_solve(p, backend.default_options(max_iterations=n))
+    assert res.iterations == n
+    assert list(res.accepted_trace[:n]) == list(G["acc"])
+    assert abs(res.initial_cost - G["cost"][0]) <= 1e-9 * G["cost"][0]
+    assert np.allclose(np.array(res.cost_trace[:n]), G["trace"], rtol=1e-6, atol=0)
+    assert np.allclose(np.array(res.radius_trace[:n]), G["radius"], rtol=1e-6, atol=0)
+    st = int(G["kf_stride"])
+    dp = np.abs(sol.kf_pose[::st, 4:] - G["pose"][:, 4:]).max()
+    da = rot_angle(sol.kf_pose[::st, :4], G["pose"][:, :4]).max()
+    ds = np.abs(sol.kf_speed_bias[::st] - G["sb"]).max()
+    print(f"{name} five iterations: K={p.K} L={p.L} O={p.O} cost {res.initial_cost:.6e} -> {res.final_cost:.6e} (oracle {G['cost'][1]:.6e}) "
+          f"max|dp|={dp:.2e} m, max angle={da:.2e} rad, max|dsb|={ds:.2e}")
+    assert dp < 1e-6 and da < 1e-7 and ds < 1e-6
+
+
 def test_multifrontal_solve_equals_one_front_solve(ctx):
     """The nested-dissection multifrontal elimination (k_front.hip) is the same Cholesky solve in a different elimination
     order: the full GBA of the 3-agent map must land where ONE front — the dense 15K-order system, COVGPU_GBA_DENSE=1 —

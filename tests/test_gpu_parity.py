@@ -359,20 +359,31 @@ def test_pgo_solve_matches_oracle(ctx):
 
 @pytest.mark.parametrize("name,kf", [("small", 60), ("mh123", 200)])
 def test_pgo_block_arrow_solve_equals_dense_solve(ctx, name, kf, monkeypatch):
-    """k_pgo.hip (agents eliminated independently, loop keyframes as the dense border) against the plain dense
-    Cholesky of the same pose-graph system (COVGPU_PGO_DENSE=1): same trust-region trajectory to round-off."""
+    """The pose-graph solve on its elimination tree (default since round 6) and k_pgo.hip's block-arrow scheme (agents eliminated
+    independently, loop keyframes as the dense border) against the plain dense Cholesky of the same pose-graph system
+    (COVGPU_PGO_DENSE=1): same trust-region trajectory to round-off."""
     cfg = synth.config_named(name); cfg.max_kf_per_agent = kf; cfg.drift_trans = 0.05; cfg.drift_yaw_deg = 0.5
     m = synth.make_map(cfg)
     p = mapdata.flatten_pgo(m, {}, mapdata.PgoParams())[0]
     assert 6 * p.K >= 8 * 128  # large enough for the block plan to be built
     g, _ = opts(strategy=capi.COVGPU_DOGLEG)
     sol, res = ctx.pgo_solve(p, g)
+    lay = ctx.layout()
     monkeypatch.setenv("COVGPU_PGO_DENSE", "1")
     ref, rres = ctx.pgo_solve(p, g)
     monkeypatch.delenv("COVGPU_PGO_DENSE")
     assert res.iterations == rres.iterations and res.termination == rres.termination
     assert abs(res.final_cost - rres.final_cost) <= 1e-9 * abs(rres.final_cost)
     assert np.abs(sol.kf_pose - ref.kf_pose).max() < 1e-9
+    # round 6: the default is the multifrontal solve on the pose graph's own elimination tree (chains read from the edge graph); round 2's
+    # block-arrow scheme (COVGPU_PGO_ND=0) is a third elimination order of the same system
+    assert lay["nd_fronts"] >= 1, "the default pose-graph solve runs on the elimination tree"
+    monkeypatch.setenv("COVGPU_PGO_ND", "0")
+    arr, ares = ctx.pgo_solve(p, g)
+    monkeypatch.delenv("COVGPU_PGO_ND")
+    assert ctx.layout()["nd_fronts"] == 0
+    assert ares.iterations == rres.iterations and abs(ares.final_cost - rres.final_cost) <= 1e-9 * abs(rres.final_cost)
+    assert np.abs(arr.kf_pose - ref.kf_pose).max() < 1e-9
 
 
 def test_pgo_reanchor(ctx):

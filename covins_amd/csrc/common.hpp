@@ -180,9 +180,12 @@ enum { SC_COST = 0, SC_JV2 = 1, SC_GG = 2, SC_GN2 = 3, SC_GDOT = 4, SC_GMAX = 5,
        SC_COUNT = 16 };
 
 struct CholAux;
+// a record published by the FIRST thread of the next kernel on the recording stream instead of by a launch of its own (CholAux::publish_handle): at
+// that moment everything enqueued before that kernel on its stream is complete, which is all a record says
+struct DevSignal { long long* flag = nullptr; long long seq = 0; };
 // ---- launchers (each enqueues on `st`, no synchronisation)
 void launch_kobs_build(const DevProblem& P, int* pair_oa, int* pair_ob, size_t nent, hipStream_t st);  // upload: keyframe-major copies, Z slots, pair lists -> Z slots
-void launch_lm_lin(const DevProblem& P, double mu, hipStream_t st);   // landmark-major linearisation: records, H_ll, g_l, cost partials
+void launch_lm_lin(const DevProblem& P, double mu, hipStream_t st, DevSignal sig = DevSignal());   // landmark-major linearisation: records, H_ll, g_l, cost partials
 void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared = nullptr, hipStream_t side = nullptr,
                      hipEvent_t ev_lin = nullptr, hipEvent_t ev_kf = nullptr, CholAux* ax = nullptr);  // reprojection -> Hll, g, S (Schur), bred, cost
 void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st);
@@ -283,6 +286,7 @@ struct CholAux {
   void wait(hipStream_t s, hipEvent_t e0, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
   // records and waits that stand side by side on one stream as ONE launch (every launch on the panel chain's stream is ~3.5 us under load): the
   // kernel publishes r0 / r1 first, then polls w0 .. w3 — the same order as record(r0); record(r1); wait(w0 ..)
+  DevSignal publish_handle(hipEvent_t e, int tag = 0);   // gates on: the handle for the next kernel of the recording stream (flag == nullptr: record(e, s) instead)
   void sync(hipStream_t s, hipEvent_t r0, int tag0, hipEvent_t r1, int tag1, hipEvent_t w0 = nullptr, hipEvent_t w1 = nullptr, hipEvent_t w2 = nullptr,
             hipEvent_t w3 = nullptr);
   int gate_slot_of(hipEvent_t e, bool create);
@@ -465,7 +469,7 @@ void launch_tr_after_model(const DevProblem& P, TrConsts tc, hipStream_t st);   
 void launch_tr_decide(const DevProblem& P, TrConsts tc, hipStream_t st);                    // rho test, radius / damping update, accept: x = candidate
 void launch_apply_step(const DevProblem& P, hipStream_t st);    // candidate = x (+) step
 void launch_accept(const DevProblem& P, hipStream_t st);        // x = candidate
-void launch_tr_accept(const DevProblem& P, hipStream_t st);     // x = candidate if TR_ACC (device-side decision)
+void launch_tr_accept(const DevProblem& P, hipStream_t st, double* box = nullptr, double seq = 0.0);     // x = candidate if TR_ACC (device-side decision); box: k_dense.hip
 void launch_xnorm(const DevProblem& P, hipStream_t st);         // XN2
 void launch_relpose(int num, const int* ptr, const double* pB, const double* pA, const double* kpA, const double* kpB, const double* sigA,
                     const double* sigB, const double* camA, const int* distA, const double* camB, const int* distB, double th, int min_inliers,

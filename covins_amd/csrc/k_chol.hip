@@ -398,6 +398,18 @@ void CholAux::record(hipEvent_t e, hipStream_t s, int tag) {
   hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, gate_flags + slot, gate_seq[slot], lg);
   ++gate_signals;
 }
+DevSignal CholAux::publish_handle(hipEvent_t e, int tag) {
+  DevSignal d;
+  if (!gates_on) return d;
+  const int slot = gate_slot_of(e, true);
+  if (slot < 0) return d;
+  gate_seq[slot] = ++gate_counter;
+  if ((int)gate_tag_of_slot.size() <= slot) gate_tag_of_slot.resize(slot + 1, 0);
+  gate_tag_of_slot[slot] = tag;
+  d.flag = gate_flags + slot; d.seq = gate_seq[slot];
+  ++gate_signals;
+  return d;
+}
 void CholAux::wait(hipStream_t s, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3) { sync(s, nullptr, 0, nullptr, 0, e0, e1, e2, e3); }
 void CholAux::sync(hipStream_t s, hipEvent_t r0, int tag0, hipEvent_t r1, int tag1, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3) {
   hipEvent_t es[4] = {e0, e1, e2, e3};

@@ -198,7 +198,15 @@ __global__ void k_tr_decide(DevProblem P, TrConsts tc) {
     }
   }
 }
-__global__ __launch_bounds__(256) void k_tr_accept(DevProblem P) {
+// box != nullptr (round 6): the first workgroup also posts the trust-region state — what the host needs to enqueue the next iteration — into a
+// pinned host buffer, the sequence number behind it: the host polls that word instead of sleeping in hipStreamSynchronize behind a D2H copy
+__global__ __launch_bounds__(256) void k_tr_accept(DevProblem P, double* box, double seq) {
+  if (box != nullptr && blockIdx.x == 0) {
+    if (threadIdx.x < TR_COUNT) __hip_atomic_store(box + threadIdx.x, P.tr[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(box + TR_COUNT, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (P.tr[TR_ACC] == 0.0) return;
   const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (size_t q = t0; q < (size_t)7 * P.K; q += stride) P.pose[q] = P.pose_c[q];
@@ -249,11 +257,12 @@ void launch_finalize_diag(const DevProblem& P, double mu, int which, hipStream_t
 }
 // One launch clears every small per-iteration buffer: sixteen hipMemsetAsync calls were ~80 us of dispatch latency at the
 // head of every linearisation (each fill kernel runs ~5 us whatever its size).
-struct ZeroList { double* p[16]; size_t n[16]; };
+struct ZeroList { double* p[16]; size_t n[16]; int* flag; };
 __global__ __launch_bounds__(256) void k_zero_many(ZeroList z) {
   double* p = z.p[blockIdx.y];
   const size_t n = z.n[blockIdx.y];
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.0;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && z.flag != nullptr) *z.flag = 0;   // (the factorisation's failure flag: was a fill launch of its own)
 }
 void launch_zero_system(const DevProblem& P, hipStream_t st) {
   ZeroList z; int m = 0;
@@ -264,12 +273,14 @@ void launch_zero_system(const DevProblem& P, hipStream_t st) {
     add(P.Bp, (size_t)54 * P.K); add(P.Bs, (size_t)54 * P.K); add(P.Bn, (size_t)54 * P.K);
     add(P.imuAd, (size_t)2 * 81 * P.K); add(P.imuBs, (size_t)2 * 54 * P.K); add(P.imuCd, (size_t)3 * 36 * P.K); add(P.imuG, (size_t)2 * 30 * P.K);
   }
-  add(P.grad, (size_t)P.N); add(P.hdiag, (size_t)P.N);
+  // (round 6: the keyframe part only — the landmark part of both is ASSIGNED by the landmark linearisation for every landmark, which therefore
+  //  depends on nothing this launch clears and goes out first on its own stream: solver.hip enqueue_build)
+  add(P.grad, (size_t)P.n); add(P.hdiag, (size_t)P.n);
   add(P.part + (size_t)SC_COST * P.part_n, (size_t)P.part_n);
   add(P.scal + SC_GMAX, 1);   // (k_dogleg_stats takes an atomic max into it)
   for (int i = m; i < 16; ++i) { z.p[i] = nullptr; z.n[i] = 0; }
+  z.flag = P.flag;
   hipLaunchKernelGGL(k_zero_many, dim3(128, m), dim3(256), 0, st, z);
-  hipMemsetAsync(P.flag, 0, sizeof(int), st);
 }
 void launch_part_clear(const DevProblem& P, int slot0, int nslots, hipStream_t st) {
   hipMemsetAsync(P.part + (size_t)slot0 * P.part_n, 0, (size_t)nslots * P.part_n * sizeof(double), st);
@@ -297,9 +308,9 @@ void launch_combine_step_dev(const DevProblem& P, hipStream_t st) {
 }
 void launch_tr_after_solve(const DevProblem& P, TrConsts tc, int fresh, hipStream_t st) { hipLaunchKernelGGL(k_tr_after_solve, dim3(1), dim3(64), 0, st, P, tc, fresh); }
 void launch_tr_after_model(const DevProblem& P, TrConsts tc, hipStream_t st) { hipLaunchKernelGGL(k_tr_after_model, dim3(1), dim3(64), 0, st, P, tc); }
-void launch_tr_accept(const DevProblem& P, hipStream_t st) {   // x = candidate if the step logic accepted it (TR_ACC)
+void launch_tr_accept(const DevProblem& P, hipStream_t st, double* box, double seq) {   // x = candidate if the step logic accepted it (TR_ACC)
   const size_t n = std::max((size_t)9 * P.K, (size_t)3 * P.L);
-  hipLaunchKernelGGL(k_tr_accept, dim3(vec_grid((int)std::min<size_t>(n, 1u << 30))), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(k_tr_accept, dim3(vec_grid((int)std::min<size_t>(n, 1u << 30))), dim3(256), 0, st, P, box, seq);
 }
 void launch_tr_decide(const DevProblem& P, TrConsts tc, hipStream_t st) {
   hipLaunchKernelGGL(k_tr_decide, dim3(1), dim3(64), 0, st, P, tc);

@@ -90,9 +90,29 @@ COV_DEV void z_of(const ObsLin& e, const double* R, double* Z) {
   }
 }
 
+// (compile-time A/B: -DCOVGPU_LMLIN_WAVES=n / -DCOVGPU_PAIR_WAVES=n cap the registers for n waves per SIMD; tools/gpu_ab.sh with COVGPU_LIBRARY)
+#ifndef COVGPU_LMLIN_WAVES
+#define COVGPU_LMLIN_WAVES 0
+#endif
+#ifndef COVGPU_PAIR_WAVES
+#define COVGPU_PAIR_WAVES 0
+#endif
+#if COVGPU_LMLIN_WAVES > 0
+#define LMLIN_ATTR __attribute__((amdgpu_waves_per_eu(COVGPU_LMLIN_WAVES, COVGPU_LMLIN_WAVES)))
+#else
+#define LMLIN_ATTR
+#endif
+#if COVGPU_PAIR_WAVES > 0
+#define PAIR_ATTR __attribute__((amdgpu_waves_per_eu(COVGPU_PAIR_WAVES, COVGPU_PAIR_WAVES)))
+#else
+#define PAIR_ATTR
+#endif
 template <int G>
-__global__ __launch_bounds__(kBuildThreads) void k_lm_lin(DevProblem P, double mu) {
+__global__ __launch_bounds__(kBuildThreads) LMLIN_ATTR void k_lm_lin(DevProblem P, double mu, DevSignal sig) {
   constexpr int GROUPS = kBuildThreads / G;
+  // "everything before this kernel on its stream is complete" (the previous iteration's state update, the preintegration): the side stream's
+  // kernels of this pass start from it — published here instead of by a launch in front of the pass's critical path
+  if (sig.flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sig.flag, sig.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int lane = threadIdx.x % G, grp = threadIdx.x / G;
   const int l = blockIdx.x * GROUPS + grp;
   const bool lm_ok = l < P.L;
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(64) void k_kf_reduce(DevProblem P) {
 // 0.78 ms on the 5-agent map, the longest kernel of the linearisation.)
 constexpr int kPairLanes = 16, kPairsPerWg = 8;
 constexpr int kPairChunk = 64;   // consecutive workgroups (of kPairsPerWg pairs) that one XCD takes together
-__global__ __launch_bounds__(kPairLanes * kPairsPerWg) void k_pair_blocks(DevProblem P, int pair_xcd_order) {
+__global__ __launch_bounds__(kPairLanes * kPairsPerWg) PAIR_ATTR void k_pair_blocks(DevProblem P, int pair_xcd_order) {
   __shared__ double sp[kPairsPerWg][36][kPairLanes + 1];
   const int grp = threadIdx.x / kPairLanes, g = threadIdx.x % kPairLanes;
   // XCD-aware order (round 5): workgroup b runs on XCD b % 8 (observed dispatch order; placement affects speed only). The pair list is sorted by
@@ -415,10 +435,10 @@ constexpr int kG = 16;
 // disjoint entries; whatever comes next on `st` follows both.
 // first pass alone (per-observation records, per-landmark blocks, cost partials: touches nothing of the pose system) — the caller
 // enqueues it ahead of the clearing of the fronts
-void launch_lm_lin(const DevProblem& P, double mu, hipStream_t st) {
+void launch_lm_lin(const DevProblem& P, double mu, hipStream_t st, DevSignal sig) {
   if (P.L == 0) return;
   const int groups = kBuildThreads / kG, nblk = (P.L + groups - 1) / groups;
-  hipLaunchKernelGGL(k_lm_lin<kG>, dim3(nblk), dim3(kBuildThreads), 0, st, P, mu);
+  hipLaunchKernelGGL(k_lm_lin<kG>, dim3(nblk), dim3(kBuildThreads), 0, st, P, mu, sig);
 }
 // the two passes that write the pose system, behind launch_lm_lin on `st`
 void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared, hipStream_t side, hipEvent_t ev_lin, hipEvent_t ev_kf, CholAux* ax) {

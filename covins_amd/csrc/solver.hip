@@ -63,6 +63,9 @@ struct covgpu_context {
   size_t alloc_bytes = 0;  // device bytes behind `allocs` (the footprint covgpu_get_layout reports)
   double* h_scal = nullptr;  // pinned mirror of P.scal + flag
   double* h_tr = nullptr;    // pinned mirror of P.tr (device-side trust region)
+  double* h_box = nullptr;   // pinned + mapped [TR_COUNT + 1]: the last kernel of an iteration posts P.tr and a sequence number here (k_tr_accept), the host polls it
+  double* d_box = nullptr;   // its device address (nullptr: not available — D2H copy + stream synchronisation)
+  double box_seq = 0.0;
   int profiling = 0;
   covgpu_profile_t prof;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -333,6 +336,13 @@ extern "C" int covgpu_create(const covgpu_options* opt, covgpu_context** out) {
   }
   HIPCHK(hipHostMalloc((void**)&c->h_scal, (SC_COUNT + 4) * sizeof(double), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&c->h_tr, TR_COUNT * sizeof(double), hipHostMallocDefault));
+  {
+    static const bool box_on = getenv("COVGPU_MAILBOX") == nullptr || atoi(getenv("COVGPU_MAILBOX")) != 0;
+    if (box_on && hipHostMalloc((void**)&c->h_box, (TR_COUNT + 1) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+      std::memset(c->h_box, 0, (TR_COUNT + 1) * sizeof(double));
+      if (hipHostGetDevicePointer((void**)&c->d_box, c->h_box, 0) != hipSuccess) c->d_box = nullptr;
+    } else { (void)hipGetLastError(); c->h_box = nullptr; }
+  }
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   std::memset(&c->P, 0, sizeof(c->P));
   *out = c;
@@ -358,6 +368,7 @@ extern "C" void covgpu_destroy(covgpu_context* c) {
   c->chol.destroy();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_tr) (void)hipHostFree(c->h_tr);
+  if (c->h_box) (void)hipHostFree(c->h_box);
   clear_shard(c);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
@@ -1066,17 +1077,27 @@ static void enqueue_build(covgpu_context* c, double mu) {
   // launches ahead of everything, the linearisation started ~0.1 ms into the iteration.)
   // (measured, round 4: clearing the fronts BEHIND the previous linear solve instead — under the trust-region tail — takes 0.11 ms off
   //  this pass and puts 0.12 ms onto the tail and the solve: the 0.65 GB of stores contend with the tail's re-linearisations)
-  launch_zero_system(P, c->st);
+  // (round 6: the landmark linearisation — the head of the pass's critical path — is the FIRST launch of the iteration on the main stream; the small
+  //  clears, which it does not depend on, open the side stream instead: their first readers are the inertial kernels there and, on the main
+  //  stream, kernels behind the join of the side stream (ev_kf). Before: clears, a fill and a record in front of it, ~12 us.)
+  // The side stream's kernels read the estimate (and the preintegration): they follow "the main stream is complete up to here", published by the
+  // landmark linearisation's own first thread (no launch in front of it) — or, without landmarks / device flags, by a record.
   hipStream_t side = c->chol.mid;
-  c->chol.record(c->chol.ev_zero, c->st);
-  launch_lm_lin(P, mu, c->st);   // writes per-observation records, per-landmark blocks and cost partials only
+  {
+    DevSignal sig = P.L > 0 ? c->chol.publish_handle(c->chol.ev_zero) : DevSignal();
+    if (sig.flag == nullptr) c->chol.record(c->chol.ev_zero, c->st);
+    launch_lm_lin(P, mu, c->st, sig);   // writes per-observation records, per-landmark blocks (incl. the landmark part of grad / hdiag) and cost partials only
+  }
+  c->chol.wait(side, c->chol.ev_zero);
+  launch_zero_system(P, side);
+  const bool forked = P.L > 0 && P.npairs > 0;   // (launch_lm_build's condition: its per-keyframe reduction and cost finisher run on `side`)
+  if (!forked) { c->chol.record(c->chol.ev_lin, side); c->chol.wait(c->st, c->chol.ev_lin); }   // ... else on the main stream: behind the clears (ev_lin is free: no fork)
   // (the head stream waits for nobody: every reader of the previous system has finished — each iteration ends with a host sync)
   if (P.nd) { launch_nd_zero(P, c->nd, c->chol.head); (void)hipMemsetAsync(P.nd_rhs, 0, c->nd.rhs_elems * sizeof(double), c->chol.head); }   // (the fronts' right-hand sides: was a fill on the chain, in front of the assembly)
   else (void)hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), c->chol.head);
   c->chol.record(c->chol.ev_fill, c->chol.head);
   // inertial factors (one wave per factor: latency, not throughput) on the side stream beside the landmark pass; their speed-bias
   // blocks are final before anything of the pose system is touched, the pose-dimension part is gathered after the visual blocks
-  c->chol.wait(side, c->chol.ev_zero);
   launch_imu_build(P, side);
   if (P.vi) {
     launch_imu_gather(P, 1, side);
@@ -1087,7 +1108,6 @@ static void enqueue_build(covgpu_context* c, double mu) {
   // the last kernel that writes one (the landmark pass's own finisher runs on the side stream when the pass forks).
   launch_edge_build(P, side);
   launch_lm_build(P, mu, c->st, c->chol.ev_fill, side, c->chol.ev_lin, c->chol.ev_kf, &c->chol);
-  const bool forked = P.L > 0 && P.npairs > 0;   // (launch_lm_build's condition: its finisher of the visual cost ran on `side`)
   if (forked) launch_part_finish(P, SC_COST, 1, side);
   c->chol.record(c->chol.ev_kf, side);
   c->chol.wait(c->st, c->chol.ev_kf);
@@ -1236,7 +1256,9 @@ static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_r
   const bool two = o.strategy == COVGPU_DOGLEG;
   const bool coll = c->sharded && c->reducer != nullptr;   // scalar all-reduce between a finish and the step logic that reads it
   static const bool host_timing = getenv("COVGPU_HOST_TIMING") != nullptr;   // dev aid: host enqueue time | host wait per iteration
+  bool use_box = false;
   while (it < o.max_iterations) {
+    use_box = false;
     const auto t_enq0 = std::chrono::steady_clock::now();
     if (fused_tail) {
       if (!reuse) {
@@ -1252,7 +1274,11 @@ static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_r
       launch_tail_cost(P, c->st);
       launch_tail_finish(P, tc, 2, two, !coll, 0, c->st);
       if (coll) { reduce_scalars(c); launch_tail_logic(P, tc, 2, 0, c->st); }
-      launch_tr_accept(P, c->st);
+      // (one GPU, no profiling events to collect: the state the host needs travels through the pinned mailbox, no D2H copy, no sleeping wait)
+      static const bool dev_aids = getenv("COVGPU_TRACE_PANELS") != nullptr || getenv("COVGPU_GATE_LOG") != nullptr;   // (their print-outs read events / device logs behind a synchronisation)
+      use_box = c->d_box != nullptr && !coll && !c->profiling && !host_timing && !dev_aids;
+      if (use_box) c->box_seq += 1.0;
+      launch_tr_accept(P, c->st, use_box ? c->d_box : nullptr, c->box_seq);
     } else {
     if (!reuse) {
       const double damp = (o.strategy == COVGPU_LM) ? 1.0 / h[TR_RADIUS] : h[TR_MU];
@@ -1274,9 +1300,29 @@ static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_r
     reduce_scalars(c);
     launch_tr_decide(P, tc, c->st);
     }
-    HIPCHK(hipMemcpyAsync(h, P.tr, TR_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
     const auto t_enq1 = std::chrono::steady_clock::now();
-    RC(wait_iteration(c));
+    if (use_box) {
+      // poll the sequence word (the kernel stores it with release semantics behind the state); every 4096 polls look at the stream: an error, or a stream
+      // that drained without the word arriving (never observed), ends in the ordinary path
+      volatile double* box = c->h_box;
+      bool got = false;
+      for (unsigned spins = 1; !got; ++spins) {
+        if (box[TR_COUNT] == c->box_seq) { got = true; break; }
+        if ((spins & 4095u) == 0) { const hipError_t q = hipStreamQuery(c->st); if (q != hipErrorNotReady) break; }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (got) {
+        for (int i = 0; i < TR_COUNT; ++i) h[i] = box[i];
+        HIPCHK(hipGetLastError());
+        if (c->chol.gate_failed()) { HIPCHK(hipStreamSynchronize(c->st)); g_err = "solve: a device-flag gate between the context's streams timed out"; return COVGPU_ERR_GATE_TIMEOUT; }
+      } else {
+        HIPCHK(hipMemcpyAsync(h, P.tr, TR_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
+        RC(wait_iteration(c));
+      }
+    } else {
+      HIPCHK(hipMemcpyAsync(h, P.tr, TR_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->st));
+      RC(wait_iteration(c));
+    }
     if (host_timing)
       std::fprintf(stderr, "[covgpu] iteration %d: host enqueue %.0f us, host wait %.0f us\n", it, std::chrono::duration<double>(t_enq1 - t_enq0).count() * 1e6,
                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enq1).count() * 1e6);

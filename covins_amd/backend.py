@@ -215,7 +215,7 @@ class Context:
     def layout(self) -> dict:
         out = (C.c_int64 * 16)()
         lib().covgpu_get_layout(self._h, out)
-        keys = ("shard_world", "shard_rank", "top_unknowns", "top_levels", "allreduce_kib", "reserved", "dense_order", "covisible_pairs",
+        keys = ("shard_world", "shard_rank", "top_unknowns", "top_levels", "allreduce_kib", "stream_ordering", "dense_order", "covisible_pairs",
                 "edge_pairs", "chains", "device_mib", "nd_fronts", "nd_levels", "nd_serial_panels", "nd_root_order", "nd_front_mib")
         return {k: int(out[i]) for i, k in enumerate(keys)}
 

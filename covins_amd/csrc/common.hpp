@@ -15,7 +15,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/covgpu.h"
@@ -277,7 +279,12 @@ struct CholAux {
   long long* gate_flags = nullptr;       // [kGateSlots] device
   int* gate_dead = nullptr;              // device: a gate gave up
   int* gate_dead_h = nullptr;            // pinned host mirror of it (written by the gate itself; read after the host synchronisation)
+  // A slot belongs to ONE (event, recording stream) pair: the signal is a plain store, and the numbers of a slot must arrive in order — the panel
+  // events are shared between the levels of a solve (k_chol.hip indexes one array by role and panel), so one event is recorded on the chain's
+  // stream at one level and on a side stream at the next; two streams storing into one slot can overtake each other and leave the OLDER number
+  // (round 6: the pose-graph solve hung on exactly that). gate_slot: event -> slot of its LAST record (what a wait polls).
   std::unordered_map<hipEvent_t, int> gate_slot;
+  std::map<std::pair<hipEvent_t, hipStream_t>, int> gate_slot_es;   // (event, stream) -> slot
   std::vector<long long> gate_seq;       // per slot: sequence number of the last record (0: never recorded)
   long long gate_counter = 0;
   double gate_timeout_s = 3.0;
@@ -286,10 +293,10 @@ struct CholAux {
   void wait(hipStream_t s, hipEvent_t e0, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
   // records and waits that stand side by side on one stream as ONE launch (every launch on the panel chain's stream is ~3.5 us under load): the
   // kernel publishes r0 / r1 first, then polls w0 .. w3 — the same order as record(r0); record(r1); wait(w0 ..)
-  DevSignal publish_handle(hipEvent_t e, int tag = 0);   // gates on: the handle for the next kernel of the recording stream (flag == nullptr: record(e, s) instead)
+  DevSignal publish_handle(hipEvent_t e, hipStream_t s, int tag = 0);   // gates on: the handle for the next kernel of the recording stream (flag == nullptr: record(e, s) instead)
   void sync(hipStream_t s, hipEvent_t r0, int tag0, hipEvent_t r1, int tag1, hipEvent_t w0 = nullptr, hipEvent_t w1 = nullptr, hipEvent_t w2 = nullptr,
             hipEvent_t w3 = nullptr);
-  int gate_slot_of(hipEvent_t e, bool create);
+  int gate_slot_of(hipEvent_t e, hipStream_t s);   // the slot of (e, s), created on demand; it becomes e's current slot
   // dev aid (COVGPU_GATE_LOG=1): every signal / gate stamps wall_clock64 (100 MHz) into a device log — an un-profiled timeline of the streams'
   // hand-overs, printed by collect(): "S<tag>@t" a signal of record(.., tag), "G<tag of the first awaited record>@t_start+wait" a gate
   long long* gate_log = nullptr; int gate_log_n = 0;

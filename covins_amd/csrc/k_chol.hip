@@ -331,8 +331,8 @@ void CholAux::init() {
   if (!gate_flags && !gates_broken) {
     static const bool want = getenv("COVGPU_GATES") == nullptr || atoi(getenv("COVGPU_GATES")) != 0;
     if (want && hipMalloc((void**)&gate_flags, kGateSlots * sizeof(long long)) == hipSuccess && hipMalloc((void**)&gate_dead, sizeof(int)) == hipSuccess &&
-        hipHostMalloc((void**)&gate_dead_h, sizeof(int), hipHostMallocDefault) == hipSuccess) {
-      (void)hipMemset(gate_flags, 0, kGateSlots * sizeof(long long)); (void)hipMemset(gate_dead, 0, sizeof(int)); *gate_dead_h = 0;
+        hipHostMalloc((void**)&gate_dead_h, 4 * sizeof(int), hipHostMallocDefault) == hipSuccess) {
+      (void)hipMemset(gate_flags, 0, kGateSlots * sizeof(long long)); (void)hipMemset(gate_dead, 0, sizeof(int)); gate_dead_h[0] = gate_dead_h[1] = gate_dead_h[2] = gate_dead_h[3] = 0;
       (void)hipDeviceSynchronize();   // (once per context: the fills are complete before the first gate polls)
       if (const char* e = getenv("COVGPU_GATE_TIMEOUT_S")) gate_timeout_s = std::max(getenv("COVGPU_GATE_TIMEOUT_MIN") ? atof(getenv("COVGPU_GATE_TIMEOUT_MIN")) : 0.01, atof(e));   // (the test of the fallback sets it below a kernel's duration)
       gates_on = true;
@@ -353,7 +353,7 @@ __global__ void k_signal(long long* flag, long long seq, long long* log) {
     if (log) log[0] = wall_clock64();
   }
 }
-struct GateArgs { const long long* f[4]; long long s[4]; int n; int* dead; int* dead_h; long long limit; long long* log; long long* pf[2]; long long ps[2]; int np; };
+struct GateArgs { const long long* f[4]; long long s[4]; int n; int* dead; int* dead_h; long long limit; long long* log; long long* pf[2]; long long ps[2]; int np; const long long* base; };
 __global__ void k_gate(GateArgs g) {
   if (threadIdx.x != 0) return;
   for (int i = 0; i < g.np; ++i) __hip_atomic_store(g.pf[i], g.ps[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // CholAux::sync: records first
@@ -367,42 +367,48 @@ __global__ void k_gate(GateArgs g) {
         if (__hip_atomic_load(g.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
         if (wall_clock64() - t0 > g.limit) {
           __hip_atomic_store(g.dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(g.dead_h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          // which wait gave up (printed with the host's warning): slot, the number awaited, the number found
+          __hip_atomic_store(g.dead_h + 1, (int)(g.f[i] - g.base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(g.dead_h + 2, (int)g.s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(g.dead_h + 3, (int)__hip_atomic_load(g.f[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(g.dead_h, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
           return;
         }
       }
     }
   }
 }
-int CholAux::gate_slot_of(hipEvent_t e, bool create) {
-  auto it = gate_slot.find(e);
-  if (it != gate_slot.end()) return it->second;
-  if (!create) return -1;
-  const int slot = (int)gate_slot.size();
-  if (slot >= kGateSlots) return -1;   // (never on the shipped maps: 9 events per panel of the widest level)
-  gate_slot.emplace(e, slot);
-  if ((int)gate_seq.size() <= slot) gate_seq.resize(slot + 1, 0);
+int CholAux::gate_slot_of(hipEvent_t e, hipStream_t s) {
+  const std::pair<hipEvent_t, hipStream_t> key(e, s);
+  auto it = gate_slot_es.find(key);
+  int slot;
+  if (it != gate_slot_es.end()) slot = it->second;
+  else {
+    slot = (int)gate_slot_es.size();
+    if (slot >= kGateSlots) return -1;   // (never on the shipped maps: 9 events per panel of the widest level, at most two streams each)
+    gate_slot_es.emplace(key, slot);
+    if ((int)gate_seq.size() <= slot) gate_seq.resize(slot + 1, 0);
+  }
+  gate_slot[e] = slot;
   return slot;
 }
 void CholAux::record(hipEvent_t e, hipStream_t s, int tag) {
   if (!gates_on) { (void)hipEventRecord(e, s); return; }
-  const int slot = gate_slot_of(e, true);
-  if (slot < 0) { (void)hipEventRecord(e, s); return; }
+  const int slot = gate_slot_of(e, s);
+  if (slot < 0) { gate_slot.erase(e); (void)hipEventRecord(e, s); return; }
   gate_seq[slot] = ++gate_counter;
   long long* lg = nullptr;
-  if (gate_log != nullptr && gate_log_n < kGateLogMax) {
-    lg = gate_log + 2 * (size_t)gate_log_n++; gate_log_tag.push_back(tag); gate_log_kind.push_back('S');
-    if ((int)gate_tag_of_slot.size() <= slot) gate_tag_of_slot.resize(slot + 1, 0);
-    gate_tag_of_slot[slot] = tag;
-  }
+  if ((int)gate_tag_of_slot.size() <= slot) gate_tag_of_slot.resize(slot + 1, 0);
+  gate_tag_of_slot[slot] = tag;
+  if (gate_log != nullptr && gate_log_n < kGateLogMax) { lg = gate_log + 2 * (size_t)gate_log_n++; gate_log_tag.push_back(tag); gate_log_kind.push_back('S'); }
   hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, gate_flags + slot, gate_seq[slot], lg);
   ++gate_signals;
 }
-DevSignal CholAux::publish_handle(hipEvent_t e, int tag) {
+DevSignal CholAux::publish_handle(hipEvent_t e, hipStream_t s, int tag) {
   DevSignal d;
   if (!gates_on) return d;
-  const int slot = gate_slot_of(e, true);
-  if (slot < 0) return d;
+  const int slot = gate_slot_of(e, s);
+  if (slot < 0) { gate_slot.erase(e); return d; }
   gate_seq[slot] = ++gate_counter;
   if ((int)gate_tag_of_slot.size() <= slot) gate_tag_of_slot.resize(slot + 1, 0);
   gate_tag_of_slot[slot] = tag;
@@ -420,14 +426,14 @@ void CholAux::sync(hipStream_t s, hipEvent_t r0, int tag0, hipEvent_t r1, int ta
     if (!gates_on) { for (hipEvent_t e : es) if (e != nullptr) (void)hipStreamWaitEvent(s, e, 0); return; }
     r0 = r1 = nullptr;
   }
-  GateArgs g; g.n = 0; g.dead = gate_dead; g.dead_h = gate_dead_h; g.limit = (long long)(gate_timeout_s * 1e8); g.log = nullptr; g.np = 0;
+  GateArgs g; g.n = 0; g.dead = gate_dead; g.dead_h = gate_dead_h; g.limit = (long long)(gate_timeout_s * 1e8); g.log = nullptr; g.np = 0; g.base = gate_flags;
   g.pf[0] = g.pf[1] = nullptr; g.ps[0] = g.ps[1] = 0;
   {
     hipEvent_t rs[2] = {r0, r1}; const int tags[2] = {tag0, tag1};
     for (int i = 0; i < 2; ++i) {
       if (rs[i] == nullptr) continue;
-      const int slot = gate_slot_of(rs[i], true);
-      if (slot < 0) { (void)hipEventRecord(rs[i], s); continue; }
+      const int slot = gate_slot_of(rs[i], s);
+      if (slot < 0) { gate_slot.erase(rs[i]); (void)hipEventRecord(rs[i], s); continue; }
       gate_seq[slot] = ++gate_counter;
       if ((int)gate_tag_of_slot.size() <= slot) gate_tag_of_slot.resize(slot + 1, 0);
       gate_tag_of_slot[slot] = tags[i];
@@ -451,7 +457,7 @@ void CholAux::sync(hipStream_t s, hipEvent_t r0, int tag0, hipEvent_t r1, int ta
 }
 void CholAux::gates_disable() {
   gates_on = false; gates_broken = true;
-  gate_slot.clear(); gate_seq.clear();
+  gate_slot.clear(); gate_slot_es.clear(); gate_seq.clear();
   if (gate_dead) (void)hipMemset(gate_dead, 0, sizeof(int));
   if (gate_dead_h) *gate_dead_h = 0;
 }
@@ -490,7 +496,7 @@ void CholAux::destroy() {
   if (gate_dead) { (void)hipFree(gate_dead); gate_dead = nullptr; }
   if (gate_log) { (void)hipFree(gate_log); gate_log = nullptr; }
   if (gate_dead_h) { (void)hipHostFree(gate_dead_h); gate_dead_h = nullptr; }
-  gates_on = false; gate_slot.clear(); gate_seq.clear();
+  gates_on = false; gate_slot.clear(); gate_slot_es.clear(); gate_seq.clear();
   if (bwd_scr) { (void)hipFree(bwd_scr); bwd_scr = nullptr; bwd_scr_elems = 0; }
   if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
 }

@@ -560,11 +560,11 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     for (int l = l0; l < l1; ++l) {
       hipEvent_t pre = nullptr;
       if (prev_split) {
-        ax.record(ax.ev_xa, st);      // (the bulk stream already follows the level below through its own update; this
+        ax.record(ax.ev_xa, st, 5);   // (the bulk stream already follows the level below through its own update; this
         ax.wait(ax.aux, ax.ev_xa);    //  also covers a batch that declined the split)
         extend(l, top_children, 1, st);
         extend(l, top_children, 2, ax.aux);
-        ax.record(ax.ev_xb, ax.aux);
+        ax.record(ax.ev_xb, ax.aux, 6);
         pre = ax.ev_xb;
       } else extend(l, top_children, 0, st);
       const NdLevel& L = nd.lev[l];

@@ -394,7 +394,7 @@ extern "C" void covgpu_get_profile2(covgpu_context* c, double* out) {
   out[12] = out[13] = out[14] = out[15] = 0.0;
 }
 
-// out[16] = { shard world, shard rank, scalar unknowns of the replicated top, top levels, KiB all-reduced per linear solve, 0,
+// out[16] = { shard world, shard rank, scalar unknowns of the replicated top, top levels, KiB all-reduced per linear solve, stream ordering (1 flags | 0 events | -1 fell back),
 //             dense order npad, covisible pairs, edge pairs, IMU chains, device MiB allocated for the problem,
 //             fronts, levels, serial 256-column panels, order of the root level, MiB of fronts } (include/covgpu.h)
 extern "C" void covgpu_get_layout(covgpu_context* c, int64_t* out) {
@@ -404,6 +404,7 @@ extern "C" void covgpu_get_layout(covgpu_context* c, int64_t* out) {
   out[0] = c->sharded ? c->world : 0; out[1] = c->sharded ? c->rank : 0; out[2] = c->nd.ntop;   // ranks | rank | scalar unknowns of the replicated top nodes
   out[3] = (int64_t)c->nd.lev.size() - c->nd.top_lev0;                                          // top levels
   out[4] = (int64_t)(((c->nd.top_pack != nullptr ? (size_t)c->nd.n_top_tiles * kTile * kTile : c->nd.M_elems - c->nd.M_sub) + c->nd.rhs_top + 2 * (size_t)c->nd.ntop) * sizeof(double)) >> 10;  // KiB all-reduced per linear solve
+  out[5] = c->chol.gates_on ? 1 : (c->chol.gates_broken && getenv("COVGPU_GATES") == nullptr ? -1 : 0);   // stream ordering: 1 device flags | 0 HIP events (COVGPU_GATES=0) | -1 fell back to events after a gate timed out
   out[6] = P.npad; out[7] = P.npairs; out[8] = P.nepairs; out[9] = P.nchains; out[10] = (int64_t)(c->alloc_bytes >> 20);
   if (P.nd) {  // multifrontal form: nodes, levels, serial 256-column panels (sum of the levels' interior orders / 256), root order, front bytes (MiB)
     out[11] = P.nd_nnodes; out[12] = P.nd_nlev;
@@ -1084,18 +1085,18 @@ static void enqueue_build(covgpu_context* c, double mu) {
   // landmark linearisation's own first thread (no launch in front of it) — or, without landmarks / device flags, by a record.
   hipStream_t side = c->chol.mid;
   {
-    DevSignal sig = P.L > 0 ? c->chol.publish_handle(c->chol.ev_zero) : DevSignal();
-    if (sig.flag == nullptr) c->chol.record(c->chol.ev_zero, c->st);
+    DevSignal sig = P.L > 0 ? c->chol.publish_handle(c->chol.ev_zero, c->st, 1) : DevSignal();
+    if (sig.flag == nullptr) c->chol.record(c->chol.ev_zero, c->st, 1);
     launch_lm_lin(P, mu, c->st, sig);   // writes per-observation records, per-landmark blocks (incl. the landmark part of grad / hdiag) and cost partials only
   }
   c->chol.wait(side, c->chol.ev_zero);
   launch_zero_system(P, side);
   const bool forked = P.L > 0 && P.npairs > 0;   // (launch_lm_build's condition: its per-keyframe reduction and cost finisher run on `side`)
-  if (!forked) { c->chol.record(c->chol.ev_lin, side); c->chol.wait(c->st, c->chol.ev_lin); }   // ... else on the main stream: behind the clears (ev_lin is free: no fork)
+  if (!forked) { c->chol.record(c->chol.ev_lin, side, 2); c->chol.wait(c->st, c->chol.ev_lin); }   // ... else on the main stream: behind the clears (ev_lin is free: no fork)
   // (the head stream waits for nobody: every reader of the previous system has finished — each iteration ends with a host sync)
   if (P.nd) { launch_nd_zero(P, c->nd, c->chol.head); (void)hipMemsetAsync(P.nd_rhs, 0, c->nd.rhs_elems * sizeof(double), c->chol.head); }   // (the fronts' right-hand sides: was a fill on the chain, in front of the assembly)
   else (void)hipMemsetAsync(P.Sred, 0, (size_t)P.npad * P.npad * sizeof(double), c->chol.head);
-  c->chol.record(c->chol.ev_fill, c->chol.head);
+  c->chol.record(c->chol.ev_fill, c->chol.head, 3);
   // inertial factors (one wave per factor: latency, not throughput) on the side stream beside the landmark pass; their speed-bias
   // blocks are final before anything of the pose system is touched, the pose-dimension part is gathered after the visual blocks
   launch_imu_build(P, side);
@@ -1109,7 +1110,7 @@ static void enqueue_build(covgpu_context* c, double mu) {
   launch_edge_build(P, side);
   launch_lm_build(P, mu, c->st, c->chol.ev_fill, side, c->chol.ev_lin, c->chol.ev_kf, &c->chol);
   if (forked) launch_part_finish(P, SC_COST, 1, side);
-  c->chol.record(c->chol.ev_kf, side);
+  c->chol.record(c->chol.ev_kf, side, 4);
   c->chol.wait(c->st, c->chol.ev_kf);
   launch_imu_gather(P, 0, c->st);  // pose-dimension part: adds onto the blocks k_kf_reduce assigned (fixed order: visual, inertial, loop)
   launch_edge_gather(P, c->st);
@@ -1369,7 +1370,9 @@ static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_r
 static int solve_any(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) {
   int rc = solve_impl_dev(c, opt, out);
   if (rc == COVGPU_ERR_GATE_TIMEOUT) {
-    std::fprintf(stderr, "[covgpu] warning: device-flag stream ordering timed out; repeating the solve with HIP events (this context keeps them)\n");
+    std::fprintf(stderr, "[covgpu] warning: device-flag stream ordering timed out (slot %d awaited %d, found %d; %ld signals, %ld gates so far); repeating the solve with HIP events (this context keeps them)\n",
+                 c->chol.gate_dead_h[1], c->chol.gate_dead_h[2], c->chol.gate_dead_h[3], c->chol.gate_signals, c->chol.gate_waits);
+    if (c->chol.gate_dead_h[1] >= 0 && c->chol.gate_dead_h[1] < (int)c->chol.gate_tag_of_slot.size()) std::fprintf(stderr, "[covgpu]          (tag of that slot: %d)\n", c->chol.gate_tag_of_slot[c->chol.gate_dead_h[1]]);
     (void)hipDeviceSynchronize();
     c->chol.gates_disable();
     rc = solve_impl_dev(c, opt, out);

@@ -49,6 +49,25 @@ def test_device_flag_ordering_equals_event_ordering(tmp_path, name):
         assert np.array_equal(a[k], b[k]), f"device-flag ordering and event ordering differ in {k}"
 
 
+def test_no_solve_falls_back_to_events():
+    """Device-flag ordering must hold on every path without ever reaching its timeout: GBA and — the case that hung in round 6, when two streams
+    stored into one flag slot (one panel event recorded on the chain's stream at one level and on a side stream at the next) — the pose graph,
+    on one context, one after the other (covgpu_get_layout: stream_ordering 1 = flags, -1 = fell back to events)."""
+    from covins_amd import backend, mapdata, synth
+    m = synth.make_map(synth.config_named("mh123"))
+    p, _ = mapdata.flatten_gba(m, visual_only=False, loop_loss=True)
+    q = mapdata.flatten_pgo(m, {}, mapdata.PgoParams())[0]
+    ctx = backend.Context(0)
+    try:
+        for _ in range(2):
+            ctx.gba_solve(p, backend.default_options(max_iterations=4))
+            assert ctx.layout()["stream_ordering"] == 1
+            sol, res = ctx.pgo_solve(q, backend.default_options(max_iterations=10))
+            assert ctx.layout()["stream_ordering"] == 1 and res.final_cost < res.initial_cost
+    finally:
+        ctx.close()
+
+
 def test_gate_timeout_falls_back_to_events(tmp_path):
     """A gate that cannot be satisfied in time raises the context's give-up flag; the solve is repeated with HIP events and the result is the
     event ordering's (here the timeout is set below a kernel's duration: 1e-7 s)."""

@@ -348,9 +348,9 @@ int bwd_front_max_tiles();   // fronts of at most this many interior tiles: back
 void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStream_t st, int tfact, int tend, DenseBatch bt = DenseBatch());
 // 256-column panel chain (k_panel.hip): with it the Linv buffer holds, per tile, the eight 16x16 diagonal-block inverses
 // instead of the 128x128 inverse. COVGPU_PANEL=0 selects the round-2a chain (two 128-column potrf + inverse per panel).
-void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
+bool launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
                         hipStream_t st, const long long* btab = nullptr, int nb = -1, const int* own = nullptr, const int* list = nullptr, int n_big = 0,
-                        int n_small = 0);   // nb: 16-column blocks to factor (-1: the whole panel); own / list / n_big / n_small: k_panel.hip (round 6)
+                        int n_small = 0, DevSignal sa = DevSignal(), DevSignal sb = DevSignal());   // returns false if nothing was launched   // nb: 16-column blocks to factor (-1: the whole panel); own / list / n_big / n_small: k_panel.hip (round 6)
 void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, double* x, int ncol, int nbt, size_t sM, size_t sR, hipStream_t st,
                       const long long* btab, const int* live, int tI, BwdXfer xf = BwdXfer());
 void launch_bwd_front(const double* S, int tI, int ntiles, int nchunk, double* y, const double* Linv, int nbt, size_t sL, size_t sR, hipStream_t st,

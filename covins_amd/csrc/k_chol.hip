@@ -353,6 +353,11 @@ __global__ void k_signal(long long* flag, long long seq, long long* log) {
     if (log) log[0] = wall_clock64();
   }
 }
+__global__ void k_signal2(DevSignal a, DevSignal b) {
+  if (threadIdx.x != 0) return;
+  if (a.flag != nullptr) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (b.flag != nullptr) __hip_atomic_store(b.flag, b.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 struct GateArgs { const long long* f[4]; long long s[4]; int n; int* dead; int* dead_h; long long limit; long long* log; long long* pf[2]; long long ps[2]; int np; const long long* base; };
 __global__ void k_gate(GateArgs g) {
   if (threadIdx.x != 0) return;
@@ -674,14 +679,24 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   }
   // k_potrf_panel of big panel P, all fronts of the batch; profiling: an event pair around the launch and its algorithmic flops
   // (per front n^3 / 3 for the factorisation + n^2 for the forward substitution riding along, n = the front's REAL columns in the panel)
+  // records of the chain's stream waiting to be published by the next panel factorisation's first thread (CholAux::publish_handle)
+  DevSignal pend[2]; hipEvent_t pend_ev[2] = {nullptr, nullptr}; int pend_tag[2] = {0, 0}; int npend = 0;
+  auto flush_pending = [&]() {   // no factorisation follows (or none was launched): an ordinary launch publishes them
+    if (npend == 0) return;
+    hipLaunchKernelGGL(k_signal2, dim3(1), dim3(64), 0, M, pend[0], npend > 1 ? pend[1] : DevSignal());
+    npend = 0;
+  };
   auto potrf = [&](int t0, int w, int nbp) {
     const bool prof = ax.profile && nbp != 0;
     if (prof) {
       while (ax.prof_ev2.size() < 2 * (ax.prof_flops2.size() + 1)) { hipEvent_t e; (void)hipEventCreate(&e); ax.prof_ev2.push_back(e); }
       (void)hipEventRecord(ax.prof_ev2[2 * ax.prof_flops2.size()], M);
     }
-    if (bt.plist != nullptr) launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp, bt.own_dims, bt.plist, bt.pbig_h[t0 / 2], bt.psmall_h[t0 / 2]);
-    else launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp);
+    const DevSignal sa = npend > 0 ? pend[0] : DevSignal(), sb = npend > 1 ? pend[1] : DevSignal();
+    bool launched;
+    if (bt.plist != nullptr) launched = launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp, bt.own_dims, bt.plist, bt.pbig_h[t0 / 2], bt.psmall_h[t0 / 2], sa, sb);
+    else launched = launch_potrf_panel(S, ld, t0, w, Linv, flag, b, npad, nbt, bt.sM, bt.sL, bt.sR, M, bt.tab, nbp, nullptr, nullptr, 0, 0, sa, sb);
+    if (launched) npend = 0; else flush_pending();
     if (prof) {
       double fl = 0.0;
       for (int a = 0; a < nbt; ++a) {
@@ -722,6 +737,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       }
     }
     if (P == Pstop) {  // only the look-ahead updates of the last eliminated panel; nothing of this panel is factored
+      flush_pending();
       record(eH[P], H, 100 * (P + 1) + 10);
       record(eC[P], R, 100 * (P + 1) + 12);
       record(eB[P], B, 100 * (P + 1) + 11);
@@ -863,7 +879,16 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       // (A bulk launched at the same instant as the next diagonal update takes every workgroup slot first and the chain waits
       //  ~75 us for the first round of tiles to retire: the bulk starts after that small kernel in either regime.)
       if (chain_bound || eh_now) record(chain_bound ? eH[P] : eRc[P], M, 100 * (P + 1) + (chain_bound ? 10 : 16));
-      else ax.sync(M, eH[P], 100 * (P + 1) + 10, eRc[P], 100 * (P + 1) + 16);
+      else {
+        // (round 6) both records ride with the NEXT panel's factorisation, whose first thread publishes them: their waiters — stream H's look-ahead
+        // of the next panel, the bulk update — are enqueued before that launch, but the chain's stream waits for neither of them in between
+        static const bool ride = getenv("COVGPU_RECORD_RIDE") == nullptr || atoi(getenv("COVGPU_RECORD_RIDE")) != 0;
+        if (ride && ax.gates_on && npend == 0) {
+          pend[0] = ax.publish_handle(eH[P], M, 100 * (P + 1) + 10); pend[1] = ax.publish_handle(eRc[P], M, 100 * (P + 1) + 16);
+          npend = (pend[0].flag != nullptr && pend[1].flag != nullptr) ? 2 : 0;
+          if (npend == 0) { record(eH[P], M, 100 * (P + 1) + 10); record(eRc[P], M, 100 * (P + 1) + 16); }   // (out of slots: HIP events took over inside publish_handle's fallback)
+        } else ax.sync(M, eH[P], 100 * (P + 1) + 10, eRc[P], 100 * (P + 1) + 16);
+      }
       if (T > h1 && !merge) {
         wait(R, chain_bound ? eH[P] : e1[P]);   // (measured, round 4: waiting for rows h instead — so that the chain's substitution runs alone — 299.9 -> 297.5 it/s)
         launch_trsm_sub(S, ld, t0, w, h1, T, Linv, b, npad, nbt, bt.sM, bt.sL, bt.sR, bt.live, bt.tI, R, false, bt.tab, nbp, bt.own_dims);
@@ -898,10 +923,17 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       const int cntC = (listed && P < (int)tc.listC.size() && tc.listC[P] != nullptr) ? tc.countC[P] : 0;
       if (!listed || tc.count[P] > 0 || cntC > 0) {
         if (ax.profile) (void)hipEventRecord(ax.prof_ev[2 * ax.prof_flops.size()], B);
+        // A long bulk update keeps every CU full for hundreds of microseconds, and the next panel's factorisation — one 16-wave workgroup that needs an
+        // EMPTY CU — waits for its tail (12-agent map, root: period = bulk + the whole exposed chain). In pieces of kBulkChunk tiles the chip drains
+        // between two launches and the waiting workgroup (higher stream priority) gets its CU. (0: one launch.)
+        static const int kBulkChunk = getenv("COVGPU_BULK_CHUNK") ? atoi(getenv("COVGPU_BULK_CHUNK")) : 0;
         auto tri = [&](const int* list, int count) {
-          g.tri = list;
-          if (count <= kQuarterMax) hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_TRI, 64, 64>), dim3(count, 1, 4), dim3(256), (size_t)(64 + 64) * (KCQ + kLdsPad) * sizeof(double), B, g);
-          else hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(count, 1), dim3(256), lds_gemm, B, g);
+          if (count <= kQuarterMax) { g.tri = list; hipLaunchKernelGGL((k_gemm_abt_q<MODE_SYRK_TRI, 64, 64>), dim3(count, 1, 4), dim3(256), (size_t)(64 + 64) * (KCQ + kLdsPad) * sizeof(double), B, g); return; }
+          const int step = kBulkChunk > 0 ? std::max(512, (kBulkChunk / 8) * 8) : count;
+          for (int o = 0; o < count; o += step) {
+            g.tri = list + o;
+            hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK_TRI>, dim3(std::min(step, count - o), 1), dim3(256), lds_gemm, B, g);
+          }
         };
         if (cntC > 0) {   // the next-but-one panel's two tile columns first: what the chain waits for
           tri(tc.listC[P], cntC);
@@ -920,6 +952,7 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
     record(eB[P], B, 100 * (P + 1) + 11);
     if (!recA) record(eA[P], B, 100 * (P + 1) + 18);
   }
+  flush_pending();
   wait(M, !split_last && !tail_on_chain ? eB[Plast] : nullptr, Plast >= 1 ? eB[Plast - 1] : nullptr, !tail_on_chain ? eC[Plast] : nullptr, !tail_on_chain ? eH[Plast] : nullptr);
   if (!solve) return;
   // y = L^-1 b was formed along the way (potrf: y_p = L_pp^-1 b_p; every TRSM: b[rows] -= L[rows, p] y_p) and lives

@@ -216,8 +216,14 @@ COV_DEV void panel_out(const double* pan, double* sRhs, const double* rs, double
 template <int NWV>
 COV_DEV void potrf_panel_body(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
                               const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR,
-                              const long long* __restrict__ btab, const int* __restrict__ own, const int* __restrict__ list) {
+                              const long long* __restrict__ btab, const int* __restrict__ own, const int* __restrict__ list, DevSignal sa, DevSignal sb) {
   constexpr int PROWS = (NWV == 16) ? 256 : PROWS4;   // (shadows the 16-wave constant)
+  // records of the chain's stream that stand right in front of this launch are published by its first thread (CholAux::publish_handle): at this
+  // point everything enqueued before the launch is complete — one launch less per panel on the serial chain
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (sa.flag != nullptr) __hip_atomic_store(sa.flag, sa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sb.flag != nullptr) __hip_atomic_store(sb.flag, sb.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   constexpr int NTW = (NWV == 16) ? 12 : 3;           // tile waves
   const int front = list != nullptr ? list[blockIdx.x] : (int)blockIdx.x;
   if (own != nullptr) {
@@ -491,14 +497,14 @@ COV_DEV void potrf_panel_body(double* __restrict__ M, size_t ld, int k0, int nb,
 
 __global__ __launch_bounds__(64 * NW) void k_potrf_panel(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
                                                          const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR,
-                                                         const long long* __restrict__ btab, const int* __restrict__ own, const int* __restrict__ list) {
-  potrf_panel_body<16>(M, ld, k0, nb, Dinv_out, flag, rhs, yout, bsM, bsL, bsR, btab, own, list);
+                                                         const long long* __restrict__ btab, const int* __restrict__ own, const int* __restrict__ list, DevSignal sa, DevSignal sb) {
+  potrf_panel_body<16>(M, ld, k0, nb, Dinv_out, flag, rhs, yout, bsM, bsL, bsR, btab, own, list, sa, sb);
 }
 // (three workgroups per CU: 42 KB of LDS each; at most 168 registers per wave)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_potrf_panel4(double* __restrict__ M, size_t ld, int k0, int nb, double* __restrict__ Dinv_out, int* flag,
                                                          const double* __restrict__ rhs, double* __restrict__ yout, size_t bsM, size_t bsL, size_t bsR,
-                                                         const long long* __restrict__ btab, const int* __restrict__ own, const int* __restrict__ list) {
-  potrf_panel_body<4>(M, ld, k0, nb, Dinv_out, flag, rhs, yout, bsM, bsL, bsR, btab, own, list);
+                                                         const long long* __restrict__ btab, const int* __restrict__ own, const int* __restrict__ list, DevSignal sa, DevSignal sb) {
+  potrf_panel_body<4>(M, ld, k0, nb, Dinv_out, flag, rhs, yout, bsM, bsL, bsR, btab, own, list, sa, sb);
 }
 
 struct TrsmSubArgs {
@@ -1021,10 +1027,10 @@ void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, dou
                      sR, btab, live, tI, xf);
 }
 
-void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
-                        hipStream_t st, const long long* btab, int nb, const int* own, const int* list, int n_big, int n_small) {
+bool launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* flag, double* b, int npad, int nbt, size_t sM, size_t sL, size_t sR,
+                        hipStream_t st, const long long* btab, int nb, const int* own, const int* list, int n_big, int n_small, DevSignal sa, DevSignal sb) {
   if (nb < 0) nb = 8 * w;
-  if (nb == 0) return;  // an all-padding panel of every front of the batch: L = I, Dinv = I, y = 0 are in place
+  if (nb == 0) return false;  // an all-padding panel of every front of the batch: L = I, Dinv = I, y = 0 are in place
   static bool once = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds4);
@@ -1034,18 +1040,20 @@ void launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* 
   double* Lp = Linv + (size_t)t0 * kTile * kTile;
   const double* yb = b ? b + npad : nullptr;
   if (list == nullptr) {   // every front of the batch in the sixteen-wave form (arrow blocks of the pose graph, the dense solve)
-    hipLaunchKernelGGL(k_potrf_panel, dim3(nbt), dim3(64 * NW), kPanelLds, st, S, ld, t0 * kTile, nb, Lp, flag, (const double*)b, (double*)yb, sM, sL, sR, btab, own, list);
-    return;
+    hipLaunchKernelGGL(k_potrf_panel, dim3(nbt), dim3(64 * NW), kPanelLds, st, S, ld, t0 * kTile, nb, Lp, flag, (const double*)b, (double*)yb, sM, sL, sR, btab, own, list, sa, sb);
+    return true;
   }
   // list[0 .. n_big): fronts with more than 128 real columns in this panel | list[n_big .. n_big + n_small): the others that have any (four waves)
   // The four-wave form runs three fronts per CU on the same three matrix pipes: per front it is slower (one tile wave per SIMD instead of four), so it
   // only pays when the small fronts outnumber the CUs — 5-agent map, 182 speed-bias segments: 245 it/s with it against 250 without.
   static const int small_min = getenv("COVGPU_POTRF4_MIN") ? atoi(getenv("COVGPU_POTRF4_MIN")) : 384;
   if (n_small <= small_min) { n_big += n_small; n_small = 0; }
-  if (n_big > 0) hipLaunchKernelGGL(k_potrf_panel, dim3(n_big), dim3(64 * NW), kPanelLds, st, S, ld, t0 * kTile, nb, Lp, flag, (const double*)b, (double*)yb, sM, sL, sR, btab, own, list);
+  // (the pending records go out with the first launch that happens; false: nothing was launched — the caller publishes them itself)
+  if (n_big > 0) hipLaunchKernelGGL(k_potrf_panel, dim3(n_big), dim3(64 * NW), kPanelLds, st, S, ld, t0 * kTile, nb, Lp, flag, (const double*)b, (double*)yb, sM, sL, sR, btab, own, list, sa, sb);
   if (n_small > 0)
     hipLaunchKernelGGL(k_potrf_panel4, dim3(n_small), dim3(256), kPanelLds4, st, S, ld, t0 * kTile, std::min(nb, 8), Lp, flag, (const double*)b, (double*)yb, sM, sL, sR, btab, own,
-                       list + n_big);
+                       list + n_big, n_big > 0 ? DevSignal() : sa, n_big > 0 ? DevSignal() : sb);
+  return n_big > 0 || n_small > 0;
 }
 
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,

@@ -293,7 +293,8 @@ struct CholAux {
   void wait(hipStream_t s, hipEvent_t e0, hipEvent_t e1 = nullptr, hipEvent_t e2 = nullptr, hipEvent_t e3 = nullptr);
   // records and waits that stand side by side on one stream as ONE launch (every launch on the panel chain's stream is ~3.5 us under load): the
   // kernel publishes r0 / r1 first, then polls w0 .. w3 — the same order as record(r0); record(r1); wait(w0 ..)
-  DevSignal publish_handle(hipEvent_t e, hipStream_t s, int tag = 0);   // gates on: the handle for the next kernel of the recording stream (flag == nullptr: record(e, s) instead)
+  DevSignal publish_handle(hipEvent_t e, hipStream_t s, int tag = 0);
+  void record_handle(DevSignal d, hipStream_t s);   // publishes a handle by a launch of its own after all (the kernel it was meant for is not launched)   // gates on: the handle for the next kernel of the recording stream (flag == nullptr: record(e, s) instead)
   void sync(hipStream_t s, hipEvent_t r0, int tag0, hipEvent_t r1, int tag1, hipEvent_t w0 = nullptr, hipEvent_t w1 = nullptr, hipEvent_t w2 = nullptr,
             hipEvent_t w3 = nullptr);
   int gate_slot_of(hipEvent_t e, hipStream_t s);   // the slot of (e, s), created on demand; it becomes e's current slot

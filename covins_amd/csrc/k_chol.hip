@@ -421,6 +421,7 @@ DevSignal CholAux::publish_handle(hipEvent_t e, hipStream_t s, int tag) {
   ++gate_signals;
   return d;
 }
+void CholAux::record_handle(DevSignal d, hipStream_t s) { if (d.flag != nullptr) hipLaunchKernelGGL(k_signal2, dim3(1), dim3(64), 0, s, d, DevSignal()); }
 void CholAux::wait(hipStream_t s, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3) { sync(s, nullptr, 0, nullptr, 0, e0, e1, e2, e3); }
 void CholAux::sync(hipStream_t s, hipEvent_t r0, int tag0, hipEvent_t r1, int tag1, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3) {
   hipEvent_t es[4] = {e0, e1, e2, e3};
@@ -880,9 +881,13 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
       //  ~75 us for the first round of tiles to retire: the bulk starts after that small kernel in either regime.)
       if (chain_bound || eh_now) record(chain_bound ? eH[P] : eRc[P], M, 100 * (P + 1) + (chain_bound ? 10 : 16));
       else {
-        // (round 6) both records ride with the NEXT panel's factorisation, whose first thread publishes them: their waiters — stream H's look-ahead
-        // of the next panel, the bulk update — are enqueued before that launch, but the chain's stream waits for neither of them in between
-        static const bool ride = getenv("COVGPU_RECORD_RIDE") == nullptr || atoi(getenv("COVGPU_RECORD_RIDE")) != 0;
+        // (round 6, OPT-IN: COVGPU_RECORD_RIDE=1) both records ride with the NEXT panel's factorisation, whose first thread publishes them — one launch
+        // less per panel (-1 % of the factorisation). Their waiters (stream H's look-ahead of the next panel, the bulk update) are then enqueued BEFORE
+        // the launch that publishes: harmless while every stream has a hardware queue of its own, a deadlock (until the gate's timeout) as soon as
+        // two streams of the process share one — a gate in front of the publishing launch in the same queue holds it back. Several contexts in one
+        // process (virtual ranks, the facade's context beside another) do share queues: tests/test_gpu_shard.py hung on it. Default: off —
+        // every gate is enqueued after the launch that publishes its record, and the ordering cannot deadlock whatever the queue mapping.
+        static const bool ride = getenv("COVGPU_RECORD_RIDE") != nullptr && atoi(getenv("COVGPU_RECORD_RIDE")) != 0;
         if (ride && ax.gates_on && npend == 0) {
           pend[0] = ax.publish_handle(eH[P], M, 100 * (P + 1) + 10); pend[1] = ax.publish_handle(eRc[P], M, 100 * (P + 1) + 16);
           npend = (pend[0].flag != nullptr && pend[1].flag != nullptr) ? 2 : 0;

@@ -349,7 +349,9 @@ __global__ __launch_bounds__(256) void k_nd_assemble(DevProblem P, const int* __
 // One workgroup per 64x64 tile of a host-built list (only tiles some child contributes to); a thread owns a 4x4 sub-grid.
 // Round 5: tile and child descriptors flattened on the host (NdDev::extw / extc): tile -> child entry -> row map -> value, with the child entry two
 // and the row maps one child ahead of the gather — the kernel is a chain of dependent loads on the critical path of every level transition.
-__global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, const int* __restrict__ work, const int* __restrict__ child, int second_pass, int store_border) {
+__global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, const int* __restrict__ work, const int* __restrict__ child, int second_pass, int store_border, DevSignal sig) {
+  // ("the chain's stream has finished the level below": published by this launch's first thread instead of a launch of its own — CholAux::publish_handle)
+  if (sig.flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sig.flag, sig.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int4 w0 = reinterpret_cast<const int4*>(work)[2 * (size_t)blockIdx.x], w1 = reinterpret_cast<const int4*>(work)[2 * (size_t)blockIdx.x + 1];
   const size_t foff = (size_t)(unsigned)w0.x | ((size_t)(unsigned)w0.y << 32);
   const size_t ld = (size_t)w0.z;
@@ -531,7 +533,7 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     return bt;
   };
   // part: 0 all tiles | 1 the tiles of the fronts' first 256 rows | 2 the others
-  auto extend = [&](int l, bool top_children, int part, hipStream_t s2) {
+  auto extend = [&](int l, bool top_children, int part, hipStream_t s2, DevSignal sig = DevSignal()) -> bool {
     const NdLevel& L = nd.lev[l];
     int first = top_children ? L.ext2_first : L.ext_first, count = top_children ? L.ext2_count : L.ext_count;
     const int countA = top_children ? L.ext2_countA : L.ext_countA;
@@ -539,7 +541,8 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     if (part == 2) { first += countA; count -= countA; }
     if (count > 0)
       hipLaunchKernelGGL(k_nd_extend, dim3(count), dim3(256), 0, s2, P, lev_args(P, nd, l), (const int*)(nd.extw + 8 * (size_t)first),
-                         (const int*)(top_children ? nd.extc2 : nd.extc), top_children ? 1 : 0, (!top_children && l < ltop && nd_store_border()) ? 1 : 0);
+                         (const int*)(top_children ? nd.extc2 : nd.extc), top_children ? 1 : 0, (!top_children && l < ltop && nd_store_border()) ? 1 : 0, sig);
+    return count > 0;
   };
   // split: the trailing update of this level's last panel is split for the look-ahead into the next level (DenseBatch::split_ta)
   auto factor = [&](int l, bool split, hipEvent_t pre_trsm) {
@@ -560,9 +563,13 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     for (int l = l0; l < l1; ++l) {
       hipEvent_t pre = nullptr;
       if (prev_split) {
-        ax.record(ax.ev_xa, st, 5);   // (the bulk stream already follows the level below through its own update; this
-        ax.wait(ax.aux, ax.ev_xa);    //  also covers a batch that declined the split)
-        extend(l, top_children, 1, st);
+        // (the bulk stream already follows the level below through its own update; this also covers a batch that declined the split. Round 6: the
+        //  record rides with the first half of the extend-add — published by its first thread — when that launch exists)
+        DevSignal sig = ax.publish_handle(ax.ev_xa, st, 5);
+        const int cntA = top_children ? nd.lev[l].ext2_countA : nd.lev[l].ext_countA;
+        if (sig.flag == nullptr || cntA <= 0) { if (sig.flag != nullptr) ax.record_handle(sig, st); else ax.record(ax.ev_xa, st, 5); sig = DevSignal(); }
+        extend(l, top_children, 1, st, sig);
+        ax.wait(ax.aux, ax.ev_xa);
         extend(l, top_children, 2, ax.aux);
         ax.record(ax.ev_xb, ax.aux, 6);
         pre = ax.ev_xb;

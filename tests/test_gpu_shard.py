@@ -45,6 +45,9 @@ def run_virtual_ranks(prob, plan, job):
     for t in th: t.join(timeout=600)
     assert not err, err
     grp.close()
+    # round 6: several contexts in one process share the runtime's hardware queues — exactly where a device-flag gate enqueued in front of the launch
+    # that publishes its record would dead-lock (and time out into the event ordering): every rank must still be on flags (1), or on events by request (0)
+    assert all(s[1]["stream_ordering"] >= 0 for s in stats if s is not None), [s[1]["stream_ordering"] for s in stats if s is not None]
     return out, stats[0]
 
 

@@ -8,6 +8,9 @@ tag=${1:-pmc}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
+# counter collection serialises kernels: a polling gate kernel (device-flag stream ordering, round 6) would wait for a producer the profiler has not
+# let start. The counters are per kernel and do not depend on how the streams are ordered: HIP events here.
+export COVGPU_GATES=0
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
   rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_$ctr -o pmc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --sustain-s 0 --a12-leg 0 > $root/gpurun_out/${tag}_pmc_$ctr.log 2>&1
@@ -52,7 +55,12 @@ for row in csv.DictReader(open(os.path.join(root, "gpurun_out", "${tag}_pmc_hbm_
         c = int(row["Calls"]); b = c * (float(row["FETCH_x2_MB_per_call"]) + float(row["WRITE_MB_per_call"])) * 1048576.0
         bbytes += b; parts[nm] = parts.get(nm, 0.0) + b
         if nm == "k_lm_lin": its = c
+ext = 0.0
+for row in csv.DictReader(open(os.path.join(root, "gpurun_out", "${tag}_pmc_hbm_traffic.csv"))):
+    if "k_nd_extend" in row["Name"]:
+        ext += int(row["Calls"]) * (float(row["FETCH_x2_MB_per_call"]) + float(row["WRITE_MB_per_call"])) * 1048576.0
 if its:
+    out["extend_add_bytes_per_iteration"] = ext / its   # (round 6: the extend-add stores the border x border tiles whole instead of k_nd_zero clearing them)
     out["build_bytes_per_iteration"] = bbytes / its
     out["build_bytes_by_kernel"] = {k: round(v / its / 1e6, 1) for k, v in sorted(parts.items(), key=lambda kv: -kv[1])}   # MB
 busy = wsum = 0.0

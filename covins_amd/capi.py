@@ -216,6 +216,7 @@ def declare(lib: C.CDLL, prefix: str) -> None:
         d("covisibility", [C.c_void_p, C.c_int32, C.c_int64, _ip, _ip, _ip, C.POINTER(C.c_int64)])
         d("gba_solve_multi", [OP, PP, RP, C.c_int32, _ip, C.c_double, _bp, _ip, C.POINTER(C.c_int64)])
         d("nd_plan_create", [OP, PP, C.c_int32, C.POINTER(C.c_void_p)])
+        d("nd_plan_create_pgo", [OP, PP, C.c_int32, C.POINTER(C.c_void_p)])
         d("nd_plan_destroy", [C.c_void_p], None)
         d("nd_plan_info", [C.c_void_p, C.POINTER(C.c_int64)], None)
         d("nd_plan_arrays", [C.c_void_p, _ip, _ip, _ip, _ip, _ip, _ip], None)

@@ -592,6 +592,32 @@ static int nd_plan_create_mode(const covgpu_options* opt, const covgpu_problem* 
     return (int)COVGPU_OK;
   });
 }
+// Host-only: the plan PoseGraphOptimization's solve runs on (round 6): 6-dof blocks, chains read from the edge graph (build_chains_pgo), couplings = the edge pairs
+extern "C" int covgpu_nd_plan_create_pgo(const covgpu_options* opt, const covgpu_problem* p, int32_t leaf_dims, covgpu_nd_plan** out) {
+  (void)opt;
+  return guarded([&] {
+    *out = nullptr;
+    RC(validate(p, true, false));
+    std::vector<int> perm, pos_kf, chain_ptr;
+    build_chains_pgo(p, perm, pos_kf, chain_ptr);
+    std::vector<uint64_t> keys;
+    for (int e = 0; e < p->num_edge; ++e) {
+      const int a = perm[p->edge_i[e]], b = perm[p->edge_j[e]];
+      if (a == b) { g_err = "invalid problem: self edge"; return (int)COVGPU_ERR_INVALID_ARG; }
+      keys.push_back(((uint64_t)(uint32_t)std::max(a, b) << 32) | (uint32_t)std::min(a, b));
+    }
+    std::sort(keys.begin(), keys.end()); keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    std::vector<int> ei(keys.size()), ej(keys.size());
+    for (size_t q = 0; q < keys.size(); ++q) { ei[q] = (int)(keys[q] >> 32); ej[q] = (int)(keys[q] & 0xffffffffull); }
+    covgpu_nd_plan* pl = new covgpu_nd_plan();
+    pl->pos_kf = pos_kf;
+    if (!nd_plan_build(p->num_kf, false, (int)chain_ptr.size() - 1, chain_ptr.data(), 0, nullptr, nullptr, (int)ei.size(), ei.data(), ej.data(), nd_leaf_dims(leaf_dims), pl->hp, -1)) {
+      delete pl; g_err = "nested-dissection plan: a coupling joins two branches"; return (int)COVGPU_ERR_INVALID_ARG;
+    }
+    *out = pl;
+    return (int)COVGPU_OK;
+  });
+}
 extern "C" void covgpu_nd_plan_destroy(covgpu_nd_plan* pl) { delete pl; }
 // out[16] = { nodes, levels, depth, own entries, front-structure entries, front elements (all batches), flops, largest own dims,
 //             largest border dims, root own dims, 0 ... }

@@ -316,6 +316,9 @@ int32_t covgpu_pgo_partition(int32_t num_kf, int32_t num_edge, const int32_t* ed
  * leaf_dims <= 0: default (COVGPU_ND_LEAF or 600 scalar unknowns per leaf). tests/test_nd_plan.py replays the plan in numpy. */
 typedef struct covgpu_nd_plan covgpu_nd_plan;
 int  covgpu_nd_plan_create(const covgpu_options* opt, const covgpu_problem* p, int32_t leaf_dims, covgpu_nd_plan** out);
+/* the same for a pose-graph problem (edges only): the plan covgpu_pgo_solve runs on since round 6 — 6-dof blocks, an agent's time axis read from the
+ * edge graph (connected components of the graph without its bridges, each in breadth-first order: solver.hip build_chains_pgo) */
+int  covgpu_nd_plan_create_pgo(const covgpu_options* opt, const covgpu_problem* p, int32_t leaf_dims, covgpu_nd_plan** out);
 void covgpu_nd_plan_destroy(covgpu_nd_plan* plan);
 /* out16 = { nodes, levels, depth, own entries, front-structure entries, front elements over all batches, flops of the partial
  *           factorisations, largest own dims, largest border dims, largest root, 0... } */

@@ -13,11 +13,11 @@ from covins_amd import backend, mapdata, synth
 from oracle import covo
 
 
-def _plan(prob, opt, leaf):
+def _plan(prob, opt, leaf, pgo=False):
     lib = backend.lib()
     h = C.c_void_p()
     s = prob.as_struct()
-    rc = lib.covgpu_nd_plan_create(C.byref(opt), C.byref(s), leaf, C.byref(h))
+    rc = (lib.covgpu_nd_plan_create_pgo if pgo else lib.covgpu_nd_plan_create)(C.byref(opt), C.byref(s), leaf, C.byref(h))
     assert rc == 0, lib.covgpu_last_error()
     info = (C.c_int64 * 16)()
     lib.covgpu_nd_plan_info(h, info)
@@ -249,3 +249,28 @@ def test_many_short_imu_chains_plan_in_milliseconds(small_map, keep_every):
     x = _replay(S, bvec, parent, level, own, st, 15)
     xd = np.linalg.solve(S, bvec)
     assert np.abs(x - xd).max() <= 1e-9 * np.abs(xd).max()
+
+
+@pytest.mark.parametrize("name,kf,leaf", [("small", None, 60), ("mh123", 120, 0)])
+def test_pose_graph_plan_replays_to_the_dense_solve(name, kf, leaf):
+    """Round 6: PoseGraphOptimization's linear solve runs on the elimination tree too (covgpu_nd_plan_create_pgo: 6-dof blocks, an agent's time axis
+    read from the edge graph — connected components of the graph without its bridges, each in breadth-first order). The plan replayed in numpy on
+    the ORACLE's pose-graph system (optimization_be.cpp:846-1021 assembled by oracle/covo.schur(pgo=True)) must equal the dense solve: every edge's
+    block has its place in a front, no fill outside the fronts; the chains must be few (one per agent, not one per keyframe) and the separators of
+    the time axis narrow."""
+    cfg = synth.config_named(name)
+    if kf:
+        cfg.max_kf_per_agent = kf
+    cfg.drift_trans = 0.05; cfg.drift_yaw_deg = 0.5
+    m = synth.make_map(cfg)
+    p = mapdata.flatten_pgo(m, {}, mapdata.PgoParams())[0]
+    S, bvec, _ = covo.schur(p, covo.default_options(), 1e-6, pgo=True)
+    info, parent, level, own, st = _plan(p, backend.default_options(), leaf, pgo=True)
+    assert all((v & 1) == 0 for o in own for v in o)
+    x = _replay(S, bvec, parent, level, own, st, 6)
+    xd = np.linalg.solve(S, bvec)
+    assert np.abs(x - xd).max() <= 1e-8 * np.abs(xd).max()
+    od = np.array([6 * len(o) for o in own])
+    if info[0] > 3:
+        # the root separates agents (a cover of the few loop edges) or halves of a time axis (~5 keyframes): far below the system's order
+        assert od[np.asarray(parent) < 0].max() <= max(90, 6 * p.K // 8)

@@ -33,6 +33,7 @@ struct DevProblem {
   int npad;    // n rounded up to a multiple of kTile (leading dimension of Sred)
   int N;       // n + 3 L
   int vi;      // 1: speed-bias blocks + IMU factors active
+  int lm_group;  // lanes per landmark of the landmark-major kernels: 4 | 8 | 16 (k_visual.hip; 0 = 16)
   double reproj_loss_a, gravity;
 
   // state: current, candidate, initial (restart point of covgpu_solve_resident)

@@ -25,6 +25,8 @@
 //   obs_*          one thread per observation over the SoA stream (cost, J*v products, test dumps).
 // All writes to the pose system go through c_entry (common.hpp): the fronts of the multifrontal solve (nd_entry), or the dense
 // matrix of the per-kernel test entry points.
+#include <type_traits>
+
 #include "common.hpp"
 #include "dev_math.hpp"
 #include "reduce.hpp"
@@ -428,7 +430,12 @@ static inline int stream_grid(int n) {
   return b < 1 ? 1 : (b > 2048 ? 2048 : b);  // memory-bound streams: cap at 8 blocks x 256 CUs, grid-stride the rest
 }
 
-constexpr int kG = 16;
+// lanes per landmark of the landmark-major kernels (k_lm_lin, k_lm_backsub, k_lm_outliers): DevProblem::lm_group, chosen at upload from the map's mean
+// track length (round 6) — the 5-agent map's tracks average 10 observations (16 lanes: 63 % of the lanes busy), configs[4]'s 4.1 (16 lanes: 25 %)
+template <typename F> static void with_group(int g, F&& f) {
+  if (g == 4) f(std::integral_constant<int, 4>()); else if (g == 8) f(std::integral_constant<int, 8>()); else f(std::integral_constant<int, 16>());
+}
+static int lm_blocks(const DevProblem& P) { const int g = P.lm_group == 4 || P.lm_group == 8 ? P.lm_group : 16; const int groups = kBuildThreads / g; return (P.L + groups - 1) / groups; }
 
 // side != nullptr: the per-keyframe reduction (diagonal blocks, gradient, right-hand side: compute-heavy re-linearisation) runs on the
 // side stream beside the pair pass (off-diagonal blocks: L2-bound record reads) — both follow the landmark pass only and write
@@ -437,8 +444,8 @@ constexpr int kG = 16;
 // enqueues it ahead of the clearing of the fronts
 void launch_lm_lin(const DevProblem& P, double mu, hipStream_t st, DevSignal sig) {
   if (P.L == 0) return;
-  const int groups = kBuildThreads / kG, nblk = (P.L + groups - 1) / groups;
-  hipLaunchKernelGGL(k_lm_lin<kG>, dim3(nblk), dim3(kBuildThreads), 0, st, P, mu, sig);
+  const int nblk = lm_blocks(P);
+  with_group(P.lm_group, [&](auto G) { hipLaunchKernelGGL(k_lm_lin<decltype(G)::value>, dim3(nblk), dim3(kBuildThreads), 0, st, P, mu, sig); });
 }
 // the two passes that write the pose system, behind launch_lm_lin on `st`
 void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t pose_system_cleared, hipStream_t side, hipEvent_t ev_lin, hipEvent_t ev_kf, CholAux* ax) {
@@ -446,7 +453,7 @@ void launch_lm_build(const DevProblem& P, double mu, hipStream_t st, hipEvent_t 
   auto record = [&](hipEvent_t e, hipStream_t s) { if (ax) ax->record(e, s); else (void)hipEventRecord(e, s); };
   auto wait = [&](hipStream_t s, hipEvent_t e0, hipEvent_t e1 = nullptr) { if (ax) ax->wait(s, e0, e1); else { if (e0) (void)hipStreamWaitEvent(s, e0, 0); if (e1) (void)hipStreamWaitEvent(s, e1, 0); } };
   if (P.L == 0) { if (pose_system_cleared) wait(st, pose_system_cleared); return; }
-  const int groups = kBuildThreads / kG, nblk = (P.L + groups - 1) / groups;
+  const int nblk = lm_blocks(P);
   const bool fork = side != nullptr && ev_lin != nullptr && ev_kf != nullptr && P.npairs > 0;
   hipStream_t s2 = fork ? side : st;
   // the side stream follows the landmark linearisation; the first writers of the pose system (both streams) follow the clearing of the fronts
@@ -484,8 +491,7 @@ void launch_kobs_build(const DevProblem& P, int* pair_oa, int* pair_ob, size_t n
 }
 void launch_lm_backsub(const DevProblem& P, const double* dp, double* out_all, hipStream_t st) {
   if (P.L == 0) return;
-  const int groups = kBuildThreads / kG;
-  hipLaunchKernelGGL(k_lm_backsub<kG>, dim3((P.L + groups - 1) / groups), dim3(kBuildThreads), 0, st, P, dp, out_all);
+  with_group(P.lm_group, [&](auto G) { hipLaunchKernelGGL(k_lm_backsub<decltype(G)::value>, dim3(lm_blocks(P)), dim3(kBuildThreads), 0, st, P, dp, out_all); });
 }
 void launch_obs_jvp(const DevProblem& P, const double* v_all, hipStream_t st) {
   if (P.O == 0) return;
@@ -530,8 +536,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_lm_outliers(DevProblem P, dou
 }
 void launch_lm_outliers(const DevProblem& P, double th, unsigned char* erase, int* left, unsigned long long* counts, hipStream_t st) {
   if (P.L == 0) return;
-  constexpr int GROUPS = kBuildThreads / kG;
-  hipLaunchKernelGGL(k_lm_outliers<kG>, dim3((P.L + GROUPS - 1) / GROUPS), dim3(kBuildThreads), 0, st, P, th, erase, left, counts);
+  with_group(P.lm_group, [&](auto G) { hipLaunchKernelGGL(k_lm_outliers<decltype(G)::value>, dim3(lm_blocks(P)), dim3(kBuildThreads), 0, st, P, th, erase, left, counts); });
 }
 
 void launch_obs_norms(const DevProblem& P, double* norms, hipStream_t st) {

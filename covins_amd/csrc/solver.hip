@@ -754,6 +754,11 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
   P.I = vi ? p->num_imu : 0; P.E = p->num_edge;
   P.S = P.I ? p->imu_sample_ptr[P.I] : 0;
   P.vi = vi; P.D = vi ? 15 : 6; P.n = P.D * P.K;
+  {  // lanes per landmark of the landmark-major kernels, from the mean track length (COVGPU_LM_GROUP forces 4 / 8 / 16)
+    const double mean_track = P.L > 0 ? (double)P.O / P.L : 0.0;
+    P.lm_group = mean_track <= 5.0 ? 4 : (mean_track <= 8.0 ? 8 : 16);   // configs[4] (4.1): linearise+Schur 4.65 ms at 16 lanes, 4.24 at 8, 4.11 at 4; 5-agent map (10.0): 16 and 8 alike
+    if (const char* e = getenv("COVGPU_LM_GROUP")) { const int g = atoi(e); if (g == 4 || g == 8 || g == 16) P.lm_group = g; }
+  }
   P.npad = ((6 * P.K + kTile - 1) / kTile) * kTile;  // dense stage = pose-pose system only (k_struct.hip)
   P.N = P.n + 3 * P.L;
   // IMU chains -> chain-major keyframe order

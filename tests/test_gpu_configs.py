@@ -33,7 +33,9 @@ def test_config3_three_agents_pgo_then_gba():
     a2 = ate(m)
     # (round 5: cameras look where the ground truth says — at the hall's far walls — and agent 3 carries the recorded IMU, which agrees with the
     #  ground-truth file to a few centimetres only: the oracle ends at 0.030 m on this map, 0.021 / 0.027 / 0.031 per agent)
-    assert info["outliers_removed"] >= 0 and a2 < a0 and a2 < 0.05 and a2 <= a1 * 1.05
+    print(f"config3: ATE start {a0:.4f} after PGO {a1:.4f} after GBA {a2:.4f} m")
+    # (bounds pinned to the oracle's value with a 20 % margin — observed 0.0293)
+    assert info["outliers_removed"] >= 0 and a2 < a0 and a2 < 1.2 * 0.030 and a2 <= a1 * 1.05
     tr = np.array(info["round2"].cost_trace[:info["round2"].iterations])
     assert np.all(np.diff(tr) <= 1e-9 * tr[:-1])
     assert m.kf_gba_optimized.all()
@@ -50,11 +52,13 @@ def test_gba_outlier_round_removes_gross_outliers():
     info = Optimization.GlobalBundleAdjustment(m, 10, -1.0, False, True, False)
     removed = info["outliers_removed"]
     assert 0.03 * n_obs < removed < 0.12 * n_obs and m.O == n_obs - removed
-    assert ate(m) < 0.04      # (what 15 s of trajectory per agent and landmarks 5-12 m away determine: the oracle ends at 0.027 m)
+    print(f"outlier round: ATE {ate(m):.4f} m")
+    assert ate(m) < 1.2 * 0.027      # observed 0.0285 (what 15 s of trajectory per agent and landmarks 5-12 m away determine: the oracle ends at 0.027 m)
     # without the outlier round the Cauchy loss still keeps the estimate sane, but worse
     m2 = synth.make_map(cfg)
     Optimization.GlobalBundleAdjustment(m2, 10, -1.0, False, False, False)
-    assert m2.O == n_obs and ate(m2) < 0.1
+    print(f"without the outlier round: ATE {ate(m2):.4f} m")
+    assert m2.O == n_obs and ate(m2) < 0.04   # observed 0.0267
 
 
 def test_dogleg_and_lm_agree_at_convergence():
@@ -92,7 +96,8 @@ def test_visual_only_gba_and_equidistant_camera():
     rng = np.random.default_rng(0)
     me.obs_uv[idx.obs_rows] = (r * pt.obs_sigma[:, None] + rng.normal(0, 1.0, r.shape)).astype(np.float32)
     Optimization.GlobalBundleAdjustment(me, 10, -1.0, False, True, False)
-    assert ate(me) < 0.04
+    print(f"equidistant: ATE {ate(me):.4f} m")
+    assert ate(me) < 0.03   # observed 0.0243
 
 
 @pytest.mark.parametrize("fix_loaded", [False, True])

@@ -66,7 +66,7 @@ def test_full_size_solve_matches_oracle_golden(ctx, name, sname, strategy):
     print(f"{name}/{sname}: max|dp|={dp:.2e} m, max angle={da:.2e} rad, max|dsb|={ds:.2e}, landmarks good<={d_good:.2e} m "
           f"whitened<={d_white:.2e} ill={n_ill}/{len(idx)}, ATE gpu {ate_gpu:.6f} cpu {ate_cpu:.6f} (delta {abs(ate_gpu - ate_cpu):.2e} m)")
     assert dp < 1e-6 and da < 1e-7 and ds < 1e-6
-    assert d_good < 1e-6 and d_white < 1e-4 and n_ill <= len(idx) // 12
+    assert d_good < 1e-6 and d_white < 1e-4 and n_ill <= 5   # (observed 0 .. 1 of 2 731 .. 10 754 stored landmarks)
     assert abs(ate_gpu - ate_cpu) < 1e-3  # north-star acceptance: final ATE within 1e-3 m of the CPU path (printed: ~1e-9)
 
 

@@ -244,7 +244,8 @@ def _compare_solution(sol, ref, res, rres, o, pos_tol=1e-6, ang_tol=1e-7, lm_tol
     assert rot_angle(sol.kf_pose[:, :4], ref.kf_pose[:, :4]).max() < ang_tol
     if sol.L:
         n_ill, d_good, d_white = landmark_parity(sol.lm_pos, ref)
-        assert d_good < 1e-6 and d_white < 1e-4 and n_ill <= max(5, sol.L // 12), (n_ill, d_good, d_white)
+        print(f"landmark parity: ill-conditioned {n_ill} of {sol.L}, well-conditioned within {d_good:.2e} m, whitened {d_white:.2e}")
+        assert d_good < 1e-6 and d_white < 1e-4 and n_ill <= 5, (n_ill, d_good, d_white)   # (observed: 0 of 295 / 5 037)
     assert abs(res.final_cost - rres.final_cost) <= 1e-8 * rres.final_cost
 
 

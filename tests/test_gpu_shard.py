@@ -91,6 +91,13 @@ def test_sharded_gauss_newton_step_equals_unsharded(name, world):
           f"{np.abs(dl - dl0).max():.2e} m, {st['collectives']} collectives, {st['bytes'] / 1e6:.1f} MB, top unknowns {lay['top_unknowns']}")
     assert np.abs(dx - dx0).max() <= 1e-9 * scale
     assert np.abs(dl - dl0).max() <= 1e-9 * max(np.abs(dl0).max(), 1.0)
+    if (name, world) == ("mh123", 2):
+        #  ... and once against the DEFAULT one-GPU tree, another elimination order of the same system: rounding x condition (observed 3e-9 at mu = 1e-8)
+        ctx = backend.Context(0)
+        dxd, dld, _ = ctx.gn_step(p, o, 1e-8)
+        ctx.close()
+        print(f"{name} world {world}: against the default tree {np.abs(dx - dxd).max() / scale:.2e} (relative)")
+        assert np.abs(dx - dxd).max() <= 1e-7 * scale
     assert st["collectives"] == 1    # one exchange per linear solve (covgpu_gn_step reads no trust-region scalars)
 
 
@@ -115,7 +122,9 @@ def test_sharded_solve_equals_unsharded(name, world, strategy):
     # ones within 1e-4 whitened units (a landmark almost on one ray moves micrometres along it between two summation orders)
     from tests.util import landmark_parity
     n_ill, d_good, d_white = landmark_parity(sol.lm_pos, s0)
-    assert dp < 1e-8 and ds < 1e-8 and d_good < 1e-6 and d_white < 1e-4 and n_ill <= p.L // 12
+    print(f"{name} world {world}: ill-conditioned landmarks {n_ill} of {p.L}, well-conditioned within {d_good:.2e} m, whitened {d_white:.2e}")
+    # (the count of ill-conditioned landmarks bounded by what is measured — 0 .. 3 of 86 030 — not by L / 12)
+    assert dp < 1e-8 and ds < 1e-8 and d_good < 1e-6 and d_white < 1e-4 and n_ill <= 10
     assert per_it <= 3.0   # top fronts once per linear solve + two scalar exchanges (k_tail.hip); a rejected step needs one less
 
 

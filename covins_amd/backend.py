@@ -76,6 +76,27 @@ def default_options(**kw) -> Options:
     return o
 
 
+def gba_two_round_multi(prob: FlatProblem, opt: Options, threshold: float, devices, round1_iterations: int = 5, use_loops_round2: bool = True,
+                        loop_loss_round2: float = 1.0, kf_fixed_round2=None):
+    """Both rounds of GlobalBundleAdjustment on len(devices) ranks behind one call (covgpu_gba_two_round_multi; ranks that share a device are virtual
+    ranks on the library's in-process group). Returns what Context.gba_two_round returns."""
+    q = prob.copy(); s = q.as_struct(); r1 = Result(); r2 = Result()
+    erase = np.zeros(max(prob.O, 1), np.uint8); left = np.zeros(max(prob.L, 1), np.int32); cnt = (C.c_int64 * 2)()
+    tr = capi.TwoRound()
+    tr.outlier_threshold = float(threshold); tr.round1_iterations = int(round1_iterations); tr.use_loops_round2 = int(bool(use_loops_round2))
+    tr.loop_loss_round2 = float(loop_loss_round2)
+    fx = None
+    if kf_fixed_round2 is not None:
+        fx = np.ascontiguousarray(kf_fixed_round2, np.uint8)
+        tr.kf_fixed_round2 = fx.ctypes.data_as(C.POINTER(C.c_uint8))
+    dev = np.ascontiguousarray(devices, np.int32)
+    rc = lib().covgpu_gba_two_round_multi(C.byref(opt), C.byref(s), C.byref(tr), len(dev), iptr(dev), erase.ctypes.data_as(capi._bp), iptr(left), cnt,
+                                          C.byref(r1), C.byref(r2))
+    if rc != 0:
+        raise CovGpuError(f"covgpu error {rc}: {lib().covgpu_last_error().decode()}")
+    return q, r1, r2, erase[:prob.O].astype(bool), left[:prob.L], (int(cnt[0]), int(cnt[1]))
+
+
 class Context:
     """One solver context = one HIP stream + HBM workspace (covgpu_create / covgpu_destroy)."""
 

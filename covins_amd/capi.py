@@ -215,6 +215,7 @@ def declare(lib: C.CDLL, prefix: str) -> None:
         d("outlier_pass", [C.c_void_p, C.c_double, _bp, _ip, C.POINTER(C.c_int64)])
         d("covisibility", [C.c_void_p, C.c_int32, C.c_int64, _ip, _ip, _ip, C.POINTER(C.c_int64)])
         d("gba_solve_multi", [OP, PP, RP, C.c_int32, _ip, C.c_double, _bp, _ip, C.POINTER(C.c_int64)])
+        d("gba_two_round_multi", [OP, PP, C.POINTER(TwoRound), C.c_int32, _ip, _bp, _ip, C.POINTER(C.c_int64), RP, RP])
         d("nd_plan_create", [OP, PP, C.c_int32, C.POINTER(C.c_void_p)])
         d("nd_plan_create_pgo", [OP, PP, C.c_int32, C.POINTER(C.c_void_p)])
         d("nd_plan_destroy", [C.c_void_p], None)

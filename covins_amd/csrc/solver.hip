@@ -1457,7 +1457,9 @@ static int gba_two_round_impl(covgpu_context* c, const covgpu_options* opt, covg
                               int32_t* lm_left, int64_t* counts, covgpu_result* round1, covgpu_result* round2) {
   return guarded([&]() -> int {
     if (!tr || !obs_erase || !lm_left) { g_err = "covgpu_gba_two_round: NULL argument"; return (int)COVGPU_ERR_INVALID_ARG; }
-    if (c->sharded) { g_err = "covgpu_gba_two_round runs on one GPU (sharded solve: covgpu_gba_solve_multi per round)"; return (int)COVGPU_ERR_INVALID_ARG; }
+    // (round 6: a sharded context takes the call too — every rank derives the second round of ITS share on its device: its landmarks' outlier decisions,
+    //  compaction and pair lists are local, the elimination tree stays, and both solves issue the same collectives on every rank. The caller merges the
+    //  ranks' flags and estimates: covgpu_gba_two_round_multi.)
     covgpu_options o1 = *opt;
     o1.max_iterations = tr->round1_iterations > 0 ? tr->round1_iterations : 5;   // :262
     auto t0 = std::chrono::steady_clock::now();
@@ -1593,8 +1595,10 @@ void make_sub(const covgpu_problem& p, int r, const int32_t* lm_rank, const int3
 }
 }  // namespace
 
-extern "C" int covgpu_gba_solve_multi(const covgpu_options* opt, covgpu_problem* p, covgpu_result* out, int32_t n_ranks, const int32_t* devices,
-                                      double outlier_threshold, uint8_t* obs_erase, int32_t* lm_left, int64_t* counts) {
+// tr == nullptr: ONE solve per rank (+ the outlier decisions at its estimate when obs_erase is given) | tr != nullptr: both rounds of a GlobalBundleAdjustment
+// call per rank (gba_two_round_impl on the rank's sharded context; `out1` = the first round's result)
+static int gba_multi_impl(const covgpu_options* opt, covgpu_problem* p, covgpu_result* out, int32_t n_ranks, const int32_t* devices,
+                          double outlier_threshold, uint8_t* obs_erase, int32_t* lm_left, int64_t* counts, const covgpu_two_round* tr, covgpu_result* out1) {
   return guarded([&] {
     if (n_ranks < 1 || n_ranks > 16 || !devices) { g_err = "covgpu_gba_solve_multi: 1..16 ranks with a device each"; return (int)COVGPU_ERR_INVALID_ARG; }
     std::vector<int32_t> lm_rank(std::max(p->num_lm, 1)), imu_rank(std::max(p->num_imu, 1)), edge_rank(std::max(p->num_edge, 1));
@@ -1611,7 +1615,7 @@ extern "C" int covgpu_gba_solve_multi(const covgpu_options* opt, covgpu_problem*
     struct GroupGuard { covgpu_group* g; ~GroupGuard() { if (g) covgpu_group_destroy(g); } } grp_guard{grp};
     std::vector<SubProblem> sub(n_ranks);
     for (int r = 0; r < n_ranks; ++r) make_sub(*p, r, lm_rank.data(), imu_rank.data(), edge_rank.data(), sub[r]);
-    std::vector<covgpu_result> res(n_ranks);
+    std::vector<covgpu_result> res(n_ranks), res1(n_ranks);
     std::vector<int> rcs(n_ranks, COVGPU_OK);
     std::vector<std::string> errs(n_ranks);
     std::vector<std::vector<uint8_t>> er(n_ranks);
@@ -1637,6 +1641,17 @@ extern "C" int covgpu_gba_solve_multi(const covgpu_options* opt, covgpu_problem*
       if (!fail.load()) give_up(grp ? covgpu_set_shard_group(c, plan, r, grp) : covgpu_set_shard_rccl(c, plan, r, n_ranks, uid));   // stage 2: the collective (ncclCommInitRank: every rank is here)
       if (c) c->peer_fail = &fail;
       bar.wait();
+      if (tr != nullptr) {
+        // both rounds behind one call on this rank's share (upload, outlier round, device-side second round, solve, download into the share's arrays)
+        if (!fail.load()) {
+          er[r].assign(sub[r].obs_kf.size() + 1, 0); ll[r].assign(sub[r].lm_id.size() + 1, 0);
+          give_up(gba_two_round_impl(c, &o, &sub[r].view, tr, er[r].data(), ll[r].data(), &cnt[2 * (size_t)r], &res1[r], &res[r]));
+          if (c) c->have = false;
+        }
+        rcs[r] = rc;
+        if (c) covgpu_destroy(c);
+        return;
+      }
       const auto t_up0 = std::chrono::steady_clock::now();
       if (!fail.load()) give_up(guarded([&] { return upload_impl(c, &o, &sub[r].view, false); }));  // (guarded: a host exception in a rank's thread would otherwise terminate the process with the peers parked at the barrier) stage 3: validation + H2D of the rank's share (OOM, malformed share)
       const double t_up = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_up0).count();
@@ -1681,19 +1696,33 @@ extern "C" int covgpu_gba_solve_multi(const covgpu_options* opt, covgpu_problem*
         if (obs_erase) for (size_t i = 0; i < sub[r].obs_id.size(); ++i) obs_erase[sub[r].obs_id[i]] = er[r][i];
         if (counts) { counts[0] += cnt[2 * (size_t)r]; counts[1] += cnt[2 * (size_t)r + 1]; }
       }
-      if (out) {
+      auto combine = [&](covgpu_result* dst, const std::vector<covgpu_result>& rs) {
+        if (!dst) return;
         // the trust-region trace, costs and counts are identical on every rank (all-reduced scalars): rank 0's. Per-rank fields
         // are combined: IMU factors dropped for a non-PD covariance are counted where the factor lives (sum), timings are the slowest rank's
-        *out = res[0];
+        *dst = rs[0];
         for (int r = 1; r < n_ranks; ++r) {
-          out->reserved += res[r].reserved;
-          out->t_upload_s = std::max(out->t_upload_s, res[r].t_upload_s); out->t_download_s = std::max(out->t_download_s, res[r].t_download_s);
-          out->t_solve_s = std::max(out->t_solve_s, res[r].t_solve_s);
+          dst->reserved += rs[r].reserved;
+          dst->t_upload_s = std::max(dst->t_upload_s, rs[r].t_upload_s); dst->t_download_s = std::max(dst->t_download_s, rs[r].t_download_s);
+          dst->t_solve_s = std::max(dst->t_solve_s, rs[r].t_solve_s);
         }
-      }
+      };
+      combine(out, res);
+      if (tr != nullptr) combine(out1, res1);
     }
     return rc;
   });
+}
+extern "C" int covgpu_gba_solve_multi(const covgpu_options* opt, covgpu_problem* p, covgpu_result* out, int32_t n_ranks, const int32_t* devices,
+                                      double outlier_threshold, uint8_t* obs_erase, int32_t* lm_left, int64_t* counts) {
+  return gba_multi_impl(opt, p, out, n_ranks, devices, outlier_threshold, obs_erase, lm_left, counts, nullptr, nullptr);
+}
+// Both rounds of a GlobalBundleAdjustment call on n_ranks devices (round 6): ONE flatten and ONE upload per rank, the second round derived on every rank's
+// device from its share (covgpu_gba_two_round's scheme); obs_erase / lm_left / counts / the estimates merged as covgpu_gba_solve_multi merges them.
+extern "C" int covgpu_gba_two_round_multi(const covgpu_options* opt, covgpu_problem* p, const covgpu_two_round* tr, int32_t n_ranks, const int32_t* devices,
+                                          uint8_t* obs_erase, int32_t* lm_left, int64_t* counts, covgpu_result* round1, covgpu_result* round2) {
+  if (!tr || !obs_erase || !lm_left) { g_err = "covgpu_gba_two_round_multi: NULL argument"; return COVGPU_ERR_INVALID_ARG; }
+  return gba_multi_impl(opt, p, round2, n_ranks, devices, tr->outlier_threshold, obs_erase, lm_left, counts, tr, round1);
 }
 
 // ------------------------------------------------------------------------------------------------ test entry points

@@ -361,6 +361,12 @@ int  covgpu_set_shard_none(covgpu_context* ctx);   /* back to the single-GPU for
  * estimate, merged over the ranks (obs_erase [O], lm_left [L], counts[2] as covgpu_outlier_pass). */
 int  covgpu_gba_solve_multi(const covgpu_options* opt, covgpu_problem* p, covgpu_result* out, int32_t n_ranks, const int32_t* devices,
                             double outlier_threshold, uint8_t* obs_erase, int32_t* lm_left, int64_t* counts);
+/* Both rounds of a GlobalBundleAdjustment call (optimization_be.cpp:56-618) on n_ranks devices behind one call (round 6): the plan on the full problem, ONE
+ * upload per rank, the second round derived on every rank's device from its own share exactly as covgpu_gba_two_round derives it on one GPU (a
+ * landmark's outlier decisions, the compaction and the pair lists are local to its rank; the elimination tree stays); obs_erase [O], lm_left [L],
+ * counts[2] and the second round's estimate merged into `p` as covgpu_gba_solve_multi merges them. */
+int  covgpu_gba_two_round_multi(const covgpu_options* opt, covgpu_problem* p, const covgpu_two_round* tr, int32_t n_ranks, const int32_t* devices,
+                                uint8_t* obs_erase, int32_t* lm_left, int64_t* counts, covgpu_result* round1, covgpu_result* round2);
 int  covgpu_allreduce_host(covgpu_context* ctx, double* host, int64_t n, int32_t op /* 0 sum, 1 max */);  /* through the context's collective */
 void covgpu_shard_stats(covgpu_context* ctx, int64_t* out4);  /* collectives issued, bytes all-reduced, rank, world */
 

@@ -484,7 +484,7 @@ class OptimizationT {
     };
     covgpu_context* ctx = params().n_gpus > 1 ? nullptr : Context();   // (the sharded solve creates its own contexts, one per device)
     lap("context");
-    if (outlier_removal && params().device_second_round && params().n_gpus <= 1) {
+    if (outlier_removal && params().device_second_round) {
       // Both rounds behind one call. The first round's problem is walked once (:80-254); the outlier round, the erase decisions
       // (:270-290) and the rebuilt second-round problem (:296-557) stay on the device; the map is brought to the state the reference
       // leaves: observations erased (:281-289), the second round's estimate written back (:572-609), Map::Clean (:614).
@@ -506,7 +506,11 @@ class OptimizationT {
       std::vector<uint8_t> erase(f.obs_kf.size() + 1);
       std::vector<int32_t> lm_left(ix.lms.size() + 1);
       int64_t counts[2] = {0, 0};
-      if (covgpu_gba_two_round(ctx, &o, &p, &tr, erase.data(), lm_left.data(), counts, &r1, &r2) != COVGPU_OK) detail::fatal(covgpu_last_error());
+      if (prm.n_gpus > 1) {   // (round 6) the sharded route: one upload per rank, the second round derived on every rank's device from its share
+        std::vector<int32_t> dev(prm.n_gpus);
+        for (int i = 0; i < prm.n_gpus; ++i) dev[i] = i < (int)prm.devices.size() ? prm.devices[i] : i;
+        if (covgpu_gba_two_round_multi(&o, &p, &tr, prm.n_gpus, dev.data(), erase.data(), lm_left.data(), counts, &r1, &r2) != COVGPU_OK) detail::fatal(covgpu_last_error());
+      } else if (covgpu_gba_two_round(ctx, &o, &p, &tr, erase.data(), lm_left.data(), counts, &r1, &r2) != COVGPU_OK) detail::fatal(covgpu_last_error());
       lap("upload + both rounds on the device");
       size_t num_bad = 0, lms2 = 0;
       for (size_t l = 0; l < ix.lms.size(); ++l) {

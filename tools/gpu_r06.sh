@@ -15,6 +15,12 @@ if has marks; then   # un-profiled event marks only
   COVGPU_TRACE_PANELS=1 python bench.py --steps 1 --warmup 1 --no-e2e --no-cpu-baseline --sustain-s 0 --a12-leg 0 2>&1 >/dev/null | grep "covgpu marks" | tail -2 > gpurun_out/${tag}_marks_unprofiled.txt
   cat gpurun_out/${tag}_marks_unprofiled.txt
 fi
+if has gatelog; then   # un-profiled timeline of the streams' hand-overs (signal / gate kernels stamp wall_clock64)
+  COVGPU_GATE_LOG=1 python bench.py --steps 1 --warmup 1 --no-e2e --no-cpu-baseline --sustain-s 0 --a12-leg 0 2>&1 >/dev/null | grep "covgpu gate log" | tail -1 > gpurun_out/${tag}_gate_log.txt
+fi
+if has soak; then      # four minutes of solves back to back: no gate may time out
+  python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --a12-leg 0 --sustain-s 240 > gpurun_out/${tag}_soak.json 2> gpurun_out/${tag}_soak.err; grep -c "timed out" gpurun_out/${tag}_soak.err
+fi
 if has quick; then   # the metric's line only, short
   timeout 600 python bench.py --gpus 1 --steps 10 --warmup 3 --no-e2e --no-cpu-baseline --sustain-s 0 --a12-leg 0 > gpurun_out/${tag}_bench_quick.json 2> gpurun_out/${tag}_bench_quick.err
 fi

@@ -229,6 +229,8 @@ struct CholAux {
   hipEvent_t ev_xb = nullptr;    // multifrontal look-ahead: second half of a level's extend-add done (bulk stream)
   int* bwd_cnt = nullptr;        // ticket counters of k_bwd_front (65536, zero between launches)
   double* bwd_scr = nullptr; size_t bwd_scr_elems = 0;   // its scratch (grown on demand by launch_nd_solve)
+  double* bwd_pipe = nullptr; size_t bwd_pipe_elems = 0; // k_bwd_pipe's scratch, filled with its "empty" word (grown on demand by launch_nd_solve)
+  bool pipe_broken = false;       // a pipeline workgroup waited too long (gate_failed): launch per tile for the life of the context
   hipEvent_t ev_xa = nullptr;    // ... the chain's stream has enqueued the level below completely
   hipEvent_t ev_zero = nullptr;  // per-iteration buffers cleared (main stream): the side stream's inertial kernels follow
   hipEvent_t ev_lin = nullptr, ev_kf = nullptr;  // landmark linearisation done (main stream) | per-keyframe reduction done (side stream): launch_lm_build
@@ -332,6 +334,8 @@ struct DenseBatch {
   hipEvent_t pre_trsm = nullptr;
   int* bwd_cnt = nullptr;          // [n] zeroed ticket counters: whole-front backward substitution in one launch (k_panel.hip: k_bwd_front)
   double* bwd_scr = nullptr;       // its scratch: [n][interior tiles <= 4][row chunks][128]
+  double* bwd_pipe = nullptr;      // k_bwd_pipe's sentinel-filled scratch (fronts of bwd_pipe_min_tiles() interior tiles and more); nullptr: launch per tile
+  int *pipe_dead = nullptr, *pipe_dead_h = nullptr; double pipe_timeout_s = 3.0;   // CholAux::gate_dead / gate_dead_h / gate_timeout_s
   const int* own_dims_h = nullptr; // host copy of own_dims (flop accounting of the profiled run)
   const int* own_dims = nullptr;   // device, [n]: real interior order of every matrix of the batch — substitutions and rank updates stop at a
                                    // front's OWN last real column (own_max is the batch's: levels mix fronts of 9 .. 250 unknowns)
@@ -346,6 +350,7 @@ struct DenseBatch {
 };
 void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int npad, hipStream_t st, CholAux& ax, int tstop = -1,
                               bool solve = true, DenseBatch bt = DenseBatch());  // tstop >= 0 (even): eliminate tile columns [0, tstop) only
+int bwd_pipe_min_tiles();    // fronts of at least this many interior tiles: backward substitution as one pipelined launch (k_chol.hip)
 int bwd_front_max_tiles();   // fronts of at most this many interior tiles: backward substitution in one launch (k_chol.hip)
 void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStream_t st, int tfact, int tend, DenseBatch bt = DenseBatch());
 // 256-column panel chain (k_panel.hip): with it the Linv buffer holds, per tile, the eight 16x16 diagonal-block inverses
@@ -357,6 +362,11 @@ void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, dou
                       const long long* btab, const int* live, int tI, BwdXfer xf = BwdXfer());
 void launch_bwd_front(const double* S, int tI, int ntiles, int nchunk, double* y, const double* Linv, int nbt, size_t sL, size_t sR, hipStream_t st,
                       const long long* btab, const int* live, BwdXfer xf, int* cnt, double* scr);
+// fronts of many interior tiles: the whole backward substitution as one launch of cooperating workgroups (k_panel.hip: k_bwd_pipe). pipe: sentinel-filled
+// scratch of at least nbt * ntiles * (nchunk + 1) * 128 doubles (launch_pipe_fill once; the kernel leaves it as it found it)
+void launch_bwd_pipe(const double* S, int tI, int ntiles, int nchunk, double* y, const double* Linv, int nbt, size_t sL, size_t sR, hipStream_t st,
+                     const long long* btab, const int* live, BwdXfer xf, double* pipe, int* dead, int* dead_h, double timeout_s);
+void launch_pipe_fill(double* buf, size_t n, hipStream_t st);
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
                      size_t sR, const int* live, int tI, hipStream_t st, bool chain = false, const long long* btab = nullptr, int nb = -1, const int* own = nullptr);
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,

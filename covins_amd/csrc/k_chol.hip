@@ -328,13 +328,15 @@ void CholAux::init() {
   if (!ev_xb) (void)hipEventCreateWithFlags(&ev_xb, hipEventDisableTiming);
   if (!ev_xa) (void)hipEventCreateWithFlags(&ev_xa, hipEventDisableTiming);
   if (!bwd_cnt && hipMalloc((void**)&bwd_cnt, 65536 * sizeof(int)) == hipSuccess) (void)hipMemset(bwd_cnt, 0, 65536 * sizeof(int));
+  // (the "gave up" word and its host mirror serve the gates and the pipelined backward substitution alike)
+  if (!gate_dead && hipMalloc((void**)&gate_dead, sizeof(int)) == hipSuccess) (void)hipMemset(gate_dead, 0, sizeof(int));
+  if (!gate_dead_h && hipHostMalloc((void**)&gate_dead_h, 4 * sizeof(int), hipHostMallocDefault) == hipSuccess) gate_dead_h[0] = gate_dead_h[1] = gate_dead_h[2] = gate_dead_h[3] = 0;
+  if (const char* e = getenv("COVGPU_GATE_TIMEOUT_S")) gate_timeout_s = std::max(getenv("COVGPU_GATE_TIMEOUT_MIN") ? atof(getenv("COVGPU_GATE_TIMEOUT_MIN")) : 0.01, atof(e));   // (the tests of the fallback set it below a kernel's duration)
   if (!gate_flags && !gates_broken) {
     static const bool want = getenv("COVGPU_GATES") == nullptr || atoi(getenv("COVGPU_GATES")) != 0;
-    if (want && hipMalloc((void**)&gate_flags, kGateSlots * sizeof(long long)) == hipSuccess && hipMalloc((void**)&gate_dead, sizeof(int)) == hipSuccess &&
-        hipHostMalloc((void**)&gate_dead_h, 4 * sizeof(int), hipHostMallocDefault) == hipSuccess) {
-      (void)hipMemset(gate_flags, 0, kGateSlots * sizeof(long long)); (void)hipMemset(gate_dead, 0, sizeof(int)); gate_dead_h[0] = gate_dead_h[1] = gate_dead_h[2] = gate_dead_h[3] = 0;
+    if (want && gate_dead != nullptr && gate_dead_h != nullptr && hipMalloc((void**)&gate_flags, kGateSlots * sizeof(long long)) == hipSuccess) {
+      (void)hipMemset(gate_flags, 0, kGateSlots * sizeof(long long));
       (void)hipDeviceSynchronize();   // (once per context: the fills are complete before the first gate polls)
-      if (const char* e = getenv("COVGPU_GATE_TIMEOUT_S")) gate_timeout_s = std::max(getenv("COVGPU_GATE_TIMEOUT_MIN") ? atof(getenv("COVGPU_GATE_TIMEOUT_MIN")) : 0.01, atof(e));   // (the test of the fallback sets it below a kernel's duration)
       gates_on = true;
       if (getenv("COVGPU_GATE_LOG") && hipMalloc((void**)&gate_log, 2 * (size_t)kGateLogMax * sizeof(long long)) != hipSuccess) gate_log = nullptr;
     } else gates_broken = true;   // (events)
@@ -463,6 +465,8 @@ void CholAux::sync(hipStream_t s, hipEvent_t r0, int tag0, hipEvent_t r1, int ta
 }
 void CholAux::gates_disable() {
   gates_on = false; gates_broken = true;
+  pipe_broken = true;
+  if (bwd_pipe) { launch_pipe_fill(bwd_pipe, bwd_pipe_elems, nullptr); (void)hipDeviceSynchronize(); }   // (whatever the interrupted launch left behind)
   gate_slot.clear(); gate_slot_es.clear(); gate_seq.clear();
   if (gate_dead) (void)hipMemset(gate_dead, 0, sizeof(int));
   if (gate_dead_h) *gate_dead_h = 0;
@@ -504,6 +508,7 @@ void CholAux::destroy() {
   if (gate_dead_h) { (void)hipHostFree(gate_dead_h); gate_dead_h = nullptr; }
   gates_on = false; gate_slot.clear(); gate_slot_es.clear(); gate_seq.clear();
   if (bwd_scr) { (void)hipFree(bwd_scr); bwd_scr = nullptr; bwd_scr_elems = 0; }
+  if (bwd_pipe) { (void)hipFree(bwd_pipe); bwd_pipe = nullptr; bwd_pipe_elems = 0; }
   if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
 }
 void CholAux::mark(hipStream_t s, int tag) {
@@ -972,6 +977,12 @@ int bwd_front_max_tiles() {
   static const int v = getenv("COVGPU_BWD_FRONT_TILES") ? std::max(1, atoi(getenv("COVGPU_BWD_FRONT_TILES"))) : 4;
   return v;
 }
+// Fronts of at least this many interior tiles: one launch, one workgroup per tile, hand-overs inside the launch (k_panel.hip: k_bwd_pipe).
+// COVGPU_BWD_PIPE=0 disables it.
+int bwd_pipe_min_tiles() {
+  static const int v = (getenv("COVGPU_BWD_PIPE") && atoi(getenv("COVGPU_BWD_PIPE")) == 0) ? (1 << 30) : getenv("COVGPU_BWD_PIPE_MIN") ? std::max(1, atoi(getenv("COVGPU_BWD_PIPE_MIN"))) : 2;
+  return v;
+}
 // L^T x = y for the factored tile columns [0, tfact) of an npad-order matrix; for tile rows p in [tfact, tend) x_p is
 // GIVEN (already in b[p*128 ..]) and only its contribution L[rows p, cols < tfact*128]^T x_p is taken out of y.
 void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStream_t st, int tfact, int tend, DenseBatch bt) {
@@ -980,6 +991,11 @@ void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStrea
   {
     // multifrontal front of few interior tiles: given rows and every interior tile in ONE launch (k_panel.hip: k_bwd_front)
     const int nt_real = bt.own_max > 0 ? std::min(tfact, (bt.own_max + kTile - 1) / kTile) : tfact;
+    if (bt.bwd_pipe != nullptr && bt.pipe_dead != nullptr && bt.xfer.gidx != nullptr && bt.tab != nullptr && bt.live != nullptr && nt_real >= bwd_pipe_min_tiles() && nbt <= 65535) {
+      launch_bwd_pipe(S, tfact, nt_real, ((tend - tfact) * kTile + 255) / 256, b + npad, Linv, nbt, bt.sL, bt.sR, st, bt.tab, bt.live, bt.xfer, bt.bwd_pipe, bt.pipe_dead,
+                      bt.pipe_dead_h, bt.pipe_timeout_s);
+      return;
+    }
     if (bt.bwd_cnt != nullptr && bt.bwd_scr != nullptr && bt.xfer.gidx != nullptr && bt.tab != nullptr && bt.live != nullptr && nt_real >= 1 && nt_real <= bwd_front_max_tiles() &&
         nbt <= 65536) {
       const int nchunk = std::max(1, ((tend - tfact) * kTile + 255) / 256);

@@ -513,6 +513,21 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
       ax.bwd_scr_elems = need;
     }
   }
+  if (!ax.pipe_broken && ax.gate_dead != nullptr && ax.gate_dead_h != nullptr) {  // scratch of the pipelined backward substitution (k_bwd_pipe): [fronts][interior tiles][chunks + 1][128], filled once
+    size_t need = 0;
+    for (const NdLevel& L : nd.lev) {
+      const int T = std::min(L.nI / kTile, (L.own_max + kTile - 1) / kTile);
+      if (L.n > 0 && T >= bwd_pipe_min_tiles()) need = std::max(need, (size_t)L.n * T * ((L.ntot - L.nI + 255) / 256 + 1) * kTile);
+    }
+    if (need > ax.bwd_pipe_elems) {
+      if (ax.bwd_pipe) { (void)hipDeviceSynchronize(); (void)hipFree(ax.bwd_pipe); }
+      ax.bwd_pipe = nullptr; ax.bwd_pipe_elems = 0;
+      if (hipMalloc((void**)&ax.bwd_pipe, need * sizeof(double)) == hipSuccess) {
+        ax.bwd_pipe_elems = need;
+        launch_pipe_fill(ax.bwd_pipe, need, st);   // (stream-ordered before the first use)
+      } else ax.bwd_pipe = nullptr;                // (launch per tile)
+    }
+  }
   ax.mark(st, -1);
   // (the right-hand sides were cleared on the head stream of the build, beside the fronts: solver.hip enqueue_build)
   {
@@ -618,6 +633,7 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     bt.xfer.x = dst; bt.xfer.first = L.first;
     static const bool fused_bwd = getenv("COVGPU_ND_BWD_FUSED") == nullptr || atoi(getenv("COVGPU_ND_BWD_FUSED")) != 0;
     bt.bwd_cnt = fused_bwd ? ax.bwd_cnt : nullptr; bt.bwd_scr = ax.bwd_scr;
+    if (fused_bwd && !ax.pipe_broken && ax.bwd_pipe != nullptr) { bt.bwd_pipe = ax.bwd_pipe; bt.pipe_dead = ax.gate_dead; bt.pipe_dead_h = ax.gate_dead_h; bt.pipe_timeout_s = ax.gate_timeout_s; }
     dense_backward_solve(P.nd_M, P.nd_rhs + L.rhs_off, P.nd_Linv + L.linv_off, L.ntot, st, L.nI / kTile, L.ntot / kTile, bt);
     ax.mark(st, -5);
   }

@@ -1019,6 +1019,196 @@ __global__ __launch_bounds__(256) void k_bwd_front(const double* __restrict__ M,
   }
 }
 
+// ---- Backward substitution of fronts with MANY interior tiles as ONE launch: a pipeline of workgroups (round 6) -----------------------------------
+// The top of the elimination tree holds single fronts of 4 .. 16 interior tiles; one launch per tile (k_bwd_step_sub) costs 8.8 us a tile — a launch
+// boundary (3.6 us under load) and two dependent memory latencies around 1 us of arithmetic — 141 us for the 5-agent map's root. Here every interior
+// tile p has its own workgroup, all in one launch:
+//   helpers     (tile ct, 256-row chunk k of the border): partial sums of y_ct -= L[border rows, ct]^T x_border, as in k_bwd_front
+//   pipeline p  v = y_p - (its helpers' sums) - sum_{q > p} L[q, p]^T x_q, taking the x_q in the order they are solved (q = last .. p + 1; tile L[q, p]
+//               is in registers before x_q arrives), then x_p = L_pp^-T v with the block inverses, publishes x_p, writes it to the solution vector.
+// Hand-over between workgroups: the DATA WORDS are the flags. Every slot of `scr` / `xpub` holds kPipeEmpty (a NaN payload no arithmetic produces)
+// between launches; the producer stores its values with agent-scope stores, the consumer polls the word it needs until it differs
+// (tools/pipe_probe.hip: 0.6 us per hand-over across XCDs, against 1.15 for flag + data and 3.6 for a launch boundary). A helper's slot has one
+// reader, which puts kPipeEmpty back; x_q is read by every pipeline workgroup p < q, the LAST of which (p = 0) restores the front's slots — by
+// induction over the chain every other read has completed when workgroup 0 holds x_1. No counters, no clearing launch.
+// Forward progress: a workgroup only waits for workgroups with a LOWER linear index (helpers first, then the tiles from the last to the first),
+// which the dispatcher has started before it — no co-residency assumption. A wait beyond `limit` raises the gate's dead flag (CholAux::gate_failed:
+// the solve is repeated on the launch-per-tile path and the context stays there).
+static constexpr unsigned long long kPipeEmpty = 0x7ff8c0f6a11d0e5full;
+struct BwdPipeArgs {
+  const double* M; int tI, T, nchunk; double* y; const double* Dinv_all; size_t bsL, bsR; const long long* btab; const int* live; BwdXfer xf;
+  double *scr, *xpub; int *dead, *dead_h; long long limit; int check;   // check: polls between two looks at the clock, minus one (a power of two)
+};
+COV_DEV double pipe_take(double* slot, const BwdPipeArgs& g, bool restore) {
+  unsigned long long* w = reinterpret_cast<unsigned long long*>(slot);
+  unsigned long long v;
+  long long t0 = 0; int spins = 0;
+  while ((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kPipeEmpty) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & g.check) == 0) {
+      if (t0 == 0) t0 = wall_clock64();
+      else if (wall_clock64() - t0 > g.limit || __hip_atomic_load(g.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (atomicExch(g.dead, 1) == 0) { g.dead_h[1] = -2; g.dead_h[2] = (int)blockIdx.x; g.dead_h[3] = (int)blockIdx.y; __threadfence_system(); g.dead_h[0] = 1; }
+        v = 0ull; break;
+      }
+    }
+  }
+  if (restore) __hip_atomic_store(w, kPipeEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)v);
+}
+__global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) {
+  const int batch = blockIdx.y, tid = threadIdx.x;
+  const int nIt = g.live[2 * batch];            // real interior tiles of this front
+  const int node = g.xf.first + batch;
+  const int nst = g.xf.st_dims[node];
+  const int nch = (nst + 255) / 256;            // row chunks of this front's border (0: the root)
+  const double* M = g.M + (size_t)g.btab[2 * batch];
+  const size_t ld = (size_t)g.btab[2 * batch + 1];
+  double* scr_f = g.scr + (size_t)batch * g.T * g.nchunk * kTile;   // [tile][chunk][128]
+  double* xpub_f = g.xpub + (size_t)batch * g.T * kTile;            // [tile][128]
+  const int nhelp = g.T * g.nchunk;
+  __shared__ double2 part[4][64];
+  __shared__ double sx[kTile], sv[kTile], sxq[2][kTile], part2[2][kTile];
+  if ((int)blockIdx.x < nhelp) {
+    const int ct = blockIdx.x / g.nchunk, k = blockIdx.x % g.nchunk;
+    if (ct >= nIt || k >= nch) return;
+    double* sxg = &sxq[0][0];   // 256 doubles
+    const int r0 = g.tI * kTile + 256 * k, nr = min(256, nst - 256 * k);
+    const int* gi = g.xf.gidx + g.xf.st_g[node] + 256 * k;
+    if (tid < nr) sxg[tid] = g.xf.x[gi[tid]];
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    const int col = ct * kTile + 2 * lane;
+    double2 acc = {0.0, 0.0};
+    const double* Lp = M + (size_t)r0 * ld + col;
+    int r = wv;
+    for (; r + 28 < nr; r += 32) {
+      double2 v[8]; double xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { v[u] = *reinterpret_cast<const double2*>(Lp + (size_t)(r + 4 * u) * ld); xv[u] = sxg[r + 4 * u]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += v[u].x * xv[u]; acc.y += v[u].y * xv[u]; }
+    }
+    for (; r < nr; r += 4) { const double2 v = *reinterpret_cast<const double2*>(Lp + (size_t)r * ld); const double xv = sxg[r]; acc.x += v.x * xv; acc.y += v.y * xv; }
+    part[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0) {
+      const double2 a = part[0][lane], b = part[1][lane], c = part[2][lane], d = part[3][lane];
+      double* dst = scr_f + ((size_t)ct * g.nchunk + k) * kTile + 2 * lane;
+      __hip_atomic_store(dst, ((a.x + b.x) + c.x) + d.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 1, ((a.y + b.y) + c.y) + d.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  const int p = g.T - 1 - ((int)blockIdx.x - nhelp);
+  if (p >= nIt) return;
+  const int k0 = p * kTile;
+  double* y = g.y + (size_t)batch * g.bsR;
+  const double* Dinv = g.Dinv_all + (size_t)batch * g.bsL + (size_t)p * kTile * kTile;
+  const int c = tid & 127, h = tid >> 7, jbc = c >> 4, cl = c & 15;
+  const bool act = tid < kTile;
+  // ---- everything this tile will need that is already there: the first tile of its column, y_p, the diagonal tile
+  double Lq[64];
+  int q = nIt - 1;
+  if (q > p) {
+    const double* src = M + (size_t)(q * kTile + 64 * h) * ld + k0 + c;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) Lq[r] = src[(size_t)r * ld];
+  }
+  double v = act ? y[k0 + c] : 0.0;
+  double dv[PB];
+#pragma unroll
+  for (int r = 0; r < PB; ++r) dv[r] = act ? Dinv[jbc * 256 + r * PB + cl] : 0.0;
+  // (the diagonal tile's blocks below the block diagonal go to LDS, packed by block row jb = 1 .. 7: [16 rows][16 jb columns] at 128 jb (jb - 1) —
+  //  in registers, as k_bwd_step_sub holds them, they and the column tile above exceed the register file)
+  extern __shared__ double sLc[];
+#pragma unroll
+  for (int jb = 1; jb < 8; ++jb)
+#pragma unroll
+    for (int rr = 0; rr < PB; rr += 2) {
+      const int r = rr + h;
+      if (c < PB * jb) sLc[128 * jb * (jb - 1) + r * PB * jb + c] = M[(size_t)(k0 + PB * jb + r) * ld + k0 + c];
+    }
+  // ---- the border's share (helpers), in chunk order
+  if (act)
+    for (int q0 = 0; q0 < nch; q0 += 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = q0 + u < nch ? pipe_take(scr_f + ((size_t)p * g.nchunk + q0 + u) * kTile + c, g, true) : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v -= t[u];
+    }
+  // ---- the tiles solved before this one, in the order they are solved
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  for (; q > p; --q) {
+    if (act) sxq[q & 1][c] = pipe_take(xpub_f + (size_t)q * kTile + c, g, false);
+    __syncthreads();
+    const double* xs = &sxq[q & 1][64 * h];
+#pragma unroll
+    for (int r = 0; r < 64; r += 4) { a0 += Lq[r] * xs[r]; a1 += Lq[r + 1] * xs[r + 1]; a2 += Lq[r + 2] * xs[r + 2]; a3 += Lq[r + 3] * xs[r + 3]; }
+    if (q - 1 > p) {
+      const double* src = M + (size_t)((q - 1) * kTile + 64 * h) * ld + k0 + c;
+#pragma unroll
+      for (int r = 0; r < 64; ++r) Lq[r] = src[(size_t)r * ld];
+    }
+  }
+  part2[h][c] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (act) v -= part2[0][c] + part2[1][c];
+  // ---- x_p = L_pp^-T v (block inverses; the same steps as k_bwd_step_sub)
+#pragma unroll
+  for (int jb = 7; jb >= 0; --jb) {
+    if (act && jbc == jb) sv[c] = v;
+    __syncthreads();
+    if (act && jbc == jb) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int r = 0; r < PB; r += 4) {
+        s0 += dv[r] * sv[PB * jb + r]; s1 += dv[r + 1] * sv[PB * jb + r + 1];
+        s2 += dv[r + 2] * sv[PB * jb + r + 2]; s3 += dv[r + 3] * sv[PB * jb + r + 3];
+      }
+      sx[c] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (jb > 0 && act && jbc < jb) {
+      const double* Lt = sLc + 128 * jb * (jb - 1) + c;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int r = 0; r < PB; r += 4) {
+        s0 += Lt[r * PB * jb] * sx[PB * jb + r]; s1 += Lt[(r + 1) * PB * jb] * sx[PB * jb + r + 1];
+        s2 += Lt[(r + 2) * PB * jb] * sx[PB * jb + r + 2]; s3 += Lt[(r + 3) * PB * jb] * sx[PB * jb + r + 3];
+      }
+      v -= (s0 + s1) + (s2 + s3);
+    }
+  }
+  if (act && p > 0) __hip_atomic_store(xpub_f + (size_t)p * kTile + c, sx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  {  // own unknowns of this tile -> solution vector
+    const int n = g.xf.own_dims[node];
+    const int* gi = g.xf.gidx + g.xf.own_g[node];
+    if (act && k0 + c < n) g.xf.x[gi[k0 + c]] = sx[c];
+  }
+  // the last tile of the chain has seen every x_q of the front, and so has everybody else by then: the slots are free again
+  if (p == 0)
+    for (int i = kTile + tid; i < nIt * kTile; i += 256)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(xpub_f + i), kPipeEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_pipe_fill(unsigned long long* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = kPipeEmpty;
+}
+void launch_pipe_fill(double* buf, size_t n, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(k_pipe_fill, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(buf), n);
+}
+void launch_bwd_pipe(const double* S, int tI, int ntiles, int nchunk, double* y, const double* Linv, int nbt, size_t sL, size_t sR, hipStream_t st,
+                     const long long* btab, const int* live, BwdXfer xf, double* pipe, int* dead, int* dead_h, double timeout_s) {
+  BwdPipeArgs g{S, tI, ntiles, nchunk, y, Linv, sL, sR, btab, live, xf, pipe, pipe + (size_t)nbt * ntiles * nchunk * kTile, dead, dead_h, (long long)(timeout_s * 1e8), 2047};
+  static const int check = getenv("COVGPU_PIPE_SPIN_CHECK") ? std::max(1, atoi(getenv("COVGPU_PIPE_SPIN_CHECK"))) : 2048;   // (the test of the fallback: 1)
+  g.check = check - 1;
+  constexpr size_t lds = (size_t)128 * 7 * 8 * sizeof(double);   // the packed blocks of the diagonal tile
+  static bool once = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); return true; }();
+  (void)once;
+  hipLaunchKernelGGL(k_bwd_pipe, dim3(ntiles * nchunk + ntiles, nbt), dim3(256), lds, st, g);
+}
+
 // ---- launch wrappers (k_chol.hip schedules them) ----------------------------------------------------------------------
 void launch_bwd_given(const double* S, size_t ld, int r0, int r1, double* y, double* x, int ncol, int nbt, size_t sM, size_t sR, hipStream_t st,
                       const long long* btab, const int* live, int tI, BwdXfer xf) {

@@ -394,7 +394,7 @@ extern "C" void covgpu_get_profile2(covgpu_context* c, double* out) {
   out[12] = out[13] = out[14] = out[15] = 0.0;
 }
 
-// out[16] = { shard world, shard rank, scalar unknowns of the replicated top, top levels, KiB all-reduced per linear solve, stream ordering (1 flags | 0 events | -1 fell back),
+// out[16] = { shard world, shard rank, scalar unknowns of the replicated top, top levels, KiB all-reduced per linear solve, stream ordering (1 flags | 0 events | -1 fell back: events and no in-launch hand-overs),
 //             dense order npad, covisible pairs, edge pairs, IMU chains, device MiB allocated for the problem,
 //             fronts, levels, serial 256-column panels, order of the root level, MiB of fronts } (include/covgpu.h)
 extern "C" void covgpu_get_layout(covgpu_context* c, int64_t* out) {
@@ -404,7 +404,7 @@ extern "C" void covgpu_get_layout(covgpu_context* c, int64_t* out) {
   out[0] = c->sharded ? c->world : 0; out[1] = c->sharded ? c->rank : 0; out[2] = c->nd.ntop;   // ranks | rank | scalar unknowns of the replicated top nodes
   out[3] = (int64_t)c->nd.lev.size() - c->nd.top_lev0;                                          // top levels
   out[4] = (int64_t)(((c->nd.top_pack != nullptr ? (size_t)c->nd.n_top_tiles * kTile * kTile : c->nd.M_elems - c->nd.M_sub) + c->nd.rhs_top + 2 * (size_t)c->nd.ntop) * sizeof(double)) >> 10;  // KiB all-reduced per linear solve
-  out[5] = c->chol.gates_on ? 1 : (c->chol.gates_broken && getenv("COVGPU_GATES") == nullptr ? -1 : 0);   // stream ordering: 1 device flags | 0 HIP events (COVGPU_GATES=0) | -1 fell back to events after a gate timed out
+  out[5] = c->chol.pipe_broken ? -1 : c->chol.gates_on ? 1 : 0;   // stream ordering: 1 device flags | 0 HIP events (COVGPU_GATES=0) | -1 a gate or the backward pipeline timed out: events and the launch-per-tile substitution from then on
   out[6] = P.npad; out[7] = P.npairs; out[8] = P.nepairs; out[9] = P.nchains; out[10] = (int64_t)(c->alloc_bytes >> 20);
   if (P.nd) {  // multifrontal form: nodes, levels, serial 256-column panels (sum of the levels' interior orders / 256), root order, front bytes (MiB)
     out[11] = P.nd_nnodes; out[12] = P.nd_nlev;
@@ -1401,6 +1401,10 @@ static int solve_impl_dev(covgpu_context* c, const covgpu_options* opt, covgpu_r
 static int solve_any(covgpu_context* c, const covgpu_options* opt, covgpu_result* out) {
   int rc = solve_impl_dev(c, opt, out);
   if (rc == COVGPU_ERR_GATE_TIMEOUT) {
+    if (c->chol.gate_dead_h[1] == -2)   // (k_panel.hip: pipe_take)
+      std::fprintf(stderr, "[covgpu] warning: a hand-over inside the pipelined backward substitution timed out (workgroup %d of front %d of its level); repeating the solve with a launch per tile and HIP events (this context keeps them)\n",
+                   c->chol.gate_dead_h[2], c->chol.gate_dead_h[3]);
+    else
     std::fprintf(stderr, "[covgpu] warning: device-flag stream ordering timed out (slot %d awaited %d, found %d; %ld signals, %ld gates so far); repeating the solve with HIP events (this context keeps them)\n",
                  c->chol.gate_dead_h[1], c->chol.gate_dead_h[2], c->chol.gate_dead_h[3], c->chol.gate_signals, c->chol.gate_waits);
     if (c->chol.gate_dead_h[1] >= 0 && c->chol.gate_dead_h[1] < (int)c->chol.gate_tag_of_slot.size()) std::fprintf(stderr, "[covgpu]          (tag of that slot: %d)\n", c->chol.gate_tag_of_slot[c->chol.gate_dead_h[1]]);

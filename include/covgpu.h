@@ -378,7 +378,8 @@ void covgpu_shard_stats(covgpu_context* ctx, int64_t* out4);  /* collectives iss
 void covgpu_set_profiling(covgpu_context* ctx, int on);
 /* layout of the uploaded problem: out[16] = { ranks of a sharded solve (0: single GPU), this rank, scalar unknowns of the
  * replicated top nodes, top levels, KiB all-reduced per linear solve, how the context orders its streams (1 device flags, 0 HIP events
- * by COVGPU_GATES=0, -1 events after a flag gate timed out), dense pose order (padded), covisible keyframe pairs,
+ * by COVGPU_GATES=0, -1 events and the launch-per-tile backward substitution after a flag gate or a hand-over inside the pipelined
+ * backward substitution timed out), dense pose order (padded), covisible keyframe pairs,
  * edge pairs, IMU chains, device MiB allocated for the problem (from the allocator, not by hand), fronts, levels, serial
  * 256-column panels, order of the last level's fronts, MiB of fronts } */
 void covgpu_get_layout(covgpu_context* ctx, int64_t* out16);

@@ -18,4 +18,4 @@ if __name__ == "__main__":
     ctx = backend.Context(0)
     sol, res = ctx.gba_solve(p, o)
     np.savez(out, pose=sol.kf_pose, sb=sol.kf_speed_bias, lm=sol.lm_pos, cost=np.array(res.cost_trace[:res.iterations]),
-             acc=np.array(res.accepted_trace[:res.iterations]), final=res.final_cost)
+             acc=np.array(res.accepted_trace[:res.iterations]), final=res.final_cost, ordering=np.int64(ctx.layout()["stream_ordering"]))

@@ -69,19 +69,32 @@ def test_no_solve_falls_back_to_events():
 
 
 def test_gate_timeout_falls_back_to_events(tmp_path):
-    """A gate that cannot be satisfied in time raises the context's give-up flag; the solve is repeated with HIP events and the result is the
-    event ordering's (here the timeout is set below a kernel's duration: 1e-7 s)."""
-    a = _solve(tmp_path, "events", "mh01", COVGPU_GATES="0")
+    """A gate that cannot be satisfied in time raises the context's give-up flag; the solve is repeated with HIP events — and without the
+    hand-overs inside a launch (k_bwd_pipe), which rest on the same kind of wait — and the result is that form's (here the timeout is set below
+    a kernel's duration: 1e-7 s)."""
+    a = _solve(tmp_path, "events", "mh01", COVGPU_GATES="0", COVGPU_BWD_PIPE="0")
     b = _solve(tmp_path, "gates_timing_out", "mh01", COVGPU_GATE_TIMEOUT_S="0.0000001", COVGPU_GATE_TIMEOUT_MIN="0")
     for k in ("pose", "sb", "lm", "cost", "acc"):
         assert np.array_equal(a[k], b[k])
+    assert b["ordering"] == -1
+
+
+def test_backward_pipeline_timeout_falls_back_to_a_launch_per_tile(tmp_path):
+    """The pipelined backward substitution (one workgroup per interior tile, the solved tiles handed over inside the launch) gives up the same way:
+    a hand-over that does not arrive in time raises the give-up flag, the solve is repeated with a launch per tile. Here the stream ordering is
+    already HIP events (so only the pipeline can time out), the clock is looked at after every poll and the limit is 1e-7 s."""
+    a = _solve(tmp_path, "events", "mh01", COVGPU_GATES="0", COVGPU_BWD_PIPE="0")
+    b = _solve(tmp_path, "pipe_timing_out", "mh01", COVGPU_GATES="0", COVGPU_GATE_TIMEOUT_S="0.0000001", COVGPU_GATE_TIMEOUT_MIN="0", COVGPU_PIPE_SPIN_CHECK="1")
+    for k in ("pose", "sb", "lm", "cost", "acc"):
+        assert np.array_equal(a[k], b[k])
+    assert b["ordering"] == -1 and a["ordering"] == 0
 
 
 def test_kernel_form_switches_stay_at_rounding_level(tmp_path):
     a = _solve(tmp_path, "default", "mh01")
     # (round_3_tail: the trust-region tail as ~25 launches with the second J*v pass on the combined step, instead of k_tail.hip's
     #  one pass over both dogleg directions: the model decrease is the same quadratic form, summed in another order)
-    for tag, env in (("full_tiles", dict(COVGPU_QUARTER_MAX="0")), ("per_tile_backward", dict(COVGPU_ND_BWD_FUSED="0")),
+    for tag, env in (("full_tiles", dict(COVGPU_QUARTER_MAX="0")), ("per_tile_backward", dict(COVGPU_ND_BWD_FUSED="0")), ("no_backward_pipeline", dict(COVGPU_BWD_PIPE="0")),
                      ("round_3_tail", dict(COVGPU_TAIL="0"))):
         b = _solve(tmp_path, tag, "mh01", **env)
         assert np.array_equal(a["acc"], b["acc"])

@@ -1056,23 +1056,19 @@ COV_DEV double pipe_take(double* slot, const BwdPipeArgs& g, bool restore) {
   if (restore) __hip_atomic_store(w, kPipeEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return __longlong_as_double((long long)v);
 }
-__global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) {
-  const int batch = blockIdx.y, tid = threadIdx.x;
-  const int nIt = g.live[2 * batch];            // real interior tiles of this front
+// helper workgroup hx = tile * nchunk + chunk of front `batch`: its 256 border rows' share of y_tile, into its slot of `scr`
+COV_DEV void bwd_pipe_helper(const BwdPipeArgs& g, int hx, int batch, double* sxg /* [256] */, double2 (*part)[64]) {
+  const int tid = threadIdx.x;
+  const int nIt = g.live[2 * batch];
   const int node = g.xf.first + batch;
   const int nst = g.xf.st_dims[node];
-  const int nch = (nst + 255) / 256;            // row chunks of this front's border (0: the root)
+  const int nch = (nst + 255) / 256;
   const double* M = g.M + (size_t)g.btab[2 * batch];
   const size_t ld = (size_t)g.btab[2 * batch + 1];
-  double* scr_f = g.scr + (size_t)batch * g.T * g.nchunk * kTile;   // [tile][chunk][128]
-  double* xpub_f = g.xpub + (size_t)batch * g.T * kTile;            // [tile][128]
-  const int nhelp = g.T * g.nchunk;
-  __shared__ double2 part[4][64];
-  __shared__ double sx[kTile], sv[kTile], sxq[2][kTile], part2[2][kTile];
-  if ((int)blockIdx.x < nhelp) {
-    const int ct = blockIdx.x / g.nchunk, k = blockIdx.x % g.nchunk;
+  double* scr_f = g.scr + (size_t)batch * g.T * g.nchunk * kTile;
+  {
+    const int ct = hx / g.nchunk, k = hx % g.nchunk;
     if (ct >= nIt || k >= nch) return;
-    double* sxg = &sxq[0][0];   // 256 doubles
     const int r0 = g.tI * kTile + 256 * k, nr = min(256, nst - 256 * k);
     const int* gi = g.xf.gidx + g.xf.st_g[node] + 256 * k;
     if (tid < nr) sxg[tid] = g.xf.x[gi[tid]];
@@ -1098,8 +1094,22 @@ __global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) {
       __hip_atomic_store(dst, ((a.x + b.x) + c.x) + d.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(dst + 1, ((a.y + b.y) + c.y) + d.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return;
   }
+}
+__global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) {
+  const int batch = blockIdx.y, tid = threadIdx.x;
+  const int nIt = g.live[2 * batch];            // real interior tiles of this front
+  const int node = g.xf.first + batch;
+  const int nst = g.xf.st_dims[node];
+  const int nch = (nst + 255) / 256;            // row chunks of this front's border (0: the root)
+  const double* M = g.M + (size_t)g.btab[2 * batch];
+  const size_t ld = (size_t)g.btab[2 * batch + 1];
+  double* scr_f = g.scr + (size_t)batch * g.T * g.nchunk * kTile;   // [tile][chunk][128]
+  double* xpub_f = g.xpub + (size_t)batch * g.T * kTile;            // [tile][128]
+  const int nhelp = g.T * g.nchunk;
+  __shared__ double2 part[4][64];
+  __shared__ double sx[kTile], sv[kTile], sxq[2][kTile], part2[2][kTile];
+  if ((int)blockIdx.x < nhelp) { bwd_pipe_helper(g, (int)blockIdx.x, batch, &sxq[0][0], part); return; }
   const int p = g.T - 1 - ((int)blockIdx.x - nhelp);
   if (p >= nIt) return;
   const int k0 = p * kTile;
@@ -1108,14 +1118,9 @@ __global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) {
   const int c = tid & 127, h = tid >> 7, jbc = c >> 4, cl = c & 15;
   const bool act = tid < kTile;
   // ---- everything this tile will need that is already there: the first tile of its column, y_p, the diagonal tile
-  double Lq[64];
-  int q = nIt - 1;
-  if (q > p) {
-    const double* src = M + (size_t)(q * kTile + 64 * h) * ld + k0 + c;
-#pragma unroll
-    for (int r = 0; r < 64; ++r) Lq[r] = src[(size_t)r * ld];
-  }
   double v = act ? y[k0 + c] : 0.0;
+  const int n_own = g.xf.own_dims[node];
+  const int gi_own = (act && k0 + c < n_own) ? g.xf.gidx[g.xf.own_g[node] + k0 + c] : -1;   // (loaded here, not between the last sum and its store)
   double dv[PB];
 #pragma unroll
   for (int r = 0; r < PB; ++r) dv[r] = act ? Dinv[jbc * 256 + r * PB + cl] : 0.0;
@@ -1140,26 +1145,36 @@ __global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) {
     }
   // ---- the tiles solved before this one, in the order they are solved
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  for (; q > p; --q) {
-    if (act) sxq[q & 1][c] = pipe_take(xpub_f + (size_t)q * kTile + c, g, false);
-    __syncthreads();
-    const double* xs = &sxq[q & 1][64 * h];
-#pragma unroll
-    for (int r = 0; r < 64; r += 4) { a0 += Lq[r] * xs[r]; a1 += Lq[r + 1] * xs[r + 1]; a2 += Lq[r + 2] * xs[r + 2]; a3 += Lq[r + 3] * xs[r + 3]; }
-    if (q - 1 > p) {
-      const double* src = M + (size_t)((q - 1) * kTile + 64 * h) * ld + k0 + c;
+#ifdef COVGPU_PIPE_PROBE
+  long long tp0 = wall_clock64(), tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;
+#endif
+  for (int q = nIt - 1; q > p; --q) {   // (tile L[q, p] is loaded at the top of its step, before the poll: see k_bwd_pipe64)
+    double Lq[64];
+    {
+      const double* src = M + (size_t)(q * kTile + 64 * h) * ld + k0 + c;
 #pragma unroll
       for (int r = 0; r < 64; ++r) Lq[r] = src[(size_t)r * ld];
     }
+    if (act) sxq[q & 1][c] = pipe_take(xpub_f + (size_t)q * kTile + c, g, false);
+    lds_barrier();
+#ifdef COVGPU_PIPE_PROBE
+    tp1 = wall_clock64();
+#endif
+    const double* xs = &sxq[q & 1][64 * h];
+#pragma unroll
+    for (int r = 0; r < 64; r += 4) { a0 += Lq[r] * xs[r]; a1 += Lq[r + 1] * xs[r + 1]; a2 += Lq[r + 2] * xs[r + 2]; a3 += Lq[r + 3] * xs[r + 3]; }
   }
   part2[h][c] = (a0 + a1) + (a2 + a3);
-  __syncthreads();
+  lds_barrier();
   if (act) v -= part2[0][c] + part2[1][c];
+#ifdef COVGPU_PIPE_PROBE
+  tp2 = wall_clock64();
+#endif
   // ---- x_p = L_pp^-T v (block inverses; the same steps as k_bwd_step_sub)
 #pragma unroll
   for (int jb = 7; jb >= 0; --jb) {
     if (act && jbc == jb) sv[c] = v;
-    __syncthreads();
+    lds_barrier();
     if (act && jbc == jb) {
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
@@ -1169,7 +1184,7 @@ __global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) {
       }
       sx[c] = (s0 + s1) + (s2 + s3);
     }
-    __syncthreads();
+    lds_barrier();
     if (jb > 0 && act && jbc < jb) {
       const double* Lt = sLc + 128 * jb * (jb - 1) + c;
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -1181,13 +1196,217 @@ __global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) {
       v -= (s0 + s1) + (s2 + s3);
     }
   }
+#ifdef COVGPU_PIPE_PROBE
+  tp3 = wall_clock64();
+#endif
   if (act && p > 0) __hip_atomic_store(xpub_f + (size_t)p * kTile + c, sx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  {  // own unknowns of this tile -> solution vector
-    const int n = g.xf.own_dims[node];
-    const int* gi = g.xf.gidx + g.xf.own_g[node];
-    if (act && k0 + c < n) g.xf.x[gi[k0 + c]] = sx[c];
-  }
+#ifdef COVGPU_PIPE_PROBE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  tp4 = wall_clock64();
+  if (tid == 0 && nst == 0) printf("pipe tile %2d: start %lld  last x in +%lld  gemv+reduce +%lld  solve +%lld  published +%lld (10 ns ticks)\n", p, tp0 % 100000000ll, tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3);
+#endif
+  if (gi_own >= 0) g.xf.x[gi_own] = sx[c];   // own unknowns of this tile -> solution vector
   // the last tile of the chain has seen every x_q of the front, and so has everybody else by then: the slots are free again
+  if (p == 0)
+    for (int i = kTile + tid; i < nIt * kTile; i += 256)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(xpub_f + i), kPipeEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The same pipeline for the FEW fronts at the top of the tree (at most 128 interior tiles in the launch), where the chain of tiles is the whole cost:
+// measured on the 5-agent map's root, a tile of k_bwd_pipe costs 4.4 us — 0.6 hand-over, 1.0 the product with the newest x_q, 2.8 the eight-step
+// substitution with the 16x16 block inverses (two barriers a step). Here every tile's workgroup first forms the INVERSES OF THE TWO 64x64 DIAGONAL
+// BLOCKS of its tile by two doubling steps from the 16x16 inverses ([[A,0],[B,C]]^-1 = [[A^-1,0],[-C^-1 B A^-1, C^-1]]; ~2 us, while the chain is
+// still far away for all but the first tile), and the substitution becomes three products of 16 terms a lane with wave-local sums:
+//   x_hi = C^-T v_hi;  x_lo = A^-T (v_lo - B^T x_hi)        (three barriers instead of sixteen)
+// and the product with x_q sums inside a wave too (column c's two half sums sit 32 lanes apart). Pipeline workgroups come FIRST in the launch (their
+// preparation starts at once); a workgroup takes a whole CU (111 KB of LDS), so with at most 128 of them the helpers always find room: no deadlock.
+constexpr int kP64W = 0, kP64S1 = 2 * 64 * 65, kP64S2 = kP64S1 + 4 * 16 * 17, kP64Y = kP64S2 + 2 * 32 * 33, kP64V = kP64Y + 2 * 32 * 33, kP64Doubles = kP64V + 128 + 128 + 64 + 256;
+__global__ __launch_bounds__(256) void k_bwd_pipe64(BwdPipeArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double sm64[];
+  const int batch = blockIdx.y, tid = threadIdx.x;
+  if ((int)blockIdx.x >= g.T) { bwd_pipe_helper(g, (int)blockIdx.x - g.T, batch, sm64, reinterpret_cast<double2(*)[64]>(sm64 + 256)); return; }
+  const int nIt = g.live[2 * batch];
+  const int p = g.T - 1 - (int)blockIdx.x;
+  if (p >= nIt) return;
+  const int node = g.xf.first + batch;
+  const int nch = (g.xf.st_dims[node] + 255) / 256;
+  const double* M = g.M + (size_t)g.btab[2 * batch];
+  const size_t ld = (size_t)g.btab[2 * batch + 1];
+  double* scr_f = g.scr + (size_t)batch * g.T * g.nchunk * kTile;
+  double* xpub_f = g.xpub + (size_t)batch * g.T * kTile;
+  const int k0 = p * kTile;
+  double* y = g.y + (size_t)batch * g.bsR;
+  const double* Dinv = g.Dinv_all + (size_t)batch * g.bsL + (size_t)p * kTile * kTile;
+  double (*W)[64][65] = reinterpret_cast<double (*)[64][65]>(sm64 + kP64W);     // the two 64x64 inverses (lower; zeros above the diagonal)
+  double (*S1)[16][17] = reinterpret_cast<double (*)[16][17]>(sm64 + kP64S1);  // L blocks (2t+1, 2t) of the tile, t < 4
+  double (*S2)[32][33] = reinterpret_cast<double (*)[32][33]>(sm64 + kP64S2);  // L blocks rows 64u+32.., cols 64u.., u < 2
+  double (*Y2)[32][33] = reinterpret_cast<double (*)[32][33]>(sm64 + kP64Y);
+  double (*Y1)[16][17] = reinterpret_cast<double (*)[16][17]>(sm64 + kP64Y);
+  double* sx = sm64 + kP64V; double* sv = sx + 128; double* svlo = sv + 128; double* sxq = svlo + 64;   // sxq: [2][128]
+  const int w = tid >> 6, l = tid & 63;
+  const int c = 32 * w + (l & 31), h = l >> 5;      // product with x_q: column c, row half h
+  const bool vh = h == 0;                           // ... and the lane that holds v[c]
+  const int cc = 16 * w + (l & 15), gq = l >> 4;    // substitution: column cc of a 64-block, row group gq
+  // ---- loads of everything that is already there: what the inverses need first (loads return in order), then the first tile of the column, y_p, B.
+  //      (Every barrier below orders LDS traffic only: __syncthreads() would also wait for the loads and stores in flight — a memory latency each)
+  double dreg[8], s1reg[4], s2reg[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dreg[i] = Dinv[tid + 256 * i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int e = tid + 256 * i, t = e >> 8, rr = (e >> 4) & 15, cx = e & 15; s1reg[i] = M[(size_t)(k0 + 32 * t + 16 + rr) * ld + k0 + 32 * t + cx]; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const int e = tid + 256 * i, u = e >> 10, rr = (e >> 5) & 31, cx = e & 31; s2reg[i] = M[(size_t)(k0 + 64 * u + 32 + rr) * ld + k0 + 64 * u + cx]; }
+  double v = vh ? y[k0 + c] : 0.0;
+  // (where this tile's unknowns go in the solution vector: the index loads would sit between the sums and the stores of the last steps)
+  const int n_own = g.xf.own_dims[node];
+  const int* gi = g.xf.gidx + g.xf.own_g[node];
+  const int gi_hi = (gq == 0 && k0 + 64 + cc < n_own) ? gi[k0 + 64 + cc] : -1, gi_lo = (gq == 0 && k0 + cc < n_own) ? gi[k0 + cc] : -1;
+  {
+    for (int i = tid; i < 2 * 64 * 65; i += 256) sm64[kP64W + i] = 0.0;
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int e = tid + 256 * i, blk = e >> 8, rr = (e >> 4) & 15, cx = e & 15; W[blk >> 2][16 * (blk & 3) + rr][16 * (blk & 3) + cx] = dreg[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int e = tid + 256 * i; S1[e >> 8][(e >> 4) & 15][e & 15] = s1reg[i]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int e = tid + 256 * i; S2[e >> 10][(e >> 5) & 31][e & 31] = s2reg[i]; }
+    lds_barrier();
+  }
+  double bb[16];   // (B of this tile: needed last, loaded once the staging registers are free)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bb[i] = M[(size_t)(k0 + 64 + 16 * gq + i) * ld + k0 + cc];
+  {  // ---- 16 -> 32: four pairs, one per wave
+    const int t = w, u = t >> 1, o = 32 * (t & 1), c1 = l & 15, r0 = 4 * (l >> 4);
+    double yv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const double d = W[u][o + k][o + c1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) yv[i] += S1[t][r0 + i][k] * d;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Y1[t][r0 + i][c1] = yv[i];
+    lds_barrier();
+    double xv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const double yk = Y1[t][k][c1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xv[i] -= W[u][o + 16 + r0 + i][o + 16 + k] * yk;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) W[u][o + 16 + r0 + i][o + c1] = xv[i];
+    lds_barrier();
+  }
+  {  // ---- 32 -> 64: two pairs, two waves each
+    const int u = tid >> 7, l2 = tid & 127, c2 = l2 & 31, r0 = 8 * (l2 >> 5);
+    double yv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const double d = W[u][k][c2];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) yv[i] += S2[u][r0 + i][k] * d;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Y2[u][r0 + i][c2] = yv[i];
+    lds_barrier();
+    double xv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const double yk = Y2[u][k][c2];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xv[i] -= W[u][32 + r0 + i][32 + k] * yk;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) W[u][32 + r0 + i][c2] = xv[i];
+    lds_barrier();
+  }
+  double w1[16], w0[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { w1[i] = W[1][16 * gq + i][cc]; w0[i] = W[0][16 * gq + i][cc]; }
+  // ---- the border's share (helpers), in chunk order
+  if (vh)
+    for (int q0 = 0; q0 < nch; q0 += 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = q0 + u < nch ? pipe_take(scr_f + ((size_t)p * g.nchunk + q0 + u) * kTile + c, g, true) : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v -= t[u];
+    }
+  // ---- the tiles solved before this one, in the order they are solved
+  // (tile L[q, p] is loaded at the top of the step that uses it, before x_q is polled — loads return in order, so the poll comes back behind it;
+  //  a workgroup that keeps up with the chain spends that latency waiting for x_q anyway. Prefetching it a step ahead into the same registers made
+  //  the compiler rotate 128 registers through copies every step: 1 us of a 3.8 us step)
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#ifdef COVGPU_PIPE_PROBE
+  long long tp0 = wall_clock64(), tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;
+#endif
+  for (int q = nIt - 1; q > p; --q) {
+    double Lq[64];
+    {
+      const double* src = M + (size_t)(q * kTile + 64 * h) * ld + k0 + c;
+#pragma unroll
+      for (int r = 0; r < 64; ++r) Lq[r] = src[(size_t)r * ld];
+    }
+    if (vh) sxq[128 * (q & 1) + c] = pipe_take(xpub_f + (size_t)q * kTile + c, g, false);
+    lds_barrier();
+#ifdef COVGPU_PIPE_PROBE
+    tp1 = wall_clock64();
+#endif
+    const double2* xs = reinterpret_cast<const double2*>(sxq + 128 * (q & 1) + 64 * h);
+#pragma unroll
+    for (int r = 0; r < 32; r += 2) {
+      const double2 x0 = xs[r], x1 = xs[r + 1];
+      a0 += Lq[2 * r] * x0.x; a1 += Lq[2 * r + 1] * x0.y; a2 += Lq[2 * r + 2] * x1.x; a3 += Lq[2 * r + 3] * x1.y;
+    }
+  }
+  {
+    double acc = (a0 + a1) + (a2 + a3);
+    acc += __shfl_xor(acc, 32, 64);
+    if (vh) { v -= acc; sv[c] = v; }
+  }
+  lds_barrier();
+#ifdef COVGPU_PIPE_PROBE
+  tp2 = wall_clock64();
+#endif
+  {  // x_hi = C^-T v_hi
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) { s0 += w1[i] * sv[64 + 16 * gq + i]; s1 += w1[i + 1] * sv[64 + 16 * gq + i + 1]; }
+    double sum = s0 + s1;
+    sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+    if (gq == 0) {
+      sx[64 + cc] = sum;
+      if (p > 0) __hip_atomic_store(xpub_f + (size_t)p * kTile + 64 + cc, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (gi_hi >= 0) g.xf.x[gi_hi] = sum;
+    }
+  }
+  lds_barrier();
+  {  // v_lo - B^T x_hi
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) { s0 += bb[i] * sx[64 + 16 * gq + i]; s1 += bb[i + 1] * sx[64 + 16 * gq + i + 1]; }
+    double sum = s0 + s1;
+    sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+    if (gq == 0) svlo[cc] = sv[cc] - sum;
+  }
+  lds_barrier();
+  {  // x_lo = A^-T (...)
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) { s0 += w0[i] * svlo[16 * gq + i]; s1 += w0[i + 1] * svlo[16 * gq + i + 1]; }
+    double sum = s0 + s1;
+    sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+    if (gq == 0) {
+      if (p > 0) __hip_atomic_store(xpub_f + (size_t)p * kTile + cc, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (gi_lo >= 0) g.xf.x[gi_lo] = sum;
+    }
+  }
+#ifdef COVGPU_PIPE_PROBE
+  tp3 = wall_clock64();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  tp4 = wall_clock64();
+  if (tid == 0 && nch == 0) printf("pipe64 tile %2d: start %lld  last x in +%lld  product +%lld  solve +%lld  stores done +%lld (10 ns ticks)\n", p, tp0 % 100000000ll, tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3);
+#endif
   if (p == 0)
     for (int i = kTile + tid; i < nIt * kTile; i += 256)
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(xpub_f + i), kPipeEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1206,6 +1425,15 @@ void launch_bwd_pipe(const double* S, int tI, int ntiles, int nchunk, double* y,
   constexpr size_t lds = (size_t)128 * 7 * 8 * sizeof(double);   // the packed blocks of the diagonal tile
   static bool once = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); return true; }();
   (void)once;
+  // few tiles in the launch: the form with the 64x64 inverses (a whole CU per tile workgroup)
+  static const int max64 = getenv("COVGPU_BWD_PIPE64") ? atoi(getenv("COVGPU_BWD_PIPE64")) : 128;
+  if (nbt * ntiles <= max64) {
+    constexpr size_t lds64 = (size_t)kP64Doubles * sizeof(double);
+    static bool once64 = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_pipe64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64); return true; }();
+    (void)once64;
+    hipLaunchKernelGGL(k_bwd_pipe64, dim3(ntiles + ntiles * nchunk, nbt), dim3(256), lds64, st, g);
+    return;
+  }
   hipLaunchKernelGGL(k_bwd_pipe, dim3(ntiles * nchunk + ntiles, nbt), dim3(256), lds, st, g);
 }
 

@@ -1038,6 +1038,7 @@ static constexpr unsigned long long kPipeEmpty = 0x7ff8c0f6a11d0e5full;
 struct BwdPipeArgs {
   const double* M; int tI, T, nchunk; double* y; const double* Dinv_all; size_t bsL, bsR; const long long* btab; const int* live; BwdXfer xf;
   double *scr, *xpub; int *dead, *dead_h; long long limit; int check;   // check: polls between two looks at the clock, minus one (a power of two)
+  int fault;   // dev aid (COVGPU_PIPE_FAULT=1, tests): the first tile of every chain withholds its result — whoever waits for it runs into the limit
 };
 COV_DEV double pipe_take(double* slot, const BwdPipeArgs& g, bool restore) {
   unsigned long long* w = reinterpret_cast<unsigned long long*>(slot);
@@ -1199,7 +1200,7 @@ __global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) {
 #ifdef COVGPU_PIPE_PROBE
   tp3 = wall_clock64();
 #endif
-  if (act && p > 0) __hip_atomic_store(xpub_f + (size_t)p * kTile + c, sx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (act && p > 0 && !(g.fault && p == nIt - 1)) __hip_atomic_store(xpub_f + (size_t)p * kTile + c, sx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef COVGPU_PIPE_PROBE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   tp4 = wall_clock64();
@@ -1376,7 +1377,7 @@ __global__ __launch_bounds__(256) void k_bwd_pipe64(BwdPipeArgs g) {
     sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
     if (gq == 0) {
       sx[64 + cc] = sum;
-      if (p > 0) __hip_atomic_store(xpub_f + (size_t)p * kTile + 64 + cc, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (p > 0 && !(g.fault && p == nIt - 1)) __hip_atomic_store(xpub_f + (size_t)p * kTile + 64 + cc, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (gi_hi >= 0) g.xf.x[gi_hi] = sum;
     }
   }
@@ -1397,7 +1398,7 @@ __global__ __launch_bounds__(256) void k_bwd_pipe64(BwdPipeArgs g) {
     double sum = s0 + s1;
     sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
     if (gq == 0) {
-      if (p > 0) __hip_atomic_store(xpub_f + (size_t)p * kTile + cc, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (p > 0 && !(g.fault && p == nIt - 1)) __hip_atomic_store(xpub_f + (size_t)p * kTile + cc, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (gi_lo >= 0) g.xf.x[gi_lo] = sum;
     }
   }
@@ -1419,7 +1420,9 @@ void launch_pipe_fill(double* buf, size_t n, hipStream_t st) {
 }
 void launch_bwd_pipe(const double* S, int tI, int ntiles, int nchunk, double* y, const double* Linv, int nbt, size_t sL, size_t sR, hipStream_t st,
                      const long long* btab, const int* live, BwdXfer xf, double* pipe, int* dead, int* dead_h, double timeout_s) {
-  BwdPipeArgs g{S, tI, ntiles, nchunk, y, Linv, sL, sR, btab, live, xf, pipe, pipe + (size_t)nbt * ntiles * nchunk * kTile, dead, dead_h, (long long)(timeout_s * 1e8), 2047};
+  BwdPipeArgs g{S, tI, ntiles, nchunk, y, Linv, sL, sR, btab, live, xf, pipe, pipe + (size_t)nbt * ntiles * nchunk * kTile, dead, dead_h, (long long)(timeout_s * 1e8), 2047, 0};
+  static const int fault = getenv("COVGPU_PIPE_FAULT") ? atoi(getenv("COVGPU_PIPE_FAULT")) : 0;
+  g.fault = fault;
   static const int check = getenv("COVGPU_PIPE_SPIN_CHECK") ? std::max(1, atoi(getenv("COVGPU_PIPE_SPIN_CHECK"))) : 2048;   // (the test of the fallback: 1)
   g.check = check - 1;
   constexpr size_t lds = (size_t)128 * 7 * 8 * sizeof(double);   // the packed blocks of the diagonal tile

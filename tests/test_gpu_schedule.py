@@ -82,9 +82,11 @@ def test_gate_timeout_falls_back_to_events(tmp_path):
 def test_backward_pipeline_timeout_falls_back_to_a_launch_per_tile(tmp_path):
     """The pipelined backward substitution (one workgroup per interior tile, the solved tiles handed over inside the launch) gives up the same way:
     a hand-over that does not arrive in time raises the give-up flag, the solve is repeated with a launch per tile. Here the stream ordering is
-    already HIP events (so only the pipeline can time out), the clock is looked at after every poll and the limit is 1e-7 s."""
+    already HIP events (so only the pipeline can time out), the first tile of every chain withholds its result (COVGPU_PIPE_FAULT: a workgroup that
+    keeps up never has to wait otherwise), the clock is looked at after every poll and the limit is 1e-7 s."""
     a = _solve(tmp_path, "events", "mh01", COVGPU_GATES="0", COVGPU_BWD_PIPE="0")
-    b = _solve(tmp_path, "pipe_timing_out", "mh01", COVGPU_GATES="0", COVGPU_GATE_TIMEOUT_S="0.0000001", COVGPU_GATE_TIMEOUT_MIN="0", COVGPU_PIPE_SPIN_CHECK="1")
+    b = _solve(tmp_path, "pipe_timing_out", "mh01", COVGPU_GATES="0", COVGPU_GATE_TIMEOUT_S="0.0000001", COVGPU_GATE_TIMEOUT_MIN="0", COVGPU_PIPE_SPIN_CHECK="1",
+               COVGPU_PIPE_FAULT="1")
     for k in ("pose", "sb", "lm", "cost", "acc"):
         assert np.array_equal(a[k], b[k])
     assert b["ordering"] == -1 and a["ordering"] == 0

@@ -65,7 +65,10 @@ constexpr int LDT = KC + kLdsPad;   // LDS pitch (doubles) of the full-tile kern
 #define COVGPU_PFQ 2   // round 4: 4 (+2 % on a map whose trailing updates were ~300 workgroups: one per CU). Round 5, corrected map (~1 000 workgroups per
                        // launch): two chunks in flight are 138 VGPRs instead of 210 — three workgroups per CU instead of two: 233.9 / 233.5 against 231.8 / 231.2 it/s
 #endif
-constexpr int PFF = COVGPU_PFF, PFQ = COVGPU_PFQ;   // chunks in flight in registers: full tiles, quarter forms
+#ifndef COVGPU_PFR
+#define COVGPU_PFR 2   // the 64x64 RECT form (a dozen workgroups on the serial chain: the next panel's diagonal block): chunks in flight
+#endif
+constexpr int PFF = COVGPU_PFF, PFQ = COVGPU_PFQ, PFR = COVGPU_PFR;   // chunks in flight in registers: full tiles, quarter forms
 
 enum { MODE_SYRK_TRI = 0, MODE_SYRK_RECT = 1, MODE_TRSM = 2 };
 
@@ -287,7 +290,7 @@ COV_DEV void gemm_abt_body(const GemmArgs& g) {
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_gemm_abt(GemmArgs g) { gemm_abt_body<MODE, kTile, kTile, KC, PFF>(g); }
 template <int MODE, int TSA, int TSB>
-__global__ __launch_bounds__(256, 2) void k_gemm_abt_q(GemmArgs g) { gemm_abt_body<MODE, TSA, TSB, KCQ, PFQ>(g); }
+__global__ __launch_bounds__(256, 2) void k_gemm_abt_q(GemmArgs g) { gemm_abt_body<MODE, TSA, TSB, KCQ, (MODE == MODE_SYRK_RECT ? PFR : PFQ)>(g); }
 
 // The single-workgroup potrf (133 KB LDS + 174 VGPRs x 256 threads: needs an EMPTY CU) starves for the whole duration
 // of a bulk trailing update when every CU holds two bulk workgroups: 400-800 us instead of ~100 us (profiles/r01q,

@@ -1218,15 +1218,18 @@ __global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) {
 // BLOCKS of its tile by two doubling steps from the 16x16 inverses ([[A,0],[B,C]]^-1 = [[A^-1,0],[-C^-1 B A^-1, C^-1]]; ~2 us, while the chain is
 // still far away for all but the first tile), and the substitution becomes three products of 16 terms a lane with wave-local sums:
 //   x_hi = C^-T v_hi;  x_lo = A^-T (v_lo - B^T x_hi)        (three barriers instead of sixteen)
-// and the product with x_q sums inside a wave too (column c's two half sums sit 32 lanes apart). Pipeline workgroups come FIRST in the launch (their
-// preparation starts at once); a workgroup takes a whole CU (111 KB of LDS), so with at most 128 of them the helpers always find room: no deadlock.
+// and the product with x_q sums inside a wave too (column c's two half sums sit 32 lanes apart). The order of the workgroups is k_bwd_pipe's (helpers
+// first): a workgroup takes a whole CU (111 KB of LDS), and with the tile workgroups first two contexts running this launch at once (virtual ranks of a
+// sharded solve on one GPU) could fill every CU with tile workgroups that wait for helpers which find no room. Launches of more than 128 tile workgroups
+// use k_bwd_pipe (eight to a CU).
 constexpr int kP64W = 0, kP64S1 = 2 * 64 * 65, kP64S2 = kP64S1 + 4 * 16 * 17, kP64Y = kP64S2 + 2 * 32 * 33, kP64V = kP64Y + 2 * 32 * 33, kP64Doubles = kP64V + 128 + 128 + 64 + 256;
 __global__ __launch_bounds__(256) void k_bwd_pipe64(BwdPipeArgs g) {
   extern __shared__ __attribute__((aligned(16))) double sm64[];
   const int batch = blockIdx.y, tid = threadIdx.x;
-  if ((int)blockIdx.x >= g.T) { bwd_pipe_helper(g, (int)blockIdx.x - g.T, batch, sm64, reinterpret_cast<double2(*)[64]>(sm64 + 256)); return; }
+  const int nhelp = g.T * g.nchunk;
+  if ((int)blockIdx.x < nhelp) { bwd_pipe_helper(g, (int)blockIdx.x, batch, sm64, reinterpret_cast<double2(*)[64]>(sm64 + 256)); return; }
   const int nIt = g.live[2 * batch];
-  const int p = g.T - 1 - (int)blockIdx.x;
+  const int p = g.T - 1 - ((int)blockIdx.x - nhelp);
   if (p >= nIt) return;
   const int node = g.xf.first + batch;
   const int nch = (g.xf.st_dims[node] + 255) / 256;
@@ -1434,7 +1437,7 @@ void launch_bwd_pipe(const double* S, int tI, int ntiles, int nchunk, double* y,
     constexpr size_t lds64 = (size_t)kP64Doubles * sizeof(double);
     static bool once64 = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_pipe64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64); return true; }();
     (void)once64;
-    hipLaunchKernelGGL(k_bwd_pipe64, dim3(ntiles + ntiles * nchunk, nbt), dim3(256), lds64, st, g);
+    hipLaunchKernelGGL(k_bwd_pipe64, dim3(ntiles * nchunk + ntiles, nbt), dim3(256), lds64, st, g);
     return;
   }
   hipLaunchKernelGGL(k_bwd_pipe, dim3(ntiles * nchunk + ntiles, nbt), dim3(256), lds, st, g);

@@ -367,6 +367,17 @@ void launch_bwd_front(const double* S, int tI, int ntiles, int nchunk, double* y
 void launch_bwd_pipe(const double* S, int tI, int ntiles, int nchunk, double* y, const double* Linv, int nbt, size_t sL, size_t sR, hipStream_t st,
                      const long long* btab, const int* live, BwdXfer xf, double* pipe, int* dead, int* dead_h, double timeout_s);
 void launch_pipe_fill(double* buf, size_t n, hipStream_t st);
+// several (bottom) levels of the tree in ONE launch (k_panel.hip: k_bwd_tree); lev[0] is the HIGHEST of them. pipe: as above, at least the sum over the
+// levels of nbt * T * (nchunk + 1) * 128 doubles
+constexpr int kBwdTreeMax = 8;
+constexpr int kPipeChunk = 128;              // border rows per helper workgroup of the pipelined backward substitution
+struct BwdTreeLevel {
+  int nbt, T, nchunk, tI, first;             // fronts | interior tiles (max) | 256-row chunks of the border (max) | padded interior tiles | first node
+  double* y; size_t bsR; const double* Dinv; size_t bsL; const long long* btab; const int* live;
+  size_t scr_off, xpub_off;                  // (filled in by the launcher)
+};
+void launch_bwd_tree(const double* M, const BwdTreeLevel* lev, int nlev, BwdXfer xf, double* pipe, int* dead, int* dead_h, double timeout_s, hipStream_t st);
+unsigned long long pipe_empty_word();        // the "empty" word of the hand-over slots (k_nd_assemble fills the solution vector's merged entries with it)
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
                      size_t sR, const int* live, int tI, hipStream_t st, bool chain = false, const long long* btab = nullptr, int nb = -1, const int* own = nullptr);
 void launch_bwd_step_sub(const double* S, size_t ld, int p, const double* Linv_p, double* y, double* x, int ncol, int nblocks, int nbt, size_t sM,
@@ -436,6 +447,9 @@ struct NdDev {
   // device tables of the assembly kernels (owned by the context's allocation list)
   int *own_dims = nullptr, *st_dims = nullptr, *own_g = nullptr, *st_g = nullptr;  // [nodes] sizes | offsets into gidx
   int *gidx = nullptr;                     // solution index D kf + component of every own / border scalar of every node
+  // bottom levels whose backward substitution runs as ONE launch (k_bwd_tree): levels [0, tree_levels) (0: none) and the solution indices of their
+  // fronts' own unknowns (filled with the hand-over's "empty" word at the start of a solve)
+  int tree_levels = 0; int* tree_fill = nullptr; std::vector<int> h_tree_fill;
   int *cptr = nullptr, *cidx = nullptr;    // [nodes + 1], children that are subtree nodes (all children on a single GPU)
   int *cptr2 = nullptr, *cidx2 = nullptr;  // [nodes + 1], children that are top nodes
   int *inv_off = nullptr, *inv = nullptr;  // [nodes] offset of the node's map parent front row -> own front row (-1: none)

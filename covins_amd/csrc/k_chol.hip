@@ -995,7 +995,7 @@ void dense_backward_solve(double* S, double* b, double* Linv, int npad, hipStrea
     // multifrontal front of few interior tiles: given rows and every interior tile in ONE launch (k_panel.hip: k_bwd_front)
     const int nt_real = bt.own_max > 0 ? std::min(tfact, (bt.own_max + kTile - 1) / kTile) : tfact;
     if (bt.bwd_pipe != nullptr && bt.pipe_dead != nullptr && bt.xfer.gidx != nullptr && bt.tab != nullptr && bt.live != nullptr && nt_real >= bwd_pipe_min_tiles() && nbt <= 65535) {
-      launch_bwd_pipe(S, tfact, nt_real, ((tend - tfact) * kTile + 255) / 256, b + npad, Linv, nbt, bt.sL, bt.sR, st, bt.tab, bt.live, bt.xfer, bt.bwd_pipe, bt.pipe_dead,
+      launch_bwd_pipe(S, tfact, nt_real, ((tend - tfact) * kTile + kPipeChunk - 1) / kPipeChunk, b + npad, Linv, nbt, bt.sL, bt.sR, st, bt.tab, bt.live, bt.xfer, bt.bwd_pipe, bt.pipe_dead,
                       bt.pipe_dead_h, bt.pipe_timeout_s);
       return;
     }

@@ -259,6 +259,16 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& 
     children(dev.h_cptr, dev.h_cidx);
     children(dev.h_cptr2, dev.h_cidx2);
   }
+  {  // bottom levels whose backward substitution runs as one launch (k_panel.hip: k_bwd_tree): while a level's fronts hold at most two interior tiles
+    int ls = 0;
+    const int lmax = std::min(std::min(nlev, Hs), kBwdTreeMax);
+    while (ls < lmax && dev.lev[ls].n > 0 && dev.lev[ls].n <= 65535 && (dev.lev[ls].own_max + kTile - 1) / kTile <= 2) ++ls;
+    dev.tree_levels = ls >= 2 ? ls : 0;
+    dev.h_tree_fill.clear();
+    for (int l = 0; l < dev.tree_levels; ++l)
+      for (int i = dev.lev[l].first; i < dev.lev[l].first + dev.lev[l].n; ++i)
+        for (int q = 0; q < dev.h_own_dims[i]; ++q) dev.h_tree_fill.push_back(dev.h_gidx[dev.h_own_g[i] + q]);
+  }
   dev.active = true;
 }
 
@@ -316,8 +326,11 @@ __global__ __launch_bounds__(256) void k_nd_zero(DevProblem P, NdZeroArgs z) {
 
 // speed-bias part of the system (block-tridiagonal rows Ad / Ae and their couplings Bp / Bs / Bn to the poses, filled by the
 // inertial kernels and damped by k_finalize_diag) and the right-hand side -> fronts. One thread per entry.
-__global__ __launch_bounds__(256) void k_nd_assemble(DevProblem P, const int* __restrict__ rhs_off) {
+__global__ __launch_bounds__(256) void k_nd_assemble(DevProblem P, const int* __restrict__ rhs_off, double* __restrict__ x, const int* __restrict__ fill, int nfill,
+                                                      unsigned long long empty) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  // (the solution vector's entries of the levels whose backward substitution is ONE launch start a solve "empty": k_panel.hip, k_bwd_tree)
+  if (t < nfill) reinterpret_cast<unsigned long long*>(x)[fill[t]] = empty;
   if (P.vi) {
     const int pos = t / 324, e = t - 324 * pos;
     if (pos < P.K) {
@@ -517,7 +530,15 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     size_t need = 0;
     for (const NdLevel& L : nd.lev) {
       const int T = std::min(L.nI / kTile, (L.own_max + kTile - 1) / kTile);
-      if (L.n > 0 && T >= bwd_pipe_min_tiles()) need = std::max(need, (size_t)L.n * T * ((L.ntot - L.nI + 255) / 256 + 1) * kTile);
+      if (L.n > 0 && T >= bwd_pipe_min_tiles()) need = std::max(need, (size_t)L.n * T * ((L.ntot - L.nI + kPipeChunk - 1) / kPipeChunk + 1) * kTile);
+    }
+    {
+      size_t tree = 0;
+      for (int l = 0; l < nd.tree_levels; ++l) {
+        const NdLevel& L = nd.lev[l];
+        tree += (size_t)L.n * std::min(L.nI / kTile, (L.own_max + kTile - 1) / kTile) * ((L.ntot - L.nI + kPipeChunk - 1) / kPipeChunk + 1) * kTile;
+      }
+      need = std::max(need, tree);
     }
     if (need > ax.bwd_pipe_elems) {
       if (ax.bwd_pipe) { (void)hipDeviceSynchronize(); (void)hipFree(ax.bwd_pipe); }
@@ -528,11 +549,17 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
       } else ax.bwd_pipe = nullptr;                // (launch per tile)
     }
   }
+  static const bool fused_bwd = getenv("COVGPU_ND_BWD_FUSED") == nullptr || atoi(getenv("COVGPU_ND_BWD_FUSED")) != 0;
+  static const bool tree_env = getenv("COVGPU_BWD_TREE") == nullptr || atoi(getenv("COVGPU_BWD_TREE")) != 0;
+  // the bottom levels' backward substitution as one launch (k_bwd_tree): needs the pipeline's scratch and the give-up word
+  const bool tree_on = tree_env && fused_bwd && nd.tree_levels >= 2 && nd.tree_fill != nullptr && !ax.pipe_broken && ax.bwd_pipe != nullptr && ax.gate_dead != nullptr &&
+                       bwd_pipe_min_tiles() < (1 << 29);
   ax.mark(st, -1);
   // (the right-hand sides were cleared on the head stream of the build, beside the fronts: solver.hip enqueue_build)
   {
-    const int cnt = std::max(P.vi ? 324 * P.K : 0, P.n);
-    hipLaunchKernelGGL(k_nd_assemble, dim3((cnt + 255) / 256), dim3(256), 0, st, P, (const int*)nd.rhs_node);
+    const int nfill = tree_on ? (int)nd.h_tree_fill.size() : 0;
+    const int cnt = std::max(std::max(P.vi ? 324 * P.K : 0, P.n), nfill);
+    hipLaunchKernelGGL(k_nd_assemble, dim3((cnt + 255) / 256), dim3(256), 0, st, P, (const int*)nd.rhs_node, dst, (const int*)nd.tree_fill, nfill, pipe_empty_word());
   }
   ax.mark(st, -2);
   auto batch = [&](int l) {
@@ -623,7 +650,7 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     }
     run_levels(ltop, nlev, true);
   }
-  for (int l = nlev - 1; l >= 0; --l) {
+  for (int l = nlev - 1; l >= (tree_on ? nd.tree_levels : 0); --l) {
     // top-down: the ancestors' unknowns are read from `dst` by the first launch of the level, the fronts' own unknowns are
     // written there by its last (BwdXfer)
     const NdLevel& L = nd.lev[l];
@@ -631,10 +658,23 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     DenseBatch bt = batch(l);
     bt.xfer.gidx = nd.gidx; bt.xfer.own_g = nd.own_g; bt.xfer.st_g = nd.st_g; bt.xfer.own_dims = nd.own_dims; bt.xfer.st_dims = nd.st_dims;
     bt.xfer.x = dst; bt.xfer.first = L.first;
-    static const bool fused_bwd = getenv("COVGPU_ND_BWD_FUSED") == nullptr || atoi(getenv("COVGPU_ND_BWD_FUSED")) != 0;
     bt.bwd_cnt = fused_bwd ? ax.bwd_cnt : nullptr; bt.bwd_scr = ax.bwd_scr;
     if (fused_bwd && !ax.pipe_broken && ax.bwd_pipe != nullptr) { bt.bwd_pipe = ax.bwd_pipe; bt.pipe_dead = ax.gate_dead; bt.pipe_dead_h = ax.gate_dead_h; bt.pipe_timeout_s = ax.gate_timeout_s; }
     dense_backward_solve(P.nd_M, P.nd_rhs + L.rhs_off, P.nd_Linv + L.linv_off, L.ntot, st, L.nI / kTile, L.ntot / kTile, bt);
+    ax.mark(st, -5);
+  }
+  if (tree_on) {   // levels tree_levels - 1 .. 0 in one launch
+    BwdTreeLevel tl[kBwdTreeMax];
+    for (int q = 0; q < nd.tree_levels; ++q) {
+      const NdLevel& L = nd.lev[nd.tree_levels - 1 - q];
+      BwdTreeLevel& t = tl[q];
+      t.nbt = L.n; t.T = std::min(L.nI / kTile, (L.own_max + kTile - 1) / kTile); t.nchunk = (L.ntot - L.nI + kPipeChunk - 1) / kPipeChunk; t.tI = L.nI / kTile; t.first = L.first;
+      t.y = P.nd_rhs + L.rhs_off + L.ntot; t.bsR = (size_t)2 * L.ntot; t.Dinv = P.nd_Linv + L.linv_off; t.bsL = (size_t)L.nI * kTile;
+      t.btab = P.nd_ntab + 2 * (size_t)L.first; t.live = L.live; t.scr_off = t.xpub_off = 0;
+    }
+    BwdXfer xf;
+    xf.gidx = nd.gidx; xf.own_g = nd.own_g; xf.st_g = nd.st_g; xf.own_dims = nd.own_dims; xf.st_dims = nd.st_dims; xf.x = dst; xf.first = 0;
+    launch_bwd_tree(P.nd_M, tl, nd.tree_levels, xf, ax.bwd_pipe, ax.gate_dead, ax.gate_dead_h, ax.gate_timeout_s, st);
     ax.mark(st, -5);
   }
   ax.mark(st, -6);

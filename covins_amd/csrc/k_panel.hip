@@ -1039,6 +1039,8 @@ struct BwdPipeArgs {
   const double* M; int tI, T, nchunk; double* y; const double* Dinv_all; size_t bsL, bsR; const long long* btab; const int* live; BwdXfer xf;
   double *scr, *xpub; int *dead, *dead_h; long long limit; int check;   // check: polls between two looks at the clock, minus one (a power of two)
   int fault;   // dev aid (COVGPU_PIPE_FAULT=1, tests): the first tile of every chain withholds its result — whoever waits for it runs into the limit
+  int tree;    // k_bwd_tree (several levels in one launch): the ancestors' unknowns are POLLED in the solution vector (its entries of the merged levels
+               // hold kPipeEmpty since k_nd_assemble), a front's own unknowns go there with agent-scope stores
 };
 COV_DEV double pipe_take(double* slot, const BwdPipeArgs& g, bool restore) {
   unsigned long long* w = reinterpret_cast<unsigned long long*>(slot);
@@ -1057,52 +1059,52 @@ COV_DEV double pipe_take(double* slot, const BwdPipeArgs& g, bool restore) {
   if (restore) __hip_atomic_store(w, kPipeEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return __longlong_as_double((long long)v);
 }
-// helper workgroup hx = tile * nchunk + chunk of front `batch`: its 256 border rows' share of y_tile, into its slot of `scr`
-COV_DEV void bwd_pipe_helper(const BwdPipeArgs& g, int hx, int batch, double* sxg /* [256] */, double2 (*part)[64]) {
+// helper workgroup hx = tile * nchunk + chunk of front `batch`: its kPipeChunk border rows' share of y_tile, into its slot of `scr`.
+// ALL its rows of L are in registers (32 double2 a lane) before the ancestors' unknowns are gathered: what follows their arrival is arithmetic only.
+// (First form: 256 rows a workgroup in eight batches of eight loads — eight dependent memory latencies, ~10 us of every level's ~20.)
+COV_DEV void bwd_pipe_helper(const BwdPipeArgs& g, int hx, int batch, double* sxg /* [kPipeChunk] */, double2 (*part)[64]) {
   const int tid = threadIdx.x;
   const int nIt = g.live[2 * batch];
   const int node = g.xf.first + batch;
   const int nst = g.xf.st_dims[node];
-  const int nch = (nst + 255) / 256;
+  const int nch = (nst + kPipeChunk - 1) / kPipeChunk;
   const double* M = g.M + (size_t)g.btab[2 * batch];
   const size_t ld = (size_t)g.btab[2 * batch + 1];
   double* scr_f = g.scr + (size_t)batch * g.T * g.nchunk * kTile;
-  {
-    const int ct = hx / g.nchunk, k = hx % g.nchunk;
-    if (ct >= nIt || k >= nch) return;
-    const int r0 = g.tI * kTile + 256 * k, nr = min(256, nst - 256 * k);
-    const int* gi = g.xf.gidx + g.xf.st_g[node] + 256 * k;
-    if (tid < nr) sxg[tid] = g.xf.x[gi[tid]];
-    __syncthreads();
-    const int lane = tid & 63, wv = tid >> 6;
-    const int col = ct * kTile + 2 * lane;
-    double2 acc = {0.0, 0.0};
-    const double* Lp = M + (size_t)r0 * ld + col;
-    int r = wv;
-    for (; r + 28 < nr; r += 32) {
-      double2 v[8]; double xv[8];
+  const int ct = hx / g.nchunk, k = hx % g.nchunk;
+  if (ct >= nIt || k >= nch) return;
+  const int r0 = g.tI * kTile + kPipeChunk * k, nr = min(kPipeChunk, nst - kPipeChunk * k);
+  const int lane = tid & 63, wv = tid >> 6;
+  const int col = ct * kTile + 2 * lane;
+  const double* Lp = M + (size_t)r0 * ld + col;
+  static_assert(kPipeChunk == 128, "32 rows a wave");
+  double2 v[32];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { v[u] = *reinterpret_cast<const double2*>(Lp + (size_t)(r + 4 * u) * ld); xv[u] = sxg[r + 4 * u]; }
+  for (int u = 0; u < 32; ++u) v[u] = (wv + 4 * u < nr) ? *reinterpret_cast<const double2*>(Lp + (size_t)(wv + 4 * u) * ld) : double2{0.0, 0.0};
+  const int* gi = g.xf.gidx + g.xf.st_g[node] + kPipeChunk * k;
+  if (tid < kPipeChunk) sxg[tid] = tid < nr ? (g.tree ? pipe_take(g.xf.x + gi[tid], g, false) : g.xf.x[gi[tid]]) : 0.0;
+  __syncthreads();
+  double2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0};
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { acc.x += v[u].x * xv[u]; acc.y += v[u].y * xv[u]; }
-    }
-    for (; r < nr; r += 4) { const double2 v = *reinterpret_cast<const double2*>(Lp + (size_t)r * ld); const double xv = sxg[r]; acc.x += v.x * xv; acc.y += v.y * xv; }
-    part[wv][lane] = acc;
-    __syncthreads();
-    if (wv == 0) {
-      const double2 a = part[0][lane], b = part[1][lane], c = part[2][lane], d = part[3][lane];
-      double* dst = scr_f + ((size_t)ct * g.nchunk + k) * kTile + 2 * lane;
-      __hip_atomic_store(dst, ((a.x + b.x) + c.x) + d.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(dst + 1, ((a.y + b.y) + c.y) + d.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  for (int u = 0; u < 32; u += 2) {
+    const double x0 = sxg[wv + 4 * u], x1 = sxg[wv + 4 * u + 4];
+    a0.x += v[u].x * x0; a0.y += v[u].y * x0; a1.x += v[u + 1].x * x1; a1.y += v[u + 1].y * x1;
+  }
+  part[wv][lane] = double2{a0.x + a1.x, a0.y + a1.y};
+  __syncthreads();
+  if (wv == 0) {
+    const double2 a = part[0][lane], b = part[1][lane], c = part[2][lane], d = part[3][lane];
+    double* dst = scr_f + ((size_t)ct * g.nchunk + k) * kTile + 2 * lane;
+    __hip_atomic_store(dst, ((a.x + b.x) + c.x) + d.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 1, ((a.y + b.y) + c.y) + d.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-__global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) {
-  const int batch = blockIdx.y, tid = threadIdx.x;
+COV_DEV void bwd_pipe_body(const BwdPipeArgs& g, const int bx, const int batch) {   // bx: the workgroup's index inside its front (helpers first)
+  const int tid = threadIdx.x;
   const int nIt = g.live[2 * batch];            // real interior tiles of this front
   const int node = g.xf.first + batch;
   const int nst = g.xf.st_dims[node];
-  const int nch = (nst + 255) / 256;            // row chunks of this front's border (0: the root)
+  const int nch = (nst + kPipeChunk - 1) / kPipeChunk;   // row chunks of this front's border (0: the root)
   const double* M = g.M + (size_t)g.btab[2 * batch];
   const size_t ld = (size_t)g.btab[2 * batch + 1];
   double* scr_f = g.scr + (size_t)batch * g.T * g.nchunk * kTile;   // [tile][chunk][128]
@@ -1110,8 +1112,8 @@ __global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) {
   const int nhelp = g.T * g.nchunk;
   __shared__ double2 part[4][64];
   __shared__ double sx[kTile], sv[kTile], sxq[2][kTile], part2[2][kTile];
-  if ((int)blockIdx.x < nhelp) { bwd_pipe_helper(g, (int)blockIdx.x, batch, &sxq[0][0], part); return; }
-  const int p = g.T - 1 - ((int)blockIdx.x - nhelp);
+  if (bx < nhelp) { bwd_pipe_helper(g, bx, batch, &sxq[0][0], part); return; }
+  const int p = g.T - 1 - (bx - nhelp);
   if (p >= nIt) return;
   const int k0 = p * kTile;
   double* y = g.y + (size_t)batch * g.bsR;
@@ -1206,11 +1208,32 @@ __global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) {
   tp4 = wall_clock64();
   if (tid == 0 && nst == 0) printf("pipe tile %2d: start %lld  last x in +%lld  gemv+reduce +%lld  solve +%lld  published +%lld (10 ns ticks)\n", p, tp0 % 100000000ll, tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3);
 #endif
-  if (gi_own >= 0) g.xf.x[gi_own] = sx[c];   // own unknowns of this tile -> solution vector
+  if (gi_own >= 0) {   // own unknowns of this tile -> solution vector
+    if (g.tree) __hip_atomic_store(g.xf.x + gi_own, sx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else g.xf.x[gi_own] = sx[c];
+  }
   // the last tile of the chain has seen every x_q of the front, and so has everybody else by then: the slots are free again
   if (p == 0)
     for (int i = kTile + tid; i < nIt * kTile; i += 256)
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(xpub_f + i), kPipeEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(256) void k_bwd_pipe(BwdPipeArgs g) { bwd_pipe_body(g, (int)blockIdx.x, (int)blockIdx.y); }
+// SEVERAL LEVELS of the tree in one launch (the bottom levels: hundreds of fronts of one or two interior tiles, ~20 us a level as launches of their
+// own — a boundary, the gather of the ancestors' unknowns, the rows of L, the sums, the tile, the scatter, each a dependent memory latency). The
+// levels stand in the grid from the highest to the lowest; a front's helpers POLL its ancestors' unknowns in the solution vector, whose entries of the
+// merged levels k_nd_assemble filled with kPipeEmpty at the start of the solve (entries of higher levels hold values long since: the poll falls
+// through), and the tile workgroups publish a front's own unknowns there with agent-scope stores. A workgroup still only waits for workgroups with a
+// lower linear index. What a level loads that does not depend on the levels above — its rows of L, its block inverses — is in flight while it waits.
+struct BwdTreeArgs { BwdPipeArgs base; BwdTreeLevel lev[kBwdTreeMax]; int wg0[kBwdTreeMax + 1]; int nlev; };
+__global__ __launch_bounds__(256) void k_bwd_tree(BwdTreeArgs a) {
+  int l = 0;
+  while (l + 1 < a.nlev && (int)blockIdx.x >= a.wg0[l + 1]) ++l;
+  const BwdTreeLevel& L = a.lev[l];
+  BwdPipeArgs g = a.base;
+  g.tI = L.tI; g.T = L.T; g.nchunk = L.nchunk; g.y = L.y; g.Dinv_all = L.Dinv; g.bsL = L.bsL; g.bsR = L.bsR; g.btab = L.btab; g.live = L.live; g.xf.first = L.first;
+  g.scr = a.base.scr + L.scr_off; g.xpub = a.base.scr + L.xpub_off; g.tree = 1;
+  const int per = L.T * L.nchunk + L.T, local = (int)blockIdx.x - a.wg0[l];
+  bwd_pipe_body(g, local % per, local / per);
 }
 // The same pipeline for the FEW fronts at the top of the tree (at most 128 interior tiles in the launch), where the chain of tiles is the whole cost:
 // measured on the 5-agent map's root, a tile of k_bwd_pipe costs 4.4 us — 0.6 hand-over, 1.0 the product with the newest x_q, 2.8 the eight-step
@@ -1232,7 +1255,7 @@ __global__ __launch_bounds__(256) void k_bwd_pipe64(BwdPipeArgs g) {
   const int p = g.T - 1 - ((int)blockIdx.x - nhelp);
   if (p >= nIt) return;
   const int node = g.xf.first + batch;
-  const int nch = (g.xf.st_dims[node] + 255) / 256;
+  const int nch = (g.xf.st_dims[node] + kPipeChunk - 1) / kPipeChunk;
   const double* M = g.M + (size_t)g.btab[2 * batch];
   const size_t ld = (size_t)g.btab[2 * batch + 1];
   double* scr_f = g.scr + (size_t)batch * g.T * g.nchunk * kTile;
@@ -1418,12 +1441,32 @@ __global__ __launch_bounds__(256) void k_bwd_pipe64(BwdPipeArgs g) {
 __global__ void k_pipe_fill(unsigned long long* p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = kPipeEmpty;
 }
+unsigned long long pipe_empty_word() { return kPipeEmpty; }
 void launch_pipe_fill(double* buf, size_t n, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(k_pipe_fill, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(buf), n);
 }
+void launch_bwd_tree(const double* M, const BwdTreeLevel* lev, int nlev, BwdXfer xf, double* pipe, int* dead, int* dead_h, double timeout_s, hipStream_t st) {
+  BwdTreeArgs a;
+  a.base = BwdPipeArgs{M, 0, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, xf, pipe, pipe, dead, dead_h, (long long)(timeout_s * 1e8), 2047, 0, 1};
+  static const int check = getenv("COVGPU_PIPE_SPIN_CHECK") ? std::max(1, atoi(getenv("COVGPU_PIPE_SPIN_CHECK"))) : 2048;
+  static const int fault = getenv("COVGPU_PIPE_FAULT") ? atoi(getenv("COVGPU_PIPE_FAULT")) : 0;
+  a.base.check = check - 1; a.base.fault = fault;
+  a.nlev = nlev; a.wg0[0] = 0;
+  size_t off = 0;
+  for (int l = 0; l < nlev; ++l) {
+    a.lev[l] = lev[l];
+    a.lev[l].scr_off = off; off += (size_t)lev[l].nbt * lev[l].T * lev[l].nchunk * kTile;
+    a.lev[l].xpub_off = off; off += (size_t)lev[l].nbt * lev[l].T * kTile;
+    a.wg0[l + 1] = a.wg0[l] + lev[l].nbt * (lev[l].T * lev[l].nchunk + lev[l].T);
+  }
+  constexpr size_t lds = (size_t)128 * 7 * 8 * sizeof(double);
+  static bool once = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_tree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); return true; }();
+  (void)once;
+  hipLaunchKernelGGL(k_bwd_tree, dim3(a.wg0[nlev]), dim3(256), lds, st, a);
+}
 void launch_bwd_pipe(const double* S, int tI, int ntiles, int nchunk, double* y, const double* Linv, int nbt, size_t sL, size_t sR, hipStream_t st,
                      const long long* btab, const int* live, BwdXfer xf, double* pipe, int* dead, int* dead_h, double timeout_s) {
-  BwdPipeArgs g{S, tI, ntiles, nchunk, y, Linv, sL, sR, btab, live, xf, pipe, pipe + (size_t)nbt * ntiles * nchunk * kTile, dead, dead_h, (long long)(timeout_s * 1e8), 2047, 0};
+  BwdPipeArgs g{S, tI, ntiles, nchunk, y, Linv, sL, sR, btab, live, xf, pipe, pipe + (size_t)nbt * ntiles * nchunk * kTile, dead, dead_h, (long long)(timeout_s * 1e8), 2047, 0, 0};
   static const int fault = getenv("COVGPU_PIPE_FAULT") ? atoi(getenv("COVGPU_PIPE_FAULT")) : 0;
   g.fault = fault;
   static const int check = getenv("COVGPU_PIPE_SPIN_CHECK") ? std::max(1, atoi(getenv("COVGPU_PIPE_SPIN_CHECK"))) : 2048;   // (the test of the fallback: 1)

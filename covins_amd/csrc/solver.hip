@@ -985,6 +985,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
       RC(dev_upload(c, &nd.own_dims, nd.h_own_dims.data(), nd.h_own_dims.size())); RC(dev_upload(c, &nd.st_dims, nd.h_st_dims.data(), nd.h_st_dims.size()));
       RC(dev_upload(c, &nd.own_g, nd.h_own_g.data(), nd.h_own_g.size())); RC(dev_upload(c, &nd.st_g, nd.h_st_g.data(), nd.h_st_g.size()));
       RC(dev_upload(c, &nd.gidx, nd.h_gidx.data(), nd.h_gidx.size()));
+      RC(dev_upload(c, &nd.tree_fill, nd.h_tree_fill.empty() ? (const int*)nullptr : nd.h_tree_fill.data(), std::max<size_t>(nd.h_tree_fill.size(), 1)));
       RC(dev_upload(c, &nd.cptr, nd.h_cptr.data(), nd.h_cptr.size())); RC(dev_upload(c, &nd.cidx, nd.h_cidx.data(), nd.h_cidx.size()));
       RC(dev_upload(c, &nd.cptr2, nd.h_cptr2.data(), nd.h_cptr2.size())); RC(dev_upload(c, &nd.cidx2, nd.h_cidx2.data(), nd.h_cidx2.size()));
       RC(dev_upload(c, &nd.inv_off, nd.h_inv_off.data(), nd.h_inv_off.size())); RC(dev_upload(c, &nd.inv, nd.h_inv.data(), nd.h_inv.size()));

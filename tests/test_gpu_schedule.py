@@ -96,7 +96,7 @@ def test_kernel_form_switches_stay_at_rounding_level(tmp_path):
     a = _solve(tmp_path, "default", "mh01")
     # (round_3_tail: the trust-region tail as ~25 launches with the second J*v pass on the combined step, instead of k_tail.hip's
     #  one pass over both dogleg directions: the model decrease is the same quadratic form, summed in another order)
-    for tag, env in (("full_tiles", dict(COVGPU_QUARTER_MAX="0")), ("per_tile_backward", dict(COVGPU_ND_BWD_FUSED="0")), ("no_backward_pipeline", dict(COVGPU_BWD_PIPE="0")),
+    for tag, env in (("full_tiles", dict(COVGPU_QUARTER_MAX="0")), ("per_tile_backward", dict(COVGPU_ND_BWD_FUSED="0")), ("no_backward_pipeline", dict(COVGPU_BWD_PIPE="0")), ("bottom_levels_one_by_one", dict(COVGPU_BWD_TREE="0")),
                      ("round_3_tail", dict(COVGPU_TAIL="0"))):
         b = _solve(tmp_path, tag, "mh01", **env)
         assert np.array_equal(a["acc"], b["acc"])

@@ -424,6 +424,7 @@ bool round2_compact_device(int L, int O, int K, const unsigned char* d_erase, co
 
 // ---- multifrontal solve of the whole reduced camera system (k_front.hip)
 struct NdHostPlan;
+constexpr int kExtRec = 144;   // ints per extend-add record: 8 header | 8 child | 64 + 64 row maps (576 bytes)
 struct NdLevel {
   int n = 0, nI = 0, ntot = 0;          // fronts in the batch (0: nothing of this level on this rank) | padded interior order | largest front order
   int first = 0;                          // first node (level order) = row of nd_ntab where this level's batch table starts
@@ -461,6 +462,8 @@ struct NdDev {
   // inv_off / ntab, row map)
   int *extw = nullptr, *extc = nullptr, *extc2 = nullptr;
   std::vector<int> h_extw, h_extc, h_extc2, h_ext_kind;
+  // ... and as records of kExtRec ints (k_nd_extend_rec): [tiles] first records, then the overflow records of tiles with several contributing children
+  int* extr = nullptr; size_t ext_over = 0; std::vector<int> h_extr;
   int *bb_off = nullptr, *bb = nullptr;    // per node: offset of its lower-triangular map over BORDER 128-tiles in bb (1: a child contributes to the tile; see DenseBatch::beta0)
   int *top_var = nullptr, *top_r = nullptr, *top_g = nullptr;  // per scalar unknown of the top nodes: variable | component | solution index
   int ntop = 0;

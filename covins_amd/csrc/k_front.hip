@@ -234,6 +234,40 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& 
       w[0] = (int)(unsigned)(fo & 0xffffffffull); w[1] = (int)(unsigned)(fo >> 32); w[2] = (int)dev.h_ntab[2 * (size_t)node + 1]; w[3] = dev.h_rhs_node[node];
       w[4] = dev.h_ext[3 * q + 1]; w[5] = dev.h_ext[3 * q + 2]; w[6] = cp[node]; w[7] = cp[node + 1];
     }
+    // Round 6, the same lists as RECORDS of kExtRec ints (k_nd_extend_rec): per tile ONE record {header | first contributing child | that child's row
+    // maps for the tile's 64 rows and 64 columns}, found by the tile's index alone, and one overflow record per further contributing child. The kernel's
+    // chain of dependent loads is record -> values instead of tile -> child entries -> row maps -> values; children that reach neither the tile's rows
+    // nor its columns are not visited at all (their terms were zero: same sums, same order).
+    dev.h_extr.assign((size_t)kExtRec * nt, -1);
+    dev.ext_over = nt;
+    for (size_t q = 0; q < nt; ++q) {
+      const int node = dev.h_ext[3 * q], a = dev.h_ext[3 * q + 1], b = dev.h_ext[3 * q + 2];
+      const std::vector<int>& cp = dev.h_ext_kind[q] ? dev.h_cptr2 : dev.h_cptr;
+      const std::vector<int>& ci = dev.h_ext_kind[q] ? dev.h_cidx2 : dev.h_cidx;
+      int nrec = 0;
+      const size_t next = dev.h_extr.size() / kExtRec - nt;
+      for (int k = cp[node]; k < cp[node + 1]; ++k) {
+        const int ch = ci[k];
+        const int* inv = dev.h_inv.data() + dev.h_inv_off[ch];
+        int maps[128];
+        bool anyr = false, anyc = false;
+        for (int e = 0; e < 64; ++e) {
+          const int r = 64 * a + e, c = 64 * b + e;
+          maps[e] = r < ld[node] ? inv[r] : -1; maps[64 + e] = c < ld[node] ? inv[c] : -1;
+          anyr = anyr || maps[e] >= 0; anyc = anyc || maps[64 + e] >= 0;
+        }
+        if (!anyr || !anyc) continue;
+        if (nrec > 0) dev.h_extr.resize(dev.h_extr.size() + kExtRec, -1);
+        int* r = nrec == 0 ? dev.h_extr.data() + (size_t)kExtRec * q : dev.h_extr.data() + dev.h_extr.size() - kExtRec;
+        const unsigned long long mo = (unsigned long long)dev.h_ntab[2 * (size_t)ch];
+        r[8] = (int)(unsigned)(mo & 0xffffffffull); r[9] = (int)(unsigned)(mo >> 32); r[10] = (int)dev.h_ntab[2 * (size_t)ch + 1]; r[11] = dev.h_rhs_node[ch];
+        for (int e = 0; e < 128; ++e) r[16 + e] = maps[e];
+        ++nrec;
+      }
+      int* w = dev.h_extr.data() + (size_t)kExtRec * q;
+      for (int e = 0; e < 6; ++e) w[e] = dev.h_extw[8 * q + e];
+      w[6] = nrec; w[7] = (int)next;
+    }
   }
   // border x border 128-tiles that receive something from a child (NdDev::bb): only those are cleared per iteration and read by the first
   // panel's trailing update. A top front of a sharded solve is summed over the ranks as it stands: all its tiles count as contributed to.
@@ -438,6 +472,71 @@ __global__ __launch_bounds__(256) void k_nd_extend(DevProblem P, NdLevArgs a, co
   }
 }
 
+// The same extend-add reading RECORDS (nd_tables: NdDev::extr): the level transitions sit on the serial chain with a dozen workgroups each, and a
+// workgroup of k_nd_extend is a chain of six dependent loads under a chip full of trailing updates (tile -> child entries -> row maps -> values, a
+// child at a time, then the right-hand side's read-modify-write) — 35-50 us for ten tiles. Here: record (header, first child and its maps: one
+// address, known from the tile index) -> values (and the overflow records of further children) -> store. Bit-identical to k_nd_extend.
+__global__ __launch_bounds__(256) void k_nd_extend_rec(DevProblem P, NdLevArgs a, const int* __restrict__ recs, const int* __restrict__ over, int second_pass, int store_border, DevSignal sig) {
+  if (sig.flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(sig.flag, sig.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int* rec = recs + (size_t)kExtRec * blockIdx.x;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const int4 w0 = reinterpret_cast<const int4*>(rec)[0], w1 = reinterpret_cast<const int4*>(rec)[1];
+  int4 chn = reinterpret_cast<const int4*>(rec)[2];
+  int irn[4], icn[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { irn[i] = rec[16 + ty + 16 * i]; icn[i] = rec[80 + tx + 16 * i]; }
+  const size_t foff = (size_t)(unsigned)w0.x | ((size_t)(unsigned)w0.y << 32);
+  const size_t ld = (size_t)w0.z;
+  const int rhs_p = w0.w, tr = w1.x, tc = w1.y, nrec = w1.z, next = w1.w;
+  double* F = P.nd_M + foff;
+  const int nrow = (int)ld;
+  int rr[4], cc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { rr[i] = 64 * tr + ty + 16 * i; cc[i] = 64 * tc + tx + 16 * i; }
+  double v[4][4], rv[4] = {0.0, 0.0, 0.0, 0.0};
+  bool hit[4][4];
+  const bool own_cols = second_pass != 0 || 64 * tc < a.nI;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[i][j] = (own_cols && rr[i] < nrow && cc[j] <= rr[i]) ? F[(size_t)rr[i] * ld + cc[j]] : 0.0;
+      hit[i][j] = false;
+    }
+  for (int k = 0; k < nrec; ++k) {
+    const double* C = P.nd_M + ((size_t)(unsigned)chn.x | ((size_t)(unsigned)chn.y << 32));
+    const size_t ldc = (size_t)chn.z;
+    const int crhs = chn.w;
+    int ir[4], ic[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ir[i] = irn[i]; ic[i] = icn[i]; }
+    if (k + 1 < nrec) {   // the next child's record is in flight while this one's entries are gathered
+      const int* r2 = over + (size_t)kExtRec * (next + k);
+      chn = reinterpret_cast<const int4*>(r2)[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { irn[i] = r2[16 + ty + 16 * i]; icn[i] = r2[80 + tx + 16 * i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (ir[i] < 0) continue;
+      if (tr == tc && tx == 0) rv[i] += P.nd_rhs[crhs + ir[i]];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (ic[j] < 0 || cc[j] > rr[i]) continue;
+        v[i][j] += C[(size_t)(ir[i] > ic[j] ? ir[i] : ic[j]) * ldc + (ir[i] > ic[j] ? ic[j] : ir[i])];
+        hit[i][j] = true;
+      }
+    }
+  }
+  const bool store_all = !own_cols && store_border != 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (hit[i][j] || (store_all && rr[i] < nrow && cc[j] <= rr[i])) F[(size_t)rr[i] * ld + cc[j]] = v[i][j];
+    if (rv[i] != 0.0) P.nd_rhs[rhs_p + rr[i]] += rv[i];
+  }
+}
+
 // block inverses of the padding columns are the identity once and for all (the panel kernel never writes them: DenseBatch::own_max)
 __global__ __launch_bounds__(256) void k_nd_linv_init(double* __restrict__ Linv, size_t n) {
   const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -581,7 +680,11 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     const int countA = top_children ? L.ext2_countA : L.ext_countA;
     if (part == 1) count = countA;
     if (part == 2) { first += countA; count -= countA; }
-    if (count > 0)
+    static const bool records = getenv("COVGPU_EXT_RECORDS") == nullptr || atoi(getenv("COVGPU_EXT_RECORDS")) != 0;
+    if (count > 0 && records && nd.extr != nullptr)
+      hipLaunchKernelGGL(k_nd_extend_rec, dim3(count), dim3(256), 0, s2, P, lev_args(P, nd, l), (const int*)(nd.extr + (size_t)kExtRec * first),
+                         (const int*)(nd.extr + (size_t)kExtRec * nd.ext_over), top_children ? 1 : 0, (!top_children && l < ltop && nd_store_border()) ? 1 : 0, sig);
+    else if (count > 0)
       hipLaunchKernelGGL(k_nd_extend, dim3(count), dim3(256), 0, s2, P, lev_args(P, nd, l), (const int*)(nd.extw + 8 * (size_t)first),
                          (const int*)(top_children ? nd.extc2 : nd.extc), top_children ? 1 : 0, (!top_children && l < ltop && nd_store_border()) ? 1 : 0, sig);
     return count > 0;

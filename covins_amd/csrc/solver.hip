@@ -993,6 +993,7 @@ static int upload_impl(covgpu_context* c, const covgpu_options* opt, const covgp
       RC(dev_upload(c, &nd.ext, nd.h_ext.data(), nd.h_ext.size()));
       auto up_or_zero = [&](int** dst, const std::vector<int>& h, size_t least) { return dev_upload(c, dst, h.empty() ? (const int*)nullptr : h.data(), std::max(h.size(), least)); };
       RC(up_or_zero(&nd.extw, nd.h_extw, 8)); RC(up_or_zero(&nd.extc, nd.h_extc, 6)); RC(up_or_zero(&nd.extc2, nd.h_extc2, 6));
+      RC(up_or_zero(&nd.extr, nd.h_extr, kExtRec));
       RC(dev_upload(c, &nd.bb_off, nd.h_bb_off.data(), nd.h_bb_off.size()));
       RC(dev_upload(c, &nd.bb, nd.h_bb.data(), std::max<size_t>(nd.h_bb.size(), 1)));
       RC(dev_upload(c, &nd.top_var, nd.h_top_var.data(), nd.h_top_var.size())); RC(dev_upload(c, &nd.top_r, nd.h_top_r.data(), nd.h_top_r.size()));

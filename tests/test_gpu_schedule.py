@@ -49,6 +49,17 @@ def test_device_flag_ordering_equals_event_ordering(tmp_path, name):
         assert np.array_equal(a[k], b[k]), f"device-flag ordering and event ordering differ in {k}"
 
 
+@pytest.mark.parametrize("name", ["mh01", "mh123"])
+def test_extend_add_from_records_changes_no_bit(tmp_path, name):
+    """Round 6: the extend-add reads one record per (tile, contributing child) — header, child and row maps behind one address — instead of chasing
+    tile -> child entries -> row maps (k_nd_extend_rec | k_nd_extend, COVGPU_EXT_RECORDS=0). Children that reach neither the tile's rows nor its columns
+    are skipped; their terms were zero. Same sums in the same order: the same bits."""
+    a = _solve(tmp_path, "records", name)
+    b = _solve(tmp_path, "chased", name, COVGPU_EXT_RECORDS="0")
+    for k in ("pose", "sb", "lm", "cost", "acc"):
+        assert np.array_equal(a[k], b[k]), f"the two extend-add kernels differ in {k}"
+
+
 def test_no_solve_falls_back_to_events():
     """Device-flag ordering must hold on every path without ever reaching its timeout: GBA and — the case that hung in round 6, when two streams
     stored into one flag slot (one panel event recorded on the chain's stream at one level and on a side stream at the next) — the pose graph,

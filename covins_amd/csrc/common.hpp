@@ -376,7 +376,8 @@ struct BwdTreeLevel {
   double* y; size_t bsR; const double* Dinv; size_t bsL; const long long* btab; const int* live;
   size_t scr_off, xpub_off;                  // (filled in by the launcher)
 };
-void launch_bwd_tree(const double* M, const BwdTreeLevel* lev, int nlev, BwdXfer xf, double* pipe, int* dead, int* dead_h, double timeout_s, hipStream_t st);
+void launch_bwd_tree(const double* M, const BwdTreeLevel* lev, int nlev, BwdXfer xf, double* pipe, int* dead, int* dead_h, double timeout_s, hipStream_t st,
+                     bool form64 = false);   // form64: the tile workgroups of k_bwd_pipe64 (top levels: at most 128 of them in the launch)
 unsigned long long pipe_empty_word();        // the "empty" word of the hand-over slots (k_nd_assemble fills the solution vector's merged entries with it)
 void launch_trsm_sub(double* S, size_t ld, int t0, int w, int r0, int r1, const double* Linv, double* b, int npad, int nbt, size_t sM, size_t sL,
                      size_t sR, const int* live, int tI, hipStream_t st, bool chain = false, const long long* btab = nullptr, int nb = -1, const int* own = nullptr);
@@ -451,6 +452,7 @@ struct NdDev {
   // bottom levels whose backward substitution runs as ONE launch (k_bwd_tree): levels [0, tree_levels) (0: none) and the solution indices of their
   // fronts' own unknowns (filled with the hand-over's "empty" word at the start of a solve)
   int tree_levels = 0; int* tree_fill = nullptr; std::vector<int> h_tree_fill;
+  int tree_top0 = 0;                       // ... and the TOP levels [tree_top0, levels) as one launch of the 64x64-inverse form (== levels: none)
   int *cptr = nullptr, *cidx = nullptr;    // [nodes + 1], children that are subtree nodes (all children on a single GPU)
   int *cptr2 = nullptr, *cidx2 = nullptr;  // [nodes + 1], children that are top nodes
   int *inv_off = nullptr, *inv = nullptr;  // [nodes] offset of the node's map parent front row -> own front row (-1: none)

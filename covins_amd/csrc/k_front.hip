@@ -298,10 +298,21 @@ void nd_tables(const NdHostPlan& hp, const int* pos_kf, int D, int rank, NdDev& 
     const int lmax = std::min(std::min(nlev, Hs), kBwdTreeMax);
     while (ls < lmax && dev.lev[ls].n > 0 && dev.lev[ls].n <= 65535 && (dev.lev[ls].own_max + kTile - 1) / kTile <= 2) ++ls;
     dev.tree_levels = ls >= 2 ? ls : 0;
+    // the top levels, from the root down while the tile workgroups stay within 128 (k_bwd_tree64: a workgroup takes a whole CU) and every front has two
+    // interior tiles or more somewhere in the level
+    int lt = nlev, wgs = 0;
+    while (lt > dev.tree_levels && nlev - lt < kBwdTreeMax) {
+      const NdLevel& L = dev.lev[lt - 1];
+      const int T = std::min(L.nI / kTile, (L.own_max + kTile - 1) / kTile);
+      if (L.n <= 0 || T < 2 || wgs + L.n * T > 128) break;
+      wgs += L.n * T; --lt;
+    }
+    dev.tree_top0 = nlev - lt >= 2 ? lt : nlev;
     dev.h_tree_fill.clear();
-    for (int l = 0; l < dev.tree_levels; ++l)
-      for (int i = dev.lev[l].first; i < dev.lev[l].first + dev.lev[l].n; ++i)
-        for (int q = 0; q < dev.h_own_dims[i]; ++q) dev.h_tree_fill.push_back(dev.h_gidx[dev.h_own_g[i] + q]);
+    for (int l = 0; l < nlev; ++l)
+      if (l < dev.tree_levels || l >= dev.tree_top0)
+        for (int i = dev.lev[l].first; i < dev.lev[l].first + dev.lev[l].n; ++i)
+          for (int q = 0; q < dev.h_own_dims[i]; ++q) dev.h_tree_fill.push_back(dev.h_gidx[dev.h_own_g[i] + q]);
   }
   dev.active = true;
 }
@@ -632,12 +643,14 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
       if (L.n > 0 && T >= bwd_pipe_min_tiles()) need = std::max(need, (size_t)L.n * T * ((L.ntot - L.nI + kPipeChunk - 1) / kPipeChunk + 1) * kTile);
     }
     {
-      size_t tree = 0;
-      for (int l = 0; l < nd.tree_levels; ++l) {
+      size_t tree = 0, tree2 = 0;
+      for (int l = 0; l < (int)nd.lev.size(); ++l) {
         const NdLevel& L = nd.lev[l];
-        tree += (size_t)L.n * std::min(L.nI / kTile, (L.own_max + kTile - 1) / kTile) * ((L.ntot - L.nI + kPipeChunk - 1) / kPipeChunk + 1) * kTile;
+        const size_t e = (size_t)L.n * std::min(L.nI / kTile, (L.own_max + kTile - 1) / kTile) * ((L.ntot - L.nI + kPipeChunk - 1) / kPipeChunk + 1) * kTile;
+        if (l < nd.tree_levels) tree += e;
+        if (l >= nd.tree_top0) tree2 += e;
       }
-      need = std::max(need, tree);
+      need = std::max(need, std::max(tree, tree2));
     }
     if (need > ax.bwd_pipe_elems) {
       if (ax.bwd_pipe) { (void)hipDeviceSynchronize(); (void)hipFree(ax.bwd_pipe); }
@@ -651,12 +664,14 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
   static const bool fused_bwd = getenv("COVGPU_ND_BWD_FUSED") == nullptr || atoi(getenv("COVGPU_ND_BWD_FUSED")) != 0;
   static const bool tree_env = getenv("COVGPU_BWD_TREE") == nullptr || atoi(getenv("COVGPU_BWD_TREE")) != 0;
   // the bottom levels' backward substitution as one launch (k_bwd_tree): needs the pipeline's scratch and the give-up word
-  const bool tree_on = tree_env && fused_bwd && nd.tree_levels >= 2 && nd.tree_fill != nullptr && !ax.pipe_broken && ax.bwd_pipe != nullptr && ax.gate_dead != nullptr &&
-                       bwd_pipe_min_tiles() < (1 << 29);
+  const bool tree_ok = tree_env && fused_bwd && nd.tree_fill != nullptr && !ax.pipe_broken && ax.bwd_pipe != nullptr && ax.gate_dead != nullptr && bwd_pipe_min_tiles() <= 2;
+  static const bool tree_top_env = getenv("COVGPU_BWD_TREE_TOP") == nullptr || atoi(getenv("COVGPU_BWD_TREE_TOP")) != 0;
+  const bool tree_on = tree_ok && nd.tree_levels >= 2;
+  const bool tree_top_on = tree_ok && tree_top_env && nd.tree_top0 < (int)nd.lev.size();
   ax.mark(st, -1);
   // (the right-hand sides were cleared on the head stream of the build, beside the fronts: solver.hip enqueue_build)
   {
-    const int nfill = tree_on ? (int)nd.h_tree_fill.size() : 0;
+    const int nfill = (tree_on || tree_top_on) ? (int)nd.h_tree_fill.size() : 0;
     const int cnt = std::max(std::max(P.vi ? 324 * P.K : 0, P.n), nfill);
     hipLaunchKernelGGL(k_nd_assemble, dim3((cnt + 255) / 256), dim3(256), 0, st, P, (const int*)nd.rhs_node, dst, (const int*)nd.tree_fill, nfill, pipe_empty_word());
   }
@@ -753,7 +768,23 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     }
     run_levels(ltop, nlev, true);
   }
-  for (int l = nlev - 1; l >= (tree_on ? nd.tree_levels : 0); --l) {
+  auto tree_launch = [&](int l_hi, int l_lo, bool form64) {   // levels l_hi .. l_lo (downwards) in one launch
+    BwdTreeLevel tl[kBwdTreeMax];
+    int nq = 0;
+    for (int l = l_hi; l >= l_lo; --l) {
+      const NdLevel& L = nd.lev[l];
+      BwdTreeLevel& t = tl[nq++];
+      t.nbt = L.n; t.T = std::min(L.nI / kTile, (L.own_max + kTile - 1) / kTile); t.nchunk = (L.ntot - L.nI + kPipeChunk - 1) / kPipeChunk; t.tI = L.nI / kTile; t.first = L.first;
+      t.y = P.nd_rhs + L.rhs_off + L.ntot; t.bsR = (size_t)2 * L.ntot; t.Dinv = P.nd_Linv + L.linv_off; t.bsL = (size_t)L.nI * kTile;
+      t.btab = P.nd_ntab + 2 * (size_t)L.first; t.live = L.live; t.scr_off = t.xpub_off = 0;
+    }
+    BwdXfer xf;
+    xf.gidx = nd.gidx; xf.own_g = nd.own_g; xf.st_g = nd.st_g; xf.own_dims = nd.own_dims; xf.st_dims = nd.st_dims; xf.x = dst; xf.first = 0;
+    launch_bwd_tree(P.nd_M, tl, nq, xf, ax.bwd_pipe, ax.gate_dead, ax.gate_dead_h, ax.gate_timeout_s, st, form64);
+    ax.mark(st, -5);
+  };
+  if (tree_top_on) tree_launch(nlev - 1, nd.tree_top0, true);
+  for (int l = (tree_top_on ? nd.tree_top0 : nlev) - 1; l >= (tree_on ? nd.tree_levels : 0); --l) {
     // top-down: the ancestors' unknowns are read from `dst` by the first launch of the level, the fronts' own unknowns are
     // written there by its last (BwdXfer)
     const NdLevel& L = nd.lev[l];
@@ -766,20 +797,7 @@ bool launch_nd_solve(const DevProblem& P, NdDev& nd, double* dst, double mu, hip
     dense_backward_solve(P.nd_M, P.nd_rhs + L.rhs_off, P.nd_Linv + L.linv_off, L.ntot, st, L.nI / kTile, L.ntot / kTile, bt);
     ax.mark(st, -5);
   }
-  if (tree_on) {   // levels tree_levels - 1 .. 0 in one launch
-    BwdTreeLevel tl[kBwdTreeMax];
-    for (int q = 0; q < nd.tree_levels; ++q) {
-      const NdLevel& L = nd.lev[nd.tree_levels - 1 - q];
-      BwdTreeLevel& t = tl[q];
-      t.nbt = L.n; t.T = std::min(L.nI / kTile, (L.own_max + kTile - 1) / kTile); t.nchunk = (L.ntot - L.nI + kPipeChunk - 1) / kPipeChunk; t.tI = L.nI / kTile; t.first = L.first;
-      t.y = P.nd_rhs + L.rhs_off + L.ntot; t.bsR = (size_t)2 * L.ntot; t.Dinv = P.nd_Linv + L.linv_off; t.bsL = (size_t)L.nI * kTile;
-      t.btab = P.nd_ntab + 2 * (size_t)L.first; t.live = L.live; t.scr_off = t.xpub_off = 0;
-    }
-    BwdXfer xf;
-    xf.gidx = nd.gidx; xf.own_g = nd.own_g; xf.st_g = nd.st_g; xf.own_dims = nd.own_dims; xf.st_dims = nd.st_dims; xf.x = dst; xf.first = 0;
-    launch_bwd_tree(P.nd_M, tl, nd.tree_levels, xf, ax.bwd_pipe, ax.gate_dead, ax.gate_dead_h, ax.gate_timeout_s, st);
-    ax.mark(st, -5);
-  }
+  if (tree_on) tree_launch(nd.tree_levels - 1, 0, false);   // levels tree_levels - 1 .. 0 in one launch
   ax.mark(st, -6);
   return true;
 }

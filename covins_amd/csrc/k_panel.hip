@@ -1246,13 +1246,13 @@ __global__ __launch_bounds__(256) void k_bwd_tree(BwdTreeArgs a) {
 // sharded solve on one GPU) could fill every CU with tile workgroups that wait for helpers which find no room. Launches of more than 128 tile workgroups
 // use k_bwd_pipe (eight to a CU).
 constexpr int kP64W = 0, kP64S1 = 2 * 64 * 65, kP64S2 = kP64S1 + 4 * 16 * 17, kP64Y = kP64S2 + 2 * 32 * 33, kP64V = kP64Y + 2 * 32 * 33, kP64Doubles = kP64V + 128 + 128 + 64 + 256;
-__global__ __launch_bounds__(256) void k_bwd_pipe64(BwdPipeArgs g) {
+COV_DEV void bwd_pipe64_body(const BwdPipeArgs& g, const int bx, const int batch) {
   extern __shared__ __attribute__((aligned(16))) double sm64[];
-  const int batch = blockIdx.y, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int nhelp = g.T * g.nchunk;
-  if ((int)blockIdx.x < nhelp) { bwd_pipe_helper(g, (int)blockIdx.x, batch, sm64, reinterpret_cast<double2(*)[64]>(sm64 + 256)); return; }
+  if (bx < nhelp) { bwd_pipe_helper(g, bx, batch, sm64, reinterpret_cast<double2(*)[64]>(sm64 + 256)); return; }
   const int nIt = g.live[2 * batch];
-  const int p = g.T - 1 - ((int)blockIdx.x - nhelp);
+  const int p = g.T - 1 - (bx - nhelp);
   if (p >= nIt) return;
   const int node = g.xf.first + batch;
   const int nch = (g.xf.st_dims[node] + kPipeChunk - 1) / kPipeChunk;
@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(256) void k_bwd_pipe64(BwdPipeArgs g) {
     if (gq == 0) {
       sx[64 + cc] = sum;
       if (p > 0 && !(g.fault && p == nIt - 1)) __hip_atomic_store(xpub_f + (size_t)p * kTile + 64 + cc, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (gi_hi >= 0) g.xf.x[gi_hi] = sum;
+      if (gi_hi >= 0) { if (g.tree) __hip_atomic_store(g.xf.x + gi_hi, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else g.xf.x[gi_hi] = sum; }
     }
   }
   lds_barrier();
@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(256) void k_bwd_pipe64(BwdPipeArgs g) {
     sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
     if (gq == 0) {
       if (p > 0 && !(g.fault && p == nIt - 1)) __hip_atomic_store(xpub_f + (size_t)p * kTile + cc, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (gi_lo >= 0) g.xf.x[gi_lo] = sum;
+      if (gi_lo >= 0) { if (g.tree) __hip_atomic_store(g.xf.x + gi_lo, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else g.xf.x[gi_lo] = sum; }
     }
   }
 #ifdef COVGPU_PIPE_PROBE
@@ -1438,6 +1438,18 @@ __global__ __launch_bounds__(256) void k_bwd_pipe64(BwdPipeArgs g) {
     for (int i = kTile + tid; i < nIt * kTile; i += 256)
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(xpub_f + i), kPipeEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__global__ __launch_bounds__(256) void k_bwd_pipe64(BwdPipeArgs g) { bwd_pipe64_body(g, (int)blockIdx.x, (int)blockIdx.y); }
+// ... and the TOP levels of the tree in one launch of this form (at most 128 tile workgroups in all): k_bwd_tree's scheme
+__global__ __launch_bounds__(256) void k_bwd_tree64(BwdTreeArgs a) {
+  int l = 0;
+  while (l + 1 < a.nlev && (int)blockIdx.x >= a.wg0[l + 1]) ++l;
+  const BwdTreeLevel& L = a.lev[l];
+  BwdPipeArgs g = a.base;
+  g.tI = L.tI; g.T = L.T; g.nchunk = L.nchunk; g.y = L.y; g.Dinv_all = L.Dinv; g.bsL = L.bsL; g.bsR = L.bsR; g.btab = L.btab; g.live = L.live; g.xf.first = L.first;
+  g.scr = a.base.scr + L.scr_off; g.xpub = a.base.scr + L.xpub_off; g.tree = 1;
+  const int per = L.T * L.nchunk + L.T, local = (int)blockIdx.x - a.wg0[l];
+  bwd_pipe64_body(g, local % per, local / per);
+}
 __global__ void k_pipe_fill(unsigned long long* p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = kPipeEmpty;
 }
@@ -1445,7 +1457,7 @@ unsigned long long pipe_empty_word() { return kPipeEmpty; }
 void launch_pipe_fill(double* buf, size_t n, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(k_pipe_fill, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(buf), n);
 }
-void launch_bwd_tree(const double* M, const BwdTreeLevel* lev, int nlev, BwdXfer xf, double* pipe, int* dead, int* dead_h, double timeout_s, hipStream_t st) {
+void launch_bwd_tree(const double* M, const BwdTreeLevel* lev, int nlev, BwdXfer xf, double* pipe, int* dead, int* dead_h, double timeout_s, hipStream_t st, bool form64) {
   BwdTreeArgs a;
   a.base = BwdPipeArgs{M, 0, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, xf, pipe, pipe, dead, dead_h, (long long)(timeout_s * 1e8), 2047, 0, 1};
   static const int check = getenv("COVGPU_PIPE_SPIN_CHECK") ? std::max(1, atoi(getenv("COVGPU_PIPE_SPIN_CHECK"))) : 2048;
@@ -1459,10 +1471,15 @@ void launch_bwd_tree(const double* M, const BwdTreeLevel* lev, int nlev, BwdXfer
     a.lev[l].xpub_off = off; off += (size_t)lev[l].nbt * lev[l].T * kTile;
     a.wg0[l + 1] = a.wg0[l] + lev[l].nbt * (lev[l].T * lev[l].nchunk + lev[l].T);
   }
-  constexpr size_t lds = (size_t)128 * 7 * 8 * sizeof(double);
-  static bool once = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_tree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); return true; }();
+  constexpr size_t lds = (size_t)128 * 7 * 8 * sizeof(double), lds64 = (size_t)kP64Doubles * sizeof(double);
+  static bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_tree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_tree64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+    return true;
+  }();
   (void)once;
-  hipLaunchKernelGGL(k_bwd_tree, dim3(a.wg0[nlev]), dim3(256), lds, st, a);
+  if (form64) hipLaunchKernelGGL(k_bwd_tree64, dim3(a.wg0[nlev]), dim3(256), lds64, st, a);
+  else hipLaunchKernelGGL(k_bwd_tree, dim3(a.wg0[nlev]), dim3(256), lds, st, a);
 }
 void launch_bwd_pipe(const double* S, int tI, int ntiles, int nchunk, double* y, const double* Linv, int nbt, size_t sL, size_t sR, hipStream_t st,
                      const long long* btab, const int* live, BwdXfer xf, double* pipe, int* dead, int* dead_h, double timeout_s) {

@@ -13,6 +13,7 @@
 //     length N = n + 3 L with the pose part first, so norms and combinations are single flat kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 #include <map>
@@ -185,6 +186,14 @@ enum { SC_COST = 0, SC_JV2 = 1, SC_GG = 2, SC_GN2 = 3, SC_GDOT = 4, SC_GMAX = 5,
 struct CholAux;
 // a record published by the FIRST thread of the next kernel on the recording stream instead of by a launch of its own (CholAux::publish_handle): at
 // that moment everything enqueued before that kernel on its stream is complete, which is all a record says
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) acts on the CURRENT device's copy of the function: once per device, not once per process (a process
+// that drives several GPUs — covgpu_gba_solve_multi, one host thread per device — would launch the large-LDS kernels un-prepared on all but the first)
+inline bool first_use_on_device(std::atomic<unsigned long long>& seen) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return true;   // (unknown: set the attribute again, it is idempotent)
+  const unsigned long long bit = 1ull << d;
+  return (seen.fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
+}
 struct DevSignal { long long* flag = nullptr; long long seq = 0; };
 // ---- launchers (each enqueues on `st`, no synchronisation)
 void launch_kobs_build(const DevProblem& P, int* pair_oa, int* pair_ob, size_t nent, hipStream_t st);  // upload: keyframe-major copies, Z slots, pair lists -> Z slots

@@ -572,11 +572,11 @@ void dense_cholesky_solve_raw(double* S, double* b, double* Linv, int* flag, int
   const int T = npad / kTile;
   const size_t ld = (size_t)npad;
   const size_t lds_gemm = (size_t)2 * kTile * LDT * sizeof(double);
-  static std::once_flag attr_once;  // (the pose-graph solve calls this from several host threads at once)
-  std::call_once(attr_once, [&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_SYRK_TRI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_SYRK_RECT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
-  });
+  static std::atomic<unsigned long long> attr_seen{0};  // (per device; several host threads may arrive at once: the attribute is idempotent)
+  if (first_use_on_device(attr_seen)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_SYRK_TRI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_abt<MODE_SYRK_RECT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm);
+  }
   ax.init();
   const int NP = (T + 1) / 2;  // big panels of two tile columns
   // events per big panel: H rows-h done | B bulk done | C rows-r done | 1 potrf(t0) | 2 X(t0+1,t0) | 3 potrf(t0+1) | Rc next diagonal updated

@@ -1472,12 +1472,11 @@ void launch_bwd_tree(const double* M, const BwdTreeLevel* lev, int nlev, BwdXfer
     a.wg0[l + 1] = a.wg0[l] + lev[l].nbt * (lev[l].T * lev[l].nchunk + lev[l].T);
   }
   constexpr size_t lds = (size_t)128 * 7 * 8 * sizeof(double), lds64 = (size_t)kP64Doubles * sizeof(double);
-  static bool once = [] {
+  static std::atomic<unsigned long long> seen{0};
+  if (first_use_on_device(seen)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_tree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_tree64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
-    return true;
-  }();
-  (void)once;
+  }
   if (form64) hipLaunchKernelGGL(k_bwd_tree64, dim3(a.wg0[nlev]), dim3(256), lds64, st, a);
   else hipLaunchKernelGGL(k_bwd_tree, dim3(a.wg0[nlev]), dim3(256), lds, st, a);
 }
@@ -1489,14 +1488,13 @@ void launch_bwd_pipe(const double* S, int tI, int ntiles, int nchunk, double* y,
   static const int check = getenv("COVGPU_PIPE_SPIN_CHECK") ? std::max(1, atoi(getenv("COVGPU_PIPE_SPIN_CHECK"))) : 2048;   // (the test of the fallback: 1)
   g.check = check - 1;
   constexpr size_t lds = (size_t)128 * 7 * 8 * sizeof(double);   // the packed blocks of the diagonal tile
-  static bool once = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); return true; }();
-  (void)once;
+  static std::atomic<unsigned long long> seen{0}, seen64{0};
+  if (first_use_on_device(seen)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   // few tiles in the launch: the form with the 64x64 inverses (a whole CU per tile workgroup)
   static const int max64 = getenv("COVGPU_BWD_PIPE64") ? atoi(getenv("COVGPU_BWD_PIPE64")) : 128;
   if (nbt * ntiles <= max64) {
     constexpr size_t lds64 = (size_t)kP64Doubles * sizeof(double);
-    static bool once64 = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_pipe64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64); return true; }();
-    (void)once64;
+    if (first_use_on_device(seen64)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_pipe64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
     hipLaunchKernelGGL(k_bwd_pipe64, dim3(ntiles * nchunk + ntiles, nbt), dim3(256), lds64, st, g);
     return;
   }
@@ -1515,12 +1513,11 @@ bool launch_potrf_panel(double* S, size_t ld, int t0, int w, double* Linv, int* 
                         hipStream_t st, const long long* btab, int nb, const int* own, const int* list, int n_big, int n_small, DevSignal sa, DevSignal sb) {
   if (nb < 0) nb = 8 * w;
   if (nb == 0) return false;  // an all-padding panel of every front of the batch: L = I, Dinv = I, y = 0 are in place
-  static bool once = [] {
+  static std::atomic<unsigned long long> seen{0};
+  if (first_use_on_device(seen)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_panel4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds4);
-    return true;
-  }();
-  (void)once;
+  }
   double* Lp = Linv + (size_t)t0 * kTile * kTile;
   const double* yb = b ? b + npad : nullptr;
   if (list == nullptr) {   // every front of the batch in the sixteen-wave form (arrow blocks of the pose graph, the dense solve)
